@@ -1,0 +1,265 @@
+"""ctypes/numpy binding of oracle/libcpd_oracle.so (TEST INFRASTRUCTURE ONLY)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libcpd_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libiou3d_ref.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_i32_p = ctypes.POINTER(ctypes.c_int32)
+c_i64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+def build_oracle(force=False):
+    """Compile the C restatement with gcc (seconds). Also builds oracle/_ref when the reference
+    tree is present (build container only)."""
+    src = os.path.join(_HERE, "cpd_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
+    ref_src = "/root/reference/cpd/ops/iou3d_nms/src/iou3d_cpu.cpp"
+    if os.path.exists(ref_src) and not os.path.exists(_REF):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+def load_reference_iou():
+    """Returns f(a[N,7], b[M,7]) -> iou[N,M] backed by the reference's compiled iou3d_cpu.cpp,
+    or None when oracle/_ref has not been built."""
+    if not os.path.exists(_REF):
+        return None
+    import torch  # noqa: F401  (libtorch must be loadable)
+    lib = ctypes.CDLL(_REF)
+
+    def f(a, b):
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        lib.ref_boxes_iou_bev_cpu(_fp(a), a.shape[0], _fp(b), b.shape[0], _fp(out))
+        return out
+
+    return f
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_i32_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _arr3(v):
+    return (ctypes.c_int32 * 3)(*[int(x) for x in v])
+
+
+def _farr(v):
+    return (ctypes.c_float * len(v))(*[float(x) for x in v])
+
+
+class Oracle:
+    """numpy-level wrappers around the C oracle. One method per C-ABI entry point of
+    include/cpd_hip.h, same argument meaning, host arrays."""
+
+    def __init__(self):
+        build_oracle()
+        self.lib = ctypes.CDLL(_LIB)
+        self.lib.cpd_ref_box_overlap.restype = ctypes.c_float
+        self.lib.cpd_ref_iou_bev.restype = ctypes.c_float
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            raise RuntimeError("oracle %s failed: %d" % (what, rc))
+
+    # ---- B1 voxelizer ------------------------------------------------------------------------
+    def grid_size(self, vsize_xyz, range_xyz):
+        g = (ctypes.c_int32 * 3)()
+        self.lib.cpd_ref_grid_size(_farr(vsize_xyz), _farr(range_xyz), g)
+        return [g[0], g[1], g[2]]
+
+    def voxelize(self, points, vsize_xyz, range_xyz, max_points, max_voxels):
+        points = _f32(points)
+        n, c = points.shape
+        voxels = np.empty((max_voxels, max_points, c), np.float32)
+        coords = np.empty((max_voxels, 3), np.int32)
+        num = np.empty((max_voxels,), np.int32)
+        m = ctypes.c_int32(0)
+        self._check(self.lib.cpd_ref_voxelize(_fp(points), n, c, _farr(vsize_xyz), _farr(range_xyz),
+                                               max_points, max_voxels, _fp(voxels), _ip(coords), _ip(num),
+                                               ctypes.byref(m)), "voxelize")
+        m = m.value
+        return voxels[:m].copy(), coords[:m].copy(), num[:m].copy()
+
+    def mean_vfe(self, voxels, num_points):
+        voxels = _f32(voxels)
+        m, p, c = voxels.shape
+        out = np.empty((m, c), np.float32)
+        self._check(self.lib.cpd_ref_mean_vfe(_fp(voxels), _ip(_i32(num_points)), m, p, c, _fp(out)), "mean_vfe")
+        return out
+
+    # ---- B2 sparse conv ----------------------------------------------------------------------
+    def subm_rulebook(self, indices, batch, shape, ksize):
+        indices = _i32(indices)
+        n = indices.shape[0]
+        kv = int(np.prod(ksize))
+        nbr = np.empty((kv, n), np.int32)
+        self._check(self.lib.cpd_ref_subm_rulebook(_ip(indices), n, batch, _arr3(shape), _arr3(ksize), _ip(nbr)),
+                    "subm_rulebook")
+        return nbr
+
+    def conv_out_shape(self, in_shape, ksize, stride, pad):
+        o = (ctypes.c_int32 * 3)()
+        self._check(self.lib.cpd_ref_conv_out_shape(_arr3(in_shape), _arr3(ksize), _arr3(stride), _arr3(pad), o),
+                    "conv_out_shape")
+        return [o[0], o[1], o[2]]
+
+    def conv_outset(self, in_indices, batch, in_shape, ksize, stride, pad):
+        in_indices = _i32(in_indices)
+        n = in_indices.shape[0]
+        kv = int(np.prod(ksize))
+        cap = max(1, n * kv)
+        out = np.empty((cap, 4), np.int32)
+        cnt = ctypes.c_int32(0)
+        self._check(self.lib.cpd_ref_conv_outset(_ip(in_indices), n, batch, _arr3(in_shape), _arr3(ksize),
+                                                  _arr3(stride), _arr3(pad), _ip(out), cap, ctypes.byref(cnt)),
+                    "conv_outset")
+        return out[:cnt.value].copy()
+
+    def conv_rulebook(self, in_indices, out_indices, batch, in_shape, ksize, stride, pad):
+        in_indices = _i32(in_indices)
+        out_indices = _i32(out_indices)
+        kv = int(np.prod(ksize))
+        nbr = np.empty((kv, out_indices.shape[0]), np.int32)
+        self._check(self.lib.cpd_ref_conv_rulebook(_ip(in_indices), in_indices.shape[0], _ip(out_indices),
+                                                    out_indices.shape[0], batch, _arr3(in_shape), _arr3(ksize),
+                                                    _arr3(stride), _arr3(pad), _ip(nbr)), "conv_rulebook")
+        return nbr
+
+    def sparse_conv(self, feat_in, weight, bias, nbr):
+        """weight: reference layout (Cout, kD, kH, kW, Cin)."""
+        feat_in = _f32(feat_in)
+        weight = _f32(weight)
+        cout, cin = weight.shape[0], weight.shape[-1]
+        kv, n_out = nbr.shape
+        assert weight.size == cout * kv * cin and feat_in.shape[1] == cin
+        out = np.empty((n_out, cout), np.float32)
+        b = _f32(bias) if bias is not None else None
+        self._check(self.lib.cpd_ref_sparse_conv(_fp(feat_in), cin, _fp(weight), _fp(b) if b is not None else None,
+                                                  _ip(_i32(nbr)), kv, n_out, cout, _fp(out)), "sparse_conv")
+        return out
+
+    def affine_rows(self, x, scale=None, shift=None, residual=None, relu=False):
+        x = _f32(x).copy()
+        n, c = x.shape
+        s = _f32(scale) if scale is not None else None
+        t = _f32(shift) if shift is not None else None
+        r = _f32(residual) if residual is not None else None
+        self._check(self.lib.cpd_ref_affine_rows(_fp(x), n, c, _fp(s) if s is not None else None,
+                                                  _fp(t) if t is not None else None,
+                                                  _fp(r) if r is not None else None, int(relu)), "affine_rows")
+        return x
+
+    def densify(self, feat, indices, batch, shape):
+        feat = _f32(feat)
+        n, c = feat.shape
+        out = np.empty((batch, c * shape[0], shape[1], shape[2]), np.float32)
+        self._check(self.lib.cpd_ref_densify(_fp(feat), _ip(_i32(indices)), n, c, batch, _arr3(shape), _fp(out)),
+                    "densify")
+        return out
+
+    # ---- dense BEV convs ---------------------------------------------------------------------
+    def conv2d(self, x, w, bias=None, stride=1, pad=1):
+        x = _f32(x)
+        w = _f32(w)
+        b, cin, h, wd = x.shape
+        cout, _, kh, kw = w.shape
+        ho = (h + 2 * pad - kh) // stride + 1
+        wo = (wd + 2 * pad - kw) // stride + 1
+        out = np.empty((b, cout, ho, wo), np.float32)
+        bb = _f32(bias) if bias is not None else None
+        self._check(self.lib.cpd_ref_conv2d(_fp(x), b, cin, h, wd, _fp(w), _fp(bb) if bb is not None else None,
+                                             cout, kh, kw, stride, pad, _fp(out)), "conv2d")
+        return out
+
+    def deconv2d(self, x, w, k):
+        x = _f32(x)
+        w = _f32(w)
+        b, cin, h, wd = x.shape
+        cout = w.shape[1]
+        out = np.empty((b, cout, h * k, wd * k), np.float32)
+        self._check(self.lib.cpd_ref_deconv2d(_fp(x), b, cin, h, wd, _fp(w), cout, k, _fp(out)), "deconv2d")
+        return out
+
+    def bn_relu(self, x, gamma, beta, mean, var, eps, relu=True):
+        x = _f32(x).copy()
+        b, c = x.shape[:2]
+        hw = int(np.prod(x.shape[2:]))
+        self._check(self.lib.cpd_ref_bn_relu_nchw(_fp(x), b, c, hw, _fp(_f32(gamma)), _fp(_f32(beta)),
+                                                   _fp(_f32(mean)), _fp(_f32(var)), ctypes.c_float(eps), int(relu)),
+                    "bn_relu")
+        return x
+
+    # ---- decode ------------------------------------------------------------------------------
+    def topk(self, v, k):
+        v = _f32(v).ravel()
+        s = np.empty(k, np.float32)
+        i = np.empty(k, np.int32)
+        self._check(self.lib.cpd_ref_topk(_fp(v), v.size, k, _fp(s), _ip(i)), "topk")
+        return s, i
+
+    def center_decode(self, hm, center, center_z, dim, rot, K, stride, voxel_xy, range_lo_xy, limit_range,
+                      score_thresh):
+        hm = _f32(hm)
+        nc, h, w = hm.shape
+        boxes = np.empty((K, 7), np.float32)
+        scores = np.empty(K, np.float32)
+        labels = np.empty(K, np.int32)
+        n = ctypes.c_int32(0)
+        self._check(self.lib.cpd_ref_center_decode(
+            _fp(hm), _fp(_f32(center)), _fp(_f32(center_z)), _fp(_f32(dim)), _fp(_f32(rot)), nc, h, w, K,
+            ctypes.c_float(stride), _farr(voxel_xy), _farr(range_lo_xy), _farr(limit_range),
+            ctypes.c_float(score_thresh), _fp(boxes), _fp(scores), _ip(labels), ctypes.byref(n)), "center_decode")
+        return boxes[:n.value].copy(), scores[:n.value].copy(), labels[:n.value].copy()
+
+    # ---- B3 iou / nms ------------------------------------------------------------------------
+    def _pair(self, fn, a, b):
+        a = _f32(a)
+        b = _f32(b)
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        self._check(fn(_fp(a), a.shape[0], _fp(b), b.shape[0], _fp(out)), "pairwise")
+        return out
+
+    def boxes_overlap_bev(self, a, b):
+        return self._pair(self.lib.cpd_ref_boxes_overlap_bev, a, b)
+
+    def boxes_iou_bev(self, a, b):
+        return self._pair(self.lib.cpd_ref_boxes_iou_bev, a, b)
+
+    def boxes_iou3d(self, a, b):
+        return self._pair(self.lib.cpd_ref_boxes_iou3d, a, b)
+
+    def _nms(self, fn, boxes, thr):
+        boxes = _f32(boxes)
+        n = boxes.shape[0]
+        keep = np.empty(max(n, 1), np.int64)
+        k = ctypes.c_int32(0)
+        self._check(fn(_fp(boxes), n, ctypes.c_float(thr), keep.ctypes.data_as(c_i64_p), ctypes.byref(k)), "nms")
+        return keep[:k.value].copy()
+
+    def nms(self, boxes_sorted, thr):
+        return self._nms(self.lib.cpd_ref_nms, boxes_sorted, thr)
+
+    def nms_normal(self, boxes_sorted, thr):
+        return self._nms(self.lib.cpd_ref_nms_normal, boxes_sorted, thr)

@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the REFERENCE itself (run in the build container only).
+
+What is executed here is the reference's own code, imported from /root/reference by file path:
+  * cpd/models/backbones_3d/vfe/mean_vfe.py            -> MeanVFE.forward
+  * cpd/models/backbones_2d/base_bev_backbone.py       -> BaseBEVBackbone.forward
+  * cpd/models/dense_heads/center_head.py              -> SeparateHead.forward
+  * cpd/models/model_utils/centernet_utils.py          -> _topk, decode_bbox_from_heatmap
+  * cpd/models/model_utils/model_nms_utils.py          -> class_agnostic_nms
+  * cpd/ops/iou3d_nms/src/iou3d_cpu.cpp (compiled: oracle/_ref/libiou3d_ref.so) -> boxes_iou_bev_cpu
+The reference cannot be imported as a package here (spconv / numba / easydict / its CUDA
+extensions are absent), so leaf files are loaded under a synthetic package `r` whose missing
+siblings are empty modules. `numba` is replaced by an identity-decorator module: the only numba
+user in these files (circle_nms, centernet_utils.py:80-104) is asserted unused by the reference
+(l.161) and is never called here. `iou3d_nms_utils` (needs the CUDA extension) is replaced by a
+module whose nms_gpu sorts by score exactly as iou3d_nms_utils.py:103-118 does and takes its IoUs
+from the compiled reference iou3d_cpu.cpp, followed by the greedy scan of iou3d_nms.cpp:121-132.
+
+Only DATA is written (tests/golden/*.npz): inputs, weights and the reference's outputs. No
+reference source text is stored. Usage:  python tests/golden/make_golden.py
+"""
+import ctypes
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("CPD_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+FP = ctypes.POINTER(ctypes.c_float)
+
+
+class AttrDict(dict):
+    """Minimal stand-in for easydict.EasyDict (attribute access + .get)."""
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _pkg(name):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def ref_iou_lib():
+    path = os.path.join(REPO, "oracle", "_ref", "libiou3d_ref.so")
+    if not os.path.exists(path):
+        raise SystemExit("build oracle/_ref first: make -C oracle ref")
+    return ctypes.CDLL(path)
+
+
+def ref_iou_bev(lib, a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    lib.ref_boxes_iou_bev_cpu(a.ctypes.data_as(FP), a.shape[0], b.ctypes.data_as(FP), b.shape[0],
+                              out.ctypes.data_as(FP))
+    return out
+
+
+def greedy_keep(iou, thr):
+    """Bitmask NMS on an IoU matrix of score-sorted boxes (iou3d_nms.cpp:117-133 semantics)."""
+    n = iou.shape[0]
+    removed = np.zeros(n, bool)
+    keep = []
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(i)
+        removed[i + 1:] |= iou[i, i + 1:] > thr
+    return np.asarray(keep, np.int64)
+
+
+def setup_reference():
+    for p in ["r", "r.models", "r.models.dense_heads", "r.models.model_utils", "r.models.backbones_3d",
+              "r.models.backbones_3d.vfe", "r.models.backbones_2d", "r.utils", "r.ops", "r.ops.iou3d_nms"]:
+        _pkg(p)
+    numba = types.ModuleType("numba")
+    numba.jit = lambda *a, **k: (lambda f: f)
+    sys.modules["numba"] = numba
+    sys.modules["r.utils.box_utils"] = types.ModuleType("r.utils.box_utils")
+    lib = ref_iou_lib()
+
+    nms_mod = types.ModuleType("r.ops.iou3d_nms.iou3d_nms_utils")
+
+    def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+        order = scores.sort(0, descending=True)[1]
+        if pre_maxsize is not None:
+            order = order[:pre_maxsize]
+        b = boxes[order].contiguous().numpy()
+        keep = greedy_keep(ref_iou_bev(lib, b, b), thresh)
+        return order[torch.from_numpy(keep)].contiguous(), None
+
+    nms_mod.nms_gpu = nms_gpu
+    sys.modules["r.ops.iou3d_nms.iou3d_nms_utils"] = nms_mod
+    sys.modules["r.ops.iou3d_nms"].iou3d_nms_utils = nms_mod
+
+    m = {}
+    m["vfe_template"] = _load("r.models.backbones_3d.vfe.vfe_template", "cpd/models/backbones_3d/vfe/vfe_template.py")
+    m["mean_vfe"] = _load("r.models.backbones_3d.vfe.mean_vfe", "cpd/models/backbones_3d/vfe/mean_vfe.py")
+    m["bev"] = _load("r.models.backbones_2d.base_bev_backbone", "cpd/models/backbones_2d/base_bev_backbone.py")
+    m["loss_utils"] = _load("r.utils.loss_utils", "cpd/utils/loss_utils.py")
+    m["centernet_utils"] = _load("r.models.model_utils.centernet_utils", "cpd/models/model_utils/centernet_utils.py")
+    m["model_nms_utils"] = _load("r.models.model_utils.model_nms_utils", "cpd/models/model_utils/model_nms_utils.py")
+    sys.modules["r.models.model_utils"].centernet_utils = m["centernet_utils"]
+    sys.modules["r.models.model_utils"].model_nms_utils = m["model_nms_utils"]
+    sys.modules["r.utils"].loss_utils = m["loss_utils"]
+    m["center_head"] = _load("r.models.dense_heads.center_head", "cpd/models/dense_heads/center_head.py")
+    m["lib"] = lib
+    return m
+
+
+def rand_boxes(rng, n, span=30.0):
+    b = np.zeros((n, 7), np.float32)
+    b[:, 0:2] = rng.uniform(-span, span, (n, 2))
+    b[:, 2] = rng.uniform(-1, 1, n)
+    b[:, 3:6] = np.exp(rng.normal(0, 0.25, (n, 3))) * np.array([4.7, 2.1, 1.7])
+    b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+    return b
+
+
+def adversarial_boxes(rng):
+    """identical / nested / touching / theta ~ +-pi / tiny / near-duplicate boxes."""
+    base = rand_boxes(rng, 24, span=6.0)
+    out = [base]
+    out.append(base[:6].copy())                                   # identical
+    nested = base[:6].copy(); nested[:, 3:5] *= 0.5; out.append(nested)
+    touch = base[:6].copy(); touch[:, 6] = 0; t2 = touch.copy(); t2[:, 0] += t2[:, 3]; out += [touch, t2]
+    pi = base[:6].copy(); pi[:, 6] = np.float32(np.pi) - 1e-4; p2 = pi.copy(); p2[:, 6] = -np.float32(np.pi) + 1e-4
+    out += [pi, p2]
+    tiny = base[:6].copy(); tiny[:, 3:5] = 1e-3; out.append(tiny)
+    dup = base[:12].copy(); dup[:, :2] += rng.normal(0, 0.05, (12, 2)); dup[:, 6] += rng.normal(0, 0.02, 12)
+    out.append(dup)
+    ax = base[:6].copy(); ax[:, 6] = np.float32(np.pi / 2); out.append(ax)
+    return np.concatenate(out, 0).astype(np.float32)
+
+
+def borderline_free(iou, thr, margin=2e-4):
+    return not np.any(np.abs(iou - thr) < margin)
+
+
+def main():
+    torch.manual_seed(0)
+    rng = np.random.default_rng(20240928)
+    m = setup_reference()
+    lib = m["lib"]
+    out = {}
+
+    # ---- 1. MeanVFE (mean_vfe.py:16-61) ------------------------------------------------------
+    M, P, C = 257, 5, 5
+    num = rng.integers(0, P + 1, M).astype(np.int32)
+    vox = rng.normal(0, 3, (M, P, C)).astype(np.float32)
+    for v in range(M):
+        vox[v, num[v]:] = 0
+    vfe = m["mean_vfe"].MeanVFE(AttrDict(), num_point_features=C, num_frames=1)
+    bd = {"voxels": torch.from_numpy(vox), "voxel_num_points": torch.from_numpy(num)}
+    feat = vfe(bd)["voxel_features"].numpy()
+    np.savez_compressed(os.path.join(HERE, "mean_vfe.npz"), voxels=vox, num_points=num, features=feat)
+
+    # ---- 2. BaseBEVBackbone (base_bev_backbone.py:6-122), reduced widths ---------------------
+    cfg = AttrDict(LAYER_NUMS=[2, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[16, 32],
+                   UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[32, 32])
+    net = m["bev"].BaseBEVBackbone(cfg, num_frames=1, input_channels=32)
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+    net.eval()
+    x = torch.randn(1, 32, 24, 20)
+    with torch.no_grad():
+        y = net({"spatial_features": x})["st_features_2d"]
+    d = {"bev_in": x.numpy(), "bev_out": y.numpy()}
+    for k, v in net.state_dict().items():
+        d["sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "bev_backbone.npz"), **d)
+
+    # ---- 3. shared conv + SeparateHead (center_head.py:11-45,73-80) --------------------------
+    head_dict = {"center": dict(out_channels=2, num_conv=2), "center_z": dict(out_channels=1, num_conv=2),
+                 "dim": dict(out_channels=3, num_conv=2), "rot": dict(out_channels=2, num_conv=2),
+                 "hm": dict(out_channels=3, num_conv=2)}
+    sep = m["center_head"].SeparateHead(input_channels=16, sep_head_dict=head_dict, init_bias=-2.19, use_bias=True)
+    shared = torch.nn.Sequential(torch.nn.Conv2d(64, 16, 3, stride=1, padding=1, bias=True),
+                                 torch.nn.BatchNorm2d(16), torch.nn.ReLU())   # center_head.py:73-80
+    with torch.no_grad():
+        for mod in list(sep.modules()) + list(shared.modules()):
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+    sep.eval(); shared.eval()
+    xh = torch.randn(1, 64, 20, 24)
+    with torch.no_grad():
+        mid = shared(xh)
+        heads = sep(mid)
+    d = {"head_in": xh.numpy(), "shared_out": mid.numpy()}
+    for k, v in heads.items():
+        d["out." + k] = v.numpy()
+    for k, v in shared.state_dict().items():
+        d["shared." + k] = v.numpy()
+    for k, v in sep.state_dict().items():
+        d["sep." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "center_head.npz"), **d)
+
+    # ---- 4. _topk + decode_bbox_from_heatmap (centernet_utils.py:136-216) ---------------------
+    cu = m["centernet_utils"]
+    H, W, K = 47, 47, 60
+    hm_logit = torch.randn(1, 3, H, W) * 1.5 - 1.0
+    center = torch.randn(1, 2, H, W) * 0.3
+    center_z = torch.randn(1, 1, H, W) * 0.5
+    dim_log = torch.randn(1, 3, H, W) * 0.3 + 0.8
+    rot = torch.randn(1, 2, H, W)
+    pcr = [-75.2, -75.2, -2, 75.2, 75.2, 4]
+    vs = [0.1, 0.1, 0.15]
+    stride = 32  # 47*32*0.1 = 150.4 m span
+    limit = torch.tensor([-70.0, -70.0, -1.0, 70.0, 70.0, 1.0])
+    ts, ti, tc, ty, tx = cu._topk(hm_logit.sigmoid(), K=K)
+    dec = cu.decode_bbox_from_heatmap(
+        heatmap=hm_logit.sigmoid(), rot_cos=rot[:, 0:1], rot_sin=rot[:, 1:2], center=center,
+        center_z=center_z, dim=dim_log.exp(), point_cloud_range=pcr, voxel_size=vs,
+        feature_map_stride=stride, K=K, circle_nms=False, score_thresh=0.1,
+        post_center_limit_range=limit)[0]
+    np.savez_compressed(
+        os.path.join(HERE, "decode.npz"), hm=hm_logit.numpy(), center=center.numpy(),
+        center_z=center_z.numpy(), dim=dim_log.numpy(), rot=rot.numpy(), K=K, stride=stride,
+        pcr=np.array(pcr, np.float32), vs=np.array(vs, np.float32), limit=limit.numpy(), score_thresh=0.1,
+        topk_scores=ts.numpy(), topk_inds=ti.numpy(), topk_classes=tc.numpy(), topk_ys=ty.numpy(),
+        topk_xs=tx.numpy(), boxes=dec["pred_boxes"].numpy(), scores=dec["pred_scores"].numpy(),
+        labels=dec["pred_labels"].numpy())
+
+    # ---- 5. BEV IoU matrices from the compiled reference iou3d_cpu.cpp ------------------------
+    a = rand_boxes(rng, 150, span=12.0)
+    b = rand_boxes(rng, 130, span=12.0)
+    adv = adversarial_boxes(rng)
+    np.savez_compressed(os.path.join(HERE, "iou_bev.npz"), a=a, b=b, iou_ab=ref_iou_bev(lib, a, b),
+                        adv=adv, iou_adv=ref_iou_bev(lib, adv, adv))
+
+    # ---- 6. class_agnostic_nms (model_nms_utils.py:115-134) -----------------------------------
+    d = {}
+    for tag, n, thr, span in [("n64", 64, 0.8, 8.0), ("n500", 500, 0.8, 25.0), ("n500_t3", 500, 0.3, 25.0),
+                              ("n1000_t1", 1000, 0.1, 40.0)]:
+        for attempt in range(400):
+            bx = rand_boxes(rng, n, span=span)
+            k = n // 10
+            bx[n - k:] = bx[:k]
+            bx[n - k:, :2] += rng.normal(0, 0.25, (k, 2)).astype(np.float32)
+            bx[n - k:, 6] += rng.normal(0, 0.05, k).astype(np.float32)
+            sc = rng.permutation(n).astype(np.float32) / n + 0.001  # distinct scores
+            order = np.argsort(-sc, kind="stable")
+            iou = ref_iou_bev(lib, bx[order], bx[order])
+            if borderline_free(iou[np.triu_indices(n, 1)], thr):
+                break
+        else:
+            raise RuntimeError("no borderline-free set for " + tag)
+        cfgn = AttrDict(NMS_TYPE="nms_gpu", NMS_THRESH=thr, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=500)
+        sel, sel_sc = m["model_nms_utils"].class_agnostic_nms(
+            box_scores=torch.from_numpy(sc), box_preds=torch.from_numpy(bx), nms_config=cfgn, score_thresh=None)
+        d[tag + ".boxes"] = bx
+        d[tag + ".scores"] = sc
+        d[tag + ".thr"] = np.float32(thr)
+        d[tag + ".selected"] = sel.numpy()
+        d[tag + ".selected_scores"] = sel_sc.numpy()
+    np.savez_compressed(os.path.join(HERE, "nms.npz"), **d)
+    print("golden fixtures written to", HERE)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("  %-22s %8d B" % (f, os.path.getsize(os.path.join(HERE, f))))
+
+
+if __name__ == "__main__":
+    main()
