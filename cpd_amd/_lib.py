@@ -1,0 +1,104 @@
+"""ctypes binding of cpd_amd/csrc/libcpd_hip.so (the C-ABI of include/cpd_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing the ops raises.
+torch is imported first on purpose -- it brings the process's HIP runtime (libamdhip64.so.7), which
+libcpd_hip.so then binds to, so both share streams and device memory.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcpd_hip.so")
+
+CPD_ERRORS = {-1: "CPD_ERR_ARG", -2: "CPD_ERR_WORKSPACE", -3: "CPD_ERR_LAUNCH", -4: "CPD_ERR_UNSUPPORTED"}
+
+
+class CpdHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_VP, _I, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_I3 = ctypes.POINTER(ctypes.c_int32)
+_FP = ctypes.POINTER(ctypes.c_float)
+
+# name -> (restype, argtypes): one row per declaration in include/cpd_hip.h
+SIGNATURES = {
+    "cpd_version": (ctypes.c_char_p, []),
+    "cpd_last_hip_error": (_I, []),
+    "cpd_voxel_grid_size": (_I, [_FP, _FP, _I3]),
+    "cpd_voxelize_workspace_bytes": (_SZ, [_I, _I, _I, _FP, _FP]),
+    "cpd_voxelize": (_I, [_VP, _I, _I, _FP, _FP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_index_bytes": (_SZ, [_I, _I3, _I]),
+    "cpd_index_build": (_I, [_VP, _I, _I, _I3, _VP, _SZ, _VP]),
+    "cpd_rulebook_subm": (_I, [_VP, _I, _I, _I3, _I3, _VP, _VP, _VP]),
+    "cpd_conv_out_shape": (_I, [_I3, _I3, _I3, _I3, _I3]),
+    "cpd_conv_outset": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _SZ, _VP, _VP]),
+    "cpd_index_emit": (_I, [_VP, _I, _I3, _VP, _I, _VP]),
+    "cpd_rulebook_conv": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _VP, _VP]),
+    "cpd_packed_weight_floats": (_SZ, [_I, _I, _I]),
+    "cpd_pack_weight": (_I, [_VP, _I, _I, _I, _VP, _VP]),
+    "cpd_gather_conv": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _VP]),
+    "cpd_densify_nchw": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
+    "cpd_densify_nhwc": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
+    "cpd_rulebook_conv2d": (_I, [_I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
+    "cpd_center_decode_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "cpd_center_decode": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _F, _FP, _FP, _FP, _F, _VP, _VP, _VP,
+                               _VP, _VP, _SZ, _VP]),
+    "cpd_boxes_overlap_bev": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
+    "cpd_boxes_iou_bev": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
+    "cpd_boxes_iou3d": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
+    "cpd_nms_workspace_bytes": (_SZ, [_I]),
+    "cpd_nms_rotated": (_I, [_VP, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_nms_normal": (_I, [_VP, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_boxes_iou_bev_cpu": (_I, [_VP, _I, _VP, _I, _VP]),
+}
+
+
+def lib():
+    """Load (once) and return the C-ABI library. Raises loudly when it is absent: the product has
+    no eager/PyTorch/CPU fallback for these ops."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CpdHipError(
+                "libcpd_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C cpd_amd/csrc`); there is no fallback path")
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)  # AttributeError = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = cdll
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        extra = ""
+        if rc == -3:
+            extra = " (hipError %d)" % lib().cpd_last_hip_error()
+        raise CpdHipError("%s failed: %s%s" % (what, CPD_ERRORS.get(rc, rc), extra))
+
+
+def farr(v):
+    return (ctypes.c_float * len(v))(*[float(x) for x in v])
+
+
+def iarr(v):
+    return (ctypes.c_int32 * len(v))(*[int(x) for x in v])
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "cpd_hip: tensor must be contiguous"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,145 @@
+// common.h -- shared helpers for libcpd_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cpd_hip.h"
+
+#define CPD_WAVE 64
+
+extern thread_local int g_cpd_last_hip_error;
+
+static inline int cpd_check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_cpd_last_hip_error = (int)e;
+        return CPD_ERR_LAUNCH;
+    }
+    return CPD_OK;
+}
+#define CPD_HIP_TRY(expr)                       \
+    do {                                        \
+        hipError_t _e = (expr);                 \
+        if (_e != hipSuccess) {                 \
+            g_cpd_last_hip_error = (int)_e;     \
+            return CPD_ERR_LAUNCH;              \
+        }                                       \
+    } while (0)
+
+static inline hipStream_t cpd_s(cpd_stream_t s) { return (hipStream_t)s; }
+static inline size_t cpd_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int cpd_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// Device-wide exclusive scan over a virtual sequence value(i), i in [0,n), in three launches:
+//   scan_reduce  : per-block sums            (blocks of SCAN_BLOCK threads x SCAN_ITEMS items)
+//   scan_spine   : exclusive scan of the block sums by one workgroup, total -> *total_out
+//   scan_apply   : per-item exclusive prefix handed to a consumer functor
+// Thread t of a block owns SCAN_ITEMS consecutive items, so prefixes follow index order.
+// ---------------------------------------------------------------------------------------------
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 16
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).
+// Returns the exclusive prefix; *block_total receives the sum. `sm` needs 17 uint32.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t *block_total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) sm[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        uint32_t w = lane < nw ? sm[lane] : 0;
+        uint32_t winc = wave_incl_scan(w);
+        if (lane < nw) sm[lane] = winc - w;  // exclusive per-wave offset
+        if (lane == nw - 1) sm[16] = winc;
+    }
+    __syncthreads();
+    uint32_t res = sm[wid] + inc - v;
+    *block_total = sm[16];
+    __syncthreads();
+    return res;
+}
+
+template <class ValueFn>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(long long n, ValueFn value, uint32_t *block_sums) {
+    __shared__ uint32_t sm[17];
+    long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        long long i = base + k;
+        if (i < n) s += value(i);
+    }
+    uint32_t tot;
+    block_excl_scan(s, sm, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// (template only to give the kernel inline linkage: every translation unit carries its own copy)
+template <int kUnused>
+__global__ void __launch_bounds__(1024) scan_spine_kernel(uint32_t *block_sums, int nb, int32_t *total_out,
+                                                          int32_t total_cap) {
+    __shared__ uint32_t sm[17];
+    uint32_t carry = 0;
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < nb ? block_sums[i] : 0u;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(v, sm, &tot);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) {
+        int32_t t = (int32_t)carry;
+        if (total_cap >= 0 && t > total_cap) t = total_cap;
+        *total_out = t;
+    }
+}
+
+template <class ValueFn, class ConsumeFn>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(long long n, ValueFn value, const uint32_t *block_sums,
+                                                                ConsumeFn consume) {
+    __shared__ uint32_t sm[17];
+    long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        long long i = base + k;
+        v[k] = i < n ? value(i) : 0u;
+        s += v[k];
+    }
+    uint32_t tot;
+    uint32_t pre = block_excl_scan(s, sm, &tot) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        long long i = base + k;
+        if (i < n) consume(i, v[k], pre);
+        pre += v[k];
+    }
+}
+
+// Host driver: block_sums must hold scan_num_blocks(n) uint32. total_out (device i32) may be null;
+// the total written there is clamped to total_cap when total_cap >= 0.
+static inline int scan_num_blocks(long long n) { return n <= 0 ? 1 : (int)((n + SCAN_TILE - 1) / SCAN_TILE); }
+
+template <class ValueFn, class ConsumeFn>
+static inline int device_scan(long long n, ValueFn value, ConsumeFn consume, uint32_t *block_sums, int32_t *total_out,
+                              int32_t total_cap, hipStream_t s) {
+    int nb = scan_num_blocks(n);
+    scan_reduce_kernel<<<nb, SCAN_BLOCK, 0, s>>>(n, value, block_sums);
+    scan_spine_kernel<0><<<1, 1024, 0, s>>>(block_sums, nb, total_out, total_cap);
+    scan_apply_kernel<<<nb, SCAN_BLOCK, 0, s>>>(n, value, block_sums, consume);
+    return cpd_check_launch();
+}

@@ -1,0 +1,222 @@
+// decode.hip -- CenterHead box decode for gfx950.
+//
+// Replaces, for one sample, CenterHead.generate_predicted_boxes (center_head.py:252-303) ->
+// centernet_utils._topk (centernet_utils.py:136-151) + decode_bbox_from_heatmap (l.154-216):
+//   sigmoid(hm) -> per-class top-K over H*W -> top-K over (class, K) -> gather the regression
+//   maps at the winners -> exp(dim), atan2(sin, cos), centre scaling -> POST_CENTER_LIMIT_RANGE
+//   and SCORE_THRESH masks -> order-preserving compaction (scores stay sorted descending).
+// The reference runs this as ~20 small torch kernels; here it is two launches:
+//   topk_class_kernel : one 1024-thread workgroup per class: 4-pass radix select of the K-th key
+//                       (LDS histogram), ordered tie collection, 1024-wide bitonic sort in LDS
+//   decode_kernel     : one workgroup: second top-K, gather, decode, mask, block-scan compaction
+// Ties are broken by ascending flat index (torch.topk leaves tie order unspecified).
+#include "common.h"
+
+namespace {
+
+struct MapView {  // map[pixel * pix + channel * ch]
+    const float *p;
+    int pix, ch;
+    __device__ __forceinline__ float at(int pixel, int channel) const {
+        return p[(size_t)pixel * pix + (size_t)channel * ch];
+    }
+};
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct TopkSmem {
+    uint32_t hist[256];
+    unsigned long long packed[1024];
+    uint32_t scan[17];
+    uint32_t sel, remaining, cnt_gt;
+};
+
+// Block-wide (1024 threads) top-K of keyfn(i), i in [0,n). On return sm.packed[0..K) holds
+// (key << 32 | ~index) sorted descending, i.e. key descending then index ascending.
+template <class KeyFn>
+__device__ void block_topk(int n, int K, KeyFn keyfn, TopkSmem &sm) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    uint32_t prefix = 0, pmask = 0;
+    uint32_t remaining = (uint32_t)K;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 256; b += nth) sm.hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += nth) {
+            uint32_t key = keyfn(i);
+            if ((key & pmask) == prefix) atomicAdd(&sm.hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t c = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (c + sm.hist[d] >= remaining) break;
+                c += sm.hist[d];
+            }
+            sm.sel = (uint32_t)d;
+            sm.remaining = remaining - c;
+        }
+        __syncthreads();
+        prefix |= sm.sel << shift;
+        pmask |= 255u << shift;
+        remaining = sm.remaining;
+        __syncthreads();
+    }
+    const uint32_t kth = prefix;          // K-th largest key
+    const uint32_t n_gt = (uint32_t)K - remaining;  // keys strictly greater
+    if (tid == 0) sm.cnt_gt = 0;
+    for (int i = tid; i < 1024; i += nth) sm.packed[i] = 0ull;
+    __syncthreads();
+    // strictly greater keys: any order (sorted afterwards)
+    for (int i = tid; i < n; i += nth) {
+        uint32_t key = keyfn(i);
+        if (key > kth) {
+            uint32_t pos = atomicAdd(&sm.cnt_gt, 1u);
+            sm.packed[pos] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)i);
+        }
+    }
+    // ties with the K-th key: lowest indices first -> ordered selection over contiguous chunks
+    const int chunk = (n + nth - 1) / nth;
+    const int i0 = tid * chunk, i1 = min(n, i0 + chunk);
+    uint32_t mine = 0;
+    for (int i = i0; i < i1; ++i) mine += keyfn(i) == kth ? 1u : 0u;
+    uint32_t tot;
+    uint32_t rank = block_excl_scan(mine, sm.scan, &tot);
+    for (int i = i0; i < i1 && rank < remaining; ++i)
+        if (keyfn(i) == kth) {
+            sm.packed[n_gt + rank] = ((unsigned long long)kth << 32) | (uint32_t)(~(uint32_t)i);
+            ++rank;
+        }
+    __syncthreads();
+    // bitonic sort, descending, 1024 elements (zeros pad the tail and sink to the end)
+    for (int k = 2; k <= 1024; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < 1024; i += nth) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = sm.packed[i], b = sm.packed[ixj];
+                    bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { sm.packed[i] = b; sm.packed[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+struct SigKey {
+    MapView hm;
+    int cls;
+    __device__ __forceinline__ uint32_t operator()(int i) const { return f2key(sigmoidf(hm.at(i, cls))); }
+};
+struct ArrKey {
+    const float *v;
+    __device__ __forceinline__ uint32_t operator()(int i) const { return f2key(v[i]); }
+};
+
+__global__ void __launch_bounds__(1024) topk_class_kernel(MapView hm, int hw, int K, float *__restrict__ s1,
+                                                          int32_t *__restrict__ i1) {
+    __shared__ TopkSmem sm;
+    const int cls = blockIdx.x;
+    block_topk(hw, K, SigKey{hm, cls}, sm);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        unsigned long long p = sm.packed[k];
+        s1[(size_t)cls * K + k] = key2f((uint32_t)(p >> 32));
+        i1[(size_t)cls * K + k] = (int32_t)(~(uint32_t)p);
+    }
+}
+
+struct DecodeParams {
+    MapView center, center_z, dim, rot;
+    int num_class, h, w, K;
+    float stride, vx, vy, lox, loy;
+    float lim[6];
+    float score_thresh;
+};
+
+__global__ void __launch_bounds__(1024) decode_kernel(DecodeParams q, const float *__restrict__ s1,
+                                                      const int32_t *__restrict__ i1, float *__restrict__ boxes,
+                                                      float *__restrict__ scores, int32_t *__restrict__ labels,
+                                                      int32_t *__restrict__ n_out) {
+    __shared__ TopkSmem sm;
+    const int K = q.K;
+    block_topk(q.num_class * K, K, ArrKey{s1}, sm);
+    const int k = threadIdx.x;
+    float bx[7];
+    float sc = 0.f;
+    int cls = 0;
+    uint32_t keep = 0;
+    if (k < K) {
+        unsigned long long p = sm.packed[k];
+        sc = key2f((uint32_t)(p >> 32));
+        const int i2 = (int)(~(uint32_t)p);
+        cls = i2 / K;
+        const int ind = i1[i2];
+        const float xs = (float)(ind % q.w), ys = (float)(ind / q.w);
+        bx[0] = (xs + q.center.at(ind, 0)) * q.stride * q.vx + q.lox;
+        bx[1] = (ys + q.center.at(ind, 1)) * q.stride * q.vy + q.loy;
+        bx[2] = q.center_z.at(ind, 0);
+        bx[3] = expf(q.dim.at(ind, 0));
+        bx[4] = expf(q.dim.at(ind, 1));
+        bx[5] = expf(q.dim.at(ind, 2));
+        bx[6] = atan2f(q.rot.at(ind, 1), q.rot.at(ind, 0));  // rot[0]=cos, rot[1]=sin (center_head.py:266-267)
+        bool ok = bx[0] >= q.lim[0] && bx[1] >= q.lim[1] && bx[2] >= q.lim[2] && bx[0] <= q.lim[3] &&
+                  bx[1] <= q.lim[4] && bx[2] <= q.lim[5];
+        ok = ok && (sc > q.score_thresh);
+        keep = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    uint32_t tot;
+    uint32_t pos = block_excl_scan(keep, sm.scan, &tot);
+    if (keep) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) boxes[(size_t)pos * 7 + c] = bx[c];
+        scores[pos] = sc;
+        labels[pos] = cls;
+    }
+    if (threadIdx.x == 0) *n_out = (int32_t)tot;
+}
+
+}  // namespace
+
+extern "C" size_t cpd_center_decode_workspace_bytes(int num_class, int hw, int k) {
+    if (num_class <= 0 || hw <= 0 || k <= 0) return 0;
+    return cpd_align((size_t)num_class * k * 4) * 2;
+}
+
+extern "C" int cpd_center_decode(const float *hm, const float *center, const float *center_z, const float *dim,
+                                 const float *rot, int pix_stride, int ch_stride, int num_class, int h, int w, int k,
+                                 float feature_map_stride, const float voxel_xy[2], const float range_lo_xy[2],
+                                 const float limit_range[6], float score_thresh, float *boxes, float *scores,
+                                 int32_t *labels, int32_t *n_out, void *workspace, size_t workspace_bytes,
+                                 cpd_stream_t stream) {
+    if (!hm || !center || !center_z || !dim || !rot || !boxes || !scores || !labels || !n_out || !workspace ||
+        !voxel_xy || !range_lo_xy || !limit_range || num_class <= 0 || h <= 0 || w <= 0 || k <= 0)
+        return CPD_ERR_ARG;
+    const long long hw = (long long)h * w;
+    if (k > 1024 || k > hw || (long long)num_class * k > (1 << 24) || hw >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
+    if (workspace_bytes < cpd_center_decode_workspace_bytes(num_class, (int)hw, k)) return CPD_ERR_WORKSPACE;
+    hipStream_t s = cpd_s(stream);
+    float *s1 = (float *)workspace;
+    int32_t *i1 = (int32_t *)((char *)workspace + cpd_align((size_t)num_class * k * 4));
+    topk_class_kernel<<<num_class, 1024, 0, s>>>(MapView{hm, pix_stride, ch_stride}, (int)hw, k, s1, i1);
+    DecodeParams q;
+    q.center = MapView{center, pix_stride, ch_stride};
+    q.center_z = MapView{center_z, pix_stride, ch_stride};
+    q.dim = MapView{dim, pix_stride, ch_stride};
+    q.rot = MapView{rot, pix_stride, ch_stride};
+    q.num_class = num_class; q.h = h; q.w = w; q.K = k;
+    q.stride = feature_map_stride; q.vx = voxel_xy[0]; q.vy = voxel_xy[1];
+    q.lox = range_lo_xy[0]; q.loy = range_lo_xy[1];
+    for (int i = 0; i < 6; ++i) q.lim[i] = limit_range[i];
+    q.score_thresh = score_thresh;
+    decode_kernel<<<1, 1024, 0, s>>>(q, s1, i1, boxes, scores, labels, n_out);
+    return cpd_check_launch();
+}

@@ -1,0 +1,329 @@
+// iou3d_nms.hip -- rotated BEV overlap / IoU / 3D IoU / NMS for gfx950.
+//
+// Replaces the iou3d_nms_cuda extension: cpd/ops/iou3d_nms/src/iou3d_nms_kernel.cu (geometry
+// l.35-234, pairwise kernels l.236-265, bitmask NMS l.267-372) and the host side of
+// cpd/ops/iou3d_nms/src/iou3d_nms.cpp:90-186 (mask D2H + serial CPU greedy scan).
+//
+// Geometry: the reference's polygon-clipping arithmetic is restated with the same fp32 operation
+// order (edge x edge crossings i=0..3 x j=0..3, then corners interleaved b-in-a / a-in-b, centroid,
+// bubble sort by atan2, shoelace fan), so degenerate cases (MARGIN corners, parallel edges) agree.
+// The functions are __host__ __device__: the one CPU entry point of the reference extension
+// (boxes_iou_bev_cpu, iou3d_cpu.cpp:232-252) is served by the same code.
+//
+// NMS: the reference's 64-thread block IS a CDNA wavefront and its mask word IS a wave ballot. Here
+// lane = column box, each wave walks its 64 rows, and `__ballot(iou > thr)` yields the mask word
+// directly (all 64 lanes busy on every pair instead of one thread looping over 64 columns). The
+// greedy scan runs on the device in one wave (removed-set kept as one 64-bit word per lane), so
+// the reference's blocking D2H copy of the N x N/64 mask disappears.
+#include <math.h>
+
+#include "common.h"
+
+#define IOU_EPS 1e-8f
+
+namespace {
+
+struct P2 { float x, y; };
+
+__host__ __device__ __forceinline__ float cross3(P2 p1, P2 p2, P2 p0) {
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+__host__ __device__ __forceinline__ bool rect_cross(P2 p1, P2 p2, P2 q1, P2 q2) {
+    return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
+           fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+
+struct BoxG {      // per-box derived geometry, computed once per box per pair
+    float b[7];
+    float cs, sn;  // cos/sin(heading)
+    float ncs, nsn;  // cos/sin(-heading) as the reference evaluates them for the corner test
+    P2 c[5];
+};
+
+__host__ __device__ __forceinline__ void box_setup(const float *box, BoxG &g) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) g.b[k] = box[k];
+    const float hx = box[3] / 2, hy = box[4] / 2;
+    const float x1 = box[0] - hx, y1 = box[1] - hy, x2 = box[0] + hx, y2 = box[1] + hy;
+    g.cs = cosf(box[6]);
+    g.sn = sinf(box[6]);
+    g.ncs = cosf(-box[6]);
+    g.nsn = sinf(-box[6]);
+    const float rx[4] = {x1, x2, x2, x1}, ry[4] = {y1, y1, y2, y2};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float dx = rx[k] - box[0], dy = ry[k] - box[1];
+        g.c[k].x = dx * g.cs + dy * (-g.sn) + box[0];
+        g.c[k].y = dx * g.sn + dy * g.cs + box[1];
+    }
+    g.c[4] = g.c[0];
+}
+
+__host__ __device__ __forceinline__ bool in_box2d(const BoxG &g, P2 p) {
+    const float margin = 1e-2f;
+    const float rx = (p.x - g.b[0]) * g.ncs + (p.y - g.b[1]) * (-g.nsn);
+    const float ry = (p.x - g.b[0]) * g.nsn + (p.y - g.b[1]) * g.ncs;
+    return fabsf(rx) < g.b[3] / 2 + margin && fabsf(ry) < g.b[4] / 2 + margin;
+}
+
+__host__ __device__ __forceinline__ bool seg_intersection(P2 p1, P2 p0, P2 q1, P2 q0, P2 &ans) {
+    if (!rect_cross(p0, p1, q0, q1)) return false;
+    const float s1 = cross3(q0, p1, p0);
+    const float s2 = cross3(p1, q1, p0);
+    const float s3 = cross3(p0, q1, q0);
+    const float s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+    const float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > IOU_EPS) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return true;
+}
+
+__host__ __device__ inline float box_overlap_g(const BoxG &A, const BoxG &B) {
+    P2 pts[16];
+    float ang[16];
+    float cx = 0.f, cy = 0.f;
+    int cnt = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            P2 x;
+            if (seg_intersection(A.c[i + 1], A.c[i], B.c[j + 1], B.c[j], x)) {
+                cx = cx + x.x;
+                cy = cy + x.y;
+                pts[cnt++] = x;
+            }
+        }
+    for (int k = 0; k < 4; ++k) {
+        if (in_box2d(A, B.c[k])) {
+            cx = cx + B.c[k].x; cy = cy + B.c[k].y;
+            pts[cnt++] = B.c[k];
+        }
+        if (in_box2d(B, A.c[k])) {
+            cx = cx + A.c[k].x; cy = cy + A.c[k].y;
+            pts[cnt++] = A.c[k];
+        }
+    }
+    if (cnt == 0) return 0.f;  // reference: 0/0 centroid, empty loops, |0|/2
+    cx /= cnt;
+    cy /= cnt;
+    // the reference re-evaluates atan2 inside every comparison; the angles are pure functions of
+    // the points, so evaluating them once and carrying them through the swaps is identical.
+    for (int k = 0; k < cnt; ++k) ang[k] = atan2f(pts[k].y - cy, pts[k].x - cx);
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (ang[i] > ang[i + 1]) {
+                P2 tp = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = tp;
+                float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const float ux = pts[k].x - pts[0].x, uy = pts[k].y - pts[0].y;
+        const float vx = pts[k + 1].x - pts[0].x, vy = pts[k + 1].y - pts[0].y;
+        area += ux * vy - uy * vx;
+    }
+    return fabsf(area) / 2.0f;
+}
+
+__host__ __device__ __forceinline__ float iou_bev_g(const BoxG &A, const BoxG &B) {
+    const float sa = A.b[3] * A.b[4], sb = B.b[3] * B.b[4];
+    const float so = box_overlap_g(A, B);
+    return so / fmaxf(sa + sb - so, IOU_EPS);
+}
+
+__host__ __device__ __forceinline__ float iou_normal_g(const float *a, const float *b) {
+    const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float inter = width * height;
+    return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, IOU_EPS);
+}
+
+enum { MODE_OVERLAP = 0, MODE_IOU_BEV = 1, MODE_IOU3D = 2 };
+
+// Pairwise matrices: lane = column box (b side, kept in registers), each wave walks 16 rows.
+template <int MODE>
+__global__ void __launch_bounds__(256) pairwise_kernel(const float *__restrict__ a, int n, const float *__restrict__ b,
+                                                       int m, float *__restrict__ out) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.y * 4 + wave) * 16;
+    if (row0 >= n) return;
+    BoxG B;
+    const bool colok = col < m;
+    box_setup(b + 7 * (size_t)(colok ? col : 0), B);
+    const int row1 = row0 + 16 < n ? row0 + 16 : n;
+    for (int row = row0; row < row1; ++row) {
+        BoxG A;
+        box_setup(a + 7 * (size_t)row, A);  // wave-uniform address: scalar/broadcast loads
+        float v;
+        if (MODE == MODE_OVERLAP) {
+            v = box_overlap_g(A, B);
+        } else if (MODE == MODE_IOU_BEV) {
+            v = iou_bev_g(A, B);
+        } else {
+            // boxes_iou3d_gpu, iou3d_nms_utils.py:76-98
+            const float amax = A.b[2] + A.b[5] / 2, amin = A.b[2] - A.b[5] / 2;
+            const float bmax = B.b[2] + B.b[5] / 2, bmin = B.b[2] - B.b[5] / 2;
+            float oh = fminf(amax, bmax) - fmaxf(amin, bmin);
+            oh = oh < 0.f ? 0.f : oh;
+            const float o3 = box_overlap_g(A, B) * oh;
+            const float va = A.b[3] * A.b[4] * A.b[5], vb = B.b[3] * B.b[4] * B.b[5];
+            v = o3 / fmaxf(va + vb - o3, 1e-6f);
+        }
+        if (colok) out[(size_t)row * m + col] = v;
+    }
+}
+
+// mask[row][cb] bit i = iou(row, 64*cb + i) > thr, for columns after the row inside the diagonal
+// block and all columns of later blocks (iou3d_nms_kernel.cu:267-311). Blocks below the diagonal
+// are never read by the scan (it starts at j = nblock) and are not computed.
+template <bool NORMAL>
+__global__ void __launch_bounds__(256) nms_mask_kernel(const float *__restrict__ boxes, int n, float thr,
+                                                       unsigned long long *__restrict__ mask) {
+    const int cb = blockIdx.x, rbk = blockIdx.y;
+    if (rbk > cb) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncb = (n + 63) >> 6;
+    const int col = cb * 64 + lane;
+    const bool colok = col < n;
+    BoxG B;
+    box_setup(boxes + 7 * (size_t)(colok ? col : 0), B);
+    for (int rr = wave * 16; rr < wave * 16 + 16; ++rr) {
+        const int row = rbk * 64 + rr;
+        if (row >= n) break;
+        bool hit = false;
+        if (colok && (rbk != cb || lane > rr)) {
+            if (NORMAL) {
+                hit = iou_normal_g(boxes + 7 * (size_t)row, B.b) > thr;
+            } else {
+                BoxG A;
+                box_setup(boxes + 7 * (size_t)row, A);
+                hit = iou_bev_g(A, B) > thr;
+            }
+        }
+        const unsigned long long word = __ballot(hit);
+        if (lane == 0) mask[(size_t)row * ncb + cb] = word;
+    }
+}
+
+// Greedy scan (iou3d_nms.cpp:117-133) by ONE wave. Lane w owns word w (+64, +128, ...) of the
+// removed set. Per 64-box block: the 64 diagonal words sit one per lane, the in-block greedy pass
+// is register-only (shuffles), and only then are the kept rows' later words OR-ed in with
+// independent, pipelined loads -- two dependent memory round trips per block instead of one per box.
+__global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *__restrict__ mask, int n,
+                                                      long long *__restrict__ keep, int *__restrict__ num_keep) {
+    const int lane = threadIdx.x;
+    const int ncb = (n + 63) >> 6;
+    constexpr int MAXW = 8;  // up to 64*64*8 = 32768 boxes
+    unsigned long long remv[MAXW];
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) remv[k] = 0ull;
+    int kept = 0;
+    for (int nb = 0; nb < ncb; ++nb) {
+        unsigned long long cur = 0ull;
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k)
+            if (k == (nb >> 6)) cur = __shfl(remv[k], nb & 63, 64);
+        const int lim = n - nb * 64 < 64 ? n - nb * 64 : 64;
+        const int myrow = nb * 64 + lane;
+        const unsigned long long diag = lane < lim ? mask[(size_t)myrow * ncb + nb] : 0ull;
+        unsigned long long keptmask = 0ull;
+        for (int ib = 0; ib < lim; ++ib) {
+            const unsigned long long d = __shfl(diag, ib, 64);
+            if (!(cur & (1ull << ib))) {
+                keptmask |= 1ull << ib;
+                cur |= d;
+            }
+        }
+        if (keptmask & (1ull << lane)) keep[kept + __popcll(keptmask & ((1ull << lane) - 1ull))] = myrow;
+        kept += __popcll(keptmask);
+        // later words of every kept row of this block
+        unsigned long long km = keptmask;
+        while (km) {
+            const int ib = __ffsll(km) - 1;
+            km &= km - 1;
+            const size_t rowoff = (size_t)(nb * 64 + ib) * ncb;
+#pragma unroll
+            for (int k = 0; k < MAXW; ++k) {
+                const int w = lane + 64 * k;
+                if (w > nb && w < ncb) remv[k] |= mask[rowoff + w];
+            }
+        }
+    }
+    if (lane == 0) *num_keep = kept;
+}
+
+static int nms_impl(bool normal, const float *boxes, int n, float thr, int64_t *keep, int32_t *num_keep, void *ws,
+                    size_t ws_bytes, hipStream_t s) {
+    if (n < 0 || !keep || !num_keep || (n > 0 && (!boxes || !ws))) return CPD_ERR_ARG;
+    if (n > 64 * 64 * 8) return CPD_ERR_UNSUPPORTED;
+    if (n == 0) {
+        CPD_HIP_TRY(hipMemsetAsync(num_keep, 0, 4, s));
+        return CPD_OK;
+    }
+    if (ws_bytes < cpd_nms_workspace_bytes(n)) return CPD_ERR_WORKSPACE;
+    const int ncb = (n + 63) / 64;
+    unsigned long long *mask = (unsigned long long *)ws;
+    dim3 grid(ncb, ncb);
+    if (normal) nms_mask_kernel<true><<<grid, 256, 0, s>>>(boxes, n, thr, mask);
+    else nms_mask_kernel<false><<<grid, 256, 0, s>>>(boxes, n, thr, mask);
+    nms_scan_kernel<<<1, 64, 0, s>>>(mask, n, (long long *)keep, num_keep);
+    return cpd_check_launch();
+}
+
+template <int MODE>
+static int pairwise_impl(const float *a, int n, const float *b, int m, float *out, hipStream_t s) {
+    if (n < 0 || m < 0 || (n > 0 && m > 0 && (!a || !b || !out))) return CPD_ERR_ARG;
+    if (n == 0 || m == 0) return CPD_OK;
+    dim3 grid(cpd_div_up(m, 64), cpd_div_up(n, 64));
+    pairwise_kernel<MODE><<<grid, 256, 0, s>>>(a, n, b, m, out);
+    return cpd_check_launch();
+}
+
+}  // namespace
+
+extern "C" int cpd_boxes_overlap_bev(const float *a, int n, const float *b, int m, float *out, cpd_stream_t stream) {
+    return pairwise_impl<MODE_OVERLAP>(a, n, b, m, out, cpd_s(stream));
+}
+extern "C" int cpd_boxes_iou_bev(const float *a, int n, const float *b, int m, float *out, cpd_stream_t stream) {
+    return pairwise_impl<MODE_IOU_BEV>(a, n, b, m, out, cpd_s(stream));
+}
+extern "C" int cpd_boxes_iou3d(const float *a, int n, const float *b, int m, float *out, cpd_stream_t stream) {
+    return pairwise_impl<MODE_IOU3D>(a, n, b, m, out, cpd_s(stream));
+}
+
+extern "C" size_t cpd_nms_workspace_bytes(int n) {
+    if (n <= 0) return 256;
+    return cpd_align((size_t)n * ((n + 63) / 64) * 8);
+}
+extern "C" int cpd_nms_rotated(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep, void *workspace,
+                               size_t workspace_bytes, cpd_stream_t stream) {
+    return nms_impl(false, boxes, n, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream));
+}
+extern "C" int cpd_nms_normal(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep, void *workspace,
+                              size_t workspace_bytes, cpd_stream_t stream) {
+    return nms_impl(true, boxes, n, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream));
+}
+
+extern "C" int cpd_boxes_iou_bev_cpu(const float *a, int n, const float *b, int m, float *out) {
+    if (n < 0 || m < 0 || (n > 0 && m > 0 && (!a || !b || !out))) return CPD_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        BoxG A;
+        box_setup(a + 7 * (size_t)i, A);
+        for (int j = 0; j < m; ++j) {
+            BoxG B;
+            box_setup(b + 7 * (size_t)j, B);
+            out[(size_t)i * m + j] = iou_bev_g(A, B);
+        }
+    }
+    return CPD_OK;
+}

@@ -1,0 +1,378 @@
+// site_index.hip -- active-site index, rulebooks and densify for the sparse backbone (gfx950).
+//
+// Replaces the indice-pair ("rulebook") generation and .dense() of [SPCONV] spconv-cu111 2.1.22
+// as used by cpd/models/backbones_3d/spconv_backbone.py:414-455,524-529 and
+// cpd/models/backbones_2d/map_to_bev/height_compression.py:136-138.
+//
+// Design (MI355X-first, not a hash-table port): the occupancy of a (batch,z,y,x) grid is a dense
+// BITMAP (1 bit/cell) plus a per-64-cell popcount prefix. That gives
+//   * coordinate -> row lookup in two coalescable loads (word + prefix), the three x-neighbours
+//     of a 3x3x3 stencil share one word;
+//   * the canonical ascending (b,z,y,x) order of any site set for free (rank = prefix+popcount),
+//     so SparseConv3d outputs need neither sort nor unique -- parity with the reference is defined
+//     on that order;
+//   * no probing, no collisions, deterministic results.
+// Memory scales with grid volume: 17 MB for the 41x1504x1504 Waymo grid, 104 MB for the
+// 61x3008x3008 stress grid -- irrelevant next to 288 GB of HBM3E and mostly Infinity-Cache hits.
+// Row ids of an arbitrary-order site list (level 0 keeps the voxelizer's first-appearance order)
+// go through perm[rank]; canonical lists use rank directly.
+#include "common.h"
+
+namespace {
+
+struct IndexView {
+    uint64_t *bitmap;
+    uint32_t *base;
+    uint32_t *bsum;
+    int32_t *perm;    // rank -> row id
+    int32_t *flags;   // [0] = 1 when perm is in use
+    long long cells, words;
+    size_t bytes;
+};
+
+static IndexView index_carve(void *mem, int batch, const int32_t shape[3], int n_cap) {
+    IndexView v;
+    size_t off = 0;
+    char *b = (char *)mem;
+    auto take = [&](size_t bytes) {
+        void *p = b ? (void *)(b + off) : nullptr;
+        off += cpd_align(bytes);
+        return p;
+    };
+    v.cells = (long long)batch * shape[0] * shape[1] * shape[2];
+    v.words = (v.cells + 63) / 64;
+    v.flags = (int32_t *)take(256);
+    v.bitmap = (uint64_t *)take((size_t)v.words * 8);
+    v.base = (uint32_t *)take((size_t)v.words * 4);
+    v.bsum = (uint32_t *)take((size_t)scan_num_blocks(v.words) * 4);
+    v.perm = (int32_t *)take((size_t)(n_cap > 0 ? n_cap : 1) * 4);
+    v.bytes = off;
+    return v;
+}
+
+struct Grid {
+    int32_t b, d, h, w;
+    __host__ __device__ long long key(int bi, int z, int y, int x) const {
+        return (((long long)bi * d + z) * h + y) * w + x;
+    }
+};
+
+__device__ __forceinline__ int32_t site_lookup(const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
+                                               const int32_t *__restrict__ perm, long long key) {
+    uint64_t w = bitmap[key >> 6];
+    uint64_t bit = 1ull << (key & 63);
+    if (!(w & bit)) return -1;
+    int32_t r = (int32_t)(base[key >> 6] + __popcll(w & (bit - 1ull)));
+    return perm ? perm[r] : r;
+}
+
+__global__ void __launch_bounds__(256) index_mark_kernel(const int32_t *__restrict__ idx, int n, Grid g, uint64_t *bitmap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 q = reinterpret_cast<const int4 *>(idx)[i];
+    if ((unsigned)q.x >= (unsigned)g.b || (unsigned)q.y >= (unsigned)g.d || (unsigned)q.z >= (unsigned)g.h ||
+        (unsigned)q.w >= (unsigned)g.w)
+        return;  // out-of-range rows are ignored (they can never be looked up)
+    long long k = g.key(q.x, q.y, q.z, q.w);
+    atomicOr((unsigned long long *)&bitmap[k >> 6], 1ull << (k & 63));
+}
+
+__global__ void __launch_bounds__(256) index_perm_kernel(const int32_t *__restrict__ idx, int n, Grid g,
+                                                         const uint64_t *__restrict__ bitmap,
+                                                         const uint32_t *__restrict__ base, int32_t *perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 q = reinterpret_cast<const int4 *>(idx)[i];
+    if ((unsigned)q.x >= (unsigned)g.b || (unsigned)q.y >= (unsigned)g.d || (unsigned)q.z >= (unsigned)g.h ||
+        (unsigned)q.w >= (unsigned)g.w)
+        return;
+    int32_t r = site_lookup(bitmap, base, nullptr, g.key(q.x, q.y, q.z, q.w));
+    perm[r] = i;
+}
+
+struct PopcFn {
+    const uint64_t *bitmap;
+    __device__ uint32_t operator()(long long w) const { return (uint32_t)__popcll(bitmap[w]); }
+};
+struct StoreBaseFn {
+    uint32_t *base;
+    __device__ void operator()(long long w, uint32_t, uint32_t prefix) const { base[w] = prefix; }
+};
+struct EmitFn {  // write the coordinates of every set bit in canonical order
+    const uint64_t *bitmap;
+    const uint32_t *base;
+    int32_t *out;
+    int n_cap;
+    Grid g;
+    __device__ void operator()(long long wi, uint32_t, uint32_t) const {
+        uint64_t w = bitmap[wi];
+        uint32_t r = base[wi];
+        while (w) {
+            int bpos = __ffsll((unsigned long long)w) - 1;
+            w &= w - 1;
+            long long k = wi * 64 + bpos;
+            if ((int)r < n_cap) {
+                int x = (int)(k % g.w);
+                long long t = k / g.w;
+                int y = (int)(t % g.h);
+                t /= g.h;
+                int z = (int)(t % g.d);
+                int bi = (int)(t / g.d);
+                reinterpret_cast<int4 *>(out)[r] = make_int4(bi, z, y, x);
+            }
+            ++r;
+        }
+    }
+};
+
+// One thread per output row, all taps: nbr[t][j] coalesced over j.
+__global__ void __launch_bounds__(256)
+rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd, int kh, int kw, int sd, int sh, int sw,
+                int pd, int ph, int pw, const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
+                const int32_t *__restrict__ perm_in, const int32_t *__restrict__ flags, int32_t *__restrict__ nbr) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    // flags[0] != 0: arbitrary-order site list, row id = perm[rank]; 0: canonical list, row id = rank
+    const int32_t *perm = flags[0] ? perm_in : nullptr;
+    int4 q = reinterpret_cast<const int4 *>(out_idx)[j];
+    int t = 0;
+    for (int tz = 0; tz < kd; ++tz) {
+        int z = q.y * sd - pd + tz;
+        for (int ty = 0; ty < kh; ++ty) {
+            int y = q.z * sh - ph + ty;
+            for (int tx = 0; tx < kw; ++tx, ++t) {
+                int x = q.w * sw - pw + tx;
+                int32_t r = -1;
+                if ((unsigned)z < (unsigned)gin.d && (unsigned)y < (unsigned)gin.h && (unsigned)x < (unsigned)gin.w &&
+                    (unsigned)q.x < (unsigned)gin.b)
+                    r = site_lookup(bitmap, base, perm, gin.key(q.x, z, y, x));
+                nbr[(size_t)t * n_out + j] = r;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+outset_mark_kernel(const int32_t *__restrict__ in_idx, int n_in, Grid gout, int kd, int kh, int kw, int sd, int sh, int sw,
+                   int pd, int ph, int pw, uint64_t *bitmap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    int4 q = reinterpret_cast<const int4 *>(in_idx)[i];
+    if ((unsigned)q.x >= (unsigned)gout.b) return;
+    for (int tz = 0; tz < kd; ++tz) {
+        int nz = q.y + pd - tz;
+        if (nz < 0 || nz % sd) continue;
+        nz /= sd;
+        if (nz >= gout.d) continue;
+        for (int ty = 0; ty < kh; ++ty) {
+            int ny = q.z + ph - ty;
+            if (ny < 0 || ny % sh) continue;
+            ny /= sh;
+            if (ny >= gout.h) continue;
+            for (int tx = 0; tx < kw; ++tx) {
+                int nx = q.w + pw - tx;
+                if (nx < 0 || nx % sw) continue;
+                nx /= sw;
+                if (nx >= gout.w) continue;
+                long long k = gout.key(q.x, nz, ny, nx);
+                uint64_t bit = 1ull << (k & 63);
+                // most marks hit an already-set bit: test first to keep atomics off the hot path
+                if (!(bitmap[k >> 6] & bit))
+                    atomicOr((unsigned long long *)&bitmap[k >> 6], bit);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) emit_words_kernel(long long words, EmitFn fn) {
+    long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < words) fn(w, 0u, 0u);
+}
+
+__global__ void __launch_bounds__(256) densify_nhwc_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                           int n, int c4, Grid g, float *__restrict__ out) {
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int i = (int)(tid / c4), k = (int)(tid % c4);
+    if (i >= n) return;
+    int4 q = reinterpret_cast<const int4 *>(idx)[i];
+    float4 v = reinterpret_cast<const float4 *>(feat)[(size_t)i * c4 + k];
+    size_t pix = ((size_t)q.x * g.h + q.z) * g.w + q.w;
+    reinterpret_cast<float4 *>(out)[(pix * g.d + q.y) * c4 + k] = v;
+}
+
+__global__ void __launch_bounds__(256) densify_nchw_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                           int n, int c, Grid g, float *__restrict__ out) {
+    // lanes run over sites (canonical order => consecutive x), channels looped through LDS-free
+    // strided reads: out[b][ch*D+z][y][x]
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int ch = (int)(tid / n), i = (int)(tid % n);
+    if (ch >= c) return;
+    int4 q = reinterpret_cast<const int4 *>(idx)[i];
+    size_t plane = (size_t)g.h * g.w;
+    out[(((size_t)q.x * c + ch) * g.d + q.y) * plane + (size_t)q.z * g.w + q.w] = feat[(size_t)i * c + ch];
+}
+
+__global__ void __launch_bounds__(256) rulebook_conv2d_kernel(int batch, int h, int w, int ho, int wo, int kh, int kw,
+                                                              int stride, int pad, int32_t *__restrict__ nbr) {
+    long long n_out = (long long)batch * ho * wo;
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    int x = (int)(j % wo);
+    long long t2 = j / wo;
+    int y = (int)(t2 % ho), b = (int)(t2 / ho);
+    int t = 0;
+    for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx, ++t) {
+            int iy = y * stride - pad + ky, ix = x * stride - pad + kx;
+            int32_t r = -1;
+            if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) r = (int32_t)(((long long)b * h + iy) * w + ix);
+            nbr[(size_t)t * n_out + j] = r;
+        }
+}
+
+static int valid_shape(int batch, const int32_t s[3]) {
+    if (batch <= 0 || !s || s[0] <= 0 || s[1] <= 0 || s[2] <= 0) return 0;
+    long long cells = (long long)batch * s[0] * s[1] * s[2];
+    return cells < (1ll << 40);
+}
+
+static int scan_bitmap(const IndexView &v, int32_t *total_out, int32_t cap, hipStream_t s) {
+    return device_scan(v.words, PopcFn{v.bitmap}, StoreBaseFn{v.base}, v.bsum, total_out, cap, s);
+}
+
+}  // namespace
+
+extern "C" size_t cpd_index_bytes(int batch, const int32_t shape_zyx[3], int n_capacity) {
+    if (!valid_shape(batch, shape_zyx) || n_capacity < 0) return 0;
+    return index_carve(nullptr, batch, shape_zyx, n_capacity).bytes;
+}
+
+extern "C" int cpd_index_build(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3], void *index,
+                               size_t index_bytes, cpd_stream_t stream) {
+    if (!valid_shape(batch, shape_zyx) || n < 0 || !index || (n > 0 && !indices)) return CPD_ERR_ARG;
+    IndexView v = index_carve(index, batch, shape_zyx, n);
+    if (index_bytes < v.bytes) return CPD_ERR_WORKSPACE;
+    hipStream_t s = cpd_s(stream);
+    Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
+    CPD_HIP_TRY(hipMemsetAsync(v.bitmap, 0, (size_t)v.words * 8, s));
+    CPD_HIP_TRY(hipMemsetAsync(v.flags, 0, 4, s));
+    CPD_HIP_TRY(hipMemsetAsync(v.flags, 1, 1, s));  // flags[0] = 1 (little endian): perm in use
+    if (n > 0) index_mark_kernel<<<cpd_div_up(n, 256), 256, 0, s>>>(indices, n, g, v.bitmap);
+    int rc = scan_bitmap(v, nullptr, -1, s);
+    if (rc) return rc;
+    if (n > 0) index_perm_kernel<<<cpd_div_up(n, 256), 256, 0, s>>>(indices, n, g, v.bitmap, v.base, v.perm);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_conv_out_shape(const int32_t in_shape[3], const int32_t ksize[3], const int32_t stride[3],
+                                  const int32_t pad[3], int32_t out_shape[3]) {
+    if (!in_shape || !ksize || !stride || !pad || !out_shape) return CPD_ERR_ARG;
+    for (int d = 0; d < 3; ++d) {
+        if (ksize[d] <= 0 || stride[d] <= 0 || pad[d] < 0) return CPD_ERR_ARG;
+        out_shape[d] = (in_shape[d] + 2 * pad[d] - ksize[d]) / stride[d] + 1;
+        if (out_shape[d] <= 0) return CPD_ERR_ARG;
+    }
+    return CPD_OK;
+}
+
+static int rulebook_launch(const int32_t *out_idx, int n_out, int batch, const int32_t in_shape[3], const int32_t k[3],
+                           const int32_t st[3], const int32_t pd[3], const void *index, int32_t *nbr, hipStream_t s) {
+    // the index was carved with some capacity; pointers before perm do not depend on it
+    IndexView v = index_carve(const_cast<void *>(index), batch, in_shape, 1);
+    Grid g{batch, in_shape[0], in_shape[1], in_shape[2]};
+    if (n_out > 0)
+        rulebook_kernel<<<cpd_div_up(n_out, 256), 256, 0, s>>>(out_idx, n_out, g, k[0], k[1], k[2], st[0], st[1], st[2],
+                                                               pd[0], pd[1], pd[2], v.bitmap, v.base,
+                                                               v.perm, v.flags, nbr);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_rulebook_subm(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3],
+                                 const int32_t ksize[3], const void *index, int32_t *nbr, cpd_stream_t stream) {
+    if (!valid_shape(batch, shape_zyx) || n < 0 || !ksize || !index || (n > 0 && (!indices || !nbr))) return CPD_ERR_ARG;
+    for (int d = 0; d < 3; ++d)
+        if (ksize[d] <= 0 || !(ksize[d] & 1)) return CPD_ERR_ARG;
+    const int32_t one[3] = {1, 1, 1};
+    const int32_t pad[3] = {ksize[0] / 2, ksize[1] / 2, ksize[2] / 2};
+    return rulebook_launch(indices, n, batch, shape_zyx, ksize, one, pad, index, nbr, cpd_s(stream));
+}
+
+extern "C" int cpd_rulebook_conv(const int32_t *out_indices, int n_out, int batch, const int32_t in_shape[3],
+                                 const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3],
+                                 const void *in_index, int32_t *nbr, cpd_stream_t stream) {
+    int32_t os[3];
+    if (!valid_shape(batch, in_shape) || n_out < 0 || !in_index || (n_out > 0 && (!out_indices || !nbr)))
+        return CPD_ERR_ARG;
+    int rc = cpd_conv_out_shape(in_shape, ksize, stride, pad, os);
+    if (rc) return rc;
+    return rulebook_launch(out_indices, n_out, batch, in_shape, ksize, stride, pad, in_index, nbr, cpd_s(stream));
+}
+
+extern "C" int cpd_conv_outset(const int32_t *in_indices, int n_in, int batch, const int32_t in_shape[3],
+                               const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3], void *out_index,
+                               size_t out_index_bytes, int32_t *n_out, cpd_stream_t stream) {
+    int32_t os[3];
+    if (!valid_shape(batch, in_shape) || n_in < 0 || !out_index || !n_out || (n_in > 0 && !in_indices)) return CPD_ERR_ARG;
+    int rc = cpd_conv_out_shape(in_shape, ksize, stride, pad, os);
+    if (rc) return rc;
+    if (!valid_shape(batch, os)) return CPD_ERR_UNSUPPORTED;
+    IndexView v = index_carve(out_index, batch, os, 0);
+    if (out_index_bytes < v.bytes) return CPD_ERR_WORKSPACE;
+    hipStream_t s = cpd_s(stream);
+    Grid g{batch, os[0], os[1], os[2]};
+    CPD_HIP_TRY(hipMemsetAsync(v.bitmap, 0, (size_t)v.words * 8, s));
+    CPD_HIP_TRY(hipMemsetAsync(v.flags, 0, 4, s));  // canonical: rank == row id, perm unused
+    if (n_in > 0)
+        outset_mark_kernel<<<cpd_div_up(n_in, 256), 256, 0, s>>>(in_indices, n_in, g, ksize[0], ksize[1], ksize[2],
+                                                                 stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],
+                                                                 v.bitmap);
+    return scan_bitmap(v, n_out, -1, s);
+}
+
+extern "C" int cpd_index_emit(const void *index, int batch, const int32_t shape_zyx[3], int32_t *indices, int n_capacity,
+                              cpd_stream_t stream) {
+    if (!valid_shape(batch, shape_zyx) || !index || n_capacity < 0 || (n_capacity > 0 && !indices)) return CPD_ERR_ARG;
+    IndexView v = index_carve(const_cast<void *>(index), batch, shape_zyx, 0);
+    Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
+    hipStream_t s = cpd_s(stream);
+    long long nthreads = v.words;
+    auto fn = EmitFn{v.bitmap, v.base, indices, n_capacity, g};
+    emit_words_kernel<<<cpd_div_up(nthreads, 256), 256, 0, s>>>(nthreads, fn);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_densify_nhwc(const float *feat, const int32_t *indices, int n, int c, int batch,
+                                const int32_t shape_zyx[3], float *out, cpd_stream_t stream) {
+    if (!valid_shape(batch, shape_zyx) || n < 0 || c <= 0 || (c & 3) || !out || (n > 0 && (!feat || !indices)))
+        return CPD_ERR_ARG;
+    hipStream_t s = cpd_s(stream);
+    Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
+    size_t total = (size_t)batch * shape_zyx[0] * shape_zyx[1] * shape_zyx[2] * c;
+    CPD_HIP_TRY(hipMemsetAsync(out, 0, total * sizeof(float), s));
+    long long threads = (long long)n * (c / 4);
+    if (threads > 0) densify_nhwc_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(feat, indices, n, c / 4, g, out);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_densify_nchw(const float *feat, const int32_t *indices, int n, int c, int batch,
+                                const int32_t shape_zyx[3], float *out, cpd_stream_t stream) {
+    if (!valid_shape(batch, shape_zyx) || n < 0 || c <= 0 || !out || (n > 0 && (!feat || !indices))) return CPD_ERR_ARG;
+    hipStream_t s = cpd_s(stream);
+    Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
+    size_t total = (size_t)batch * shape_zyx[0] * shape_zyx[1] * shape_zyx[2] * c;
+    CPD_HIP_TRY(hipMemsetAsync(out, 0, total * sizeof(float), s));
+    long long threads = (long long)n * c;
+    if (threads > 0) densify_nchw_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(feat, indices, n, c, g, out);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_rulebook_conv2d(int batch, int h, int w, int kh, int kw, int stride, int pad, int32_t *nbr,
+                                   cpd_stream_t stream) {
+    if (batch <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 || !nbr) return CPD_ERR_ARG;
+    int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    if (ho <= 0 || wo <= 0) return CPD_ERR_ARG;
+    long long n_out = (long long)batch * ho * wo;
+    if (n_out >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
+    rulebook_conv2d_kernel<<<cpd_div_up(n_out, 256), 256, 0, cpd_s(stream)>>>(batch, h, w, ho, wo, kh, kw, stride, pad, nbr);
+    return cpd_check_launch();
+}

@@ -1,0 +1,267 @@
+// voxelize.hip -- point cloud -> voxels (+ fused MeanVFE) on gfx950.
+//
+// Replaces VoxelGeneratorWrapper.generate -> [SPCONV] Point2VoxelCPU3d.point_to_voxel
+// (cpd/datasets/processor/data_processor.py:14-59) and MeanVFE (mean_vfe.py:41-43).
+//
+// The reference is a SERIAL scan over points with a dense int32 lookup volume; voxel ids follow
+// first appearance and each voxel keeps its first P points in point order. The same result is
+// produced here data-parallel, with no sort and no hash probing:
+//   1 keys      : cell key per point (fp32 floor((p-lo)/vs), IEEE division), occupancy bit set
+//                 in a dense bitmap over the grid (1 bit per cell; 92.7 M cells = 11.6 MB for the
+//                 Waymo grid -- trivially resident in 288 GB HBM / 256 MB Infinity Cache)
+//   2 scan      : popcount prefix over the bitmap  -> dense rank r of every occupied cell
+//   3 first     : first[r] = min point index (atomicMin)
+//   4 order     : flag(i) = (first[rank_i] == i); prefix sum over POINT order of the flags gives
+//                 the serial first-appearance voxel id; ids >= max_voxels are dropped exactly as
+//                 the serial scan would
+//   5 insert    : per voxel, the P smallest point indices via an atomicMin insertion cascade
+//   6 gather    : coalesced copy of the kept points into voxels[M,P,C], count, mean
+// HBM traffic is ~ the points read 3x (12 B/pt keys + rows) + outputs; see DESIGN.md.
+#include "common.h"
+
+thread_local int g_cpd_last_hip_error = 0;
+
+extern "C" const char *cpd_version(void) { return "cpd_hip 0.1 (gfx950)"; }
+extern "C" int cpd_last_hip_error(void) { return g_cpd_last_hip_error; }
+
+extern "C" int cpd_voxel_grid_size(const float vsize_xyz[3], const float range_xyz[6], int32_t grid_zyx[3]) {
+    if (!vsize_xyz || !range_xyz || !grid_zyx) return CPD_ERR_ARG;
+    for (int a = 0; a < 3; ++a) {
+        float g = (range_xyz[3 + a] - range_xyz[a]) / vsize_xyz[a];
+        grid_zyx[2 - a] = (int32_t)roundf(g);
+        if (grid_zyx[2 - a] <= 0) return CPD_ERR_ARG;
+    }
+    return CPD_OK;
+}
+
+namespace {
+
+struct VoxGeom {
+    float lo[3];   // x,y,z lower bounds
+    float vs[3];   // x,y,z voxel size
+    int32_t g[3];  // z,y,x grid
+};
+
+struct VoxWs {
+    uint64_t *bitmap;   // [words]
+    uint32_t *base;     // [words] popcount prefix
+    uint32_t *bsum_bm;  // scan block sums (bitmap)
+    uint32_t *bsum_pt;  // scan block sums (points)
+    int32_t *pkey;      // [n] cell key or -1
+    int32_t *prank;     // [n] dense rank of the point's cell
+    int32_t *first;     // [n] min point index per rank
+    int32_t *vid;       // [n] voxel id per rank
+    int32_t *slots;     // [cap*P] kept point indices per voxel (sorted ascending)
+    int32_t *counts;    // [cap] points seen per voxel
+    int32_t *nocc;      // scalar: occupied cells
+    long long words;
+    size_t bytes;
+};
+
+static VoxWs carve(void *ws, int n, int P, int cap, long long cells) {
+    VoxWs w;
+    size_t off = 0;
+    char *b = (char *)ws;
+    auto take = [&](size_t bytes) {
+        void *p = b ? (void *)(b + off) : nullptr;
+        off += cpd_align(bytes);
+        return p;
+    };
+    w.words = (cells + 63) / 64;
+    w.bitmap = (uint64_t *)take((size_t)w.words * 8);
+    w.base = (uint32_t *)take((size_t)w.words * 4);
+    w.bsum_bm = (uint32_t *)take((size_t)scan_num_blocks(w.words) * 4);
+    w.bsum_pt = (uint32_t *)take((size_t)scan_num_blocks(n) * 4);
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    w.pkey = (int32_t *)take(nn * 4);
+    w.prank = (int32_t *)take(nn * 4);
+    w.first = (int32_t *)take(nn * 4);
+    w.vid = (int32_t *)take(nn * 4);
+    w.slots = (int32_t *)take((size_t)(cap > 0 ? cap : 1) * P * 4);
+    w.counts = (int32_t *)take((size_t)(cap > 0 ? cap : 1) * 4);
+    w.nocc = (int32_t *)take(4);
+    w.bytes = off;
+    return w;
+}
+
+__global__ void __launch_bounds__(256) vox_keys_kernel(const float *__restrict__ pts, int n, int c, VoxGeom geo,
+                                                       int32_t *__restrict__ pkey, uint64_t *bitmap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pts + (size_t)i * c;
+    int32_t cz[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {  // j over z,y,x ; coordinate axis 2-j
+        // fp32 subtract then IEEE-correct fp32 divide then floor: bit-identical to the serial CPU
+        // voxelizer at voxel boundaries (no reciprocal multiply, no contraction possible here).
+        float f = floorf(__fdiv_rn(__fsub_rn(p[2 - j], geo.lo[2 - j]), geo.vs[2 - j]));
+        if (!(f >= 0.0f) || !(f < (float)geo.g[j])) ok = false;
+        cz[j] = ok ? (int32_t)f : 0;
+    }
+    int32_t key = -1;
+    if (ok) {
+        key = (cz[0] * geo.g[1] + cz[1]) * geo.g[2] + cz[2];
+        atomicOr((unsigned long long *)&bitmap[key >> 6], 1ull << (key & 63));
+    }
+    pkey[i] = key;
+}
+
+__global__ void __launch_bounds__(256) vox_first_kernel(int n, const int32_t *__restrict__ pkey,
+                                                        const uint64_t *__restrict__ bitmap,
+                                                        const uint32_t *__restrict__ base, int32_t *__restrict__ prank,
+                                                        int32_t *first) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t key = pkey[i];
+    int32_t r = -1;
+    if (key >= 0) {
+        uint64_t w = bitmap[key >> 6];
+        r = (int32_t)(base[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1ull)));
+        atomicMin(&first[r], i);
+    }
+    prank[i] = r;
+}
+
+struct FlagFn {  // 1 iff point i is the first point of its voxel
+    const int32_t *prank;
+    const int32_t *first;
+    __device__ uint32_t operator()(long long i) const {
+        int32_t r = prank[i];
+        return (r >= 0 && first[r] == (int32_t)i) ? 1u : 0u;
+    }
+};
+struct AssignVoxelFn {  // flagged point i starts voxel id = prefix (serial first-appearance order)
+    const int32_t *prank;
+    const int32_t *pkey;
+    int32_t *vid;
+    int32_t *coords;
+    int coord_cols, batch_idx, max_voxels;
+    int32_t gy, gx;
+    __device__ void operator()(long long i, uint32_t flag, uint32_t prefix) const {
+        if (!flag) return;
+        int32_t v = (int32_t)prefix;
+        vid[prank[i]] = v;
+        if (v < max_voxels) {
+            int32_t key = pkey[i];
+            int32_t x = key % gx, y = (key / gx) % gy, z = key / (gx * gy);
+            int32_t *o = coords + (size_t)v * coord_cols;
+            if (coord_cols == 4) { o[0] = batch_idx; o[1] = z; o[2] = y; o[3] = x; }
+            else { o[0] = z; o[1] = y; o[2] = x; }
+        }
+    }
+};
+
+struct PopcFn {
+    const uint64_t *bitmap;
+    __device__ uint32_t operator()(long long w) const { return (uint32_t)__popcll(bitmap[w]); }
+};
+struct StoreBaseFn {
+    uint32_t *base;
+    __device__ void operator()(long long w, uint32_t, uint32_t prefix) const { base[w] = prefix; }
+};
+
+__global__ void __launch_bounds__(256) vox_insert_kernel(int n, int P, int max_voxels,
+                                                         const int32_t *__restrict__ prank,
+                                                         const int32_t *__restrict__ vid, int32_t *slots,
+                                                         int32_t *counts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t r = prank[i];
+    if (r < 0) return;
+    int32_t v = vid[r];
+    if (v >= max_voxels) return;
+    atomicAdd(&counts[v], 1);
+    // Insertion cascade: slot p ends up holding the (p+1)-th smallest point index of the voxel.
+    // Every value enters slot 0; whatever loses an atomicMin moves on to the next slot.
+    int32_t x = i;
+    int32_t *s = slots + (size_t)v * P;
+    for (int p = 0; p < P; ++p) {
+        int32_t old = atomicMin(&s[p], x);
+        if (old == 0x7f7f7f7f) break;  // slot was empty: nothing displaced
+        x = old > x ? old : x;
+    }
+}
+
+__global__ void __launch_bounds__(256) vox_gather_kernel(const float *__restrict__ pts, int c, int P, int cap,
+                                                         const int32_t *__restrict__ n_vox,
+                                                         const int32_t *__restrict__ slots,
+                                                         const int32_t *__restrict__ counts, float *voxels,
+                                                         int32_t *num_points, float *mean) {
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = (int)(tid / c), ch = (int)(tid % c);
+    if (v >= cap || v >= *n_vox) return;
+    int cnt = counts[v];
+    if (cnt > P) cnt = P;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) {  // sum order p = 0..P-1, zeros included (mean_vfe.py:41)
+        float val = 0.f;
+        if (p < cnt) val = pts[(size_t)slots[(size_t)v * P + p] * c + ch];
+        if (voxels) voxels[((size_t)v * P + p) * c + ch] = val;
+        s += val;
+    }
+    if (mean) mean[(size_t)v * c + ch] = __fdiv_rn(s, (float)(cnt < 1 ? 1 : cnt));
+    if (ch == 0) num_points[v] = cnt;
+}
+
+}  // namespace
+
+static int vox_geom(const float vs[3], const float rg[6], VoxGeom *g, long long *cells) {
+    int32_t grid[3];
+    int rc = cpd_voxel_grid_size(vs, rg, grid);
+    if (rc) return rc;
+    for (int a = 0; a < 3; ++a) { g->lo[a] = rg[a]; g->vs[a] = vs[a]; g->g[a] = grid[a]; }
+    *cells = (long long)grid[0] * grid[1] * grid[2];
+    if (*cells >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
+    return CPD_OK;
+}
+
+extern "C" size_t cpd_voxelize_workspace_bytes(int n_points, int max_points, int max_voxels, const float vsize_xyz[3],
+                                               const float range_xyz[6]) {
+    VoxGeom g;
+    long long cells;
+    if (n_points < 0 || max_points <= 0 || max_voxels <= 0) return 0;
+    if (vox_geom(vsize_xyz, range_xyz, &g, &cells)) return 0;
+    int cap = max_voxels < n_points ? max_voxels : n_points;
+    return carve(nullptr, n_points, max_points, cap, cells).bytes;
+}
+
+extern "C" int cpd_voxelize(const float *points, int n_points, int c, const float vsize_xyz[3],
+                            const float range_xyz[6], int max_points, int max_voxels, int batch_idx, int coord_cols,
+                            float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
+                            int32_t *n_voxels, void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
+    if (n_points < 0 || c < 3 || max_points <= 0 || max_voxels <= 0 || !coords || !num_points || !n_voxels ||
+        !workspace || (coord_cols != 3 && coord_cols != 4) || (n_points > 0 && !points))
+        return CPD_ERR_ARG;
+    VoxGeom geo;
+    long long cells;
+    int rc = vox_geom(vsize_xyz, range_xyz, &geo, &cells);
+    if (rc) return rc;
+    hipStream_t s = cpd_s(stream);
+    const int n = n_points;
+    const int cap = max_voxels < n ? max_voxels : n;
+    VoxWs w = carve(workspace, n, max_points, cap, cells);
+    if (workspace_bytes < w.bytes) return CPD_ERR_WORKSPACE;
+    if (n == 0) {
+        CPD_HIP_TRY(hipMemsetAsync(n_voxels, 0, 4, s));
+        return CPD_OK;
+    }
+    CPD_HIP_TRY(hipMemsetAsync(w.bitmap, 0, (size_t)w.words * 8, s));
+    CPD_HIP_TRY(hipMemsetAsync(w.first, 0x7f, (size_t)n * 4, s));
+    CPD_HIP_TRY(hipMemsetAsync(w.slots, 0x7f, (size_t)cap * max_points * 4, s));
+    CPD_HIP_TRY(hipMemsetAsync(w.counts, 0, (size_t)cap * 4, s));
+    const int nb = cpd_div_up(n, 256);
+    vox_keys_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, w.pkey, w.bitmap);
+    rc = device_scan(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
+    if (rc) return rc;
+    vox_first_kernel<<<nb, 256, 0, s>>>(n, w.pkey, w.bitmap, w.base, w.prank, w.first);
+    rc = device_scan(n, FlagFn{w.prank, w.first},
+                     AssignVoxelFn{w.prank, w.pkey, w.vid, coords, coord_cols, batch_idx, max_voxels, geo.g[1], geo.g[2]},
+                     w.bsum_pt, n_voxels, max_voxels, s);
+    if (rc) return rc;
+    vox_insert_kernel<<<nb, 256, 0, s>>>(n, max_points, max_voxels, w.prank, w.vid, w.slots, w.counts);
+    const long long threads = (long long)cap * c;
+    vox_gather_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(points, c, max_points, cap, n_voxels, w.slots, w.counts,
+                                                               voxels, num_points, mean_features);
+    return cpd_check_launch();
+}

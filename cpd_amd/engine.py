@@ -1,0 +1,426 @@
+"""Fused forward engine of the hot path: points -> boxes, one process per GPU.
+
+Mirrors CenterPoint.forward's module_topology (cpd/models/detectors/detector3d_template.py:22-25,
+centerpoint.py:9-22) for the one-stage path
+    MeanVFE -> VoxelResBackBone8x -> HeightCompression -> BaseBEVBackbone -> CenterHead -> NMS
+but as a flat list of C-ABI launches on one HIP stream: eval-mode BatchNorm, bias, ReLU and the
+SparseBasicBlock residual are folded into the conv epilogues, activations stay channels-last in
+HBM, rulebooks are built once per indice_key, and nothing leaves the device until the final boxes.
+Weights come in under the reference's own state_dict names (so a CPD checkpoint loads unchanged).
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class ModelConfig:
+    """The fields of voxel_rcnn_cproto_center.yaml / waymo_unsupervised_cproto.yaml the path reads."""
+    point_cloud_range: List[float] = field(default_factory=lambda: [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0])
+    voxel_size: List[float] = field(default_factory=lambda: [0.1, 0.1, 0.15])
+    max_points_per_voxel: int = 5
+    max_voxels: int = 1000000
+    num_point_features: int = 5
+    num_filters: List[int] = field(default_factory=lambda: [16, 32, 64, 128])      # BACKBONE_3D.NUM_FILTERS
+    out_features: int = 128                                                        # BACKBONE_3D.OUT_FEATURES
+    bev_layer_nums: List[int] = field(default_factory=lambda: [5, 5])              # BACKBONE_2D.*
+    bev_layer_strides: List[int] = field(default_factory=lambda: [1, 2])
+    bev_num_filters: List[int] = field(default_factory=lambda: [128, 256])
+    bev_upsample_strides: List[int] = field(default_factory=lambda: [1, 2])
+    bev_num_upsample_filters: List[int] = field(default_factory=lambda: [256, 256])
+    shared_conv_channel: int = 64                                                  # DENSE_HEAD.*
+    num_class: int = 3
+    head_order: List[str] = field(default_factory=lambda: ["center", "center_z", "dim", "rot"])
+    head_channels: Dict[str, int] = field(default_factory=lambda: {"center": 2, "center_z": 1, "dim": 3, "rot": 2})
+    feature_map_stride: int = 8
+    score_thresh: float = 0.1
+    post_center_limit_range: List[float] = field(default_factory=lambda: [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0])
+    max_obj_per_sample: int = 500
+    nms_thresh: float = 0.8
+    nms_pre_maxsize: int = 4096
+    nms_post_maxsize: int = 500
+
+    @property
+    def grid_zyx(self):
+        return ops.voxel_grid_size(self.voxel_size, self.point_cloud_range)
+
+    @property
+    def sparse_shape(self):
+        g = self.grid_zyx
+        return [g[0] + 1, g[1], g[2]]     # grid_size[::-1] + [1,0,0]  (spconv_backbone.py:412)
+
+    def head_names(self):
+        return list(self.head_order) + ["hm"]
+
+    def head_out(self, name):
+        return self.num_class if name == "hm" else self.head_channels[name]
+
+
+# Sparse stages of VoxelResBackBone8x (spconv_backbone.py:414-455): (name, ksize, stride, pad)
+_DOWN = {
+    "conv2": ([3, 3, 3], [2, 2, 2], [1, 1, 1]),
+    "conv3": ([3, 3, 3], [2, 2, 2], [1, 1, 1]),
+    "conv4": ([3, 3, 3], [2, 2, 2], [0, 1, 1]),
+    "conv_out": ([3, 1, 1], [2, 1, 1], [0, 0, 0]),
+}
+
+
+def init_state_dict(cfg: ModelConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights under the REFERENCE's state_dict names and layouts (spconv-2.x conv
+    weights (Cout,kD,kH,kW,Cin); torch Conv2d / ConvTranspose2d / BatchNorm). BN statistics are
+    non-trivial so that folding errors would show up in parity tests."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv3d(name, cin, cout, k, bias):
+        fan = cin * k[0] * k[1] * k[2]
+        sd[name + ".weight"] = torch.randn(cout, k[0], k[1], k[2], cin, generator=g) * math.sqrt(2.0 / fan)
+        if bias:
+            sd[name + ".bias"] = torch.randn(cout, generator=g) * 0.05
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.rand(c, generator=g) * 0.5 + 0.75
+        sd[name + ".bias"] = torch.randn(c, generator=g) * 0.1
+        sd[name + ".running_mean"] = torch.randn(c, generator=g) * 0.1
+        sd[name + ".running_var"] = torch.rand(c, generator=g) * 0.5 + 0.75
+        sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    def conv2d(name, cin, cout, k, bias, transposed=False):
+        fan = cin * k * k
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        sd[name + ".weight"] = torch.randn(*shape, generator=g) * math.sqrt(2.0 / fan)
+        if bias:
+            sd[name + ".bias"] = torch.randn(cout, generator=g) * 0.05
+
+    nf = cfg.num_filters
+    p = "backbone_3d."
+    conv3d(p + "conv_input.0", cfg.num_point_features, nf[0], [3, 3, 3], False)
+    bn(p + "conv_input.1", nf[0])
+
+    def basic_block(name, c):
+        conv3d(name + ".conv1", c, c, [3, 3, 3], True)
+        bn(name + ".bn1", c)
+        conv3d(name + ".conv2", c, c, [3, 3, 3], True)
+        bn(name + ".bn2", c)
+
+    basic_block(p + "conv1.0", nf[0])
+    basic_block(p + "conv1.1", nf[0])
+    for lvl, stage in enumerate(["conv2", "conv3", "conv4"], start=1):
+        k = _DOWN[stage][0]
+        conv3d(p + stage + ".0.0", nf[lvl - 1], nf[lvl], k, False)
+        bn(p + stage + ".0.1", nf[lvl])
+        basic_block(p + stage + ".1", nf[lvl])
+        basic_block(p + stage + ".2", nf[lvl])
+    conv3d(p + "conv_out.0", nf[3], cfg.out_features, _DOWN["conv_out"][0], False)
+    bn(p + "conv_out.1", cfg.out_features)
+
+    # BaseBEVBackbone (base_bev_backbone.py:27-59)
+    p = "backbone_2d."
+    depth = 2  # sparse_shape z after conv_out for a 41-deep input; generic value computed by engine
+    c_in_list = [cfg.out_features * depth] + cfg.bev_num_filters[:-1]
+    for lvl in range(len(cfg.bev_layer_nums)):
+        c = cfg.bev_num_filters[lvl]
+        conv2d(p + "blocks.%d.1" % lvl, c_in_list[lvl], c, 3, False)
+        bn(p + "blocks.%d.2" % lvl, c)
+        for k in range(cfg.bev_layer_nums[lvl]):
+            conv2d(p + "blocks.%d.%d" % (lvl, 4 + 3 * k), c, c, 3, False)
+            bn(p + "blocks.%d.%d" % (lvl, 5 + 3 * k), c)
+        u = cfg.bev_upsample_strides[lvl]
+        conv2d(p + "deblocks.%d.0" % lvl, c, cfg.bev_num_upsample_filters[lvl], u, False, transposed=True)
+        bn(p + "deblocks.%d.1" % lvl, cfg.bev_num_upsample_filters[lvl])
+
+    # CenterHead (center_head.py:73-94, SeparateHead l.11-45; USE_BIAS_BEFORE_NORM True)
+    p = "dense_head."
+    c_cat = sum(cfg.bev_num_upsample_filters)
+    sc = cfg.shared_conv_channel
+    conv2d(p + "shared_conv.0", c_cat, sc, 3, True)
+    bn(p + "shared_conv.1", sc)
+    for name in cfg.head_names():
+        q = p + "heads_list.0.%s." % name
+        conv2d(q + "0.0", sc, sc, 3, True)
+        bn(q + "0.1", sc)
+        conv2d(q + "1", sc, cfg.head_out(name), 3, True)
+        if name == "hm":
+            sd[q + "1.bias"] = torch.full((cfg.num_class,), -2.19)   # center_head.py:30
+    return sd
+
+
+def _fold_bn(sd, bn_name, eps, conv_bias=None):
+    """Eval BatchNorm (+ preceding conv bias) as per-channel scale/shift."""
+    w, b = sd[bn_name + ".weight"].double(), sd[bn_name + ".bias"].double()
+    mean, var = sd[bn_name + ".running_mean"].double(), sd[bn_name + ".running_var"].double()
+    scale = w / torch.sqrt(var + eps)
+    shift = b - mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.double() * scale
+    return scale.float(), shift.float()
+
+
+class _Layer:
+    __slots__ = ("w", "kv", "c_in", "c_out", "scale", "shift", "relu")
+
+    def __init__(self, w_kio, scale, shift, relu, device):
+        w_kio = w_kio.to(device=device, dtype=torch.float32).contiguous()
+        self.kv, self.c_in, self.c_out = w_kio.shape
+        self.w = ops.pack_weight(w_kio)
+        self.scale = scale.to(device).contiguous() if scale is not None else None
+        self.shift = shift.to(device).contiguous() if shift is not None else None
+        self.relu = relu
+
+
+class CenterPointEngine:
+    """points [N, C] (device f32)  ->  {'pred_boxes','pred_scores','pred_labels'} per frame."""
+
+    SPARSE_BN_EPS = 1e-3   # spconv_backbone.py:410
+    BEV_BN_EPS = 1e-3      # base_bev_backbone.py:38
+    HEAD_BN_EPS = 1e-5     # nn.BatchNorm2d default, center_head.py:24,78
+
+    def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.sd = state_dict
+        self.voxelizer = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features,
+                                       cfg.max_points_per_voxel, cfg.max_voxels, device=self.device)
+        self._build_sparse()
+        self._bev_cache = {}
+        self._build_dense()
+
+    # ------------------------------------------------------------------ weights
+    def _sparse_w(self, name):
+        w = self.sd[name + ".weight"]                     # (Cout, kD, kH, kW, Cin)
+        cout, cin = w.shape[0], w.shape[-1]
+        return w.reshape(cout, -1, cin).permute(1, 2, 0)   # [kv, Cin, Cout]
+
+    def _build_sparse(self):
+        sd, dev, eps = self.sd, self.device, self.SPARSE_BN_EPS
+        p = "backbone_3d."
+        L = {}
+        s, t = _fold_bn(sd, p + "conv_input.1", eps)
+        L["conv_input"] = _Layer(self._sparse_w(p + "conv_input.0"), s, t, True, dev)
+
+        def block(name):
+            s1, t1 = _fold_bn(sd, name + ".bn1", eps, sd.get(name + ".conv1.bias"))
+            s2, t2 = _fold_bn(sd, name + ".bn2", eps, sd.get(name + ".conv2.bias"))
+            return (_Layer(self._sparse_w(name + ".conv1"), s1, t1, True, dev),
+                    _Layer(self._sparse_w(name + ".conv2"), s2, t2, True, dev))   # relu after the residual add
+
+        L["conv1"] = [block(p + "conv1.0"), block(p + "conv1.1")]
+        for stage in ["conv2", "conv3", "conv4"]:
+            s, t = _fold_bn(sd, p + stage + ".0.1", eps)
+            L[stage + ".down"] = _Layer(self._sparse_w(p + stage + ".0.0"), s, t, True, dev)
+            L[stage] = [block(p + stage + ".1"), block(p + stage + ".2")]
+        s, t = _fold_bn(sd, p + "conv_out.1", eps)
+        L["conv_out"] = _Layer(self._sparse_w(p + "conv_out.0"), s, t, True, dev)
+        self.sparse = L
+
+    def _build_dense(self):
+        cfg, sd, dev = self.cfg, self.sd, self.device
+        p = "backbone_2d."
+        depth = self._final_depth()
+        C = cfg.out_features
+        self.bev_levels = []
+        for lvl in range(len(cfg.bev_layer_nums)):
+            convs = []
+            names = ["blocks.%d.1" % lvl] + ["blocks.%d.%d" % (lvl, 4 + 3 * k) for k in range(cfg.bev_layer_nums[lvl])]
+            bns = ["blocks.%d.2" % lvl] + ["blocks.%d.%d" % (lvl, 5 + 3 * k) for k in range(cfg.bev_layer_nums[lvl])]
+            for i, (cn, bnn) in enumerate(zip(names, bns)):
+                w = sd[p + cn + ".weight"]                                   # (Cout, Cin, 3, 3)
+                if lvl == 0 and i == 0:
+                    # reference channel = c*D + z (height_compression.py:136-138); ours = z*C + c
+                    cout = w.shape[0]
+                    w = w.reshape(cout, C, depth, 3, 3).permute(0, 2, 1, 3, 4).reshape(cout, depth * C, 3, 3)
+                s, t = _fold_bn(sd, p + bnn, self.BEV_BN_EPS)
+                convs.append(_Layer(w.permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]), s, t, True, dev))
+            u = cfg.bev_upsample_strides[lvl]
+            wd = sd[p + "deblocks.%d.0.weight" % lvl]                        # (Cin, Cout, u, u)
+            s, t = _fold_bn(sd, p + "deblocks.%d.1" % lvl, self.BEV_BN_EPS)
+            cin, cout = wd.shape[0], wd.shape[1]
+            # ConvTranspose2d(k=s=u) = one 1x1 GEMM with the u*u taps stacked along the columns
+            w_kio = wd.permute(0, 2, 3, 1).reshape(1, cin, u * u * cout)
+            de = _Layer(w_kio, s.repeat(u * u), t.repeat(u * u), True, dev)
+            self.bev_levels.append((convs, de, u, cout))
+        p = "dense_head."
+        s, t = _fold_bn(sd, p + "shared_conv.1", self.HEAD_BN_EPS, sd.get(p + "shared_conv.0.bias"))
+        w = sd[p + "shared_conv.0.weight"]
+        self.shared = _Layer(w.permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]), s, t, True, dev)
+        # the five SeparateHead branches: first convs fused along Cout, second convs block-diagonal
+        names = cfg.head_names()
+        sc = cfg.shared_conv_channel
+        w1, s1, t1 = [], [], []
+        n_out = sum(cfg.head_out(n) for n in names)
+        w2 = torch.zeros(9, sc * len(names), n_out)
+        b2 = torch.zeros(n_out)
+        self.head_slices = {}
+        col = 0
+        for hi, name in enumerate(names):
+            q = p + "heads_list.0.%s." % name
+            w = sd[q + "0.0.weight"]
+            w1.append(w.permute(2, 3, 1, 0).reshape(9, sc, sc))
+            s, t = _fold_bn(sd, q + "0.1", self.HEAD_BN_EPS, sd.get(q + "0.0.bias"))
+            s1.append(s); t1.append(t)
+            wo = sd[q + "1.weight"]                                          # (co, sc, 3, 3)
+            co = wo.shape[0]
+            w2[:, hi * sc:(hi + 1) * sc, col:col + co] = wo.permute(2, 3, 1, 0).reshape(9, sc, co)
+            b2[col:col + co] = sd[q + "1.bias"]
+            self.head_slices[name] = (col, co)
+            col += co
+        self.head1 = _Layer(torch.cat(w1, dim=2), torch.cat(s1), torch.cat(t1), True, dev)
+        self.head2 = _Layer(w2, None, b2, False, dev)
+        self.head_ld = 16 * ((n_out + 15) // 16)
+
+    def _final_depth(self):
+        shape = self.cfg.sparse_shape
+        for stage in ["conv2", "conv3", "conv4", "conv_out"]:
+            k, s, pd = _DOWN[stage]
+            shape = ops.conv_out_shape(shape, k, s, pd)
+        return shape[0]
+
+    # ------------------------------------------------------------------ forward pieces
+    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0):
+        return ops.gather_conv(x, layer.c_in, layer.w, nbr, layer.kv, n_out, layer.c_out, layer.scale, layer.shift,
+                               residual, layer.relu, out=out, out_row_map=out_row_map, out_col_group=out_col_group)
+
+    def _blocks(self, blocks, x, nbr):
+        n = x.shape[0]
+        for c1, c2 in blocks:                      # SparseBasicBlock, spconv_backbone.py:120-136
+            y = self._conv(c1, x, nbr, n)
+            x = self._conv(c2, y, nbr, n, residual=x)
+        return x
+
+    def backbone3d(self, feats, coords, batch):
+        """VoxelResBackBone8x.forward (spconv_backbone.py:502-558). Returns per-level
+        {name: (features, indices, spatial_shape)} and the stride-8 output."""
+        L = self.sparse
+        shape = self.cfg.sparse_shape
+        index = ops.SiteIndex.build(coords, batch, shape)
+        nbr = ops.rulebook_subm(coords, index)               # 'subm1' and 'res1' are the same L0 table
+        x = self._conv(L["conv_input"], feats, nbr, coords.shape[0])
+        x = self._blocks(L["conv1"], x, nbr)
+        levels = {"x_conv1": (x, coords, shape)}
+        for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
+            k, s, pd = _DOWN[stage]
+            out_idx, out_index, out_shape = ops.conv_outset(coords, batch, shape, k, s, pd)
+            nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
+            x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0])
+            nbr = ops.rulebook_subm(out_idx, out_index)
+            x = self._blocks(L[stage], x, nbr)
+            coords, index, shape = out_idx, out_index, out_shape
+            levels["x_conv%d" % i] = (x, coords, shape)
+        k, s, pd = _DOWN["conv_out"]
+        out_idx, out_index, out_shape = ops.conv_outset(coords, batch, shape, k, s, pd)
+        nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
+        x = self._conv(L["conv_out"], x, nbr_dn, out_idx.shape[0])
+        return levels, (x, out_idx, out_shape)
+
+    def _bev_tables(self, batch, h, w):
+        key = (batch, h, w)
+        if key not in self._bev_cache:
+            dev = self.device
+            t = {}
+            t["s1"] = ops.rulebook_conv2d(batch, h, w, 3, 3, 1, 1, dev)
+            t["s2"] = ops.rulebook_conv2d(batch, h, w, 3, 3, 2, 1, dev)
+            h2, w2 = t["s2"][1], t["s2"][2]
+            t["s1_half"] = ops.rulebook_conv2d(batch, h2, w2, 3, 3, 1, 1, dev)
+            # ConvTranspose2d(k=s=2) destination rows: tap (a,b) of coarse pixel (y,x) -> (2y+a, 2x+b)
+            b_i = torch.arange(batch, device=dev).view(-1, 1, 1)
+            yy = torch.arange(h2, device=dev).view(1, -1, 1)
+            xx = torch.arange(w2, device=dev).view(1, 1, -1)
+            maps = []
+            for a in range(2):
+                for bb in range(2):
+                    maps.append(((b_i * h + 2 * yy + a) * w + 2 * xx + bb).reshape(-1))
+            t["up2"] = torch.stack(maps).to(torch.int32).contiguous()
+            self._bev_cache[key] = t
+        return self._bev_cache[key]
+
+    def bev_and_head(self, dense_rows, batch, h, w):
+        """BaseBEVBackbone.forward (base_bev_backbone.py:85-122) + CenterHead convs
+        (center_head.py:323-330) on channels-last rows [batch*h*w, C]."""
+        cfg = self.cfg
+        T = self._bev_tables(batch, h, w)
+        n_full = batch * h * w
+        c_cat = sum(cfg.bev_num_upsample_filters)
+        cat = torch.empty((n_full, c_cat), dtype=torch.float32, device=self.device)
+        x = dense_rows
+        col = 0
+        cur_h, cur_w = h, w
+        for lvl, (convs, de, u, c_up) in enumerate(self.bev_levels):
+            stride = cfg.bev_layer_strides[lvl]
+            if stride == 1:
+                nbr0, ho, wo = T["s1"] if (cur_h, cur_w) == (h, w) else T["s1_half"]
+            elif stride == 2 and (cur_h, cur_w) == (h, w):
+                nbr0, ho, wo = T["s2"]
+            else:
+                raise NotImplementedError("BEV stride pattern outside the shipped configs")
+            n_lvl = batch * ho * wo
+            x = self._conv(convs[0], x, nbr0, n_lvl)
+            nbr_same = T["s1"][0] if (ho, wo) == (h, w) else T["s1_half"][0]
+            for cv in convs[1:]:
+                x = self._conv(cv, x, nbr_same, n_lvl)
+            cur_h, cur_w = ho, wo
+            dst = cat[:, col:col + c_up]
+            if u == 1:
+                self._conv(de, x, None, n_lvl, out=dst)
+            elif u == 2 and (ho * 2, wo * 2) == (h, w):
+                self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up)
+            else:
+                raise NotImplementedError("upsample stride outside the shipped configs")
+            col += c_up
+        s = self._conv(self.shared, cat, T["s1"][0], n_full)
+        h1 = self._conv(self.head1, s, T["s1"][0], n_full)
+        out = torch.empty((n_full, self.head_ld), dtype=torch.float32, device=self.device)
+        self._conv(self.head2, h1, T["s1"][0], n_full, out=out)
+        return cat, out
+
+    def decode_and_nms(self, head_rows, batch, h, w):
+        """generate_predicted_boxes (center_head.py:252-303) + class_agnostic_nms
+        (model_nms_utils.py:115-134) per sample; everything stays on the device."""
+        cfg = self.cfg
+        ld = self.head_ld
+        results = []
+        for b in range(batch):
+            base = head_rows[b * h * w:(b + 1) * h * w]
+            sl = self.head_slices
+            boxes, scores, labels, n = ops.center_decode(
+                base[:, sl["hm"][0]:], base[:, sl["center"][0]:], base[:, sl["center_z"][0]:],
+                base[:, sl["dim"][0]:], base[:, sl["rot"][0]:], ld, 1, cfg.num_class, h, w,
+                cfg.max_obj_per_sample, float(cfg.feature_map_stride), cfg.voxel_size[:2],
+                cfg.point_cloud_range[:2], cfg.post_center_limit_range, cfg.score_thresh)
+            # scores are already sorted descending (top-K order survives the mask), so the
+            # topk(NMS_PRE_MAXSIZE) + sort inside nms_gpu are identities here
+            boxes, scores, labels = boxes[:cfg.nms_pre_maxsize], scores[:cfg.nms_pre_maxsize], labels[:cfg.nms_pre_maxsize]
+            keep = ops.nms(boxes, cfg.nms_thresh)[:cfg.nms_post_maxsize]
+            results.append({"pred_boxes": boxes[keep], "pred_scores": scores[keep],
+                            "pred_labels": labels[keep].long() + 1})
+        return results
+
+    # ------------------------------------------------------------------ whole frame(s)
+    @torch.no_grad()
+    def forward(self, points_list, return_intermediates=False):
+        """points_list: list of [N_i, C] device tensors (one per frame of the batch)."""
+        if isinstance(points_list, torch.Tensor):
+            points_list = [points_list]
+        batch = len(points_list)
+        feats, coords = [], []
+        for b, pts in enumerate(points_list):
+            _, c, _, mean, _ = self.voxelizer(pts, batch_idx=b, coord_cols=4, want_voxels=False, want_mean=True)
+            feats.append(mean)
+            coords.append(c)
+        feats = torch.cat(feats) if batch > 1 else feats[0]
+        coords = torch.cat(coords) if batch > 1 else coords[0]
+        levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch)
+        d, h, w = out_shape
+        dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
+        cat, head = self.bev_and_head(dense, batch, h, w)
+        results = self.decode_and_nms(head, batch, h, w)
+        if return_intermediates:
+            return results, dict(voxel_features=feats, voxel_coords=coords, levels=levels,
+                                 encoded=(x, out_idx, out_shape), spatial_features_nhwc=dense, bev_cat=cat,
+                                 head_rows=head)
+        return results
+
+    __call__ = forward

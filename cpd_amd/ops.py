@@ -1,0 +1,271 @@
+"""Tensor-level wrappers of the C-ABI (include/cpd_hip.h): allocate outputs / workspaces with torch,
+pass raw device pointers and the current HIP stream. PyTorch is plumbing here (device memory,
+streams); every computation happens in libcpd_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, farr, iarr, lib, ptr, stream
+
+
+def _dev(t):
+    return t.device
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.CpdHipError("%s must be a device (HIP) tensor" % name)
+
+
+# ---------------------------------------------------------------------------------------- B1
+def voxel_grid_size(vsize_xyz, range_xyz):
+    g = (ctypes.c_int32 * 3)()
+    check(lib().cpd_voxel_grid_size(farr(vsize_xyz), farr(range_xyz), g), "cpd_voxel_grid_size")
+    return [g[0], g[1], g[2]]
+
+
+class Voxelizer:
+    """Device voxelizer with a persistent workspace (sized for `max_points_in` points)."""
+
+    def __init__(self, vsize_xyz, range_xyz, num_point_features, max_points_per_voxel, max_voxels, device="cuda"):
+        self.vs = [float(v) for v in vsize_xyz]
+        self.rg = [float(v) for v in range_xyz]
+        self.c = int(num_point_features)
+        self.P = int(max_points_per_voxel)
+        self.max_voxels = int(max_voxels)
+        self.device = torch.device(device)
+        self.grid_zyx = voxel_grid_size(self.vs, self.rg)
+        self._ws = None
+        self._ws_n = -1
+
+    def _workspace(self, n):
+        if self._ws is None or n > self._ws_n:
+            nbytes = lib().cpd_voxelize_workspace_bytes(n, self.P, self.max_voxels, farr(self.vs), farr(self.rg))
+            if nbytes == 0:
+                raise _lib.CpdHipError("cpd_voxelize_workspace_bytes: unsupported geometry")
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_n = n
+        return self._ws
+
+    def __call__(self, points, batch_idx=0, coord_cols=4, want_voxels=True, want_mean=True, sync=True):
+        """points [N, C] f32 device tensor. Returns (voxels|None, coords, num_points, mean|None, n)
+        where n is a python int (sync=True, rows sliced) or the device scalar (sync=False, capacity
+        sized rows)."""
+        _need_cuda(points, "points")
+        points = points.contiguous()
+        n, c = points.shape
+        assert c == self.c and points.dtype == torch.float32
+        cap = max(1, min(self.max_voxels, n))
+        dev = points.device
+        voxels = torch.empty((cap, self.P, c), dtype=torch.float32, device=dev) if want_voxels else None
+        coords = torch.empty((cap, coord_cols), dtype=torch.int32, device=dev)
+        num = torch.empty((cap,), dtype=torch.int32, device=dev)
+        mean = torch.empty((cap, c), dtype=torch.float32, device=dev) if want_mean else None
+        nvox = torch.zeros((1,), dtype=torch.int32, device=dev)
+        ws = self._workspace(n)
+        check(lib().cpd_voxelize(ptr(points), n, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
+                                 int(batch_idx), int(coord_cols), ptr(voxels), ptr(coords), ptr(num), ptr(mean),
+                                 ptr(nvox), ptr(ws), ws.numel(), stream()), "cpd_voxelize")
+        if not sync:
+            return voxels, coords, num, mean, nvox
+        m = int(nvox.item())
+        return (voxels[:m] if voxels is not None else None, coords[:m], num[:m],
+                mean[:m] if mean is not None else None, m)
+
+
+# ---------------------------------------------------------------------------------------- B2
+class SiteIndex:
+    """Occupancy bitmap + popcount prefix of a site set (see csrc/site_index.hip)."""
+
+    def __init__(self, batch, shape_zyx, capacity, device):
+        self.batch = int(batch)
+        self.shape = [int(s) for s in shape_zyx]
+        nbytes = lib().cpd_index_bytes(self.batch, iarr(self.shape), int(capacity))
+        if nbytes == 0:
+            raise _lib.CpdHipError("cpd_index_bytes: unsupported grid %s x batch %d" % (self.shape, self.batch))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    @staticmethod
+    def build(indices, batch, shape_zyx):
+        _need_cuda(indices, "indices")
+        indices = indices.contiguous()
+        assert indices.dtype == torch.int32 and indices.shape[1] == 4
+        idx = SiteIndex(batch, shape_zyx, indices.shape[0], indices.device)
+        check(lib().cpd_index_build(ptr(indices), indices.shape[0], idx.batch, iarr(idx.shape), ptr(idx.buf),
+                                    idx.buf.numel(), stream()), "cpd_index_build")
+        return idx
+
+
+def rulebook_subm(indices, index, ksize=(3, 3, 3)):
+    indices = indices.contiguous()
+    n = indices.shape[0]
+    kv = int(ksize[0] * ksize[1] * ksize[2])
+    nbr = torch.empty((kv, n), dtype=torch.int32, device=indices.device)
+    check(lib().cpd_rulebook_subm(ptr(indices), n, index.batch, iarr(index.shape), iarr(ksize), ptr(index.buf),
+                                  ptr(nbr), stream()), "cpd_rulebook_subm")
+    return nbr
+
+
+def conv_out_shape(in_shape, ksize, stride, pad):
+    o = (ctypes.c_int32 * 3)()
+    check(lib().cpd_conv_out_shape(iarr(in_shape), iarr(ksize), iarr(stride), iarr(pad), o), "cpd_conv_out_shape")
+    return [o[0], o[1], o[2]]
+
+
+def conv_outset(in_indices, batch, in_shape, ksize, stride, pad):
+    """Active output sites of a SparseConv3d in canonical (b,z,y,x) order.
+    Returns (out_indices [n_out,4] i32, out_index SiteIndex, out_shape)."""
+    in_indices = in_indices.contiguous()
+    out_shape = conv_out_shape(in_shape, ksize, stride, pad)
+    out_index = SiteIndex(batch, out_shape, 0, in_indices.device)
+    n_out_dev = torch.zeros((1,), dtype=torch.int32, device=in_indices.device)
+    check(lib().cpd_conv_outset(ptr(in_indices), in_indices.shape[0], batch, iarr(in_shape), iarr(ksize),
+                                iarr(stride), iarr(pad), ptr(out_index.buf), out_index.buf.numel(), ptr(n_out_dev),
+                                stream()), "cpd_conv_outset")
+    n_out = int(n_out_dev.item())  # the one host sync of a strided layer: sizes the output tensors
+    out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=in_indices.device)
+    check(lib().cpd_index_emit(ptr(out_index.buf), batch, iarr(out_shape), ptr(out_indices), n_out, stream()),
+          "cpd_index_emit")
+    return out_indices, out_index, out_shape
+
+
+def rulebook_conv(out_indices, in_index, ksize, stride, pad):
+    out_indices = out_indices.contiguous()
+    n_out = out_indices.shape[0]
+    kv = int(ksize[0] * ksize[1] * ksize[2])
+    nbr = torch.empty((kv, n_out), dtype=torch.int32, device=out_indices.device)
+    check(lib().cpd_rulebook_conv(ptr(out_indices), n_out, in_index.batch, iarr(in_index.shape), iarr(ksize),
+                                  iarr(stride), iarr(pad), ptr(in_index.buf), ptr(nbr), stream()), "cpd_rulebook_conv")
+    return nbr
+
+
+def pack_weight(w_kio):
+    """w_kio: [kv, c_in, c_out] f32 device tensor -> packed MFMA-fragment weights."""
+    _need_cuda(w_kio, "weight")
+    w_kio = w_kio.contiguous().float()
+    kv, cin, cout = w_kio.shape
+    packed = torch.empty((lib().cpd_packed_weight_floats(kv, cin, cout),), dtype=torch.float32, device=w_kio.device)
+    check(lib().cpd_pack_weight(ptr(w_kio), kv, cin, cout, ptr(packed), stream()), "cpd_pack_weight")
+    return packed
+
+
+def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=None, residual=None, relu=False,
+                out=None, out_row_map=None, out_col_group=0):
+    """out[j,:c_out] = act((sum_t in[nbr[t][j]] . W[t]) * scale + shift + residual[j]).
+    `inp` / `out` / `residual` are 2-D row tensors whose row stride may exceed the channel count."""
+    _need_cuda(inp, "inp")
+    assert inp.dim() == 2 and inp.stride(1) == 1
+    if out is None:
+        out = torch.empty((n_out, c_out), dtype=torch.float32, device=inp.device)
+    assert out.dim() == 2 and out.stride(1) == 1
+    res_ld = 0
+    if residual is not None:
+        assert residual.dim() == 2 and residual.stride(1) == 1
+        res_ld = residual.stride(0)
+    check(lib().cpd_gather_conv(
+        ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w),
+        ptr(nbr), kv, n_out, c_out, ptr(scale), ptr(shift),
+        ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
+        ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), stream()),
+        "cpd_gather_conv")
+    return out
+
+
+def densify_nchw(feat, indices, batch, shape_zyx):
+    feat = feat.contiguous()
+    n, c = feat.shape
+    out = torch.empty((batch, c * shape_zyx[0], shape_zyx[1], shape_zyx[2]), dtype=torch.float32, device=feat.device)
+    check(lib().cpd_densify_nchw(ptr(feat), ptr(indices.contiguous()), n, c, batch, iarr(shape_zyx), ptr(out),
+                                 stream()), "cpd_densify_nchw")
+    return out
+
+
+def densify_nhwc(feat, indices, batch, shape_zyx, out=None):
+    feat = feat.contiguous()
+    n, c = feat.shape
+    if out is None:
+        out = torch.empty((batch, shape_zyx[1], shape_zyx[2], shape_zyx[0] * c), dtype=torch.float32,
+                          device=feat.device)
+    check(lib().cpd_densify_nhwc(ptr(feat), ptr(indices.contiguous()), n, c, batch, iarr(shape_zyx), ptr(out),
+                                 stream()), "cpd_densify_nhwc")
+    return out
+
+
+def rulebook_conv2d(batch, h, w, kh, kw, stride, pad, device):
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (w + 2 * pad - kw) // stride + 1
+    nbr = torch.empty((kh * kw, batch * ho * wo), dtype=torch.int32, device=device)
+    check(lib().cpd_rulebook_conv2d(batch, h, w, kh, kw, stride, pad, ptr(nbr), stream()), "cpd_rulebook_conv2d")
+    return nbr, ho, wo
+
+
+# ------------------------------------------------------------------------------------ decode
+def center_decode(hm, center, center_z, dim, rot, pix_stride, ch_stride, num_class, h, w, k, feature_map_stride,
+                  voxel_xy, range_lo_xy, limit_range, score_thresh, sync=True):
+    dev = hm.device
+    boxes = torch.empty((k, 7), dtype=torch.float32, device=dev)
+    scores = torch.empty((k,), dtype=torch.float32, device=dev)
+    labels = torch.empty((k,), dtype=torch.int32, device=dev)
+    n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty(lib().cpd_center_decode_workspace_bytes(num_class, h * w, k), dtype=torch.uint8, device=dev)
+    check(lib().cpd_center_decode(
+        ctypes.c_void_p(hm.data_ptr()), ctypes.c_void_p(center.data_ptr()), ctypes.c_void_p(center_z.data_ptr()),
+        ctypes.c_void_p(dim.data_ptr()), ctypes.c_void_p(rot.data_ptr()), pix_stride, ch_stride, num_class, h, w, k,
+        float(feature_map_stride), farr(voxel_xy), farr(range_lo_xy), farr(limit_range), float(score_thresh),
+        ptr(boxes), ptr(scores), ptr(labels), ptr(n_out), ptr(ws), ws.numel(), stream()), "cpd_center_decode")
+    if not sync:
+        return boxes, scores, labels, n_out
+    n = int(n_out.item())
+    return boxes[:n], scores[:n], labels[:n], n
+
+
+# ---------------------------------------------------------------------------------------- B3
+def _pairwise(fn, name, a, b):
+    _need_cuda(a, "boxes_a")
+    a = a.contiguous().float()
+    b = b.contiguous().float()
+    assert a.shape[1] == 7 and b.shape[1] == 7
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(fn(ptr(a), a.shape[0], ptr(b), b.shape[0], ptr(out), stream()), name)
+    return out
+
+
+def boxes_overlap_bev(a, b):
+    return _pairwise(lib().cpd_boxes_overlap_bev, "cpd_boxes_overlap_bev", a, b)
+
+
+def boxes_iou_bev(a, b):
+    return _pairwise(lib().cpd_boxes_iou_bev, "cpd_boxes_iou_bev", a, b)
+
+
+def boxes_iou3d(a, b):
+    return _pairwise(lib().cpd_boxes_iou3d, "cpd_boxes_iou3d", a, b)
+
+
+def nms(boxes_sorted, thresh, normal=False, sync=True):
+    """boxes sorted by descending score. Returns kept row ids (device i64 [num]) (sync=True) or
+    (keep [n], num_keep [1]) device tensors."""
+    _need_cuda(boxes_sorted, "boxes")
+    boxes_sorted = boxes_sorted.contiguous().float()
+    n = boxes_sorted.shape[0]
+    dev = boxes_sorted.device
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    num = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty(lib().cpd_nms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    fn = lib().cpd_nms_normal if normal else lib().cpd_nms_rotated
+    check(fn(ptr(boxes_sorted), n, float(thresh), ptr(keep), ptr(num), ptr(ws), ws.numel(), stream()), "cpd_nms")
+    if not sync:
+        return keep, num
+    return keep[:int(num.item())]
+
+
+def boxes_iou_bev_cpu(a, b):
+    """Host tensors (iou3d_nms_utils.boxes_bev_iou_cpu contract)."""
+    a = a.contiguous().float()
+    b = b.contiguous().float()
+    assert not a.is_cuda and not b.is_cuda
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32)
+    check(lib().cpd_boxes_iou_bev_cpu(ptr(a), a.shape[0], ptr(b), b.shape[0], ptr(out)), "cpd_boxes_iou_bev_cpu")
+    return out

@@ -1,0 +1,185 @@
+/*
+ * cpd_hip.h -- C-ABI of libcpd_hip.so: the MI355X (gfx950) implementation of CPD's detection
+ * hot path  voxelize -> sparse 3D conv backbone -> BEV dense head -> rotated NMS.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types. Every DATA pointer is
+ * a DEVICE pointer unless its comment says HOST; small geometry arrays (voxel size, ranges,
+ * shapes, kernel/stride/pad triples) are HOST arrays read at call time. All functions enqueue on
+ * `stream` (a hipStream_t passed as void*) and return without synchronising unless stated. They
+ * never allocate device memory and never call exit(): workspaces are caller-owned (size queries
+ * below) so a whole frame can be captured into a hipGraph. Return value: CPD_OK (0) or a
+ * negative CPD_ERR_* code (the reference's exit(-1) CHECK_INPUT macros, iou3d_nms.cpp:14-26,
+ * become error codes; the Python shim turns them into exceptions).
+ *
+ * Each entry point cites the reference interface it replaces (path:line under /root/reference;
+ * [SPCONV] = behaviour of the un-vendored dependency spconv-cu111==2.1.22 as used at that call
+ * site). INTEGRATION.md shows the reference-side binding for each.
+ */
+#ifndef CPD_HIP_H
+#define CPD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *cpd_stream_t; /* hipStream_t; NULL = the default stream, as the reference uses */
+
+#define CPD_OK 0
+#define CPD_ERR_ARG (-1)         /* bad argument (null pointer, non-positive size, bad shape) */
+#define CPD_ERR_WORKSPACE (-2)   /* caller workspace smaller than the *_bytes() query         */
+#define CPD_ERR_LAUNCH (-3)      /* HIP runtime reported an error; see cpd_last_hip_error()   */
+#define CPD_ERR_UNSUPPORTED (-4) /* size outside the supported envelope (e.g. >2^31 cells)    */
+
+const char *cpd_version(void);
+int cpd_last_hip_error(void); /* hipError_t of the last CPD_ERR_LAUNCH on this thread */
+
+/* ===== B1. Voxelizer (+ fused MeanVFE) =====================================================
+ * Replaces VoxelGeneratorWrapper.generate -> [SPCONV] Point2VoxelCPU3d.point_to_voxel
+ * (cpd/datasets/processor/data_processor.py:14-59, driver l.128-183) and MeanVFE.forward
+ * (cpd/models/backbones_3d/vfe/mean_vfe.py:41-43).
+ * Semantics: serial first-appearance voxel order, first `max_points` points of a voxel in
+ * point order, fp32 floor((p-lo)/vs), upper bound exclusive, voxel cap `max_voxels`.
+ */
+/* grid = round((hi-lo)/vs) in fp32, returned (z,y,x). HOST in, HOST out. */
+int cpd_voxel_grid_size(const float vsize_xyz[3], const float range_xyz[6], int32_t grid_zyx[3]);
+size_t cpd_voxelize_workspace_bytes(int n_points, int max_points, int max_voxels,
+                                    const float vsize_xyz[3], const float range_xyz[6]);
+/* points [n_points, c] f32 (x,y,z,...). Outputs sized for cap = min(max_voxels, n_points) rows:
+ *   voxels        [cap, max_points, c] f32, zero padded            (may be NULL)
+ *   coords        [cap, coord_cols] i32; coord_cols 3 -> (z,y,x), 4 -> (batch_idx,z,y,x)
+ *                 (the pad of collate_batch, cpd/datasets/dataset.py:264)
+ *   num_points    [cap] i32
+ *   mean_features [cap, c] f32 = sum_p voxels / max(num,1)         (may be NULL)
+ *   n_voxels      device i32 scalar                                                         */
+int cpd_voxelize(const float *points, int n_points, int c, const float vsize_xyz[3],
+                 const float range_xyz[6], int max_points, int max_voxels, int batch_idx,
+                 int coord_cols, float *voxels, int32_t *coords, int32_t *num_points,
+                 float *mean_features, int32_t *n_voxels, void *workspace, size_t workspace_bytes,
+                 cpd_stream_t stream);
+
+/* ===== B2. Sparse convolution ==============================================================
+ * Replaces [SPCONV] SparseConvTensor / SubMConv3d / SparseConv3d / .dense() as called from
+ * cpd/models/backbones_3d/spconv_backbone.py:17-21,108-115,414-455,524-529 and
+ * cpd/models/backbones_2d/map_to_bev/height_compression.py:136-138.
+ *
+ * Site index: a dense occupancy bitmap over (batch, z, y, x) plus a popcount prefix, giving
+ * coordinate -> row lookup and, for free, the canonical ascending (b,z,y,x) order of a site set.
+ * Rulebook: output-stationary neighbour table nbr[kv][n_out] (i32, -1 = no input), tap index
+ * t = (tz*kH + ty)*kW + tx as in the spconv-2.x weight layout (Cout,kD,kH,kW,Cin). The same
+ * table is the `indice_dict` entry a SparseConvTensor caches per indice_key.
+ */
+size_t cpd_index_bytes(int batch, const int32_t shape_zyx[3], int n_capacity);
+/* Build the index of `indices` [n,4] i32 (b,z,y,x) (any order; row ids = positions). */
+int cpd_index_build(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3],
+                    void *index, size_t index_bytes, cpd_stream_t stream);
+/* SubMConv3d rulebook: output set == input set, same order; tap t reads coord + t - k/2. */
+int cpd_rulebook_subm(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3],
+                      const int32_t ksize[3], const void *index, int32_t *nbr,
+                      cpd_stream_t stream);
+/* out_shape = (in + 2*pad - k)/stride + 1. HOST only. */
+int cpd_conv_out_shape(const int32_t in_shape[3], const int32_t ksize[3], const int32_t stride[3],
+                       const int32_t pad[3], int32_t out_shape[3]);
+/* SparseConv3d output set: marks every output coordinate reached by an active input, builds the
+ * OUTPUT site index in `out_index` (sized by cpd_index_bytes(batch, out_shape, capacity)) and
+ * writes the number of active outputs to the device scalar n_out.                           */
+int cpd_conv_outset(const int32_t *in_indices, int n_in, int batch, const int32_t in_shape[3],
+                    const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3],
+                    void *out_index, size_t out_index_bytes, int32_t *n_out, cpd_stream_t stream);
+/* Write the index's sites as [n,4] i32 rows in canonical ascending (b,z,y,x) order. */
+int cpd_index_emit(const void *index, int batch, const int32_t shape_zyx[3], int32_t *indices,
+                   int n_capacity, cpd_stream_t stream);
+/* SparseConv3d rulebook: nbr[t][o] = input row at o*stride - pad + t. */
+int cpd_rulebook_conv(const int32_t *out_indices, int n_out, int batch, const int32_t in_shape[3],
+                      const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3],
+                      const void *in_index, int32_t *nbr, cpd_stream_t stream);
+
+/* Weights for cpd_gather_conv: pack a dense [kv][c_in][c_out] f32 tensor (device) into the
+ * MFMA-fragment order the kernel streams (zero padded to multiples of 16).                   */
+size_t cpd_packed_weight_floats(int kv, int c_in, int c_out);
+int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *packed,
+                    cpd_stream_t stream);
+/* The one GEMM-shaped kernel of the path (fp32 MFMA, exact fp32 fma chain):
+ *   out[j, :] = act( (sum_t W[t]^T . in[nbr[t][j], :]) * scale + shift + residual[j, :] )
+ * Used for SubMConv3d / SparseConv3d (rulebook from above, bias/eval-BatchNorm1d folded into
+ * scale/shift, SparseBasicBlock residual + ReLU fused: spconv_backbone.py:100-136) and, with a
+ * dense pixel rulebook, for every Conv2d/ConvTranspose2d(+BN+ReLU) of BaseBEVBackbone
+ * (cpd/models/backbones_2d/base_bev_backbone.py:31-59) and CenterHead
+ * (cpd/models/dense_heads/center_head.py:21-27,73-80) on channels-last maps.
+ *   in   [n_in rows, in_ld floats per row], first c_in floats of a row are the features
+ *   nbr  [kv][n_out] or NULL (kv must be 1: identity, i.e. a 1x1 conv / linear layer)
+ *   scale, shift [c_out] or NULL (1 / 0); residual [n_out, res_ld] or NULL; relu 0/1
+ *   out  [n_out, out_ld]; only columns [0, c_out) of each row are written
+ *   out_row_map: NULL, or i32 destination rows. With out_col_group == 0 it is [n_out]: row j
+ *                is written to row out_row_map[j]. With out_col_group = G > 0 the c_out columns
+ *                are G-wide groups: column c of row j goes to row out_row_map[(c/G)*n_out + j],
+ *                column c % G -- one launch computes the k*k taps of ConvTranspose2d(k, s=k)
+ *                (base_bev_backbone.py:52-56) and interleaves them into the upsampled map.   */
+int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float *packed_w,
+                    const int32_t *nbr, int kv, int n_out, int c_out, const float *scale,
+                    const float *shift, const float *residual, int res_ld, int relu, float *out,
+                    int out_ld, const int32_t *out_row_map, int out_col_group, cpd_stream_t stream);
+
+/* SparseConvTensor.dense() + view(N, C*D, H, W) (height_compression.py:136-138).
+ *   nchw: out (B, C*D, H, W), channel = c*D + z   -- the reference layout
+ *   nhwc: out (B, H, W, D*C), channel = z*C + c   -- channels-last, feeds cpd_gather_conv
+ * Both zero-fill `out` themselves.                                                           */
+int cpd_densify_nchw(const float *feat, const int32_t *indices, int n, int c, int batch,
+                     const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
+int cpd_densify_nhwc(const float *feat, const int32_t *indices, int n, int c, int batch,
+                     const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
+/* Dense-pixel rulebooks for the BEV convs: nbr[kh*kw][ho*wo*batch] for a (kh x kw, stride, pad)
+ * Conv2d over a (batch, h, w) channels-last map. */
+int cpd_rulebook_conv2d(int batch, int h, int w, int kh, int kw, int stride, int pad,
+                        int32_t *nbr, cpd_stream_t stream);
+
+/* ===== CenterHead decode ===================================================================
+ * Replaces CenterHead.generate_predicted_boxes (center_head.py:252-303) ->
+ * centernet_utils.decode_bbox_from_heatmap / _topk (centernet_utils.py:136-216) for one sample:
+ * sigmoid(hm), exp(dim), per-class top-K then top-K over classes, gather, atan2(sin,cos),
+ * centre scaling, POST_CENTER_LIMIT_RANGE and SCORE_THRESH masks, order-preserving compaction.
+ * Head maps are addressed as map[pixel*pix_stride + channel*ch_stride] so both the reference's
+ * NCHW planes and this library's channels-last rows can be decoded in place.
+ * Outputs (capacity K): boxes [K,7] (x,y,z,dx,dy,dz,heading), scores [K], labels [K] i32
+ * (0-based class id), n_out device scalar.                                                   */
+size_t cpd_center_decode_workspace_bytes(int num_class, int hw, int k);
+int cpd_center_decode(const float *hm, const float *center, const float *center_z,
+                      const float *dim, const float *rot, int pix_stride, int ch_stride,
+                      int num_class, int h, int w, int k, float feature_map_stride,
+                      const float voxel_xy[2], const float range_lo_xy[2],
+                      const float limit_range[6], float score_thresh, float *boxes, float *scores,
+                      int32_t *labels, int32_t *n_out, void *workspace, size_t workspace_bytes,
+                      cpd_stream_t stream);
+
+/* ===== B3. iou3d_nms =======================================================================
+ * Replaces the iou3d_nms_cuda extension (cpd/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17).
+ * Boxes are [n,7] f32 (x,y,z,dx,dy,dz,heading), contiguous.                                  */
+/* boxes_overlap_bev_gpu (iou3d_nms.cpp:49-68): out[n,m] rotated BEV intersection area. */
+int cpd_boxes_overlap_bev(const float *a, int n, const float *b, int m, float *out,
+                          cpd_stream_t stream);
+/* boxes_iou_bev_gpu (iou3d_nms.cpp:70-88): out[n,m] rotated BEV IoU. */
+int cpd_boxes_iou_bev(const float *a, int n, const float *b, int m, float *out,
+                      cpd_stream_t stream);
+/* boxes_iou3d_gpu (iou3d_nms_utils.py:67-100) fused: BEV overlap x height overlap / union. */
+int cpd_boxes_iou3d(const float *a, int n, const float *b, int m, float *out,
+                    cpd_stream_t stream);
+/* nms_gpu / nms_normal_gpu (iou3d_nms.cpp:90-137,139-186): boxes sorted by descending score.
+ * The 64x64 bitmask (iou3d_nms_kernel.cu:267-311) AND the greedy scan run on the device; keep
+ * [n] i64 and num_keep (i32 scalar) are DEVICE buffers -- the reference's blocking D2H copy of
+ * the whole mask is gone; the shim copies keep[:num] back to satisfy the CPU-`keep` contract. */
+size_t cpd_nms_workspace_bytes(int n);
+int cpd_nms_rotated(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
+                    void *workspace, size_t workspace_bytes, cpd_stream_t stream);
+int cpd_nms_normal(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
+                   void *workspace, size_t workspace_bytes, cpd_stream_t stream);
+/* boxes_iou_bev_cpu (iou3d_cpu.cpp:232-252): HOST pointers, runs on the calling thread. This is
+ * the one CPU entry point the reference extension itself exports (used by the dataloader's
+ * gt-sampling, database_sampler.py:445-446); it is product code, not the test oracle.        */
+int cpd_boxes_iou_bev_cpu(const float *a, int n, const float *b, int m, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPD_HIP_H */

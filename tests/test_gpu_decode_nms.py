@@ -1,0 +1,104 @@
+"""CenterHead decode and B3 (iou3d_nms) parity on the GPU against the reference goldens and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from cpd_amd import iou3d_nms_utils, ops
+from cpd_amd.synthetic import random_boxes
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_decode_matches_reference_golden(hip, golden):
+    g = golden("decode")
+    K = int(g["K"])
+    hm, center, cz, dim, rot = (dev(g[k][0]) for k in ("hm", "center", "center_z", "dim", "rot"))
+    nc, h, w = hm.shape
+    boxes, scores, labels, n = ops.center_decode(hm, center, cz, dim, rot, 1, h * w, nc, h, w, K, float(g["stride"]),
+                                                 g["vs"][:2], g["pcr"][:2], g["limit"], float(g["score_thresh"]))
+    assert n == g["boxes"].shape[0]
+    np.testing.assert_array_equal(labels.cpu().numpy(), g["labels"])
+    np.testing.assert_allclose(scores.cpu().numpy(), g["scores"], atol=1e-6)
+    np.testing.assert_allclose(boxes.cpu().numpy(), g["boxes"], atol=1e-5, rtol=1e-5)
+
+
+def test_decode_channels_last_and_full_size(oracle, hip):
+    """188x188 maps, K=500, channels-last rows exactly as the engine lays the head output out."""
+    rng = np.random.default_rng(12)
+    h = w = 188
+    K = 500
+    rows = rng.normal(size=(h * w, 16)).astype(np.float32)
+    rows[:, 8:11] = rows[:, 8:11] * 2.0 - 1.0
+    sl = dict(center=0, center_z=2, dim=3, rot=6, hm=8)
+    t = dev(rows)
+    pcr, vs = [-75.2, -75.2, -2, 75.2, 75.2, 4], [0.1, 0.1, 0.15]
+    boxes, scores, labels, n = ops.center_decode(t[:, 8:], t[:, 0:], t[:, 2:], t[:, 3:], t[:, 6:], 16, 1, 3, h, w, K, 8.0,
+                                                 vs[:2], pcr[:2], pcr, 0.1)
+    planes = rows.T.reshape(16, h, w)
+    b0, s0, l0 = oracle.center_decode(planes[8:11], planes[0:2], planes[2:3], planes[3:6], planes[6:8], K, 8.0, vs[:2],
+                                      pcr[:2], pcr, 0.1)
+    assert n == b0.shape[0] and n > 100
+    np.testing.assert_array_equal(labels.cpu().numpy(), l0)
+    np.testing.assert_allclose(scores.cpu().numpy(), s0, atol=1e-6)
+    np.testing.assert_allclose(boxes.cpu().numpy(), b0, atol=1e-4, rtol=1e-5)
+    assert (np.diff(scores.cpu().numpy()) <= 0).all()          # sortedness property
+
+
+def finite_close(got, want, atol):
+    m = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), m)
+    np.testing.assert_allclose(got[m], want[m], atol=atol, rtol=0)
+
+
+def test_iou_matrices_match_reference_golden(oracle, hip, golden):
+    g = golden("iou_bev")
+    a, b = dev(g["a"]), dev(g["b"])
+    np.testing.assert_allclose(ops.boxes_iou_bev(a, b).cpu().numpy(), g["iou_ab"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(ops.boxes_overlap_bev(a, b).cpu().numpy(), oracle.boxes_overlap_bev(g["a"], g["b"]), atol=1e-4)
+    np.testing.assert_allclose(ops.boxes_iou3d(a, b).cpu().numpy(), oracle.boxes_iou3d(g["a"], g["b"]), atol=1e-4)
+    np.testing.assert_allclose(iou3d_nms_utils.boxes_iou3d_gpu(a, b).cpu().numpy(), oracle.boxes_iou3d(g["a"], g["b"]), atol=1e-4)
+    adv = dev(g["adv"])
+    finite_close(ops.boxes_iou_bev(adv, adv).cpu().numpy(), g["iou_adv"], 1e-4)
+    # the CPU entry point of the extension (boxes_bev_iou_cpu)
+    np.testing.assert_allclose(iou3d_nms_utils.boxes_bev_iou_cpu(g["a"], g["b"]), g["iou_ab"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["n64", "n500", "n500_t3", "n1000_t1"])
+def test_nms_matches_reference_golden(hip, golden, tag):
+    """class_agnostic_nms semantics (model_nms_utils.py:115-134) through the iou3d_nms_utils mirror."""
+    g = golden("nms")
+    boxes, scores, thr = dev(g[tag + ".boxes"]), dev(g[tag + ".scores"]), float(g[tag + ".thr"])
+    s_top, idx = torch.topk(scores, k=min(4096, scores.shape[0]))
+    keep, _ = iou3d_nms_utils.nms_gpu(boxes[idx][:, 0:7], s_top, thr)
+    sel = idx[keep[:500]]
+    np.testing.assert_array_equal(sel.cpu().numpy(), g[tag + ".selected"])
+
+
+@pytest.mark.parametrize("n,thr", [(1, 0.5), (63, 0.3), (64, 0.3), (65, 0.3), (500, 0.8), (4096, 0.7)])
+def test_nms_rotated_and_normal_vs_oracle(oracle, hip, n, thr):
+    b, s = random_boxes(n, n, span=max(8.0, n ** 0.5 * 1.5))
+    order = np.argsort(-s, kind="stable")
+    bs = b[order]
+    iou = oracle.boxes_iou_bev(bs, bs)
+    if np.any(np.abs(iou[np.triu_indices(n, 1)] - thr) < 2e-4):
+        pytest.skip("borderline IoU in this random set")
+    np.testing.assert_array_equal(ops.nms(dev(bs), thr).cpu().numpy(), oracle.nms(bs, thr))
+    np.testing.assert_array_equal(ops.nms(dev(bs), thr, normal=True).cpu().numpy(), oracle.nms_normal(bs, thr))
+    # idempotence: NMS of the survivors keeps everything
+    kept = bs[oracle.nms(bs, thr)]
+    assert ops.nms(dev(kept), thr).shape[0] == kept.shape[0]
+    # extension-shaped entry point with the CPU `keep` contract (iou3d_nms.cpp:90-137)
+    from cpd_amd import iou3d_nms_cuda
+    keep = torch.LongTensor(n)
+    num = iou3d_nms_cuda.nms_gpu(dev(bs), keep, thr)
+    np.testing.assert_array_equal(keep[:num].numpy(), oracle.nms(bs, thr))
+
+
+def test_empty_inputs(hip):
+    e = torch.zeros((0, 7), device="cuda")
+    assert ops.nms(e, 0.5).shape[0] == 0
+    assert ops.boxes_iou_bev(e, torch.zeros((3, 7), device="cuda")).shape == (0, 3)

@@ -1,0 +1,165 @@
+"""B2 parity on the GPU: site index, SubM / regular rulebooks (bit-exact incl. canonical order),
+sparse conv through the fp32-MFMA gather kernel (<= 1e-4), densify (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from cpd_amd import ops
+from cpd_amd.synthetic import KITTI, WAYMO, kitti_cloud, waymo_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype else t
+
+
+def random_sites(rng, batch, shape, n):
+    cells = batch * shape[0] * shape[1] * shape[2]
+    lin = rng.choice(cells, size=min(n, cells), replace=False)
+    b, r = np.divmod(lin, shape[0] * shape[1] * shape[2])
+    z, r = np.divmod(r, shape[1] * shape[2])
+    y, x = np.divmod(r, shape[2])
+    return np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+def voxel_coords(oracle, cfg, pts):
+    _, c, _ = oracle.voxelize(pts, cfg["voxel_size"], cfg["point_cloud_range"], 5, cfg["max_voxels"])
+    return np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+
+
+def sparse_shape(cfg):
+    g = ops.voxel_grid_size(cfg["voxel_size"], cfg["point_cloud_range"])
+    return [g[0] + 1, g[1], g[2]]
+
+
+@pytest.mark.parametrize("batch,shape,n", [(2, [7, 33, 65], 3000), (1, [41, 200, 176], 20000), (3, [5, 64, 64], 61440)])
+def test_subm_rulebook_bit_exact(oracle, hip, batch, shape, n):
+    rng = np.random.default_rng(n)
+    idx = random_sites(rng, batch, shape, n)
+    index = ops.SiteIndex.build(dev(idx), batch, shape)
+    nbr = ops.rulebook_subm(dev(idx), index).cpu().numpy()
+    np.testing.assert_array_equal(nbr, oracle.subm_rulebook(idx, batch, shape, [3, 3, 3]))
+
+
+@pytest.mark.parametrize("ksize,stride,pad", [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1]),
+                                              ([3, 1, 1], [2, 1, 1], [0, 0, 0])])
+def test_regular_conv_rulebook_bit_exact(oracle, hip, ksize, stride, pad):
+    rng = np.random.default_rng(11)
+    batch, shape = 2, [11, 40, 52]
+    idx = random_sites(rng, batch, shape, 6000)
+    out_idx, out_index, out_shape = ops.conv_outset(dev(idx), batch, shape, ksize, stride, pad)
+    want_idx = oracle.conv_outset(idx, batch, shape, ksize, stride, pad)
+    np.testing.assert_array_equal(out_idx.cpu().numpy(), want_idx)        # canonical (b,z,y,x) order
+    assert out_shape == oracle.conv_out_shape(shape, ksize, stride, pad)
+    index = ops.SiteIndex.build(dev(idx), batch, shape)
+    nbr = ops.rulebook_conv(out_idx, index, ksize, stride, pad).cpu().numpy()
+    np.testing.assert_array_equal(nbr, oracle.conv_rulebook(idx, want_idx, batch, shape, ksize, stride, pad))
+    # SubM on the canonical output list (perm unused path)
+    nbr2 = ops.rulebook_subm(out_idx, out_index).cpu().numpy()
+    np.testing.assert_array_equal(nbr2, oracle.subm_rulebook(want_idx, batch, out_shape, [3, 3, 3]))
+
+
+def test_waymo_level_chain_bit_exact(oracle, hip):
+    """Config W: the whole indice chain L0 -> L4 of VoxelResBackBone8x on the 160k cloud."""
+    idx = voxel_coords(oracle, WAYMO, waymo_cloud(0))
+    shape = sparse_shape(WAYMO)
+    assert shape == [41, 1504, 1504]
+    d_idx = dev(idx)
+    index = ops.SiteIndex.build(d_idx, 1, shape)
+    np.testing.assert_array_equal(ops.rulebook_subm(d_idx, index).cpu().numpy(),
+                                  oracle.subm_rulebook(idx, 1, shape, [3, 3, 3]))
+    cur, cur_d, cur_index = idx, d_idx, index
+    for k, s, p in [([3, 3, 3], [2, 2, 2], [1, 1, 1])] * 2 + [([3, 3, 3], [2, 2, 2], [0, 1, 1]), ([3, 1, 1], [2, 1, 1], [0, 0, 0])]:
+        o_d, o_index, o_shape = ops.conv_outset(cur_d, 1, shape, k, s, p)
+        want = oracle.conv_outset(cur, 1, shape, k, s, p)
+        np.testing.assert_array_equal(o_d.cpu().numpy(), want)
+        np.testing.assert_array_equal(ops.rulebook_conv(o_d, cur_index, k, s, p).cpu().numpy(),
+                                      oracle.conv_rulebook(cur, want, 1, shape, k, s, p))
+        cur, cur_d, cur_index, shape = want, o_d, o_index, o_shape
+    assert shape == [2, 188, 188]
+
+
+def run_conv(feat, w, nbr, scale=None, shift=None, residual=None, relu=False):
+    cout, cin = w.shape[0], w.shape[-1]
+    w_kio = torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda()
+    packed = ops.pack_weight(w_kio)
+    out = ops.gather_conv(dev(feat), cin, packed, dev(nbr), nbr.shape[0], nbr.shape[1], cout,
+                          dev(scale) if scale is not None else None, dev(shift) if shift is not None else None,
+                          dev(residual) if residual is not None else None, relu)
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("cin,cout", [(5, 16), (4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
+def test_subm_conv_matches_oracle(oracle, hip, cin, cout):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    batch, shape = 2, [9, 40, 40]
+    idx = random_sites(rng, batch, shape, 5000)
+    feat = rng.normal(size=(idx.shape[0], cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32) * 0.1
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    nbr = oracle.subm_rulebook(idx, batch, shape, [3, 3, 3])
+    raw = oracle.sparse_conv(feat, w, bias, nbr)
+    # plain conv + bias (the un-fused module path)
+    np.testing.assert_allclose(run_conv(feat, w, nbr, None, bias), raw, atol=1e-4, rtol=0)
+    # fused BN-affine + residual + ReLU (SparseBasicBlock tail); residual needs cin == cout
+    res = feat if cin == cout else None
+    want = oracle.affine_rows(oracle.sparse_conv(feat, w, None, nbr), scale, bias, res, True)
+    np.testing.assert_allclose(run_conv(feat, w, nbr, scale, bias, res, True), want, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("ms,nt", [(1, 1), (1, 4), (2, 2), (2, 4), (2, 8), (4, 1), (4, 4), (4, 8), (1, 8)])
+def test_every_tile_shape_gives_the_same_conv(oracle, hip, ms, nt, monkeypatch):
+    rng = np.random.default_rng(77)
+    batch, shape, cin, cout = 1, [6, 30, 30], 32, 128
+    idx = random_sites(rng, batch, shape, 1500)
+    feat = rng.normal(size=(idx.shape[0], cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    nbr = oracle.subm_rulebook(idx, batch, shape, [3, 3, 3])
+    monkeypatch.setenv("CPD_GC_MS", str(ms)); monkeypatch.setenv("CPD_GC_NT", str(nt))
+    np.testing.assert_allclose(run_conv(feat, w, nbr), oracle.sparse_conv(feat, w, None, nbr), atol=1e-4, rtol=0)
+
+
+def test_regular_conv_and_densify(oracle, hip):
+    rng = np.random.default_rng(21)
+    batch, shape, cin, cout = 2, [5, 24, 28], 64, 128
+    idx = random_sites(rng, batch, shape, 2500)
+    feat = rng.normal(size=(idx.shape[0], cin)).astype(np.float32)
+    k, s, p = [3, 1, 1], [2, 1, 1], [0, 0, 0]
+    w = (rng.normal(size=[cout] + k + [cin]) * np.sqrt(2.0 / (3 * cin))).astype(np.float32)
+    out_idx = oracle.conv_outset(idx, batch, shape, k, s, p)
+    oshape = oracle.conv_out_shape(shape, k, s, p)
+    nbr = oracle.conv_rulebook(idx, out_idx, batch, shape, k, s, p)
+    want = oracle.sparse_conv(feat, w, None, nbr)
+    got = run_conv(feat, w, nbr)
+    np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
+    # dense(): reference layout bit-exact, channels-last layout = the same numbers permuted
+    nchw = ops.densify_nchw(dev(want), dev(out_idx), batch, oshape).cpu().numpy()
+    ref = oracle.densify(want, out_idx, batch, oshape)
+    np.testing.assert_array_equal(nchw, ref)
+    nhwc = ops.densify_nhwc(dev(want), dev(out_idx), batch, oshape).cpu().numpy()    # (B,H,W,D*C), ch = z*C + c
+    D, C = oshape[0], cout
+    np.testing.assert_array_equal(nhwc.reshape(batch, oshape[1], oshape[2], D, C).transpose(0, 4, 3, 1, 2)
+                                  .reshape(batch, C * D, oshape[1], oshape[2]), ref)
+
+
+def test_kitti_c4_subm_path(oracle, hip):
+    """Config C4: 20k KITTI cloud at 0.05 m -> high-sparsity SubM layers 4->16->16."""
+    idx = voxel_coords(oracle, KITTI, kitti_cloud(0))
+    shape = sparse_shape(KITTI)
+    assert shape == [41, 1600, 1408]
+    rng = np.random.default_rng(4)
+    feat = rng.normal(size=(idx.shape[0], 4)).astype(np.float32)
+    index = ops.SiteIndex.build(dev(idx), 1, shape)
+    nbr = ops.rulebook_subm(dev(idx), index).cpu().numpy()
+    want_nbr = oracle.subm_rulebook(idx, 1, shape, [3, 3, 3])
+    np.testing.assert_array_equal(nbr, want_nbr)
+    w1 = (rng.normal(size=(16, 3, 3, 3, 4)) * 0.2).astype(np.float32)
+    w2 = (rng.normal(size=(16, 3, 3, 3, 16)) * 0.1).astype(np.float32)
+    x = run_conv(feat, w1, nbr, relu=True)
+    y = run_conv(x, w2, nbr, relu=True)
+    xr = np.maximum(oracle.sparse_conv(feat, w1, None, want_nbr), 0)
+    yr = np.maximum(oracle.sparse_conv(xr, w2, None, want_nbr), 0)
+    np.testing.assert_allclose(x, xr, atol=1e-4); np.testing.assert_allclose(y, yr, atol=1e-4)

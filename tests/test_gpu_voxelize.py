@@ -1,0 +1,77 @@
+"""B1 parity on the GPU: cpd_voxelize vs the serial CPU oracle -- coordinates, order, counts and
+payload bit-exact; fused means <= 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from cpd_amd import ops
+from cpd_amd.synthetic import KITTI, KITTI_C1, WAYMO, kitti_cloud, waymo_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(points, cfg, P=None, maxv=None, coord_cols=3):
+    P = P or cfg["max_points_per_voxel"]
+    maxv = maxv or cfg["max_voxels"]
+    vz = ops.Voxelizer(cfg["voxel_size"], cfg["point_cloud_range"], points.shape[1], P, maxv)
+    v, c, n, mean, m = vz(torch.from_numpy(points).cuda(), batch_idx=3, coord_cols=coord_cols)
+    return v.cpu().numpy(), c.cpu().numpy(), n.cpu().numpy(), mean.cpu().numpy()
+
+
+def check(oracle, points, cfg, P=None, maxv=None):
+    P = P or cfg["max_points_per_voxel"]
+    maxv = maxv or cfg["max_voxels"]
+    v, c, n, mean = run_hip(points, cfg, P, maxv)
+    v0, c0, n0 = oracle.voxelize(points, cfg["voxel_size"], cfg["point_cloud_range"], P, maxv)
+    assert c.shape == c0.shape
+    np.testing.assert_array_equal(c, c0)
+    np.testing.assert_array_equal(n, n0)
+    np.testing.assert_array_equal(v, v0)
+    np.testing.assert_allclose(mean, oracle.mean_vfe(v0, n0), rtol=1e-6, atol=1e-6)
+    return c0.shape[0]
+
+
+def test_waymo_160k_bit_exact(oracle, hip):
+    m = check(oracle, waymo_cloud(0), WAYMO)
+    assert m > 50000
+
+
+def test_kitti_20k_c1_and_c4(oracle, hip):
+    pts = kitti_cloud(0)
+    check(oracle, pts, KITTI_C1)
+    check(oracle, pts, KITTI)
+
+
+def test_shuffled_points_and_small_caps(oracle, hip):
+    rng = np.random.default_rng(5)
+    pts = waymo_cloud(1, n_points=40000)
+    rng.shuffle(pts)                       # train-mode shuffle (data_processor.py:105-126)
+    check(oracle, pts, WAYMO)
+    check(oracle, pts, WAYMO, P=2, maxv=1500)      # voxel cap and per-voxel cap both bite
+    dense = pts.copy(); dense[:, :2] *= 0.02       # many points per voxel
+    check(oracle, dense, WAYMO, P=5, maxv=700)
+
+
+def test_boundaries_nan_and_ragged(oracle, hip):
+    pts = waymo_cloud(2, n_points=5000)
+    pts[0, :3] = [-75.2, -75.2, -2.0]; pts[1, :3] = [75.2, 0, 0]; pts[2, :3] = [0, 0, 4.0]
+    pts[3, 0] = np.nan; pts[4, 1] = 1e30; pts[5, :3] = [75.19999, 75.19999, 3.99999]; pts[6, 2] = -np.inf
+    check(oracle, pts, WAYMO)
+    check(oracle, pts[:1], WAYMO)
+    # empty cloud
+    vz = ops.Voxelizer(WAYMO["voxel_size"], WAYMO["point_cloud_range"], 5, 5, 100)
+    v, c, n, mean, m = vz(torch.zeros((0, 5), device="cuda"))
+    assert m == 0 and c.shape[0] == 0
+
+
+def test_batch_column_and_voxel_boundaries(oracle, hip):
+    """Points placed exactly on voxel faces: fp32 floor((p-lo)/vs) must round as the CPU does."""
+    rng = np.random.default_rng(9)
+    k = rng.integers(0, 1504, (20000, 2)).astype(np.float32)
+    pts = np.zeros((20000, 5), np.float32)
+    pts[:, 0] = np.float32(-75.2) + k[:, 0] * np.float32(0.1)
+    pts[:, 1] = np.float32(-75.2) + k[:, 1] * np.float32(0.1)
+    pts[:, 2] = np.float32(-2.0) + rng.integers(0, 40, 20000).astype(np.float32) * np.float32(0.15)
+    check(oracle, pts, WAYMO)
+    v, c, n, mean = run_hip(pts, WAYMO, coord_cols=4)
+    assert c.shape[1] == 4 and (c[:, 0] == 3).all()
