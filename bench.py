@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s through voxelize -> sparse 3D backbone -> BEV head -> NMS on synthetic
+160k-point Waymo-shape clouds (BASELINE.json config 2), one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the whole hot path over one batch of `--frames` resident point clouds per GPU.
+Frames are sharded across ranks with NO data-path collective (forward-only inference shards by
+frame: SURVEY 8e); RCCL is used only for the timing barrier / max-over-ranks. Inputs are already in
+HBM when the timed region starts; outputs (boxes) stay on the device.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : dominant kernel (gather_conv_kernel<ms,nt,vec>, fp32 MFMA bound) measured live with
+                 HIP events on the launch stream in a second pass right after the timed region
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host
+                 cores on one full frame (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from cpd_amd import ops  # noqa: E402
+from cpd_amd.engine import CenterPointEngine, ModelConfig, init_state_dict  # noqa: E402
+from cpd_amd.synthetic import waymo_cloud  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+POOL = 4                        # distinct synthetic frames per rank, cycled
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=1, help="frames per step per GPU")
+    ap.add_argument("--points", type=int, default=160000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class ConvProfiler:
+    """Brackets every cpd_gather_conv launch with HIP events on the launch stream and books its
+    ALGORITHMIC flops: 2 * (valid (row, tap) pairs) * c_in * c_out (padding / skipped taps excluded)."""
+
+    def __init__(self):
+        self.records = []
+        self.pairs_cache = {}
+        self._orig = None
+
+    def _pairs(self, nbr, n_out):
+        if nbr is None:
+            return n_out
+        key = (nbr.data_ptr(), tuple(nbr.shape))
+        if key not in self.pairs_cache:
+            self.pairs_cache[key] = int((nbr >= 0).sum().item())
+        return self.pairs_cache[key]
+
+    def __enter__(self):
+        self._orig = ops.gather_conv
+        prof = self
+
+        def wrapped(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
+            ms, nt, vec = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0))
+            flops = 2.0 * prof._pairs(nbr, n_out) * c_in * c_out
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = prof._orig(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw)
+            e1.record(s)
+            prof.records.append(((ms, nt, vec), flops, e0, e1, (n_out, c_in, c_out, kv)))
+            return out
+
+        ops.gather_conv = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        ops.gather_conv = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        total_ms = 0.0
+        for key, flops, e0, e1, _ in self.records:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(key, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += ms
+            a[2] += 1
+            total_ms += ms
+        return agg, total_ms
+
+
+def cpu_baseline(cfg, sd, points_np):
+    """The oracle's un-fused restatement of the reference graph on the host CPU, one full frame."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import ref_pipeline
+    from oracle import Oracle
+    o = Oracle()
+    cores = os.cpu_count() or 1
+    # one untimed voxelizer call so that, as in the reference's generator object, the dense lookup
+    # volume already exists (it is allocated once per worker, data_processor.py:133-144)
+    o.voxelize(points_np[:1000], cfg.voxel_size, cfg.point_cloud_range, cfg.max_points_per_voxel, cfg.max_voxels)
+    t0 = time.perf_counter()
+    ref_pipeline.forward(o, cfg, sd, [points_np])
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 full 160k-point frame through the whole path (oracle/cpd_oracle.c, OpenMP on %d threads), "
+                      "%.1f s" % (cores, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    cfg = ModelConfig()
+    sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
+    eng = CenterPointEngine(cfg, sd, device="cuda:%d" % local)
+    clouds_np = [waymo_cloud(rank * POOL + i, n_points=args.points) for i in range(POOL)]
+    clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
+    B = args.frames
+
+    def step(i):
+        return eng.forward([clouds[(i * B + j) % POOL] for j in range(B)])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = {
+        "metric": "frames/sec voxelize->sparse3D->BEV->NMS, 160k-pt Waymo cloud",
+        "value": world * args.steps * B / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: Waymo-shape %d-point cloud, CPD VoxelResBackBone8x + HeightCompression + "
+                               "BaseBEVBackbone + CenterHead + rotated NMS, forward-only" % args.points,
+                   "frames_per_step_per_gpu": B, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
+                   "parallelism": "frame-sharded replicas x%d, no data-path collective" % world,
+                   "weights": "random-init (seed 0), eval-mode BN folded"},
+    }
+
+    if not args.no_roofline:
+        with ConvProfiler() as prof:
+            n_prof = max(1, min(args.steps, 5))
+            for i in range(n_prof):
+                step(i)
+            agg, conv_ms = prof.summary()
+        key, (flops, ms, launches) = max(agg.items(), key=lambda kv: kv[1][1])
+        achieved = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "gather_conv_kernel<%d,%d,%s>" % (key[0], key[1], "true" if key[2] else "false"),
+            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": None, "launches_per_frame": launches / (n_prof * B), "avg_launch_us": 1e3 * ms / launches,
+            "algorithmic_gflop_per_launch": flops / launches / 1e9,
+            "all_conv_kernels": {"gather_conv_kernel<%d,%d,%d>" % k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_frame": v[1] / (n_prof * B),
+                                                                      "launches_per_frame": v[2] / (n_prof * B)} for k, v in sorted(agg.items())},
+            "conv_ms_per_frame": conv_ms / (n_prof * B),
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, clouds_np[0])
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

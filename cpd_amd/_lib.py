@@ -42,6 +42,7 @@ SIGNATURES = {
     "cpd_packed_weight_floats": (_SZ, [_I, _I, _I]),
     "cpd_pack_weight": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "cpd_gather_conv": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _VP]),
+    "cpd_gather_conv_tile": (_I, [_I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "cpd_densify_nchw": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_densify_nhwc": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_rulebook_conv2d": (_I, [_I, _I, _I, _I, _I, _I, _I, _VP, _VP]),

@@ -288,6 +288,20 @@ extern "C" int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, 
     return cpd_check_launch();
 }
 
+static void plan_tile(int n_out, int c_in, int c_out, int in_ld, const void *in, int *ms, int *nt, int *vec) {
+    const int ntot = (c_out + 15) / 16;
+    choose_tile(n_out, ntot, ms, nt);
+    if (const char *e = getenv("CPD_GC_MS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *ms = v; }
+    if (const char *e = getenv("CPD_GC_NT")) { int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 5 || v == 8) && ntot % v == 0) *nt = v; }
+    *vec = (c_in % 16 == 0) && (in_ld % 4 == 0) && (((uintptr_t)in & 15) == 0);
+}
+
+extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, int *ms, int *nt, int *vec) {
+    if (n_out <= 0 || c_in <= 0 || c_out <= 0 || !ms || !nt || !vec) return CPD_ERR_ARG;
+    plan_tile(n_out, c_in, c_out, in_ld, nullptr, ms, nt, vec);
+    return CPD_OK;
+}
+
 extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
                                int kv, int n_out, int c_out, const float *scale, const float *shift,
                                const float *residual, int res_ld, int relu, float *out, int out_ld,
@@ -303,11 +317,9 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
-    int ms, nt;
-    choose_tile(n_out, p.ntot, &ms, &nt);
-    if (const char *e = getenv("CPD_GC_MS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) ms = v; }
-    if (const char *e = getenv("CPD_GC_NT")) { int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 5 || v == 8) && p.ntot % v == 0) nt = v; }
-    const bool vec = (c_in % 16 == 0) && (in_ld % 4 == 0) && (((uintptr_t)in & 15) == 0);
+    int ms, nt, veci;
+    plan_tile(n_out, c_in, c_out, in_ld, in, &ms, &nt, &veci);
+    const bool vec = veci != 0;
     gc_kernel_t k = pick(ms, nt, vec);
     if (!k) return CPD_ERR_UNSUPPORTED;
     p.n_rb = (n_out + 16 * ms - 1) / (16 * ms);

@@ -269,3 +269,11 @@ def boxes_iou_bev_cpu(a, b):
     out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32)
     check(lib().cpd_boxes_iou_bev_cpu(ptr(a), a.shape[0], ptr(b), b.shape[0], ptr(out)), "cpd_boxes_iou_bev_cpu")
     return out
+
+
+def gather_conv_tile(n_out, c_in, c_out, in_ld):
+    """(ms, nt, vec) of the gather_conv_kernel<ms,nt,vec> instantiation cpd_gather_conv will run."""
+    ms, nt, vec = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), ctypes.byref(ms), ctypes.byref(nt),
+                                     ctypes.byref(vec)), "cpd_gather_conv_tile")
+    return ms.value, nt.value, vec.value

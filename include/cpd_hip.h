@@ -122,6 +122,11 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
                     const float *shift, const float *residual, int res_ld, int relu, float *out,
                     int out_ld, const int32_t *out_row_map, int out_col_group, cpd_stream_t stream);
 
+/* Introspection for benchmarks/profilers: the wave tile (16*ms rows x 16*nt cols) and load path
+ * (vec = 16-byte A pieces) cpd_gather_conv will pick for this problem, i.e. which instantiation
+ * gather_conv_kernel<ms, nt, vec> runs. HOST only. */
+int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, int *ms, int *nt, int *vec);
+
 /* SparseConvTensor.dense() + view(N, C*D, H, W) (height_compression.py:136-138).
  *   nchw: out (B, C*D, H, W), channel = c*D + z   -- the reference layout
  *   nhwc: out (B, H, W, D*C), channel = z*C + c   -- channels-last, feeds cpd_gather_conv

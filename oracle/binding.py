@@ -92,6 +92,7 @@ class Oracle:
     def voxelize(self, points, vsize_xyz, range_xyz, max_points, max_voxels):
         points = _f32(points)
         n, c = points.shape
+        max_voxels = max(1, min(int(max_voxels), n))    # a cloud of n points fills at most n voxels
         voxels = np.empty((max_voxels, max_points, c), np.float32)
         coords = np.empty((max_voxels, 3), np.int32)
         num = np.empty((max_voxels,), np.int32)

@@ -52,9 +52,17 @@ int cpd_ref_voxelize(const float *points, int n, int c, const float vsize_xyz[3]
     int32_t grid[3];
     cpd_ref_grid_size(vsize_xyz, range_xyz, grid);
     const size_t cells = (size_t)grid[0] * grid[1] * grid[2];
-    int32_t *lut = (int32_t *)malloc(cells * sizeof(int32_t));
-    if (!lut) return CPD_ERR_ALLOC;
-    memset(lut, 0xff, cells * sizeof(int32_t)); /* -1 */
+    /* like the reference generator object, the dense lookup volume persists across calls and only
+     * the touched entries are reset afterwards (A.1) */
+    static int32_t *lut = NULL;
+    static size_t lut_cells = 0;
+    if (lut_cells != cells) {
+        free(lut);
+        lut = (int32_t *)malloc(cells * sizeof(int32_t));
+        if (!lut) { lut_cells = 0; return CPD_ERR_ALLOC; }
+        memset(lut, 0xff, cells * sizeof(int32_t)); /* -1 */
+        lut_cells = cells;
+    }
     memset(voxels, 0, (size_t)max_voxels * max_points * c * sizeof(float));
     memset(num_points, 0, (size_t)max_voxels * sizeof(int32_t));
     int nvox = 0;
@@ -85,7 +93,8 @@ int cpd_ref_voxelize(const float *points, int n, int c, const float vsize_xyz[3]
             num_points[v] = k + 1;
         }
     }
-    free(lut);
+    for (int v = 0; v < nvox; ++v) /* reset touched entries */
+        lut[((size_t)coords_zyx[3 * v] * grid[1] + coords_zyx[3 * v + 1]) * grid[2] + coords_zyx[3 * v + 2]] = -1;
     *n_voxels = nvox;
     return CPD_OK;
 }
