@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcpd_hip.so")
+LIB_PATH = os.environ.get("CPD_HIP_LIB", os.path.join(_HERE, "csrc", "libcpd_hip.so"))  # override: diagnostics only
 
 CPD_ERRORS = {-1: "CPD_ERR_ARG", -2: "CPD_ERR_WORKSPACE", -3: "CPD_ERR_LAUNCH", -4: "CPD_ERR_UNSUPPORTED"}
 

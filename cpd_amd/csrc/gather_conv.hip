@@ -25,6 +25,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic builds only (tools/probe): bit 0 drops the B-fragment loads, bit 1 the A gathers, so
+// the MFMA loop can be timed without its memory traffic. The shipped library is built with 0.
+#ifndef CPD_GC_ABLATE
+#define CPD_GC_ABLATE 0
+#endif
+
 namespace {
 
 struct GcParams {
@@ -76,11 +82,17 @@ struct TapRegs {
     __device__ __forceinline__ void load(const GcParams &p, const int (&idx)[MS], const float *wk, int kc, int g) {
 #pragma unroll
         for (int s = 0; s < MS; ++s)
-            if (MASK & (1u << s)) a[s] = load_a<VEC>(p, idx[s], kc, g);
+            if (MASK & (1u << s)) {
+                if (CPD_GC_ABLATE & 2) a[s] = f32x4{(float)g, 1.f, (float)kc, 2.f};
+                else a[s] = load_a<VEC>(p, idx[s], kc, g);
+            }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[q][nt] = wk[((size_t)q * p.ntot + nt) * 64];
+            for (int nt = 0; nt < NT; ++nt) {
+                if (CPD_GC_ABLATE & 1) b[q][nt] = (float)(q + nt + g);
+                else b[q][nt] = wk[((size_t)q * p.ntot + nt) * 64];
+            }
     }
     __device__ __forceinline__ void mma(const int (&idx)[MS], f32x4 (&acc)[MS][NT]) {
 #pragma unroll
@@ -254,12 +266,13 @@ static gc_kernel_t pick(int ms, int nt, bool vec) {
     return nullptr;
 }
 
-// Tile choice: the biggest accumulator tile that still yields enough independent wave tiles to
-// fill 256 CUs x 4 SIMDs twice over (MI355X wants >> 1024 waves; fp32 MFMA needs 1 wave/SIMD).
+// Tile choice (measured, tools/sweep_tiles.py on MI355X): per-wave efficiency grows with the tile
+// (B fragments reused across MS row sub-tiles, A pieces across NT column tiles) but fp32 MFMA only
+// needs one wave per SIMD, so what matters first is having >= ~4 wave tiles per SIMD (4096 items)
+// to keep 256 CUs x 4 SIMDs evenly loaded; take the largest tile that still gives that many.
 static void choose_tile(int n_out, int ntot, int *ms_out, int *nt_out) {
-    static const int cand[][2] = {{4, 8}, {4, 5}, {2, 8}, {4, 4}, {2, 5}, {2, 4}, {4, 2}, {1, 8},
-                                  {4, 1}, {2, 2}, {1, 5}, {1, 4}, {2, 1}, {1, 2}, {1, 1}};
-    const long long want = 2048;
+    static const int cand[][2] = {{2, 8}, {4, 4}, {2, 5}, {2, 4}, {2, 2}, {1, 4}, {1, 5}, {1, 2}, {2, 1}, {1, 1}};
+    const long long want = 4096;
     int best_ms = 1, best_nt = 1;
     long long best_items = -1;
     for (auto &c : cand) {
