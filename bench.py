@@ -70,14 +70,14 @@ class ConvProfiler:
         prof = self
 
         def wrapped(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
-            ms, nt, vec = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0))
+            kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False))
             flops = 2.0 * prof._pairs(nbr, n_out) * c_in * c_out
             s = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
             out = prof._orig(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw)
             e1.record(s)
-            prof.records.append(((ms, nt, vec), flops, e0, e1, (n_out, c_in, c_out, kv)))
+            prof.records.append((kname, flops, e0, e1, (n_out, c_in, c_out, kv)))
             return out
 
         ops.gather_conv = wrapped
@@ -180,11 +180,11 @@ def main():
         key, (flops, ms, launches) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12
         out["roofline"] = {
-            "bound": "mfma", "kernel": "gather_conv_kernel<%d,%d,%s>" % (key[0], key[1], "true" if key[2] else "false"),
+            "bound": "mfma", "kernel": key,
             "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
             "traffic": None, "launches_per_frame": launches / (n_prof * B), "avg_launch_us": 1e3 * ms / launches,
             "algorithmic_gflop_per_launch": flops / launches / 1e9,
-            "all_conv_kernels": {"gather_conv_kernel<%d,%d,%d>" % k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_frame": v[1] / (n_prof * B),
+            "all_conv_kernels": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_frame": v[1] / (n_prof * B),
                                                                       "launches_per_frame": v[2] / (n_prof * B)} for k, v in sorted(agg.items())},
             "conv_ms_per_frame": conv_ms / (n_prof * B),
         }

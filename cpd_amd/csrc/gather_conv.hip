@@ -1,4 +1,4 @@
-// gather_conv.hip -- the one GEMM-shaped kernel of the path: rulebook-driven implicit GEMM on the
+// gather_conv.hip -- the one GEMM-shaped op of the path: rulebook-driven implicit GEMM on the
 // gfx950 fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 fma chain, 157 TFLOP/s peak).
 //
 //   out[j, :] = act( (sum_t in[nbr[t][j], :] . W[t]) * scale + shift + residual[j, :] )
@@ -11,22 +11,30 @@
 //     (base_bev_backbone.py:31-59) and CenterHead (center_head.py:21-27,73-80) on channels-last
 //     maps, with a dense pixel rulebook (cpd_rulebook_conv2d) -- cuDNN's role in the reference.
 //
-// Wavefront-segmented: one wave64 owns a (16*MS rows) x (16*NT cols) output tile, keeps it in
-// accumulator registers across all taps and all input channels, and writes it once. No LDS, no
-// barriers: A rows are gathered straight from L2 as 16-byte pieces in MFMA operand order (lane
-// (r,g) holds channels 4g..4g+3 of row r), B fragments are pre-packed so each MFMA's B operand is
-// one fully coalesced 256-byte read shared by all MS row sub-tiles. Row sub-tiles (16 rows) with no
-// active neighbour at a tap skip that tap's MFMAs (wave-uniform branch on a ballot) -- that is what
-// "sparse" buys on the matrix pipe. Work items are laid out so each XCD's L2 sees a contiguous band
-// of output rows (A halo reuse) and all XCDs stream the same (L2-resident) weights.
+// Two kernels share the operand mapping (MFMA k-slot g of 16-channel chunk kc, step q <-> channel
+// 16*kc + 4*g + q, so a lane's four steps are one 16-byte piece of a feature row) and the packed
+// weight image P[t][kc][g][n][q] (a lane's four steps of one column are one 16-byte piece too):
+//
+//   wave kernel (gather_conv_kernel<MS,NT>): one wave64 owns a (16*MS) x (16*NT) output tile in
+//     accumulator registers across all taps/channels; no LDS, no barriers; A pieces gathered
+//     straight from L2, B pieces as coalesced 16-byte loads; 16-row sub-tiles with no neighbour at
+//     a tap skip that tap's MFMAs (wave-uniform branch on a ballot) -- what "sparse" buys on the
+//     matrix pipe. Used for the sparse backbone and small layers.
+//   workgroup kernel (tile_conv_kernel<BM,BN>): 4 waves share a BM x BN tile; per 32-channel stage
+//     the gathered A rows and the B panel go global -> registers -> LDS (double buffered, one
+//     barrier per stage, next stage's loads in flight under the current MFMAs), every wave then
+//     feeds its MFMAs with conflict-free ds_read_b128. Cuts L2->CU traffic by the tile's reuse
+//     factor; used for the dense BEV / head convolutions (CPD_GC_DENSE flag).
+// Work items are laid out so each XCD's L2 sees a contiguous band of output rows (A halo reuse)
+// while all XCDs stream the same L2-resident weights.
 #include <stdlib.h>
 
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Diagnostic builds only (tools/probe): bit 0 drops the B-fragment loads, bit 1 the A gathers, so
-// the MFMA loop can be timed without its memory traffic. The shipped library is built with 0.
+// Diagnostic builds only (tools/probe): bit 0 drops the B loads, bit 1 the A gathers, so the MFMA
+// loop can be timed without its memory traffic. The shipped library is built with 0.
 #ifndef CPD_GC_ABLATE
 #define CPD_GC_ABLATE 0
 #endif
@@ -41,7 +49,7 @@ struct GcParams {
     float *out;
     const int32_t *out_row_map;
     int in_ld, c_in, kc;  // kc = 16-channel chunks
-    int kv, n_out, c_out, ntot;
+    int kv, n_out, c_out, ntot, np;  // np = padded columns (16*ntot)
     int res_ld, relu, out_ld, col_group;
     int n_rb, n_cb, items;
 };
@@ -52,17 +60,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-// A piece for lane (r,g): channels kc*16+4g .. +3 of input row idx. Rows without a neighbour
+// A piece: 4 consecutive channels starting at `ch` of input row idx. Rows without a neighbour
 // (idx < 0) read row 0 and are zeroed by a select afterwards, so the load itself is unconditional
 // (no exec-mask branches between the loads and the MFMAs they feed).
 template <bool VEC>
-__device__ __forceinline__ f32x4 load_a(const GcParams &p, int idx, int kc, int g) {
-    const float *row = p.in + (size_t)(idx < 0 ? 0 : idx) * p.in_ld + kc * 16 + 4 * g;
+__device__ __forceinline__ f32x4 load_a(const GcParams &p, int idx, int ch) {
+    const float *row = p.in + (size_t)(idx < 0 ? 0 : idx) * p.in_ld + ch;
     f32x4 a;
     if (VEC) {
         a = *reinterpret_cast<const f32x4 *>(row);
     } else {
-        const int ch = kc * 16 + 4 * g;
         a[0] = ch + 0 < p.c_in ? row[0] : 0.f;
         a[1] = ch + 1 < p.c_in ? row[1] : 0.f;
         a[2] = ch + 2 < p.c_in ? row[2] : 0.f;
@@ -75,24 +82,62 @@ __device__ __forceinline__ f32x4 zero_if(f32x4 a, bool z) {
     return a;
 }
 
+// Shared epilogue. C/D layout of 16x16x4: col = lane & 15, row = 4*(lane >> 4) + i.
+template <int MS, int NT>
+__device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT], int row0, int col0, int r, int g) {
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = col0 + nt * 16 + r;
+        sc[nt] = (p.scale && col < p.c_out) ? p.scale[col] : 1.f;
+        sh[nt] = (p.shift && col < p.c_out) ? p.shift[col] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < MS; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 16 * s + 4 * g + i;
+            if (row >= p.n_out) continue;
+            size_t orow = (size_t)row;
+            if (p.out_row_map && !p.col_group) orow = (size_t)p.out_row_map[row];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = col0 + nt * 16 + r;
+                if (col >= p.c_out) continue;
+                float v = acc[s][nt][i];
+                v = v * sc[nt] + sh[nt];
+                if (p.residual) v += p.residual[(size_t)row * p.res_ld + col];
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.col_group) {
+                    const int grp = col / p.col_group;
+                    const size_t drow = (size_t)p.out_row_map[(size_t)grp * p.n_out + row];
+                    p.out[drow * p.out_ld + (col - grp * p.col_group)] = v;
+                } else {
+                    p.out[orow * p.out_ld + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ================================== wave kernel ==============================================
 template <int MS, int NT, bool VEC, unsigned MASK>
 struct TapRegs {
     f32x4 a[MS];
-    float b[4][NT];
+    f32x4 b[NT];  // b[nt][q]
+    // wk points at P[t][kc][g][col0 + j][0] for this lane
     __device__ __forceinline__ void load(const GcParams &p, const int (&idx)[MS], const float *wk, int kc, int g) {
 #pragma unroll
         for (int s = 0; s < MS; ++s)
             if (MASK & (1u << s)) {
                 if (CPD_GC_ABLATE & 2) a[s] = f32x4{(float)g, 1.f, (float)kc, 2.f};
-                else a[s] = load_a<VEC>(p, idx[s], kc, g);
+                else a[s] = load_a<VEC>(p, idx[s], kc * 16 + 4 * g);
             }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (CPD_GC_ABLATE & 1) b[q][nt] = (float)(q + nt + g);
-                else b[q][nt] = wk[((size_t)q * p.ntot + nt) * 64];
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            if (CPD_GC_ABLATE & 1) b[nt] = f32x4{(float)nt, 1.f, (float)g, 2.f};
+            else b[nt] = *reinterpret_cast<const f32x4 *>(wk + (size_t)nt * 64);
+        }
     }
     __device__ __forceinline__ void mma(const int (&idx)[MS], f32x4 (&acc)[MS][NT]) {
 #pragma unroll
@@ -105,18 +150,18 @@ struct TapRegs {
 #pragma unroll
                 for (int s = 0; s < MS; ++s)
                     if (MASK & (1u << s))
-                        acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][q], b[q][nt], acc[s][nt], 0, 0, 0);
+                        acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][q], b[nt][q], acc[s][nt], 0, 0, 0);
     }
 };
 
 // One tap for the row sub-tiles in MASK. Two register sets ping-pong over the 16-channel chunks
-// (no copies), so the next chunk's A pieces and B fragments stay in flight under the current
-// chunk's MFMAs behind a counted vmcnt.
+// (no copies), so the next chunk's A and B pieces stay in flight under the current chunk's MFMAs
+// behind a counted vmcnt.
 template <int MS, int NT, bool VEC, unsigned MASK>
 __device__ __forceinline__ void tap_compute(const GcParams &p, const int (&idx)[MS], const float *wt, int g,
                                             f32x4 (&acc)[MS][NT]) {
     TapRegs<MS, NT, VEC, MASK> r0, r1;
-    const size_t kstride = (size_t)4 * p.ntot * 64;
+    const size_t kstride = (size_t)4 * p.np * 4;  // floats per 16-channel chunk of P
     r0.load(p, idx, wt, 0, g);
     int kc = 0;
     for (; kc + 1 < p.kc; kc += 2) {
@@ -137,6 +182,7 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
     const int r = lane & 15, g = lane >> 4;
     const int row0 = rb * (16 * MS);
+    const int col0 = cb * NT * 16;
 
     f32x4 acc[MS][NT];
 #pragma unroll
@@ -144,7 +190,7 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const size_t w_tap = (size_t)p.kc * 4 * p.ntot * 64;
+    const size_t w_tap = (size_t)p.kc * 4 * p.np * 4;
     // Rulebook column of this wave's rows, fetched one tap ahead (unconditional, clamped loads).
     int rowc[MS];
     bool rowok[MS];
@@ -171,7 +217,7 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
             for (int s = 0; s < MS; ++s) idx_nxt[s] = p.nbr[(size_t)(t + 1) * p.n_out + rowc[s]];
         }
         if (!active) continue;  // no row of this tile has a neighbour at tap t
-        const float *wt = p.w + (size_t)t * w_tap + (size_t)(cb * NT) * 64 + lane;
+        const float *wt = p.w + (size_t)t * w_tap + ((size_t)g * p.np + col0 + r) * 4;
         if constexpr (MS == 1) {
             tap_compute<MS, NT, VEC, 1u>(p, idx, wt, g, acc);
         } else if constexpr (MS == 2) {
@@ -183,60 +229,144 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
             tap_compute<MS, NT, VEC, (1u << MS) - 1u>(p, idx, wt, g, acc);
         }
     }
+    epilogue<MS, NT>(p, acc, row0, col0, r, g);
+}
 
-    // Epilogue: C/D layout of 16x16x4: col = lane & 15, row = 4*(lane >> 4) + i.
-    float sc[NT], sh[NT];
+// ================================ workgroup kernel ===========================================
+// LDS images of one 32-channel stage (pieces = 16 B):
+//   A: piece (c,g) of tile row m at ((c*4+g)*BM + (m ^ (c*4+g))) * 16   (XOR keeps both the
+//      8-lanes-per-row staging writes and the 16-rows-per-group fragment reads conflict-free)
+//   B: piece (c,g) of tile col n at ((c*4+g)*BN + n) * 16               (lane-linear both ways)
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) tile_conv_kernel(GcParams p) {
+    constexpr int MS = BM / 32, NT = BN / 32;  // 2 x 2 waves, wave tile (BM/2) x (BN/2)
+    constexpr int AJ = BM / 32;                // A pieces staged per thread per stage
+    constexpr int BJ = BN / 32;                // B pieces staged per thread per stage
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
+    const int row0 = rb * BM, col0 = cb * BN;
+
+    f32x4 acc[MS][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = (cb * NT + nt) * 16 + r;
-        sc[nt] = (p.scale && col < p.c_out) ? p.scale[col] : 1.f;
-        sh[nt] = (p.shift && col < p.c_out) ? p.shift[col] : 0.f;
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging roles: 8 lanes cover one 128-B line (32 channels) of a gathered row
+    const int a_piece = tid & 7;  // c = a_piece >> 2, g = a_piece & 3
+    const int a_row = tid >> 3;   // + 32*j
+    int a_rowc[AJ];
+    bool a_ok[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int row = row0 + a_row + 32 * j;
+        a_ok[j] = row < p.n_out;
+        a_rowc[j] = a_ok[j] ? row : p.n_out - 1;
     }
+    const int sk = p.kc >> 1;  // stages per tap (c_in is a multiple of 32 here)
+    const int n_stage = p.kv * sk;
+    const size_t w_chunk = (size_t)4 * p.np * 4;  // floats per 16-channel chunk of P
+
+    int idx_cur[AJ];
 #pragma unroll
-    for (int s = 0; s < MS; ++s) {
+    for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr ? p.nbr[a_rowc[j]] : a_rowc[j];
+
+    f32x4 ra[AJ], rbv[BJ];
+    auto stage_load = [&](int st) {
+        const int t = st / sk, kk = st - t * sk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + 16 * s + 4 * g + i;
-            if (row >= p.n_out) continue;
-            size_t orow = (size_t)row;
-            if (p.out_row_map && !p.col_group) orow = (size_t)p.out_row_map[row];
+        for (int j = 0; j < AJ; ++j) {
+            const int id = a_ok[j] ? idx_cur[j] : -1;
+            ra[j] = zero_if(load_a<true>(p, id, kk * 32 + a_piece * 4), id < 0);
+        }
+        const float *wt = p.w + ((size_t)t * p.kc + kk * 2) * w_chunk;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = (cb * NT + nt) * 16 + r;
-                if (col >= p.c_out) continue;
-                float v = acc[s][nt][i];
-                v = v * sc[nt] + sh[nt];
-                if (p.residual) v += p.residual[(size_t)row * p.res_ld + col];
-                if (p.relu) v = v > 0.f ? v : 0.f;
-                if (p.col_group) {
-                    const int grp = col / p.col_group;
-                    const size_t drow = (size_t)p.out_row_map[(size_t)grp * p.n_out + row];
-                    p.out[drow * p.out_ld + (col - grp * p.col_group)] = v;
-                } else {
-                    p.out[orow * p.out_ld + col] = v;
+        for (int j = 0; j < BJ; ++j) {
+            const int id = j * 256 + tid;  // piece id in the B stage image
+            const int cg = id / BN, n = id - cg * BN;
+            rbv[j] = *reinterpret_cast<const f32x4 *>(wt + ((size_t)cg * p.np + col0 + n) * 4);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char *sa = smem + buf * (A_BYTES + B_BYTES);
+        char *sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = a_row + 32 * j;
+            *reinterpret_cast<f32x4 *>(sa + ((a_piece * BM + (m ^ a_piece)) << 4)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4 *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+    };
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int st = 0; st < n_stage; ++st) {
+        const int nx = st + 1;
+        if (nx < n_stage) {
+            const int t_nx = nx / sk;
+            if (nx - t_nx * sk == 0) {  // the next stage opens a new tap: switch to its rulebook column
+#pragma unroll
+                for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr[(size_t)t_nx * p.n_out + a_rowc[j]];
+            }
+            stage_load(nx);
+        }
+        {
+            const char *sa = smem + (st & 1) * (A_BYTES + B_BYTES);
+            const char *sb = sa + A_BYTES;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int piece = c * 4 + g;
+                f32x4 a[MS], b[NT];
+#pragma unroll
+                for (int s = 0; s < MS; ++s) {
+                    const int m = wr * (BM / 2) + 16 * s + r;
+                    a[s] = *reinterpret_cast<const f32x4 *>(sa + ((piece * BM + (m ^ piece)) << 4));
                 }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = wc * (BN / 2) + 16 * nt + r;
+                    b[nt] = *reinterpret_cast<const f32x4 *>(sb + ((piece * BN + n) << 4));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int s = 0; s < MS; ++s)
+                            acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][q], b[nt][q], acc[s][nt], 0, 0, 0);
             }
         }
+        if (nx < n_stage) stage_store(nx & 1);
+        __syncthreads();
     }
+    epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
 }
 
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restrict__ w, int kv, int c_in, int c_out, int kc,
-                                                          int ntot, float *__restrict__ packed) {
-    // packed[(((t*KC + kc)*4 + q)*NTOT + nt)*64 + lane] = W[t][kc*16 + 4*(lane>>4) + q][nt*16 + (lane&15)]
-    size_t total = (size_t)kv * kc * 4 * ntot * 64;
+                                                          int np, float *__restrict__ packed) {
+    // packed[(((t*KC + kc)*4 + g)*NP + n)*4 + q] = W[t][kc*16 + 4*g + q][n]   (zero padded)
+    size_t total = (size_t)kv * kc * 4 * np * 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    int lane = (int)(i & 63);
-    size_t rest = i >> 6;
-    int nt = (int)(rest % ntot);
-    rest /= ntot;
-    int q = (int)(rest & 3);
+    int q = (int)(i & 3);
+    size_t rest = i >> 2;
+    int n = (int)(rest % np);
+    rest /= np;
+    int g = (int)(rest & 3);
     rest >>= 2;
     int k = (int)(rest % kc);
     int t = (int)(rest / kc);
-    int ch = k * 16 + 4 * (lane >> 4) + q, col = nt * 16 + (lane & 15);
+    int ch = k * 16 + 4 * g + q;
     float v = 0.f;
-    if (ch < c_in && col < c_out) v = w[((size_t)t * c_in + ch) * c_out + col];
+    if (ch < c_in && n < c_out) v = w[((size_t)t * c_in + ch) * c_out + n];
     packed[i] = v;
 }
 
@@ -265,12 +395,19 @@ static gc_kernel_t pick(int ms, int nt, bool vec) {
     }
     return nullptr;
 }
+static gc_kernel_t pick_tile(int bm, int bn) {
+    if (bm == 128 && bn == 128) return tile_conv_kernel<128, 128>;
+    if (bm == 64 && bn == 128) return tile_conv_kernel<64, 128>;
+    if (bm == 128 && bn == 64) return tile_conv_kernel<128, 64>;
+    if (bm == 64 && bn == 64) return tile_conv_kernel<64, 64>;
+    return nullptr;
+}
 
-// Tile choice (measured, tools/sweep_tiles.py on MI355X): per-wave efficiency grows with the tile
-// (B fragments reused across MS row sub-tiles, A pieces across NT column tiles) but fp32 MFMA only
-// needs one wave per SIMD, so what matters first is having >= ~4 wave tiles per SIMD (4096 items)
-// to keep 256 CUs x 4 SIMDs evenly loaded; take the largest tile that still gives that many.
-static void choose_tile(int n_out, int ntot, int *ms_out, int *nt_out) {
+// Wave tile choice (measured, tools/sweep_tiles.py on MI355X): per-wave efficiency grows with the
+// tile (B pieces reused across MS row sub-tiles, A pieces across NT column tiles) but fp32 MFMA
+// only needs one wave per SIMD, so what matters first is having >= ~4 wave tiles per SIMD (4096
+// items) to keep 256 CUs x 4 SIMDs evenly loaded; take the largest tile that still gives that.
+static void choose_wave_tile(int n_out, int ntot, int *ms_out, int *nt_out) {
     static const int cand[][2] = {{2, 8}, {4, 4}, {2, 5}, {2, 4}, {2, 2}, {1, 4}, {1, 5}, {1, 2}, {2, 1}, {1, 1}};
     const long long want = 4096;
     int best_ms = 1, best_nt = 1;
@@ -286,39 +423,74 @@ static void choose_tile(int n_out, int ntot, int *ms_out, int *nt_out) {
     *nt_out = best_nt;
 }
 
+// Workgroup tile for the dense path: largest BM x BN (BN | c_out) with >= 1024 workgroups
+// (4 per CU); 0 x 0 = use the wave kernel.
+static void choose_wg_tile(int n_out, int c_in, int c_out, int *bm_out, int *bn_out) {
+    *bm_out = *bn_out = 0;
+    if (c_in % 32 || c_out % 64) return;
+    static const int cand[][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+    long long best_items = -1;
+    for (auto &c : cand) {
+        int bm = c[0], bn = c[1];
+        if (c_out % bn) continue;
+        long long items = (long long)((n_out + bm - 1) / bm) * (c_out / bn);
+        if (items >= 1024) { *bm_out = bm; *bn_out = bn; return; }
+        if (items > best_items) { best_items = items; *bm_out = bm; *bn_out = bn; }
+    }
+}
+
+struct GcPlan {
+    int use_wg;     // 1: tile_conv_kernel<a,b>, 0: gather_conv_kernel<a,b,vec>
+    int a, b, vec;  // (bm,bn) or (ms,nt)
+};
+
+static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, int flags) {
+    GcPlan pl;
+    const int ntot = (c_out + 15) / 16;
+    pl.vec = (c_in % 16 == 0) && (in_ld % 4 == 0) && (((uintptr_t)in & 15) == 0);
+    pl.use_wg = 0;
+    int force_wg = -1;
+    if (const char *e = getenv("CPD_GC_WG")) force_wg = atoi(e);
+    if (((flags & 1) && force_wg != 0) || force_wg > 0) {
+        int bm, bn;
+        choose_wg_tile(n_out, c_in, c_out, &bm, &bn);
+        if (const char *e = getenv("CPD_GC_BM")) { int v = atoi(e); if ((v == 64 || v == 128) && bm) bm = v; }
+        if (const char *e = getenv("CPD_GC_BN")) { int v = atoi(e); if ((v == 64 || v == 128) && bn && c_out % v == 0) bn = v; }
+        if (bm && bn && pl.vec) { pl.use_wg = 1; pl.a = bm; pl.b = bn; return pl; }
+    }
+    choose_wave_tile(n_out, ntot, &pl.a, &pl.b);
+    if (const char *e = getenv("CPD_GC_MS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) pl.a = v; }
+    if (const char *e = getenv("CPD_GC_NT")) { int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 5 || v == 8) && ntot % v == 0) pl.b = v; }
+    return pl;
+}
+
 }  // namespace
 
 extern "C" size_t cpd_packed_weight_floats(int kv, int c_in, int c_out) {
     if (kv <= 0 || c_in <= 0 || c_out <= 0) return 0;
-    return (size_t)kv * ((c_in + 15) / 16) * 4 * ((c_out + 15) / 16) * 64;
+    return (size_t)kv * ((c_in + 15) / 16) * 4 * (((c_out + 15) / 16) * 16) * 4;
 }
 
 extern "C" int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *packed, cpd_stream_t stream) {
     if (!w_kio || !packed || kv <= 0 || c_in <= 0 || c_out <= 0) return CPD_ERR_ARG;
-    int kc = (c_in + 15) / 16, ntot = (c_out + 15) / 16;
+    int kc = (c_in + 15) / 16, np = ((c_out + 15) / 16) * 16;
     size_t total = cpd_packed_weight_floats(kv, c_in, c_out);
-    pack_weight_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, kc, ntot, packed);
+    pack_weight_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, kc, np, packed);
     return cpd_check_launch();
 }
 
-static void plan_tile(int n_out, int c_in, int c_out, int in_ld, const void *in, int *ms, int *nt, int *vec) {
-    const int ntot = (c_out + 15) / 16;
-    choose_tile(n_out, ntot, ms, nt);
-    if (const char *e = getenv("CPD_GC_MS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) *ms = v; }
-    if (const char *e = getenv("CPD_GC_NT")) { int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 5 || v == 8) && ntot % v == 0) *nt = v; }
-    *vec = (c_in % 16 == 0) && (in_ld % 4 == 0) && (((uintptr_t)in & 15) == 0);
-}
-
-extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, int *ms, int *nt, int *vec) {
-    if (n_out <= 0 || c_in <= 0 || c_out <= 0 || !ms || !nt || !vec) return CPD_ERR_ARG;
-    plan_tile(n_out, c_in, c_out, in_ld, nullptr, ms, nt, vec);
+extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, int flags, int *wg, int *a, int *b,
+                                    int *vec) {
+    if (n_out <= 0 || c_in <= 0 || c_out <= 0 || !wg || !a || !b || !vec) return CPD_ERR_ARG;
+    GcPlan pl = plan(n_out, c_in, c_out, in_ld, nullptr, flags);
+    *wg = pl.use_wg; *a = pl.a; *b = pl.b; *vec = pl.vec;
     return CPD_OK;
 }
 
 extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
                                int kv, int n_out, int c_out, const float *scale, const float *shift,
                                const float *residual, int res_ld, int relu, float *out, int out_ld,
-                               const int32_t *out_row_map, int out_col_group, cpd_stream_t stream) {
+                               const int32_t *out_row_map, int out_col_group, int flags, cpd_stream_t stream) {
     if (!in || !packed_w || !out || n_in < 0 || n_out < 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || in_ld < c_in ||
         (residual && res_ld < c_out) || (!nbr && kv != 1) || out_col_group < 0 || (out_col_group > 0 && !out_row_map) ||
         out_ld < (out_col_group > 0 ? (out_col_group < c_out ? out_col_group : c_out) : c_out))
@@ -328,15 +500,23 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     p.in = in; p.w = packed_w; p.nbr = nbr; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
-    p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16;
+    p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
-    int ms, nt, veci;
-    plan_tile(n_out, c_in, c_out, in_ld, in, &ms, &nt, &veci);
-    const bool vec = veci != 0;
-    gc_kernel_t k = pick(ms, nt, vec);
+    GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
+    if (pl.use_wg) {
+        gc_kernel_t k = pick_tile(pl.a, pl.b);
+        if (!k) return CPD_ERR_UNSUPPORTED;
+        p.n_rb = (n_out + pl.a - 1) / pl.a;
+        p.n_cb = c_out / pl.b;
+        p.items = p.n_rb * p.n_cb;
+        size_t lds = 2 * (size_t)(pl.a + pl.b) * 128;
+        hipLaunchKernelGGL(k, dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        return cpd_check_launch();
+    }
+    gc_kernel_t k = pick(pl.a, pl.b, pl.vec != 0);
     if (!k) return CPD_ERR_UNSUPPORTED;
-    p.n_rb = (n_out + 16 * ms - 1) / (16 * ms);
-    p.n_cb = p.ntot / nt;
+    p.n_rb = (n_out + 16 * pl.a - 1) / (16 * pl.a);
+    p.n_cb = p.ntot / pl.b;
     p.items = p.n_rb * p.n_cb;
     int blocks = (p.items + 3) / 4;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, cpd_s(stream), p);

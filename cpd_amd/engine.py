@@ -280,9 +280,10 @@ class CenterPointEngine:
         return shape[0]
 
     # ------------------------------------------------------------------ forward pieces
-    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0):
+    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False):
         return ops.gather_conv(x, layer.c_in, layer.w, nbr, layer.kv, n_out, layer.c_out, layer.scale, layer.shift,
-                               residual, layer.relu, out=out, out_row_map=out_row_map, out_col_group=out_col_group)
+                               residual, layer.relu, out=out, out_row_map=out_row_map, out_col_group=out_col_group,
+                               dense=dense)
 
     def _blocks(self, blocks, x, nbr):
         n = x.shape[0]
@@ -357,21 +358,21 @@ class CenterPointEngine:
             else:
                 raise NotImplementedError("BEV stride pattern outside the shipped configs")
             n_lvl = batch * ho * wo
-            x = self._conv(convs[0], x, nbr0, n_lvl)
+            x = self._conv(convs[0], x, nbr0, n_lvl, dense=True)
             nbr_same = T["s1"][0] if (ho, wo) == (h, w) else T["s1_half"][0]
             for cv in convs[1:]:
-                x = self._conv(cv, x, nbr_same, n_lvl)
+                x = self._conv(cv, x, nbr_same, n_lvl, dense=True)
             cur_h, cur_w = ho, wo
             dst = cat[:, col:col + c_up]
             if u == 1:
-                self._conv(de, x, None, n_lvl, out=dst)
+                self._conv(de, x, None, n_lvl, out=dst, dense=True)
             elif u == 2 and (ho * 2, wo * 2) == (h, w):
-                self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up)
+                self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up, dense=True)
             else:
                 raise NotImplementedError("upsample stride outside the shipped configs")
             col += c_up
-        s = self._conv(self.shared, cat, T["s1"][0], n_full)
-        h1 = self._conv(self.head1, s, T["s1"][0], n_full)
+        s = self._conv(self.shared, cat, T["s1"][0], n_full, dense=True)
+        h1 = self._conv(self.head1, s, T["s1"][0], n_full, dense=True)
         out = torch.empty((n_full, self.head_ld), dtype=torch.float32, device=self.device)
         self._conv(self.head2, h1, T["s1"][0], n_full, out=out)
         return cat, out

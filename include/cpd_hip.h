@@ -116,16 +116,21 @@ int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *pack
  *                is written to row out_row_map[j]. With out_col_group = G > 0 the c_out columns
  *                are G-wide groups: column c of row j goes to row out_row_map[(c/G)*n_out + j],
  *                column c % G -- one launch computes the k*k taps of ConvTranspose2d(k, s=k)
- *                (base_bev_backbone.py:52-56) and interleaves them into the upsampled map.   */
+ *                (base_bev_backbone.py:52-56) and interleaves them into the upsampled map.
+ *   flags: 0 or CPD_GC_DENSE (a performance hint only; results are identical).               */
 int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float *packed_w,
                     const int32_t *nbr, int kv, int n_out, int c_out, const float *scale,
                     const float *shift, const float *residual, int res_ld, int relu, float *out,
-                    int out_ld, const int32_t *out_row_map, int out_col_group, cpd_stream_t stream);
+                    int out_ld, const int32_t *out_row_map, int out_col_group, int flags,
+                    cpd_stream_t stream);
+#define CPD_GC_DENSE 1 /* flags: the rulebook has (almost) no -1 entries -- prefer the LDS-tiled
+                          workgroup kernel over the tap-skipping wave kernel */
 
-/* Introspection for benchmarks/profilers: the wave tile (16*ms rows x 16*nt cols) and load path
- * (vec = 16-byte A pieces) cpd_gather_conv will pick for this problem, i.e. which instantiation
- * gather_conv_kernel<ms, nt, vec> runs. HOST only. */
-int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, int *ms, int *nt, int *vec);
+/* Introspection for benchmarks/profilers: which kernel instantiation cpd_gather_conv runs for
+ * this problem: wg=1 -> tile_conv_kernel<a,b> (a x b workgroup tile), wg=0 ->
+ * gather_conv_kernel<a,b,vec> ((16a) x (16b) wave tile; vec = 16-byte A pieces). HOST only.  */
+int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, int flags, int *wg, int *a,
+                         int *b, int *vec);
 
 /* SparseConvTensor.dense() + view(N, C*D, H, W) (height_compression.py:136-138).
  *   nchw: out (B, C*D, H, W), channel = c*D + z   -- the reference layout

@@ -56,10 +56,10 @@ def test_size_queries_and_error_codes():
     vs, pcr = _lib.farr([0.1, 0.1, 0.15]), _lib.farr([-75.2, -75.2, -2, 75.2, 75.2, 4])
     assert lib.cpd_voxelize_workspace_bytes(160000, 5, 1000000, vs, pcr) > 11 * 2 ** 20
     assert lib.cpd_index_bytes(1, _lib.iarr([41, 1504, 1504]), 100000) > 16 * 2 ** 20
-    assert lib.cpd_packed_weight_floats(27, 5, 16) == 27 * 1 * 4 * 1 * 64
+    assert lib.cpd_packed_weight_floats(27, 5, 16) == 27 * 1 * 4 * 16 * 4
     assert lib.cpd_nms_workspace_bytes(500) >= 500 * 8 * 8
     # bad arguments give error codes, never exit()
-    assert lib.cpd_gather_conv(None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, 0, 0, None, 0, None, 0, None) == -1
+    assert lib.cpd_gather_conv(None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 0, None) == -1
     assert lib.cpd_voxelize(None, -1, 5, vs, pcr, 5, 10, 0, 4, None, None, None, None, None, None, 0, None) == -1
     o = (ctypes.c_int32 * 3)()
     assert lib.cpd_conv_out_shape(_lib.iarr([1, 1, 1]), _lib.iarr([3, 3, 3]), _lib.iarr([2, 2, 2]), _lib.iarr([0, 0, 0]), o) == -1

@@ -126,3 +126,32 @@ def test_center_head_matches_reference_golden(hip, golden):
         hcur, _, _ = conv2d_hip(mid, b, h, w, g[p + "0.0.weight"], None, 1, s, t, True)
         out, _, _ = conv2d_hip(hcur, b, h, w, g[p + "1.weight"], g[p + "1.bias"], 1)
         np.testing.assert_allclose(rows_nchw(out, b, h, w), g["out." + name], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("bm,bn", [(64, 64), (64, 128), (128, 64), (128, 128)])
+def test_workgroup_kernel_matches_wave_kernel_and_oracle(oracle, hip, bm, bn, monkeypatch):
+    """tile_conv_kernel<BM,BN> (LDS-staged) against the oracle, incl. ragged row tails, stride 2,
+    BN-affine + ReLU epilogue and the deconv column-group scatter."""
+    rng = np.random.default_rng(bm + bn)
+    b, cin, cout, h, w = 2, 64, 128, 21, 19
+    x = rng.normal(size=(b, cin, h, w)).astype(np.float32)
+    wt = (rng.normal(size=(cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32); shift = rng.normal(size=cout).astype(np.float32)
+    monkeypatch.setenv("CPD_GC_WG", "1"); monkeypatch.setenv("CPD_GC_BM", str(bm)); monkeypatch.setenv("CPD_GC_BN", str(bn))
+    assert ops.gather_conv_tile(b * h * w, cin, cout, cin) == "tile_conv_kernel<%d,%d>" % (bm, bn)
+    for stride in (1, 2):
+        want = np.maximum(oracle.conv2d(x, wt, None, stride, 1) * scale[None, :, None, None] + shift[None, :, None, None], 0)
+        got, ho, wo = conv2d_hip(nhwc_rows(x), b, h, w, wt, None, stride, scale, shift, True)
+        np.testing.assert_allclose(rows_nchw(got, b, ho, wo), want, atol=1e-4, rtol=0)
+    # 1x1 with column groups (ConvTranspose2d k=s=2)
+    wd = (rng.normal(size=(cin, 64, 2, 2)) * 0.2).astype(np.float32)
+    want = oracle.deconv2d(x, wd, 2)
+    packed = ops.pack_weight(torch.from_numpy(wd).permute(0, 2, 3, 1).reshape(1, cin, 256).contiguous().cuda())
+    H, W = 2 * h, 2 * w
+    bi = torch.arange(b, device="cuda").view(-1, 1, 1); yy = torch.arange(h, device="cuda").view(1, -1, 1)
+    xx = torch.arange(w, device="cuda").view(1, 1, -1)
+    maps = torch.stack([((bi * H + 2 * yy + a) * W + 2 * xx + c).reshape(-1) for a in range(2) for c in range(2)])
+    out = torch.zeros((b * H * W, 64), device="cuda")
+    ops.gather_conv(nhwc_rows(x), cin, packed, None, 1, b * h * w, 256, out=out, out_row_map=maps.to(torch.int32).contiguous(),
+                    out_col_group=64)
+    np.testing.assert_allclose(rows_nchw(out, b, H, W), want, atol=1e-4, rtol=0)

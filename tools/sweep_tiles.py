@@ -24,10 +24,15 @@ SHAPES = [  # name, batch*h*w rows (h, w), c_in, c_out, k, stride
 ]
 
 
-def time_variant(x, cin, packed, nbr, kv, n_out, cout, ms, nt, iters=5):
-    os.environ["CPD_GC_MS"], os.environ["CPD_GC_NT"] = str(ms), str(nt)
-    got = ops.gather_conv_tile(n_out, cin, cout, x.stride(0))
-    if got[0] != ms or got[1] != nt:
+def time_variant(x, cin, packed, nbr, kv, n_out, cout, ms, nt, iters=5, wg=False):
+    if wg:
+        os.environ["CPD_GC_WG"], os.environ["CPD_GC_BM"], os.environ["CPD_GC_BN"] = "1", str(ms), str(nt)
+        want = "tile_conv_kernel<%d,%d>" % (ms, nt)
+    else:
+        os.environ["CPD_GC_WG"] = "0"
+        os.environ["CPD_GC_MS"], os.environ["CPD_GC_NT"] = str(ms), str(nt)
+        want = "gather_conv_kernel<%d,%d,true>" % (ms, nt)
+    if ops.gather_conv_tile(n_out, cin, cout, x.stride(0)) != want:
         return None
     out = torch.empty((n_out, cout), device="cuda")
     ops.gather_conv(x, cin, packed, nbr, kv, n_out, cout, out=out)
@@ -62,10 +67,15 @@ def main():
                     t = time_variant(x, cin, packed, nbr, kv, n_out, cout, ms, nt)
                     if t is not None:
                         res["%d,%d" % (ms, nt)] = [round(t * 1e3, 1), round(flops / t / 1e9, 1)]
+            for bm in (64, 128):
+                for bn in (64, 128):
+                    t = time_variant(x, cin, packed, nbr, kv, n_out, cout, bm, bn, wg=True)
+                    if t is not None:
+                        res["wg%dx%d" % (bm, bn)] = [round(t * 1e3, 1), round(flops / t / 1e9, 1)]
             best = max(res.items(), key=lambda kv_: kv_[1][1])
             print(json.dumps({"shape": name, "batch": batch, "n_out": n_out, "gflop": round(flops / 1e9, 2), "best": best,
                               "us_tflops": res}), flush=True)
-    os.environ.pop("CPD_GC_MS"), os.environ.pop("CPD_GC_NT")
+    
 
 
 if __name__ == "__main__":
