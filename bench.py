@@ -28,7 +28,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from cpd_amd import ops  # noqa: E402
+from cpd_amd import dist_utils, ops  # noqa: E402
 from cpd_amd.engine import CenterPointEngine, ModelConfig, init_state_dict  # noqa: E402
 from cpd_amd.synthetic import waymo_cloud  # noqa: E402
 
@@ -42,9 +42,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1, help="frames per step per GPU")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent frames in flight per GPU (worker threads, "
+                    "one HIP stream + engine workspace each)")
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print a per-launch table of the conv kernels (stderr)")
     return ap.parse_args()
 
 
@@ -120,44 +123,59 @@ def cpu_baseline(cfg, sd, points_np):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = dist_utils.env_rank()
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    distributed = dist_utils.init("nccl", torch.device("cuda", local))   # "nccl" is RCCL on ROCm
 
     cfg = ModelConfig()
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
-    eng = CenterPointEngine(cfg, sd, device="cuda:%d" % local)
-    clouds_np = [waymo_cloud(rank * POOL + i, n_points=args.points) for i in range(POOL)]
+    dev = "cuda:%d" % local
+    S = max(1, args.streams)
+    engines = [CenterPointEngine(cfg, sd, device=dev) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    eng = engines[0]
+    clouds_np = [waymo_cloud(sd_, n_points=args.points) for sd_ in dist_utils.frame_seeds(rank, POOL)]
     clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
     B = args.frames
+    torch.cuda.synchronize()
 
-    def step(i):
-        return eng.forward([clouds[(i * B + j) % POOL] for j in range(B)])
+    def step(i, w=0):
+        return engines[w].forward([clouds[(i * B + j) % POOL] for j in range(B)])
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def run_steps(n):
+        """n steps, dealt round-robin to S worker threads; each worker owns a HIP stream, an engine
+        workspace and its frames' host-side count reads, so latency-bound phases of one frame
+        (voxelizer, rulebooks, decode, NMS, count syncs) overlap the MFMA phases of the others."""
+        if S == 1:
+            for i in range(n):
+                step(i)
+            return
+        import threading
 
-    for i in range(args.warmup):
-        step(i)
+        def worker(w):
+            torch.cuda.set_device(local)
+            with torch.cuda.stream(streams[w]):
+                for i in range(w, n, S):
+                    step(i, w)
+                streams[w].synchronize()
+
+        ts = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    barrier = dist_utils.barrier
+
+    run_steps(args.warmup)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device="cuda" if distributed else "cpu")
 
     out = {
         "metric": "frames/sec voxelize->sparse3D->BEV->NMS, 160k-pt Waymo cloud",
@@ -166,7 +184,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: Waymo-shape %d-point cloud, CPD VoxelResBackBone8x + HeightCompression + "
                                "BaseBEVBackbone + CenterHead + rotated NMS, forward-only" % args.points,
-                   "frames_per_step_per_gpu": B, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
+                   "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
                    "parallelism": "frame-sharded replicas x%d, no data-path collective" % world,
                    "weights": "random-init (seed 0), eval-mode BN folded"},
     }
@@ -177,6 +195,13 @@ def main():
             for i in range(n_prof):
                 step(i)
             agg, conv_ms = prof.summary()
+            if args.layers and rank == 0:
+                per = len(prof.records) // n_prof
+                for kname, flops, e0, e1, shp in prof.records[-per:]:
+                    ms = e0.elapsed_time(e1)
+                    dense_fl = 2.0 * shp[0] * shp[3] * shp[1] * shp[2]
+                    print("%-34s n_out %7d  %3d->%4d kv %2d  %8.1f us  useful %6.1f TF  density %.2f" %
+                          (kname, shp[0], shp[1], shp[2], shp[3], ms * 1e3, flops / ms / 1e9, flops / dense_fl), file=sys.stderr)
         key, (flops, ms, launches) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12
         out["roofline"] = {
@@ -194,8 +219,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    dist_utils.shutdown()
 
 
 if __name__ == "__main__":

@@ -408,7 +408,7 @@ static gc_kernel_t pick_tile(int bm, int bn) {
 // only needs one wave per SIMD, so what matters first is having >= ~4 wave tiles per SIMD (4096
 // items) to keep 256 CUs x 4 SIMDs evenly loaded; take the largest tile that still gives that.
 static void choose_wave_tile(int n_out, int ntot, int *ms_out, int *nt_out) {
-    static const int cand[][2] = {{2, 8}, {4, 4}, {2, 5}, {2, 4}, {2, 2}, {1, 4}, {1, 5}, {1, 2}, {2, 1}, {1, 1}};
+    static const int cand[][2] = {{2, 4}, {2, 5}, {2, 2}, {1, 4}, {1, 5}, {1, 2}, {2, 1}, {1, 1}};
     const long long want = 4096;
     int best_ms = 1, best_nt = 1;
     long long best_items = -1;
@@ -423,20 +423,14 @@ static void choose_wave_tile(int n_out, int ntot, int *ms_out, int *nt_out) {
     *nt_out = best_nt;
 }
 
-// Workgroup tile for the dense path: largest BM x BN (BN | c_out) with >= 1024 workgroups
-// (4 per CU); 0 x 0 = use the wave kernel.
+// Workgroup tile for the dense path (measured): 64 x 128 (else 64 x 64) once there are >= 2048
+// workgroups (8 per CU); below that the wave kernel's finer items balance the chip better.
 static void choose_wg_tile(int n_out, int c_in, int c_out, int *bm_out, int *bn_out) {
     *bm_out = *bn_out = 0;
     if (c_in % 32 || c_out % 64) return;
-    static const int cand[][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-    long long best_items = -1;
-    for (auto &c : cand) {
-        int bm = c[0], bn = c[1];
-        if (c_out % bn) continue;
-        long long items = (long long)((n_out + bm - 1) / bm) * (c_out / bn);
-        if (items >= 1024) { *bm_out = bm; *bn_out = bn; return; }
-        if (items > best_items) { best_items = items; *bm_out = bm; *bn_out = bn; }
-    }
+    const int bn = (c_out % 128 == 0) ? 128 : 64;
+    long long items = (long long)((n_out + 63) / 64) * (c_out / bn);
+    if (items >= 2048) { *bm_out = 64; *bn_out = bn; }
 }
 
 struct GcPlan {
@@ -454,6 +448,7 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
     if (((flags & 1) && force_wg != 0) || force_wg > 0) {
         int bm, bn;
         choose_wg_tile(n_out, c_in, c_out, &bm, &bn);
+        if (force_wg > 0 && !bm && c_in % 32 == 0 && c_out % 64 == 0) { bm = 64; bn = 64; }
         if (const char *e = getenv("CPD_GC_BM")) { int v = atoi(e); if ((v == 64 || v == 128) && bm) bm = v; }
         if (const char *e = getenv("CPD_GC_BN")) { int v = atoi(e); if ((v == 64 || v == 128) && bn && c_out % v == 0) bn = v; }
         if (bm && bn && pl.vec) { pl.use_wg = 1; pl.a = bm; pl.b = bn; return pl; }

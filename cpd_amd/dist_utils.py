@@ -1,0 +1,54 @@
+"""One-process-per-GPU helpers for the frame-sharded multi-GPU path (bench.py, N > 1).
+
+The forward path shards by FRAME (every stage is per batch element: SURVEY 8e), so there is no
+data-path collective: ranks only meet at the timing barrier and at the max-over-ranks of the
+elapsed time. Backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU for the tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend="nccl", device=None):
+    rank, world, _ = env_rank()
+    if world == 1:
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return True
+
+
+def frame_seeds(rank, pool):
+    """Disjoint synthetic-frame seeds per rank: rank r owns frames [r*pool, (r+1)*pool)."""
+    return [rank * pool + i for i in range(pool)]
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_throughput(units_per_rank, elapsed_local, device="cpu"):
+    """Whole-job units/s: all ranks' units over the slowest rank's time."""
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return world * units_per_rank / max_over_ranks(elapsed_local, device)
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

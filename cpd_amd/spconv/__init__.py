@@ -1,0 +1,28 @@
+"""Drop-in for the subset of `spconv` (spconv-cu111==2.1.22) that CPD imports, backed by the HIP
+kernels of this package. `cpd/utils/spconv_utils.py:34-36` does `import spconv.pytorch as spconv`;
+`cpd_amd.spconv.install()` registers these modules under the `spconv` / `cumm` names so the
+reference files import unchanged."""
+import sys
+import types
+
+from . import pytorch  # noqa: F401
+from . import utils  # noqa: F401
+from .pytorch import (SparseConv3d, SparseConvTensor, SparseInverseConv3d, SparseModule,  # noqa: F401
+                      SparseSequential, SubMConv3d)
+
+__version__ = "2.1.22+cpd_amd"
+
+
+def install():
+    """Make `import spconv`, `import spconv.pytorch`, `from spconv.pytorch.utils import PointToVoxel`,
+    `from spconv.utils import Point2VoxelCPU3d` and `import cumm.tensorview as tv` resolve to this
+    package (only if the real spconv is absent)."""
+    me = sys.modules[__name__]
+    for name, mod in {"spconv": me, "spconv.pytorch": pytorch, "spconv.pytorch.conv": pytorch.conv,
+                      "spconv.pytorch.utils": pytorch.utils, "spconv.utils": utils}.items():
+        sys.modules.setdefault(name, mod)
+    cumm = types.ModuleType("cumm")
+    cumm.tensorview = utils.tensorview
+    sys.modules.setdefault("cumm", cumm)
+    sys.modules.setdefault("cumm.tensorview", utils.tensorview)
+    return me

@@ -1,0 +1,43 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the frame sharding + barrier + max-over-ranks timing
+that bench.py uses with RCCL on the GPUs (no data-path collective exists to test)."""
+import os
+import socket
+
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from cpd_amd import dist_utils as du
+    assert du.init("gloo")
+    seeds = du.frame_seeds(rank, 4)
+    du.barrier()
+    elapsed = 1.0 + rank            # rank 1 is the slow one
+    mx = du.max_over_ranks(elapsed)
+    thr = du.aggregate_throughput(units_per_rank=10, elapsed_local=elapsed)
+    du.barrier()
+    q.put((rank, seeds, mx, thr))
+    du.shutdown()
+
+
+def test_two_rank_frame_sharding_and_timing():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, s0, m0, t0), (r1, s1, m1, t1) = out
+    assert set(s0).isdisjoint(s1) and len(s0) == len(s1) == 4      # disjoint frame shards
+    assert m0 == m1 == 2.0                                          # max over ranks
+    assert abs(t0 - 10.0) < 1e-9 and t0 == t1                       # 2 ranks * 10 units / 2.0 s

@@ -86,3 +86,40 @@ def test_full_size_properties(hip):
     rb = eng.forward([p1, p0])
     np.testing.assert_allclose(rb[1]["pred_boxes"].cpu().numpy(), r0[0]["pred_boxes"].cpu().numpy(), atol=1e-4)
     np.testing.assert_array_equal(rb[1]["pred_labels"].cpu().numpy(), r0[0]["pred_labels"].cpu().numpy())
+
+
+def test_module_api_matches_engine(oracle, hip):
+    """The un-fused drop-in modules (cpd_amd.models, reference batch_dict contract) and the fused
+    engine give the same detections from the same reference-named weights; the numpy
+    VoxelGeneratorWrapper mirror reproduces the oracle's voxels."""
+    from cpd_amd import models
+    from cpd_amd.voxel_generator import VoxelGeneratorWrapper
+    cfg = small_cfg()
+    cfg.bev_layer_nums = [5, 5]
+    mcfg = models.waymo_centerpoint_cfg()
+    mcfg.BACKBONE_2D.NUM_FILTERS = cfg.bev_num_filters
+    mcfg.BACKBONE_2D.NUM_UPSAMPLE_FILTERS = cfg.bev_num_upsample_filters
+    mcfg.DENSE_HEAD.POST_PROCESSING.POST_CENTER_LIMIT_RANGE = cfg.post_center_limit_range
+    mcfg.DENSE_HEAD.POST_PROCESSING.MAX_OBJ_PER_SAMPLE = cfg.max_obj_per_sample
+    net = models.CenterPoint(mcfg, point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size).cuda().eval()
+    sd = init_state_dict(cfg, seed=5)
+    net.load_state_dict(sd)
+    pts = waymo_cloud(2, n_points=40000)
+    pts[:, :2] *= 0.3
+    gen = VoxelGeneratorWrapper(cfg.voxel_size, cfg.point_cloud_range, 5, cfg.max_points_per_voxel, cfg.max_voxels)
+    voxels, coords, num = gen.generate(pts)
+    v0, c0, n0 = oracle.voxelize(pts, cfg.voxel_size, cfg.point_cloud_range, cfg.max_points_per_voxel, cfg.max_voxels)
+    np.testing.assert_array_equal(coords, c0); np.testing.assert_array_equal(voxels, v0); np.testing.assert_array_equal(num, n0)
+    # collate_batch pad + load_data_to_gpu's float cast (dataset.py:264, models/__init__.py:24)
+    batch = {"voxels": torch.from_numpy(voxels).cuda(), "voxel_num_points": torch.from_numpy(num).float().cuda(),
+             "voxel_coords": torch.from_numpy(np.pad(coords, ((0, 0), (1, 0)))).float().cuda(), "batch_size": 1}
+    with torch.no_grad():
+        pred, _ = net(batch)
+    eng = net.to_engine()
+    res = eng.forward([torch.from_numpy(pts).cuda()])
+    assert pred[0]["pred_boxes"].shape == res[0]["pred_boxes"].shape
+    np.testing.assert_array_equal(pred[0]["pred_labels"].cpu().numpy(), res[0]["pred_labels"].cpu().numpy())
+    np.testing.assert_allclose(pred[0]["pred_scores"].cpu().numpy(), res[0]["pred_scores"].cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(pred[0]["pred_boxes"].cpu().numpy(), res[0]["pred_boxes"].cpu().numpy(), atol=1e-3, rtol=1e-4)
+    assert batch["spatial_features"].shape[1] == 256 and batch["encoded_spconv_tensor_stride"] == 8
+    assert set(batch["multi_scale_3d_features"]) == {"x_conv1", "x_conv2", "x_conv3", "x_conv4"}
