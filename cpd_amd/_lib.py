@@ -34,14 +34,14 @@ SIGNATURES = {
     "cpd_voxelize": (_I, [_VP, _I, _I, _FP, _FP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_index_bytes": (_SZ, [_I, _I3, _I]),
     "cpd_index_build": (_I, [_VP, _I, _I, _I3, _VP, _SZ, _VP]),
-    "cpd_rulebook_subm": (_I, [_VP, _I, _I, _I3, _I3, _VP, _VP, _VP]),
+    "cpd_rulebook_subm": (_I, [_VP, _I, _I, _I3, _I3, _VP, _VP, _VP, _VP]),
     "cpd_conv_out_shape": (_I, [_I3, _I3, _I3, _I3, _I3]),
     "cpd_conv_outset": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _SZ, _VP, _VP]),
     "cpd_index_emit": (_I, [_VP, _I, _I3, _VP, _I, _VP]),
-    "cpd_rulebook_conv": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _VP, _VP]),
+    "cpd_rulebook_conv": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _VP, _VP, _VP]),
     "cpd_packed_weight_floats": (_SZ, [_I, _I, _I]),
     "cpd_pack_weight": (_I, [_VP, _I, _I, _I, _VP, _VP]),
-    "cpd_gather_conv": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _I, _VP]),
+    "cpd_gather_conv": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _I, _VP]),
     "cpd_gather_conv_tile": (_I, [_I, _I, _I, _I, _I] + [ctypes.POINTER(_I)] * 4),
     "cpd_densify_nchw": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_densify_nhwc": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),

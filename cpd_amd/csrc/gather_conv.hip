@@ -45,13 +45,14 @@ struct GcParams {
     const float *in;
     const float *w;
     const int32_t *nbr;
+    const uint32_t *tapmask;  // per 16-row sub-tile: bit t = some row has a neighbour at tap t (or NULL)
     const float *scale, *shift, *residual;
     float *out;
     const int32_t *out_row_map;
     int in_ld, c_in, kc;  // kc = 16-channel chunks
     int kv, n_out, c_out, ntot, np;  // np = padded columns (16*ntot)
     int res_ld, relu, out_ld, col_group;
-    int n_rb, n_cb, items;
+    int n_rb, n_cb, items, n_sub;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -121,56 +122,32 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
 }
 
 // ================================== wave kernel ==============================================
-template <int MS, int NT, bool VEC, unsigned MASK>
-struct TapRegs {
+// One pipeline step = (tap t, 16-channel chunk kc) of this wave's tile. Two register sets ping-pong
+// over the FLAT sequence of steps of all ACTIVE taps (no copies, no per-tap bubble): while one
+// set's MFMAs issue, the next step's A pieces, B pieces and -- a tap ahead -- its rulebook column
+// are in flight behind a counted vmcnt. Which taps are active for which 16-row sub-tile comes from
+// the rulebook's tap mask (one word per sub-tile), so inactive (sub-tile, tap) pairs cost nothing.
+template <int MS, int NT>
+struct StepRegs {
     f32x4 a[MS];
     f32x4 b[NT];  // b[nt][q]
-    // wk points at P[t][kc][g][col0 + j][0] for this lane
-    __device__ __forceinline__ void load(const GcParams &p, const int (&idx)[MS], const float *wk, int kc, int g) {
-#pragma unroll
-        for (int s = 0; s < MS; ++s)
-            if (MASK & (1u << s)) {
-                if (CPD_GC_ABLATE & 2) a[s] = f32x4{(float)g, 1.f, (float)kc, 2.f};
-                else a[s] = load_a<VEC>(p, idx[s], kc * 16 + 4 * g);
-            }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (CPD_GC_ABLATE & 1) b[nt] = f32x4{(float)nt, 1.f, (float)g, 2.f};
-            else b[nt] = *reinterpret_cast<const f32x4 *>(wk + (size_t)nt * 64);
-        }
-    }
-    __device__ __forceinline__ void mma(const int (&idx)[MS], f32x4 (&acc)[MS][NT]) {
-#pragma unroll
-        for (int s = 0; s < MS; ++s)
-            if (MASK & (1u << s)) a[s] = zero_if(a[s], idx[s] < 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int s = 0; s < MS; ++s)
-                    if (MASK & (1u << s))
-                        acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][q], b[nt][q], acc[s][nt], 0, 0, 0);
-    }
+    int idx[MS];
+    unsigned act;  // sub-tiles with at least one neighbour at this step's tap
 };
 
-// One tap for the row sub-tiles in MASK. Two register sets ping-pong over the 16-channel chunks
-// (no copies), so the next chunk's A and B pieces stay in flight under the current chunk's MFMAs
-// behind a counted vmcnt.
-template <int MS, int NT, bool VEC, unsigned MASK>
-__device__ __forceinline__ void tap_compute(const GcParams &p, const int (&idx)[MS], const float *wt, int g,
-                                            f32x4 (&acc)[MS][NT]) {
-    TapRegs<MS, NT, VEC, MASK> r0, r1;
-    const size_t kstride = (size_t)4 * p.np * 4;  // floats per 16-channel chunk of P
-    r0.load(p, idx, wt, 0, g);
-    int kc = 0;
-    for (; kc + 1 < p.kc; kc += 2) {
-        r1.load(p, idx, wt + (size_t)(kc + 1) * kstride, kc + 1, g);
-        r0.mma(idx, acc);
-        if (kc + 2 < p.kc) r0.load(p, idx, wt + (size_t)(kc + 2) * kstride, kc + 2, g);
-        r1.mma(idx, acc);
-    }
-    if (kc < p.kc) r0.mma(idx, acc);
+template <int MS, int NT, unsigned MASK>
+__device__ __forceinline__ void step_mma(StepRegs<MS, NT> &R, f32x4 (&acc)[MS][NT]) {
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+        if (MASK & (1u << s)) R.a[s] = zero_if(R.a[s], R.idx[s] < 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < MS; ++s)
+                if (MASK & (1u << s))
+                    acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.a[s][q], R.b[nt][q], acc[s][nt], 0, 0, 0);
 }
 
 template <int MS, int NT, bool VEC>
@@ -190,8 +167,6 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const size_t w_tap = (size_t)p.kc * 4 * p.np * 4;
-    // Rulebook column of this wave's rows, fetched one tap ahead (unconditional, clamped loads).
     int rowc[MS];
     bool rowok[MS];
 #pragma unroll
@@ -200,33 +175,102 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
         rowok[s] = row < p.n_out;
         rowc[s] = rowok[s] ? row : p.n_out - 1;
     }
-    int idx_nxt[MS];
+    // tap activity of each 16-row sub-tile (wave-uniform); without a mask every tap is active
+    const unsigned all_taps = p.kv >= 32 ? 0xffffffffu : ((1u << p.kv) - 1u);
+    unsigned tm[MS];
+    unsigned any = 0;
 #pragma unroll
-    for (int s = 0; s < MS; ++s) idx_nxt[s] = p.nbr ? p.nbr[rowc[s]] : rowc[s];
-    for (int t = 0; t < p.kv; ++t) {
-        int idx[MS];
-        unsigned active = 0;
-#pragma unroll
-        for (int s = 0; s < MS; ++s) {
-            const int v = rowok[s] ? idx_nxt[s] : -1;
-            idx[s] = v;
-            if (__ballot(v >= 0)) active |= 1u << s;
+    for (int s = 0; s < MS; ++s) {
+        unsigned m = all_taps;
+        if (p.tapmask) {
+            const int st = (row0 >> 4) + s;
+            m = st < p.n_sub ? p.tapmask[st] : 0u;
+        } else if (row0 + 16 * s >= p.n_out) {
+            m = 0u;
         }
-        if (t + 1 < p.kv) {
+        tm[s] = __builtin_amdgcn_readfirstlane(m);
+        any |= tm[s];
+    }
+    auto next_tap = [&](int t) -> int {  // next active tap after t, or -1
+        const unsigned m = t >= 31 ? 0u : (any & ~((2u << t) - 1u));
+        return m ? __builtin_ctz(m) : -1;
+    };
+    auto act_of = [&](int t) -> unsigned {
+        unsigned a = 0;
 #pragma unroll
-            for (int s = 0; s < MS; ++s) idx_nxt[s] = p.nbr[(size_t)(t + 1) * p.n_out + rowc[s]];
+        for (int s = 0; s < MS; ++s) a |= ((tm[s] >> t) & 1u) << s;
+        return a;
+    };
+    // The rulebook columns of this wave's rows for all taps go to LDS once (one round of
+    // independent loads); the pipeline then reads them with ds_read, which keeps every global load
+    // inside it unconditional and counted on vmcnt alone.
+    __shared__ int s_idx[4][32][16 * MS];
+    {
+        const int total = p.kv * 16 * MS;
+        for (int e = lane; e < total; e += 64) {
+            const int t = e / (16 * MS), rr = e - t * (16 * MS);
+            const int row = row0 + rr;
+            int v = -1;
+            if (row < p.n_out) v = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
+            s_idx[wave][t][rr] = v;
         }
-        if (!active) continue;  // no row of this tile has a neighbour at tap t
-        const float *wt = p.w + (size_t)t * w_tap + ((size_t)g * p.np + col0 + r) * 4;
-        if constexpr (MS == 1) {
-            tap_compute<MS, NT, VEC, 1u>(p, idx, wt, g, acc);
-        } else if constexpr (MS == 2) {
-            // exact 16-row skipping: only the sub-tiles that have a neighbour issue MFMAs
-            if (active == 3u) tap_compute<MS, NT, VEC, 3u>(p, idx, wt, g, acc);
-            else if (active == 1u) tap_compute<MS, NT, VEC, 1u>(p, idx, wt, g, acc);
-            else tap_compute<MS, NT, VEC, 2u>(p, idx, wt, g, acc);
-        } else {
-            tap_compute<MS, NT, VEC, (1u << MS) - 1u>(p, idx, wt, g, acc);
+    }
+    (void)rowc; (void)rowok;
+
+    int t_cur = any ? __builtin_ctz(any) : -1;
+    if (t_cur >= 0) {
+        const size_t w_chunk = (size_t)4 * p.np * 4;  // floats per 16-channel chunk of P
+        const float *wl = p.w + ((size_t)g * p.np + col0 + r) * 4;
+        int kc_cur = 0;
+        int t_ld = t_cur;  // tap the load cursor points at (stays valid after the last step)
+
+        StepRegs<MS, NT> R0, R1;
+        auto load = [&](StepRegs<MS, NT> &R) {
+            R.act = act_of(t_ld);
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                R.idx[s] = s_idx[wave][t_ld][16 * s + r];
+                if (CPD_GC_ABLATE & 2) R.a[s] = f32x4{(float)g, 1.f, (float)kc_cur, 2.f};
+                else R.a[s] = load_a<VEC>(p, R.idx[s], kc_cur * 16 + 4 * g);
+            }
+            const float *wk = wl + ((size_t)t_ld * p.kc + kc_cur) * w_chunk;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (CPD_GC_ABLATE & 1) R.b[nt] = f32x4{(float)nt, 1.f, (float)g, 2.f};
+                else R.b[nt] = *reinterpret_cast<const f32x4 *>(wk + (size_t)nt * 64);
+            }
+        };
+        // move the load cursor to the next (tap, chunk); t_cur = -1 once the last step is loaded
+        // (the cursor then keeps pointing at valid memory: the trailing load is a harmless dummy)
+        auto advance = [&]() {
+            if (++kc_cur == p.kc) {
+                kc_cur = 0;
+                t_cur = next_tap(t_cur);
+                if (t_cur >= 0) t_ld = t_cur;
+            }
+        };
+        auto mma = [&](StepRegs<MS, NT> &R) {
+            if constexpr (MS == 1) {
+                step_mma<MS, NT, 1u>(R, acc);
+            } else if constexpr (MS == 2) {
+                if (R.act == 3u) step_mma<MS, NT, 3u>(R, acc);
+                else if (R.act == 1u) step_mma<MS, NT, 1u>(R, acc);
+                else step_mma<MS, NT, 2u>(R, acc);
+            } else {
+                step_mma<MS, NT, (1u << MS) - 1u>(R, acc);
+            }
+        };
+
+        load(R0);
+        while (true) {
+            advance();
+            load(R1);
+            mma(R0);
+            if (t_cur < 0) break;
+            advance();
+            load(R0);
+            mma(R1);
+            if (t_cur < 0) break;
         }
     }
     epilogue<MS, NT>(p, acc, row0, col0, r, g);
@@ -483,16 +527,16 @@ extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, i
 }
 
 extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
-                               int kv, int n_out, int c_out, const float *scale, const float *shift,
+                               const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
                                const float *residual, int res_ld, int relu, float *out, int out_ld,
                                const int32_t *out_row_map, int out_col_group, int flags, cpd_stream_t stream) {
     if (!in || !packed_w || !out || n_in < 0 || n_out < 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || in_ld < c_in ||
-        (residual && res_ld < c_out) || (!nbr && kv != 1) || out_col_group < 0 || (out_col_group > 0 && !out_row_map) ||
+        (residual && res_ld < c_out) || (!nbr && kv != 1) || (tapmask && kv > 32) || out_col_group < 0 || (out_col_group > 0 && !out_row_map) ||
         out_ld < (out_col_group > 0 ? (out_col_group < c_out ? out_col_group : c_out) : c_out))
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
     GcParams p;
-    p.in = in; p.w = packed_w; p.nbr = nbr; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.in = in; p.w = packed_w; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;

@@ -129,13 +129,17 @@ struct EmitFn {  // write the coordinates of every set bit in canonical order
 __global__ void __launch_bounds__(256)
 rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd, int kh, int kw, int sd, int sh, int sw,
                 int pd, int ph, int pw, const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
-                const int32_t *__restrict__ perm_in, const int32_t *__restrict__ flags, int32_t *__restrict__ nbr) {
+                const int32_t *__restrict__ perm_in, const int32_t *__restrict__ flags, int32_t *__restrict__ nbr,
+                uint32_t *__restrict__ tapmask) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_out) return;
+    const bool live = j < n_out;
+    if (!live) j = n_out - 1;  // keep whole waves alive for the ballots below
     // flags[0] != 0: arbitrary-order site list, row id = perm[rank]; 0: canonical list, row id = rank
     const int32_t *perm = flags[0] ? perm_in : nullptr;
     int4 q = reinterpret_cast<const int4 *>(out_idx)[j];
     int t = 0;
+    uint32_t my_mask = 0;  // lanes 0..3 of a wave collect the tap masks of its four 16-row sub-tiles
+    const int lane = threadIdx.x & 63;
     for (int tz = 0; tz < kd; ++tz) {
         int z = q.y * sd - pd + tz;
         for (int ty = 0; ty < kh; ++ty) {
@@ -146,9 +150,15 @@ rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd
                 if ((unsigned)z < (unsigned)gin.d && (unsigned)y < (unsigned)gin.h && (unsigned)x < (unsigned)gin.w &&
                     (unsigned)q.x < (unsigned)gin.b)
                     r = site_lookup(bitmap, base, perm, gin.key(q.x, z, y, x));
-                nbr[(size_t)t * n_out + j] = r;
+                if (live) nbr[(size_t)t * n_out + j] = r;
+                const unsigned long long hit = __ballot(live && r >= 0);
+                if (lane < 4 && t < 32 && ((hit >> (16 * lane)) & 0xffffull)) my_mask |= 1u << t;
             }
         }
+    }
+    if (tapmask && lane < 4) {
+        const int sub = ((blockIdx.x * blockDim.x + (threadIdx.x & ~63)) >> 4) + lane;
+        if (sub < (n_out + 15) / 16) tapmask[sub] = my_mask;
     }
 }
 
@@ -276,36 +286,39 @@ extern "C" int cpd_conv_out_shape(const int32_t in_shape[3], const int32_t ksize
 }
 
 static int rulebook_launch(const int32_t *out_idx, int n_out, int batch, const int32_t in_shape[3], const int32_t k[3],
-                           const int32_t st[3], const int32_t pd[3], const void *index, int32_t *nbr, hipStream_t s) {
+                           const int32_t st[3], const int32_t pd[3], const void *index, int32_t *nbr, uint32_t *tapmask,
+                           hipStream_t s) {
     // the index was carved with some capacity; pointers before perm do not depend on it
     IndexView v = index_carve(const_cast<void *>(index), batch, in_shape, 1);
     Grid g{batch, in_shape[0], in_shape[1], in_shape[2]};
     if (n_out > 0)
         rulebook_kernel<<<cpd_div_up(n_out, 256), 256, 0, s>>>(out_idx, n_out, g, k[0], k[1], k[2], st[0], st[1], st[2],
                                                                pd[0], pd[1], pd[2], v.bitmap, v.base,
-                                                               v.perm, v.flags, nbr);
+                                                               v.perm, v.flags, nbr,
+                                                               (k[0] * k[1] * k[2] <= 32) ? tapmask : nullptr);
     return cpd_check_launch();
 }
 
 extern "C" int cpd_rulebook_subm(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3],
-                                 const int32_t ksize[3], const void *index, int32_t *nbr, cpd_stream_t stream) {
+                                 const int32_t ksize[3], const void *index, int32_t *nbr, uint32_t *tapmask,
+                                 cpd_stream_t stream) {
     if (!valid_shape(batch, shape_zyx) || n < 0 || !ksize || !index || (n > 0 && (!indices || !nbr))) return CPD_ERR_ARG;
     for (int d = 0; d < 3; ++d)
         if (ksize[d] <= 0 || !(ksize[d] & 1)) return CPD_ERR_ARG;
     const int32_t one[3] = {1, 1, 1};
     const int32_t pad[3] = {ksize[0] / 2, ksize[1] / 2, ksize[2] / 2};
-    return rulebook_launch(indices, n, batch, shape_zyx, ksize, one, pad, index, nbr, cpd_s(stream));
+    return rulebook_launch(indices, n, batch, shape_zyx, ksize, one, pad, index, nbr, tapmask, cpd_s(stream));
 }
 
 extern "C" int cpd_rulebook_conv(const int32_t *out_indices, int n_out, int batch, const int32_t in_shape[3],
                                  const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3],
-                                 const void *in_index, int32_t *nbr, cpd_stream_t stream) {
+                                 const void *in_index, int32_t *nbr, uint32_t *tapmask, cpd_stream_t stream) {
     int32_t os[3];
     if (!valid_shape(batch, in_shape) || n_out < 0 || !in_index || (n_out > 0 && (!out_indices || !nbr)))
         return CPD_ERR_ARG;
     int rc = cpd_conv_out_shape(in_shape, ksize, stride, pad, os);
     if (rc) return rc;
-    return rulebook_launch(out_indices, n_out, batch, in_shape, ksize, stride, pad, in_index, nbr, cpd_s(stream));
+    return rulebook_launch(out_indices, n_out, batch, in_shape, ksize, stride, pad, in_index, nbr, tapmask, cpd_s(stream));
 }
 
 extern "C" int cpd_conv_outset(const int32_t *in_indices, int n_in, int batch, const int32_t in_shape[3],

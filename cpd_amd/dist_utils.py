@@ -18,10 +18,9 @@ def init(backend="nccl", device=None):
     if world == 1:
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    kw = {}
-    if backend == "nccl" and device is not None:
-        kw["device_id"] = device
-    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    # lazy communicator creation (no device_id): the first collective binds each rank to the GPU
+    # selected with torch.cuda.set_device(LOCAL_RANK)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     return True
 
 

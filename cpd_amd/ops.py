@@ -98,13 +98,21 @@ class SiteIndex:
         return idx
 
 
+def _new_tapmask(n, kv, device):
+    if kv > 32 or n == 0:
+        return None
+    return torch.empty(((n + 15) // 16,), dtype=torch.int32, device=device)
+
+
 def rulebook_subm(indices, index, ksize=(3, 3, 3)):
     indices = indices.contiguous()
     n = indices.shape[0]
     kv = int(ksize[0] * ksize[1] * ksize[2])
     nbr = torch.empty((kv, n), dtype=torch.int32, device=indices.device)
+    tapmask = _new_tapmask(n, kv, indices.device)
     check(lib().cpd_rulebook_subm(ptr(indices), n, index.batch, iarr(index.shape), iarr(ksize), ptr(index.buf),
-                                  ptr(nbr), stream()), "cpd_rulebook_subm")
+                                  ptr(nbr), ptr(tapmask), stream()), "cpd_rulebook_subm")
+    nbr.tapmask = tapmask      # travels with the table; cpd_gather_conv skips empty (row group, tap) pairs with it
     return nbr
 
 
@@ -136,8 +144,11 @@ def rulebook_conv(out_indices, in_index, ksize, stride, pad):
     n_out = out_indices.shape[0]
     kv = int(ksize[0] * ksize[1] * ksize[2])
     nbr = torch.empty((kv, n_out), dtype=torch.int32, device=out_indices.device)
+    tapmask = _new_tapmask(n_out, kv, out_indices.device)
     check(lib().cpd_rulebook_conv(ptr(out_indices), n_out, in_index.batch, iarr(in_index.shape), iarr(ksize),
-                                  iarr(stride), iarr(pad), ptr(in_index.buf), ptr(nbr), stream()), "cpd_rulebook_conv")
+                                  iarr(stride), iarr(pad), ptr(in_index.buf), ptr(nbr), ptr(tapmask), stream()),
+          "cpd_rulebook_conv")
+    nbr.tapmask = tapmask
     return nbr
 
 
@@ -166,7 +177,7 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
         res_ld = residual.stride(0)
     check(lib().cpd_gather_conv(
         ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w),
-        ptr(nbr), kv, n_out, c_out, ptr(scale), ptr(shift),
+        ptr(nbr), ptr(getattr(nbr, "tapmask", None)), kv, n_out, c_out, ptr(scale), ptr(shift),
         ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
         ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), 1 if dense else 0,
         stream()),

@@ -75,9 +75,12 @@ size_t cpd_index_bytes(int batch, const int32_t shape_zyx[3], int n_capacity);
 /* Build the index of `indices` [n,4] i32 (b,z,y,x) (any order; row ids = positions). */
 int cpd_index_build(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3],
                     void *index, size_t index_bytes, cpd_stream_t stream);
-/* SubMConv3d rulebook: output set == input set, same order; tap t reads coord + t - k/2. */
+/* SubMConv3d rulebook: output set == input set, same order; tap t reads coord + t - k/2.
+ * tapmask (optional, u32 [ceil(n/16)], kernel volume <= 32): bit t of word s is set iff some row
+ * of the 16-row group s has a neighbour at tap t -- lets cpd_gather_conv skip empty
+ * (row group, tap) pairs without touching nbr. */
 int cpd_rulebook_subm(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3],
-                      const int32_t ksize[3], const void *index, int32_t *nbr,
+                      const int32_t ksize[3], const void *index, int32_t *nbr, uint32_t *tapmask,
                       cpd_stream_t stream);
 /* out_shape = (in + 2*pad - k)/stride + 1. HOST only. */
 int cpd_conv_out_shape(const int32_t in_shape[3], const int32_t ksize[3], const int32_t stride[3],
@@ -94,7 +97,7 @@ int cpd_index_emit(const void *index, int batch, const int32_t shape_zyx[3], int
 /* SparseConv3d rulebook: nbr[t][o] = input row at o*stride - pad + t. */
 int cpd_rulebook_conv(const int32_t *out_indices, int n_out, int batch, const int32_t in_shape[3],
                       const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3],
-                      const void *in_index, int32_t *nbr, cpd_stream_t stream);
+                      const void *in_index, int32_t *nbr, uint32_t *tapmask, cpd_stream_t stream);
 
 /* Weights for cpd_gather_conv: pack a dense [kv][c_in][c_out] f32 tensor (device) into the
  * MFMA-fragment order the kernel streams (zero padded to multiples of 16).                   */
@@ -110,6 +113,7 @@ int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *pack
  * (cpd/models/dense_heads/center_head.py:21-27,73-80) on channels-last maps.
  *   in   [n_in rows, in_ld floats per row], first c_in floats of a row are the features
  *   nbr  [kv][n_out] or NULL (kv must be 1: identity, i.e. a 1x1 conv / linear layer)
+ *   tapmask: the rulebook's tap masks (see cpd_rulebook_subm) or NULL (every tap computed)
  *   scale, shift [c_out] or NULL (1 / 0); residual [n_out, res_ld] or NULL; relu 0/1
  *   out  [n_out, out_ld]; only columns [0, c_out) of each row are written
  *   out_row_map: NULL, or i32 destination rows. With out_col_group == 0 it is [n_out]: row j
@@ -119,7 +123,7 @@ int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *pack
  *                (base_bev_backbone.py:52-56) and interleaves them into the upsampled map.
  *   flags: 0 or CPD_GC_DENSE (a performance hint only; results are identical).               */
 int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float *packed_w,
-                    const int32_t *nbr, int kv, int n_out, int c_out, const float *scale,
+                    const int32_t *nbr, const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale,
                     const float *shift, const float *residual, int res_ld, int relu, float *out,
                     int out_ld, const int32_t *out_row_map, int out_col_group, int flags,
                     cpd_stream_t stream);

@@ -59,7 +59,7 @@ def test_size_queries_and_error_codes():
     assert lib.cpd_packed_weight_floats(27, 5, 16) == 27 * 1 * 4 * 16 * 4
     assert lib.cpd_nms_workspace_bytes(500) >= 500 * 8 * 8
     # bad arguments give error codes, never exit()
-    assert lib.cpd_gather_conv(None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 0, None) == -1
+    assert lib.cpd_gather_conv(None, 0, 0, 0, None, None, None, 0, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 0, None) == -1
     assert lib.cpd_voxelize(None, -1, 5, vs, pcr, 5, 10, 0, 4, None, None, None, None, None, None, 0, None) == -1
     o = (ctypes.c_int32 * 3)()
     assert lib.cpd_conv_out_shape(_lib.iarr([1, 1, 1]), _lib.iarr([3, 3, 3]), _lib.iarr([2, 2, 2]), _lib.iarr([0, 0, 0]), o) == -1

@@ -163,3 +163,37 @@ def test_kitti_c4_subm_path(oracle, hip):
     xr = np.maximum(oracle.sparse_conv(feat, w1, None, want_nbr), 0)
     yr = np.maximum(oracle.sparse_conv(xr, w2, None, want_nbr), 0)
     np.testing.assert_allclose(x, xr, atol=1e-4); np.testing.assert_allclose(y, yr, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,n", [(16, 16, 5000), (32, 64, 3000), (128, 128, 2000), (64, 64, 40000)])
+def test_tapmask_skipping_is_exact(oracle, hip, cin, cout, n):
+    """Device rulebook + tap masks (empty (row group, tap) pairs skipped) == oracle, on clustered
+    sites so that many pairs really are empty; regular conv path as well."""
+    rng = np.random.default_rng(n)
+    batch, shape = 2, [9, 64, 64]
+    idx = random_sites(rng, batch, [9, 24, 24], n // 4 if n > 20000 else n // 8)      # dense blob
+    far = random_sites(rng, batch, shape, n // 6)                                      # plus scattered sites
+    idx = np.unique(np.concatenate([idx, far]), axis=0).astype(np.int32)
+    rng.shuffle(idx)
+    feat = rng.normal(size=(idx.shape[0], cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    d_idx = dev(idx)
+    index = ops.SiteIndex.build(d_idx, batch, shape)
+    nbr = ops.rulebook_subm(d_idx, index)
+    want_nbr = oracle.subm_rulebook(idx, batch, shape, [3, 3, 3])
+    np.testing.assert_array_equal(nbr.cpu().numpy(), want_nbr)
+    tm = nbr.tapmask.cpu().numpy().view(np.uint32)
+    valid = np.pad(want_nbr >= 0, ((0, 0), (0, (-idx.shape[0]) % 16))).reshape(27, -1, 16).any(2)     # [27, n_sub]
+    want_tm = (valid.astype(np.uint64) << np.arange(27, dtype=np.uint64)[:, None]).sum(0).astype(np.uint32)
+    np.testing.assert_array_equal(tm, want_tm)
+    w_kio = torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda()
+    got = ops.gather_conv(dev(feat), cin, ops.pack_weight(w_kio), nbr, 27, idx.shape[0], cout).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.sparse_conv(feat, w, None, want_nbr), atol=1e-4, rtol=0)
+    # strided conv with its own masks
+    k, s, p = [3, 3, 3], [2, 2, 2], [1, 1, 1]
+    o_d, o_index, o_shape = ops.conv_outset(d_idx, batch, shape, k, s, p)
+    nbr2 = ops.rulebook_conv(o_d, index, k, s, p)
+    want2 = oracle.conv_rulebook(idx, o_d.cpu().numpy(), batch, shape, k, s, p)
+    np.testing.assert_array_equal(nbr2.cpu().numpy(), want2)
+    got2 = ops.gather_conv(dev(feat), cin, ops.pack_weight(w_kio), nbr2, 27, o_d.shape[0], cout).cpu().numpy()
+    np.testing.assert_allclose(got2, oracle.sparse_conv(feat, w, None, want2), atol=1e-4, rtol=0)
