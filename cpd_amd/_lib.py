@@ -46,15 +46,17 @@ SIGNATURES = {
     "cpd_densify_nchw": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_densify_nhwc": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_rulebook_conv2d": (_I, [_I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
-    "cpd_center_decode_workspace_bytes": (_SZ, [_I, _I, _I]),
-    "cpd_center_decode": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _F, _FP, _FP, _FP, _F, _VP, _VP, _VP,
-                               _VP, _VP, _SZ, _VP]),
+    "cpd_center_decode_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "cpd_center_decode": (_I, [_VP, _VP, _VP, _VP, _VP, _I, ctypes.c_longlong, _I, _I, _I, _I, _I, _I, _F, _FP, _FP, _FP, _F,
+                               _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_boxes_overlap_bev": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
     "cpd_boxes_iou_bev": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
     "cpd_boxes_iou3d": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
     "cpd_nms_workspace_bytes": (_SZ, [_I]),
     "cpd_nms_rotated": (_I, [_VP, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_nms_normal": (_I, [_VP, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_nms_batch": (_I, [_VP, _VP, _I, _I, _F, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_select_boxes": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "cpd_boxes_iou_bev_cpu": (_I, [_VP, _I, _VP, _I, _VP]),
 }
 

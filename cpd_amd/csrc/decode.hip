@@ -14,9 +14,12 @@
 
 namespace {
 
-struct MapView {  // map[pixel * pix + channel * ch]
+struct MapView {  // map[pixel * pix + channel * ch] of the sample the pointer was offset to
     const float *p;
     int pix, ch;
+    __device__ __forceinline__ MapView sample(int b, long long sample_stride) const {
+        return MapView{p + (size_t)b * sample_stride, pix, ch};
+    }
     __device__ __forceinline__ float at(int pixel, int channel) const {
         return p[(size_t)pixel * pix + (size_t)channel * ch];
     }
@@ -111,6 +114,71 @@ __device__ void block_topk(int n, int K, KeyFn keyfn, TopkSmem &sm) {
         }
 }
 
+// Fast path for the per-class stage: one histogram of the raw logits over 2048 LINEAR bins (low
+// LDS-atomic contention, unlike radix digits of sigmoid values that share their exponent byte), a
+// suffix scan to the bin holding the K-th element, then an exact bitonic sort of the <= 1024
+// candidates above it on their sigmoid keys. Falls back to the exact radix select when the
+// candidate set does not fit (degenerate score distributions).
+struct TopkHist {
+    uint32_t hist[2048];
+    uint32_t cnt, bstar, ok;
+};
+__device__ __forceinline__ int logit_bin(float x) {
+    float t = (x + 20.0f) * 51.2f;             // [-20, 20) -> [0, 2048)
+    t = t < 0.f ? 0.f : (t > 2047.f ? 2047.f : t);
+    return (x != x) ? 0 : (int)t;
+}
+__device__ bool block_topk_logits(const MapView &hm, int cls, int n, int K, TopkHist &h, TopkSmem &sm) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int b = tid; b < 2048; b += nth) h.hist[b] = 0;
+    if (tid == 0) { h.cnt = 0; h.ok = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += nth) atomicAdd(&h.hist[logit_bin(hm.at(i, cls))], 1u);
+    __syncthreads();
+    if (tid < 64) {  // wave 0: suffix sums over 2048 bins, 32 bins per lane, from the top
+        const int hi = 2047 - tid * 32;        // lane 0 owns the top 32 bins
+        uint32_t s = 0;
+        for (int k = 0; k < 32; ++k) s += h.hist[hi - k];
+        const uint32_t incl = wave_incl_scan(s), before = incl - s;
+        if (before < (uint32_t)K && incl >= (uint32_t)K) {  // the K-th element is in this lane's bins
+            uint32_t c = before;
+            int b = hi;
+            for (; b > hi - 32; --b) {
+                c += h.hist[b];
+                if (c >= (uint32_t)K) break;
+            }
+            h.bstar = (uint32_t)b;
+            h.ok = c <= 1024u ? 1u : 0u;       // candidates = everything in bins >= b*
+        }
+    }
+    __syncthreads();
+    if (!h.ok) return false;
+    const int bstar = (int)h.bstar;
+    for (int i = tid; i < 1024; i += nth) sm.packed[i] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += nth) {
+        const float x = hm.at(i, cls);
+        if (logit_bin(x) >= bstar) {
+            const uint32_t pos = atomicAdd(&h.cnt, 1u);
+            sm.packed[pos] = ((unsigned long long)f2key(sigmoidf(x)) << 32) | (uint32_t)(~(uint32_t)i);
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= 1024; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < 1024; i += nth) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = sm.packed[i], b = sm.packed[ixj];
+                    bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { sm.packed[i] = b; sm.packed[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    return true;
+}
+
 struct SigKey {
     MapView hm;
     int cls;
@@ -121,20 +189,24 @@ struct ArrKey {
     __device__ __forceinline__ uint32_t operator()(int i) const { return f2key(v[i]); }
 };
 
-__global__ void __launch_bounds__(1024) topk_class_kernel(MapView hm, int hw, int K, float *__restrict__ s1,
-                                                          int32_t *__restrict__ i1) {
+__global__ void __launch_bounds__(1024) topk_class_kernel(MapView hm_all, long long sample_stride, int num_class, int hw,
+                                                          int K, float *__restrict__ s1, int32_t *__restrict__ i1) {
     __shared__ TopkSmem sm;
-    const int cls = blockIdx.x;
-    block_topk(hw, K, SigKey{hm, cls}, sm);
+    __shared__ TopkHist hist;
+    const int cls = blockIdx.x, b = blockIdx.y;
+    const MapView hm = hm_all.sample(b, sample_stride);
+    if (!block_topk_logits(hm, cls, hw, K, hist, sm)) block_topk(hw, K, SigKey{hm, cls}, sm);
+    const size_t o = ((size_t)b * num_class + cls) * K;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         unsigned long long p = sm.packed[k];
-        s1[(size_t)cls * K + k] = key2f((uint32_t)(p >> 32));
-        i1[(size_t)cls * K + k] = (int32_t)(~(uint32_t)p);
+        s1[o + k] = key2f((uint32_t)(p >> 32));
+        i1[o + k] = (int32_t)(~(uint32_t)p);
     }
 }
 
 struct DecodeParams {
     MapView center, center_z, dim, rot;
+    long long sample_stride;
     int num_class, h, w, K;
     float stride, vx, vy, lox, loy;
     float lim[6];
@@ -147,6 +219,17 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecodeParams q, const floa
                                                       int32_t *__restrict__ n_out) {
     __shared__ TopkSmem sm;
     const int K = q.K;
+    const int bsmp = blockIdx.x;
+    s1 += (size_t)bsmp * q.num_class * K;
+    i1 += (size_t)bsmp * q.num_class * K;
+    boxes += (size_t)bsmp * K * 7;
+    scores += (size_t)bsmp * K;
+    labels += (size_t)bsmp * K;
+    n_out += bsmp;
+    q.center = q.center.sample(bsmp, q.sample_stride);
+    q.center_z = q.center_z.sample(bsmp, q.sample_stride);
+    q.dim = q.dim.sample(bsmp, q.sample_stride);
+    q.rot = q.rot.sample(bsmp, q.sample_stride);
     block_topk(q.num_class * K, K, ArrKey{s1}, sm);
     const int k = threadIdx.x;
     float bx[7];
@@ -186,37 +269,40 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecodeParams q, const floa
 
 }  // namespace
 
-extern "C" size_t cpd_center_decode_workspace_bytes(int num_class, int hw, int k) {
-    if (num_class <= 0 || hw <= 0 || k <= 0) return 0;
-    return cpd_align((size_t)num_class * k * 4) * 2;
+extern "C" size_t cpd_center_decode_workspace_bytes(int batch, int num_class, int hw, int k) {
+    if (batch <= 0 || num_class <= 0 || hw <= 0 || k <= 0) return 0;
+    return cpd_align((size_t)batch * num_class * k * 4) * 2;
 }
 
 extern "C" int cpd_center_decode(const float *hm, const float *center, const float *center_z, const float *dim,
-                                 const float *rot, int pix_stride, int ch_stride, int num_class, int h, int w, int k,
+                                 const float *rot, int batch, long long sample_stride, int pix_stride, int ch_stride,
+                                 int num_class, int h, int w, int k,
                                  float feature_map_stride, const float voxel_xy[2], const float range_lo_xy[2],
                                  const float limit_range[6], float score_thresh, float *boxes, float *scores,
                                  int32_t *labels, int32_t *n_out, void *workspace, size_t workspace_bytes,
                                  cpd_stream_t stream) {
     if (!hm || !center || !center_z || !dim || !rot || !boxes || !scores || !labels || !n_out || !workspace ||
-        !voxel_xy || !range_lo_xy || !limit_range || num_class <= 0 || h <= 0 || w <= 0 || k <= 0)
+        !voxel_xy || !range_lo_xy || !limit_range || batch <= 0 || num_class <= 0 || h <= 0 || w <= 0 || k <= 0)
         return CPD_ERR_ARG;
     const long long hw = (long long)h * w;
     if (k > 1024 || k > hw || (long long)num_class * k > (1 << 24) || hw >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
-    if (workspace_bytes < cpd_center_decode_workspace_bytes(num_class, (int)hw, k)) return CPD_ERR_WORKSPACE;
+    if (workspace_bytes < cpd_center_decode_workspace_bytes(batch, num_class, (int)hw, k)) return CPD_ERR_WORKSPACE;
     hipStream_t s = cpd_s(stream);
     float *s1 = (float *)workspace;
-    int32_t *i1 = (int32_t *)((char *)workspace + cpd_align((size_t)num_class * k * 4));
-    topk_class_kernel<<<num_class, 1024, 0, s>>>(MapView{hm, pix_stride, ch_stride}, (int)hw, k, s1, i1);
+    int32_t *i1 = (int32_t *)((char *)workspace + cpd_align((size_t)batch * num_class * k * 4));
+    topk_class_kernel<<<dim3(num_class, batch), 1024, 0, s>>>(MapView{hm, pix_stride, ch_stride}, sample_stride, num_class,
+                                                              (int)hw, k, s1, i1);
     DecodeParams q;
     q.center = MapView{center, pix_stride, ch_stride};
     q.center_z = MapView{center_z, pix_stride, ch_stride};
     q.dim = MapView{dim, pix_stride, ch_stride};
     q.rot = MapView{rot, pix_stride, ch_stride};
+    q.sample_stride = sample_stride;
     q.num_class = num_class; q.h = h; q.w = w; q.K = k;
     q.stride = feature_map_stride; q.vx = voxel_xy[0]; q.vy = voxel_xy[1];
     q.lox = range_lo_xy[0]; q.loy = range_lo_xy[1];
     for (int i = 0; i < 6; ++i) q.lim[i] = limit_range[i];
     q.score_thresh = score_thresh;
-    decode_kernel<<<1, 1024, 0, s>>>(q, s1, i1, boxes, scores, labels, n_out);
+    decode_kernel<<<batch, 1024, 0, s>>>(q, s1, i1, boxes, scores, labels, n_out);
     return cpd_check_launch();
 }

@@ -185,44 +185,68 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const float *__restrict__
 
 // mask[row][cb] bit i = iou(row, 64*cb + i) > thr, for columns after the row inside the diagonal
 // block and all columns of later blocks (iou3d_nms_kernel.cu:267-311). Blocks below the diagonal
-// are never read by the scan (it starts at j = nblock) and are not computed.
+// are never read by the scan (it starts at j = nblock) and are not computed. One WAVE per
+// (row, column block): lane = column box, the ballot is the mask word -- N * N/64 / 2 independent
+// waves instead of the reference's 64 serial IoUs per thread. Batched over samples (blockIdx.z);
+// per-sample box counts may live on the device (no host round trip between decode and NMS).
 template <bool NORMAL>
-__global__ void __launch_bounds__(256) nms_mask_kernel(const float *__restrict__ boxes, int n, float thr,
-                                                       unsigned long long *__restrict__ mask) {
-    const int cb = blockIdx.x, rbk = blockIdx.y;
-    if (rbk > cb) return;
+__global__ void __launch_bounds__(256) nms_mask_kernel(const float *__restrict__ boxes_all, const int32_t *__restrict__ counts,
+                                                       int n_host, int cap, float thr,
+                                                       unsigned long long *__restrict__ mask_all) {
+    const int smp = blockIdx.z;
+    const int n = counts ? min(counts[smp], cap) : n_host;
+    const int cb = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ncb = (n + 63) >> 6;
+    const int row = blockIdx.y * 4 + wave;
+    if (row >= n || cb * 64 >= n || cb < (row >> 6)) return;
+    const float *boxes = boxes_all + (size_t)smp * cap * 7;
+    const int ncb_cap = (cap + 63) >> 6;
+    unsigned long long *mask = mask_all + (size_t)smp * cap * ncb_cap;
     const int col = cb * 64 + lane;
-    const bool colok = col < n;
-    BoxG B;
-    box_setup(boxes + 7 * (size_t)(colok ? col : 0), B);
-    for (int rr = wave * 16; rr < wave * 16 + 16; ++rr) {
-        const int row = rbk * 64 + rr;
-        if (row >= n) break;
-        bool hit = false;
-        if (colok && (rbk != cb || lane > rr)) {
-            if (NORMAL) {
-                hit = iou_normal_g(boxes + 7 * (size_t)row, B.b) > thr;
-            } else {
-                BoxG A;
-                box_setup(boxes + 7 * (size_t)row, A);
-                hit = iou_bev_g(A, B) > thr;
-            }
+    bool hit = false;
+    if (col < n && col > row) {
+        if (NORMAL) {
+            hit = iou_normal_g(boxes + 7 * (size_t)row, boxes + 7 * (size_t)col) > thr;
+        } else {
+            BoxG A, B;
+            box_setup(boxes + 7 * (size_t)row, A);
+            box_setup(boxes + 7 * (size_t)col, B);
+            hit = iou_bev_g(A, B) > thr;
         }
-        const unsigned long long word = __ballot(hit);
-        if (lane == 0) mask[(size_t)row * ncb + cb] = word;
     }
+    const unsigned long long word = __ballot(hit);
+    if (lane == 0) mask[(size_t)row * ncb_cap + cb] = word;
 }
 
-// Greedy scan (iou3d_nms.cpp:117-133) by ONE wave. Lane w owns word w (+64, +128, ...) of the
-// removed set. Per 64-box block: the 64 diagonal words sit one per lane, the in-block greedy pass
-// is register-only (shuffles), and only then are the kept rows' later words OR-ed in with
-// independent, pipelined loads -- two dependent memory round trips per block instead of one per box.
-__global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *__restrict__ mask, int n,
-                                                      long long *__restrict__ keep, int *__restrict__ num_keep) {
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Greedy scan (iou3d_nms.cpp:117-133) by ONE wave per sample. Lane w owns word w (+64, ...) of the
+// removed set. Per 64-box block: the 64 diagonal words sit one per lane and the in-block greedy
+// pass is register-only (shuffles); then lane i (= kept row i of the block) reads its later words
+// and a butterfly OR folds them into the removed set. With LDS=true the sample's whole mask is
+// first copied into LDS with coalesced, pipelined loads (fits up to 1024 boxes).
+template <bool LDS>
+__global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *__restrict__ mask_all,
+                                                      const int32_t *__restrict__ counts, int n_host, int cap,
+                                                      long long *__restrict__ keep_all, int *__restrict__ num_keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_mask[];
+    const int smp = blockIdx.x;
+    const int n = counts ? min(counts[smp], cap) : n_host;
     const int lane = threadIdx.x;
+    const int ncb_cap = (cap + 63) >> 6;
     const int ncb = (n + 63) >> 6;
+    const unsigned long long *gmask = mask_all + (size_t)smp * cap * ncb_cap;
+    long long *keep = keep_all + (size_t)smp * cap;
+    if (LDS) {
+        const int total = n * ncb_cap;
+        for (int e = lane; e < total; e += 64) s_mask[e] = gmask[e];
+        __syncthreads();
+    }
+    const unsigned long long *mask = LDS ? s_mask : gmask;
     constexpr int MAXW = 8;  // up to 64*64*8 = 32768 boxes
     unsigned long long remv[MAXW];
 #pragma unroll
@@ -235,7 +259,7 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *
             if (k == (nb >> 6)) cur = __shfl(remv[k], nb & 63, 64);
         const int lim = n - nb * 64 < 64 ? n - nb * 64 : 64;
         const int myrow = nb * 64 + lane;
-        const unsigned long long diag = lane < lim ? mask[(size_t)myrow * ncb + nb] : 0ull;
+        const unsigned long long diag = lane < lim ? mask[(size_t)myrow * ncb_cap + nb] : 0ull;
         unsigned long long keptmask = 0ull;
         for (int ib = 0; ib < lim; ++ib) {
             const unsigned long long d = __shfl(diag, ib, 64);
@@ -244,40 +268,63 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *
                 cur |= d;
             }
         }
-        if (keptmask & (1ull << lane)) keep[kept + __popcll(keptmask & ((1ull << lane) - 1ull))] = myrow;
+        const bool mine = (keptmask >> lane) & 1ull;
+        if (mine) keep[kept + __popcll(keptmask & ((1ull << lane) - 1ull))] = myrow;
         kept += __popcll(keptmask);
-        // later words of every kept row of this block
-        unsigned long long km = keptmask;
-        while (km) {
-            const int ib = __ffsll(km) - 1;
-            km &= km - 1;
-            const size_t rowoff = (size_t)(nb * 64 + ib) * ncb;
+        // later words: lane i holds row (nb*64+i); fold word w of all kept rows with a butterfly OR
+        for (int w = nb + 1; w < ncb; ++w) {
+            const unsigned long long v = mine ? mask[(size_t)myrow * ncb_cap + w] : 0ull;
+            const unsigned long long all = wave_or64(v);
 #pragma unroll
-            for (int k = 0; k < MAXW; ++k) {
-                const int w = lane + 64 * k;
-                if (w > nb && w < ncb) remv[k] |= mask[rowoff + w];
-            }
+            for (int k = 0; k < MAXW; ++k)
+                if (k == (w >> 6) && lane == (w & 63)) remv[k] |= all;
         }
     }
-    if (lane == 0) *num_keep = kept;
+    if (lane == 0) num_keep[smp] = kept;
 }
 
-static int nms_impl(bool normal, const float *boxes, int n, float thr, int64_t *keep, int32_t *num_keep, void *ws,
-                    size_t ws_bytes, hipStream_t s) {
-    if (n < 0 || !keep || !num_keep || (n > 0 && (!boxes || !ws))) return CPD_ERR_ARG;
-    if (n > 64 * 64 * 8) return CPD_ERR_UNSUPPORTED;
-    if (n == 0) {
-        CPD_HIP_TRY(hipMemsetAsync(num_keep, 0, 4, s));
+static int nms_impl(bool normal, const float *boxes, const int32_t *counts, int batch, int cap, float thr, int64_t *keep,
+                    int32_t *num_keep, void *ws, size_t ws_bytes, hipStream_t s) {
+    if (cap < 0 || batch <= 0 || !keep || !num_keep || (cap > 0 && (!boxes || !ws))) return CPD_ERR_ARG;
+    if (cap > 64 * 64 * 8) return CPD_ERR_UNSUPPORTED;
+    if (cap == 0) {
+        CPD_HIP_TRY(hipMemsetAsync(num_keep, 0, 4 * (size_t)batch, s));
         return CPD_OK;
     }
-    if (ws_bytes < cpd_nms_workspace_bytes(n)) return CPD_ERR_WORKSPACE;
-    const int ncb = (n + 63) / 64;
+    if (ws_bytes < (size_t)batch * cpd_nms_workspace_bytes(cap)) return CPD_ERR_WORKSPACE;
+    const int ncb = (cap + 63) / 64;
     unsigned long long *mask = (unsigned long long *)ws;
-    dim3 grid(ncb, ncb);
-    if (normal) nms_mask_kernel<true><<<grid, 256, 0, s>>>(boxes, n, thr, mask);
-    else nms_mask_kernel<false><<<grid, 256, 0, s>>>(boxes, n, thr, mask);
-    nms_scan_kernel<<<1, 64, 0, s>>>(mask, n, (long long *)keep, num_keep);
+    dim3 grid(ncb, (cap + 3) / 4, batch);
+    if (normal) nms_mask_kernel<true><<<grid, 256, 0, s>>>(boxes, counts, cap, cap, thr, mask);
+    else nms_mask_kernel<false><<<grid, 256, 0, s>>>(boxes, counts, cap, cap, thr, mask);
+    const size_t lds = (size_t)cap * ncb * 8;
+    if (lds <= 64 * 1024)
+        nms_scan_kernel<true><<<batch, 64, lds, s>>>(mask, counts, cap, cap, (long long *)keep, num_keep);
+    else
+        nms_scan_kernel<false><<<batch, 64, 0, s>>>(mask, counts, cap, cap, (long long *)keep, num_keep);
     return cpd_check_launch();
+}
+
+// class_agnostic_nms tail (model_nms_utils.py:126-127): out[k] = in[keep[k]] for k < min(num_keep, post_max)
+__global__ void __launch_bounds__(256) select_boxes_kernel(const float *__restrict__ boxes, const float *__restrict__ scores,
+                                                           const int32_t *__restrict__ labels,
+                                                           const long long *__restrict__ keep,
+                                                           const int32_t *__restrict__ num_keep, int cap, int post_max,
+                                                           int label_offset, float *__restrict__ out_boxes,
+                                                           float *__restrict__ out_scores, long long *__restrict__ out_labels,
+                                                           int32_t *__restrict__ out_n) {
+    const int smp = blockIdx.y;
+    const int nk = min(num_keep[smp], post_max);
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) out_n[smp] = nk;
+    if (k >= nk) return;
+    const long long src = keep[(size_t)smp * cap + k];
+    const float *b = boxes + ((size_t)smp * cap + src) * 7;
+    float *o = out_boxes + ((size_t)smp * post_max + k) * 7;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) o[c] = b[c];
+    out_scores[(size_t)smp * post_max + k] = scores[(size_t)smp * cap + src];
+    out_labels[(size_t)smp * post_max + k] = (long long)labels[(size_t)smp * cap + src] + label_offset;
 }
 
 template <int MODE>
@@ -307,11 +354,31 @@ extern "C" size_t cpd_nms_workspace_bytes(int n) {
 }
 extern "C" int cpd_nms_rotated(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep, void *workspace,
                                size_t workspace_bytes, cpd_stream_t stream) {
-    return nms_impl(false, boxes, n, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream));
+    return nms_impl(false, boxes, nullptr, 1, n, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream));
 }
 extern "C" int cpd_nms_normal(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep, void *workspace,
                               size_t workspace_bytes, cpd_stream_t stream) {
-    return nms_impl(true, boxes, n, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream));
+    return nms_impl(true, boxes, nullptr, 1, n, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream));
+}
+extern "C" int cpd_nms_batch(const float *boxes, const int32_t *counts, int batch, int capacity, float thresh, int normal,
+                             int64_t *keep, int32_t *num_keep, void *workspace, size_t workspace_bytes,
+                             cpd_stream_t stream) {
+    if (!counts) return CPD_ERR_ARG;
+    return nms_impl(normal != 0, boxes, counts, batch, capacity, thresh, keep, num_keep, workspace, workspace_bytes,
+                    cpd_s(stream));
+}
+extern "C" int cpd_select_boxes(const float *boxes, const float *scores, const int32_t *labels, const int64_t *keep,
+                                const int32_t *num_keep, int batch, int capacity, int post_max, int label_offset,
+                                float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_n,
+                                cpd_stream_t stream) {
+    if (!boxes || !scores || !labels || !keep || !num_keep || !out_boxes || !out_scores || !out_labels || !out_n ||
+        batch <= 0 || capacity <= 0 || post_max <= 0)
+        return CPD_ERR_ARG;
+    dim3 grid(cpd_div_up(post_max, 256), batch);
+    select_boxes_kernel<<<grid, 256, 0, cpd_s(stream)>>>(boxes, scores, labels, (const long long *)keep, num_keep, capacity,
+                                                         post_max, label_offset, out_boxes, out_scores,
+                                                         (long long *)out_labels, out_n);
+    return cpd_check_launch();
 }
 
 extern "C" int cpd_boxes_iou_bev_cpu(const float *a, int n, const float *b, int m, float *out) {

@@ -185,6 +185,7 @@ class CenterPointEngine:
         self.sd = state_dict
         self.voxelizer = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features,
                                        cfg.max_points_per_voxel, cfg.max_voxels, device=self.device)
+        self._voxelizers = [self.voxelizer]
         self._build_sparse()
         self._bev_cache = {}
         self._build_dense()
@@ -379,25 +380,25 @@ class CenterPointEngine:
 
     def decode_and_nms(self, head_rows, batch, h, w):
         """generate_predicted_boxes (center_head.py:252-303) + class_agnostic_nms
-        (model_nms_utils.py:115-134) per sample; everything stays on the device."""
+        (model_nms_utils.py:115-134) for all samples of the batch: five launches, nothing read back
+        until the final per-sample counts."""
         cfg = self.cfg
         ld = self.head_ld
-        results = []
-        for b in range(batch):
-            base = head_rows[b * h * w:(b + 1) * h * w]
-            sl = self.head_slices
-            boxes, scores, labels, n = ops.center_decode(
-                base[:, sl["hm"][0]:], base[:, sl["center"][0]:], base[:, sl["center_z"][0]:],
-                base[:, sl["dim"][0]:], base[:, sl["rot"][0]:], ld, 1, cfg.num_class, h, w,
-                cfg.max_obj_per_sample, float(cfg.feature_map_stride), cfg.voxel_size[:2],
-                cfg.point_cloud_range[:2], cfg.post_center_limit_range, cfg.score_thresh)
-            # scores are already sorted descending (top-K order survives the mask), so the
-            # topk(NMS_PRE_MAXSIZE) + sort inside nms_gpu are identities here
-            boxes, scores, labels = boxes[:cfg.nms_pre_maxsize], scores[:cfg.nms_pre_maxsize], labels[:cfg.nms_pre_maxsize]
-            keep = ops.nms(boxes, cfg.nms_thresh)[:cfg.nms_post_maxsize]
-            results.append({"pred_boxes": boxes[keep], "pred_scores": scores[keep],
-                            "pred_labels": labels[keep].long() + 1})
-        return results
+        sl = self.head_slices
+        base = head_rows
+        boxes, scores, labels, counts = ops.center_decode(
+            base[:, sl["hm"][0]:], base[:, sl["center"][0]:], base[:, sl["center_z"][0]:], base[:, sl["dim"][0]:],
+            base[:, sl["rot"][0]:], ld, 1, cfg.num_class, h, w, cfg.max_obj_per_sample, float(cfg.feature_map_stride),
+            cfg.voxel_size[:2], cfg.point_cloud_range[:2], cfg.post_center_limit_range, cfg.score_thresh, sync=False,
+            batch=batch, sample_stride=h * w * ld)
+        # scores come out sorted descending (top-K order survives the masks), so the
+        # topk(NMS_PRE_MAXSIZE) + sort inside nms_gpu are identities (K = 500 <= 4096)
+        assert cfg.max_obj_per_sample <= cfg.nms_pre_maxsize
+        keep, num_keep = ops.nms_batch(boxes, counts, cfg.nms_thresh)
+        ob, os_, ol, on = ops.select_boxes(boxes, scores, labels, keep, num_keep, cfg.nms_post_maxsize, label_offset=1)
+        ns = on.tolist()                      # the one host read-back of the stage
+        return [{"pred_boxes": ob[b, :ns[b]], "pred_scores": os_[b, :ns[b]], "pred_labels": ol[b, :ns[b]]}
+                for b in range(batch)]
 
     # ------------------------------------------------------------------ whole frame(s)
     @torch.no_grad()
@@ -406,13 +407,19 @@ class CenterPointEngine:
         if isinstance(points_list, torch.Tensor):
             points_list = [points_list]
         batch = len(points_list)
-        feats, coords = [], []
-        for b, pts in enumerate(points_list):
-            _, c, _, mean, _ = self.voxelizer(pts, batch_idx=b, coord_cols=4, want_voxels=False, want_mean=True)
-            feats.append(mean)
-            coords.append(c)
-        feats = torch.cat(feats) if batch > 1 else feats[0]
-        coords = torch.cat(coords) if batch > 1 else coords[0]
+        outs = [self._voxelizers[b % len(self._voxelizers)](pts, batch_idx=b, coord_cols=4, want_voxels=False,
+                                                             want_mean=True, sync=False)
+                for b, pts in enumerate(points_list)] if batch <= len(self._voxelizers) else None
+        if outs is None:
+            while len(self._voxelizers) < batch:       # one workspace per in-flight frame of the batch
+                self._voxelizers.append(ops.Voxelizer(self.cfg.voxel_size, self.cfg.point_cloud_range,
+                                                      self.cfg.num_point_features, self.cfg.max_points_per_voxel,
+                                                      self.cfg.max_voxels, device=self.device))
+            outs = [self._voxelizers[b](pts, batch_idx=b, coord_cols=4, want_voxels=False, want_mean=True, sync=False)
+                    for b, pts in enumerate(points_list)]
+        ms = torch.cat([o[4] for o in outs]).tolist() if batch > 1 else [int(outs[0][4].item())]   # one read-back
+        feats = torch.cat([o[3][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][3][:ms[0]]
+        coords = torch.cat([o[1][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][1][:ms[0]]
         levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch)
         d, h, w = out_shape
         dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])

@@ -215,22 +215,54 @@ def rulebook_conv2d(batch, h, w, kh, kw, stride, pad, device):
 
 # ------------------------------------------------------------------------------------ decode
 def center_decode(hm, center, center_z, dim, rot, pix_stride, ch_stride, num_class, h, w, k, feature_map_stride,
-                  voxel_xy, range_lo_xy, limit_range, score_thresh, sync=True):
+                  voxel_xy, range_lo_xy, limit_range, score_thresh, sync=True, batch=1, sample_stride=0):
+    """Decode `batch` samples in one call (sample b's maps start b*sample_stride floats later).
+    sync=True and batch == 1: returns (boxes[n,7], scores[n], labels[n], n) sliced on the host.
+    Otherwise: capacity-sized (boxes[batch,k,7], scores[batch,k], labels[batch,k], counts[batch])
+    device tensors and no host synchronisation."""
     dev = hm.device
-    boxes = torch.empty((k, 7), dtype=torch.float32, device=dev)
-    scores = torch.empty((k,), dtype=torch.float32, device=dev)
-    labels = torch.empty((k,), dtype=torch.int32, device=dev)
-    n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ws = torch.empty(lib().cpd_center_decode_workspace_bytes(num_class, h * w, k), dtype=torch.uint8, device=dev)
+    boxes = torch.empty((batch, k, 7), dtype=torch.float32, device=dev)
+    scores = torch.empty((batch, k), dtype=torch.float32, device=dev)
+    labels = torch.empty((batch, k), dtype=torch.int32, device=dev)
+    n_out = torch.zeros((batch,), dtype=torch.int32, device=dev)
+    ws = torch.empty(lib().cpd_center_decode_workspace_bytes(batch, num_class, h * w, k), dtype=torch.uint8, device=dev)
     check(lib().cpd_center_decode(
         ctypes.c_void_p(hm.data_ptr()), ctypes.c_void_p(center.data_ptr()), ctypes.c_void_p(center_z.data_ptr()),
-        ctypes.c_void_p(dim.data_ptr()), ctypes.c_void_p(rot.data_ptr()), pix_stride, ch_stride, num_class, h, w, k,
-        float(feature_map_stride), farr(voxel_xy), farr(range_lo_xy), farr(limit_range), float(score_thresh),
-        ptr(boxes), ptr(scores), ptr(labels), ptr(n_out), ptr(ws), ws.numel(), stream()), "cpd_center_decode")
-    if not sync:
+        ctypes.c_void_p(dim.data_ptr()), ctypes.c_void_p(rot.data_ptr()), int(batch), int(sample_stride), pix_stride,
+        ch_stride, num_class, h, w, k, float(feature_map_stride), farr(voxel_xy), farr(range_lo_xy), farr(limit_range),
+        float(score_thresh), ptr(boxes), ptr(scores), ptr(labels), ptr(n_out), ptr(ws), ws.numel(), stream()),
+        "cpd_center_decode")
+    if not sync or batch != 1:
         return boxes, scores, labels, n_out
     n = int(n_out.item())
-    return boxes[:n], scores[:n], labels[:n], n
+    return boxes[0, :n], scores[0, :n], labels[0, :n], n
+
+
+def nms_batch(boxes, counts, thresh, normal=False):
+    """boxes [batch, cap, 7] (descending score per sample), counts [batch] i32 on the device.
+    Returns (keep [batch, cap] i64, num_keep [batch] i32), no host synchronisation."""
+    boxes = boxes.contiguous()
+    batch, cap = boxes.shape[0], boxes.shape[1]
+    keep = torch.empty((batch, cap), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros((batch,), dtype=torch.int32, device=boxes.device)
+    ws = torch.empty(batch * lib().cpd_nms_workspace_bytes(cap), dtype=torch.uint8, device=boxes.device)
+    check(lib().cpd_nms_batch(ptr(boxes), ptr(counts), batch, cap, float(thresh), 1 if normal else 0, ptr(keep), ptr(num),
+                              ptr(ws), ws.numel(), stream()), "cpd_nms_batch")
+    return keep, num
+
+
+def select_boxes(boxes, scores, labels, keep, num_keep, post_max, label_offset=0):
+    """out[b][k] = in[b][keep[b][k]], k < min(num_keep[b], post_max). Returns padded
+    (boxes [batch,post_max,7], scores, labels i64, counts [batch] i32)."""
+    batch, cap = boxes.shape[0], boxes.shape[1]
+    dev = boxes.device
+    ob = torch.empty((batch, post_max, 7), dtype=torch.float32, device=dev)
+    os_ = torch.empty((batch, post_max), dtype=torch.float32, device=dev)
+    ol = torch.empty((batch, post_max), dtype=torch.int64, device=dev)
+    on = torch.zeros((batch,), dtype=torch.int32, device=dev)
+    check(lib().cpd_select_boxes(ptr(boxes), ptr(scores), ptr(labels), ptr(keep), ptr(num_keep), batch, cap, int(post_max),
+                                 int(label_offset), ptr(ob), ptr(os_), ptr(ol), ptr(on), stream()), "cpd_select_boxes")
+    return ob, os_, ol, on
 
 
 # ---------------------------------------------------------------------------------------- B3
@@ -265,7 +297,7 @@ def nms(boxes_sorted, thresh, normal=False, sync=True):
     dev = boxes_sorted.device
     keep = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
     num = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ws = torch.empty(lib().cpd_nms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(256, lib().cpd_nms_workspace_bytes(n)), dtype=torch.uint8, device=dev)
     fn = lib().cpd_nms_normal if normal else lib().cpd_nms_rotated
     check(fn(ptr(boxes_sorted), n, float(thresh), ptr(keep), ptr(num), ptr(ws), ws.numel(), stream()), "cpd_nms")
     if not sync:

@@ -156,12 +156,14 @@ int cpd_rulebook_conv2d(int batch, int h, int w, int kh, int kw, int stride, int
  * centre scaling, POST_CENTER_LIMIT_RANGE and SCORE_THRESH masks, order-preserving compaction.
  * Head maps are addressed as map[pixel*pix_stride + channel*ch_stride] so both the reference's
  * NCHW planes and this library's channels-last rows can be decoded in place.
- * Outputs (capacity K): boxes [K,7] (x,y,z,dx,dy,dz,heading), scores [K], labels [K] i32
- * (0-based class id), n_out device scalar.                                                   */
-size_t cpd_center_decode_workspace_bytes(int num_class, int hw, int k);
+ * `batch` samples are decoded by one call: sample b's maps start sample_stride floats after
+ * sample b-1's. Outputs (capacity K per sample): boxes [batch,K,7] (x,y,z,dx,dy,dz,heading),
+ * scores [batch,K], labels [batch,K] i32 (0-based class id), n_out [batch] device counts.     */
+size_t cpd_center_decode_workspace_bytes(int batch, int num_class, int hw, int k);
 int cpd_center_decode(const float *hm, const float *center, const float *center_z,
-                      const float *dim, const float *rot, int pix_stride, int ch_stride,
-                      int num_class, int h, int w, int k, float feature_map_stride,
+                      const float *dim, const float *rot, int batch, long long sample_stride,
+                      int pix_stride, int ch_stride, int num_class, int h, int w, int k,
+                      float feature_map_stride,
                       const float voxel_xy[2], const float range_lo_xy[2],
                       const float limit_range[6], float score_thresh, float *boxes, float *scores,
                       int32_t *labels, int32_t *n_out, void *workspace, size_t workspace_bytes,
@@ -188,6 +190,20 @@ int cpd_nms_rotated(const float *boxes, int n, float thresh, int64_t *keep, int3
                     void *workspace, size_t workspace_bytes, cpd_stream_t stream);
 int cpd_nms_normal(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
                    void *workspace, size_t workspace_bytes, cpd_stream_t stream);
+/* Batched form for the per-sample NMS loop of generate_predicted_boxes (center_head.py:281-296):
+ * boxes [batch, capacity, 7] sorted by descending score per sample, valid counts [batch] ON THE
+ * DEVICE (e.g. cpd_center_decode's n_out -- no host read-back in between); keep [batch, capacity],
+ * num_keep [batch]; workspace = batch * cpd_nms_workspace_bytes(capacity).                      */
+int cpd_nms_batch(const float *boxes, const int32_t *counts, int batch, int capacity, float thresh,
+                  int normal, int64_t *keep, int32_t *num_keep, void *workspace,
+                  size_t workspace_bytes, cpd_stream_t stream);
+/* class_agnostic_nms tail (model_nms_utils.py:126-127,134) + the `+1` of center_head.py:301, batched:
+ * out[b][k] = in[b][keep[b][k]] for k < out_n[b] = min(num_keep[b], post_max).
+ * out_boxes [batch,post_max,7], out_scores [batch,post_max], out_labels [batch,post_max] i64.  */
+int cpd_select_boxes(const float *boxes, const float *scores, const int32_t *labels,
+                     const int64_t *keep, const int32_t *num_keep, int batch, int capacity,
+                     int post_max, int label_offset, float *out_boxes, float *out_scores,
+                     int64_t *out_labels, int32_t *out_n, cpd_stream_t stream);
 /* boxes_iou_bev_cpu (iou3d_cpu.cpp:232-252): HOST pointers, runs on the calling thread. This is
  * the one CPU entry point the reference extension itself exports (used by the dataloader's
  * gt-sampling, database_sampler.py:445-446); it is product code, not the test oracle.        */
