@@ -39,10 +39,10 @@ POOL = 4                        # distinct synthetic frames per rank, cycled
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--frames", type=int, default=4, help="frames per step per GPU")
-    ap.add_argument("--streams", type=int, default=3, help="concurrent frames in flight per GPU (worker threads, "
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent frames in flight per GPU (worker threads, "
                     "one HIP stream + engine workspace each)")
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
