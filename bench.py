@@ -103,6 +103,19 @@ class ConvProfiler:
         return agg, total_ms
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_summary.json: 2 x FETCH_SIZE + WRITE_SIZE, per MI355X_MICROARCH.md), or None.
+    bench.py cannot run the counters itself; the number is from the same command's PMC run."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return {"bytes_per_launch": k["hbm_bytes_per_launch_corrected"], "mfma_busy_frac": k["mfma_busy_frac_of_simd_cycles"],
+                "source": "profiles/r01_pmc_summary.json"} if k else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, sd, points_np):
     """The oracle's un-fused restatement of the reference graph on the host CPU, one full frame."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -208,7 +221,7 @@ def main():
         conv_flops = sum(v[0] for v in agg.values()) / (n_prof * B)        # algorithmic conv flop per frame
         out["roofline"] = {
             "bound": "mfma", "kernel": key, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(key),
             "launches_per_frame": launches / (n_prof * B), "avg_launch_us": 1e3 * ms / launches,
             "algorithmic_gflop_per_launch": flops / launches / 1e9,
             "note": "per-launch figures measured with %d concurrent stream(s): a launch shares the chip with the other "
