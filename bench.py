@@ -110,8 +110,7 @@ def pmc_traffic(kernel):
     try:
         with open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")) as f:
             k = json.load(f)["kernels"].get(kernel)
-        return {"bytes_per_launch": k["hbm_bytes_per_launch_corrected"], "mfma_busy_frac": k["mfma_busy_frac_of_simd_cycles"],
-                "source": "profiles/r01_pmc_summary.json"} if k else None
+        return k["hbm_bytes_per_launch_corrected"] if k else None
     except Exception:
         return None
 
@@ -222,6 +221,7 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "kernel": key, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(key),
+            "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_summary.json)",
             "launches_per_frame": launches / (n_prof * B), "avg_launch_us": 1e3 * ms / launches,
             "algorithmic_gflop_per_launch": flops / launches / 1e9,
             "note": "per-launch figures measured with %d concurrent stream(s): a launch shares the chip with the other "
