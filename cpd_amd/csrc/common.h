@@ -71,14 +71,18 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, ui
     return res;
 }
 
+// Item <-> thread mapping (coalesced): a block owns SCAN_TILE consecutive items, each of its 4 waves a
+// contiguous quarter, and in iteration k lane l of a wave touches item wave_base + 64*k + l -- so
+// every wave access is 64 consecutive items and prefixes still follow index order.
 template <class ValueFn>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(long long n, ValueFn value, uint32_t *block_sums) {
     __shared__ uint32_t sm[17];
-    long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long wbase = (long long)blockIdx.x * SCAN_TILE + (long long)wave * (SCAN_TILE / 4);
     uint32_t s = 0;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        long long i = base + k;
+        const long long i = wbase + k * 64 + lane;
         if (i < n) s += value(i);
     }
     uint32_t tot;
@@ -111,22 +115,30 @@ template <class ValueFn, class ConsumeFn>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(long long n, ValueFn value, const uint32_t *block_sums,
                                                                 ConsumeFn consume) {
     __shared__ uint32_t sm[17];
-    long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long wbase = (long long)blockIdx.x * SCAN_TILE + (long long)wave * (SCAN_TILE / 4);
+    // pass 1: this wave's total (values are cheap to recompute: popcounts / flag tests)
     uint32_t s = 0;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        long long i = base + k;
-        v[k] = i < n ? value(i) : 0u;
-        s += v[k];
+        const long long i = wbase + k * 64 + lane;
+        if (i < n) s += value(i);
     }
     uint32_t tot;
-    uint32_t pre = block_excl_scan(s, sm, &tot) + block_sums[blockIdx.x];
-#pragma unroll
+    const uint32_t incl = wave_incl_scan(s);
+    const uint32_t wave_total = __shfl(incl, 63, 64);
+    if (lane == 0) sm[wave] = wave_total;
+    __syncthreads();
+    uint32_t carry = block_sums[blockIdx.x];
+    for (int w = 0; w < wave; ++w) carry += sm[w];
+    (void)tot;
+    // pass 2: in index order, 64 items at a time
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        long long i = base + k;
-        if (i < n) consume(i, v[k], pre);
-        pre += v[k];
+        const long long i = wbase + k * 64 + lane;
+        const uint32_t v = i < n ? value(i) : 0u;
+        const uint32_t inc = wave_incl_scan(v);
+        if (i < n) consume(i, v, carry + inc - v);
+        carry += __shfl(inc, 63, 64);
     }
 }
 
