@@ -58,6 +58,18 @@ SIGNATURES = {
     "cpd_nms_batch": (_I, [_VP, _VP, _I, _I, _F, _I, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_select_boxes": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "cpd_boxes_iou_bev_cpu": (_I, [_VP, _I, _VP, _I, _VP]),
+    "cpd_col_reduce_workspace_bytes": (_SZ, [_I, _I]),
+    "cpd_col_sum": (_I, [_VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
+    "cpd_bn_stats": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_affine_rows": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),
+    "cpd_bn_bwd_reduce": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_bn_bwd_apply": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP]),
+    "cpd_relu_bwd": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
+    "cpd_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "cpd_conv_wgrad": (_I, [_VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _VP, _I, _VP, _SZ, _VP]),
+    "cpd_rulebook_conv_transpose": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _VP, _VP]),
+    "cpd_rulebook_conv2d_transpose": (_I, [_I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
+    "cpd_adam_step": (_I, [_VP, _VP, _VP, _VP, _SZ, _F, _F, _F, _F, _F, _I, _F, _VP]),
 }
 
 

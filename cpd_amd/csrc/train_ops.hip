@@ -1,0 +1,423 @@
+// train_ops.hip -- kernels the TRAIN step (BASELINE config 3) needs on top of the forward path:
+//   * column reductions over [n, c] row tensors: BatchNorm batch statistics (training-mode
+//     nn.BatchNorm1d/2d, spconv_backbone.py:410, base_bev_backbone.py:38, center_head.py:24,78) and
+//     the two sums of BatchNorm backward, deterministic two-stage (no atomics);
+//   * fused row-wise affine (+residual)(+ReLU)  = BN apply in training mode;
+//   * BatchNorm(+ReLU) backward apply;
+//   * weight gradient of the rulebook convolution (cpd_gather_conv's adjoint w.r.t. W) on the
+//     fp32 matrix pipe, 4-row skip granularity, deterministic two-stage reduction over row chunks;
+//   * transposed rulebooks for the input gradient of strided convs (sparse and 2-D);
+//   * Adam step on a flat parameter buffer (tools/train_utils/optimization: adam_onecycle without
+//     the one-cycle schedule; plain decoupled weight decay).
+// The input gradient itself is cpd_gather_conv again, on transposed (and, for SubM / stride-1
+// convs, tap-flipped) weights with the same or the transposed rulebook.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+enum { COL_SUM = 0, COL_STATS = 1, COL_BNBWD = 2 };
+
+struct ColParams {
+    const float *a;      // COL_SUM/COL_STATS: x ; COL_BNBWD: dy
+    const float *y;      // COL_BNBWD: BN(+ReLU) output, for the ReLU mask (may be null: no ReLU)
+    const float *x;      // COL_BNBWD: BN input
+    const float *mean, *invstd;
+    int lda, ldy, ldx;
+    int n, c, rows_per_block;
+};
+
+// One block reduces rows [b*rpb, (b+1)*rpb) of all columns: thread = (column % cw, row lane).
+template <int MODE>
+__global__ void __launch_bounds__(256) col_partial_kernel(ColParams p, float *__restrict__ part) {
+    __shared__ float sm1[256], sm2[256];
+    const int cw = p.c < 256 ? p.c : 256;          // columns handled side by side
+    const int lanes = 256 / cw;                     // row lanes per column
+    const int col_l = threadIdx.x % cw, rl = threadIdx.x / cw;
+    const int r0 = blockIdx.x * p.rows_per_block;
+    const int r1 = min(p.n, r0 + p.rows_per_block);
+    for (int cb = 0; cb < p.c; cb += cw) {
+        const int col = cb + col_l;
+        float s1 = 0.f, s2 = 0.f;
+        if (col < p.c && rl < lanes) {
+            float mu = 0.f, is = 1.f;
+            if (MODE == COL_BNBWD) { mu = p.mean[col]; is = p.invstd[col]; }
+            for (int r = r0 + rl; r < r1; r += lanes) {
+                float v = p.a[(size_t)r * p.lda + col];
+                if (MODE == COL_SUM) {
+                    s1 += v;
+                } else if (MODE == COL_STATS) {
+                    s1 += v; s2 += v * v;
+                } else {
+                    if (p.y && !(p.y[(size_t)r * p.ldy + col] > 0.f)) v = 0.f;
+                    const float xh = (p.x[(size_t)r * p.ldx + col] - mu) * is;
+                    s1 += v; s2 += v * xh;
+                }
+            }
+        }
+        sm1[threadIdx.x] = s1; sm2[threadIdx.x] = s2;
+        __syncthreads();
+        if (rl == 0 && col < p.c) {
+            for (int k = 1; k < lanes; ++k) { s1 += sm1[k * cw + col_l]; s2 += sm2[k * cw + col_l]; }
+            part[((size_t)blockIdx.x * 2 + 0) * p.c + col] = s1;
+            part[((size_t)blockIdx.x * 2 + 1) * p.c + col] = s2;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) col_final_kernel(const float *__restrict__ part, int nb, int c, float *__restrict__ s1,
+                                                        float *__restrict__ s2) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nb; ++k) { a += part[((size_t)k * 2 + 0) * c + col]; b += part[((size_t)k * 2 + 1) * c + col]; }
+    s1[col] = (float)a;
+    if (s2) s2[col] = (float)b;
+}
+
+__global__ void __launch_bounds__(256) affine_rows_kernel(const float *__restrict__ x, int ldx, int n, int c,
+                                                          const float *__restrict__ scale, const float *__restrict__ shift,
+                                                          const float *__restrict__ res, int ldr, int relu,
+                                                          float *__restrict__ out, int ldo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)n * c;
+    if (i >= total) return;
+    const int r = (int)(i / c), col = (int)(i - (long long)r * c);
+    float v = x[(size_t)r * ldx + col];
+    if (scale) v *= scale[col];
+    if (shift) v += shift[col];
+    if (res) v += res[(size_t)r * ldr + col];
+    if (relu && !(v > 0.f)) v = 0.f;
+    out[(size_t)r * ldo + col] = v;
+}
+
+// dx = a * (dy_m - s1/n - xhat * s2/n), a = gamma*invstd ; dy_m = dy masked by (y > 0);
+// dres (optional) = dy_m, the gradient flowing into a residual input added before the ReLU.
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ y,
+                                                           int ldy, const float *__restrict__ x, int ldx, int n, int c,
+                                                           const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                           const float *__restrict__ gamma, const float *__restrict__ s1,
+                                                           const float *__restrict__ s2, float *__restrict__ dx, int lddx,
+                                                           float *__restrict__ dres, int lddres) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)n * c;
+    if (i >= total) return;
+    const int r = (int)(i / c), col = (int)(i - (long long)r * c);
+    float g = dy[(size_t)r * lddy + col];
+    if (y && !(y[(size_t)r * ldy + col] > 0.f)) g = 0.f;
+    if (dres) dres[(size_t)r * lddres + col] = g;
+    const float is = invstd[col];
+    const float xh = (x[(size_t)r * ldx + col] - mean[col]) * is;
+    const float inv_n = 1.0f / (float)n;
+    dx[(size_t)r * lddx + col] = gamma[col] * is * (g - s1[col] * inv_n - xh * s2[col] * inv_n);
+}
+
+// ReLU backward for layers without BatchNorm in between: dx = dy * (y > 0)
+__global__ void __launch_bounds__(256) relu_bwd_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ y,
+                                                       int ldy, int n, int c, float *__restrict__ dx, int lddx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * c) return;
+    const int r = (int)(i / c), col = (int)(i - (long long)r * c);
+    dx[(size_t)r * lddx + col] = y[(size_t)r * ldy + col] > 0.f ? dy[(size_t)r * lddy + col] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[t][ci][co] = sum_j in[nbr[t][j]][ci] * dy[j][co].
+// One wave = one (row chunk, tap, ci tile, co tile); MFMA 16x16x4 with K = 4 rows per step:
+// lane (r, g) feeds A with VA consecutive channels of gathered row g and B with VB consecutive
+// channels of dy row g, so one step is VA*VB MFMAs on a (16*VA) x (16*VB) tile. 4-row groups
+// with no neighbour are skipped (wave-uniform). Row-chunk partials are summed by a second kernel.
+// ---------------------------------------------------------------------------------------------
+struct WgParams {
+    const float *in;
+    const float *dy;
+    const int32_t *nbr;
+    float *part;
+    int in_ld, dy_ld, c_in, c_out, kv, n_out;
+    int rows_per_chunk, n_chunks, ci_tiles, co_tiles;
+};
+
+template <int VA, int VB>
+__global__ void __launch_bounds__(64) wgrad_kernel(WgParams p) {
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    int id = blockIdx.x;
+    const int cot = id % p.co_tiles; id /= p.co_tiles;
+    const int cit = id % p.ci_tiles; id /= p.ci_tiles;
+    const int t = id % p.kv;
+    const int chunk = id / p.kv;
+    const int r0 = chunk * p.rows_per_chunk, r1 = min(p.n_out, r0 + p.rows_per_chunk);
+    const int ci0 = cit * 16 * VA, co0 = cot * 16 * VB;
+
+    f32x4 acc[VA][VB];
+#pragma unroll
+    for (int a = 0; a < VA; ++a)
+#pragma unroll
+        for (int b = 0; b < VB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int j0 = r0; j0 < r1; j0 += 64) {
+        // rulebook entries of 64 rows in one coalesced load, then 16 steps of 4 rows
+        const int jr = j0 + lane;
+        int idxv = -1;
+        if (jr < r1) idxv = p.nbr ? p.nbr[(size_t)t * p.n_out + jr] : jr;
+        if (!__any(idxv >= 0)) continue;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int idx = __shfl(idxv, 4 * s + g, 64);
+            if (!__any(idx >= 0)) continue;
+            const int row = j0 + 4 * s + g;
+            float av[VA], bv[VB];
+            const float *ap = p.in + (size_t)(idx < 0 ? 0 : idx) * p.in_ld + ci0 + VA * r;
+            const float *bp = p.dy + (size_t)(row < r1 ? row : r0) * p.dy_ld + co0 + VB * r;
+#pragma unroll
+            for (int a = 0; a < VA; ++a) av[a] = (idx >= 0 && ci0 + VA * r + a < p.c_in) ? ap[a] : 0.f;
+#pragma unroll
+            for (int b = 0; b < VB; ++b) bv[b] = (row < r1 && co0 + VB * r + b < p.c_out) ? bp[b] : 0.f;
+#pragma unroll
+            for (int a = 0; a < VA; ++a)
+#pragma unroll
+                for (int b = 0; b < VB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // D[i][j]: i = 4g+e <-> channel ci0 + VA*i + a ; j = r <-> column co0 + VB*r + b
+    float *out = p.part + ((size_t)chunk * p.kv + t) * p.c_in * p.c_out;
+#pragma unroll
+    for (int a = 0; a < VA; ++a)
+#pragma unroll
+        for (int b = 0; b < VB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = ci0 + VA * (4 * g + e) + a, co = co0 + VB * r + b;
+                if (ci < p.c_in && co < p.c_out) out[(size_t)ci * p.c_out + co] = acc[a][b][e];
+            }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int n_chunks, size_t elems,
+                                                           float *__restrict__ dw, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= elems) return;
+    float s = accumulate ? dw[i] : 0.f;
+    for (int k = 0; k < n_chunks; ++k) s += part[(size_t)k * elems + i];
+    dw[i] = s;
+}
+
+typedef void (*wg_kernel_t)(WgParams);
+static wg_kernel_t pick_wg(int va, int vb) {
+    switch (va * 10 + vb) {
+        case 11: return wgrad_kernel<1, 1>;
+        case 12: return wgrad_kernel<1, 2>;
+        case 14: return wgrad_kernel<1, 4>;
+        case 21: return wgrad_kernel<2, 1>;
+        case 22: return wgrad_kernel<2, 2>;
+        case 24: return wgrad_kernel<2, 4>;
+        case 41: return wgrad_kernel<4, 1>;
+        case 42: return wgrad_kernel<4, 2>;
+        case 44: return wgrad_kernel<4, 4>;
+    }
+    return nullptr;
+}
+static int lanes_per_16(int c) { return c >= 64 ? 4 : (c >= 32 ? 2 : 1); }
+
+// Transposed rulebook of a strided sparse conv: nbrT[t][i] = output row fed by input i through tap t.
+struct GridT { int32_t b, d, h, w; };
+__device__ __forceinline__ int32_t lookup_canonical(const uint64_t *bitmap, const uint32_t *base, long long key) {
+    const uint64_t w = bitmap[key >> 6];
+    const uint64_t bit = 1ull << (key & 63);
+    if (!(w & bit)) return -1;
+    return (int32_t)(base[key >> 6] + __popcll(w & (bit - 1ull)));
+}
+__global__ void __launch_bounds__(256)
+rulebook_transpose_kernel(const int32_t *__restrict__ in_idx, int n_in, GridT go, int kd, int kh, int kw, int sd, int sh, int sw,
+                          int pd, int ph, int pw, const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
+                          int32_t *__restrict__ nbr_t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    const int4 q = reinterpret_cast<const int4 *>(in_idx)[i];
+    int t = 0;
+    for (int tz = 0; tz < kd; ++tz)
+        for (int ty = 0; ty < kh; ++ty)
+            for (int tx = 0; tx < kw; ++tx, ++t) {
+                int32_t rr = -1;
+                const int nz = q.y + pd - tz, ny = q.z + ph - ty, nx = q.w + pw - tx;
+                if (nz >= 0 && ny >= 0 && nx >= 0 && nz % sd == 0 && ny % sh == 0 && nx % sw == 0) {
+                    const int oz = nz / sd, oy = ny / sh, ox = nx / sw;
+                    if (oz < go.d && oy < go.h && ox < go.w)
+                        rr = lookup_canonical(bitmap, base, (((long long)q.x * go.d + oz) * go.h + oy) * go.w + ox);
+                }
+                nbr_t[(size_t)t * n_in + i] = rr;
+            }
+}
+
+__global__ void __launch_bounds__(256) rulebook_conv2d_transpose_kernel(int batch, int h, int w, int ho, int wo, int kh, int kw,
+                                                                        int stride, int pad, int32_t *__restrict__ nbr_t) {
+    const long long n_in = (long long)batch * h * w;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    const int x = (int)(i % w);
+    const long long t2 = i / w;
+    const int y = (int)(t2 % h), b = (int)(t2 / h);
+    int t = 0;
+    for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx, ++t) {
+            int32_t rr = -1;
+            const int ny = y + pad - ky, nx = x + pad - kx;
+            if (ny >= 0 && nx >= 0 && ny % stride == 0 && nx % stride == 0) {
+                const int oy = ny / stride, ox = nx / stride;
+                if (oy < ho && ox < wo) rr = (int32_t)(((long long)b * ho + oy) * wo + ox);
+            }
+            nbr_t[(size_t)t * n_in + i] = rr;
+        }
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2, float gscale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float w = p[i];
+    w -= lr * wd * w;                                   // decoupled weight decay (true_wd, fastai_optim.py:132-150)
+    w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = w;
+}
+
+}  // namespace
+
+static int col_reduce(int mode, const float *a, int lda, const float *y, int ldy, const float *x, int ldx, const float *mean,
+                      const float *invstd, int n, int c, float *s1, float *s2, void *ws, size_t ws_bytes, hipStream_t s) {
+    if (!a || !s1 || n <= 0 || c <= 0 || !ws) return CPD_ERR_ARG;
+    const int rpb = 1024;
+    const int nb = (n + rpb - 1) / rpb;
+    if (ws_bytes < (size_t)nb * 2 * c * sizeof(float)) return CPD_ERR_WORKSPACE;
+    ColParams p{a, y, x, mean, invstd, lda, ldy, ldx, n, c, rpb};
+    float *part = (float *)ws;
+    if (mode == COL_SUM) col_partial_kernel<COL_SUM><<<nb, 256, 0, s>>>(p, part);
+    else if (mode == COL_STATS) col_partial_kernel<COL_STATS><<<nb, 256, 0, s>>>(p, part);
+    else col_partial_kernel<COL_BNBWD><<<nb, 256, 0, s>>>(p, part);
+    col_final_kernel<<<cpd_div_up(c, 256), 256, 0, s>>>(part, nb, c, s1, s2);
+    return cpd_check_launch();
+}
+
+extern "C" size_t cpd_col_reduce_workspace_bytes(int n, int c) {
+    if (n <= 0 || c <= 0) return 0;
+    return cpd_align((size_t)((n + 1023) / 1024) * 2 * c * sizeof(float));
+}
+extern "C" int cpd_col_sum(const float *x, int ldx, int n, int c, float *sum, void *ws, size_t ws_bytes, cpd_stream_t st) {
+    return col_reduce(COL_SUM, x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, n, c, sum, nullptr, ws, ws_bytes, cpd_s(st));
+}
+extern "C" int cpd_bn_stats(const float *x, int ldx, int n, int c, float *sum, float *sumsq, void *ws, size_t ws_bytes,
+                            cpd_stream_t st) {
+    if (!sumsq) return CPD_ERR_ARG;
+    return col_reduce(COL_STATS, x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, n, c, sum, sumsq, ws, ws_bytes, cpd_s(st));
+}
+extern "C" int cpd_bn_bwd_reduce(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, const float *mean,
+                                 const float *invstd, int n, int c, float *dbeta, float *dgamma, void *ws, size_t ws_bytes,
+                                 cpd_stream_t st) {
+    if (!x || !mean || !invstd || !dgamma) return CPD_ERR_ARG;
+    return col_reduce(COL_BNBWD, dy, lddy, y, ldy, x, ldx, mean, invstd, n, c, dbeta, dgamma, ws, ws_bytes, cpd_s(st));
+}
+extern "C" int cpd_affine_rows(const float *x, int ldx, int n, int c, const float *scale, const float *shift,
+                               const float *residual, int ldr, int relu, float *out, int ldo, cpd_stream_t st) {
+    if (!x || !out || n < 0 || c <= 0) return CPD_ERR_ARG;
+    if (n == 0) return CPD_OK;
+    affine_rows_kernel<<<cpd_div_up((long long)n * c, 256), 256, 0, cpd_s(st)>>>(x, ldx, n, c, scale, shift, residual, ldr, relu,
+                                                                                out, ldo);
+    return cpd_check_launch();
+}
+extern "C" int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, int n, int c,
+                                const float *mean, const float *invstd, const float *gamma, const float *dbeta,
+                                const float *dgamma, float *dx, int lddx, float *dres, int lddres, cpd_stream_t st) {
+    if (!dy || !x || !mean || !invstd || !gamma || !dbeta || !dgamma || !dx || n <= 0 || c <= 0) return CPD_ERR_ARG;
+    bn_bwd_apply_kernel<<<cpd_div_up((long long)n * c, 256), 256, 0, cpd_s(st)>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd,
+                                                                                 gamma, dbeta, dgamma, dx, lddx, dres, lddres);
+    return cpd_check_launch();
+}
+extern "C" int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, int n, int c, float *dx, int lddx,
+                            cpd_stream_t st) {
+    if (!dy || !y || !dx || n < 0 || c <= 0) return CPD_ERR_ARG;
+    if (n == 0) return CPD_OK;
+    relu_bwd_kernel<<<cpd_div_up((long long)n * c, 256), 256, 0, cpd_s(st)>>>(dy, lddy, y, ldy, n, c, dx, lddx);
+    return cpd_check_launch();
+}
+
+static void wgrad_plan(int n_out, int c_in, int c_out, int kv, WgParams *p, int *va, int *vb) {
+    *va = lanes_per_16(c_in); *vb = lanes_per_16(c_out);
+    p->ci_tiles = (c_in + 16 * *va - 1) / (16 * *va);
+    p->co_tiles = (c_out + 16 * *vb - 1) / (16 * *vb);
+    // enough waves to fill the chip, few enough chunks to keep the partial buffer small
+    long long per_chunk = (long long)kv * p->ci_tiles * p->co_tiles;
+    int chunks = (int)((8192 + per_chunk - 1) / per_chunk);
+    int max_chunks = (n_out + 255) / 256;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    p->rows_per_chunk = ((n_out + chunks - 1) / chunks + 63) / 64 * 64;
+    p->n_chunks = (n_out + p->rows_per_chunk - 1) / p->rows_per_chunk;
+}
+extern "C" size_t cpd_conv_wgrad_workspace_bytes(int n_out, int c_in, int c_out, int kv) {
+    if (n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0) return 0;
+    WgParams p; int va, vb;
+    wgrad_plan(n_out, c_in, c_out, kv, &p, &va, &vb);
+    return cpd_align((size_t)p.n_chunks * kv * c_in * c_out * sizeof(float));
+}
+extern "C" int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out, const int32_t *nbr,
+                              int kv, int n_out, float *dw_kio, int accumulate, void *ws, size_t ws_bytes, cpd_stream_t st) {
+    if (!in || !dy || !dw_kio || !ws || n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || (!nbr && kv != 1)) return CPD_ERR_ARG;
+    WgParams p;
+    int va, vb;
+    wgrad_plan(n_out, c_in, c_out, kv, &p, &va, &vb);
+    if (ws_bytes < (size_t)p.n_chunks * kv * c_in * c_out * sizeof(float)) return CPD_ERR_WORKSPACE;
+    p.in = in; p.dy = dy; p.nbr = nbr; p.part = (float *)ws;
+    p.in_ld = in_ld; p.dy_ld = dy_ld; p.c_in = c_in; p.c_out = c_out; p.kv = kv; p.n_out = n_out;
+    wg_kernel_t k = pick_wg(va, vb);
+    if (!k) return CPD_ERR_UNSUPPORTED;
+    const long long blocks = (long long)p.n_chunks * kv * p.ci_tiles * p.co_tiles;
+    if (blocks >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), 0, cpd_s(st), p);
+    const size_t elems = (size_t)kv * c_in * c_out;
+    wgrad_reduce_kernel<<<cpd_div_up((long long)elems, 256), 256, 0, cpd_s(st)>>>(p.part, p.n_chunks, elems, dw_kio, accumulate);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_rulebook_conv_transpose(const int32_t *in_indices, int n_in, int batch, const int32_t in_shape[3],
+                                           const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3],
+                                           const void *out_index, int32_t *nbr_t, cpd_stream_t st) {
+    int32_t os[3];
+    if (!in_indices || !out_index || !nbr_t || n_in <= 0 || batch <= 0) return CPD_ERR_ARG;
+    int rc = cpd_conv_out_shape(in_shape, ksize, stride, pad, os);
+    if (rc) return rc;
+    // the output index is canonical (built by cpd_conv_outset): header 256 B, bitmap, base
+    const long long cells = (long long)batch * os[0] * os[1] * os[2];
+    const long long words = (cells + 63) / 64;
+    const char *b = (const char *)out_index;
+    const uint64_t *bitmap = (const uint64_t *)(b + 256);
+    const uint32_t *base = (const uint32_t *)(b + 256 + cpd_align((size_t)words * 8));
+    GridT go{batch, os[0], os[1], os[2]};
+    rulebook_transpose_kernel<<<cpd_div_up(n_in, 256), 256, 0, cpd_s(st)>>>(in_indices, n_in, go, ksize[0], ksize[1], ksize[2],
+                                                                           stride[0], stride[1], stride[2], pad[0], pad[1],
+                                                                           pad[2], bitmap, base, nbr_t);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_rulebook_conv2d_transpose(int batch, int h, int w, int kh, int kw, int stride, int pad, int32_t *nbr_t,
+                                             cpd_stream_t st) {
+    if (batch <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 || !nbr_t) return CPD_ERR_ARG;
+    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    const long long n_in = (long long)batch * h * w;
+    rulebook_conv2d_transpose_kernel<<<cpd_div_up(n_in, 256), 256, 0, cpd_s(st)>>>(batch, h, w, ho, wo, kh, kw, stride, pad, nbr_t);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float grad_scale, cpd_stream_t st) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step <= 0) return CPD_ERR_ARG;
+    if (n == 0) return CPD_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    adam_kernel<<<cpd_div_up((long long)n, 256), 256, 0, cpd_s(st)>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                                                                     weight_decay, bc1, bc2, grad_scale);
+    return cpd_check_launch();
+}

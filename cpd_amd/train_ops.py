@@ -1,0 +1,112 @@
+"""Tensor-level wrappers of the training entry points of the C-ABI (include/cpd_hip.h, "Training step")."""
+import ctypes
+
+import torch
+
+from ._lib import check, iarr, lib, ptr, stream
+
+_ws_cache = {}
+
+
+def _ws(nbytes, device):
+    """Grow-only scratch buffer per (device, stream) -- the kernels on one stream run in order."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0)
+
+
+def col_sum(x):
+    n, c = x.shape
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().cpd_col_reduce_workspace_bytes(n, c), x.device)
+    check(lib().cpd_col_sum(_p(x), _ld(x), n, c, ptr(out), ptr(ws), ws.numel(), stream()), "cpd_col_sum")
+    return out
+
+
+def bn_stats(x):
+    """(sum[c], sumsq[c]) over the rows of x [n, c]."""
+    n, c = x.shape
+    s1 = torch.empty((c,), dtype=torch.float32, device=x.device)
+    s2 = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().cpd_col_reduce_workspace_bytes(n, c), x.device)
+    check(lib().cpd_bn_stats(_p(x), _ld(x), n, c, ptr(s1), ptr(s2), ptr(ws), ws.numel(), stream()), "cpd_bn_stats")
+    return s1, s2
+
+
+def affine_rows(x, scale=None, shift=None, residual=None, relu=False, out=None):
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(lib().cpd_affine_rows(_p(x), _ld(x), n, c, ptr(scale), ptr(shift), _p(residual),
+                                _ld(residual) if residual is not None else 0, int(bool(relu)), _p(out), _ld(out), stream()),
+          "cpd_affine_rows")
+    return out
+
+
+def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False):
+    """BatchNorm(+ReLU when y is given) backward. Returns (dx, dgamma, dbeta, dres|None)."""
+    n, c = x.shape
+    dev = x.device
+    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+    dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+    ws = _ws(lib().cpd_col_reduce_workspace_bytes(n, c), dev)
+    check(lib().cpd_bn_bwd_reduce(_p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(x), _ld(x), ptr(mean), ptr(invstd),
+                                  n, c, ptr(dbeta), ptr(dgamma), ptr(ws), ws.numel(), stream()), "cpd_bn_bwd_reduce")
+    dx = torch.empty((n, c), dtype=torch.float32, device=dev)
+    dres = torch.empty((n, c), dtype=torch.float32, device=dev) if want_dres else None
+    check(lib().cpd_bn_bwd_apply(_p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(x), _ld(x), n, c, ptr(mean),
+                                 ptr(invstd), ptr(gamma), ptr(dbeta), ptr(dgamma), _p(dx), _ld(dx), _p(dres),
+                                 _ld(dres) if dres is not None else 0, stream()), "cpd_bn_bwd_apply")
+    return dx, dgamma, dbeta, dres
+
+
+def relu_backward(dy, y):
+    n, c = y.shape
+    dx = torch.empty((n, c), dtype=torch.float32, device=y.device)
+    check(lib().cpd_relu_bwd(_p(dy), _ld(dy), _p(y), _ld(y), n, c, _p(dx), _ld(dx), stream()), "cpd_relu_bwd")
+    return dx
+
+
+def conv_wgrad(inp, c_in, dy, c_out, nbr, kv, n_out, dw=None, accumulate=False):
+    """dw[kv, c_in, c_out] (+)= sum_j inp[nbr[t][j]]^T dy[j]."""
+    if dw is None:
+        dw = torch.empty((kv, c_in, c_out), dtype=torch.float32, device=inp.device)
+        accumulate = False
+    ws = _ws(lib().cpd_conv_wgrad_workspace_bytes(n_out, c_in, c_out, kv), inp.device)
+    check(lib().cpd_conv_wgrad(_p(inp), _ld(inp), c_in, _p(dy), _ld(dy), c_out, ptr(nbr), kv, n_out, ptr(dw),
+                               int(bool(accumulate)), ptr(ws), ws.numel(), stream()), "cpd_conv_wgrad")
+    return dw
+
+
+def rulebook_conv_transpose(in_indices, batch, in_shape, ksize, stride, pad, out_index):
+    n_in = in_indices.shape[0]
+    kv = int(ksize[0] * ksize[1] * ksize[2])
+    nbr_t = torch.empty((kv, n_in), dtype=torch.int32, device=in_indices.device)
+    check(lib().cpd_rulebook_conv_transpose(ptr(in_indices.contiguous()), n_in, batch, iarr(in_shape), iarr(ksize), iarr(stride),
+                                            iarr(pad), ptr(out_index.buf), ptr(nbr_t), stream()), "cpd_rulebook_conv_transpose")
+    return nbr_t
+
+
+def rulebook_conv2d_transpose(batch, h, w, kh, kw, stride, pad, device):
+    nbr_t = torch.empty((kh * kw, batch * h * w), dtype=torch.int32, device=device)
+    check(lib().cpd_rulebook_conv2d_transpose(batch, h, w, kh, kw, stride, pad, ptr(nbr_t), stream()),
+          "cpd_rulebook_conv2d_transpose")
+    return nbr_t
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    check(lib().cpd_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr), float(beta1),
+                              float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), stream()),
+          "cpd_adam_step")

@@ -209,6 +209,58 @@ int cpd_select_boxes(const float *boxes, const float *scores, const int32_t *lab
  * gt-sampling, database_sampler.py:445-446); it is product code, not the test oracle.        */
 int cpd_boxes_iou_bev_cpu(const float *a, int n, const float *b, int m, float *out);
 
+
+/* ===== Training step (BASELINE config 3) ====================================================
+ * Forward in training mode is cpd_gather_conv (no folded BN) + cpd_bn_stats + cpd_affine_rows; the
+ * input gradient of every conv is cpd_gather_conv again on transposed (tap-flipped for SubM /
+ * stride-1) weights with the same or the transposed rulebook; the rest is below. These replace
+ * what torch autograd + cuDNN + spconv's backward ops do under tools/train_utils/train_utils.py:41
+ * (loss.backward()) for the modules of the path.                                               */
+size_t cpd_col_reduce_workspace_bytes(int n, int c);
+/* column sums of x[n, c] (bias gradients). */
+int cpd_col_sum(const float *x, int ldx, int n, int c, float *sum, void *ws, size_t ws_bytes,
+                cpd_stream_t stream);
+/* training-mode BatchNorm statistics: sum[c], sumsq[c] over the n rows (two-stage, deterministic). */
+int cpd_bn_stats(const float *x, int ldx, int n, int c, float *sum, float *sumsq, void *ws,
+                 size_t ws_bytes, cpd_stream_t stream);
+/* out = act(x * scale + shift + residual): BatchNorm apply (scale = gamma*invstd,
+ * shift = beta - mean*scale), SparseBasicBlock tail (spconv_backbone.py:131-134). In place allowed. */
+int cpd_affine_rows(const float *x, int ldx, int n, int c, const float *scale, const float *shift,
+                    const float *residual, int ldr, int relu, float *out, int ldo,
+                    cpd_stream_t stream);
+/* BatchNorm(+ReLU) backward. dy_m = dy * (y > 0) (y = NULL: no ReLU);
+ * reduce: dbeta = sum dy_m, dgamma = sum dy_m * xhat; apply: dx = gamma*invstd*(dy_m - dbeta/n -
+ * xhat*dgamma/n), optional dres = dy_m (gradient into a residual added before the ReLU).       */
+int cpd_bn_bwd_reduce(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx,
+                      const float *mean, const float *invstd, int n, int c, float *dbeta,
+                      float *dgamma, void *ws, size_t ws_bytes, cpd_stream_t stream);
+int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx,
+                     int n, int c, const float *mean, const float *invstd, const float *gamma,
+                     const float *dbeta, const float *dgamma, float *dx, int lddx, float *dres,
+                     int lddres, cpd_stream_t stream);
+int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, int n, int c, float *dx,
+                 int lddx, cpd_stream_t stream);
+/* Weight gradient of cpd_gather_conv: dw[t][ci][co] (+)= sum_j in[nbr[t][j]][ci] * dy[j][co]
+ * (dense [kv][c_in][c_out] layout, the layout cpd_pack_weight consumes). fp32 MFMA, deterministic. */
+size_t cpd_conv_wgrad_workspace_bytes(int n_out, int c_in, int c_out, int kv);
+int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out,
+                   const int32_t *nbr, int kv, int n_out, float *dw_kio, int accumulate, void *ws,
+                   size_t ws_bytes, cpd_stream_t stream);
+/* Transposed rulebooks for the input gradient of strided convs: nbr_t[t][i] = output row that
+ * input row i feeds through tap t (or -1). Sparse: out_index is the index cpd_conv_outset built. */
+int cpd_rulebook_conv_transpose(const int32_t *in_indices, int n_in, int batch,
+                                const int32_t in_shape[3], const int32_t ksize[3],
+                                const int32_t stride[3], const int32_t pad[3], const void *out_index,
+                                int32_t *nbr_t, cpd_stream_t stream);
+int cpd_rulebook_conv2d_transpose(int batch, int h, int w, int kh, int kw, int stride, int pad,
+                                  int32_t *nbr_t, cpd_stream_t stream);
+/* Adam with decoupled weight decay on a flat buffer (tools/train_utils/optimization/fastai_optim.py:
+ * 132-150 true_wd semantics): grad is multiplied by grad_scale first (1/world after all-reduce,
+ * clip factor). `step` counts from 1.                                                           */
+int cpd_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  float grad_scale, cpd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

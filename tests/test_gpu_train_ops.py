@@ -1,0 +1,181 @@
+"""Training kernels (config 3) against plain torch fp32 CPU references: BatchNorm statistics /
+backward vs torch autograd, conv weight and input gradients vs autograd through the gather-matmul
+form of the same convolution, transposed rulebooks vs their definition, Adam vs a numpy step."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cpd_amd import ops, train_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def random_sites(rng, batch, shape, n):
+    cells = batch * shape[0] * shape[1] * shape[2]
+    lin = rng.choice(cells, size=min(n, cells), replace=False)
+    b, r = np.divmod(lin, shape[0] * shape[1] * shape[2])
+    z, r = np.divmod(r, shape[1] * shape[2])
+    y, x = np.divmod(r, shape[2])
+    return np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("n,c", [(5000, 16), (33333, 128), (2000, 320), (70000, 64)])
+def test_bn_stats_and_backward_match_torch(hip, n, c):
+    rng = np.random.default_rng(n + c)
+    x = (rng.normal(size=(n, c)) * rng.uniform(0.5, 2, c) + rng.normal(size=c)).astype(np.float32)
+    res = rng.normal(size=(n, c)).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32); beta = rng.normal(size=c).astype(np.float32)
+    dy = rng.normal(size=(n, c)).astype(np.float32)
+    eps = 1e-3
+    # torch reference: y = relu(bn(x) + res)
+    xt = torch.tensor(x, requires_grad=True); rt = torch.tensor(res, requires_grad=True)
+    gt = torch.tensor(gamma, requires_grad=True); bt = torch.tensor(beta, requires_grad=True)
+    yt = F.relu(F.batch_norm(xt, None, None, gt, bt, training=True, eps=eps) + rt)
+    yt.backward(torch.tensor(dy))
+    # HIP
+    xd = dev(x)
+    s1, s2 = T.bn_stats(xd)
+    mean = s1 / n
+    var = (s2 / n - mean * mean).clamp_min(0)
+    np.testing.assert_allclose(mean.cpu().numpy(), x.mean(0), atol=2e-5)
+    np.testing.assert_allclose(var.cpu().numpy(), x.var(0), rtol=2e-4, atol=1e-5)
+    invstd = torch.rsqrt(var + eps)
+    scale = dev(gamma) * invstd
+    shift = dev(beta) - mean * scale
+    y = T.affine_rows(xd, scale, shift, dev(res), True)
+    np.testing.assert_allclose(y.cpu().numpy(), yt.detach().numpy(), atol=2e-4)
+    dx, dgamma, dbeta, dres = T.bn_backward(dev(dy), y, xd, mean, invstd, dev(gamma), want_dres=True)
+    np.testing.assert_allclose(dres.cpu().numpy(), rt.grad.numpy(), atol=1e-6)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), bt.grad.numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gt.grad.numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(dx.cpu().numpy(), xt.grad.numpy(), atol=2e-4)
+    np.testing.assert_allclose(T.col_sum(dev(dy)).cpu().numpy(), dy.sum(0), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(T.relu_backward(dev(dy), y).cpu().numpy(), dy * (y.cpu().numpy() > 0), atol=0)
+
+
+def gather_matmul(x, w_kio, nbr):
+    """Autograd-capable torch form of cpd_gather_conv: sum_t x[nbr[t]] @ W[t] (masked)."""
+    out = 0
+    for t in range(nbr.shape[0]):
+        idx = torch.from_numpy(nbr[t].astype(np.int64))
+        g = x[idx.clamp_min(0)] * (idx >= 0).float()[:, None]
+        out = out + g @ w_kio[t]
+    return out
+
+
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (32, 64), (64, 64), (128, 128), (64, 11)])
+def test_subm_conv_gradients_match_autograd(oracle, hip, cin, cout):
+    rng = np.random.default_rng(cin * 7 + cout)
+    batch, shape = 2, [7, 24, 24]
+    idx = random_sites(rng, batch, shape, 2500)
+    n = idx.shape[0]
+    nbr = oracle.subm_rulebook(idx, batch, shape, [3, 3, 3])
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(27, cin, cout)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    dy = rng.normal(size=(n, cout)).astype(np.float32)
+    xt = torch.tensor(x, requires_grad=True); wt = torch.tensor(w, requires_grad=True)
+    gather_matmul(xt, wt, nbr).backward(torch.tensor(dy))
+    nbr_d = dev(nbr)
+    dw = T.conv_wgrad(dev(x), cin, dev(dy), cout, nbr_d, 27, n)
+    np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=1e-4, atol=2e-3)
+    # input gradient: same table, taps flipped, weights transposed (SubM symmetry)
+    wd = torch.from_numpy(w).flip(0).transpose(1, 2).contiguous().cuda()          # [27, cout, cin]
+    dx = ops.gather_conv(dev(dy), cout, ops.pack_weight(wd), nbr_d, 27, n, cin)
+    np.testing.assert_allclose(dx.cpu().numpy(), xt.grad.numpy(), atol=2e-4)
+    # accumulate flag
+    dw2 = T.conv_wgrad(dev(x), cin, dev(dy), cout, nbr_d, 27, n, dw=dw.clone(), accumulate=True)
+    np.testing.assert_allclose(dw2.cpu().numpy(), 2 * wt.grad.numpy(), rtol=1e-4, atol=4e-3)
+
+
+def test_strided_sparse_conv_gradients(oracle, hip):
+    rng = np.random.default_rng(5)
+    batch, shape, cin, cout = 2, [9, 20, 22], 32, 64
+    k, s, p = [3, 3, 3], [2, 2, 2], [1, 1, 1]
+    idx = random_sites(rng, batch, shape, 2000)
+    d_idx = dev(idx)
+    out_idx, out_index, out_shape = ops.conv_outset(d_idx, batch, shape, k, s, p)
+    index = ops.SiteIndex.build(d_idx, batch, shape)
+    nbr = ops.rulebook_conv(out_idx, index, k, s, p)
+    nbr_np = nbr.cpu().numpy()
+    n_in, n_out = idx.shape[0], out_idx.shape[0]
+    # transposed table against its definition
+    nbr_t = T.rulebook_conv_transpose(d_idx, batch, shape, k, s, p, out_index).cpu().numpy()
+    want_t = np.full((27, n_in), -1, np.int32)
+    tt, jj = np.nonzero(nbr_np >= 0)
+    want_t[tt, nbr_np[tt, jj]] = jj
+    np.testing.assert_array_equal(nbr_t, want_t)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    w = (rng.normal(size=(27, cin, cout)) * 0.05).astype(np.float32)
+    dy = rng.normal(size=(n_out, cout)).astype(np.float32)
+    xt = torch.tensor(x, requires_grad=True); wt = torch.tensor(w, requires_grad=True)
+    gather_matmul(xt, wt, nbr_np).backward(torch.tensor(dy))
+    dw = T.conv_wgrad(dev(x), cin, dev(dy), cout, nbr, 27, n_out)
+    np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=1e-4, atol=2e-3)
+    wd = torch.from_numpy(w).transpose(1, 2).contiguous().cuda()                   # no flip: transposed table
+    dx = ops.gather_conv(dev(dy), cout, ops.pack_weight(wd), dev(nbr_t), 27, n_in, cin)
+    np.testing.assert_allclose(dx.cpu().numpy(), xt.grad.numpy(), atol=2e-4)
+
+
+def test_conv2d_and_deconv_gradients_match_torch(hip):
+    """Dense BEV convs: stride 1 (flip), stride 2 (transposed pixel table), ConvTranspose2d(k=s=2)."""
+    rng = np.random.default_rng(8)
+    b, cin, cout, h, w = 2, 32, 64, 12, 14
+    x = rng.normal(size=(b, cin, h, w)).astype(np.float32)
+    rows = lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 3, 1).reshape(-1, a.shape[1]))).cuda()
+    nchw = lambda r, hh, ww: r.cpu().numpy().reshape(b, hh, ww, -1).transpose(0, 3, 1, 2)
+    for stride in (1, 2):
+        wt = (rng.normal(size=(cout, cin, 3, 3)) * 0.1).astype(np.float32)
+        xt = torch.tensor(x, requires_grad=True); wtt = torch.tensor(wt, requires_grad=True)
+        y = F.conv2d(xt, wtt, None, stride, 1)
+        ho, wo = y.shape[2:]
+        dy = rng.normal(size=y.shape).astype(np.float32)
+        y.backward(torch.tensor(dy))
+        nbr, _, _ = ops.rulebook_conv2d(b, h, w, 3, 3, stride, 1, "cuda")
+        w_kio = torch.from_numpy(wt).permute(2, 3, 1, 0).reshape(9, cin, cout).contiguous()
+        dw = T.conv_wgrad(rows(x), cin, rows(dy), cout, nbr, 9, b * ho * wo)
+        want_dw = wtt.grad.permute(2, 3, 1, 0).reshape(9, cin, cout).numpy()
+        np.testing.assert_allclose(dw.cpu().numpy(), want_dw, rtol=1e-4, atol=2e-3)
+        if stride == 1:
+            wd, tab = w_kio.flip(0).transpose(1, 2).contiguous().cuda(), nbr
+        else:
+            wd, tab = w_kio.transpose(1, 2).contiguous().cuda(), T.rulebook_conv2d_transpose(b, h, w, 3, 3, 2, 1, "cuda")
+        dx = ops.gather_conv(rows(dy), cout, ops.pack_weight(wd), tab, 9, b * h * w, cin)
+        np.testing.assert_allclose(nchw(dx, h, w), xt.grad.numpy(), atol=2e-4)
+    # ConvTranspose2d(k=s=2): forward = 1x1 GEMM + scatter; dgrad = 4-tap gather through the same row maps
+    wd = (rng.normal(size=(cin, cout, 2, 2)) * 0.1).astype(np.float32)
+    xt = torch.tensor(x, requires_grad=True); wdt = torch.tensor(wd, requires_grad=True)
+    y = F.conv_transpose2d(xt, wdt, None, 2)
+    dy = rng.normal(size=y.shape).astype(np.float32)
+    y.backward(torch.tensor(dy))
+    H, W = 2 * h, 2 * w
+    bi = torch.arange(b, device="cuda").view(-1, 1, 1); yy = torch.arange(h, device="cuda").view(1, -1, 1)
+    xx = torch.arange(w, device="cuda").view(1, 1, -1)
+    maps = torch.stack([((bi * H + 2 * yy + a) * W + 2 * xx + c).reshape(-1) for a in range(2) for c in range(2)]).to(torch.int32).contiguous()
+    w_t = torch.from_numpy(wd).permute(2, 3, 1, 0).reshape(4, cout, cin).contiguous().cuda()      # [tap][co][ci]
+    dx = ops.gather_conv(rows(dy), cout, ops.pack_weight(w_t), maps, 4, b * h * w, cin)
+    np.testing.assert_allclose(nchw(dx, h, w), xt.grad.numpy(), atol=2e-4)
+    # dW[ci][(a,b,co)] = sum_pix x[pix][ci] * dy[(2y+a,2x+b)][co]  == wgrad with in/out roles swapped per tap
+    dwt = T.conv_wgrad(rows(dy), cout, rows(x), cin, maps, 4, b * h * w)          # [tap][co][ci]
+    want = wdt.grad.permute(2, 3, 1, 0).reshape(4, cout, cin).numpy()
+    np.testing.assert_allclose(dwt.cpu().numpy(), want, rtol=1e-4, atol=2e-3)
+
+
+def test_adam_step(hip):
+    rng = np.random.default_rng(2)
+    n = 100003
+    p = rng.normal(size=n).astype(np.float32); g = rng.normal(size=n).astype(np.float32)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    pd, md, vd = dev(p), dev(m), dev(v)
+    lr, b1, b2, eps, wd = 3e-3, 0.9, 0.99, 1e-8, 1e-2
+    for step in (1, 2, 3):
+        T.adam_step(pd, dev(g), md, vd, lr, b1, b2, eps, wd, step, grad_scale=0.5)
+        gs = g * 0.5
+        m = b1 * m + (1 - b1) * gs; v = b2 * v + (1 - b2) * gs * gs
+        p = p - lr * wd * p
+        p = p - lr * (m / (1 - b1 ** step)) / (np.sqrt(v / (1 - b2 ** step)) + eps)
+    np.testing.assert_allclose(pd.cpu().numpy(), p, rtol=1e-5, atol=1e-6)
