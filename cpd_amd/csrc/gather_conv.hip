@@ -557,6 +557,29 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restric
     packed[i] = v;
 }
 
+// Packed image of the ADJOINT weights used by the input gradient: Wd[t'][co][ci] = W[t][ci][co] with
+// t = kv-1-t' when flip is set (SubM / stride-1 convs reuse their own rulebook) else t = t'.
+__global__ void __launch_bounds__(256) pack_weight_adjoint_kernel(const float *__restrict__ w, int kv, int c_in, int c_out,
+                                                                  int flip, int kc_o, int np_o, float *__restrict__ packed) {
+    // adjoint conv has c_in' = c_out, c_out' = c_in ; kc_o = ceil(c_out/16), np_o = 16*ceil(c_in/16)
+    size_t total = (size_t)kv * kc_o * 4 * np_o * 4;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int q = (int)(i & 3);
+    size_t rest = i >> 2;
+    int n = (int)(rest % np_o);
+    rest /= np_o;
+    int g = (int)(rest & 3);
+    rest >>= 2;
+    int k = (int)(rest % kc_o);
+    int tp = (int)(rest / kc_o);
+    int ch = k * 16 + 4 * g + q;             // adjoint input channel  = original output channel
+    int t = flip ? kv - 1 - tp : tp;
+    float v = 0.f;
+    if (ch < c_out && n < c_in) v = w[((size_t)t * c_in + n) * c_out + ch];
+    packed[i] = v;
+}
+
 typedef void (*gc_kernel_t)(GcParams);
 
 template <int MS, int NT>
@@ -665,6 +688,16 @@ extern "C" int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, 
     int kc = (c_in + 15) / 16, np = ((c_out + 15) / 16) * 16;
     size_t total = cpd_packed_weight_floats(kv, c_in, c_out);
     pack_weight_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, kc, np, packed);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_pack_weight_adjoint(const float *w_kio, int kv, int c_in, int c_out, int flip_taps, float *packed,
+                                       cpd_stream_t stream) {
+    if (!w_kio || !packed || kv <= 0 || c_in <= 0 || c_out <= 0) return CPD_ERR_ARG;
+    int kc_o = (c_out + 15) / 16, np_o = ((c_in + 15) / 16) * 16;
+    size_t total = cpd_packed_weight_floats(kv, c_out, c_in);
+    pack_weight_adjoint_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, flip_taps,
+                                                                                            kc_o, np_o, packed);
     return cpd_check_launch();
 }
 

@@ -270,6 +270,33 @@ __global__ void __launch_bounds__(256) rulebook_conv2d_transpose_kernel(int batc
         }
 }
 
+// Per-channel BatchNorm bookkeeping in one launch: batch mean / biased var -> invstd, the affine
+// (scale, shift) that cpd_affine_rows applies, and the running-stat update with the unbiased
+// variance (torch.nn.BatchNorm semantics; momentum 0.01 / eps 1e-3 in the backbones).
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float *__restrict__ sum, const float *__restrict__ sumsq, int n,
+                                                          int c, float eps, float momentum, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ mean,
+                                                          float *__restrict__ invstd, float *__restrict__ scale,
+                                                          float *__restrict__ shift, float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    const double mu = (double)sum[col] / n;
+    double var = (double)sumsq[col] / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[col] = (float)mu;
+    invstd[col] = is;
+    const float sc = gamma[col] * is;
+    scale[col] = sc;
+    shift[col] = beta[col] - (float)mu * sc;
+    if (running_mean) {
+        const double unbiased = n > 1 ? var * n / (n - 1.0) : var;
+        running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * (float)mu;
+        running_var[col] = (1.f - momentum) * running_var[col] + momentum * (float)unbiased;
+    }
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2, float gscale) {
@@ -319,6 +346,16 @@ extern "C" int cpd_bn_bwd_reduce(const float *dy, int lddy, const float *y, int 
                                  cpd_stream_t st) {
     if (!x || !mean || !invstd || !dgamma) return CPD_ERR_ARG;
     return col_reduce(COL_BNBWD, dy, lddy, y, ldy, x, ldx, mean, invstd, n, c, dbeta, dgamma, ws, ws_bytes, cpd_s(st));
+}
+extern "C" int cpd_bn_finalize(const float *sum, const float *sumsq, int n, int c, float eps, float momentum, const float *gamma,
+                               const float *beta, float *mean, float *invstd, float *scale, float *shift,
+                               float *running_mean, float *running_var, cpd_stream_t st) {
+    if (!sum || !sumsq || !gamma || !beta || !mean || !invstd || !scale || !shift || n <= 0 || c <= 0 ||
+        (running_mean && !running_var))
+        return CPD_ERR_ARG;
+    bn_finalize_kernel<<<cpd_div_up(c, 256), 256, 0, cpd_s(st)>>>(sum, sumsq, n, c, eps, momentum, gamma, beta, mean, invstd, scale,
+                                                                 shift, running_mean, running_var);
+    return cpd_check_launch();
 }
 extern "C" int cpd_affine_rows(const float *x, int ldx, int n, int c, const float *scale, const float *shift,
                                const float *residual, int ldr, int relu, float *out, int ldo, cpd_stream_t st) {

@@ -27,9 +27,10 @@ def _ld(t):
     return t.stride(0)
 
 
-def col_sum(x):
+def col_sum(x, out=None):
     n, c = x.shape
-    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((c,), dtype=torch.float32, device=x.device)
     ws = _ws(lib().cpd_col_reduce_workspace_bytes(n, c), x.device)
     check(lib().cpd_col_sum(_p(x), _ld(x), n, c, ptr(out), ptr(ws), ws.numel(), stream()), "cpd_col_sum")
     return out
@@ -45,6 +46,24 @@ def bn_stats(x):
     return s1, s2
 
 
+def bn_finalize(s1, s2, n, eps, momentum, gamma, beta, running_mean=None, running_var=None):
+    """(mean, invstd, scale, shift) from the batch sums; updates the running statistics in place."""
+    c = s1.numel()
+    out = torch.empty((4, c), dtype=torch.float32, device=s1.device)
+    check(lib().cpd_bn_finalize(ptr(s1), ptr(s2), int(n), c, float(eps), float(momentum), ptr(gamma), ptr(beta), _p(out[0]),
+                                _p(out[1]), _p(out[2]), _p(out[3]), ptr(running_mean), ptr(running_var), stream()),
+          "cpd_bn_finalize")
+    return out[0], out[1], out[2], out[3]
+
+
+def pack_weight_adjoint(w_kio, flip_taps):
+    kv, cin, cout = w_kio.shape
+    packed = torch.empty((lib().cpd_packed_weight_floats(kv, cout, cin),), dtype=torch.float32, device=w_kio.device)
+    check(lib().cpd_pack_weight_adjoint(ptr(w_kio), kv, cin, cout, int(bool(flip_taps)), ptr(packed), stream()),
+          "cpd_pack_weight_adjoint")
+    return packed
+
+
 def affine_rows(x, scale=None, shift=None, residual=None, relu=False, out=None):
     n, c = x.shape
     if out is None:
@@ -55,12 +74,15 @@ def affine_rows(x, scale=None, shift=None, residual=None, relu=False, out=None):
     return out
 
 
-def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False):
-    """BatchNorm(+ReLU when y is given) backward. Returns (dx, dgamma, dbeta, dres|None)."""
+def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False, dgamma=None, dbeta=None):
+    """BatchNorm(+ReLU when y is given) backward. Returns (dx, dgamma, dbeta, dres|None);
+    dgamma / dbeta may be caller-provided (views of a flat gradient buffer)."""
     n, c = x.shape
     dev = x.device
-    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
-    dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+    if dbeta is None:
+        dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+    if dgamma is None:
+        dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
     ws = _ws(lib().cpd_col_reduce_workspace_bytes(n, c), dev)
     check(lib().cpd_bn_bwd_reduce(_p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(x), _ld(x), ptr(mean), ptr(invstd),
                                   n, c, ptr(dbeta), ptr(dgamma), ptr(ws), ws.numel(), stream()), "cpd_bn_bwd_reduce")

@@ -223,6 +223,12 @@ int cpd_col_sum(const float *x, int ldx, int n, int c, float *sum, void *ws, siz
 /* training-mode BatchNorm statistics: sum[c], sumsq[c] over the n rows (two-stage, deterministic). */
 int cpd_bn_stats(const float *x, int ldx, int n, int c, float *sum, float *sumsq, void *ws,
                  size_t ws_bytes, cpd_stream_t stream);
+/* Per-channel bookkeeping after cpd_bn_stats: mean, invstd = 1/sqrt(var_biased + eps), the affine
+ * scale = gamma*invstd / shift = beta - mean*scale, and (optional) running-stat update
+ * running = (1-momentum)*running + momentum*batch (unbiased variance), as torch.nn.BatchNorm does. */
+int cpd_bn_finalize(const float *sum, const float *sumsq, int n, int c, float eps, float momentum,
+                    const float *gamma, const float *beta, float *mean, float *invstd, float *scale,
+                    float *shift, float *running_mean, float *running_var, cpd_stream_t stream);
 /* out = act(x * scale + shift + residual): BatchNorm apply (scale = gamma*invstd,
  * shift = beta - mean*scale), SparseBasicBlock tail (spconv_backbone.py:131-134). In place allowed. */
 int cpd_affine_rows(const float *x, int ldx, int n, int c, const float *scale, const float *shift,
@@ -246,6 +252,11 @@ size_t cpd_conv_wgrad_workspace_bytes(int n_out, int c_in, int c_out, int kv);
 int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out,
                    const int32_t *nbr, int kv, int n_out, float *dw_kio, int accumulate, void *ws,
                    size_t ws_bytes, cpd_stream_t stream);
+/* Packed weights of the adjoint conv used for input gradients: Wd[t'][co][ci] = W[t][ci][co],
+ * t = kv-1-t' if flip_taps (SubM / stride-1: the forward rulebook is its own transpose up to the
+ * tap flip) else t = t' (use with a transposed rulebook). Size: cpd_packed_weight_floats(kv, c_out, c_in). */
+int cpd_pack_weight_adjoint(const float *w_kio, int kv, int c_in, int c_out, int flip_taps,
+                            float *packed, cpd_stream_t stream);
 /* Transposed rulebooks for the input gradient of strided convs: nbr_t[t][i] = output row that
  * input row i feeds through tap t (or -1). Sparse: out_index is the index cpd_conv_outset built. */
 int cpd_rulebook_conv_transpose(const int32_t *in_indices, int n_in, int batch,

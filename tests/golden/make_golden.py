@@ -279,6 +279,37 @@ def main():
         d[tag + ".selected"] = sel.numpy()
         d[tag + ".selected_scores"] = sel_sc.numpy()
     np.savez_compressed(os.path.join(HERE, "nms.npz"), **d)
+
+    # ---- 7. CenterHead target assignment + losses (center_head.py:103-250, loss_utils.py:265-386) -----
+    ch = m["center_head"]
+    fake_self = types.SimpleNamespace(point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4], voxel_size=[0.1, 0.1, 0.15])
+    n_gt = 40
+    gt = torch.zeros(n_gt, 8)
+    gt[:, 0:2] = torch.from_numpy(rng.uniform(-70, 70, (n_gt, 2))).float()
+    gt[:, 2] = torch.from_numpy(rng.uniform(-1, 1, n_gt)).float()
+    sizes = torch.tensor([[5.065, 1.86, 1.49], [1.0, 1.0, 2.0], [1.9, 0.85, 1.8]])
+    cls = torch.from_numpy(rng.integers(1, 4, n_gt))
+    gt[:, 3:6] = sizes[cls - 1] * torch.from_numpy(rng.uniform(0.9, 1.1, (n_gt, 3))).float()
+    gt[:, 6] = torch.from_numpy(rng.uniform(-np.pi, np.pi, n_gt)).float()
+    gt[:, 7] = cls.float()
+    gt[:3, 0:2] = torch.tensor([[75.19, -75.19], [-75.2, 75.19], [0.03, 0.04]])       # border / clamped centres
+    heat, ret_boxes, inds, mask = ch.CenterHead.assign_target_of_single_head(
+        fake_self, num_classes=3, gt_boxes=gt.clone(), feature_map_size=[188, 188], feature_map_stride=8,
+        num_max_objs=500, gaussian_overlap=0.1, min_radius=2)
+    lu = m["loss_utils"]
+    pred_hm = torch.clamp(torch.randn(2, 3, 24, 20).sigmoid(), 1e-4, 1 - 1e-4)
+    gt_hm = torch.rand(2, 3, 24, 20) ** 4
+    gt_hm.view(-1)[torch.randperm(gt_hm.numel())[:25]] = 1.0
+    focal = lu.FocalLossCenterNet()(pred_hm, gt_hm)
+    reg_out = torch.randn(2, 8, 24, 20)
+    reg_inds = torch.randint(0, 24 * 20, (2, 50))
+    reg_mask = (torch.rand(2, 50) > 0.4).long()
+    reg_tgt = torch.randn(2, 50, 8)
+    regl = lu.RegLossCenterNet()(reg_out, reg_mask, reg_inds, reg_tgt)
+    np.savez_compressed(os.path.join(HERE, "center_loss.npz"), gt_boxes=gt.numpy(), heatmap=heat.numpy(),
+                        ret_boxes=ret_boxes.numpy(), inds=inds.numpy(), mask=mask.numpy(), pred_hm=pred_hm.numpy(),
+                        gt_hm=gt_hm.numpy(), focal=focal.numpy(), reg_out=reg_out.numpy(), reg_inds=reg_inds.numpy(),
+                        reg_mask=reg_mask.numpy(), reg_tgt=reg_tgt.numpy(), reg_loss=regl.numpy())
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
