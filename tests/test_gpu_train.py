@@ -1,0 +1,137 @@
+"""Config 3 (train step) parity: the HIP trainer's hand-written forward/backward against the torch-CPU
+float64 autograd graph of the reference modules (tests/ref_train_torch.py) on a reduced geometry, plus
+properties of the optimiser step. Tolerances: loss 1e-4 relative; each gradient tensor, relative to
+its own max magnitude, within max(2e-3, 3 x the error a torch-fp32 run of the same reference graph
+makes) of the float64 reference -- BatchNorm bias gradients are sums with heavy cancellation, where
+fp32 (torch's or ours) is ~1e-2 off float64; conv biases in front of a BatchNorm have an exactly zero
+gradient, checked absolutely."""
+import numpy as np
+import pytest
+import torch
+
+from cpd_amd.engine import CenterPointEngine, ModelConfig, init_state_dict
+from cpd_amd.synthetic import waymo_cloud
+
+import ref_train_torch
+
+pytestmark = pytest.mark.gpu
+
+
+def small_cfg():
+    return ModelConfig(point_cloud_range=[-20.0, -20.0, -2.0, 20.0, 20.0, 4.0], post_center_limit_range=[-20, -20, -2, 20, 20, 4],
+                       bev_num_filters=[64, 128], bev_num_upsample_filters=[128, 128], bev_layer_nums=[2, 2],
+                       max_obj_per_sample=100)
+
+
+def scene(batch=2, n_gt=8, seed=0):
+    pts = [waymo_cloud(b, n_points=30000 - 5000 * b) for b in range(batch)]
+    for p in pts:
+        p[:, :2] *= 0.3
+    rng = np.random.default_rng(seed)
+    gt = np.zeros((batch, n_gt + 2, 8), np.float32)                       # two zero rows = collate padding
+    for b in range(batch):
+        for i in range(n_gt):
+            gt[b, i] = [rng.uniform(-18, 18), rng.uniform(-18, 18), rng.uniform(0, 1), 4.5 * rng.uniform(0.9, 1.1),
+                        2.0 * rng.uniform(0.9, 1.1), 1.6, rng.uniform(-3, 3), rng.integers(1, 4)]
+    return pts, gt
+
+
+@pytest.fixture(scope="module")
+def trainer_and_ref(oracle, hip):
+    from cpd_amd.train_engine import CenterPointTrainer
+    cfg = small_cfg()
+    sd = init_state_dict(cfg, seed=3)
+    pts, gt = scene()
+    tr = CenterPointTrainer(cfg, sd, num_max_objs=50)
+    sd0 = tr.state_dict()
+    loss, parts = tr.forward_backward([torch.from_numpy(p).cuda() for p in pts], torch.from_numpy(gt).cuda())
+    grads = {k: v.cpu() for k, v in tr.grad_dict().items()}
+    P = ref_train_torch.make_leaves(sd)
+    ref_loss, ref_parts, _ = ref_train_torch.forward_loss(oracle, cfg, P, pts, gt, num_max_objs=50)
+    ref_loss.backward()
+    P32 = ref_train_torch.make_leaves(sd, torch.float32)
+    ref_train_torch.forward_loss(oracle, cfg, P32, pts, gt, num_max_objs=50)[0].backward()
+    return dict(P32=P32, cfg=cfg, sd=sd, sd0=sd0, tr=tr, loss=float(loss), parts=parts, grads=grads, P=P, ref_loss=float(ref_loss),
+                ref_parts=ref_parts, pts=pts, gt=gt)
+
+
+def test_state_dict_round_trip(trainer_and_ref):
+    """Flat-buffer layouts <-> reference names/layouts lose nothing."""
+    sd, sd0 = trainer_and_ref["sd"], trainer_and_ref["sd0"]
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        assert k in sd0, k
+        np.testing.assert_array_equal(sd0[k].cpu().numpy(), v.float().numpy(), err_msg=k)
+
+
+def test_loss_matches_reference(trainer_and_ref):
+    t = trainer_and_ref
+    assert abs(t["loss"] - t["ref_loss"]) <= 1e-4 * abs(t["ref_loss"])
+    for k in ("hm_loss", "loc_loss"):
+        assert abs(float(t["parts"][k]) - float(t["ref_parts"][k])) <= 1e-4 * abs(float(t["ref_parts"][k])) + 1e-6
+
+
+def test_gradients_match_reference(trainer_and_ref):
+    t = trainer_and_ref
+    worst = []
+    for k, leaf in t["P"].items():
+        ref = leaf.grad.numpy()
+        got = t["grads"][k].double().numpy()
+        assert got.shape == ref.shape, k
+        if np.abs(ref).max() < 1e-9:                       # bias in front of a batch-stat BatchNorm
+            assert np.abs(got).max() <= 1e-3, k
+            continue
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref).max() / scale
+        err32 = np.abs(t["P32"][k].grad.double().numpy() - ref).max() / scale
+        worst.append((err / max(2e-3, 3 * err32), err, err32, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 1.0, worst[:8]
+
+
+def test_running_stats_follow_batchnorm_semantics(trainer_and_ref, oracle):
+    """running = (1-m)*running + m*batch (unbiased var), m = 0.01, for the first sparse BatchNorm."""
+    t = trainer_and_ref
+    cfg, sd = t["cfg"], t["sd"]
+    feats, coords = ref_train_torch.voxelize_batch(oracle, cfg, t["pts"])
+    nbr = oracle.subm_rulebook(coords, len(t["pts"]), cfg.sparse_shape, [3, 3, 3])
+    z = ref_train_torch._gconv(torch.as_tensor(feats, dtype=torch.float64), sd["backbone_3d.conv_input.0.weight"].double(), nbr)
+    mean, var = z.mean(0), z.var(0, unbiased=True)
+    new = t["tr"].state_dict()
+    want_m = 0.99 * sd["backbone_3d.conv_input.1.running_mean"].double() + 0.01 * mean
+    want_v = 0.99 * sd["backbone_3d.conv_input.1.running_var"].double() + 0.01 * var
+    np.testing.assert_allclose(new["backbone_3d.conv_input.1.running_mean"].cpu().double().numpy(), want_m.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(new["backbone_3d.conv_input.1.running_var"].cpu().double().numpy(), want_v.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_optimizer_step_matches_torch_adam(trainer_and_ref):
+    """One cpd_adam_step on the flat buffer == decoupled-weight-decay Adam on the same gradient
+    (fastai_optim.py:132-150: p -= lr*wd*p, then Adam), with the grad-norm clip of train_utils.py:43."""
+    tr = trainer_and_ref["tr"]
+    st = tr.store
+    p0, g = st.flat.clone(), st.grad.clone()
+    tr.total_steps = None
+    tr.optimizer_step()
+    norm = float(g.norm())
+    gs = g * min(1.0, tr.grad_clip / (norm + 1e-6)) if norm > tr.grad_clip else g
+    b1, b2 = tr.betas
+    m = (1 - b1) * gs
+    v = (1 - b2) * gs * gs
+    want = p0 * (1 - tr.lr * tr.weight_decay) - tr.lr * (m / (1 - b1)) / ((v / (1 - b2)).sqrt() + 1e-8)
+    np.testing.assert_allclose(st.flat.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-7)
+
+
+def test_training_reduces_loss_and_exports_to_engine(hip):
+    from cpd_amd.train_engine import CenterPointTrainer
+    cfg = small_cfg()
+    pts, gt = scene(seed=1)
+    dev_pts = [torch.from_numpy(p).cuda() for p in pts]
+    dev_gt = torch.from_numpy(gt).cuda()
+    tr = CenterPointTrainer(cfg, init_state_dict(cfg, seed=5), lr=1e-3, num_max_objs=50)
+    losses = [float(tr.step(dev_pts, dev_gt)[0]) for _ in range(12)]
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.6 * losses[0], losses
+    eng = CenterPointEngine(cfg, {k: v.cpu() for k, v in tr.state_dict().items()})
+    res = eng.forward(dev_pts)
+    assert len(res) == 2 and all(torch.isfinite(r["pred_boxes"]).all() for r in res)
