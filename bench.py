@@ -41,14 +41,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: 8 infer, 1 train)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent frames in flight per GPU (worker threads, "
                     "one HIP stream + engine workspace each)")
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-launch table of the conv kernels (stderr)")
-    return ap.parse_args()
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = BASELINE config 2 (the headline metric); train = config 3: forward + backward + "
+                         "one RCCL gradient all-reduce + Adam, --frames (default 1) frames per GPU per step")
+    args = ap.parse_args()
+    if args.frames is None:
+        args.frames = 8 if args.mode == "infer" else 1
+    return args
 
 
 class ConvProfiler:
@@ -133,6 +139,58 @@ def cpu_baseline(cfg, sd, points_np):
                       "%.1f s" % (cores, dt)}
 
 
+def train_main(args, cfg, sd, dev, rank, world, distributed):
+    """Config 3: one train step = voxelize + forward (batch-stat BN) + CenterHead loss + backward +
+    ONE all-reduce of the flat gradient buffer over RCCL + fused Adam + weight repack."""
+    from cpd_amd.synthetic import gt_boxes
+    from cpd_amd.train_engine import CenterPointTrainer
+    B = args.frames
+    seeds = dist_utils.frame_seeds(rank, POOL)
+    clouds = [torch.from_numpy(waymo_cloud(s, n_points=args.points)).cuda() for s in seeds]
+    gts = [torch.from_numpy(gt_boxes(s)).cuda() for s in seeds]
+    total = args.steps + args.warmup
+    tr = CenterPointTrainer(cfg, sd, device=dev, total_steps=max(total, 2), world_size=world)
+    prof = ConvProfiler() if not args.no_roofline else None
+
+    def step(i):
+        idx = [(i * B + j) % POOL for j in range(B)]
+        return tr.step([clouds[k] for k in idx], torch.stack([gts[k] for k in idx]))
+
+    for i in range(args.warmup):
+        step(i)
+    dist_utils.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = step(args.warmup + i)
+    torch.cuda.synchronize()
+    dist_utils.barrier()
+    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device="cuda" if distributed else "cpu")
+    out = {
+        "metric": "train frames/sec (fwd+bwd+Adam), 160k-pt Waymo cloud", "value": world * B * args.steps / elapsed,
+        "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]: CPD VoxelResBackBone8x + BEV head train step on Waymo-shape %d-point clouds, "
+                               "%d frame(s)/GPU, 30 synthetic GT boxes/frame" % (args.points, B),
+                   "frames_per_step_per_gpu": B, "parallelism": "data-parallel x%d, one RCCL all-reduce of the flat "
+                   "gradient buffer (%.1f MB fp32) per step" % (world, tr.store.grad.numel() * 4 / 1e6),
+                   "optimizer": "Adam(betas=(0.9,0.99)) + decoupled wd 1e-5 + OneCycle lr 3e-3 + grad-norm clip 32",
+                   "final_loss": float(loss)},
+    }
+    if prof is not None:
+        with prof:
+            for i in range(2):
+                step(total + i)
+            agg, conv_ms = prof.summary()
+        flops = sum(v[0] for v in agg.values())
+        out["conv_fwd_dgrad"] = {"ms_per_step": conv_ms / 2, "tflops": flops / (conv_ms * 1e-3) / 1e12,
+                                 "note": "cpd_gather_conv launches only (forward + input gradients), HIP events"}
+    if rank == 0:
+        print(json.dumps(out))
+    dist_utils.shutdown()
+
+
 def main():
     args = parse()
     rank, world, local = dist_utils.env_rank()
@@ -143,6 +201,8 @@ def main():
     cfg = ModelConfig()
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local
+    if args.mode == "train":
+        return train_main(args, cfg, sd, dev, rank, world, distributed)
     S = max(1, args.streams)
     engines = [CenterPointEngine(cfg, sd, device=dev) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]

@@ -25,56 +25,98 @@ struct ColParams {
     const float *x;      // COL_BNBWD: BN input
     const float *mean, *invstd;
     int lda, ldy, ldx;
-    int n, c, rows_per_block;
+    int n, c, rows_per_chunk;
+    int cq;              // column groups (of VEC columns) per block; 256 / cq row lanes
 };
 
-// One block reduces rows [b*rpb, (b+1)*rpb) of all columns: thread = (column % cw, row lane).
-template <int MODE>
+// Block (col tile, row chunk): thread = (column group q, row lane rl); a thread streams VEC
+// consecutive columns (one 16-byte load for VEC = 4) of every (256/cq)-th row of the chunk, four
+// rows in flight. Partials land in part[chunk][2][c]; col_final_kernel sums the chunks.
+template <int MODE, int VEC>
 __global__ void __launch_bounds__(256) col_partial_kernel(ColParams p, float *__restrict__ part) {
-    __shared__ float sm1[256], sm2[256];
-    const int cw = p.c < 256 ? p.c : 256;          // columns handled side by side
-    const int lanes = 256 / cw;                     // row lanes per column
-    const int col_l = threadIdx.x % cw, rl = threadIdx.x / cw;
-    const int r0 = blockIdx.x * p.rows_per_block;
-    const int r1 = min(p.n, r0 + p.rows_per_block);
-    for (int cb = 0; cb < p.c; cb += cw) {
-        const int col = cb + col_l;
-        float s1 = 0.f, s2 = 0.f;
-        if (col < p.c && rl < lanes) {
-            float mu = 0.f, is = 1.f;
-            if (MODE == COL_BNBWD) { mu = p.mean[col]; is = p.invstd[col]; }
-            for (int r = r0 + rl; r < r1; r += lanes) {
-                float v = p.a[(size_t)r * p.lda + col];
+    __shared__ float sm[2 * VEC * 256];
+    const int CQ = p.cq, RL = 256 / CQ;
+    const int q = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+    const int col = (blockIdx.x * CQ + q) * VEC;
+    const int r0 = blockIdx.y * p.rows_per_chunk;
+    const int r1 = min(p.n, r0 + p.rows_per_chunk);
+    float s1[VEC], s2[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s1[v] = 0.f; s2[v] = 0.f; mu[v] = 0.f; is[v] = 1.f; }
+    const bool live = col < p.c && rl < RL;
+    if (live) {
+        if (MODE == COL_BNBWD) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (col + v < p.c) { mu[v] = p.mean[col + v]; is[v] = p.invstd[col + v]; }
+        }
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += RL) {
+            float av[VEC], yv[VEC], xv[VEC];
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(p.a + (size_t)r * p.lda + col);
+                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[VEC - 1] = t.w;
+                if (MODE == COL_BNBWD) {
+                    const float4 u = *reinterpret_cast<const float4 *>(p.x + (size_t)r * p.ldx + col);
+                    xv[0] = u.x; xv[1] = u.y; xv[2] = u.z; xv[VEC - 1] = u.w;
+                    if (p.y) {
+                        const float4 w = *reinterpret_cast<const float4 *>(p.y + (size_t)r * p.ldy + col);
+                        yv[0] = w.x; yv[1] = w.y; yv[2] = w.z; yv[VEC - 1] = w.w;
+                    }
+                }
+            } else {
+                av[0] = p.a[(size_t)r * p.lda + col];
+                if (MODE == COL_BNBWD) {
+                    xv[0] = p.x[(size_t)r * p.ldx + col];
+                    if (p.y) yv[0] = p.y[(size_t)r * p.ldy + col];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float g = av[v];
                 if (MODE == COL_SUM) {
-                    s1 += v;
+                    s1[v] += g;
                 } else if (MODE == COL_STATS) {
-                    s1 += v; s2 += v * v;
+                    s1[v] += g; s2[v] += g * g;
                 } else {
-                    if (p.y && !(p.y[(size_t)r * p.ldy + col] > 0.f)) v = 0.f;
-                    const float xh = (p.x[(size_t)r * p.ldx + col] - mu) * is;
-                    s1 += v; s2 += v * xh;
+                    if (p.y && !(yv[v] > 0.f)) g = 0.f;
+                    s1[v] += g; s2[v] += g * ((xv[v] - mu[v]) * is[v]);
                 }
             }
         }
-        sm1[threadIdx.x] = s1; sm2[threadIdx.x] = s2;
-        __syncthreads();
-        if (rl == 0 && col < p.c) {
-            for (int k = 1; k < lanes; ++k) { s1 += sm1[k * cw + col_l]; s2 += sm2[k * cw + col_l]; }
-            part[((size_t)blockIdx.x * 2 + 0) * p.c + col] = s1;
-            part[((size_t)blockIdx.x * 2 + 1) * p.c + col] = s2;
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { sm[(2 * v) * 256 + threadIdx.x] = s1[v]; sm[(2 * v + 1) * 256 + threadIdx.x] = s2[v]; }
+    __syncthreads();
+    if (live && rl == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float a = s1[v], b = s2[v];
+            for (int k = 1; k < RL; ++k) { a += sm[(2 * v) * 256 + k * CQ + q]; b += sm[(2 * v + 1) * 256 + k * CQ + q]; }
+            if (col + v < p.c) {
+                part[((size_t)blockIdx.y * 2 + 0) * p.c + col + v] = a;
+                part[((size_t)blockIdx.y * 2 + 1) * p.c + col + v] = b;
+            }
         }
-        __syncthreads();
     }
 }
 
+// 16 columns x 16 lanes per block; lanes stride over the chunk partials, accumulate in double.
 __global__ void __launch_bounds__(256) col_final_kernel(const float *__restrict__ part, int nb, int c, float *__restrict__ s1,
                                                         float *__restrict__ s2) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c) return;
+    __shared__ double sa[256], sb[256];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nb; ++k) { a += part[((size_t)k * 2 + 0) * c + col]; b += part[((size_t)k * 2 + 1) * c + col]; }
-    s1[col] = (float)a;
-    if (s2) s2[col] = (float)b;
+    if (col < c)
+        for (int k = lane; k < nb; k += 16) { a += part[((size_t)k * 2 + 0) * c + col]; b += part[((size_t)k * 2 + 1) * c + col]; }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    if (lane == 0 && col < c) {
+        for (int k = 1; k < 16; ++k) { a += sa[k * 16 + cl]; b += sb[k * 16 + cl]; }
+        s1[col] = (float)a;
+        if (s2) s2[col] = (float)b;
+    }
 }
 
 __global__ void __launch_bounds__(256) affine_rows_kernel(const float *__restrict__ x, int ldx, int n, int c,
@@ -314,24 +356,46 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
 
 }  // namespace
 
+enum { COL_MAX_CHUNKS = 1024 };
+
 static int col_reduce(int mode, const float *a, int lda, const float *y, int ldy, const float *x, int ldx, const float *mean,
                       const float *invstd, int n, int c, float *s1, float *s2, void *ws, size_t ws_bytes, hipStream_t s) {
     if (!a || !s1 || n <= 0 || c <= 0 || !ws) return CPD_ERR_ARG;
-    const int rpb = 1024;
-    const int nb = (n + rpb - 1) / rpb;
-    if (ws_bytes < (size_t)nb * 2 * c * sizeof(float)) return CPD_ERR_WORKSPACE;
-    ColParams p{a, y, x, mean, invstd, lda, ldy, ldx, n, c, rpb};
+    auto al16 = [](const void *q, int ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (ld & 3) == 0); };
+    const bool vec = (c % 4 == 0) && al16(a, lda) && al16(y, ldy) && al16(x, ldx);
+    const int V = vec ? 4 : 1;
+    const int cq_total = (c + V - 1) / V;
+    const int cq = cq_total < 16 ? cq_total : 16;
+    const int rl = 256 / cq;
+    const int col_tiles = (cq_total + cq - 1) / cq;
+    int chunks = 4096 / col_tiles;
+    const int max_chunks = (n + 4 * rl - 1) / (4 * rl);           // at least four rows per thread
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks > COL_MAX_CHUNKS) chunks = COL_MAX_CHUNKS;
+    if (chunks < 1) chunks = 1;
+    int rpc = (n + chunks - 1) / chunks;
+    rpc = (rpc + rl - 1) / rl * rl;
+    chunks = (n + rpc - 1) / rpc;
+    if (ws_bytes < (size_t)chunks * 2 * c * sizeof(float)) return CPD_ERR_WORKSPACE;
+    ColParams p{a, y, x, mean, invstd, lda, ldy, ldx, n, c, rpc, cq};
     float *part = (float *)ws;
-    if (mode == COL_SUM) col_partial_kernel<COL_SUM><<<nb, 256, 0, s>>>(p, part);
-    else if (mode == COL_STATS) col_partial_kernel<COL_STATS><<<nb, 256, 0, s>>>(p, part);
-    else col_partial_kernel<COL_BNBWD><<<nb, 256, 0, s>>>(p, part);
-    col_final_kernel<<<cpd_div_up(c, 256), 256, 0, s>>>(part, nb, c, s1, s2);
+    const dim3 grid(col_tiles, chunks);
+    if (vec) {
+        if (mode == COL_SUM) col_partial_kernel<COL_SUM, 4><<<grid, 256, 0, s>>>(p, part);
+        else if (mode == COL_STATS) col_partial_kernel<COL_STATS, 4><<<grid, 256, 0, s>>>(p, part);
+        else col_partial_kernel<COL_BNBWD, 4><<<grid, 256, 0, s>>>(p, part);
+    } else {
+        if (mode == COL_SUM) col_partial_kernel<COL_SUM, 1><<<grid, 256, 0, s>>>(p, part);
+        else if (mode == COL_STATS) col_partial_kernel<COL_STATS, 1><<<grid, 256, 0, s>>>(p, part);
+        else col_partial_kernel<COL_BNBWD, 1><<<grid, 256, 0, s>>>(p, part);
+    }
+    col_final_kernel<<<cpd_div_up(c, 16), 256, 0, s>>>(part, chunks, c, s1, s2);
     return cpd_check_launch();
 }
 
 extern "C" size_t cpd_col_reduce_workspace_bytes(int n, int c) {
     if (n <= 0 || c <= 0) return 0;
-    return cpd_align((size_t)((n + 1023) / 1024) * 2 * c * sizeof(float));
+    return cpd_align((size_t)COL_MAX_CHUNKS * 2 * c * sizeof(float));
 }
 extern "C" int cpd_col_sum(const float *x, int ldx, int n, int c, float *sum, void *ws, size_t ws_bytes, cpd_stream_t st) {
     return col_reduce(COL_SUM, x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, n, c, sum, nullptr, ws, ws_bytes, cpd_s(st));

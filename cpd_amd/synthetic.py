@@ -111,3 +111,23 @@ def random_boxes(seed, n, span=75.0, dup_frac=0.1):
         b[n - k:, 6] += rng.normal(0, 0.05, k).astype(np.float32)
     scores = (rng.permutation(n).astype(np.float32) + 1) / (n + 1)
     return b.astype(np.float32), scores
+
+
+# PredifinedSize of waymo_unsupervised_cproto.yaml:85 (Vehicle, Pedestrian, Cyclist)
+PREDEFINED_SIZE = np.array([[5.065, 1.86, 1.49], [1.0, 1.0, 2.0], [1.9, 0.85, 1.8]], np.float32)
+
+
+def gt_boxes(seed, n=30, span=70.0):
+    """Synthetic ground truth of the config-3 train step: [n, 8] =
+    (x, y, z, dx, dy, dz, heading, class 1..3), centres uniform within +-span on the ground,
+    sizes PredifinedSize x U(0.9, 1.1), heading U(-pi, pi)."""
+    rng = np.random.default_rng(1000 + seed)
+    cls = rng.integers(1, 4, n)
+    dims = PREDEFINED_SIZE[cls - 1] * rng.uniform(0.9, 1.1, (n, 3)).astype(np.float32)
+    b = np.zeros((n, 8), np.float32)
+    b[:, 0:2] = rng.uniform(-span, span, (n, 2))
+    b[:, 2] = dims[:, 2] / 2.0                         # resting on the ground plane z = 0
+    b[:, 3:6] = dims
+    b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+    b[:, 7] = cls
+    return b
