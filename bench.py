@@ -183,6 +183,13 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
             for i in range(2):
                 step(total + i)
             agg, conv_ms = prof.summary()
+            if args.layers and rank == 0:
+                per = len(prof.records) // 2
+                for kname, fl, e0, e1, shp in prof.records[-per:]:
+                    ms = e0.elapsed_time(e1)
+                    print("%-34s n_out %7d  %3d->%4d kv %2d  %8.1f us  useful %6.1f TF  density %.2f" %
+                          (kname, shp[0], shp[1], shp[2], shp[3], ms * 1e3, fl / ms / 1e9,
+                           fl / (2.0 * shp[0] * shp[3] * shp[1] * shp[2])), file=sys.stderr)
         flops = sum(v[0] for v in agg.values())
         out["conv_fwd_dgrad"] = {"ms_per_step": conv_ms / 2, "tflops": flops / (conv_ms * 1e-3) / 1e12,
                                  "note": "cpd_gather_conv launches only (forward + input gradients), HIP events"}

@@ -61,6 +61,7 @@ SIGNATURES = {
     "cpd_col_reduce_workspace_bytes": (_SZ, [_I, _I]),
     "cpd_col_sum": (_I, [_VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "cpd_bn_stats": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_bn_stats_finalize": (_I, [_VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_bn_finalize": (_I, [_VP, _VP, _I, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_pack_weight_adjoint": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "cpd_affine_rows": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),

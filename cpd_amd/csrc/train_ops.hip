@@ -101,9 +101,32 @@ __global__ void __launch_bounds__(256) col_partial_kernel(ColParams p, float *__
     }
 }
 
+struct BnFin {
+    int n; float eps, momentum;
+    const float *gamma, *beta;
+    float *mean, *invstd, *scale, *shift, *running_mean, *running_var;
+};
+__device__ __forceinline__ void bn_finalize_col(const BnFin &f, int col, double sum, double sumsq) {
+    const double mu = sum / f.n;
+    double var = sumsq / f.n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)f.eps));
+    f.mean[col] = (float)mu;
+    f.invstd[col] = is;
+    const float sc = f.gamma[col] * is;
+    f.scale[col] = sc;
+    f.shift[col] = f.beta[col] - (float)mu * sc;
+    if (f.running_mean) {
+        const double unbiased = f.n > 1 ? var * f.n / (f.n - 1.0) : var;
+        f.running_mean[col] = (1.f - f.momentum) * f.running_mean[col] + f.momentum * (float)mu;
+        f.running_var[col] = (1.f - f.momentum) * f.running_var[col] + f.momentum * (float)unbiased;
+    }
+}
+
 // 16 columns x 16 lanes per block; lanes stride over the chunk partials, accumulate in double.
+template <bool FIN>
 __global__ void __launch_bounds__(256) col_final_kernel(const float *__restrict__ part, int nb, int c, float *__restrict__ s1,
-                                                        float *__restrict__ s2) {
+                                                        float *__restrict__ s2, BnFin fin) {
     __shared__ double sa[256], sb[256];
     const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + cl;
@@ -114,8 +137,12 @@ __global__ void __launch_bounds__(256) col_final_kernel(const float *__restrict_
     __syncthreads();
     if (lane == 0 && col < c) {
         for (int k = 1; k < 16; ++k) { a += sa[k * 16 + cl]; b += sb[k * 16 + cl]; }
-        s1[col] = (float)a;
-        if (s2) s2[col] = (float)b;
+        if (FIN) {
+            bn_finalize_col(fin, col, a, b);
+        } else {
+            s1[col] = (float)a;
+            if (s2) s2[col] = (float)b;
+        }
     }
 }
 
@@ -232,6 +259,116 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgParams p) {
             for (int e = 0; e < 4; ++e) {
                 const int ci = ci0 + VA * (4 * g + e) + a, co = co0 + VB * r + b;
                 if (ci < p.c_in && co < p.c_out) out[(size_t)ci * p.c_out + co] = acc[a][b][e];
+            }
+}
+
+// Workgroup variant for channel counts that are multiples of 64: 4 waves (2 x 2) share a TM x TN
+// (ci x co) tile of one tap over one row chunk. Per stage of 16 rows the gathered input rows and the
+// dy rows go global -> registers -> LDS (double buffered, one barrier per stage, the next stage's
+// loads in flight under the MFMAs); a wave feeds its (TM/2) x (TN/2) sub-tile with one 16-byte LDS
+// read per operand side and 4-row step. Cuts the L2 traffic of the wave kernel by the tile's reuse
+// (every row is fetched once per 128 instead of once per 64 channels of the other operand).
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) wgrad_tile_kernel(WgParams p) {
+    constexpr int KB = 16;                       // rows per stage
+    constexpr int LDA = TM + 4, LDB = TN + 4;    // +16 B: the four k-groups of a read hit different banks
+    constexpr int VA = TM / 32, VB = TN / 32;    // 16-wide MFMA tiles per wave and side
+    constexpr int PA = KB * TM / 4 / 256, PB = KB * TN / 4 / 256;   // 16-byte pieces per thread and stage
+    static_assert(PA >= 1 && PB >= 1, "tile too small for 256 threads");
+    __shared__ float sA[2][KB * LDA];
+    __shared__ float sB[2][KB * LDB];
+    __shared__ __attribute__((aligned(16))) int sValid[2][KB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = p.co_tiles;
+    const int ci0 = (blockIdx.x / tiles_n) * TM, co0 = (blockIdx.x % tiles_n) * TN;
+    const int t = blockIdx.y;
+    const int r0 = blockIdx.z * p.rows_per_chunk, r1 = min(p.n_out, r0 + p.rows_per_chunk);
+    const int n_stages = (r1 - r0 + KB - 1) / KB;
+
+    f32x4 acc[VA][VB];
+#pragma unroll
+    for (int a = 0; a < VA; ++a)
+#pragma unroll
+        for (int b = 0; b < VB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[PA], rb[PB];
+    int rv[PA];
+    auto load_stage = [&](int st) {
+        const int j0 = r0 + st * KB;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int piece = tid + 256 * i, row = piece / (TM / 4), c4 = piece % (TM / 4);
+            const int j = j0 + row;
+            int idx = -1;
+            if (j < r1) idx = p.nbr ? p.nbr[(size_t)t * p.n_out + j] : j;
+            ra[i] = idx >= 0 ? *reinterpret_cast<const float4 *>(p.in + (size_t)idx * p.in_ld + ci0 + 4 * c4)
+                             : float4{0.f, 0.f, 0.f, 0.f};
+            rv[i] = idx >= 0;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int piece = tid + 256 * i, row = piece / (TN / 4), c4 = piece % (TN / 4);
+            const int j = j0 + row;
+            rb[i] = j < r1 ? *reinterpret_cast<const float4 *>(p.dy + (size_t)j * p.dy_ld + co0 + 4 * c4)
+                           : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int piece = tid + 256 * i, row = piece / (TM / 4), c4 = piece % (TM / 4);
+            *reinterpret_cast<float4 *>(&sA[buf][row * LDA + 4 * c4]) = ra[i];
+            if (c4 == 0) sValid[buf][row] = rv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int piece = tid + 256 * i, row = piece / (TN / 4), c4 = piece % (TN / 4);
+            *reinterpret_cast<float4 *>(&sB[buf][row * LDB + 4 * c4]) = rb[i];
+        }
+    };
+
+    if (n_stages > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < n_stages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < n_stages) load_stage(st + 1);
+#pragma unroll
+        for (int ks = 0; ks < KB / 4; ++ks) {
+            const int4 ok = reinterpret_cast<const int4 *>(sValid[buf])[ks];
+            if (!(ok.x | ok.y | ok.z | ok.w)) continue;          // no row of this 4-row step has the tap
+            const int row = 4 * ks + g;
+            // VA consecutive channels per lane: channel = ci0 + wm*TM/2 + VA*r + a
+            float a_[VA], b_[VB];
+            const float *ap = &sA[buf][row * LDA + wm * (TM / 2) + VA * r];
+            const float *bp = &sB[buf][row * LDB + wn * (TN / 2) + VB * r];
+            if (VA == 4) { const f32x4 v = *reinterpret_cast<const f32x4 *>(ap); a_[0] = v[0]; a_[1] = v[1]; a_[VA - 2] = v[2]; a_[VA - 1] = v[3]; }
+            else { const float2 v = *reinterpret_cast<const float2 *>(ap); a_[0] = v.x; a_[VA - 1] = v.y; }
+            if (VB == 4) { const f32x4 v = *reinterpret_cast<const f32x4 *>(bp); b_[0] = v[0]; b_[1] = v[1]; b_[VB - 2] = v[2]; b_[VB - 1] = v[3]; }
+            else { const float2 v = *reinterpret_cast<const float2 *>(bp); b_[0] = v.x; b_[VB - 1] = v.y; }
+#pragma unroll
+            for (int a = 0; a < VA; ++a)
+#pragma unroll
+                for (int b = 0; b < VB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[a], b_[b], acc[a][b], 0, 0, 0);
+        }
+        if (st + 1 < n_stages) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i][j]: i = 4g+e <-> channel ci0 + wm*TM/2 + VA*i + a ; j = r <-> column co0 + wn*TN/2 + VB*r + b
+    float *out = p.part + ((size_t)blockIdx.z * p.kv + t) * p.c_in * p.c_out;
+#pragma unroll
+    for (int a = 0; a < VA; ++a)
+#pragma unroll
+        for (int b = 0; b < VB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = ci0 + wm * (TM / 2) + VA * (4 * g + e) + a, co = co0 + wn * (TN / 2) + VB * r + b;
+                out[(size_t)ci * p.c_out + co] = acc[a][b][e];
             }
 }
 
@@ -356,11 +493,12 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
 
 }  // namespace
 
-enum { COL_MAX_CHUNKS = 1024 };
+enum { COL_MAX_CHUNKS = 512 };
 
 static int col_reduce(int mode, const float *a, int lda, const float *y, int ldy, const float *x, int ldx, const float *mean,
-                      const float *invstd, int n, int c, float *s1, float *s2, void *ws, size_t ws_bytes, hipStream_t s) {
-    if (!a || !s1 || n <= 0 || c <= 0 || !ws) return CPD_ERR_ARG;
+                      const float *invstd, int n, int c, float *s1, float *s2, void *ws, size_t ws_bytes, hipStream_t s,
+                      const BnFin *fin = nullptr) {
+    if (!a || (!s1 && !fin) || n <= 0 || c <= 0 || !ws) return CPD_ERR_ARG;
     auto al16 = [](const void *q, int ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (ld & 3) == 0); };
     const bool vec = (c % 4 == 0) && al16(a, lda) && al16(y, ldy) && al16(x, ldx);
     const int V = vec ? 4 : 1;
@@ -368,7 +506,7 @@ static int col_reduce(int mode, const float *a, int lda, const float *y, int ldy
     const int cq = cq_total < 16 ? cq_total : 16;
     const int rl = 256 / cq;
     const int col_tiles = (cq_total + cq - 1) / cq;
-    int chunks = 4096 / col_tiles;
+    int chunks = 2048 / col_tiles;
     const int max_chunks = (n + 4 * rl - 1) / (4 * rl);           // at least four rows per thread
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks > COL_MAX_CHUNKS) chunks = COL_MAX_CHUNKS;
@@ -389,7 +527,8 @@ static int col_reduce(int mode, const float *a, int lda, const float *y, int ldy
         else if (mode == COL_STATS) col_partial_kernel<COL_STATS, 1><<<grid, 256, 0, s>>>(p, part);
         else col_partial_kernel<COL_BNBWD, 1><<<grid, 256, 0, s>>>(p, part);
     }
-    col_final_kernel<<<cpd_div_up(c, 16), 256, 0, s>>>(part, chunks, c, s1, s2);
+    if (fin) col_final_kernel<true><<<cpd_div_up(c, 16), 256, 0, s>>>(part, chunks, c, nullptr, nullptr, *fin);
+    else col_final_kernel<false><<<cpd_div_up(c, 16), 256, 0, s>>>(part, chunks, c, s1, s2, BnFin{});
     return cpd_check_launch();
 }
 
@@ -410,6 +549,14 @@ extern "C" int cpd_bn_bwd_reduce(const float *dy, int lddy, const float *y, int 
                                  cpd_stream_t st) {
     if (!x || !mean || !invstd || !dgamma) return CPD_ERR_ARG;
     return col_reduce(COL_BNBWD, dy, lddy, y, ldy, x, ldx, mean, invstd, n, c, dbeta, dgamma, ws, ws_bytes, cpd_s(st));
+}
+extern "C" int cpd_bn_stats_finalize(const float *x, int ldx, int n, int c, float eps, float momentum, const float *gamma,
+                                     const float *beta, float *mean, float *invstd, float *scale, float *shift,
+                                     float *running_mean, float *running_var, void *ws, size_t ws_bytes, cpd_stream_t st) {
+    if (!gamma || !beta || !mean || !invstd || !scale || !shift || (running_mean && !running_var)) return CPD_ERR_ARG;
+    BnFin f{n, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var};
+    return col_reduce(COL_STATS, x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, n, c, nullptr, nullptr, ws, ws_bytes, cpd_s(st),
+                      &f);
 }
 extern "C" int cpd_bn_finalize(const float *sum, const float *sumsq, int n, int c, float eps, float momentum, const float *gamma,
                                const float *beta, float *mean, float *invstd, float *scale, float *shift,
@@ -445,7 +592,27 @@ extern "C" int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, 
     return cpd_check_launch();
 }
 
+// Tile kernel plan: (TM, TN) in {64,128}^2 when both channel counts are multiples of 64.
+static bool wgrad_tile_plan(int n_out, int c_in, int c_out, int kv, WgParams *p, int *tm, int *tn) {
+    if (c_in % 64 || c_out % 64) return false;
+    *tm = c_in % 128 ? 64 : 128;
+    *tn = c_out % 128 ? 64 : 128;
+    p->ci_tiles = c_in / *tm;
+    p->co_tiles = c_out / *tn;
+    const long long per_chunk = (long long)kv * p->ci_tiles * p->co_tiles;
+    int chunks = (int)((512 + per_chunk - 1) / per_chunk);      // ~2 workgroups per CU
+    const int max_chunks = (n_out + 127) / 128;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    p->rows_per_chunk = ((n_out + chunks - 1) / chunks + 15) / 16 * 16;
+    p->n_chunks = (n_out + p->rows_per_chunk - 1) / p->rows_per_chunk;
+    return true;
+}
+
 static void wgrad_plan(int n_out, int c_in, int c_out, int kv, WgParams *p, int *va, int *vb) {
+    int tm, tn;
+    *va = *vb = 0;
+    if (wgrad_tile_plan(n_out, c_in, c_out, kv, p, &tm, &tn)) return;
     *va = lanes_per_16(c_in); *vb = lanes_per_16(c_out);
     p->ci_tiles = (c_in + 16 * *va - 1) / (16 * *va);
     p->co_tiles = (c_out + 16 * *vb - 1) / (16 * *vb);
@@ -474,11 +641,28 @@ extern "C" int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float 
     if (ws_bytes < (size_t)p.n_chunks * kv * c_in * c_out * sizeof(float)) return CPD_ERR_WORKSPACE;
     p.in = in; p.dy = dy; p.nbr = nbr; p.part = (float *)ws;
     p.in_ld = in_ld; p.dy_ld = dy_ld; p.c_in = c_in; p.c_out = c_out; p.kv = kv; p.n_out = n_out;
-    wg_kernel_t k = pick_wg(va, vb);
-    if (!k) return CPD_ERR_UNSUPPORTED;
-    const long long blocks = (long long)p.n_chunks * kv * p.ci_tiles * p.co_tiles;
-    if (blocks >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), 0, cpd_s(st), p);
+    int tm, tn;
+    const bool aligned = ((((uintptr_t)in) | ((uintptr_t)dy)) & 15) == 0 && in_ld % 4 == 0 && dy_ld % 4 == 0;
+    if (va == 0 && !aligned) {                        // tile kernel needs 16-byte rows: fall back to the wave kernel
+        va = lanes_per_16(c_in); vb = lanes_per_16(c_out);
+        p.ci_tiles = (c_in + 16 * va - 1) / (16 * va);
+        p.co_tiles = (c_out + 16 * vb - 1) / (16 * vb);
+    }
+    if (va == 0) {
+        wgrad_tile_plan(n_out, c_in, c_out, kv, &p, &tm, &tn);
+        if (p.n_chunks >= 65536 || kv >= 65536) return CPD_ERR_UNSUPPORTED;
+        const dim3 grid(p.ci_tiles * p.co_tiles, kv, p.n_chunks);
+        if (tm == 128 && tn == 128) wgrad_tile_kernel<128, 128><<<grid, 256, 0, cpd_s(st)>>>(p);
+        else if (tm == 128) wgrad_tile_kernel<128, 64><<<grid, 256, 0, cpd_s(st)>>>(p);
+        else if (tn == 128) wgrad_tile_kernel<64, 128><<<grid, 256, 0, cpd_s(st)>>>(p);
+        else wgrad_tile_kernel<64, 64><<<grid, 256, 0, cpd_s(st)>>>(p);
+    } else {
+        wg_kernel_t k = pick_wg(va, vb);
+        if (!k) return CPD_ERR_UNSUPPORTED;
+        const long long blocks = (long long)p.n_chunks * kv * p.ci_tiles * p.co_tiles;
+        if (blocks >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), 0, cpd_s(st), p);
+    }
     const size_t elems = (size_t)kv * c_in * c_out;
     wgrad_reduce_kernel<<<cpd_div_up((long long)elems, 256), 256, 0, cpd_s(st)>>>(p.part, p.n_chunks, elems, dw_kio, accumulate);
     return cpd_check_launch();

@@ -51,3 +51,16 @@ def aggregate_throughput(units_per_rank, elapsed_local, device="cpu"):
 def shutdown():
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def reduce_gradients(flat_grad, world=None, group=None):
+    """The train step's one collective: sum the flat gradient buffer over the data-parallel ranks in
+    place (RCCL ring/direct all-reduce on the GPUs, gloo in the CPU tests) and return the factor that
+    turns the sum into the mean (DistributedDataParallel's averaging, tools/train.py:143)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = world or dist.get_world_size(group)
+    if world <= 1:
+        return 1.0
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world

@@ -338,6 +338,49 @@ class CenterHead(nn.Module):
             ret[b]["pred_labels"] = torch.cat(ret[b]["pred_labels"], dim=0) + 1
         return ret
 
+    def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
+        """center_head.py:159-219 for every head, vectorised on the device (cpd_amd.center_loss;
+        pinned on goldens of the reference's assign_target_of_single_head). gt_boxes (B, M, 8)."""
+        from . import center_loss
+        tc = self.model_cfg.TARGET_ASSIGNER_CONFIG
+        ret = {"heatmaps": [], "target_boxes": [], "inds": [], "masks": []}
+        names = ["bg"] + list(self.class_names)
+        for cur in self.class_names_each_head:
+            # keep this head's boxes, relabelled 1..len(cur) (center_head.py:180-196)
+            cls = gt_boxes[..., -1].long()
+            new = torch.zeros_like(cls)
+            for j, cn in enumerate(cur):
+                new = torch.where(cls == names.index(cn), torch.full_like(cls, j + 1), new)
+            g = torch.cat([gt_boxes[..., :-1], new.unsqueeze(-1).to(gt_boxes.dtype)], dim=-1)
+            g = g * (new > 0).unsqueeze(-1).to(g.dtype)
+            heat, tgt, inds, masks = center_loss.assign_targets(
+                g, tuple(feature_map_size), self.point_cloud_range, self.voxel_size, len(cur), tc.FEATURE_MAP_STRIDE,
+                num_max_objs=tc.NUM_MAX_OBJS, gaussian_overlap=tc.GAUSSIAN_OVERLAP, min_radius=tc.MIN_RADIUS)
+            ret["heatmaps"].append(heat); ret["target_boxes"].append(tgt); ret["inds"].append(inds); ret["masks"].append(masks)
+        return ret
+
+    def get_loss(self):
+        """center_head.py:225-250. The value is exact; gradients of the module API are not tracked through
+        the C-ABI convs -- the train step with hand-written backward is cpd_amd.train_engine
+        (CenterPoint.to_trainer())."""
+        from . import center_loss
+        pds, td = self.forward_ret_dict["pred_dicts"], self.forward_ret_dict["target_dicts"]
+        lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        order = list(self.model_cfg.SEPARATE_HEAD_CFG.HEAD_ORDER)
+        tb_dict, loss = {}, 0
+        for idx, pd in enumerate(pds):
+            b, nc, h, w = pd["hm"].shape
+            rows = torch.cat([pd[k] for k in order] + [pd["hm"]], dim=1).permute(0, 2, 3, 1).reshape(b * h * w, -1)
+            hm_col = rows.shape[1] - nc
+            l, parts = center_loss.center_head_loss(rows, b, h, w, td["heatmaps"][idx], td["target_boxes"][idx], td["inds"][idx],
+                                                    td["masks"][idx], nc, hm_col=hm_col, code_weights=lw["code_weights"],
+                                                    loc_weight=lw["loc_weight"], cls_weight=lw["cls_weight"])
+            loss = loss + l
+            tb_dict["hm_loss_head_%d" % idx] = parts["hm_loss"].item()
+            tb_dict["loc_loss_head_%d" % idx] = parts["loc_loss"].item()
+        tb_dict["rpn_loss"] = float(loss)
+        return loss, tb_dict
+
     @staticmethod
     def reorder_rois_for_refining(batch_size, pred_dicts):
         n_max = max(1, max(len(d["pred_boxes"]) for d in pred_dicts))
@@ -354,10 +397,12 @@ class CenterHead(nn.Module):
     def forward(self, data_dict):
         x = self.shared_conv(data_dict["st_features_2d"])
         pred_dicts = [head(x) for head in self.heads_list]
-        if self.training:
-            raise NotImplementedError("CenterHead target assignment / loss (center_head.py:103-250) is the next "
-                                      "row of the scope table (SURVEY 8f-2); this round ships the forward path")
         self.forward_ret_dict["pred_dicts"] = pred_dicts
+        if self.training:
+            h, w = x.shape[2], x.shape[3]
+            self.forward_ret_dict["target_dicts"] = self.assign_targets(data_dict["gt_boxes"], feature_map_size=(h, w))
+            if not self.predict_boxes_when_training:
+                return data_dict
         boxes = self.generate_predicted_boxes(data_dict["batch_size"], pred_dicts)
         if self.predict_boxes_when_training:
             rois, roi_scores, roi_labels = self.reorder_rois_for_refining(data_dict["batch_size"], boxes)
@@ -398,6 +443,7 @@ def waymo_centerpoint_cfg():
                                                HEAD_DICT={"center": dict(out_channels=2, num_conv=2), "center_z": dict(out_channels=1, num_conv=2),
                                                           "dim": dict(out_channels=3, num_conv=2), "rot": dict(out_channels=2, num_conv=2)}),
                         TARGET_ASSIGNER_CONFIG=dict(FEATURE_MAP_STRIDE=8, NUM_MAX_OBJS=500, GAUSSIAN_OVERLAP=0.1, MIN_RADIUS=2),
+                        LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=2.0, code_weights=[1.0] * 8)),
                         POST_PROCESSING=dict(SCORE_THRESH=0.1, POST_CENTER_LIMIT_RANGE=[-75.2, -75.2, -2, 75.2, 75.2, 4],
                                              MAX_OBJ_PER_SAMPLE=500,
                                              NMS_CONFIG=dict(NMS_TYPE="nms_gpu", NMS_THRESH=0.8, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=500))))
@@ -448,6 +494,12 @@ class CenterPoint(nn.Module):
                            score_thresh=pp.SCORE_THRESH, post_center_limit_range=list(pp.POST_CENTER_LIMIT_RANGE),
                            max_obj_per_sample=pp.MAX_OBJ_PER_SAMPLE, nms_thresh=pp.NMS_CONFIG.NMS_THRESH,
                            nms_pre_maxsize=pp.NMS_CONFIG.NMS_PRE_MAXSIZE, nms_post_maxsize=pp.NMS_CONFIG.NMS_POST_MAXSIZE)
+
+    def to_trainer(self, device="cuda", **kw):
+        """The train step (hand-written backward + flat-buffer Adam) on this model's weights."""
+        from .train_engine import CenterPointTrainer
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+        return CenterPointTrainer(self.to_engine_config(), sd, device=device, **kw)
 
     def to_engine(self, device="cuda"):
         """The fused inference engine on this model's weights (eval-mode BatchNorm folded)."""

@@ -21,7 +21,7 @@ from typing import Dict, List
 
 import torch
 
-from . import center_loss, ops, train_ops
+from . import center_loss, dist_utils, ops, train_ops
 from .engine import _DOWN, ModelConfig
 
 
@@ -124,9 +124,8 @@ class _Conv:
         else:
             z = ops.gather_conv(x, self.c_in, self.pw, nbr, self.kv, n_out, self.c_out, None, bias, None, False,
                                 dense=dense)
-        s1, s2 = train_ops.bn_stats(z)
-        mean, invstd, scale, shift = train_ops.bn_finalize(
-            s1, s2, z.shape[0], self.eps, self.momentum, st.p(self.gn), st.p(self.be),
+        mean, invstd, scale, shift = train_ops.bn_stats_finalize(
+            z, self.eps, self.momentum, st.p(self.gn), st.p(self.be),
             self.running_mean if update_stats else None, self.running_var if update_stats else None)
         y = train_ops.affine_rows(z, scale, shift, residual, self.relu, out=out)
         self.saved = (x, nbr, n_out, z, y, mean, invstd, residual is not None, dense, up_map)
@@ -481,10 +480,7 @@ class CenterPointTrainer:
 
     def optimizer_step(self):
         st = self.store
-        scale = 1.0
-        if self.world > 1:
-            torch.distributed.all_reduce(st.grad, group=self.pg)     # the step's one collective
-            scale = 1.0 / self.world
+        scale = dist_utils.reduce_gradients(st.grad, self.world, self.pg) if self.world > 1 else 1.0   # the one collective
         if self.grad_clip:
             norm = float(st.grad.norm()) * scale                     # clip_grad_norm_, train_utils.py:43
             if norm > self.grad_clip:

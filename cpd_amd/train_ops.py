@@ -56,6 +56,17 @@ def bn_finalize(s1, s2, n, eps, momentum, gamma, beta, running_mean=None, runnin
     return out[0], out[1], out[2], out[3]
 
 
+def bn_stats_finalize(x, eps, momentum, gamma, beta, running_mean=None, running_var=None):
+    """Batch statistics of x [n, c] -> (mean, invstd, scale, shift); running stats updated in place."""
+    n, c = x.shape
+    out = torch.empty((4, c), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().cpd_col_reduce_workspace_bytes(n, c), x.device)
+    check(lib().cpd_bn_stats_finalize(_p(x), _ld(x), n, c, float(eps), float(momentum), ptr(gamma), ptr(beta), _p(out[0]),
+                                      _p(out[1]), _p(out[2]), _p(out[3]), ptr(running_mean), ptr(running_var), ptr(ws),
+                                      ws.numel(), stream()), "cpd_bn_stats_finalize")
+    return out[0], out[1], out[2], out[3]
+
+
 def pack_weight_adjoint(w_kio, flip_taps):
     kv, cin, cout = w_kio.shape
     packed = torch.empty((lib().cpd_packed_weight_floats(kv, cout, cin),), dtype=torch.float32, device=w_kio.device)

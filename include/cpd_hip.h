@@ -229,6 +229,12 @@ int cpd_bn_stats(const float *x, int ldx, int n, int c, float *sum, float *sumsq
 int cpd_bn_finalize(const float *sum, const float *sumsq, int n, int c, float eps, float momentum,
                     const float *gamma, const float *beta, float *mean, float *invstd, float *scale,
                     float *shift, float *running_mean, float *running_var, cpd_stream_t stream);
+/* cpd_bn_stats + cpd_bn_finalize in one call (two launches): the training-mode BatchNorm forward
+ * bookkeeping of one layer. */
+int cpd_bn_stats_finalize(const float *x, int ldx, int n, int c, float eps, float momentum,
+                          const float *gamma, const float *beta, float *mean, float *invstd,
+                          float *scale, float *shift, float *running_mean, float *running_var,
+                          void *workspace, size_t workspace_bytes, cpd_stream_t stream);
 /* out = act(x * scale + shift + residual): BatchNorm apply (scale = gamma*invstd,
  * shift = beta - mean*scale), SparseBasicBlock tail (spconv_backbone.py:131-134). In place allowed. */
 int cpd_affine_rows(const float *x, int ldx, int n, int c, const float *scale, const float *shift,

@@ -1,5 +1,6 @@
 """N > 1 path on CPU: world_size-2 gloo run of the frame sharding + barrier + max-over-ranks timing
-that bench.py uses with RCCL on the GPUs (no data-path collective exists to test)."""
+that bench.py uses with RCCL on the GPUs (the forward path has no data-path collective), and of the
+train step's one collective: the flat-gradient all-reduce + averaging."""
 import os
 import socket
 
@@ -21,6 +22,10 @@ def _worker(rank, world, port, q):
     elapsed = 1.0 + rank            # rank 1 is the slow one
     mx = du.max_over_ranks(elapsed)
     thr = du.aggregate_throughput(units_per_rank=10, elapsed_local=elapsed)
+    import torch
+    grad = torch.full((1000,), float(rank + 1))          # rank r holds gradient r+1 everywhere
+    scale = du.reduce_gradients(grad, world)
+    assert scale == 0.5 and torch.all(grad == 3.0)       # sum over ranks, mean = sum * scale
     du.barrier()
     q.put((rank, seeds, mx, thr))
     du.shutdown()

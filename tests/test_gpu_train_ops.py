@@ -179,3 +179,48 @@ def test_adam_step(hip):
         p = p - lr * wd * p
         p = p - lr * (m / (1 - b1 ** step)) / (np.sqrt(v / (1 - b2 ** step)) + eps)
     np.testing.assert_allclose(pd.cpu().numpy(), p, rtol=1e-5, atol=1e-6)
+
+
+def test_bn_stats_finalize_matches_torch_batchnorm(hip):
+    """Fused stats + finalize: (mean, invstd, scale, shift) and the running-stat update of
+    torch.nn.BatchNorm1d in training mode (momentum 0.01, eps 1e-3: spconv_backbone.py:410)."""
+    from cpd_amd import train_ops
+    torch.manual_seed(0)
+    for n, c, ld in [(70001, 16, 16), (35344, 128, 512), (501, 320, 320), (9000, 3, 16)]:
+        buf = torch.randn(n, ld, device="cuda") * 2 + 0.5
+        x = buf[:, :c]
+        bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+            bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+        y_ref = bn(x.contiguous())
+        mean, invstd, scale, shift = train_ops.bn_stats_finalize(x, 1e-3, 0.01, bn.weight.detach(), bn.bias.detach(), rm, rv)
+        y = train_ops.affine_rows(x, scale, shift)
+        torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(rm, bn.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv, bn.running_var, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(mean, x.double().mean(0).float(), rtol=1e-5, atol=1e-5)
+
+
+def test_adjoint_packing_gives_input_gradient(hip):
+    """cpd_gather_conv on cpd_pack_weight_adjoint(W, flip) with the SAME SubM rulebook is the
+    input gradient of the forward conv (autograd of the gather-matmul definition)."""
+    from cpd_amd import ops, train_ops
+    torch.manual_seed(1)
+    g = torch.Generator().manual_seed(3)
+    coords = torch.unique(torch.stack([torch.zeros(4000, dtype=torch.int32), *(torch.randint(0, s, (4000,), generator=g,
+                          dtype=torch.int32) for s in (9, 40, 40))], 1), dim=0).cuda()
+    shape = [9, 40, 40]
+    index = ops.SiteIndex.build(coords, 1, shape)
+    nbr = ops.rulebook_subm(coords, index)
+    n, cin, cout = coords.shape[0], 32, 48
+    x = torch.randn(n, cin, device="cuda", requires_grad=True)
+    w = torch.randn(27, cin, cout, device="cuda") * 0.1
+    idx = torch.where(nbr < 0, n, nbr).long()
+    xp = torch.cat([x, x.new_zeros(1, cin)])
+    y = sum(xp[idx[t]] @ w[t] for t in range(27))
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    dx = ops.gather_conv(dy, cout, train_ops.pack_weight_adjoint(w, True), nbr, 27, n, cin)
+    torch.testing.assert_close(dx, x.grad, rtol=1e-4, atol=1e-4)

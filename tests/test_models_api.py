@@ -49,3 +49,31 @@ def test_registry_and_cfg():
     assert net.backbone_2d.num_bev_features_post == 512
     ecfg = net.to_engine_config()
     assert ecfg.sparse_shape == [41, 1504, 1504] and ecfg.nms_thresh == 0.8
+
+
+def test_center_head_training_branch_targets_and_loss():
+    """CenterHead.assign_targets / get_loss (center_head.py:159-250) through the module API, on CPU:
+    same numbers as cpd_amd.center_loss (itself pinned on the reference goldens)."""
+    from cpd_amd import center_loss
+    cfg = models.waymo_centerpoint_cfg()
+    net = models.CenterPoint(cfg)
+    head = net.dense_head
+    torch.manual_seed(0)
+    B, h, w = 2, 24, 24
+    gt = torch.zeros(B, 6, 8)
+    for b in range(B):
+        for i in range(4):
+            gt[b, i] = torch.tensor([float(torch.empty(1).uniform_(-9, 9)), float(torch.empty(1).uniform_(-9, 9)), 0.8, 4.2, 1.9,
+                                     1.6, 0.3 * i, float(1 + (i % 3))])
+    head.point_cloud_range = [-9.6, -9.6, -2.0, 9.6, 9.6, 4.0]
+    td = head.assign_targets(gt, feature_map_size=(h, w))
+    heat, tgt, inds, masks = center_loss.assign_targets(gt, (h, w), head.point_cloud_range, head.voxel_size, 3, 8)
+    assert torch.equal(td["heatmaps"][0], heat) and torch.equal(td["inds"][0], inds) and torch.equal(td["masks"][0], masks)
+    assert int(masks.sum()) == 8
+    pd = {"hm": torch.randn(B, 3, h, w), "center": torch.randn(B, 2, h, w), "center_z": torch.randn(B, 1, h, w),
+          "dim": torch.randn(B, 3, h, w), "rot": torch.randn(B, 2, h, w)}
+    head.forward_ret_dict = {"pred_dicts": [pd], "target_dicts": td}
+    loss, tb = head.get_loss()
+    rows = torch.cat([pd[k] for k in ("center", "center_z", "dim", "rot", "hm")], 1).permute(0, 2, 3, 1).reshape(B * h * w, -1)
+    want, _ = center_loss.center_head_loss(rows, B, h, w, heat, tgt, inds, masks, 3, hm_col=8)
+    assert abs(float(loss) - float(want)) < 1e-6 and abs(tb["rpn_loss"] - float(want)) < 1e-6

@@ -23,6 +23,9 @@ rows = []
 for k, leaf in P.items():
     ref = leaf.grad.numpy(); s = max(np.abs(ref).max(), 1e-12)
     rows.append((np.abs(grads[k] - ref).max() / s, np.abs(P32[k].grad.double().numpy() - ref).max() / s, s, k))
-rows.sort(reverse=True)
-for e, e32, s, k in rows[:40]:
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
+if not flt:
+    rows.sort(reverse=True)
+rows = [r for r in rows if flt in r[3]]
+for e, e32, s, k in rows[:400]:
     print("%-50s hip %.2e  torch32 %.2e  max|ref| %.2e" % (k, e, e32, s))
