@@ -33,6 +33,17 @@ from cpd_amd.engine import CenterPointEngine, ModelConfig, init_state_dict  # no
 from cpd_amd.synthetic import waymo_cloud  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+BF16X3_PRODUCTS = 6             # bf16 MFMA products per fp32 multiply-add in the split-bf16 kernels
+
+
+def kernel_peak(kname):
+    """fp32-equivalent matrix peak of a conv kernel: the split-bf16 kernels execute 6 bf16 products
+    per algorithmic fp32 multiply-add, so their ceiling is the bf16 peak / 6."""
+    if "bf16" in kname:
+        return PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS, "bf16 dense MFMA peak 2500 TFLOP/s / 6 partial products (split-bf16, fp32-level result)"
+    return PEAK_FP32_MFMA_TFLOPS, "fp32-input MFMA peak"
+
 POOL = 4                        # distinct synthetic frames per rank, cycled
 
 
@@ -48,6 +59,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-launch table of the conv kernels (stderr)")
+    ap.add_argument("--conv-math", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="dense-layer arithmetic: split-bf16 x3 on the bf16 matrix pipe (fp32-level error) or fp32 MFMA")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE config 2 (the headline metric); train = config 3: forward + backward + "
                          "one RCCL gradient all-reduce + Adam, --frames (default 1) frames per GPU per step")
@@ -79,7 +92,7 @@ class ConvProfiler:
         prof = self
 
         def wrapped(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
-            kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False))
+            kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False), kw.get("bf16x3", False))
             flops = 2.0 * prof._pairs(nbr, n_out) * c_in * c_out
             s = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -205,7 +218,7 @@ def main():
     torch.cuda.set_device(local)
     distributed = dist_utils.init("nccl", torch.device("cuda", local))   # "nccl" is RCCL on ROCm
 
-    cfg = ModelConfig()
+    cfg = ModelConfig(conv_math=args.conv_math)
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local
     if args.mode == "train":
@@ -265,7 +278,10 @@ def main():
                                "BaseBEVBackbone + CenterHead + rotated NMS, forward-only" % args.points,
                    "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
                    "parallelism": "frame-sharded replicas x%d, no data-path collective" % world,
-                   "weights": "random-init (seed 0), eval-mode BN folded"},
+                   "weights": "random-init (seed 0), eval-mode BN folded",
+                   "conv_math": "sparse layers fp32 MFMA; dense BEV layers %s" %
+                                ("split-bf16 x3 (6 bf16 MFMA products per fp32 multiply-add, fp32-level error)"
+                                 if cfg.conv_math == "bf16x3" else "fp32 MFMA")},
     }
 
     if not args.no_roofline:
@@ -285,9 +301,11 @@ def main():
         key, (flops, ms, launches) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12
         conv_flops = sum(v[0] for v in agg.values()) / (n_prof * B)        # algorithmic conv flop per frame
+        peak, peak_basis = kernel_peak(key)
         out["roofline"] = {
-            "bound": "mfma", "kernel": key, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(key),
+            "bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "peak_basis": peak_basis, "achieved_over_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": pmc_traffic(key),
             "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_summary.json)",
             "launches_per_frame": launches / (n_prof * B), "avg_launch_us": 1e3 * ms / launches,
             "algorithmic_gflop_per_launch": flops / launches / 1e9,
@@ -297,7 +315,9 @@ def main():
             "chip_conv_frac": conv_flops * out["value"] / world / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "algorithmic_conv_gflop_per_frame": conv_flops / 1e9,
             "all_conv_kernels": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_frame": v[1] / (n_prof * B),
-                                     "launches_per_frame": v[2] / (n_prof * B)} for k, v in sorted(agg.items())},
+                                     "launches_per_frame": v[2] / (n_prof * B),
+                                     "frac_of_its_peak": v[0] / (v[1] * 1e-3) / 1e12 / kernel_peak(k)[0]}
+                                 for k, v in sorted(agg.items())},
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

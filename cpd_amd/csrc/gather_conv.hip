@@ -44,6 +44,7 @@ namespace {
 struct GcParams {
     const float *in;
     const float *w;
+    const void *wb;           // split-bf16 image of the weights (after the fp32 image) or NULL
     const int32_t *nbr;
     const uint32_t *tapmask;  // per 16-row sub-tile: bit t = some row has a neighbour at tap t (or NULL)
     const float *scale, *shift, *residual;
@@ -394,6 +395,191 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(GcParams p) {
     epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
 }
 
+// ============================ split-bf16 workgroup kernel ====================================
+// fp32-equivalent convolution on the bf16 matrix pipe (16x the fp32 MFMA rate): every fp32 operand
+// is split EXACTLY into three bf16 terms, x = h + m + l (3 x 8 significand bits; h = rne(x),
+// m = rne(x - h), l = rne(x - h - m), each difference exact in fp32), and the six partial products
+// of relative weight >= 2^-18 (hh, hm, mh, hl, lh, mm) are accumulated in fp32 by
+// v_mfma_f32_16x16x32_bf16; the dropped terms (ml, lm, ll) are < 2^-26 of the product, below fp32's
+// own rounding. 6 MFMAs of K = 32 replace 8 fp32 MFMAs of K = 4 at 1/2 the cycles each: 2.67x.
+// Weights are split once at pack time (image Pb[t][k32][piece][g][n][8] after the fp32 image);
+// gathered activation rows are split while they are staged into LDS.
+// LDS images of one 32-channel stage, per piece in {h, m, l} (slots = 16 B = 8 channels):
+//   A: k-group g of tile row m at (g*BM + (m ^ 2g)) * 16   (8-byte staging writes of two rows x
+//      8 lanes and 16-row fragment reads are both conflict-free)
+//   B: k-group g of tile col n at (g*BN + n) * 16          (lane-linear both ways)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const f32x4 &x, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    h = __builtin_convertvector(x, bf16x4);
+    const f32x4 r1 = x - __builtin_convertvector(h, f32x4);
+    m = __builtin_convertvector(r1, bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+    l = __builtin_convertvector(r2, bf16x4);
+}
+
+template <int BM, int BN, bool DB>
+__global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
+    constexpr int MS = BM / 32, NT = BN / 32;       // 2 x 2 waves, wave tile (BM/2) x (BN/2)
+    constexpr int AJ = BM / 32;                     // fp32 A pieces (4 channels) staged per thread per stage
+    constexpr int BJ = 3 * BN / 64;                 // 16-byte B pieces staged per thread per stage
+    constexpr int A_IMG = BM * 64, B_IMG = BN * 64; // bytes of one piece image
+    constexpr int STAGE = 3 * (A_IMG + B_IMG);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
+    const int row0 = rb * BM, col0 = cb * BN;
+
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int a_piece = tid & 7;   // 4 channels: k-group a_piece >> 1, half a_piece & 1
+    const int a_row = tid >> 3;    // + 32*j
+    int a_rowc[AJ];
+    bool a_ok[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int row = row0 + a_row + 32 * j;
+        a_ok[j] = row < p.n_out;
+        a_rowc[j] = a_ok[j] ? row : p.n_out - 1;
+    }
+    const int sk = p.c_in >> 5;    // 32-channel stages per tap
+    const int n_stage = p.kv * sk;
+    const size_t b_stage = (size_t)3 * 4 * p.np * 16;   // bytes of one (tap, k32) block of Pb
+
+    int idx_cur[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr ? p.nbr[a_rowc[j]] : a_rowc[j];
+
+    f32x4 ra[AJ];
+    bool rz[AJ];                    // "no neighbour": applied when the piece is split, so that nothing
+    f32x4u rbv[BJ];                 // between the loads and the MFMAs of the current stage waits on them
+    auto stage_load = [&](int st) {
+        const int t = st / sk, kk = st - t * sk;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int id = a_ok[j] ? idx_cur[j] : -1;
+            ra[j] = load_a<true>(p, id, kk * 32 + a_piece * 4);
+            rz[j] = id < 0;
+        }
+        const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int id = j * 256 + tid;        // slot in the B stage image: (piece*4 + g)*BN + n
+            const int pg = id / BN, n = id - pg * BN;
+            rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char *sa = smem + (DB ? buf : 0) * STAGE;
+        char *sb = sa + 3 * A_IMG;
+        const int ag = a_piece >> 1, half = a_piece & 1;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = a_row + 32 * j;
+            bf16x4 h, mm, l;
+            split3(zero_if(ra[j], rz[j]), h, mm, l);
+            char *dst = sa + (((ag * BM + (m ^ (2 * ag))) << 4) + half * 8);
+            *reinterpret_cast<bf16x4 *>(dst) = h;
+            *reinterpret_cast<bf16x4 *>(dst + A_IMG) = mm;
+            *reinterpret_cast<bf16x4 *>(dst + 2 * A_IMG) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+    };
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int st = 0; st < n_stage; ++st) {
+        const int nx = st + 1;
+        if (nx < n_stage) {
+            const int t_nx = nx / sk;
+            if (nx - t_nx * sk == 0) {
+#pragma unroll
+                for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr[(size_t)t_nx * p.n_out + a_rowc[j]];
+            }
+            stage_load(nx);
+        }
+        {
+            const char *sa = smem + (DB ? (st & 1) : 0) * STAGE;
+            const char *sb = sa + 3 * A_IMG;
+            bf16x8 ah[MS], am[MS], al[MS];
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                const int m = wr * (BM / 2) + 16 * s + r;
+                const char *src = sa + ((g * BM + (m ^ (2 * g))) << 4);
+                ah[s] = *reinterpret_cast<const bf16x8 *>(src);
+                am[s] = *reinterpret_cast<const bf16x8 *>(src + A_IMG);
+                al[s] = *reinterpret_cast<const bf16x8 *>(src + 2 * A_IMG);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = wc * (BN / 2) + 16 * nt + r;
+                const char *src = sb + ((g * BN + n) << 4);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + 4 * BN * 16);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(src + 8 * BN * 16);
+#pragma unroll
+                for (int s = 0; s < MS; ++s) {      // smallest terms first
+                    f32x4 c = acc[s][nt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
+                    acc[s][nt] = c;
+                }
+            }
+        }
+        if (!DB) __syncthreads();          // single buffer: everyone is done reading before it is overwritten
+        if (nx < n_stage) stage_store(nx & 1);
+        __syncthreads();
+    }
+    epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
+}
+
+// Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
+// W[t_src][ci][co] (optionally the adjoint: tap-flipped and/or transposed source).
+__global__ void __launch_bounds__(256) pack_weight_bf16_kernel(const float *__restrict__ w, int kv, int c_in, int c_out, int np,
+                                                               int adjoint, int flip, __bf16 *__restrict__ pb) {
+    // (c_in, c_out) are those of the conv this image is FOR; the source tensor is [kv][c_in][c_out],
+    // or [kv][c_out][c_in] when `adjoint` is set.
+    const int k32 = c_in >> 5;
+    const size_t total = (size_t)kv * k32 * 4 * np * 8;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i & 7);
+    size_t rest = i >> 3;
+    const int n = (int)(rest % np); rest /= np;
+    const int g = (int)(rest & 3); rest >>= 2;
+    const int kk = (int)(rest % k32);
+    const int t = (int)(rest / k32);
+    const int ch = kk * 32 + g * 8 + q;
+    const int ts = flip ? kv - 1 - t : t;
+    float v = 0.f;
+    if (n < c_out) v = adjoint ? w[((size_t)ts * c_out + n) * c_in + ch] : w[((size_t)ts * c_in + ch) * c_out + n];
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    const size_t blk = ((size_t)t * k32 + kk) * 3;       // (tap, k32) block: 3 pieces x 4 g x np x 8
+    const size_t off = ((size_t)g * np + n) * 8 + q;
+    pb[(blk + 0) * 4 * np * 8 + off] = h;
+    pb[(blk + 1) * 4 * np * 8 + off] = m;
+    pb[(blk + 2) * 4 * np * 8 + off] = l;
+}
+
 // 32x32x2 variant of the workgroup kernel: same LDS images, the wave tile is (BM/2) x (BN/2) made of
 // 32 x 32 MFMA tiles (v_mfma_f32_32x32x2_f32: 64 cycles, half as many matrix instructions per flop).
 // Operand mapping: lane (i = l & 31, h = l >> 5) holds channels 8*c8 + 4*h + q of row / column i.
@@ -660,6 +846,16 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
     const int ntot = (c_out + 15) / 16;
     pl.vec = (c_in % 16 == 0) && (in_ld % 4 == 0) && (((uintptr_t)in & 15) == 0);
     pl.use_wg = 0;
+    // split-bf16 path (CPD_GC_BF16X3): 128 x 128 tiles, needs whole 32-channel stages and 128-column tiles
+    int allow_bf16 = (flags & 2) != 0;
+    if (const char *e = getenv("CPD_GC_BF16X3")) allow_bf16 = atoi(e);
+    long long bf16_min_wgs = 256;       // at least one workgroup per CU (measured: tools/bf16x3_probe.py)
+    if (const char *e = getenv("CPD_GC_BF16_MIN")) bf16_min_wgs = atoll(e);
+    if (allow_bf16 && pl.vec && c_in % 32 == 0 && c_out % 128 == 0 &&
+        (long long)((n_out + 127) / 128) * (c_out / 128) >= bf16_min_wgs) {
+        pl.use_wg = 2; pl.a = 128; pl.b = 128;
+        return pl;
+    }
     int force_wg = -1;
     if (const char *e = getenv("CPD_GC_WG")) force_wg = atoi(e);
     if (((flags & 1) && force_wg != 0) || force_wg > 0) {
@@ -678,16 +874,32 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
 
 }  // namespace
 
+static size_t packed_f32_floats(int kv, int c_in, int c_out) {
+    return (size_t)kv * ((c_in + 15) / 16) * 4 * (((c_out + 15) / 16) * 16) * 4;
+}
+// the split-bf16 image exists when the conv has whole 32-channel stages (6 bytes per weight)
+static size_t packed_bf16_floats(int kv, int c_in, int c_out) {
+    if (c_in % 32) return 0;
+    return (size_t)kv * (c_in / 32) * 3 * 4 * (((c_out + 15) / 16) * 16) * 8 / 2;
+}
 extern "C" size_t cpd_packed_weight_floats(int kv, int c_in, int c_out) {
     if (kv <= 0 || c_in <= 0 || c_out <= 0) return 0;
-    return (size_t)kv * ((c_in + 15) / 16) * 4 * (((c_out + 15) / 16) * 16) * 4;
+    return packed_f32_floats(kv, c_in, c_out) + packed_bf16_floats(kv, c_in, c_out);
+}
+static void pack_bf16_image(const float *w, int kv, int c_in, int c_out, int adjoint, int flip, float *packed, hipStream_t s) {
+    if (!packed_bf16_floats(kv, c_in, c_out)) return;
+    const int np = ((c_out + 15) / 16) * 16;
+    const size_t total = (size_t)kv * (c_in / 32) * 4 * np * 8;
+    pack_weight_bf16_kernel<<<cpd_div_up((long long)total, 256), 256, 0, s>>>(
+        w, kv, c_in, c_out, np, adjoint, flip, reinterpret_cast<__bf16 *>(packed + packed_f32_floats(kv, c_in, c_out)));
 }
 
 extern "C" int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *packed, cpd_stream_t stream) {
     if (!w_kio || !packed || kv <= 0 || c_in <= 0 || c_out <= 0) return CPD_ERR_ARG;
     int kc = (c_in + 15) / 16, np = ((c_out + 15) / 16) * 16;
-    size_t total = cpd_packed_weight_floats(kv, c_in, c_out);
+    size_t total = packed_f32_floats(kv, c_in, c_out);
     pack_weight_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, kc, np, packed);
+    pack_bf16_image(w_kio, kv, c_in, c_out, 0, 0, packed, cpd_s(stream));
     return cpd_check_launch();
 }
 
@@ -695,9 +907,10 @@ extern "C" int cpd_pack_weight_adjoint(const float *w_kio, int kv, int c_in, int
                                        cpd_stream_t stream) {
     if (!w_kio || !packed || kv <= 0 || c_in <= 0 || c_out <= 0) return CPD_ERR_ARG;
     int kc_o = (c_out + 15) / 16, np_o = ((c_in + 15) / 16) * 16;
-    size_t total = cpd_packed_weight_floats(kv, c_out, c_in);
+    size_t total = packed_f32_floats(kv, c_out, c_in);
     pack_weight_adjoint_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, flip_taps,
                                                                                             kc_o, np_o, packed);
+    pack_bf16_image(w_kio, kv, c_out, c_in, 1, flip_taps, packed, cpd_s(stream));
     return cpd_check_launch();
 }
 
@@ -719,12 +932,30 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
     GcParams p;
-    p.in = in; p.w = packed_w; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.in = in; p.w = packed_w; p.wb = nullptr; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
+    if (pl.use_wg == 2) {
+        p.wb = packed_w + packed_f32_floats(kv, c_in, c_out);
+        p.n_rb = (n_out + pl.a - 1) / pl.a;
+        p.n_cb = c_out / pl.b;
+        p.items = p.n_rb * p.n_cb;
+        int db = 0;
+        if (const char *e = getenv("CPD_GC_BF16_DB")) db = atoi(e);
+        const size_t lds = (db ? 2 : 1) * 3 * (size_t)(pl.a + pl.b) * 64;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_conv_bf16_kernel<128, 128, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (128 + 128) * 64);
+            attr_set = true;
+        }
+        if (db) hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 128, true>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        else hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 128, false>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        return cpd_check_launch();
+    }
     if (pl.use_wg) {
         const char *e32 = getenv("CPD_GC_MFMA32");
         gc_kernel_t k = (e32 && atoi(e32)) ? pick_tile32(pl.a, pl.b) : pick_tile(pl.a, pl.b);

@@ -163,7 +163,7 @@ def pack_weight(w_kio):
 
 
 def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=None, residual=None, relu=False,
-                out=None, out_row_map=None, out_col_group=0, dense=False):
+                out=None, out_row_map=None, out_col_group=0, dense=False, bf16x3=False):
     """out[j,:c_out] = act((sum_t in[nbr[t][j]] . W[t]) * scale + shift + residual[j]).
     `inp` / `out` / `residual` are 2-D row tensors whose row stride may exceed the channel count."""
     _need_cuda(inp, "inp")
@@ -179,7 +179,7 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
         ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w),
         ptr(nbr), ptr(getattr(nbr, "tapmask", None)), kv, n_out, c_out, ptr(scale), ptr(shift),
         ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
-        ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), 1 if dense else 0,
+        ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), (1 if dense else 0) | (2 if bf16x3 else 0),
         stream()),
         "cpd_gather_conv")
     return out
@@ -315,11 +315,14 @@ def boxes_iou_bev_cpu(a, b):
     return out
 
 
-def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False):
+def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False):
     """Name of the kernel instantiation cpd_gather_conv will run for this problem."""
     wg, a, b, vec = (ctypes.c_int(0) for _ in range(4))
-    check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), 1 if dense else 0, ctypes.byref(wg),
-                                     ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)), "cpd_gather_conv_tile")
+    check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), (1 if dense else 0) | (2 if bf16x3 else 0),
+                                     ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
+          "cpd_gather_conv_tile")
+    if wg.value == 2:
+        return "tile_conv_bf16_kernel<%d,%d>" % (a.value, b.value)
     if wg.value:
         return "tile_conv_kernel<%d,%d>" % (a.value, b.value)
     return "gather_conv_kernel<%d,%d,%s>" % (a.value, b.value, "true" if vec.value else "false")

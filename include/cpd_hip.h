@@ -127,7 +127,11 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
                     const float *shift, const float *residual, int res_ld, int relu, float *out,
                     int out_ld, const int32_t *out_row_map, int out_col_group, int flags,
                     cpd_stream_t stream);
-#define CPD_GC_DENSE 1 /* flags: the rulebook has (almost) no -1 entries -- prefer the LDS-tiled
+#define CPD_GC_DENSE 1
+/* allow the split-bf16 matrix path: fp32 operands split exactly into 3 bf16 terms, 6 partial
+ * products accumulated in fp32 (error <= 2^-22 relative per product, i.e. fp32-level); used for
+ * dense layers with c_in % 32 == 0 and c_out % 128 == 0 */
+#define CPD_GC_BF16X3 2 /* flags: the rulebook has (almost) no -1 entries -- prefer the LDS-tiled
                           workgroup kernel over the tap-skipping wave kernel */
 
 /* Introspection for benchmarks/profilers: which kernel instantiation cpd_gather_conv runs for

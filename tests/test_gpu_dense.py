@@ -155,3 +155,39 @@ def test_workgroup_kernel_matches_wave_kernel_and_oracle(oracle, hip, bm, bn, mo
     ops.gather_conv(nhwc_rows(x), cin, packed, None, 1, b * h * w, 256, out=out, out_row_map=maps.to(torch.int32).contiguous(),
                     out_col_group=64)
     np.testing.assert_allclose(rows_nchw(out, b, H, W), want, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride", [(128, 128, 3, 1), (256, 256, 3, 1), (128, 256, 3, 2), (256, 1024, 1, 1)])
+def test_split_bf16_conv_is_fp32_accurate(hip, cin, cout, k, stride):
+    """CPD_GC_BF16X3: fp32 operands split exactly into three bf16 terms, six partial products on the
+    bf16 matrix pipe. Against a float64 reference it must be as accurate as the fp32-MFMA kernel
+    (<= 1e-4 absolute at O(20) outputs, and within 1.5x of the fp32 kernel's own error)."""
+    from cpd_amd import ops
+    torch.manual_seed(cin + cout)
+    batch, hw = 2, 188
+    if k == 3:
+        nbr, ho, wo = ops.rulebook_conv2d(batch, hw, hw, 3, 3, stride, 1, "cuda"); kv = 9
+    else:
+        nbr, ho, wo, kv = None, hw, hw, 1
+    n_in, n_out = batch * hw * hw, batch * ho * wo
+    x = torch.randn(n_in, cin, device="cuda") * 3.0
+    w = torch.randn(kv, cin, cout, device="cuda") * (2.0 / (kv * cin)) ** 0.5
+    pw = ops.pack_weight(w)
+    assert ops.gather_conv_tile(n_out, cin, cout, cin, dense=True, bf16x3=True).startswith("tile_conv_bf16_kernel")
+    fast = ops.gather_conv(x, cin, pw, nbr, kv, n_out, cout, dense=True, bf16x3=True)
+    exact = ops.gather_conv(x, cin, pw, nbr, kv, n_out, cout, dense=True, bf16x3=False)
+    rows = torch.randint(0, n_out, (2048,), device="cuda")
+    if nbr is None:
+        ref = x[rows].double() @ w[0].double()
+    else:
+        idx = nbr[:, rows].long()
+        xp = torch.cat([x, x.new_zeros(1, cin)]).double()
+        ref = sum(xp[torch.where(idx[t] < 0, n_in, idx[t])] @ w[t].double() for t in range(kv))
+    e_fast = (fast[rows].double() - ref).abs().max().item()
+    e_exact = (exact[rows].double() - ref).abs().max().item()
+    assert e_fast <= 1e-4, (e_fast, e_exact)
+    assert e_fast <= 1.5 * e_exact + 1e-6, (e_fast, e_exact)
+    # scale invariance: the split is exact at any magnitude (no bf16-level truncation of small values)
+    small = ops.gather_conv(x * 1e-4, cin, pw, nbr, kv, n_out, cout, dense=True, bf16x3=True)
+    e_small = (small[rows].double() - ref * 1e-4).abs().max().item()
+    assert e_small <= 1.5e-4 * max(e_fast, e_exact) + 1e-12, (e_small, e_fast)

@@ -82,9 +82,10 @@ def test_full_size_properties(hip):
     r0b, it0b = eng.forward([p0], return_intermediates=True)
     assert torch.equal(it0["head_rows"][:, :11], it0b["head_rows"][:, :11])
     assert torch.equal(r0[0]["pred_boxes"], r0b[0]["pred_boxes"])
-    # a frame's result does not depend on what else is in the batch
+    # a frame's result does not depend on what else is in the batch (different batch sizes run different
+    # kernel instantiations -- fp32-MFMA vs split-bf16 tiles -- so equality is to fp32 rounding, not bitwise)
     rb = eng.forward([p1, p0])
-    np.testing.assert_allclose(rb[1]["pred_boxes"].cpu().numpy(), r0[0]["pred_boxes"].cpu().numpy(), atol=1e-4)
+    np.testing.assert_allclose(rb[1]["pred_boxes"].cpu().numpy(), r0[0]["pred_boxes"].cpu().numpy(), atol=1e-4, rtol=2e-5)
     np.testing.assert_array_equal(rb[1]["pred_labels"].cpu().numpy(), r0[0]["pred_labels"].cpu().numpy())
 
 
