@@ -549,6 +549,161 @@ __global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
     epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
 }
 
+// Split-bf16 kernel for SPARSE layers: a workgroup owns 128 output rows x BN columns, wave w the
+// rows [32w, 32w+32) x all BN columns. Only the weights go through LDS (one (tap, 32-channel)
+// block of Pb per stage, shared by the four waves); a wave gathers ITS rows' 128-byte channel
+// blocks straight into registers (4 lanes per row, 32 B each) and splits them there -- no row is
+// fetched or split twice. Taps that none of the workgroup's eight 16-row sub-tiles has are not
+// staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
+template <int BN>
+__global__ void __launch_bounds__(256) rowwave_conv_bf16_kernel(GcParams p) {
+    constexpr int MS = 2, NT = BN / 16;
+    constexpr int BJ = 3 * BN / 64;            // 16-byte B pieces staged per thread per stage
+    constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
+    __shared__ __attribute__((aligned(16))) char sb[3 * B_IMG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
+    const int row0 = rb * 128 + wave * 32, col0 = cb * BN;
+
+    // tap activity: workgroup-wide (which stages exist) and per sub-tile of this wave
+    uint32_t wg_mask = 0xffffffffu, my_mask[MS] = {0xffffffffu, 0xffffffffu};
+    if (p.tapmask) {
+        wg_mask = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sub = rb * 8 + i;
+            const uint32_t m = sub < p.n_sub ? p.tapmask[sub] : 0u;
+            wg_mask |= m;
+            if (i == 2 * wave) my_mask[0] = m;
+            if (i == 2 * wave + 1) my_mask[1] = m;
+        }
+    }
+    auto tap_on = [&](int t) { return t >= 32 || ((wg_mask >> t) & 1u); };
+
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int rowc[MS];
+    bool row_ok[MS];
+#pragma unroll
+    for (int s = 0; s < MS; ++s) {
+        const int row = row0 + 16 * s + r;
+        row_ok[s] = row < p.n_out;
+        rowc[s] = row_ok[s] ? row : p.n_out - 1;
+    }
+    const int sk = p.c_in >> 5;
+    const size_t b_stage = (size_t)3 * 4 * p.np * 16;
+
+    int t_first = 0;
+    while (t_first < p.kv && !tap_on(t_first)) ++t_first;
+    if (t_first < p.kv) {
+        auto next_tap = [&](int t) { do { ++t; } while (t < p.kv && !tap_on(t)); return t; };
+        auto load_idx = [&](int t, int (&idx)[MS]) {
+#pragma unroll
+            for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
+        };
+        auto sub_on = [&](int s, int t) { return t >= 32 || ((my_mask[s] >> t) & 1u); };
+
+        int idx_cur[MS], idx_nxt[MS];
+        load_idx(t_first, idx_cur);
+        int t_after = next_tap(t_first);          // tap whose rulebook column sits in idx_nxt
+        if (t_after < p.kv) load_idx(t_after, idx_nxt);
+
+        f32x4 araw[MS][2];
+        bool az[MS];
+        f32x4u rbv[BJ];
+        auto stage_load = [&](int t, int kk) {
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                if (sub_on(s, t)) {
+                    const int id = row_ok[s] ? idx_cur[s] : -1;
+                    az[s] = id < 0;
+                    araw[s][0] = load_a<true>(p, id, kk * 32 + g * 8);
+                    araw[s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
+                }
+            }
+            const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int id = j * 256 + tid;
+                const int pg = id / BN, n = id - pg * BN;
+                rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+            }
+        };
+        bf16x8 ah[MS], am[MS], al[MS];
+        auto stage_commit = [&](int t) {            // B -> LDS, A -> split fragments
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                if (sub_on(s, t)) {
+                    bf16x4 h0, m0, l0, h1, m1, l1;
+                    split3(zero_if(araw[s][0], az[s]), h0, m0, l0);
+                    split3(zero_if(araw[s][1], az[s]), h1, m1, l1);
+                    ah[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    am[s] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    al[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+        };
+
+        int t = t_first, kk = 0;
+        stage_load(t, kk);
+        stage_commit(t);
+        __syncthreads();
+        while (true) {
+            // the stage after (t, kk)
+            int tn = t, kn = kk + 1;
+            if (kn == sk) { kn = 0; tn = t_after; }
+            const bool more = tn < p.kv;
+            if (more) {
+                if (kn == 0) {                      // entering tap tn: its column was prefetched a tap ago
+#pragma unroll
+                    for (int s = 0; s < MS; ++s) idx_cur[s] = idx_nxt[s];
+                    t_after = next_tap(tn);
+                    if (t_after < p.kv) load_idx(t_after, idx_nxt);
+                }
+                stage_load(tn, kn);
+            }
+            const bool on0 = sub_on(0, t), on1 = sub_on(1, t);
+            if (on0 || on1) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const char *src = sb + ((g * BN + 16 * nt + r) << 4);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + B_IMG);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(src + 2 * B_IMG);
+#pragma unroll
+                    for (int s = 0; s < MS; ++s) {
+                        if (s == 0 ? on0 : on1) {
+                            f32x4 c = acc[s][nt];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
+                            acc[s][nt] = c;
+                        }
+                    }
+                }
+            }
+            if (!more) break;
+            __syncthreads();                        // every wave is done with this stage's weights
+            stage_commit(tn);
+            __syncthreads();
+            t = tn; kk = kn;
+        }
+    }
+    epilogue<MS, NT>(p, acc, row0, col0, r, g);
+}
+
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
 // W[t_src][ci][co] (optionally the adjoint: tap-flipped and/or transposed source).
 __global__ void __launch_bounds__(256) pack_weight_bf16_kernel(const float *__restrict__ w, int kv, int c_in, int c_out, int np,
@@ -851,10 +1006,22 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
     if (const char *e = getenv("CPD_GC_BF16X3")) allow_bf16 = atoi(e);
     long long bf16_min_wgs = 256;       // at least one workgroup per CU (measured: tools/bf16x3_probe.py)
     if (const char *e = getenv("CPD_GC_BF16_MIN")) bf16_min_wgs = atoll(e);
-    if (allow_bf16 && pl.vec && c_in % 32 == 0 && c_out % 128 == 0 &&
-        (long long)((n_out + 127) / 128) * (c_out / 128) >= bf16_min_wgs) {
-        pl.use_wg = 2; pl.a = 128; pl.b = 128;
-        return pl;
+    if (allow_bf16 && !(flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 64 == 0) {     // sparse layers
+        const int bn = c_out % 128 == 0 ? 128 : 64;
+        int force_bn = 0;
+        if (const char *e = getenv("CPD_GC_ROWWAVE_BN")) force_bn = atoi(e);
+        if ((force_bn == 64 || force_bn == 128) && c_out % force_bn == 0) { pl.use_wg = 3; pl.a = 128; pl.b = force_bn; return pl; }
+        if ((long long)((n_out + 127) / 128) * (c_out / bn) >= bf16_min_wgs) {
+            pl.use_wg = 3; pl.a = 128; pl.b = bn;
+            return pl;
+        }
+    }
+    if (allow_bf16 && (flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 64 == 0) {
+        const int bn = c_out % 128 == 0 ? 128 : 64;
+        if ((long long)((n_out + 127) / 128) * (c_out / bn) >= bf16_min_wgs) {
+            pl.use_wg = 2; pl.a = 128; pl.b = bn;
+            return pl;
+        }
     }
     int force_wg = -1;
     if (const char *e = getenv("CPD_GC_WG")) force_wg = atoi(e);
@@ -938,6 +1105,15 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
+    if (pl.use_wg == 3) {
+        p.wb = packed_w + packed_f32_floats(kv, c_in, c_out);
+        p.n_rb = (n_out + 127) / 128;
+        p.n_cb = c_out / pl.b;
+        p.items = p.n_rb * p.n_cb;
+        if (pl.b == 64) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<64>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+        else hipLaunchKernelGGL((rowwave_conv_bf16_kernel<128>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+        return cpd_check_launch();
+    }
     if (pl.use_wg == 2) {
         p.wb = packed_w + packed_f32_floats(kv, c_in, c_out);
         p.n_rb = (n_out + pl.a - 1) / pl.a;
@@ -945,6 +1121,7 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
         p.items = p.n_rb * p.n_cb;
         int db = 0;
         if (const char *e = getenv("CPD_GC_BF16_DB")) db = atoi(e);
+        if (pl.b == 64) db = 0;
         const size_t lds = (db ? 2 : 1) * 3 * (size_t)(pl.a + pl.b) * 64;
         static bool attr_set = false;
         if (!attr_set) {
@@ -952,7 +1129,8 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (128 + 128) * 64);
             attr_set = true;
         }
-        if (db) hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 128, true>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        if (pl.b == 64) hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 64, false>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        else if (db) hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 128, true>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
         else hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 128, false>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
         return cpd_check_launch();
     }

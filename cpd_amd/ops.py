@@ -321,6 +321,8 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False):
     check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), (1 if dense else 0) | (2 if bf16x3 else 0),
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
           "cpd_gather_conv_tile")
+    if wg.value == 3:
+        return "rowwave_conv_bf16_kernel<%d>" % b.value
     if wg.value == 2:
         return "tile_conv_bf16_kernel<%d,%d>" % (a.value, b.value)
     if wg.value:

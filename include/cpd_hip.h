@@ -130,7 +130,7 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
 #define CPD_GC_DENSE 1
 /* allow the split-bf16 matrix path: fp32 operands split exactly into 3 bf16 terms, 6 partial
  * products accumulated in fp32 (error <= 2^-22 relative per product, i.e. fp32-level); used for
- * dense layers with c_in % 32 == 0 and c_out % 128 == 0 */
+ * dense layers with c_in % 32 == 0 and c_out % 64 == 0 */
 #define CPD_GC_BF16X3 2 /* flags: the rulebook has (almost) no -1 entries -- prefer the LDS-tiled
                           workgroup kernel over the tap-skipping wave kernel */
 

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cpd_amd import ops
 
 SHAPES = [("bev0_128to128", 188, 128, 128, 3, 1), ("bev0_256to128", 188, 256, 128, 3, 1), ("bev1_128to256_s2", 188, 128, 256, 3, 2),
-          ("bev1_256to256", 94, 256, 256, 3, 1), ("de1_256to1024", 94, 256, 1024, 1, 1)]
+          ("bev1_256to256", 94, 256, 256, 3, 1), ("de1_256to1024", 94, 256, 1024, 1, 1),
+          ("shared_512to64", 188, 512, 64, 3, 1), ("head1_64to320", 188, 64, 320, 3, 1)]
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 torch.manual_seed(0)
 for name, hw, cin, cout, k, stride in SHAPES:
