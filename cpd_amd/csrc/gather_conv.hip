@@ -558,7 +558,8 @@ __global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
 template <int BN>
 __global__ void __launch_bounds__(256) rowwave_conv_bf16_kernel(GcParams p) {
     constexpr int MS = 2, NT = BN / 16;
-    constexpr int BJ = 3 * BN / 64;            // 16-byte B pieces staged per thread per stage
+    constexpr int B_SLOTS = 3 * 4 * BN;        // 16-byte B pieces of one stage
+    constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
     __shared__ __attribute__((aligned(16))) char sb[3 * B_IMG];
 
@@ -633,13 +634,15 @@ __global__ void __launch_bounds__(256) rowwave_conv_bf16_kernel(GcParams p) {
             for (int j = 0; j < BJ; ++j) {
                 const int id = j * 256 + tid;
                 const int pg = id / BN, n = id - pg * BN;
-                rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+                if (B_SLOTS % 256 == 0 || id < B_SLOTS)
+                    rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
             }
         };
         bf16x8 ah[MS], am[MS], al[MS];
         auto stage_commit = [&](int t) {            // B -> LDS, A -> split fragments
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+            for (int j = 0; j < BJ; ++j)
+                if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
@@ -1006,8 +1009,8 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
     if (const char *e = getenv("CPD_GC_BF16X3")) allow_bf16 = atoi(e);
     long long bf16_min_wgs = 256;       // at least one workgroup per CU (measured: tools/bf16x3_probe.py)
     if (const char *e = getenv("CPD_GC_BF16_MIN")) bf16_min_wgs = atoll(e);
-    if (allow_bf16 && !(flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 64 == 0) {     // sparse layers
-        const int bn = c_out % 128 == 0 ? 128 : 64;
+    if (allow_bf16 && !(flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 32 == 0) {     // sparse layers
+        const int bn = c_out % 128 == 0 ? 128 : (c_out % 64 == 0 ? 64 : 32);
         int force_bn = 0;
         if (const char *e = getenv("CPD_GC_ROWWAVE_BN")) force_bn = atoi(e);
         if ((force_bn == 64 || force_bn == 128) && c_out % force_bn == 0) { pl.use_wg = 3; pl.a = 128; pl.b = force_bn; return pl; }
@@ -1110,7 +1113,8 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
         p.n_rb = (n_out + 127) / 128;
         p.n_cb = c_out / pl.b;
         p.items = p.n_rb * p.n_cb;
-        if (pl.b == 64) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<64>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+        if (pl.b == 32) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<32>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+        else if (pl.b == 64) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<64>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
         else hipLaunchKernelGGL((rowwave_conv_bf16_kernel<128>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
         return cpd_check_launch();
     }

@@ -32,6 +32,7 @@ class _Flat:
         self._pending = []
         self.slots = {}
         self.flat = self.grad = self.m = self.v = None
+        self.bf16x3 = True      # conv arithmetic of layers with >= 32 input channels (ModelConfig.conv_math)
 
     def add(self, name, t):
         assert name not in self.slots
@@ -114,16 +115,16 @@ class _Conv:
         bias = st.p(self.bn_) if self.bn_ else None
         if not self.has_bn:                                   # final head convs: conv + bias only
             y = ops.gather_conv(x, self.c_in, self.pw, nbr, self.kv, n_out, self.c_out, None, bias, None, self.relu,
-                                out=out, dense=dense)
+                                out=out, dense=dense, bf16x3=self.store.bf16x3)
             self.saved = (x, nbr, n_out, None, y, None, None, False, dense, None)
             return y
         if self.mode == "up" and self.up > 1:
             z = torch.empty((n_up, self.c_bn), dtype=torch.float32, device=x.device)
             ops.gather_conv(x, self.c_in, self.pw, None, 1, n_out, self.c_out, None, None, None, False, out=z,
-                            out_row_map=up_map, out_col_group=self.c_bn, dense=dense)
+                            out_row_map=up_map, out_col_group=self.c_bn, dense=dense, bf16x3=self.store.bf16x3)
         else:
             z = ops.gather_conv(x, self.c_in, self.pw, nbr, self.kv, n_out, self.c_out, None, bias, None, False,
-                                dense=dense)
+                                dense=dense, bf16x3=self.store.bf16x3)
         mean, invstd, scale, shift = train_ops.bn_stats_finalize(
             z, self.eps, self.momentum, st.p(self.gn), st.p(self.be),
             self.running_mean if update_stats else None, self.running_var if update_stats else None)
@@ -154,7 +155,7 @@ class _Conv:
             if not need_dx:
                 return None, dres
             dx = ops.gather_conv(dz, self.c_bn, self.pw_adj, up_map, u2, n_out, self.c_in, None, None, add, False,
-                                 out=dx_out, dense=dense)
+                                 out=dx_out, dense=dense, bf16x3=self.store.bf16x3)
             return dx, dres
         if nbr is None:                                       # 1x1 conv: identity rulebook for the weight gradient
             nbr_w = torch.arange(n_out, dtype=torch.int32, device=dz.device).view(1, -1)
@@ -164,7 +165,7 @@ class _Conv:
         if not need_dx:
             return None, dres
         dx = ops.gather_conv(dz, self.c_out, self.pw_adj, nbr_adj, self.kv, n_in, self.c_in, None, None, add, False,
-                             out=dx_out, dense=dense)
+                             out=dx_out, dense=dense, bf16x3=self.store.bf16x3)
         return dx, dres
 
 
@@ -202,6 +203,7 @@ class CenterPointTrainer:
         self.code_weights = code_weights
         self.steps_done = 0
         self.store = _Flat()
+        self.store.bf16x3 = cfg.conv_math == "bf16x3"
         self._voxelizers = []
         self._bev_cache = {}
         self._build(state_dict)
