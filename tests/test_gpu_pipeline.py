@@ -85,8 +85,15 @@ def test_full_size_properties(hip):
     # a frame's result does not depend on what else is in the batch (different batch sizes run different
     # kernel instantiations -- fp32-MFMA vs split-bf16 tiles -- so equality is to fp32 rounding, not bitwise)
     rb = eng.forward([p1, p0])
-    np.testing.assert_allclose(rb[1]["pred_boxes"].cpu().numpy(), r0[0]["pred_boxes"].cpu().numpy(), atol=1e-4, rtol=2e-5)
-    np.testing.assert_array_equal(rb[1]["pred_labels"].cpu().numpy(), r0[0]["pred_labels"].cpu().numpy())
+    a, b = rb[1]["pred_boxes"].cpu().numpy(), r0[0]["pred_boxes"].cpu().numpy()
+    assert a.shape == b.shape
+    # same detections; boxes whose scores tie to ~1e-6 may swap ranks between kernel paths, so match by geometry
+    d = np.abs(a[:, None, :] - b[None, :, :]).max(-1)
+    j = d.argmin(1)
+    assert sorted(j.tolist()) == list(range(len(b)))
+    np.testing.assert_allclose(a, b[j], atol=1e-4, rtol=2e-5)
+    np.testing.assert_array_equal(rb[1]["pred_labels"].cpu().numpy(), r0[0]["pred_labels"].cpu().numpy()[j])
+    np.testing.assert_allclose(rb[1]["pred_scores"].cpu().numpy(), r0[0]["pred_scores"].cpu().numpy()[j], atol=2e-5)
 
 
 def test_module_api_matches_engine(oracle, hip):
