@@ -1009,7 +1009,9 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
     if (const char *e = getenv("CPD_GC_BF16X3")) allow_bf16 = atoi(e);
     long long bf16_min_wgs = 256;       // at least one workgroup per CU (measured: tools/bf16x3_probe.py)
     if (const char *e = getenv("CPD_GC_BF16_MIN")) bf16_min_wgs = atoll(e);
-    if (allow_bf16 && !(flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 32 == 0) {     // sparse layers
+    int dense_rowwave = 0;
+    if (const char *e = getenv("CPD_GC_DENSE_ROWWAVE")) dense_rowwave = atoi(e);
+    if (allow_bf16 && (!(flags & 1) || dense_rowwave) && pl.vec && c_in % 32 == 0 && c_out % 32 == 0) {     // sparse layers
         const int bn = c_out % 128 == 0 ? 128 : (c_out % 64 == 0 ? 64 : 32);
         int force_bn = 0;
         if (const char *e = getenv("CPD_GC_ROWWAVE_BN")) force_bn = atoi(e);

@@ -3,8 +3,10 @@
 M mfma, r ds_read, w ds_write, G global load, B barrier, c cvt, |..| s_waitcnt, . other."""
 import re, sys
 s = open(sys.argv[1]).read()
-i = s.index(sys.argv[2])
-j = s.index('s_endpgm', i)
+import re as _re
+m = _re.search(r'^\S*' + _re.escape(sys.argv[2]) + r'\S*:', s, _re.M)
+i = m.start()
+j = s.index('.Lfunc_end', i)
 body = s[i:j].split('\n')
 idx = [k for k, l in enumerate(body) if 'v_mfma' in l]
 seq = []
