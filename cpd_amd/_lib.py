@@ -61,6 +61,11 @@ SIGNATURES = {
     "cpd_col_reduce_workspace_bytes": (_SZ, [_I, _I]),
     "cpd_col_sum": (_I, [_VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "cpd_bn_stats": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_voxel2pinds": (_I, [_VP, _I, _I, _I3, _VP, _VP]),
+    "cpd_voxel_query": (_I, [_I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "cpd_voxel_query_index": (_I, [_I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "cpd_group_points": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "cpd_voxel_pool_max": (_I, [_I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "cpd_bn_stats_finalize": (_I, [_VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_bn_finalize": (_I, [_VP, _VP, _I, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_pack_weight_adjoint": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),

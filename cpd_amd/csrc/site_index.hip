@@ -18,53 +18,9 @@
 // go through perm[rank]; canonical lists use rank directly.
 #include "common.h"
 
+#include "site_index_layout.h"
+
 namespace {
-
-struct IndexView {
-    uint64_t *bitmap;
-    uint32_t *base;
-    uint32_t *bsum;
-    int32_t *perm;    // rank -> row id
-    int32_t *flags;   // [0] = 1 when perm is in use
-    long long cells, words;
-    size_t bytes;
-};
-
-static IndexView index_carve(void *mem, int batch, const int32_t shape[3], int n_cap) {
-    IndexView v;
-    size_t off = 0;
-    char *b = (char *)mem;
-    auto take = [&](size_t bytes) {
-        void *p = b ? (void *)(b + off) : nullptr;
-        off += cpd_align(bytes);
-        return p;
-    };
-    v.cells = (long long)batch * shape[0] * shape[1] * shape[2];
-    v.words = (v.cells + 63) / 64;
-    v.flags = (int32_t *)take(256);
-    v.bitmap = (uint64_t *)take((size_t)v.words * 8);
-    v.base = (uint32_t *)take((size_t)v.words * 4);
-    v.bsum = (uint32_t *)take((size_t)scan_num_blocks(v.words) * 4);
-    v.perm = (int32_t *)take((size_t)(n_cap > 0 ? n_cap : 1) * 4);
-    v.bytes = off;
-    return v;
-}
-
-struct Grid {
-    int32_t b, d, h, w;
-    __host__ __device__ long long key(int bi, int z, int y, int x) const {
-        return (((long long)bi * d + z) * h + y) * w + x;
-    }
-};
-
-__device__ __forceinline__ int32_t site_lookup(const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
-                                               const int32_t *__restrict__ perm, long long key) {
-    uint64_t w = bitmap[key >> 6];
-    uint64_t bit = 1ull << (key & 63);
-    if (!(w & bit)) return -1;
-    int32_t r = (int32_t)(base[key >> 6] + __popcll(w & (bit - 1ull)));
-    return perm ? perm[r] : r;
-}
 
 __global__ void __launch_bounds__(256) index_mark_kernel(const int32_t *__restrict__ idx, int n, Grid g, uint64_t *bitmap) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

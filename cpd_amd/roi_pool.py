@@ -1,0 +1,195 @@
+"""RoI-head feature pooling of the two-stage CPD model on the C-ABI kernels of
+csrc/roi_pool.hip. Mirrors, name for name:
+
+  generate_voxel2pinds                        cpd/utils/spconv_utils.py:14-21
+  voxel_query / VoxelQueryAndGrouping          cpd/ops/pointnet2/pointnet2_stack/voxel_query_utils.py:10-110
+  grouping_operation                           cpd/ops/pointnet2/pointnet2_stack/pointnet2_utils.py:48-84
+  NeighborVoxelSAModuleMSG                     cpd/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:8-131
+  get_global_grid_points_of_roi, roi_grid_pool cpd/models/roi_heads/voxel_rcnn_head.py:186-273, 365-386
+
+The module runs eval-mode (BatchNorm folded): the per-voxel MLP (mlps_in) and the output MLP
+(mlps_out) are 1x1 `cpd_gather_conv` GEMMs; grouping, position encoding, ReLU and max-pool are one
+fused kernel (`cpd_voxel_pool_max`), so the (M, C, nsample) grouped tensors of the reference are
+never materialised. The neighbour query can use the sparse tensor's own site index
+(`cpd_voxel_query_index`) instead of a dense (B,Z,Y,X) volume.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import check, iarr, lib, ptr, stream
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def generate_voxel2pinds(indices, batch_size, spatial_shape):
+    """indices [n,4] i32 (b,z,y,x) -> int32 (B,Z,Y,X) volume of row ids, -1 = empty."""
+    indices = indices.contiguous()
+    out = torch.empty([batch_size] + [int(s) for s in spatial_shape], dtype=torch.int32, device=indices.device)
+    check(lib().cpd_voxel2pinds(ptr(indices), indices.shape[0], int(batch_size), iarr(spatial_shape), ptr(out), stream()),
+          "cpd_voxel2pinds")
+    return out
+
+
+def voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices=None, index=None):
+    """VoxelQuery.forward: (idx [M, nsample] i32 with empty balls zeroed, empty_ball_mask [M] bool).
+    new_coords [M,4] = (b,z,y,x). Pass `point_indices` (dense volume) like the reference, or `index`
+    (an ops.SiteIndex of the sparse tensor; `index.canonical` tells whether rank == row)."""
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and new_coords.is_contiguous()
+    m = new_coords.shape[0]
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    zr, yr, xr = [int(v) for v in max_range]
+    if index is not None:
+        z, y, x = index.shape
+        check(lib().cpd_voxel_query_index(m, index.batch, z, y, x, int(nsample), float(radius), zr, yr, xr, ptr(new_xyz), ptr(xyz),
+                                          ptr(new_coords), ptr(index.buf), 0 if getattr(index, "canonical", True) else 1,
+                                          xyz.shape[0], ptr(idx), stream()), "cpd_voxel_query_index")
+    else:
+        assert point_indices.is_contiguous() and point_indices.dtype == torch.int32
+        b, z, y, x = point_indices.shape
+        check(lib().cpd_voxel_query(m, z, y, x, int(nsample), float(radius), zr, yr, xr, ptr(new_xyz), ptr(xyz), ptr(new_coords),
+                                    ptr(point_indices), ptr(idx), stream()), "cpd_voxel_query")
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
+
+
+def grouping_operation(features, features_batch_cnt, idx, idx_batch_cnt):
+    """GroupingOperation.forward: (M, C, nsample) = features[batch start + idx]."""
+    features, idx = features.contiguous(), idx.contiguous()
+    m, ns = idx.shape
+    c = features.shape[1]
+    out = torch.empty((m, c, ns), dtype=torch.float32, device=features.device)
+    check(lib().cpd_group_points(int(features_batch_cnt.shape[0]), m, c, ns, ptr(features), ptr(features_batch_cnt.int().contiguous()),
+                                 ptr(idx), ptr(idx_batch_cnt.int().contiguous()), ptr(out), stream()), "cpd_group_points")
+    return out
+
+
+def voxel_pool_max(features_in, xyz, new_xyz, idx_raw, w_pos, b_pos):
+    """Fused grouping + position MLP + ReLU + max over samples -> [M, C]. idx_raw: kernel output
+    (global rows, idx[m,0] == -1 for an empty ball)."""
+    m, ns = idx_raw.shape
+    c = features_in.shape[1]
+    out = torch.empty((m, c), dtype=torch.float32, device=features_in.device)
+    check(lib().cpd_voxel_pool_max(m, c, ns, _p(features_in), features_in.stride(0), ptr(xyz), ptr(new_xyz), ptr(idx_raw),
+                                   ptr(w_pos), ptr(b_pos), _p(out), out.stride(0), stream()), "cpd_voxel_pool_max")
+    return out
+
+
+def _fold(bn):
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    return scale, bn.bias.detach() - bn.running_mean * scale
+
+
+class NeighborVoxelSAModuleMSG(nn.Module):
+    """State-dict compatible with the reference module (mlps_in / mlps_pos / mlps_out); eval mode only."""
+
+    def __init__(self, *, query_ranges, radii, nsamples, mlps, use_xyz=True, pool_method="max_pool"):
+        super().__init__()
+        assert len(query_ranges) == len(nsamples) == len(mlps)
+        if pool_method != "max_pool":
+            raise NotImplementedError("only max_pool is used by the CPD configs (voxel_rcnn_cproto_center*.yaml POOL_METHOD)")
+        self.query_ranges, self.radii, self.nsamples = query_ranges, radii, nsamples
+        self.mlps_in, self.mlps_pos, self.mlps_out = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for spec in mlps:
+            self.mlps_in.append(nn.Sequential(nn.Conv1d(spec[0], spec[1], kernel_size=1, bias=False), nn.BatchNorm1d(spec[1])))
+            self.mlps_pos.append(nn.Sequential(nn.Conv2d(3, spec[1], kernel_size=1, bias=False), nn.BatchNorm2d(spec[1])))
+            self.mlps_out.append(nn.Sequential(nn.Conv1d(spec[1], spec[2], kernel_size=1, bias=False), nn.BatchNorm1d(spec[2]),
+                                               nn.ReLU()))
+        for m in self.modules():                                   # init_weights, voxel_pool_modules.py:60-68
+            if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+                nn.init.kaiming_normal_(m.weight)
+        self._packed = None
+
+    def _pack(self):
+        pk = []
+        for k in range(len(self.nsamples)):
+            s_in, t_in = _fold(self.mlps_in[k][1])
+            w_in = self.mlps_in[k][0].weight.detach()[:, :, 0].t().contiguous()[None]          # [1, C0, C1]
+            s_p, t_p = _fold(self.mlps_pos[k][1])
+            w_pos = (self.mlps_pos[k][0].weight.detach()[:, :, 0, 0] * s_p[:, None]).t().contiguous()   # [3, C1]
+            s_o, t_o = _fold(self.mlps_out[k][1])
+            w_out = self.mlps_out[k][0].weight.detach()[:, :, 0].t().contiguous()[None]        # [1, C1, C2]
+            pk.append(dict(w_in=ops.pack_weight(w_in), s_in=s_in.contiguous(), t_in=t_in.contiguous(), w_pos=w_pos,
+                           b_pos=t_p.contiguous(), w_out=ops.pack_weight(w_out), s_out=s_o.contiguous(), t_out=t_o.contiguous(),
+                           c0=w_in.shape[1], c1=w_in.shape[2], c2=w_out.shape[2]))
+        self._packed = pk
+
+    @torch.no_grad()
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices=None,
+                index=None):
+        if self.training:
+            raise NotImplementedError("the pooling module runs eval-mode (BatchNorm folded)")
+        if self._packed is None:
+            self._pack()
+        new_coords = new_coords[:, [0, 3, 2, 1]].contiguous()                 # (b,x,y,z) -> (b,z,y,x), l.84
+        n, m = features.shape[0], new_xyz.shape[0]
+        outs = []
+        for k, pk in enumerate(self._packed):
+            fin = ops.gather_conv(features, pk["c0"], pk["w_in"], None, 1, n, pk["c1"], pk["s_in"], pk["t_in"], None, False)
+            idx = torch.zeros((m, self.nsamples[k]), dtype=torch.int32, device=xyz.device)
+            zr, yr, xr = self.query_ranges[k]
+            if index is not None:
+                z, y, x = index.shape
+                check(lib().cpd_voxel_query_index(m, index.batch, z, y, x, self.nsamples[k], float(self.radii[k]), zr, yr, xr,
+                                                  ptr(new_xyz), ptr(xyz), ptr(new_coords), ptr(index.buf),
+                                                  0 if getattr(index, "canonical", True) else 1, n, ptr(idx), stream()),
+                      "cpd_voxel_query_index")
+            else:
+                b, z, y, x = voxel2point_indices.shape
+                check(lib().cpd_voxel_query(m, z, y, x, self.nsamples[k], float(self.radii[k]), zr, yr, xr, ptr(new_xyz), ptr(xyz),
+                                            ptr(new_coords), ptr(voxel2point_indices), ptr(idx), stream()), "cpd_voxel_query")
+            pooled = voxel_pool_max(fin, xyz, new_xyz, idx, pk["w_pos"], pk["b_pos"])
+            outs.append(ops.gather_conv(pooled, pk["c1"], pk["w_out"], None, 1, m, pk["c2"], pk["s_out"], pk["t_out"], None, True))
+        return torch.cat(outs, dim=1)
+
+
+def get_voxel_centers(voxel_coords_zyx, downsample_times, voxel_size, point_cloud_range):
+    """common_utils.get_voxel_centers (cpd/utils/common_utils.py:66-82)."""
+    centers = voxel_coords_zyx[:, [2, 1, 0]].float()
+    vs = torch.tensor(voxel_size, device=centers.device).float() * downsample_times
+    return (centers + 0.5) * vs + torch.tensor(point_cloud_range[0:3], device=centers.device).float()
+
+
+def get_global_grid_points_of_roi(rois, grid_size):
+    """voxel_rcnn_head.py:365-386: (B*N, G^3, 3) global grid points of each RoI (torch on the device)."""
+    rois = rois.view(-1, rois.shape[-1])
+    n = rois.shape[0]
+    dense_idx = rois.new_ones((grid_size, grid_size, grid_size)).nonzero().repeat(n, 1, 1).float()
+    size = rois[:, 3:6]
+    local = (dense_idx + 0.5) / grid_size * size.unsqueeze(1) - size.unsqueeze(1) / 2
+    ca, sa = torch.cos(rois[:, 6]), torch.sin(rois[:, 6])
+    zeros, ones = torch.zeros_like(ca), torch.ones_like(ca)
+    rot = torch.stack((ca, sa, zeros, -sa, ca, zeros, zeros, zeros, ones), dim=1).view(-1, 3, 3)   # rotate_points_along_z
+    return torch.matmul(local, rot) + rois[:, None, 0:3], local
+
+
+def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, point_cloud_range, batch_size, indexes=None):
+    """VoxelRCNNHead.roi_grid_pool (voxel_rcnn_head.py:186-273). `levels[name]` = (features, indices, shape) as
+    returned by CenterPointEngine.backbone3d; `pool_layers[name]` a NeighborVoxelSAModuleMSG; `indexes[name]`
+    an optional ops.SiteIndex of that level (otherwise the dense voxel2pinds volume is built).
+    Returns (B*N, G^3, sum C)."""
+    grid_xyz, _ = get_global_grid_points_of_roi(rois.clone(), grid_size)
+    grid_xyz = grid_xyz.view(batch_size, -1, 3)
+    gc = torch.cat([(grid_xyz[:, :, 0:1] - point_cloud_range[0]) // voxel_size[0],
+                    (grid_xyz[:, :, 1:2] - point_cloud_range[1]) // voxel_size[1],
+                    (grid_xyz[:, :, 2:3] - point_cloud_range[2]) // voxel_size[2]], dim=-1)
+    bidx = torch.arange(batch_size, device=rois.device, dtype=gc.dtype).view(-1, 1, 1).expand(-1, gc.shape[1], 1)
+    new_cnt = torch.full((batch_size,), gc.shape[1], dtype=torch.int32, device=rois.device)
+    pooled = []
+    for name, layer in pool_layers.items():
+        feats, coords, shape = levels[name]
+        stride = strides[name]
+        xyz = get_voxel_centers(coords[:, 1:4], stride, voxel_size, point_cloud_range).contiguous()
+        cnt = torch.bincount(coords[:, 0].long(), minlength=batch_size).int()
+        cur = torch.cat([bidx, gc // stride], dim=-1).int().contiguous().view(-1, 4)
+        index = indexes.get(name) if indexes else None
+        v2p = None if index is not None else generate_voxel2pinds(coords, batch_size, shape)
+        out = layer(xyz=xyz, xyz_batch_cnt=cnt, new_xyz=grid_xyz.contiguous().view(-1, 3), new_xyz_batch_cnt=new_cnt,
+                    new_coords=cur, features=feats.contiguous(), voxel2point_indices=v2p, index=index)
+        pooled.append(out.view(-1, grid_size ** 3, out.shape[-1]))
+    return torch.cat(pooled, dim=-1)

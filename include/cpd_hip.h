@@ -282,6 +282,43 @@ int cpd_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, cpd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * RoI-head feature pooling: the pointnet2_stack CUDA extension's voxel query and
+ * grouping (cpd/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp: voxel_query_wrapper,
+ * group_points_wrapper) and generate_voxel2pinds (cpd/utils/spconv_utils.py:4-21).
+ * ------------------------------------------------------------------------------------------ */
+/* Dense (B,Z,Y,X) int32 volume: row of the voxel in `indices` [n,4] (b,z,y,x), -1 = empty. */
+int cpd_voxel2pinds(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3],
+                    int32_t *out_volume, cpd_stream_t stream);
+/* voxel_query_wrapper (voxel_query_gpu.cu:10-87): for each of m query points (new_xyz [m,3],
+ * new_coords [m,4] = (b,z,y,x) voxel coordinates) scan the (2zr+1)(2yr+1)(2xr+1) neighbourhood in
+ * dz, dy, dx order and keep the first `nsample` voxels whose centre (xyz [N,3]) lies within
+ * `radius`; the first hit pre-fills all slots; no hit: idx[0] = -1 and the other slots are left
+ * as the caller initialised them (the reference zero-fills). idx [m, nsample] i32. */
+int cpd_voxel_query(int m, int r1, int r2, int r3, int nsample, float radius, int z_range, int y_range,
+                    int x_range, const float *new_xyz, const float *xyz, const int32_t *new_coords,
+                    const int32_t *point_indices, int32_t *idx, cpd_stream_t stream);
+/* Same query through a site index (cpd_index_build / cpd_conv_outset) of the sparse tensor instead
+ * of the dense volume. use_perm: 1 for indices built by cpd_index_build over an arbitrary-order
+ * site list of n_sites rows, 0 for canonical lists. */
+int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, int nsample, float radius,
+                          int z_range, int y_range, int x_range, const float *new_xyz, const float *xyz,
+                          const int32_t *new_coords, const void *index, int use_perm, int n_sites,
+                          int32_t *idx, cpd_stream_t stream);
+/* group_points_wrapper (group_points_gpu.cu:69-99): out[pt][c][s] = features[start(batch of pt) +
+ * idx[pt][s]][c]; *_batch_cnt are device int32[b]. out [m, c, nsample]. */
+int cpd_group_points(int b, int m, int c, int nsample, const float *features,
+                     const int32_t *features_batch_cnt, const int32_t *idx, const int32_t *idx_batch_cnt,
+                     float *out, cpd_stream_t stream);
+/* Fused grouping + position encoding + ReLU + max-pool of NeighborVoxelSAModuleMSG.forward
+ * (voxel_pool_modules.py:96-117): out[m][ch] = max_s relu(features_in[idx[m][s]][ch] +
+ * (xyz[idx[m][s]] - new_xyz[m]) . w_pos[:, ch] + b_pos[ch]), relu(b_pos[ch]) for an empty ball
+ * (idx[m][0] < 0). idx holds global rows; w_pos [3, c] / b_pos [c] = Conv2d(3, c) with its
+ * eval BatchNorm folded. */
+int cpd_voxel_pool_max(int m, int c, int nsample, const float *features_in, int features_ld,
+                       const float *xyz, const float *new_xyz, const int32_t *idx, const float *w_pos,
+                       const float *b_pos, float *out, int out_ld, cpd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,6 +180,36 @@ class Oracle:
                     "densify")
         return out
 
+    # ---- RoI-head pooling ----------------------------------------------------------
+    def voxel2pinds(self, indices, batch, shape):
+        indices = _i32(indices)
+        out = np.empty((batch, shape[0], shape[1], shape[2]), np.int32)
+        self._check(self.lib.cpd_ref_voxel2pinds(_ip(indices), indices.shape[0], batch, _arr3(shape), _ip(out)), "voxel2pinds")
+        return out
+
+    def voxel_query(self, max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+        """Raw kernel semantics: idx [M, nsample] i32 pre-zeroed, idx[:,0] = -1 for empty balls."""
+        xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+        new_coords, point_indices = _i32(new_coords), _i32(point_indices)
+        m = new_coords.shape[0]
+        b, z, y, x = point_indices.shape
+        idx = np.zeros((m, nsample), np.int32)
+        self._check(self.lib.cpd_ref_voxel_query(m, z, y, x, nsample, ctypes.c_float(radius), int(max_range[0]), int(max_range[1]),
+                                                 int(max_range[2]), _fp(new_xyz), _fp(xyz), _ip(new_coords), _ip(point_indices),
+                                                 _ip(idx)), "voxel_query")
+        return idx
+
+    def group_points(self, features, features_batch_cnt, idx, idx_batch_cnt):
+        features = _f32(features)
+        idx = _i32(idx)
+        fbc, ibc = _i32(features_batch_cnt), _i32(idx_batch_cnt)
+        m, ns = idx.shape
+        c = features.shape[1]
+        out = np.empty((m, c, ns), np.float32)
+        self._check(self.lib.cpd_ref_group_points(fbc.shape[0], m, c, ns, _fp(features), _ip(fbc), _ip(idx), _ip(ibc), _fp(out)),
+                    "group_points")
+        return out
+
     # ---- dense BEV convs ---------------------------------------------------------------------
     def conv2d(self, x, w, bias=None, stride=1, pad=1):
         x = _f32(x)

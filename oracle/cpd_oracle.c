@@ -675,3 +675,93 @@ int cpd_ref_nms(const float *boxes, int n, float thr, int64_t *keep, int32_t *nu
 int cpd_ref_nms_normal(const float *boxes, int n, float thr, int64_t *keep, int32_t *num_keep) {
     return nms_impl(boxes, n, thr, keep, num_keep, 1);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * RoI-head feature pooling. The reference implements these as CUDA kernels, which
+ * cannot be executed in a GPU-less container and cannot be compiled by gcc: PARITY OF THESE THREE
+ * FUNCTIONS IS UNPINNED BY EXECUTION; they restate the kernels statement by statement, and the
+ * Python layers around them (index shifting, empty-ball handling, MLPs, pooling) are pinned by
+ * running the reference's own voxel_pool_modules.py / voxel_query_utils.py on top of these
+ * functions (tests/golden/make_golden.py section 8).
+ * ------------------------------------------------------------------------------------------ */
+
+/* cpd/utils/spconv_utils.py:4-21 generate_voxel2pinds: dense (B,Z,Y,X) volume, -1 = empty,
+ * otherwise the row of the voxel in the sparse tensor. */
+int cpd_ref_voxel2pinds(const int32_t *indices, int n, int batch, const int32_t shape[3], int32_t *out) {
+    if (!indices || !out || n < 0 || batch <= 0) return CPD_ERR_ARG;
+    const long long cells = (long long)batch * shape[0] * shape[1] * shape[2];
+    for (long long i = 0; i < cells; ++i) out[i] = -1;
+    for (int i = 0; i < n; ++i) {
+        const int32_t *q = indices + 4 * (size_t)i;
+        out[(((long long)q[0] * shape[0] + q[1]) * shape[1] + q[2]) * shape[2] + q[3]] = i;
+    }
+    return CPD_OK;
+}
+
+/* cpd/ops/pointnet2/pointnet2_stack/src/voxel_query_gpu.cu:10-87 voxel_query_kernel_stack, one
+ * query point per iteration: scan the (2zr+1)(2yr+1)(2xr+1) neighbourhood of new_coords (b,z,y,x)
+ * in dz, dy, dx order, keep the first nsample voxels whose centre is within radius; the first hit
+ * pre-fills all slots; no hit -> idx[0] = -1 (the other slots keep the caller's initial zeros). */
+int cpd_ref_voxel_query(int m, int r1, int r2, int r3, int nsample, float radius, int z_range, int y_range,
+                        int x_range, const float *new_xyz, const float *xyz, const int32_t *new_coords,
+                        const int32_t *point_indices, int32_t *idx) {
+    if (!new_xyz || !xyz || !new_coords || !point_indices || !idx || m < 0 || nsample <= 0) return CPD_ERR_ARG;
+    const float radius2 = radius * radius;
+#pragma omp parallel for schedule(static)
+    for (int pt = 0; pt < m; ++pt) {
+        const float *nx = new_xyz + 3 * (size_t)pt;
+        const int32_t *nc = new_coords + 4 * (size_t)pt;
+        int32_t *o = idx + (size_t)pt * nsample;
+        const float new_x = nx[0], new_y = nx[1], new_z = nx[2];
+        const int b = nc[0], cz = nc[1], cy = nc[2], cx = nc[3];
+        int cnt = 0;
+        for (int dz = -z_range; dz <= z_range; ++dz) {
+            const int z = cz + dz;
+            if (z < 0 || z >= r1) continue;
+            for (int dy = -y_range; dy <= y_range; ++dy) {
+                const int y = cy + dy;
+                if (y < 0 || y >= r2) continue;
+                for (int dx = -x_range; dx <= x_range; ++dx) {
+                    const int x = cx + dx;
+                    if (x < 0 || x >= r3) continue;
+                    const long long cell = (((long long)b * r1 + z) * r2 + y) * r3 + x;
+                    const int32_t nb = point_indices[cell];
+                    if (nb < 0) continue;
+                    const float xp = xyz[3 * (size_t)nb], yp = xyz[3 * (size_t)nb + 1], zp = xyz[3 * (size_t)nb + 2];
+                    const float d2 = (xp - new_x) * (xp - new_x) + (yp - new_y) * (yp - new_y) + (zp - new_z) * (zp - new_z);
+                    if (d2 > radius2) continue;
+                    if (cnt < nsample) {
+                        if (cnt == 0)
+                            for (int l = 0; l < nsample; ++l) o[l] = nb;
+                        o[cnt] = nb;
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        if (cnt == 0) o[0] = -1;
+    }
+    return CPD_OK;
+}
+
+/* cpd/ops/pointnet2/pointnet2_stack/src/group_points_gpu.cu:69-99 group_points_kernel_stack:
+ * out[pt][c][s] = features[start(batch of pt) + idx[pt][s]][c]. */
+int cpd_ref_group_points(int b, int m, int c, int nsample, const float *features, const int32_t *features_batch_cnt,
+                         const int32_t *idx, const int32_t *idx_batch_cnt, float *out) {
+    if (!features || !features_batch_cnt || !idx || !idx_batch_cnt || !out || b <= 0) return CPD_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int pt = 0; pt < m; ++pt) {
+        int bs = 0, cnt = idx_batch_cnt[0];
+        for (int k = 1; k < b; ++k) {
+            if (pt < cnt) break;
+            cnt += idx_batch_cnt[k];
+            bs = k;
+        }
+        long long start = 0;
+        for (int k = 0; k < bs; ++k) start += features_batch_cnt[k];
+        for (int ci = 0; ci < c; ++ci)
+            for (int s = 0; s < nsample; ++s)
+                out[((size_t)pt * c + ci) * nsample + s] = features[(start + idx[(size_t)pt * nsample + s]) * c + ci];
+    }
+    return CPD_OK;
+}

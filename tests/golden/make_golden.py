@@ -310,6 +310,83 @@ def main():
                         ret_boxes=ret_boxes.numpy(), inds=inds.numpy(), mask=mask.numpy(), pred_hm=pred_hm.numpy(),
                         gt_hm=gt_hm.numpy(), focal=focal.numpy(), reg_out=reg_out.numpy(), reg_inds=reg_inds.numpy(),
                         reg_mask=reg_mask.numpy(), reg_tgt=reg_tgt.numpy(), reg_loss=regl.numpy())
+    # 8. RoI-head feature pooling: the reference's NeighborVoxelSAModuleMSG /
+    #    VoxelQueryAndGrouping / GroupingOperation Python (voxel_pool_modules.py, voxel_query_utils.py,
+    #    pointnet2_utils.py), get_global_grid_points_of_roi and get_voxel_centers, with the CUDA extension
+    #    pointnet2_stack_cuda replaced by the oracle's restatement of its two kernels (oracle/cpd_oracle.c;
+    #    those kernels themselves cannot be executed here) and torch.cuda.*Tensor mapped to CPU tensors.
+    sys.path.insert(0, REPO)
+    from oracle.binding import Oracle
+    orc = Oracle()
+    for pkg in ["r.ops.pointnet2", "r.ops.pointnet2.pointnet2_stack", "r.models.roi_heads"]:
+        _pkg(pkg)
+    ext = types.ModuleType("r.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda")
+
+    def voxel_query_wrapper(M, Z, Y, X, nsample, radius, zr, yr, xr, new_xyz, xyz, new_coords, point_indices, idx):
+        idx.copy_(torch.from_numpy(orc.voxel_query([zr, yr, xr], radius, nsample, xyz.numpy(), new_xyz.numpy(),
+                                                   new_coords.numpy(), point_indices.numpy())))
+
+    def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, output):
+        output.copy_(torch.from_numpy(orc.group_points(features.detach().numpy(), features_batch_cnt.numpy(), idx.numpy(),
+                                                       idx_batch_cnt.numpy())))
+
+    ext.voxel_query_wrapper, ext.group_points_wrapper = voxel_query_wrapper, group_points_wrapper
+    sys.modules[ext.__name__] = ext
+    sys.modules["r.ops.pointnet2.pointnet2_stack"].pointnet2_stack_cuda = ext
+    torch.cuda.IntTensor = lambda *sz: torch.zeros(*sz, dtype=torch.int32)
+    torch.cuda.FloatTensor = lambda *sz: torch.zeros(*sz, dtype=torch.float32)
+    pu = _load("r.ops.pointnet2.pointnet2_stack.pointnet2_utils", "cpd/ops/pointnet2/pointnet2_stack/pointnet2_utils.py")
+    sys.modules["r.ops.pointnet2.pointnet2_stack"].pointnet2_utils = pu
+    vq = _load("r.ops.pointnet2.pointnet2_stack.voxel_query_utils", "cpd/ops/pointnet2/pointnet2_stack/voxel_query_utils.py")
+    sys.modules["r.ops.pointnet2.pointnet2_stack"].voxel_query_utils = vq
+    vp = _load("r.ops.pointnet2.pointnet2_stack.voxel_pool_modules", "cpd/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py")
+
+    torch.manual_seed(21)
+    g = np.random.default_rng(21)
+    B, shape, stride = 2, [6, 40, 44], 4                      # an x_conv3-like level: (Z, Y, X), stride 4
+    vsz, pcr = [0.1, 0.1, 0.15], [-8.8, -8.0, -2.0, 8.8, 8.0, 1.6]
+    cells = np.unique(np.stack([g.integers(0, B, 2600), g.integers(0, shape[0], 2600), g.integers(0, shape[1], 2600),
+                                g.integers(0, shape[2], 2600)], 1), axis=0).astype(np.int32)       # canonical (b,z,y,x) order
+    feats = torch.randn(cells.shape[0], 16)
+    # voxel centres as voxel_rcnn_head.py:231-236 computes them (common_utils.get_voxel_centers, l.66-82)
+    vc = torch.from_numpy(cells[:, [3, 2, 1]].astype(np.float32))
+    xyz = (vc + 0.5) * (torch.tensor(vsz) * stride) + torch.tensor(pcr[:3])
+    xyz_cnt = torch.tensor([(cells[:, 0] == b).sum() for b in range(B)], dtype=torch.int32)
+    # rois and their 3x3x3 grid points (voxel_rcnn_head.py:365-386, common_utils.rotate_points_along_z)
+    rois = torch.tensor(np.concatenate([g.uniform(-6, 6, (B, 7, 2)), g.uniform(-1.2, 0.8, (B, 7, 1)),
+                                        g.uniform(1.0, 4.5, (B, 7, 3)), g.uniform(-3.1, 3.1, (B, 7, 1))], -1), dtype=torch.float32)
+    GS = 3
+    flat = rois.view(-1, 7)
+    dense_idx = torch.ones(GS, GS, GS).nonzero().repeat(flat.shape[0], 1, 1).float()
+    local = (dense_idx + 0.5) / GS * flat[:, None, 3:6] - flat[:, None, 3:6] / 2
+    ca, sa = torch.cos(flat[:, 6]), torch.sin(flat[:, 6])
+    rot = torch.stack([ca, sa, torch.zeros_like(ca), -sa, ca, torch.zeros_like(ca), torch.zeros_like(ca), torch.zeros_like(ca),
+                       torch.ones_like(ca)], 1).view(-1, 3, 3)
+    grid_xyz = (torch.matmul(local, rot) + flat[:, None, 0:3]).view(B, -1, 3)                      # (B, N*27, 3)
+    gc = torch.cat([(grid_xyz[..., 0:1] - pcr[0]) // vsz[0], (grid_xyz[..., 1:2] - pcr[1]) // vsz[1],
+                    (grid_xyz[..., 2:3] - pcr[2]) // vsz[2]], -1)                                  # l.207-211
+    bidx = torch.arange(B, dtype=torch.float32).view(B, 1, 1).expand(B, gc.shape[1], 1)
+    new_coords = torch.cat([bidx, gc // stride], -1).int().view(-1, 4)                             # l.243-245, (b, x, y, z)
+    new_cnt = torch.full((B,), gc.shape[1], dtype=torch.int32)
+    v2p = torch.from_numpy(orc.voxel2pinds(cells, B, shape))
+    mod = vp.NeighborVoxelSAModuleMSG(query_ranges=[[1, 2, 2], [2, 4, 4]], radii=[0.9, 1.7], nsamples=[8, 16],
+                                      mlps=[[16, 16, 24], [16, 16, 24]], pool_method="max_pool").eval()
+    for mm in mod.modules():
+        if isinstance(mm, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mm.weight.data.uniform_(0.6, 1.4); mm.bias.data.normal_(0, 0.2)
+            mm.running_mean.normal_(0, 0.2); mm.running_var.uniform_(0.6, 1.4)
+    with torch.no_grad():
+        pooled = mod(xyz=xyz.contiguous(), xyz_batch_cnt=xyz_cnt, new_xyz=grid_xyz.contiguous().view(-1, 3),
+                     new_xyz_batch_cnt=new_cnt, new_coords=new_coords.contiguous(), features=feats.contiguous(),
+                     voxel2point_indices=v2p)
+        raw_idx, empty = vq.voxel_query([1, 2, 2], 0.9, 8, xyz.contiguous(), grid_xyz.contiguous().view(-1, 3),
+                                        new_coords[:, [0, 3, 2, 1]].contiguous(), v2p)
+    d = {"sd." + k: v.numpy() for k, v in mod.state_dict().items()}
+    d.update(cells=cells, shape=np.array(shape), stride=stride, voxel_size=np.array(vsz, np.float32), pcr=np.array(pcr, np.float32),
+             feats=feats.numpy(), xyz=xyz.numpy(), rois=rois.numpy(), grid_size=GS, grid_xyz=grid_xyz.numpy(),
+             new_coords_bxyz=new_coords.numpy(), pooled=pooled.numpy(), query_idx=raw_idx.numpy(), query_empty=empty.numpy())
+    np.savez_compressed(os.path.join(HERE, "roi_pool.npz"), **d)
+    print("roi_pool: %d voxels, %d grid points, %d empty balls (range 0)" % (cells.shape[0], new_coords.shape[0], int(empty.sum())))
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -1,0 +1,121 @@
+"""RoI-head feature pooling: HIP kernels vs the oracle (bit-exact indices) and the fused
+pooling module vs the output of the reference's own Python module (fixture roi_pool.npz, <= 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rng, batch, shape, n_vox, n_query):
+    cells = np.unique(np.stack([rng.integers(0, batch, n_vox)] + [rng.integers(0, s, n_vox) for s in shape], 1), axis=0).astype(np.int32)
+    xyz = ((cells[:, [3, 2, 1]] + 0.5) * np.array([0.4, 0.4, 0.6]) + np.array([-3.0, -2.0, -1.0])).astype(np.float32)
+    q = np.stack([rng.integers(0, batch, n_query)] + [rng.integers(-1, s + 1, n_query) for s in shape], 1).astype(np.int32)
+    q[:, 1:] = np.clip(q[:, 1:], 0, np.array(shape) - 1)
+    q = q[np.argsort(q[:, 0], kind="stable")]
+    qxyz = ((q[:, [3, 2, 1]] + rng.uniform(0, 1, (n_query, 3))) * np.array([0.4, 0.4, 0.6]) + np.array([-3.0, -2.0, -1.0])).astype(np.float32)
+    return cells, np.ascontiguousarray(xyz), np.ascontiguousarray(q), np.ascontiguousarray(qxyz)
+
+
+@pytest.mark.parametrize("max_range,radius,nsample", [([1, 1, 1], 0.7, 4), ([2, 2, 2], 1.1, 16), ([1, 4, 4], 1.5, 16)])
+def test_voxel_query_dense_and_indexed_match_oracle(oracle, hip, max_range, radius, nsample):
+    from cpd_amd import ops, roi_pool
+    rng = np.random.default_rng(sum(max_range) + nsample)
+    batch, shape = 3, [7, 30, 34]
+    cells, xyz, q, qxyz = _scene(rng, batch, shape, 6000, 5003)
+    v2p = oracle.voxel2pinds(cells, batch, shape)
+    want = oracle.voxel_query(max_range, radius, nsample, xyz, qxyz, q, v2p)
+    d_cells, d_xyz, d_q, d_qxyz = (torch.from_numpy(a).cuda() for a in (cells, xyz, q, qxyz))
+    got_v2p = roi_pool.generate_voxel2pinds(d_cells, batch, shape)
+    np.testing.assert_array_equal(got_v2p.cpu().numpy(), v2p)
+    empty_want = want[:, 0] == -1
+    want[empty_want] = 0
+    idx, empty = roi_pool.voxel_query(max_range, radius, nsample, d_xyz, d_qxyz, d_q, point_indices=got_v2p)
+    np.testing.assert_array_equal(empty.cpu().numpy(), empty_want)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    index = ops.SiteIndex.build(d_cells, batch, shape)           # cells are in canonical order: rank == row
+    index.canonical = True
+    idx2, empty2 = roi_pool.voxel_query(max_range, radius, nsample, d_xyz, d_qxyz, d_q, index=index)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), want)
+    # arbitrary row order goes through the index permutation
+    perm = rng.permutation(cells.shape[0])
+    index_p = ops.SiteIndex.build(torch.from_numpy(cells[perm]).cuda(), batch, shape)
+    index_p.canonical = False
+    idx3, _ = roi_pool.voxel_query(max_range, radius, nsample, torch.from_numpy(xyz[perm]).cuda(), d_qxyz, d_q, index=index_p)
+    v2p_p = oracle.voxel2pinds(cells[perm], batch, shape)
+    want_p = oracle.voxel_query(max_range, radius, nsample, xyz[perm], qxyz, q, v2p_p)
+    want_p[want_p[:, 0] == -1] = 0
+    np.testing.assert_array_equal(idx3.cpu().numpy(), want_p)
+
+
+def test_group_points_matches_oracle(oracle, hip):
+    from cpd_amd import roi_pool
+    rng = np.random.default_rng(5)
+    feat = rng.normal(size=(900, 24)).astype(np.float32)
+    fcnt, icnt = np.array([400, 500], np.int32), np.array([130, 71], np.int32)
+    idx = np.concatenate([rng.integers(0, 400, (130, 16)), rng.integers(0, 500, (71, 16))]).astype(np.int32)
+    want = oracle.group_points(feat, fcnt, idx, icnt)
+    got = roi_pool.grouping_operation(torch.from_numpy(feat).cuda(), torch.from_numpy(fcnt).cuda(), torch.from_numpy(idx).cuda(),
+                                      torch.from_numpy(icnt).cuda())
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_pool_module_reproduces_reference_module_output(golden, hip):
+    """NeighborVoxelSAModuleMSG with the reference module's own state_dict, on the reference's inputs."""
+    from cpd_amd import ops, roi_pool
+    g = golden("roi_pool")
+    mod = roi_pool.NeighborVoxelSAModuleMSG(query_ranges=[[1, 2, 2], [2, 4, 4]], radii=[0.9, 1.7], nsamples=[8, 16],
+                                            mlps=[[16, 16, 24], [16, 16, 24]])
+    sd = {k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd.")}
+    mod.load_state_dict(sd)
+    mod = mod.cuda().eval()
+    cells = torch.from_numpy(g["cells"]).cuda()
+    shape = [int(v) for v in g["shape"]]
+    xyz = roi_pool.get_voxel_centers(cells[:, 1:4], int(g["stride"]), g["voxel_size"].tolist(), g["pcr"].tolist())
+    np.testing.assert_allclose(xyz.cpu().numpy(), g["xyz"], atol=1e-6)
+    rois = torch.from_numpy(g["rois"]).cuda()
+    grid, _ = roi_pool.get_global_grid_points_of_roi(rois, int(g["grid_size"]))
+    np.testing.assert_allclose(grid.view(2, -1, 3).cpu().numpy(), g["grid_xyz"], atol=1e-5)
+    new_xyz = torch.from_numpy(g["grid_xyz"]).cuda().view(-1, 3).contiguous()
+    nc = torch.from_numpy(g["new_coords_bxyz"]).cuda()
+    cnt = torch.bincount(cells[:, 0].long(), minlength=2).int()
+    new_cnt = torch.full((2,), new_xyz.shape[0] // 2, dtype=torch.int32, device="cuda")
+    feats = torch.from_numpy(g["feats"]).cuda()
+    v2p = roi_pool.generate_voxel2pinds(cells, 2, shape)
+    out = mod(xyz.contiguous(), cnt, new_xyz, new_cnt, nc, feats, voxel2point_indices=v2p)
+    np.testing.assert_allclose(out.cpu().numpy(), g["pooled"], atol=1e-4, rtol=0)
+    index = ops.SiteIndex.build(cells, 2, shape)
+    index.canonical = True
+    out2 = mod(xyz.contiguous(), cnt, new_xyz, new_cnt, nc, feats, index=index)
+    assert torch.equal(out, out2)
+
+
+def test_roi_grid_pool_on_engine_levels(hip):
+    """End to end on the hot path's own multi-scale features: detections -> RoI grid -> pooled (B*N, 216, 128)."""
+    from cpd_amd import ops, roi_pool
+    from cpd_amd.engine import CenterPointEngine, ModelConfig, init_state_dict
+    from cpd_amd.synthetic import waymo_cloud
+    cfg = ModelConfig()
+    eng = CenterPointEngine(cfg, init_state_dict(cfg, seed=0))
+    pts = [torch.from_numpy(waymo_cloud(i)).cuda() for i in range(2)]
+    res, it = eng.forward(pts, return_intermediates=True)
+    n_roi = 64
+    rois = torch.zeros((2, n_roi, 7), device="cuda")
+    for b in range(2):
+        k = min(n_roi, res[b]["pred_boxes"].shape[0])
+        rois[b, :k] = res[b]["pred_boxes"][:k]
+        rois[b, k:, 3:6] = 1.0
+    torch.manual_seed(0)
+    layers = {name: roi_pool.NeighborVoxelSAModuleMSG(query_ranges=[[2, 2, 2], [4, 4, 4]], radii=r, nsamples=[16, 16],
+                                                      mlps=[[c, 32, 32], [c, 32, 32]]).cuda().eval()
+              for name, r, c in (("x_conv3", [0.4, 0.8], 64), ("x_conv4", [0.8, 1.6], 128))}
+    strides = {"x_conv3": 4, "x_conv4": 8}
+    dense = roi_pool.roi_grid_pool(rois, it["levels"], strides, layers, 6, cfg.voxel_size, cfg.point_cloud_range, 2)
+    assert dense.shape == (2 * n_roi, 216, 128) and torch.isfinite(dense).all()
+    indexes = {}
+    for name in layers:
+        f, c, s = it["levels"][name]
+        indexes[name] = ops.SiteIndex.build(c, 2, s)
+        indexes[name].canonical = True
+    via_index = roi_pool.roi_grid_pool(rois, it["levels"], strides, layers, 6, cfg.voxel_size, cfg.point_cloud_range, 2, indexes=indexes)
+    assert torch.equal(dense, via_index)
