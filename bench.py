@@ -122,6 +122,81 @@ class ConvProfiler:
         return agg, total_ms
 
 
+class HbmStageProfiler:
+    """HIP-event timing of the HBM-bound stages with their ALGORITHMIC bytes: voxelizer + fused
+    MeanVFE, rulebook builds, the 5/16-channel sparse convs, densify. Reported next to the HBM roofline
+    (8 TB/s nominal, MI355X_MICROARCH.md); the matrix-bound conv kernels are `roofline` proper."""
+
+    def __init__(self):
+        self.rec = {}
+        self._undo = []
+
+    def _add(self, name, nbytes, e0, e1):
+        self.rec.setdefault(name, []).append((nbytes, e0, e1))
+
+    def _wrap(self, obj, attr, name, bytes_fn):
+        orig = getattr(obj, attr)
+        prof = self
+
+        def wrapped(*a, **kw):
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = orig(*a, **kw)
+            e1.record(s)
+            prof._add(name, (a, kw, out, bytes_fn), e0, e1)
+            return out
+
+        setattr(obj, attr, wrapped)
+        self._undo.append((obj, attr, orig))
+
+    def __enter__(self):
+        # 4*N*C read + 4*M*(C+4+1) write (M resolved after the run from the device counter)
+        self._wrap(ops.Voxelizer, "__call__", "voxelize+mean_vfe",
+                   lambda a, kw, out: 4.0 * a[1].shape[0] * a[1].shape[1] + 4.0 * float(out[4].item()) * (a[1].shape[1] + 5))
+        self._wrap(ops.Voxelizer, "batch", "voxelize+mean_vfe",
+                   lambda a, kw, out: sum(4.0 * p.shape[0] * p.shape[1] for p in a[1]) +
+                   4.0 * float(out[4][-1].item()) * (a[1][0].shape[1] + 5))
+        # rulebook: read 16*N_in, write the kv x N_out table (4 B per entry) + tap masks
+        self._wrap(ops, "rulebook_subm", "rulebook_subm", lambda a, kw, out: 16.0 * a[0].shape[0] + 4.0 * out.numel())
+        self._wrap(ops, "rulebook_conv", "rulebook_conv", lambda a, kw, out: 16.0 * a[0].shape[0] + 4.0 * out.numel())
+        self._wrap(ops, "densify_nhwc", "densify", lambda a, kw, out: 4.0 * a[0].numel() + 4.0 * out.numel())
+        orig = ops.gather_conv
+        prof = self
+
+        def conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
+            if c_in > 16 or kw.get("dense", False):
+                return orig(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = orig(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw)
+            e1.record(s)
+            pairs = int((nbr >= 0).sum().item()) if nbr is not None else n_out
+            nb = 4.0 * (inp.shape[0] * c_in + n_out * c_out) + 4.0 * kv * c_in * c_out + 8.0 * pairs
+            prof._add("sparse_conv_c<=16", (None, None, None, lambda *_: nb), e0, e1)
+            return out
+
+        ops.gather_conv = conv
+        self._undo.append((ops, "gather_conv", orig))
+        return self
+
+    def __exit__(self, *exc):
+        for obj, attr, orig in reversed(self._undo):
+            setattr(obj, attr, orig)
+
+    def summary(self, frames, peak_gbps=8000.0):
+        torch.cuda.synchronize()
+        out = {}
+        for name, items in self.rec.items():
+            nbytes = sum(fn(a, kw, o) for (a, kw, o, fn), _, _ in items)
+            ms = sum(e0.elapsed_time(e1) for _, e0, e1 in items)
+            out[name] = {"us_per_frame": 1e3 * ms / frames, "algorithmic_MB_per_frame": nbytes / frames / 1e6,
+                         "GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / peak_gbps,
+                         "launch_groups_per_frame": len(items) / frames}
+        return out
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_summary.json: 2 x FETCH_SIZE + WRITE_SIZE, per MI355X_MICROARCH.md), or None.
@@ -319,6 +394,13 @@ def main():
                                      "frac_of_its_peak": v[0] / (v[1] * 1e-3) / 1e12 / kernel_peak(k)[0]}
                                  for k, v in sorted(agg.items())},
         }
+
+    if not args.no_roofline:
+        with HbmStageProfiler() as hp:
+            run_steps(max(S, 2))
+            out["hbm_stages"] = hp.summary(max(S, 2) * B)
+        out["hbm_stages"]["note"] = ("algorithmic bytes (SURVEY 8d) / HIP-event time of each call (one call = all its launches), "
+                                     "single stream; peak = 8 TB/s nominal HBM3E")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, clouds_np[0])

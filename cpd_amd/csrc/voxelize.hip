@@ -204,6 +204,116 @@ __global__ void __launch_bounds__(256) vox_gather_kernel(const float *__restrict
     if (ch == 0) num_points[v] = cnt;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Batched voxelizer: all frames of a batch in ONE set of launches. Points are concatenated in frame
+// order, a cell key carries the frame (key = frame * cells + cell) and the occupancy bitmap spans
+// batch x grid; the first-appearance scan then runs over the concatenation, which keeps every
+// frame's serial order, and a per-frame base turns global ids into the per-frame voxel ids the
+// max_voxels cap applies to. Output rows are the frames' voxels back to back.
+// ------------------------------------------------------------------------------------------
+#define CPD_VOX_MAX_FRAMES 64
+struct FrameOffsets {
+    int32_t nf;
+    int32_t off[CPD_VOX_MAX_FRAMES + 1];
+    __device__ __forceinline__ int frame_of(int i) const {
+        int f = 0;
+        while (f + 1 < nf && i >= off[f + 1]) ++f;
+        return f;
+    }
+};
+
+__global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__restrict__ pts, int n, int c, VoxGeom geo,
+                                                             int32_t cells, FrameOffsets fo, int32_t *__restrict__ pkey,
+                                                             uint64_t *bitmap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pts + (size_t)i * c;
+    int32_t cz[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float f = floorf(__fdiv_rn(__fsub_rn(p[2 - j], geo.lo[2 - j]), geo.vs[2 - j]));
+        if (!(f >= 0.0f) || !(f < (float)geo.g[j])) ok = false;
+        cz[j] = ok ? (int32_t)f : 0;
+    }
+    int32_t key = -1;
+    if (ok) {
+        key = fo.frame_of(i) * cells + (cz[0] * geo.g[1] + cz[1]) * geo.g[2] + cz[2];
+        atomicOr((unsigned long long *)&bitmap[key >> 6], 1ull << (key & 63));
+    }
+    pkey[i] = key;
+}
+
+struct AssignGlobalFn {  // flagged point i starts the voxel with GLOBAL id = prefix; frame starts record their base
+    const int32_t *prank;
+    int32_t *gid;
+    int32_t *frame_base;
+    FrameOffsets fo;
+    __device__ void operator()(long long i, uint32_t flag, uint32_t prefix) const {
+        for (int f = 0; f < fo.nf; ++f)
+            if ((int32_t)i == fo.off[f]) frame_base[f] = (int32_t)prefix;   // empty frames share an offset: all get it
+        if (flag) gid[prank[i]] = (int32_t)prefix;
+    }
+};
+
+__global__ void vox_frames_kernel(FrameOffsets fo, int n, int max_voxels, int32_t *frame_base, const int32_t *total,
+                                  int32_t *out_base, int32_t *n_voxels) {
+    if (threadIdx.x != 0) return;
+    int32_t acc = 0;
+    for (int f = 0; f < fo.nf; ++f) {
+        if (fo.off[f] >= n) frame_base[f] = *total;               // frames that start past the last point
+        const int32_t next = (f + 1 < fo.nf && fo.off[f + 1] < n) ? frame_base[f + 1] : *total;
+        int32_t cnt = next - frame_base[f];
+        if (cnt > max_voxels) cnt = max_voxels;
+        out_base[f] = acc;
+        n_voxels[f] = cnt;
+        acc += cnt;
+    }
+    out_base[fo.nf] = acc;
+    n_voxels[fo.nf] = acc;
+}
+
+__global__ void __launch_bounds__(256) vox_assign_batch_kernel(int n, int32_t cells, FrameOffsets fo, int max_voxels,
+                                                               const int32_t *__restrict__ pkey,
+                                                               const int32_t *__restrict__ prank,
+                                                               const int32_t *__restrict__ first,
+                                                               const int32_t *__restrict__ frame_base,
+                                                               const int32_t *__restrict__ out_base, int32_t *vid,
+                                                               int32_t *coords, int32_t gy, int32_t gx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = prank[i];
+    if (r < 0 || first[r] != i) return;
+    const int f = fo.frame_of(i);
+    const int32_t local = vid[r] - frame_base[f];               // vid holds the global id until here
+    if (local >= max_voxels) { vid[r] = -1; return; }
+    const int32_t row = out_base[f] + local;
+    vid[r] = row;
+    const int32_t key = pkey[i] - f * cells;
+    int32_t *o = coords + (size_t)row * 4;
+    o[0] = f; o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
+}
+
+__global__ void __launch_bounds__(256) vox_insert_batch_kernel(int n, int P, const int32_t *__restrict__ prank,
+                                                               const int32_t *__restrict__ vid, int32_t *slots,
+                                                               int32_t *counts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = prank[i];
+    if (r < 0) return;
+    const int32_t v = vid[r];
+    if (v < 0) return;                                          // voxel beyond its frame's max_voxels
+    atomicAdd(&counts[v], 1);
+    int32_t x = i;
+    int32_t *s = slots + (size_t)v * P;
+    for (int p = 0; p < P; ++p) {
+        int32_t old = atomicMin(&s[p], x);
+        if (old == 0x7f7f7f7f) break;
+        x = old > x ? old : x;
+    }
+}
+
 }  // namespace
 
 static int vox_geom(const float vs[3], const float rg[6], VoxGeom *g, long long *cells) {
@@ -262,6 +372,81 @@ extern "C" int cpd_voxelize(const float *points, int n_points, int c, const floa
     vox_insert_kernel<<<nb, 256, 0, s>>>(n, max_points, max_voxels, w.prank, w.vid, w.slots, w.counts);
     const long long threads = (long long)cap * c;
     vox_gather_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(points, c, max_points, cap, n_voxels, w.slots, w.counts,
+                                                               voxels, num_points, mean_features);
+    return cpd_check_launch();
+}
+
+// ---- batched entry points ---------------------------------------------------------------------
+static int batch_caps(int n_total, int n_frames, int max_voxels, long long cells, int *cap) {
+    if (n_frames <= 0 || n_frames > CPD_VOX_MAX_FRAMES) return CPD_ERR_UNSUPPORTED;
+    if ((long long)n_frames * cells >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
+    long long c = (long long)n_frames * max_voxels;
+    *cap = (int)(c < n_total ? c : n_total);
+    return CPD_OK;
+}
+
+extern "C" size_t cpd_voxelize_batch_workspace_bytes(int n_total, int n_frames, int max_points, int max_voxels,
+                                                     const float vsize_xyz[3], const float range_xyz[6]) {
+    VoxGeom g;
+    long long cells;
+    int cap;
+    if (n_total < 0 || max_points <= 0 || max_voxels <= 0) return 0;
+    if (vox_geom(vsize_xyz, range_xyz, &g, &cells)) return 0;
+    if (batch_caps(n_total, n_frames, max_voxels, cells, &cap)) return 0;
+    return carve(nullptr, n_total, max_points, cap, (long long)n_frames * cells).bytes + cpd_align(2 * (CPD_VOX_MAX_FRAMES + 1) * 4 + 16);
+}
+
+extern "C" int cpd_voxelize_batch(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+                                  const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
+                                  float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
+                                  int32_t *n_voxels, void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
+    if (!frame_offsets || c < 3 || max_points <= 0 || max_voxels <= 0 || !coords || !num_points || !n_voxels || !workspace)
+        return CPD_ERR_ARG;
+    VoxGeom geo;
+    long long cells;
+    int rc = vox_geom(vsize_xyz, range_xyz, &geo, &cells);
+    if (rc) return rc;
+    if (n_frames <= 0 || n_frames > CPD_VOX_MAX_FRAMES) return CPD_ERR_UNSUPPORTED;
+    FrameOffsets fo;
+    fo.nf = n_frames;
+    for (int f = 0; f <= n_frames; ++f) {
+        fo.off[f] = frame_offsets[f];
+        if (frame_offsets[f] < 0 || (f > 0 && frame_offsets[f] < frame_offsets[f - 1])) return CPD_ERR_ARG;
+    }
+    if (frame_offsets[0] != 0) return CPD_ERR_ARG;
+    const int n = frame_offsets[n_frames];
+    if (n > 0 && !points) return CPD_ERR_ARG;
+    int cap;
+    rc = batch_caps(n, n_frames, max_voxels, cells, &cap);
+    if (rc) return rc;
+    hipStream_t s = cpd_s(stream);
+    VoxWs w = carve(workspace, n, max_points, cap, (long long)n_frames * cells);
+    if (workspace_bytes < w.bytes + cpd_align(2 * (CPD_VOX_MAX_FRAMES + 1) * 4 + 16)) return CPD_ERR_WORKSPACE;
+    int32_t *frame_base = (int32_t *)((char *)workspace + w.bytes);
+    int32_t *out_base = frame_base + CPD_VOX_MAX_FRAMES + 1;
+    int32_t *total = out_base + CPD_VOX_MAX_FRAMES + 1;
+    if (n == 0) {
+        CPD_HIP_TRY(hipMemsetAsync(n_voxels, 0, (size_t)(n_frames + 1) * 4, s));
+        return CPD_OK;
+    }
+    CPD_HIP_TRY(hipMemsetAsync(w.bitmap, 0, (size_t)w.words * 8, s));
+    CPD_HIP_TRY(hipMemsetAsync(w.first, 0x7f, (size_t)n * 4, s));
+    CPD_HIP_TRY(hipMemsetAsync(w.slots, 0x7f, (size_t)cap * max_points * 4, s));
+    CPD_HIP_TRY(hipMemsetAsync(w.counts, 0, (size_t)cap * 4, s));
+    CPD_HIP_TRY(hipMemsetAsync(frame_base, 0, (CPD_VOX_MAX_FRAMES + 1) * 4, s));
+    const int nb = cpd_div_up(n, 256);
+    vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, (int32_t)cells, fo, w.pkey, w.bitmap);
+    rc = device_scan(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
+    if (rc) return rc;
+    vox_first_kernel<<<nb, 256, 0, s>>>(n, w.pkey, w.bitmap, w.base, w.prank, w.first);
+    rc = device_scan(n, FlagFn{w.prank, w.first}, AssignGlobalFn{w.prank, w.vid, frame_base, fo}, w.bsum_pt, total, -1, s);
+    if (rc) return rc;
+    vox_frames_kernel<<<1, 64, 0, s>>>(fo, n, max_voxels, frame_base, total, out_base, n_voxels);
+    vox_assign_batch_kernel<<<nb, 256, 0, s>>>(n, (int32_t)cells, fo, max_voxels, w.pkey, w.prank, w.first, frame_base, out_base,
+                                               w.vid, coords, geo.g[1], geo.g[2]);
+    vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, w.vid, w.slots, w.counts);
+    const long long threads = (long long)cap * c;
+    vox_gather_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(points, c, max_points, cap, n_voxels + n_frames, w.slots, w.counts,
                                                                voxels, num_points, mean_features);
     return cpd_check_launch();
 }

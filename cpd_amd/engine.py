@@ -411,19 +411,21 @@ class CenterPointEngine:
         if isinstance(points_list, torch.Tensor):
             points_list = [points_list]
         batch = len(points_list)
-        outs = [self._voxelizers[b % len(self._voxelizers)](pts, batch_idx=b, coord_cols=4, want_voxels=False,
-                                                             want_mean=True, sync=False)
-                for b, pts in enumerate(points_list)] if batch <= len(self._voxelizers) else None
-        if outs is None:
-            while len(self._voxelizers) < batch:       # one workspace per in-flight frame of the batch
+        if batch > 1 and self.voxelizer.batch_supported(batch):
+            # one set of voxelizer launches for the whole batch; rows come out frame after frame
+            _, coords, _, feats, nvox = self.voxelizer.batch(points_list)
+            total = int(nvox[batch].item())                 # the one read-back
+            feats, coords = feats[:total], coords[:total]
+        else:
+            while len(self._voxelizers) < batch:           # one workspace per in-flight frame of the batch
                 self._voxelizers.append(ops.Voxelizer(self.cfg.voxel_size, self.cfg.point_cloud_range,
                                                       self.cfg.num_point_features, self.cfg.max_points_per_voxel,
                                                       self.cfg.max_voxels, device=self.device))
             outs = [self._voxelizers[b](pts, batch_idx=b, coord_cols=4, want_voxels=False, want_mean=True, sync=False)
                     for b, pts in enumerate(points_list)]
-        ms = torch.cat([o[4] for o in outs]).tolist() if batch > 1 else [int(outs[0][4].item())]   # one read-back
-        feats = torch.cat([o[3][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][3][:ms[0]]
-        coords = torch.cat([o[1][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][1][:ms[0]]
+            ms = torch.cat([o[4] for o in outs]).tolist() if batch > 1 else [int(outs[0][4].item())]   # one read-back
+            feats = torch.cat([o[3][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][3][:ms[0]]
+            coords = torch.cat([o[1][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][1][:ms[0]]
         levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch)
         d, h, w = out_shape
         dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])

@@ -38,6 +38,7 @@ class Voxelizer:
         self.device = torch.device(device)
         self.grid_zyx = voxel_grid_size(self.vs, self.rg)
         self._ws = None
+        self._wsb = None
         self._ws_n = -1
 
     def _workspace(self, n):
@@ -73,6 +74,41 @@ class Voxelizer:
         m = int(nvox.item())
         return (voxels[:m] if voxels is not None else None, coords[:m], num[:m],
                 mean[:m] if mean is not None else None, m)
+
+
+    def batch_supported(self, n_frames):
+        g = voxel_grid_size(self.vs, self.rg)
+        return 0 < n_frames <= 64 and n_frames * g[0] * g[1] * g[2] < (1 << 31)
+
+    def batch(self, points_list, want_voxels=False, want_mean=True):
+        """All frames in one set of launches (cpd_voxelize_batch). Returns capacity-sized device tensors
+        (voxels|None, coords [cap,4] (b,z,y,x), num_points, mean|None, n_voxels [B+1] = per frame + total);
+        rows of frame f follow those of frame f-1. No host synchronisation."""
+        for p in points_list:
+            _need_cuda(p, "points")
+        pts = torch.cat([p.contiguous() for p in points_list]) if len(points_list) > 1 else points_list[0].contiguous()
+        nf = len(points_list)
+        offs = [0]
+        for p in points_list:
+            offs.append(offs[-1] + p.shape[0])
+        n, c = pts.shape
+        assert c == self.c and pts.dtype == torch.float32
+        cap = max(1, min(self.max_voxels * nf, n))
+        dev = pts.device
+        voxels = torch.empty((cap, self.P, c), dtype=torch.float32, device=dev) if want_voxels else None
+        coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        num = torch.empty((cap,), dtype=torch.int32, device=dev)
+        mean = torch.empty((cap, c), dtype=torch.float32, device=dev) if want_mean else None
+        nvox = torch.zeros((nf + 1,), dtype=torch.int32, device=dev)
+        nbytes = lib().cpd_voxelize_batch_workspace_bytes(n, nf, self.P, self.max_voxels, farr(self.vs), farr(self.rg))
+        if nbytes == 0:
+            raise _lib.CpdHipError("cpd_voxelize_batch: unsupported batch (%d frames)" % nf)
+        if self._wsb is None or self._wsb.numel() < nbytes:
+            self._wsb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(lib().cpd_voxelize_batch(ptr(pts), iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
+                                       ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
+                                       self._wsb.numel(), stream()), "cpd_voxelize_batch")
+        return voxels, coords, num, mean, nvox
 
 
 # ---------------------------------------------------------------------------------------- B2

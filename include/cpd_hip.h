@@ -60,6 +60,21 @@ int cpd_voxelize(const float *points, int n_points, int c, const float vsize_xyz
                  float *mean_features, int32_t *n_voxels, void *workspace, size_t workspace_bytes,
                  cpd_stream_t stream);
 
+/* All frames of a batch in one set of launches. `points` [frame_offsets[n_frames], c] holds the
+ * frames back to back; `frame_offsets` is a HOST array [n_frames + 1] (frame f = rows
+ * [off[f], off[f+1])), n_frames <= 64. Per frame the result is exactly cpd_voxelize's (same
+ * first-appearance order, max_voxels cap, max_points per voxel); rows of frame f follow those of
+ * frame f-1, coords are always (b,z,y,x) with b = f. n_voxels: device int32 [n_frames + 1] =
+ * voxels per frame, then their sum. Outputs need min(n_frames*max_voxels, n_total) rows. */
+size_t cpd_voxelize_batch_workspace_bytes(int n_total, int n_frames, int max_points_per_voxel,
+                                          int max_voxels, const float vsize_xyz[3],
+                                          const float range_xyz[6]);
+int cpd_voxelize_batch(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+                       const float vsize_xyz[3], const float range_xyz[6], int max_points_per_voxel,
+                       int max_voxels, float *voxels, int32_t *coords, int32_t *num_points,
+                       float *mean_features, int32_t *n_voxels, void *workspace, size_t workspace_bytes,
+                       cpd_stream_t stream);
+
 /* ===== B2. Sparse convolution ==============================================================
  * Replaces [SPCONV] SparseConvTensor / SubMConv3d / SparseConv3d / .dense() as called from
  * cpd/models/backbones_3d/spconv_backbone.py:17-21,108-115,414-455,524-529 and

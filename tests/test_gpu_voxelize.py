@@ -75,3 +75,27 @@ def test_batch_column_and_voxel_boundaries(oracle, hip):
     check(oracle, pts, WAYMO)
     v, c, n, mean = run_hip(pts, WAYMO, coord_cols=4)
     assert c.shape[1] == 4 and (c[:, 0] == 3).all()
+
+
+@pytest.mark.parametrize("max_voxels", [1000000, 900])
+def test_batched_voxelizer_equals_per_frame(hip, max_voxels):
+    """cpd_voxelize_batch == cpd_voxelize frame by frame (itself bit-exact vs the oracle): same rows, same
+    order, same per-frame max_voxels cap, including an empty frame in the middle."""
+    import torch
+    from cpd_amd import ops
+    from cpd_amd.synthetic import WAYMO, waymo_cloud
+    vs, rg = WAYMO["voxel_size"], WAYMO["point_cloud_range"]
+    frames = [waymo_cloud(0, n_points=30000), waymo_cloud(1, n_points=1000)[:0], waymo_cloud(2, n_points=41000),
+              waymo_cloud(3, n_points=5)]
+    vox = ops.Voxelizer(vs, rg, 5, 5, max_voxels)
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    voxels, coords, num, mean, nvox = vox.batch(dev, want_voxels=True)
+    counts = nvox.cpu().numpy()
+    row = 0
+    for b, f in enumerate(dev):
+        v1, c1, n1, m1, k = vox(f, batch_idx=b, coord_cols=4, want_voxels=True, want_mean=True, sync=True)
+        assert counts[b] == k
+        assert torch.equal(coords[row:row + k], c1) and torch.equal(num[row:row + k], n1)
+        assert torch.equal(voxels[row:row + k], v1) and torch.equal(mean[row:row + k], m1)
+        row += k
+    assert counts[len(frames)] == row
