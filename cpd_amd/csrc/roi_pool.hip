@@ -143,7 +143,94 @@ __global__ void __launch_bounds__(256) voxel_pool_max_kernel(int m, int c, int n
     out[(size_t)pt * out_ld + ch] = best;
 }
 
+// ---- dataloader pre-filter --------------------------------------------------------
+struct RangeFlagFn {      // mask_points_by_range (common_utils.py:60-63): x, y inside the closed range
+    const float *pts;
+    int c;
+    float x0, y0, x1, y1;
+    __device__ uint32_t operator()(long long i) const {
+        const float x = pts[(size_t)i * c], y = pts[(size_t)i * c + 1];
+        return (x >= x0 && x <= x1 && y >= y0 && y <= y1) ? 1u : 0u;
+    }
+};
+struct CompactRowsFn {    // stable compaction: kept row i goes to row prefix
+    const float *pts;
+    float *out;
+    int c;
+    __device__ void operator()(long long i, uint32_t flag, uint32_t prefix) const {
+        if (!flag) return;
+        for (int k = 0; k < c; ++k) out[(size_t)prefix * c + k] = pts[(size_t)i * c + k];
+    }
+};
+
+// roiaware_pool3d_kernel.cu:23-35, 313-336: first box (in box order) whose z-extent and MARGIN-grown
+// rotated rectangle contain the point. One thread per point; the boxes of a sample sit in LDS.
+__global__ void __launch_bounds__(256) points_in_boxes_kernel(int boxes_num, int pts_num, const float *__restrict__ boxes,
+                                                              const float *__restrict__ pts, int pts_ld, float margin,
+                                                              int32_t *__restrict__ out) {
+    extern __shared__ float sbox[];            // per box: cx, cy, cz, dx/2 + margin, dy/2 + margin, dz/2, cos(-rz), sin(-rz)
+    const int b = blockIdx.y;
+    const float *bx = boxes + (size_t)b * boxes_num * 7;
+    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (pt < pts_num) {
+        const float *p = pts + ((size_t)b * pts_num + pt) * pts_ld;
+        x = p[0]; y = p[1]; z = p[2];
+    }
+    int32_t hit = -1;
+    for (int k0 = 0; k0 < boxes_num; k0 += 512) {
+        const int nk = min(512, boxes_num - k0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+            const float *q = bx + (size_t)(k0 + k) * 7;
+            float *o = sbox + 8 * k;
+            o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+            o[3] = (float)(q[3] / 2.0 + margin); o[4] = (float)(q[4] / 2.0 + margin); o[5] = (float)(q[5] / 2.0);
+            o[6] = cosf(-q[6]); o[7] = sinf(-q[6]);
+        }
+        __syncthreads();
+        if (hit < 0 && pt < pts_num) {
+            for (int k = 0; k < nk; ++k) {
+                const float *o = sbox + 8 * k;
+                if (fabsf(z - o[2]) > o[5]) continue;
+                const float sx = x - o[0], sy = y - o[1];
+                const float lx = __fadd_rn(__fmul_rn(sx, o[6]), __fmul_rn(sy, -o[7]));
+                const float ly = __fadd_rn(__fmul_rn(sx, o[7]), __fmul_rn(sy, o[6]));
+                if (fabsf(lx) < o[3] && fabsf(ly) < o[4]) { hit = k0 + k; break; }
+            }
+        }
+    }
+    if (pt < pts_num) out[(size_t)b * pts_num + pt] = hit;
+}
+
 }  // namespace
+
+extern "C" size_t cpd_mask_points_workspace_bytes(int n) {
+    return cpd_align((size_t)scan_num_blocks(n) * 4 + 16);
+}
+
+extern "C" int cpd_mask_points_by_range(const float *points, int n, int c, const float range_xyz[6], float *out,
+                                        int32_t *n_out, void *workspace, size_t workspace_bytes, cpd_stream_t st) {
+    if (n < 0 || c < 2 || !range_xyz || !n_out || !workspace || (n > 0 && (!points || !out))) return CPD_ERR_ARG;
+    if (workspace_bytes < cpd_mask_points_workspace_bytes(n)) return CPD_ERR_WORKSPACE;
+    if (n == 0) {
+        CPD_HIP_TRY(hipMemsetAsync(n_out, 0, 4, cpd_s(st)));
+        return CPD_OK;
+    }
+    return device_scan(n, RangeFlagFn{points, c, range_xyz[0], range_xyz[1], range_xyz[3], range_xyz[4]},
+                       CompactRowsFn{points, out, c}, (uint32_t *)workspace, n_out, -1, cpd_s(st));
+}
+
+extern "C" int cpd_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts, int pts_ld,
+                                   float margin, int32_t *box_idx_of_points, cpd_stream_t st) {
+    if (batch < 0 || boxes_num < 0 || pts_num < 0 || pts_ld < 3 || !box_idx_of_points ||
+        (batch * boxes_num > 0 && !boxes) || (batch * pts_num > 0 && !pts))
+        return CPD_ERR_ARG;
+    if (batch == 0 || pts_num == 0) return CPD_OK;
+    points_in_boxes_kernel<<<dim3(cpd_div_up(pts_num, 256), batch), 256, 512 * 8 * sizeof(float), cpd_s(st)>>>(
+        boxes_num, pts_num, boxes, pts, pts_ld, margin, box_idx_of_points);
+    return cpd_check_launch();
+}
 
 extern "C" int cpd_voxel2pinds(const int32_t *indices, int n, int batch, const int32_t shape[3], int32_t *out,
                                cpd_stream_t st) {

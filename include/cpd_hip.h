@@ -334,6 +334,21 @@ int cpd_voxel_pool_max(int m, int c, int nsample, const float *features_in, int 
                        const float *xyz, const float *new_xyz, const int32_t *idx, const float *w_pos,
                        const float *b_pos, float *out, int out_ld, cpd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dataloader pre-filter on the device.
+ * ------------------------------------------------------------------------------------------ */
+/* mask_points_by_range + boolean indexing (cpd/utils/common_utils.py:60-63,
+ * data_processor.py:84-85): keeps, in order, the rows of points [n, c] with range[0] <= x <= range[3]
+ * and range[1] <= y <= range[4]. out [n, c]; n_out device int32. */
+size_t cpd_mask_points_workspace_bytes(int n);
+int cpd_mask_points_by_range(const float *points, int n, int c, const float range_xyz[6], float *out,
+                             int32_t *n_out, void *workspace, size_t workspace_bytes, cpd_stream_t stream);
+/* points_in_boxes_gpu (roiaware_pool3d_kernel.cu:313-336; check_pt_in_box3d l.23-35 uses MARGIN
+ * 1e-5, the CPU twin roiaware_pool3d.cpp:128-140 1e-2): boxes [batch, boxes_num, 7], pts
+ * [batch, pts_num, pts_ld >= 3] -> box_idx_of_points [batch, pts_num] = first containing box or -1. */
+int cpd_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts,
+                        int pts_ld, float margin, int32_t *box_idx_of_points, cpd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,27 @@ def _farr(v):
     return (ctypes.c_float * len(v))(*[float(x) for x in v])
 
 
+_REF_ROIAWARE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libroiaware_ref.so")
+
+
+def load_reference_points_in_boxes():
+    """Returns f(boxes[N,7], pts[M,3]) -> mask[N,M] i32 backed by the reference's compiled
+    roiaware_pool3d.cpp (points_in_boxes_cpu, MARGIN 1e-2), or None when oracle/_ref has not been built."""
+    if not os.path.exists(_REF_ROIAWARE):
+        return None
+    import torch  # noqa: F401  (libtorch / libtorch_python must be loaded first)
+    lib = ctypes.CDLL(_REF_ROIAWARE, mode=os.RTLD_LAZY)    # its unused CUDA launchers stay unresolved
+
+    def f(boxes, pts):
+        boxes = np.ascontiguousarray(boxes, np.float32)
+        pts = np.ascontiguousarray(pts, np.float32)
+        out = np.zeros((boxes.shape[0], pts.shape[0]), np.int32)
+        lib.ref_points_in_boxes_cpu(_fp(boxes), boxes.shape[0], _fp(pts), pts.shape[0], _ip(out))
+        return out
+
+    return f
+
+
 class Oracle:
     """numpy-level wrappers around the C oracle. One method per C-ABI entry point of
     include/cpd_hip.h, same argument meaning, host arrays."""
@@ -208,6 +229,25 @@ class Oracle:
         out = np.empty((m, c, ns), np.float32)
         self._check(self.lib.cpd_ref_group_points(fbc.shape[0], m, c, ns, _fp(features), _ip(fbc), _ip(idx), _ip(ibc), _fp(out)),
                     "group_points")
+        return out
+
+    # ---- dataloader pre-filter -------------------------------------------------------
+    def mask_points_by_range(self, points, limit_range):
+        points = _f32(points)
+        out = np.empty_like(points)
+        n_out = ctypes.c_int32(0)
+        self._check(self.lib.cpd_ref_mask_points_by_range(_fp(points), points.shape[0], points.shape[1], _farr(limit_range),
+                                                          _fp(out), ctypes.byref(n_out)), "mask_points_by_range")
+        return out[:n_out.value]
+
+    def points_in_boxes(self, boxes, pts, margin=1e-5):
+        """boxes [B,N,7], pts [B,M,3] -> [B,M] i32 index of the first containing box or -1."""
+        boxes, pts = _f32(boxes), _f32(pts)
+        b, n, _ = boxes.shape
+        m = pts.shape[1]
+        out = np.empty((b, m), np.int32)
+        self._check(self.lib.cpd_ref_points_in_boxes(b, n, m, _fp(boxes), _fp(pts), ctypes.c_float(margin), _ip(out)),
+                    "points_in_boxes")
         return out
 
     # ---- dense BEV convs ---------------------------------------------------------------------

@@ -765,3 +765,55 @@ int cpd_ref_group_points(int b, int m, int c, int nsample, const float *features
     }
     return CPD_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Dataloader pre-filter.
+ * ------------------------------------------------------------------------------------------ */
+
+/* common_utils.mask_points_by_range (cpd/utils/common_utils.py:60-63) followed by the boolean
+ * indexing of DataProcessor.mask_points_and_boxes_outside_range (data_processor.py:84-85): keeps,
+ * in order, the points with range[0] <= x <= range[3] and range[1] <= y <= range[4]. */
+int cpd_ref_mask_points_by_range(const float *points, int n, int c, const float range[6], float *out, int32_t *n_out) {
+    if (!points || !out || !n_out || n < 0 || c < 2) return CPD_ERR_ARG;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const float x = points[(size_t)i * c], y = points[(size_t)i * c + 1];
+        if (x >= range[0] && x <= range[3] && y >= range[1] && y <= range[4]) {
+            memcpy(out + (size_t)m * c, points + (size_t)i * c, (size_t)c * sizeof(float));
+            ++m;
+        }
+    }
+    *n_out = m;
+    return CPD_OK;
+}
+
+/* roiaware_pool3d_kernel.cu:23-35 check_pt_in_box3d (MARGIN 1e-5) / roiaware_pool3d.cpp:121-140
+ * check_pt_in_box3d_cpu (MARGIN 1e-2): point inside the z-extent and inside the rotated xy
+ * rectangle grown by MARGIN. */
+static int ref_pt_in_box(const float *pt, const float *b, float margin) {
+    const float x = pt[0], y = pt[1], z = pt[2];
+    const float cx = b[0], cy = b[1], cz = b[2], dx = b[3], dy = b[4], dz = b[5], rz = b[6];
+    if (fabsf(z - cz) > dz / 2.0) return 0;
+    const float cosa = cosf(-rz), sina = sinf(-rz);
+    const float sx = x - cx, sy = y - cy;
+    const float lx = sx * cosa + sy * (-sina);
+    const float ly = sx * sina + sy * cosa;
+    return (fabs(lx) < dx / 2.0 + margin) & (fabs(ly) < dy / 2.0 + margin);
+}
+
+/* roiaware_pool3d_kernel.cu:313-336 points_in_boxes_kernel: index of the FIRST box (in box order)
+ * that contains the point, -1 if none. boxes [B, N, 7], pts [B, M, 3], out [B, M]. */
+int cpd_ref_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts,
+                            float margin, int32_t *box_idx_of_points) {
+    if (batch < 0 || boxes_num < 0 || pts_num < 0 || !box_idx_of_points) return CPD_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)batch * pts_num; ++i) {
+        const int b = (int)(i / pts_num);
+        const float *pt = pts + 3 * (size_t)i;
+        int32_t hit = -1;
+        for (int k = 0; k < boxes_num; ++k)
+            if (ref_pt_in_box(pt, boxes + ((size_t)b * boxes_num + k) * 7, margin)) { hit = k; break; }
+        box_idx_of_points[i] = hit;
+    }
+    return CPD_OK;
+}

@@ -1,0 +1,77 @@
+"""Dataloader pre-filter: oracle vs the reference's compiled points_in_boxes_cpu and numpy
+semantics on CPU; HIP kernels vs the oracle on the GPU."""
+import numpy as np
+import pytest
+
+
+def _boxes_pts(rng, nb, npt, span=20.0):
+    boxes = np.concatenate([rng.uniform(-span, span, (nb, 2)), rng.uniform(-1, 1, (nb, 1)), rng.uniform(1.0, 6.0, (nb, 3)),
+                            rng.uniform(-np.pi, np.pi, (nb, 1))], 1).astype(np.float32)
+    pts = np.concatenate([rng.uniform(-span, span, (npt, 2)), rng.uniform(-3, 3, (npt, 1))], 1).astype(np.float32)
+    # half of the points are drawn inside boxes so that hits are common
+    k = rng.integers(0, nb, npt // 2)
+    local = rng.uniform(-0.6, 0.6, (npt // 2, 3)) * boxes[k, 3:6]
+    c, s = np.cos(boxes[k, 6]), np.sin(boxes[k, 6])
+    pts[:npt // 2, 0] = boxes[k, 0] + local[:, 0] * c - local[:, 1] * s
+    pts[:npt // 2, 1] = boxes[k, 1] + local[:, 0] * s + local[:, 1] * c
+    pts[:npt // 2, 2] = boxes[k, 2] + local[:, 2]
+    return boxes, pts.astype(np.float32)
+
+
+def _not_borderline(boxes, pts, margin, tol=1e-4):
+    """points whose local coordinates are not within tol of any box face (float64 geometry)."""
+    ok = np.ones(pts.shape[0], bool)
+    for b in boxes.astype(np.float64):
+        sx, sy = pts[:, 0] - b[0], pts[:, 1] - b[1]
+        c, s = np.cos(-b[6]), np.sin(-b[6])
+        lx, ly = sx * c - sy * s, sx * s + sy * c
+        near = (np.abs(np.abs(lx) - (b[3] / 2 + margin)) < tol) | (np.abs(np.abs(ly) - (b[4] / 2 + margin)) < tol) | \
+               (np.abs(np.abs(pts[:, 2] - b[2]) - b[5] / 2) < tol)
+        ok &= ~near
+    return ok
+
+
+def test_oracle_points_in_boxes_matches_compiled_reference(oracle):
+    from oracle.binding import load_reference_points_in_boxes
+    ref = load_reference_points_in_boxes()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (make -C oracle ref; build container only)")
+    rng = np.random.default_rng(3)
+    boxes, pts = _boxes_pts(rng, 40, 4000)
+    mask = ref(boxes, pts)                                     # (N, M) 0/1, MARGIN 1e-2 (roiaware_pool3d.cpp:131)
+    first = np.where(mask.any(0), mask.argmax(0), -1).astype(np.int32)
+    got = oracle.points_in_boxes(boxes[None], pts[None], margin=1e-2)[0]
+    ok = _not_borderline(boxes, pts, 1e-2)
+    np.testing.assert_array_equal(got[ok], first[ok])
+    assert ok.mean() > 0.95 and (first >= 0).mean() > 0.3
+
+
+def test_oracle_mask_points_by_range_is_boolean_indexing(oracle):
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-90, 90, (5000, 5)).astype(np.float32)
+    rg = [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    m = (pts[:, 0] >= rg[0]) & (pts[:, 0] <= rg[3]) & (pts[:, 1] >= rg[1]) & (pts[:, 1] <= rg[4])
+    np.testing.assert_array_equal(oracle.mask_points_by_range(pts, rg), pts[m])
+
+
+@pytest.mark.gpu
+def test_hip_prefilter_matches_oracle(oracle, hip):
+    import torch
+    from cpd_amd import prefilter
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-90, 90, (200001, 5)).astype(np.float32)
+    rg = [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    got = prefilter.mask_points_by_range(torch.from_numpy(pts).cuda(), rg)
+    np.testing.assert_array_equal(got.cpu().numpy(), oracle.mask_points_by_range(pts, rg))
+    perm = torch.from_numpy(rng.permutation(pts.shape[0]))
+    np.testing.assert_array_equal(prefilter.shuffle_points(torch.from_numpy(pts).cuda(), perm).cpu().numpy(), pts[perm.numpy()])
+    B = 3
+    bp = [_boxes_pts(rng, 700, 30011) for _ in range(B)]       # > 512 boxes: two LDS chunks
+    boxes = np.stack([b for b, _ in bp]); p3 = np.stack([p for _, p in bp])
+    want = oracle.points_in_boxes(boxes, p3, margin=1e-5)
+    got = prefilter.points_in_boxes_gpu(torch.from_numpy(p3).cuda(), torch.from_numpy(boxes).cuda()).cpu().numpy()
+    for b in range(B):
+        ok = _not_borderline(boxes[b], p3[b], 1e-5)
+        np.testing.assert_array_equal(got[b][ok], want[b][ok])
+        assert ok.mean() > 0.9
+    assert (want >= 0).mean() > 0.3
