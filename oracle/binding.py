@@ -21,7 +21,8 @@ def build_oracle(force=False):
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
     ref_src = "/root/reference/cpd/ops/iou3d_nms/src/iou3d_cpu.cpp"
-    if os.path.exists(ref_src) and not os.path.exists(_REF):
+    ref_libs = [_REF, os.path.join(_HERE, "_ref", "libroiaware_ref.so")]
+    if os.path.exists(ref_src) and not all(os.path.exists(f) for f in ref_libs):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return _LIB
 
