@@ -482,7 +482,7 @@ class CenterPointTrainer:
 
     def optimizer_step(self):
         st = self.store
-        scale = dist_utils.reduce_gradients(st.grad, self.world, self.pg) if self.world > 1 else 1.0   # the one collective
+        scale = dist_utils.reduce_gradients(st.grad, self.world, self.pg)   # the one collective (no-op without a process group)
         if self.grad_clip:
             norm = float(st.grad.norm()) * scale                     # clip_grad_norm_, train_utils.py:43
             if norm > self.grad_clip:
