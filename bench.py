@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--layers", action="store_true", help="print a per-launch table of the conv kernels (stderr)")
     ap.add_argument("--conv-math", choices=["bf16x3", "f32"], default="bf16x3",
                     help="dense-layer arithmetic: split-bf16 x3 on the bf16 matrix pipe (fp32-level error) or fp32 MFMA")
+    ap.add_argument("--host-input", action="store_true", help="points start in pinned HOST memory: the H2D copies are inside "
+                    "the timed region (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE config 2 (the headline metric); train = config 3: forward + backward + "
                          "one RCCL gradient all-reduce + Adam, --frames (default 1) frames per GPU per step")
@@ -307,7 +309,11 @@ def main():
     B = args.frames
     torch.cuda.synchronize()
 
+    host_clouds = [torch.from_numpy(c).pin_memory() for c in clouds_np] if args.host_input else None
+
     def step(i, w=0):
+        if host_clouds is not None:      # boundary hands over host buffers: H2D inside the step
+            return engines[w].forward([host_clouds[(i * B + j) % POOL].cuda(non_blocking=True) for j in range(B)])
         return engines[w].forward([clouds[(i * B + j) % POOL] for j in range(B)])
 
     def run_steps(n):
@@ -348,7 +354,7 @@ def main():
         "metric": "frames/sec voxelize->sparse3D->BEV->NMS, 160k-pt Waymo cloud",
         "value": world * args.steps * B / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (inputs in pinned host memory, H2D timed)" if args.host_input else ""),
         "config": {"workload": "configs[1]: Waymo-shape %d-point cloud, CPD VoxelResBackBone8x + HeightCompression + "
                                "BaseBEVBackbone + CenterHead + rotated NMS, forward-only" % args.points,
                    "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
