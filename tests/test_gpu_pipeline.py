@@ -131,3 +131,28 @@ def test_module_api_matches_engine(oracle, hip):
     np.testing.assert_allclose(pred[0]["pred_boxes"].cpu().numpy(), res[0]["pred_boxes"].cpu().numpy(), atol=1e-3, rtol=1e-4)
     assert batch["spatial_features"].shape[1] == 256 and batch["encoded_spconv_tensor_stride"] == 8
     assert set(batch["multi_scale_3d_features"]) == {"x_conv1", "x_conv2", "x_conv3", "x_conv4"}
+
+
+def test_empty_ragged_and_out_of_range_inputs(hip):
+    """Edge cases of the batch contract: an empty cloud, a 5-point cloud and a cloud entirely outside the
+    range, alone and mixed into a batch; a frame's detections do not depend on its neighbours."""
+    cfg = ModelConfig()
+    eng = CenterPointEngine(cfg, init_state_dict(cfg, seed=0))
+    full = torch.from_numpy(waymo_cloud(0, n_points=40000)).cuda()
+    tiny, empty = full[:5].clone(), full[:0].clone()
+    outside = full.clone()
+    outside[:, 0] += 500.0
+    alone = eng.forward([full])[0]
+    for batch in ([full, empty, tiny], [outside, full], [tiny], [outside], [empty]):
+        res = eng.forward(batch)
+        assert len(res) == len(batch)
+        for r in res:
+            assert torch.isfinite(r["pred_boxes"]).all() and r["pred_boxes"].shape[0] <= cfg.nms_post_maxsize
+        for b, pts in enumerate(batch):
+            if pts is full:
+                assert res[b]["pred_boxes"].shape == alone["pred_boxes"].shape
+                d = (res[b]["pred_boxes"][:, None, :] - alone["pred_boxes"][None, :, :]).abs().amax(-1).amin(1)
+                assert float(d.max()) < 1e-3
+    # no voxels at all: every frame sees the all-zero BEV map, so an empty and an out-of-range cloud agree
+    a, b = eng.forward([empty])[0], eng.forward([outside])[0]
+    assert torch.equal(a["pred_boxes"], b["pred_boxes"])
