@@ -66,6 +66,10 @@ SIGNATURES = {
     "cpd_mask_points_workspace_bytes": (_SZ, [_I]),
     "cpd_mask_points_by_range": (_I, [_VP, _I, _I, _FP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_points_in_boxes": (_I, [_I, _I, _I, _VP, _VP, _I, _F, _VP, _VP]),
+    "cpd_nearest_bev_iou": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
+    "cpd_anchor_assign_workspace_bytes": (_SZ, [_I, _I]),
+    "cpd_anchor_assign": (_I, [_VP, _I, _VP, _I, _VP, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_anchor_decode": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP]),
     "cpd_voxel2pinds": (_I, [_VP, _I, _I, _I3, _VP, _VP]),
     "cpd_voxel_query": (_I, [_I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_voxel_query_index": (_I, [_I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),

@@ -1,0 +1,124 @@
+"""Anchor head pieces on the C-ABI kernels of csrc/roi_pool.hip. Mirrors
+
+  AnchorGenerator.generate_anchors            cpd/models/dense_heads/target_assigner/anchor_generator.py:18-62
+  box_utils.boxes3d_nearest_bev_iou           cpd/utils/box_utils.py:275-287
+  AxisAlignedTargetAssigner.assign_targets    cpd/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:46-243
+  AnchorHeadTemplate.generate_predicted_boxes cpd/models/dense_heads/anchor_head_template.py:336-383
+
+The assigner never materialises the anchors x GT IoU matrix: `cpd_anchor_assign` keeps the per-anchor
+max / argmax and the per-GT max on chip (212k anchors x 100 GT boxes would be 85 MB per sample and class)."""
+import torch
+
+from ._lib import check, lib, ptr, stream
+
+
+class AnchorGenerator:
+    def __init__(self, anchor_range, anchor_generator_config):
+        self.anchor_range = [float(v) for v in anchor_range]
+        self.anchor_sizes = [c["anchor_sizes"] for c in anchor_generator_config]
+        self.anchor_rotations = [c["anchor_rotations"] for c in anchor_generator_config]
+        self.anchor_heights = [c["anchor_bottom_heights"] for c in anchor_generator_config]
+        self.align_center = [c.get("align_center", False) for c in anchor_generator_config]
+        self.num_of_anchor_sets = len(self.anchor_sizes)
+
+    def generate_anchors(self, grid_sizes, device="cuda"):
+        """-> ([ (1, H, W, n_size, n_rot, 7) per class ], [anchors per location per class])."""
+        r = self.anchor_range
+        all_anchors, per_loc = [], []
+        for grid_size, sizes, rots, heights, center in zip(grid_sizes, self.anchor_sizes, self.anchor_rotations, self.anchor_heights,
+                                                           self.align_center):
+            per_loc.append(len(rots) * len(sizes) * len(heights))
+            if center:
+                xs, ys = (r[3] - r[0]) / grid_size[0], (r[4] - r[1]) / grid_size[1]
+                xo, yo = xs / 2, ys / 2
+            else:
+                xs, ys = (r[3] - r[0]) / (grid_size[0] - 1), (r[4] - r[1]) / (grid_size[1] - 1)
+                xo, yo = 0, 0
+            x = torch.arange(r[0] + xo, r[3] + 1e-5, step=xs, dtype=torch.float32, device=device)
+            y = torch.arange(r[1] + yo, r[4] + 1e-5, step=ys, dtype=torch.float32, device=device)
+            z = x.new_tensor(heights)
+            size, rot = x.new_tensor(sizes), x.new_tensor(rots)
+            gx, gy, gz = torch.meshgrid([x, y, z], indexing="ij")
+            a = torch.stack((gx, gy, gz), dim=-1)[:, :, :, None, :].repeat(1, 1, 1, size.shape[0], 1)
+            a = torch.cat((a, size.view(1, 1, 1, -1, 3).repeat([*a.shape[0:3], 1, 1])), dim=-1)
+            a = a[:, :, :, :, None, :].repeat(1, 1, 1, 1, rot.shape[0], 1)
+            a = torch.cat((a, rot.view(1, 1, 1, 1, -1, 1).repeat([*a.shape[0:3], size.shape[0], 1, 1])), dim=-1)
+            a = a.permute(2, 1, 0, 3, 4, 5).contiguous()
+            a[..., 2] += a[..., 5] / 2
+            all_anchors.append(a)
+        return all_anchors, per_loc
+
+
+def boxes3d_nearest_bev_iou(boxes_a, boxes_b):
+    a, b = boxes_a[:, :7].contiguous().float(), boxes_b[:, :7].contiguous().float()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(lib().cpd_nearest_bev_iou(ptr(a), a.shape[0], ptr(b), b.shape[0], ptr(out), stream()), "cpd_nearest_bev_iou")
+    return out
+
+
+def assign_targets_single(anchors, gt_boxes, gt_classes, matched_threshold=0.6, unmatched_threshold=0.45, norm_by_num_examples=False):
+    """anchors [N,7], gt_boxes [M,7], gt_classes [M] -> dict like the reference's assign_targets_single."""
+    anchors = anchors.contiguous().float()
+    gt = gt_boxes[:, :7].contiguous().float()
+    cls = gt_classes.int().contiguous()
+    n, m = anchors.shape[0], gt.shape[0]
+    dev = anchors.device
+    labels = torch.empty((n,), dtype=torch.int32, device=dev)
+    targets = torch.empty((n, 7), dtype=torch.float32, device=dev)
+    weights = torch.empty((n,), dtype=torch.float32, device=dev)
+    ious = torch.empty((n,), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib().cpd_anchor_assign_workspace_bytes(n, m),), dtype=torch.uint8, device=dev)
+    check(lib().cpd_anchor_assign(ptr(anchors), n, ptr(gt) if m else None, m, ptr(cls) if m else None, float(matched_threshold),
+                                  float(unmatched_threshold), int(bool(norm_by_num_examples)), ptr(labels), ptr(targets),
+                                  ptr(weights), ptr(ious), ptr(ws), ws.numel(), stream()), "cpd_anchor_assign")
+    return {"box_cls_labels": labels, "box_reg_targets": targets, "reg_weights": weights, "gt_ious": ious}
+
+
+class AxisAlignedTargetAssigner:
+    """assign_targets with the reference's output layout (use_multihead = False, match_height = False, no sampling)."""
+
+    def __init__(self, anchor_generator_cfg, class_names, norm_by_num_examples=False):
+        self.class_names = list(class_names)
+        self.anchor_class_names = [c["class_name"] for c in anchor_generator_cfg]
+        self.matched = {c["class_name"]: c["matched_threshold"] for c in anchor_generator_cfg}
+        self.unmatched = {c["class_name"]: c["unmatched_threshold"] for c in anchor_generator_cfg}
+        self.norm_by_num_examples = norm_by_num_examples
+
+    def assign_targets(self, all_anchors, gt_boxes_with_classes):
+        out = {"box_cls_labels": [], "box_reg_targets": [], "reg_weights": [], "gt_ious": []}
+        gt_classes = gt_boxes_with_classes[:, :, -1]
+        gt_boxes = gt_boxes_with_classes[:, :, :-1]
+        for k in range(gt_boxes_with_classes.shape[0]):
+            cur = gt_boxes[k]
+            nz = (cur.abs().sum(1) != 0).nonzero()                      # trailing all-zero rows are padding (l.66-69)
+            cnt = int(nz[-1]) + 1 if nz.numel() else 1
+            cur, cur_cls = cur[:cnt], gt_classes[k][:cnt].int()
+            per_class = []
+            for name, anchors in zip(self.anchor_class_names, all_anchors):
+                mask = torch.tensor([self.class_names[int(c) - 1] == name for c in cur_cls.tolist()], dtype=torch.bool,
+                                    device=cur.device)
+                fms = anchors.shape[:2]                                  # the reference's feature_map_size (l.92)
+                t = assign_targets_single(anchors.view(-1, anchors.shape[-1]), cur[mask], cur_cls[mask], self.matched[name],
+                                          self.unmatched[name], self.norm_by_num_examples)
+                per_class.append((t, fms))
+            out["box_reg_targets"].append(torch.cat([t["box_reg_targets"].view(*f, -1, 7) for t, f in per_class], dim=-2).view(-1, 7))
+            for key in ("box_cls_labels", "gt_ious", "reg_weights"):
+                out[key].append(torch.cat([t[key].view(*f, -1) for t, f in per_class], dim=-1).view(-1))
+        return {k: torch.stack(v, dim=0) for k, v in out.items()}
+
+
+def generate_predicted_boxes(anchors, batch_size, cls_preds, box_preds, dir_cls_preds=None, dir_offset=0.78539,
+                             dir_limit_offset=0.0, num_dir_bins=2):
+    """anchors: list of per-class anchor tensors (or one tensor); cls/box/dir preds (B, H, W, C*). Returns
+    (batch_cls_preds (B, N, num_class), batch_box_preds (B, N, 7))."""
+    if isinstance(anchors, list):
+        anchors = torch.cat(anchors, dim=-3)
+    a = anchors.reshape(-1, anchors.shape[-1]).contiguous().float()
+    n = a.shape[0]
+    bp = box_preds.reshape(batch_size, n, -1).contiguous().float()
+    assert bp.shape[-1] == 7
+    dc = dir_cls_preds.reshape(batch_size, n, -1).contiguous().float() if dir_cls_preds is not None else None
+    out = torch.empty_like(bp)
+    check(lib().cpd_anchor_decode(ptr(bp), ptr(a), ptr(dc), batch_size, n, dc.shape[-1] if dc is not None else 0, float(dir_offset),
+                                  float(dir_limit_offset), ptr(out), stream()), "cpd_anchor_decode")
+    return cls_preds.reshape(batch_size, n, -1).float(), out

@@ -1098,7 +1098,7 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
                                const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
                                const float *residual, int res_ld, int relu, float *out, int out_ld,
                                const int32_t *out_row_map, int out_col_group, int flags, cpd_stream_t stream) {
-    if (n_out == 0 && n_in >= 0) return CPD_OK;      // an empty site set is a valid (empty) result
+    if (n_out == 0 && n_in >= 0 && c_in > 0 && c_out > 0 && kv > 0) return CPD_OK;   // an empty site set is a valid (empty) result
     if (!in || !packed_w || !out || n_in < 0 || n_out < 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || in_ld < c_in ||
         (residual && res_ld < c_out) || (!nbr && kv != 1) || (tapmask && kv > 32) || out_col_group < 0 || (out_col_group > 0 && !out_row_map) ||
         out_ld < (out_col_group > 0 ? (out_col_group < c_out ? out_col_group : c_out) : c_out))

@@ -12,6 +12,12 @@
 // neighbours are found. With the bitmap index a cell test is one bit of an L2-resident word.
 #include "site_index_layout.h"
 
+// Several kernels below must reproduce fp32 torch arithmetic op for op (the anchor assigner compares IoUs
+// for exact equality; points_in_boxes decides on face distances): this file is compiled with
+// -ffp-contract=off (csrc/Makefile). Without OCML_BASIC_ROUNDED_OPERATIONS the __fmul_rn/__fadd_rn
+// intrinsics are plain operators and do not stop contraction, and `#pragma clang fp contract(off)` at file
+// scope was observed not to reach the inlined device helpers (fused area / limit_period ops in the ISA).
+
 namespace {
 
 __global__ void __launch_bounds__(256) v2p_scatter_kernel(const int32_t *__restrict__ idx, int n, Grid g, int32_t *__restrict__ out) {
@@ -203,7 +209,198 @@ __global__ void __launch_bounds__(256) points_in_boxes_kernel(int boxes_num, int
     if (pt < pts_num) out[(size_t)b * pts_num + pt] = hit;
 }
 
+// ---- anchor head -----------------------------------------------------------------
+// fp32 op-for-op restatement of box_utils.boxes3d_lidar_to_aligned_bev_boxes / boxes_iou_normal
+// (cpd/utils/box_utils.py:238-272): the assigner compares IoUs for exact equality, so nothing here
+// may be contracted or reassociated.
+// correctly rounded fp32 quotient: the double quotient of two floats rounds to the same float as the
+// exact quotient does (53 >= 2*24 + 2 bits), independent of how the compiler lowers a float division
+__device__ __forceinline__ float div_rn(float x, float y) { return (float)((double)x / (double)y); }
+__device__ __forceinline__ float limit_period_f(float val, float offset, float period) {
+    return __fsub_rn(val, __fmul_rn(floorf(__fadd_rn(div_rn(val, period), offset)), period));
+}
+__device__ __forceinline__ float4 aligned_bev(const float *b) {
+    const float rot = fabsf(limit_period_f(b[6], 0.5f, 3.14159265358979323846f));
+    const float quarter = (float)(3.14159265358979323846 / 4);
+    const float d0 = rot < quarter ? b[3] : b[4], d1 = rot < quarter ? b[4] : b[3];
+    return make_float4(__fsub_rn(b[0], div_rn(d0, 2.f)), __fsub_rn(b[1], div_rn(d1, 2.f)),
+                       __fadd_rn(b[0], div_rn(d0, 2.f)), __fadd_rn(b[1], div_rn(d1, 2.f)));
+}
+__device__ __forceinline__ float iou_normal(const float4 a, const float4 b) {
+    const float x_len = fmaxf(__fsub_rn(fminf(a.z, b.z), fmaxf(a.x, b.x)), 0.f);
+    const float y_len = fmaxf(__fsub_rn(fminf(a.w, b.w), fmaxf(a.y, b.y)), 0.f);
+    const float area_a = __fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y));
+    const float area_b = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+    const float inter = __fmul_rn(x_len, y_len);
+    return div_rn(inter, fmaxf(__fsub_rn(__fadd_rn(area_a, area_b), inter), 1e-6f));
+}
+
+__global__ void __launch_bounds__(256) nearest_bev_iou_kernel(const float *__restrict__ a, int n, const float *__restrict__ b, int m,
+                                                              float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * m) return;
+    const int ia = (int)(i / m), ib = (int)(i - (long long)ia * m);
+    out[i] = iou_normal(aligned_bev(a + 7 * (size_t)ia), aligned_bev(b + 7 * (size_t)ib));
+}
+
+// Pass 1 of the assigner: per anchor max / first argmax over the GT boxes (no n x m matrix in HBM), and the
+// per-GT maximum over anchors through an order-preserving atomicMax on the float bits (IoUs are >= 0).
+__global__ void __launch_bounds__(256) assign_pass1_kernel(const float *__restrict__ anchors, int n, const float *__restrict__ gt, int m,
+                                                           float *__restrict__ amax_iou, int32_t *__restrict__ amax_idx,
+                                                           int32_t *__restrict__ gmax_bits) {
+    extern __shared__ float4 sgt[];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) sgt[j] = aligned_bev(gt + 7 * (size_t)j);
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = aligned_bev(anchors + 7 * (size_t)i);
+    float best = -1.f;
+    int bj = 0;
+    for (int j = 0; j < m; ++j) {
+        const float v = iou_normal(a, sgt[j]);
+        if (v > best) { best = v; bj = j; }                       // first maximum, like numpy argmax
+        if (v > 0.f) atomicMax(&gmax_bits[j], __float_as_int(v));
+    }
+    amax_iou[i] = best;
+    amax_idx[i] = bj;
+}
+
+// Pass 2: force-match anchors that attain some GT's maximum (exact float equality, l.178), thresholds,
+// background, regression targets (ResidualCoder.encode_torch) -- axis_aligned_target_assigner.py:178-243
+// with POS_FRACTION < 0.
+__global__ void __launch_bounds__(256) assign_pass2_kernel(const float *__restrict__ anchors, int n, const float *__restrict__ gt, int m,
+                                                           const int32_t *__restrict__ gt_classes, float matched, float unmatched,
+                                                           const float *__restrict__ amax_iou, const int32_t *__restrict__ amax_idx,
+                                                           const int32_t *__restrict__ gmax_bits, int32_t *__restrict__ labels,
+                                                           float *__restrict__ targets, float *__restrict__ gt_ious,
+                                                           int32_t *__restrict__ n_examples) {
+    extern __shared__ float4 sgt[];
+    float *sgm = reinterpret_cast<float *>(sgt + m);
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        sgt[j] = aligned_bev(gt + 7 * (size_t)j);
+        const int bits = gmax_bits[j];
+        sgm[j] = bits == 0 ? -1.f : __int_as_float(bits);        // empty_gt_mask: a GT no anchor overlaps matches nothing
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *an = anchors + 7 * (size_t)i;
+    const float4 a = aligned_bev(an);
+    bool forced = false;
+    for (int j = 0; j < m && !forced; ++j) forced = iou_normal(a, sgt[j]) == sgm[j];
+    const float iou = amax_iou[i];
+    const int j = amax_idx[i];
+    int32_t lab = -1;
+    if (forced || iou >= matched) lab = gt_classes[j];
+    if (iou < unmatched) lab = 0;
+    if (forced) lab = gt_classes[j];
+    labels[i] = lab;
+    gt_ious[i] = iou;
+    float *o = targets + 7 * (size_t)i;
+    if (lab > 0) {
+        const float *g = gt + 7 * (size_t)j;
+        const float dxa = fmaxf(an[3], 1e-5f), dya = fmaxf(an[4], 1e-5f), dza = fmaxf(an[5], 1e-5f);
+        const float dxg = fmaxf(g[3], 1e-5f), dyg = fmaxf(g[4], 1e-5f), dzg = fmaxf(g[5], 1e-5f);
+        const float diag = sqrtf(__fadd_rn(__fmul_rn(dxa, dxa), __fmul_rn(dya, dya)));
+        o[0] = div_rn(__fsub_rn(g[0], an[0]), diag);
+        o[1] = div_rn(__fsub_rn(g[1], an[1]), diag);
+        o[2] = div_rn(__fsub_rn(g[2], an[2]), dza);
+        o[3] = logf(div_rn(dxg, dxa)); o[4] = logf(div_rn(dyg, dya)); o[5] = logf(div_rn(dzg, dza));
+        o[6] = __fsub_rn(g[6], an[6]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = 0.f;
+    }
+    if (lab >= 0) atomicAdd(n_examples, 1);
+}
+
+__global__ void __launch_bounds__(256) assign_weights_kernel(int n, const int32_t *__restrict__ labels, const int32_t *n_examples,
+                                                             int norm, float *__restrict__ w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ne = *n_examples;
+    w[i] = labels[i] > 0 ? (norm ? 1.0f / (float)(ne > 1 ? ne : 1) : 1.0f) : 0.f;
+}
+
+// ResidualCoder.decode_torch + direction classifier (anchor_head_template.py:363-376)
+__global__ void __launch_bounds__(256) anchor_decode_kernel(const float *__restrict__ box_preds, const float *__restrict__ anchors,
+                                                            const float *__restrict__ dir_cls, long long total, int n, int nbins,
+                                                            float dir_offset, float dir_limit_offset, float period,
+                                                            float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float *t = box_preds + 7 * (size_t)i, *a = anchors + 7 * (size_t)(i % n);
+    float *o = out + 7 * (size_t)i;
+    const float diag = sqrtf(__fadd_rn(__fmul_rn(a[3], a[3]), __fmul_rn(a[4], a[4])));
+    o[0] = __fadd_rn(__fmul_rn(t[0], diag), a[0]);
+    o[1] = __fadd_rn(__fmul_rn(t[1], diag), a[1]);
+    o[2] = __fadd_rn(__fmul_rn(t[2], a[5]), a[2]);
+    o[3] = __fmul_rn(expf(t[3]), a[3]); o[4] = __fmul_rn(expf(t[4]), a[4]); o[5] = __fmul_rn(expf(t[5]), a[5]);
+    float rg = __fadd_rn(t[6], a[6]);
+    if (dir_cls) {
+        const float *d = dir_cls + (size_t)i * nbins;
+        int lab = 0;
+        for (int k = 1; k < nbins; ++k)
+            if (d[k] > d[lab]) lab = k;
+        const float dir_rot = limit_period_f(__fsub_rn(rg, dir_offset), dir_limit_offset, period);
+        rg = __fadd_rn(__fadd_rn(dir_rot, dir_offset), __fmul_rn(period, (float)lab));
+    }
+    o[6] = rg;
+}
+
 }  // namespace
+
+extern "C" int cpd_nearest_bev_iou(const float *a, int n, const float *b, int m, float *out, cpd_stream_t st) {
+    if (n < 0 || m < 0 || ((long long)n * m > 0 && (!a || !b || !out))) return CPD_ERR_ARG;
+    if ((long long)n * m == 0) return CPD_OK;
+    nearest_bev_iou_kernel<<<cpd_div_up((long long)n * m, 256), 256, 0, cpd_s(st)>>>(a, n, b, m, out);
+    return cpd_check_launch();
+}
+
+extern "C" size_t cpd_anchor_assign_workspace_bytes(int n, int m) {
+    return cpd_align((size_t)(n > 0 ? n : 1) * 8) + cpd_align((size_t)(m > 0 ? m : 1) * 4 + 16);
+}
+
+extern "C" int cpd_anchor_assign(const float *anchors, int n, const float *gt, int m, const int32_t *gt_classes, float matched_thr,
+                                 float unmatched_thr, int norm_by_num_examples, int32_t *labels, float *bbox_targets,
+                                 float *reg_weights, float *gt_ious, void *workspace, size_t workspace_bytes, cpd_stream_t st) {
+    if (n < 0 || m < 0 || m > 2048 || !workspace || (n > 0 && (!anchors || !labels || !bbox_targets || !reg_weights || !gt_ious)) ||
+        (m > 0 && (!gt || !gt_classes)))
+        return CPD_ERR_ARG;
+    if (workspace_bytes < cpd_anchor_assign_workspace_bytes(n, m)) return CPD_ERR_WORKSPACE;
+    if (n == 0) return CPD_OK;
+    hipStream_t s = cpd_s(st);
+    if (m == 0) {                                              // no GT of this class: everything is background
+        CPD_HIP_TRY(hipMemsetAsync(labels, 0, (size_t)n * 4, s));
+        CPD_HIP_TRY(hipMemsetAsync(bbox_targets, 0, (size_t)n * 28, s));
+        CPD_HIP_TRY(hipMemsetAsync(reg_weights, 0, (size_t)n * 4, s));
+        CPD_HIP_TRY(hipMemsetAsync(gt_ious, 0, (size_t)n * 4, s));
+        return CPD_OK;
+    }
+    float *amax_iou = (float *)workspace;
+    int32_t *amax_idx = (int32_t *)(amax_iou + n);
+    int32_t *gmax_bits = (int32_t *)((char *)workspace + cpd_align((size_t)n * 8));
+    int32_t *n_examples = gmax_bits + m;
+    CPD_HIP_TRY(hipMemsetAsync(gmax_bits, 0, (size_t)(m + 1) * 4, s));
+    const int nb = cpd_div_up(n, 256);
+    assign_pass1_kernel<<<nb, 256, (size_t)m * 16, s>>>(anchors, n, gt, m, amax_iou, amax_idx, gmax_bits);
+    assign_pass2_kernel<<<nb, 256, (size_t)m * 20, s>>>(anchors, n, gt, m, gt_classes, matched_thr, unmatched_thr, amax_iou, amax_idx,
+                                                       gmax_bits, labels, bbox_targets, gt_ious, n_examples);
+    assign_weights_kernel<<<nb, 256, 0, s>>>(n, labels, n_examples, norm_by_num_examples, reg_weights);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_anchor_decode(const float *box_preds, const float *anchors, const float *dir_cls_preds, int batch, int n,
+                                 int num_dir_bins, float dir_offset, float dir_limit_offset, float *out, cpd_stream_t st) {
+    if (batch < 0 || n < 0 || ((long long)batch * n > 0 && (!box_preds || !anchors || !out)) || (dir_cls_preds && num_dir_bins <= 0))
+        return CPD_ERR_ARG;
+    const long long total = (long long)batch * n;
+    if (total == 0) return CPD_OK;
+    const float period = (float)(2 * 3.14159265358979323846 / (num_dir_bins > 0 ? num_dir_bins : 1));
+    anchor_decode_kernel<<<cpd_div_up(total, 256), 256, 0, cpd_s(st)>>>(box_preds, anchors, dir_cls_preds, total, n, num_dir_bins,
+                                                                       dir_offset, dir_limit_offset, period, out);
+    return cpd_check_launch();
+}
 
 extern "C" size_t cpd_mask_points_workspace_bytes(int n) {
     return cpd_align((size_t)scan_num_blocks(n) * 4 + 16);

@@ -349,6 +349,27 @@ int cpd_mask_points_by_range(const float *points, int n, int c, const float rang
 int cpd_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts,
                         int pts_ld, float margin, int32_t *box_idx_of_points, cpd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Anchor head: anchor_head_template.py / axis_aligned_target_assigner.py / box_utils.py.
+ * ------------------------------------------------------------------------------------------ */
+/* box_utils.boxes3d_nearest_bev_iou (box_utils.py:275-287): a [n,7], b [m,7] -> out [n,m]. */
+int cpd_nearest_bev_iou(const float *a, int n, const float *b, int m, float *out, cpd_stream_t stream);
+/* AxisAlignedTargetAssigner.assign_targets_single (axis_aligned_target_assigner.py:153-243) with
+ * match_height = False and POS_FRACTION < 0: per-anchor max/argmax IoU and per-GT max are computed
+ * without an n x m matrix in HBM. labels [n] (-1 ignore, 0 background, class id), bbox_targets [n,7]
+ * (ResidualCoder.encode_torch), reg_weights [n], gt_ious [n]; m <= 2048. */
+size_t cpd_anchor_assign_workspace_bytes(int n, int m);
+int cpd_anchor_assign(const float *anchors, int n, const float *gt_boxes, int m, const int32_t *gt_classes,
+                      float matched_threshold, float unmatched_threshold, int norm_by_num_examples,
+                      int32_t *labels, float *bbox_targets, float *reg_weights, float *gt_ious,
+                      void *workspace, size_t workspace_bytes, cpd_stream_t stream);
+/* AnchorHeadTemplate.generate_predicted_boxes (anchor_head_template.py:336-383): ResidualCoder
+ * decode of box_preds [batch,n,7] against anchors [n,7] plus the direction-classifier correction
+ * (dir_cls_preds [batch,n,num_dir_bins] or NULL). out [batch,n,7]. */
+int cpd_anchor_decode(const float *box_preds, const float *anchors, const float *dir_cls_preds, int batch,
+                      int n, int num_dir_bins, float dir_offset, float dir_limit_offset, float *out,
+                      cpd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,6 +251,42 @@ class Oracle:
                     "points_in_boxes")
         return out
 
+    # ---- anchor head ---------------------------------------------------------------
+    def nearest_bev_iou(self, a, b):
+        a, b = _f32(a), _f32(b)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        self._check(self.lib.cpd_ref_nearest_bev_iou(_fp(a), a.shape[0], _fp(b), b.shape[0], _fp(out)), "nearest_bev_iou")
+        return out
+
+    def residual_encode(self, boxes, anchors):
+        boxes, anchors = _f32(boxes), _f32(anchors)
+        out = np.empty((boxes.shape[0], 7), np.float32)
+        self._check(self.lib.cpd_ref_residual_encode(_fp(boxes), _fp(anchors), boxes.shape[0], _fp(out)), "residual_encode")
+        return out
+
+    def anchor_decode(self, box_preds, anchors, dir_cls=None, dir_offset=0.78539, dir_limit_offset=0.0):
+        box_preds, anchors = _f32(box_preds), _f32(anchors)
+        b, n, _ = box_preds.shape
+        out = np.empty((b, n, 7), np.float32)
+        d = _f32(dir_cls) if dir_cls is not None else None
+        self._check(self.lib.cpd_ref_anchor_decode(_fp(box_preds), _fp(anchors), _fp(d) if d is not None else None, b, n,
+                                                   d.shape[-1] if d is not None else 0, ctypes.c_float(dir_offset),
+                                                   ctypes.c_float(dir_limit_offset), _fp(out)), "anchor_decode")
+        return out
+
+    def anchor_assign(self, anchors, gt, gt_classes, matched, unmatched, norm_by_num_examples=False):
+        anchors, gt = _f32(anchors), _f32(gt).reshape(-1, 7)
+        cls = _i32(gt_classes)
+        n = anchors.shape[0]
+        labels = np.empty((n,), np.int32)
+        tgt = np.empty((n, 7), np.float32)
+        w = np.empty((n,), np.float32)
+        ious = np.empty((n,), np.float32)
+        self._check(self.lib.cpd_ref_anchor_assign(_fp(anchors), n, _fp(gt), gt.shape[0], _ip(cls), ctypes.c_float(matched),
+                                                   ctypes.c_float(unmatched), int(norm_by_num_examples), _ip(labels), _fp(tgt),
+                                                   _fp(w), _fp(ious)), "anchor_assign")
+        return labels, tgt, w, ious
+
     # ---- dense BEV convs ---------------------------------------------------------------------
     def conv2d(self, x, w, bias=None, stride=1, pad=1):
         x = _f32(x)

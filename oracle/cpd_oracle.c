@@ -817,3 +817,152 @@ int cpd_ref_points_in_boxes(int batch, int boxes_num, int pts_num, const float *
     }
     return CPD_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Anchor head: nearest-BEV IoU, ResidualCoder, target assignment, box decoding.
+ * All of it is plain torch in the reference (importable by file path), so every function here is
+ * pinned on goldens produced by the reference code itself (tests/golden/make_golden.py section 9).
+ * Arithmetic is kept op for op in fp32 (no contraction) because the assigner compares IoUs for
+ * exact equality (axis_aligned_target_assigner.py:178).
+ * ------------------------------------------------------------------------------------------ */
+static const float CPD_PI_F = 3.14159265358979323846f;
+
+/* common_utils.limit_period (cpd/utils/common_utils.py:17-20) in fp32 tensor arithmetic */
+static float ref_limit_period(float val, float offset, float period) {
+    return val - floorf(val / period + offset) * period;
+}
+
+/* box_utils.boxes3d_lidar_to_aligned_bev_boxes (cpd/utils/box_utils.py:261-272) */
+static void ref_aligned_bev(const float *b, float out[4]) {
+    const float rot = fabsf(ref_limit_period(b[6], 0.5f, CPD_PI_F));
+    const float quarter = (float)(3.14159265358979323846 / 4);
+    const float d0 = rot < quarter ? b[3] : b[4], d1 = rot < quarter ? b[4] : b[3];
+    out[0] = b[0] - d0 / 2; out[1] = b[1] - d1 / 2; out[2] = b[0] + d0 / 2; out[3] = b[1] + d1 / 2;
+}
+
+/* box_utils.boxes_iou_normal (l.238-258) on two aligned boxes */
+static float ref_iou_normal(const float a[4], const float b[4]) {
+    const float x_min = fmaxf(a[0], b[0]), x_max = fminf(a[2], b[2]);
+    const float y_min = fmaxf(a[1], b[1]), y_max = fminf(a[3], b[3]);
+    const float x_len = fmaxf(x_max - x_min, 0.f), y_len = fmaxf(y_max - y_min, 0.f);
+    const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
+    const float area_b = (b[2] - b[0]) * (b[3] - b[1]);
+    const float inter = x_len * y_len;
+    return inter / fmaxf(area_a + area_b - inter, 1e-6f);
+}
+
+/* box_utils.boxes3d_nearest_bev_iou (l.275-287): a [n,7], b [m,7] -> [n,m] */
+int cpd_ref_nearest_bev_iou(const float *a, int n, const float *b, int m, float *out) {
+    if (n < 0 || m < 0 || (n * m > 0 && (!a || !b || !out))) return CPD_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        float ba[4];
+        ref_aligned_bev(a + 7 * (size_t)i, ba);
+        for (int j = 0; j < m; ++j) {
+            float bb[4];
+            ref_aligned_bev(b + 7 * (size_t)j, bb);
+            out[(size_t)i * m + j] = ref_iou_normal(ba, bb);
+        }
+    }
+    return CPD_OK;
+}
+
+/* ResidualCoder.encode_torch / decode_torch (cpd/utils/box_coder_utils.py:13-45, 47-81), code size 7 */
+int cpd_ref_residual_encode(const float *boxes, const float *anchors, int n, float *out) {
+    if (n < 0 || (n > 0 && (!boxes || !anchors || !out))) return CPD_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        const float *g = boxes + 7 * (size_t)i, *a = anchors + 7 * (size_t)i;
+        float *o = out + 7 * (size_t)i;
+        const float dxa = fmaxf(a[3], 1e-5f), dya = fmaxf(a[4], 1e-5f), dza = fmaxf(a[5], 1e-5f);
+        const float dxg = fmaxf(g[3], 1e-5f), dyg = fmaxf(g[4], 1e-5f), dzg = fmaxf(g[5], 1e-5f);
+        const float diag = sqrtf(dxa * dxa + dya * dya);
+        o[0] = (g[0] - a[0]) / diag; o[1] = (g[1] - a[1]) / diag; o[2] = (g[2] - a[2]) / dza;
+        o[3] = logf(dxg / dxa); o[4] = logf(dyg / dya); o[5] = logf(dzg / dza);
+        o[6] = g[6] - a[6];
+    }
+    return CPD_OK;
+}
+
+/* AnchorHeadTemplate.generate_predicted_boxes (anchor_head_template.py:336-383): decode_torch against
+ * the anchors, then the direction-classifier correction (l.365-376). box_preds [b,n,7], anchors [n,7],
+ * dir_cls [b,n,nbins] or NULL. */
+int cpd_ref_anchor_decode(const float *box_preds, const float *anchors, const float *dir_cls, int batch, int n, int nbins,
+                          float dir_offset, float dir_limit_offset, float *out) {
+    if (batch < 0 || n < 0 || (batch * n > 0 && (!box_preds || !anchors || !out)) || (dir_cls && nbins <= 0)) return CPD_ERR_ARG;
+    const float period = (float)(2 * 3.14159265358979323846 / (nbins > 0 ? nbins : 1));
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)batch * n; ++i) {
+        const float *t = box_preds + 7 * (size_t)i, *a = anchors + 7 * (size_t)(i % n);
+        float *o = out + 7 * (size_t)i;
+        const float diag = sqrtf(a[3] * a[3] + a[4] * a[4]);
+        o[0] = t[0] * diag + a[0]; o[1] = t[1] * diag + a[1]; o[2] = t[2] * a[5] + a[2];
+        o[3] = expf(t[3]) * a[3]; o[4] = expf(t[4]) * a[4]; o[5] = expf(t[5]) * a[5];
+        float rg = t[6] + a[6];
+        if (dir_cls) {
+            const float *d = dir_cls + (size_t)i * nbins;
+            int lab = 0;
+            for (int k = 1; k < nbins; ++k)
+                if (d[k] > d[lab]) lab = k;                       /* torch.max: first maximum */
+            const float dir_rot = ref_limit_period(rg - dir_offset, dir_limit_offset, period);
+            rg = dir_rot + dir_offset + period * (float)lab;
+        }
+        o[6] = rg;
+    }
+    return CPD_OK;
+}
+
+/* AxisAlignedTargetAssigner.assign_targets_single (axis_aligned_target_assigner.py:153-243) with
+ * match_height = False (nearest-BEV IoU) and POS_FRACTION < 0 (no sampling, the shipped configs).
+ * labels [n] i32 (-1 ignore, 0 background, class id), bbox_targets [n,7], reg_weights [n], gt_ious [n]. */
+int cpd_ref_anchor_assign(const float *anchors, int n, const float *gt, int m, const int32_t *gt_classes,
+                          float matched_thr, float unmatched_thr, int norm_by_num_examples, int32_t *labels,
+                          float *bbox_targets, float *reg_weights, float *gt_ious) {
+    if (n < 0 || m < 0 || !labels || !bbox_targets || !reg_weights || !gt_ious || (n > 0 && !anchors) ||
+        (m > 0 && (!gt || !gt_classes)))
+        return CPD_ERR_ARG;
+    for (int i = 0; i < n; ++i) { labels[i] = -1; gt_ious[i] = 0.f; reg_weights[i] = 0.f; }
+    memset(bbox_targets, 0, (size_t)n * 7 * sizeof(float));
+    if (m == 0 || n == 0) {
+        for (int i = 0; i < n; ++i) labels[i] = 0;
+        return CPD_OK;
+    }
+    float *ov = (float *)malloc((size_t)n * m * sizeof(float));
+    int32_t *amax = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    float *gmax = (float *)malloc((size_t)m * sizeof(float));
+    char *forced = (char *)calloc((size_t)n, 1);
+    if (!ov || !amax || !gmax || !forced) { free(ov); free(amax); free(gmax); free(forced); return CPD_ERR_ALLOC; }
+    cpd_ref_nearest_bev_iou(anchors, n, gt, m, ov);
+    for (int i = 0; i < n; ++i) {                                   /* argmax(axis=1): first maximum */
+        int best = 0;
+        for (int j = 1; j < m; ++j)
+            if (ov[(size_t)i * m + j] > ov[(size_t)i * m + best]) best = j;
+        amax[i] = best;
+        gt_ious[i] = ov[(size_t)i * m + best];
+    }
+    for (int j = 0; j < m; ++j) {
+        float mx = ov[j];
+        for (int i = 1; i < n; ++i)
+            if (ov[(size_t)i * m + j] > mx) mx = ov[(size_t)i * m + j];
+        gmax[j] = mx == 0.f ? -1.f : mx;                            /* empty_gt_mask, l.175-176 */
+    }
+    for (int i = 0; i < n; ++i)                                     /* anchors_with_max_overlap, l.178 */
+        for (int j = 0; j < m; ++j)
+            if (ov[(size_t)i * m + j] == gmax[j]) { forced[i] = 1; break; }
+    for (int i = 0; i < n; ++i) {
+        if (forced[i]) labels[i] = gt_classes[amax[i]];
+        if (gt_ious[i] >= matched_thr) labels[i] = gt_classes[amax[i]];
+    }
+    for (int i = 0; i < n; ++i)                                     /* POS_FRACTION None branch, l.214-216 */
+        if (gt_ious[i] < unmatched_thr) labels[i] = 0;
+    for (int i = 0; i < n; ++i)
+        if (forced[i]) labels[i] = gt_classes[amax[i]];
+    int n_examples = 0;
+    for (int i = 0; i < n; ++i) n_examples += labels[i] >= 0;
+    for (int i = 0; i < n; ++i) {
+        if (labels[i] <= 0) continue;
+        cpd_ref_residual_encode(gt + 7 * (size_t)amax[i], anchors + 7 * (size_t)i, 1, bbox_targets + 7 * (size_t)i);
+        reg_weights[i] = norm_by_num_examples ? 1.0f / (float)(n_examples > 1 ? n_examples : 1) : 1.0f;
+    }
+    free(ov); free(amax); free(gmax); free(forced);
+    return CPD_OK;
+}

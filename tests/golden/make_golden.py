@@ -387,6 +387,98 @@ def main():
              new_coords_bxyz=new_coords.numpy(), pooled=pooled.numpy(), query_idx=raw_idx.numpy(), query_empty=empty.numpy())
     np.savez_compressed(os.path.join(HERE, "roi_pool.npz"), **d)
     print("roi_pool: %d voxels, %d grid points, %d empty balls (range 0)" % (cells.shape[0], new_coords.shape[0], int(empty.sum())))
+    # 9. Anchor head: the reference's own AnchorGenerator, ResidualCoder, box_utils nearest-BEV IoU,
+    #    AxisAlignedTargetAssigner.assign_targets and AnchorHeadTemplate.generate_predicted_boxes, all plain torch,
+    #    loaded by file path (Tensor.cuda() mapped to identity on this GPU-less box; match_height=False, so the
+    #    iou3d_nms stub is never called).
+    import types as _t
+    from types import SimpleNamespace
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for pkg in ["r.models.dense_heads.target_assigner"]:
+        _pkg(pkg)
+    cu = _load("r.utils.common_utils_real", "cpd/utils/common_utils.py") if False else None
+    common = _t.ModuleType("r.utils.common_utils")
+
+    def check_numpy_to_torch(x):
+        if isinstance(x, np.ndarray):
+            return torch.from_numpy(x).float(), True
+        return x, False
+
+    def limit_period(val, offset=0.5, period=np.pi):                   # cpd/utils/common_utils.py:17-20 verbatim semantics
+        val, is_numpy = check_numpy_to_torch(val)
+        ans = val - torch.floor(val / period + offset) * period
+        return ans.numpy() if is_numpy else ans
+
+    common.check_numpy_to_torch, common.limit_period = check_numpy_to_torch, limit_period
+    sys.modules["r.utils.common_utils"] = common
+    sys.modules["r.utils"].common_utils = common
+    for stub in ["r.ops.roiaware_pool3d", "r.ops.roiaware_pool3d.roiaware_pool3d_utils"]:
+        sys.modules[stub] = _t.ModuleType(stub)
+    sys.modules["r.ops"].roiaware_pool3d = sys.modules["r.ops.roiaware_pool3d"]
+    sys.modules["r.ops.roiaware_pool3d"].roiaware_pool3d_utils = sys.modules["r.ops.roiaware_pool3d.roiaware_pool3d_utils"]
+    sys.modules["scipy.spatial"] = __import__("scipy.spatial").spatial
+    bu = _load("r.utils.box_utils", "cpd/utils/box_utils.py")
+    sys.modules["r.utils"].box_utils = bu
+    bc = _load("r.utils.box_coder_utils", "cpd/utils/box_coder_utils.py")
+    ag = _load("r.models.dense_heads.target_assigner.anchor_generator",
+               "cpd/models/dense_heads/target_assigner/anchor_generator.py")
+    ta = _load("r.models.dense_heads.target_assigner.axis_aligned_target_assigner",
+               "cpd/models/dense_heads/target_assigner/axis_aligned_target_assigner.py")
+    g = np.random.default_rng(33)
+    torch.manual_seed(33)
+    pcr = np.array([-20.8, -20.8, -2.0, 20.8, 20.8, 4.0], np.float32)
+    agc = [AttrDict(class_name="Vehicle", anchor_sizes=[[4.7, 2.1, 1.7]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0],
+                    align_center=False, feature_map_stride=8, matched_threshold=0.55, unmatched_threshold=0.4),
+           AttrDict(class_name="Pedestrian", anchor_sizes=[[0.91, 0.86, 1.73]], anchor_rotations=[0, 1.57],
+                    anchor_bottom_heights=[0], align_center=False, feature_map_stride=8, matched_threshold=0.5,
+                    unmatched_threshold=0.35),
+           AttrDict(class_name="Cyclist", anchor_sizes=[[1.78, 0.84, 1.78]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0],
+                    align_center=False, feature_map_stride=8, matched_threshold=0.5, unmatched_threshold=0.35)]
+    H = W = 52
+    gen = ag.AnchorGenerator(anchor_range=pcr, anchor_generator_config=agc)
+    anchors_list, per_loc = gen.generate_anchors([[W, H]] * 3)            # each (1, H, W, 1, 2, 7)
+    coder = bc.ResidualCoder()
+    n_gt = 14
+    cls = g.integers(1, 4, (2, n_gt))
+    sizes = np.array([[4.7, 2.1, 1.7], [0.91, 0.86, 1.73], [1.78, 0.84, 1.78]])
+    gt = np.zeros((2, n_gt + 3, 8), np.float32)
+    for b in range(2):
+        for i in range(n_gt):
+            gt[b, i] = [g.uniform(-19, 19), g.uniform(-19, 19), g.uniform(-0.5, 0.5), *(sizes[cls[b, i] - 1] * g.uniform(0.85, 1.15, 3)),
+                        g.uniform(-3.1, 3.1), cls[b, i]]
+    cfg_ta = AttrDict(ANCHOR_GENERATOR_CONFIG=agc, TARGET_ASSIGNER_CONFIG=AttrDict(POS_FRACTION=-1.0, SAMPLE_SIZE=512,
+                      NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False))
+    assigner = ta.AxisAlignedTargetAssigner(model_cfg=cfg_ta, class_names=["Vehicle", "Pedestrian", "Cyclist"], box_coder=coder,
+                                            grid_size=np.array([416, 416, 40]), point_cloud_range=pcr, match_height=False)
+    tgt = assigner.assign_targets([a.clone() for a in anchors_list], torch.from_numpy(gt))
+    ious = bu.boxes3d_nearest_bev_iou(anchors_list[0].view(-1, 7)[::37], torch.from_numpy(gt[0, :n_gt, :7]))
+    enc = coder.encode_torch(torch.from_numpy(gt[0, :n_gt, :7]).clone(), anchors_list[0].view(-1, 7)[:n_gt].clone())
+    # generate_predicted_boxes as an unbound call (AnchorHeadTemplate needs .cuda() modules to construct)
+    for stub in ["r.models.model_utils.model_nms_utils"]:
+        pass
+    _load("r.models.dense_heads.target_assigner.atss_target_assigner",
+          "cpd/models/dense_heads/target_assigner/atss_target_assigner.py")
+    sys.modules["r.utils"].box_coder_utils = bc
+    odiou = _t.ModuleType("r.utils.odiou_loss")       # odiou_3D is only referenced by the loss path, never called here
+    odiou.odiou_3D = None
+    sys.modules["r.utils.odiou_loss"] = odiou
+    aht = _load("r.models.dense_heads.anchor_head_template", "cpd/models/dense_heads/anchor_head_template.py")
+    n_loc = H * W
+    n_anc = n_loc * 6
+    cls_preds = torch.randn(2, H, W, 6 * 3)
+    box_preds = torch.randn(2, H, W, 6 * 7) * 0.3
+    dir_preds = torch.randn(2, H, W, 6 * 2)
+    fake = SimpleNamespace(anchors=[a.clone() for a in anchors_list], use_multihead=False, box_coder=coder,
+                           model_cfg=AttrDict(DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2))
+    bcp, bbp = aht.AnchorHeadTemplate.generate_predicted_boxes(fake, 2, cls_preds, box_preds, dir_preds)
+    np.savez_compressed(os.path.join(HERE, "anchor_head.npz"), pcr=pcr, hw=np.array([H, W]),
+                        anchors=torch.cat(anchors_list, dim=-3).numpy(), anchors_per_class=torch.stack(anchors_list).numpy(),
+                        gt=gt, labels=tgt["box_cls_labels"].numpy(), reg_targets=tgt["box_reg_targets"].numpy(),
+                        reg_weights=tgt["reg_weights"].numpy(), gt_ious=tgt["gt_ious"].numpy(), iou_sample=ious.numpy(),
+                        enc=enc.numpy(), cls_preds=cls_preds.numpy(), box_preds=box_preds.numpy(), dir_preds=dir_preds.numpy(),
+                        decoded=bbp.numpy(), batch_cls=bcp.numpy())
+    print("anchor_head: %d anchors, %d positives, %d ignored" % (n_anc, int((tgt["box_cls_labels"] > 0).sum()),
+                                                                  int((tgt["box_cls_labels"] < 0).sum())))
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

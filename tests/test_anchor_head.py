@@ -1,0 +1,81 @@
+"""Anchor head: the oracle against goldens produced by the reference's own torch code (CPU), the
+HIP kernels against the oracle and the same goldens (GPU). Labels are exact; floats <= 1e-6 (same fp32 op order)."""
+import numpy as np
+import pytest
+
+CLASSES = ["Vehicle", "Pedestrian", "Cyclist"]
+THR = {"Vehicle": (0.55, 0.4), "Pedestrian": (0.5, 0.35), "Cyclist": (0.5, 0.35)}
+
+
+def _assemble(per_class, hw):
+    """reference layout: per class (1, H, W*2[, 7]) concatenated on the last (resp. -2) axis, then flattened"""
+    H, W = hw
+    lab = np.concatenate([t[0].reshape(1, H, -1) for t in per_class], -1).reshape(-1)
+    tgt = np.concatenate([t[1].reshape(1, H, -1, 7) for t in per_class], -2).reshape(-1, 7)
+    w = np.concatenate([t[2].reshape(1, H, -1) for t in per_class], -1).reshape(-1)
+    iou = np.concatenate([t[3].reshape(1, H, -1) for t in per_class], -1).reshape(-1)
+    return lab, tgt, w, iou
+
+
+def test_oracle_reproduces_reference_assigner_and_coders(oracle, golden):
+    g = golden("anchor_head")
+    hw = [int(v) for v in g["hw"]]
+    apc = g["anchors_per_class"]                                     # (3, 1, H, W, 1, 2, 7)
+    np.testing.assert_array_equal(oracle.nearest_bev_iou(apc[0].reshape(-1, 7)[::37], g["gt"][0, :14, :7]), g["iou_sample"])
+    np.testing.assert_allclose(oracle.residual_encode(g["gt"][0, :14, :7], apc[0].reshape(-1, 7)[:14]), g["enc"], rtol=0, atol=1e-6)
+    for b in range(2):
+        gt = g["gt"][b]
+        gt = gt[:np.nonzero(np.abs(gt).sum(1))[0][-1] + 1]
+        per_class = []
+        for ci, name in enumerate(CLASSES):
+            sel = gt[gt[:, 7].astype(int) == ci + 1]
+            per_class.append(oracle.anchor_assign(apc[ci].reshape(-1, 7), sel[:, :7], sel[:, 7].astype(np.int32), *THR[name]))
+        lab, tgt, w, iou = _assemble(per_class, hw)
+        np.testing.assert_array_equal(lab, g["labels"][b])
+        np.testing.assert_array_equal(iou, g["gt_ious"][b])
+        np.testing.assert_array_equal(w, g["reg_weights"][b])
+        np.testing.assert_allclose(tgt, g["reg_targets"][b], rtol=0, atol=1e-6)
+    anchors = np.concatenate(list(apc), axis=-3).reshape(-1, 7)       # torch.cat(self.anchors, dim=-3), l.354
+    dec = oracle.anchor_decode(g["box_preds"].reshape(2, -1, 7), anchors, g["dir_preds"].reshape(2, -1, 2))
+    np.testing.assert_allclose(dec, g["decoded"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_anchor_head_matches_reference_goldens(oracle, golden, hip):
+    import torch
+    from cpd_amd import anchor_head as ah
+    g = golden("anchor_head")
+    H, W = [int(v) for v in g["hw"]]
+    cfgs = [dict(class_name="Vehicle", anchor_sizes=[[4.7, 2.1, 1.7]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0],
+                 matched_threshold=0.55, unmatched_threshold=0.4),
+            dict(class_name="Pedestrian", anchor_sizes=[[0.91, 0.86, 1.73]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0],
+                 matched_threshold=0.5, unmatched_threshold=0.35),
+            dict(class_name="Cyclist", anchor_sizes=[[1.78, 0.84, 1.78]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0],
+                 matched_threshold=0.5, unmatched_threshold=0.35)]
+    anchors, per_loc = ah.AnchorGenerator(g["pcr"].tolist(), cfgs).generate_anchors([[W, H]] * 3)
+    assert per_loc == [2, 2, 2]
+    np.testing.assert_allclose(torch.stack(anchors).cpu().numpy(), g["anchors_per_class"], rtol=0, atol=1e-5)
+    anchors = [torch.from_numpy(a).cuda() for a in g["anchors_per_class"]]          # the reference's exact anchors from here on
+    iou = ah.boxes3d_nearest_bev_iou(anchors[0].view(-1, 7)[::37], torch.from_numpy(g["gt"][0, :14, :7]).cuda())
+    np.testing.assert_array_equal(iou.cpu().numpy(), g["iou_sample"])
+    tgt = ah.AxisAlignedTargetAssigner(cfgs, CLASSES).assign_targets(anchors, torch.from_numpy(g["gt"]).cuda())
+    np.testing.assert_array_equal(tgt["box_cls_labels"].cpu().numpy(), g["labels"])
+    np.testing.assert_array_equal(tgt["gt_ious"].cpu().numpy(), g["gt_ious"])
+    np.testing.assert_array_equal(tgt["reg_weights"].cpu().numpy(), g["reg_weights"])
+    np.testing.assert_allclose(tgt["box_reg_targets"].cpu().numpy(), g["reg_targets"], rtol=0, atol=2e-6)
+    cls, dec = ah.generate_predicted_boxes(anchors, 2, torch.from_numpy(g["cls_preds"]).cuda(), torch.from_numpy(g["box_preds"]).cuda(),
+                                           torch.from_numpy(g["dir_preds"]).cuda())
+    np.testing.assert_allclose(dec.cpu().numpy(), g["decoded"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(cls.cpu().numpy(), g["batch_cls"])
+    # a Waymo-size assignment (212k anchors per class x 60 GT) against the oracle, incl. a class without GT
+    rng = np.random.default_rng(1)
+    big = ah.AnchorGenerator([-75.2, -75.2, -2, 75.2, 75.2, 4], cfgs[:1]).generate_anchors([[188, 188]])[0][0].view(-1, 7)
+    gt = np.concatenate([rng.uniform(-70, 70, (60, 2)), rng.uniform(-1, 1, (60, 1)), np.array([4.7, 2.1, 1.7]) * rng.uniform(0.8, 1.2, (60, 3)),
+                         rng.uniform(-3.1, 3.1, (60, 1))], 1).astype(np.float32)
+    want = oracle.anchor_assign(big.cpu().numpy(), gt, np.ones(60, np.int32), 0.55, 0.4)
+    got = ah.assign_targets_single(big, torch.from_numpy(gt).cuda(), torch.ones(60, dtype=torch.int32).cuda(), 0.55, 0.4)
+    np.testing.assert_array_equal(got["box_cls_labels"].cpu().numpy(), want[0])
+    np.testing.assert_array_equal(got["gt_ious"].cpu().numpy(), want[3])
+    np.testing.assert_allclose(got["box_reg_targets"].cpu().numpy(), want[1], rtol=0, atol=2e-6)
+    none = ah.assign_targets_single(big, torch.zeros((0, 7)).cuda(), torch.zeros((0,), dtype=torch.int32).cuda(), 0.55, 0.4)
+    assert int(none["box_cls_labels"].abs().sum()) == 0 and float(none["reg_weights"].sum()) == 0.0
