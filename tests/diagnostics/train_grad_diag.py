@@ -1,7 +1,7 @@
 """Diagnostic: per-tensor gradient error of the HIP trainer and of a torch-fp32 run of the same
 reference graph, both against the float64 reference (small config)."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 import ref_train_torch as R

@@ -1,7 +1,7 @@
 """Debug: inside a real train step, check every layer's BatchNorm backward and weight gradient
 against torch formulas evaluated on the same saved tensors (GPU, fp64)."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from test_gpu_train import small_cfg, scene
