@@ -193,3 +193,30 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
                     new_coords=cur, features=feats.contiguous(), voxel2point_indices=v2p, index=index)
         pooled.append(out.view(-1, grid_size ** 3, out.shape[-1]))
     return torch.cat(pooled, dim=-1)
+
+
+def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize, nms_post_maxsize):
+    """RoIHeadTemplate.proposal_layer (cpd/models/roi_heads/roi_head_template.py:53-114) for dense
+    (B, N, 7+C) / (B, N, num_class) predictions with class-agnostic rotated NMS
+    (model_nms_utils.class_agnostic_nms, l.115-134): per sample max class score -> top NMS_PRE_MAXSIZE ->
+    rotated NMS -> first NMS_POST_MAXSIZE. All samples go through ONE batched mask / scan / select launch set
+    (cpd_nms_batch, cpd_select_boxes); nothing is read back. Returns (rois [B, post, 7+C], roi_scores [B, post],
+    roi_labels [B, post] i64 = argmax class + 1); slots past a sample's kept count are zero like the reference's
+    new_zeros buffers."""
+    b, n, cdim = batch_box_preds.shape
+    scores, labels = torch.max(batch_cls_preds, dim=-1)                       # l.94
+    k = min(int(nms_pre_maxsize), n)
+    top_scores, order = torch.topk(scores, k=k, dim=1)                        # class_agnostic_nms l.124 (sorted descending)
+    boxes = torch.gather(batch_box_preds, 1, order.unsqueeze(-1).expand(-1, -1, cdim)).contiguous()
+    counts = torch.full((b,), k, dtype=torch.int32, device=boxes.device)
+    keep, num_keep = ops.nms_batch(boxes[:, :, :7].contiguous(), counts, nms_thresh)
+    top_labels = torch.gather(labels, 1, order).int().contiguous()
+    rois7, roi_scores, roi_labels, kept = ops.select_boxes(boxes[:, :, :7].contiguous(), top_scores.contiguous(), top_labels, keep,
+                                                           num_keep, int(nms_post_maxsize), label_offset=1)
+    valid = torch.arange(int(nms_post_maxsize), device=boxes.device)[None, :] < kept[:, None]
+    rois7 = rois7 * valid[..., None]
+    roi_scores = roi_scores * valid
+    roi_labels = roi_labels * valid                                            # the reference adds 1 to every slot (l.111)
+    if cdim > 7:
+        raise NotImplementedError("7+C box codes (velocity ...) are not used by the CPD configs")
+    return rois7, roi_scores, roi_labels, kept

@@ -119,3 +119,26 @@ def test_roi_grid_pool_on_engine_levels(hip):
         indexes[name].canonical = True
     via_index = roi_pool.roi_grid_pool(rois, it["levels"], strides, layers, 6, cfg.voxel_size, cfg.point_cloud_range, 2, indexes=indexes)
     assert torch.equal(dense, via_index)
+
+
+def test_proposal_layer_matches_reference_nms_golden(golden, hip):
+    """proposal_layer = per-sample max class score + class_agnostic_nms; checked on the reference's own
+    class_agnostic_nms fixture (tests/golden/nms.npz) replicated into a batch with different class layouts."""
+    from cpd_amd import roi_pool
+    g = golden("nms")
+    boxes, scores, want = g["n500_t3.boxes"], g["n500_t3.scores"], g["n500_t3.selected"]
+    thr, pre, post = float(g["n500_t3.thr"]), 4096, 500                # make_golden.py: NMS_PRE_MAXSIZE 4096, NMS_POST_MAXSIZE 500
+    n = boxes.shape[0]
+    cls = np.full((2, n, 3), -5.0, np.float32)
+    cls[0, :, 1] = scores                                          # sample 0: everything is class 2
+    cls[1, np.arange(n), np.arange(n) % 3] = scores                # sample 1: classes cycle
+    bb = np.stack([boxes, boxes]).astype(np.float32)
+    rois, rs, rl, kept = roi_pool.proposal_layer(torch.from_numpy(bb).cuda(), torch.from_numpy(cls).cuda(), thr, pre, post)
+    k = len(want)
+    assert kept.tolist() == [k, k]
+    for b in range(2):
+        np.testing.assert_array_equal(rois[b, :k].cpu().numpy(), boxes[want])
+        np.testing.assert_array_equal(rs[b, :k].cpu().numpy(), scores[want])
+        assert float(rois[b, k:].abs().sum()) == 0.0
+    assert (rl[0, :k] == 2).all()
+    np.testing.assert_array_equal(rl[1, :k].cpu().numpy(), want % 3 + 1)
