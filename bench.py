@@ -305,7 +305,8 @@ def main():
     rank, world, local = dist_utils.env_rank()
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    distributed = dist_utils.init("nccl", torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+    # "nccl" is RCCL on ROCm; CPD_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests
+    distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"), torch.device("cuda", local))
 
     cfg = ModelConfig(conv_math=args.conv_math)
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
