@@ -1027,6 +1027,12 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
             pl.use_wg = 2; pl.a = 128; pl.b = bn;
             return pl;
         }
+        long long min64 = 256;                              // 64-row tiles when 128-row tiling would leave CUs idle
+        if (const char *e = getenv("CPD_GC_BF16_MIN64")) min64 = atoll(e);
+        if ((long long)((n_out + 63) / 64) * (c_out / bn) >= min64) {
+            pl.use_wg = 2; pl.a = 64; pl.b = bn;
+            return pl;
+        }
     }
     int force_wg = -1;
     if (const char *e = getenv("CPD_GC_WG")) force_wg = atoi(e);
@@ -1129,6 +1135,12 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
         int db = 0;
         if (const char *e = getenv("CPD_GC_BF16_DB")) db = atoi(e);
         if (pl.b == 64) db = 0;
+        if (pl.a == 64) {                                   // small-problem variant: 64-row tiles double the workgroup count
+            const size_t lds64 = 3 * (size_t)(64 + pl.b) * 64;
+            if (pl.b == 128) hipLaunchKernelGGL((tile_conv_bf16_kernel<64, 128, false>), dim3(p.items), dim3(256), lds64, cpd_s(stream), p);
+            else hipLaunchKernelGGL((tile_conv_bf16_kernel<64, 64, false>), dim3(p.items), dim3(256), lds64, cpd_s(stream), p);
+            return cpd_check_launch();
+        }
         const size_t lds = (db ? 2 : 1) * 3 * (size_t)(pl.a + pl.b) * 64;
         static bool attr_set = false;
         if (!attr_set) {
