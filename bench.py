@@ -409,7 +409,7 @@ def main():
             "note": "per-launch figures measured with %d concurrent stream(s): a launch shares the chip with the other "
                     "streams' kernels, so chip-level MFMA use is chip_conv_tflops, not achieved" % S,
             "chip_conv_tflops": conv_flops * out["value"] / world / 1e12,
-            "chip_conv_frac": conv_flops * out["value"] / world / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "chip_conv_over_fp32_mfma_peak": conv_flops * out["value"] / world / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "algorithmic_conv_gflop_per_frame": conv_flops / 1e9,
             "all_conv_kernels": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_frame": v[1] / (n_prof * B),
                                      "launches_per_frame": v[2] / (n_prof * B),
