@@ -122,3 +122,61 @@ def generate_predicted_boxes(anchors, batch_size, cls_preds, box_preds, dir_cls_
     check(lib().cpd_anchor_decode(ptr(bp), ptr(a), ptr(dc), batch_size, n, dc.shape[-1] if dc is not None else 0, float(dir_offset),
                                   float(dir_limit_offset), ptr(out), stream()), "cpd_anchor_decode")
     return cls_preds.reshape(batch_size, n, -1).float(), out
+
+
+class AnchorHeadSingle(torch.nn.Module):
+    """Inference path of AnchorHeadSingle (cpd/models/dense_heads/anchor_head_single.py:194-356): occupancy anchor
+    mask, the 1x1 conv_cls / conv_box / conv_dir_cls (cpd_gather_conv through cpd_amd.models.Conv2d; state_dict
+    names as in the reference), masked anchors, generate_predicted_boxes (cpd_anchor_decode)."""
+
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, **kwargs):
+        super().__init__()
+        from .models import Conv2d
+        self.model_cfg, self.num_class, self.class_names = model_cfg, num_class, list(class_names)
+        self.range = [float(v) for v in point_cloud_range]
+        self.voxel_size = (self.range[3] - self.range[0]) / float(grid_size[0])
+        agc = model_cfg["ANCHOR_GENERATOR_CONFIG"]
+        fms = [[int(grid_size[0]) // c["feature_map_stride"], int(grid_size[1]) // c["feature_map_stride"]] for c in agc]
+        self._gen = (AnchorGenerator(self.range, agc), fms)
+        self.anchors_root = None                                     # built on the first forward (device known then)
+        per_loc = sum(len(c["anchor_rotations"]) * len(c["anchor_sizes"]) * len(c["anchor_bottom_heights"]) for c in agc)
+        self.num_anchors_per_location = per_loc
+        self.conv_cls = Conv2d(input_channels, per_loc * num_class, kernel_size=1)
+        self.conv_box = Conv2d(input_channels, per_loc * 7, kernel_size=1)
+        self.num_dir_bins = model_cfg.get("NUM_DIR_BINS", 2)
+        self.conv_dir_cls = Conv2d(input_channels, per_loc * self.num_dir_bins, kernel_size=1) \
+            if model_cfg.get("USE_DIRECTION_CLASSIFIER", None) is not None else None
+
+    def get_anchor_mask(self, points, shape):
+        """l.238-278: BEV cells within +-10 cells of a coarse (x10) cell that contains a point. The reference builds
+        the index list in numpy and relies on torch indexing, negative indices wrapping around included."""
+        h, w = shape[-2], shape[-1]
+        stride = float(torch.round(torch.tensor(self.voxel_size * 8.0 * 10.0)))
+        dev = points.device
+        in_x = ((points[:, 1] - self.range[0]) / stride).long().clamp(max=w // 10 - 1)
+        in_y = ((points[:, 2] - self.range[1]) / stride).long().clamp(max=h // 10 - 1)
+        coarse = torch.zeros(h // 10, w // 10, device=dev)
+        coarse[in_y, in_x] = 1
+        idx = coarse.nonzero() * 10                                  # (K, 2) row, col
+        off = torch.arange(-10, 10, device=dev)
+        rows = (idx[:, None, None, 0] + off[None, :, None]).expand(-1, 20, 20).reshape(-1)
+        cols = (idx[:, None, None, 1] + off[None, None, :]).expand(-1, 20, 20).reshape(-1)
+        mask = torch.zeros(h, w, device=dev)
+        mask[rows, cols] = 1
+        return mask.bool()
+
+    @torch.no_grad()
+    def forward(self, data_dict):
+        x = data_dict["st_features_2d"]
+        if self.anchors_root is None:
+            self.anchors_root = self._gen[0].generate_anchors(self._gen[1], device=x.device)[0]
+        mask = self.get_anchor_mask(data_dict["points"], x.shape)
+        anchors = [a[:, mask, ...] for a in self.anchors_root]
+        pick = lambda t: t.permute(0, 2, 3, 1).contiguous()[:, mask, :]
+        cls_preds, box_preds = pick(self.conv_cls(x)), pick(self.conv_box(x))
+        dir_preds = pick(self.conv_dir_cls(x)) if self.conv_dir_cls is not None else None
+        cls, boxes = generate_predicted_boxes(anchors, data_dict["batch_size"], cls_preds, box_preds, dir_preds,
+                                              self.model_cfg.get("DIR_OFFSET", 0.78539), self.model_cfg.get("DIR_LIMIT_OFFSET", 0.0),
+                                              self.num_dir_bins)
+        data_dict.update(batch_cls_preds=cls, batch_box_preds=boxes, cls_preds_normalized=False)
+        return data_dict

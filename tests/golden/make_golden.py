@@ -459,9 +459,7 @@ def main():
     _load("r.models.dense_heads.target_assigner.atss_target_assigner",
           "cpd/models/dense_heads/target_assigner/atss_target_assigner.py")
     sys.modules["r.utils"].box_coder_utils = bc
-    odiou = _t.ModuleType("r.utils.odiou_loss")       # odiou_3D is only referenced by the loss path, never called here
-    odiou.odiou_3D = None
-    sys.modules["r.utils.odiou_loss"] = odiou
+    _load("r.utils.odiou_loss", "cpd/utils/odiou_loss.py")            # plain torch/scipy; only constructed, never called here
     aht = _load("r.models.dense_heads.anchor_head_template", "cpd/models/dense_heads/anchor_head_template.py")
     n_loc = H * W
     n_anc = n_loc * 6
@@ -477,6 +475,33 @@ def main():
                         reg_weights=tgt["reg_weights"].numpy(), gt_ious=tgt["gt_ious"].numpy(), iou_sample=ious.numpy(),
                         enc=enc.numpy(), cls_preds=cls_preds.numpy(), box_preds=box_preds.numpy(), dir_preds=dir_preds.numpy(),
                         decoded=bbp.numpy(), batch_cls=bcp.numpy())
+    # 10. AnchorHeadSingle.forward in eval mode (anchor_head_single.py:194-356), constructed on CPU thanks to the
+    #     identity Tensor.cuda: occupancy anchor mask (l.238-278, incl. its wrap-around negative indices), the three
+    #     1x1 convs, masked anchors, generate_predicted_boxes.
+    sys.modules["r.models.model_utils"].model_nms_utils = m["model_nms_utils"]
+    sys.modules.setdefault("cv2", _t.ModuleType("cv2"))              # imported by the reference file (l.6), never used
+    ahs = _load("r.models.dense_heads.anchor_head_single", "cpd/models/dense_heads/anchor_head_single.py")
+    mcfg = AttrDict(ANCHOR_GENERATOR_CONFIG=agc, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
+                    TARGET_ASSIGNER_CONFIG=AttrDict(NAME="AxisAlignedTargetAssigner", POS_FRACTION=-1.0, SAMPLE_SIZE=512,
+                                                    NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False, BOX_CODER="ResidualCoder"),
+                    LOSS_CONFIG=AttrDict(LOSS_WEIGHTS=AttrDict(cls_weight=1.0, loc_weight=2.0, dir_weight=0.2,
+                                                               code_weights=[1.0] * 7)))
+    head = ahs.AnchorHeadSingle(model_cfg=mcfg, num_frames=1, input_channels=24, num_class=3, class_names=["Vehicle", "Pedestrian", "Cyclist"],
+                                grid_size=np.array([416, 416, 40]), point_cloud_range=pcr, predict_boxes_when_training=False).eval()
+    with torch.no_grad():
+        head.conv_box.weight.normal_(0, 0.05); head.conv_cls.weight.normal_(0, 0.05); head.conv_dir_cls.weight.normal_(0, 0.05)
+    pts_bev = torch.cat([torch.zeros(300, 1), torch.from_numpy(g.uniform(-20.5, 20.5, (300, 3)).astype(np.float32))], 1)
+    pts_bev[:150, 1:3] *= 0.35                                        # a cluster, so the mask is neither empty nor full
+    pts_bev = pts_bev[(pts_bev[:, 1].abs() < 9) | (pts_bev[:, 2] > 12)]
+    feat2d = torch.randn(2, 24, H, W)
+    dd = {"points": pts_bev, "st_features_2d": feat2d, "batch_size": 2}
+    with torch.no_grad():
+        mask = head.get_anchor_mask(dd, feat2d.shape)
+        outd = head(dict(dd))
+    ah_sd = {"ahs." + k: v.numpy() for k, v in head.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "anchor_head_single.npz"), points=pts_bev.numpy(), feat=feat2d.numpy(), mask=mask.numpy(),
+                        batch_cls_preds=outd["batch_cls_preds"].numpy(), batch_box_preds=outd["batch_box_preds"].numpy(), pcr=pcr, **ah_sd)
+    print("anchor_head_single: mask keeps %d of %d locations, %d boxes/sample" % (int(mask.sum()), mask.numel(), outd["batch_box_preds"].shape[1]))
     print("anchor_head: %d anchors, %d positives, %d ignored" % (n_anc, int((tgt["box_cls_labels"] > 0).sum()),
                                                                   int((tgt["box_cls_labels"] < 0).sum())))
     print("golden fixtures written to", HERE)

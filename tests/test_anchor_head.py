@@ -79,3 +79,26 @@ def test_hip_anchor_head_matches_reference_goldens(oracle, golden, hip):
     np.testing.assert_allclose(got["box_reg_targets"].cpu().numpy(), want[1], rtol=0, atol=2e-6)
     none = ah.assign_targets_single(big, torch.zeros((0, 7)).cuda(), torch.zeros((0,), dtype=torch.int32).cuda(), 0.55, 0.4)
     assert int(none["box_cls_labels"].abs().sum()) == 0 and float(none["reg_weights"].sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_anchor_head_single_forward_matches_reference_module(golden, hip):
+    """The whole eval forward of the reference's AnchorHeadSingle (mask, 1x1 convs, masked anchors, decoding)."""
+    import torch
+    from cpd_amd import anchor_head as ah
+    g = golden("anchor_head_single")
+    cfgs = [dict(class_name=n, anchor_sizes=[s], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0], align_center=False,
+                 feature_map_stride=8, matched_threshold=0.5, unmatched_threshold=0.35)
+            for n, s in (("Vehicle", [4.7, 2.1, 1.7]), ("Pedestrian", [0.91, 0.86, 1.73]), ("Cyclist", [1.78, 0.84, 1.78]))]
+    mcfg = dict(ANCHOR_GENERATOR_CONFIG=cfgs, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2)
+    head = ah.AnchorHeadSingle(mcfg, 24, 3, CLASSES, np.array([416, 416, 40]), g["pcr"].tolist())
+    sd = {k[4:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("ahs.")}
+    missing = head.load_state_dict(sd, strict=False)
+    assert not missing.missing_keys                                  # every parameter of ours exists in the reference module
+    head = head.cuda().eval()
+    dd = {"points": torch.from_numpy(g["points"]).cuda(), "st_features_2d": torch.from_numpy(g["feat"]).cuda(), "batch_size": 2}
+    mask = head.get_anchor_mask(dd["points"], dd["st_features_2d"].shape)
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])
+    out = head(dd)
+    np.testing.assert_allclose(out["batch_cls_preds"].cpu().numpy(), g["batch_cls_preds"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["batch_box_preds"].cpu().numpy(), g["batch_box_preds"], atol=2e-4, rtol=1e-5)
