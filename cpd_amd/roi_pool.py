@@ -220,3 +220,104 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize
     if cdim > 7:
         raise NotImplementedError("7+C box codes (velocity ...) are not used by the CPD configs")
     return rois7, roi_scores, roi_labels, kept
+
+
+class VoxelRCNNHead(nn.Module):
+    """Eval forward of VoxelRCNNHead (cpd/models/roi_heads/voxel_rcnn_head.py:664-760, 876-916): RoI grid pooling,
+    shared FC / cls / reg stacks (Linear + eval BatchNorm1d + ReLU folded into `cpd_gather_conv` GEMM epilogues) and
+    RoIHeadTemplate.generate_predicted_boxes (roi_head_template.py:269-299). Same constructor arguments and
+    state_dict names as the reference module; the training branch (proposal target sampling, losses) is not built."""
+
+    def __init__(self, input_channels, model_cfg, point_cloud_range=None, voxel_size=None, num_frames=1, num_class=1, **kwargs):
+        super().__init__()
+        self.model_cfg, self.point_cloud_range, self.voxel_size, self.num_class = model_cfg, point_cloud_range, voxel_size, num_class
+        pool = model_cfg["ROI_GRID_POOL"]
+        self.grid_size = pool["GRID_SIZE"]
+        self.sources = list(pool["FEATURES_SOURCE"])
+        self.roi_grid_pool_layers = nn.ModuleList()
+        c_out = 0
+        for src in self.sources:
+            lc = pool["POOL_LAYERS"][src]
+            mlps = [[input_channels[src]] + list(m) for m in lc["MLPS"]]
+            self.roi_grid_pool_layers.append(NeighborVoxelSAModuleMSG(query_ranges=lc["QUERY_RANGES"], nsamples=lc["NSAMPLE"],
+                                                                      radii=lc["POOL_RADIUS"], mlps=mlps, pool_method=lc["POOL_METHOD"]))
+            c_out += sum(m[-1] for m in mlps)
+        dp = model_cfg["DP_RATIO"]
+
+        def stack(pre, widths, final=None):
+            layers = []
+            for k, wdt in enumerate(widths):
+                layers += [nn.Linear(pre, wdt, bias=False), nn.BatchNorm1d(wdt), nn.ReLU()]
+                pre = wdt
+                if k != len(widths) - 1 and dp > 0:
+                    layers.append(nn.Dropout(dp))
+            if final is not None:
+                layers.append(nn.Linear(pre, final, bias=True))
+            return nn.Sequential(*layers)
+
+        self.shared_fc_layers = stack(self.grid_size ** 3 * c_out, model_cfg["SHARED_FC"])
+        self.cls_layers = stack(model_cfg["SHARED_FC"][-1], model_cfg["CLS_FC"], num_class)
+        self.reg_layers = stack(model_cfg["SHARED_FC"][-1], model_cfg["REG_FC"], 7 * num_class)
+        self._fc = None
+
+    def _pack_fc(self):
+        def pack(seq):
+            out, mods, i = [], list(seq), 0
+            while i < len(mods):
+                lin = mods[i]
+                if not isinstance(lin, nn.Linear):
+                    i += 1
+                    continue
+                w = ops.pack_weight(lin.weight.detach().t().contiguous()[None])                # [1, in, out]
+                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+                    s, t = _fold(mods[i + 1])
+                    out.append((w, lin.in_features, lin.out_features, s.contiguous(), t.contiguous(), True))
+                else:
+                    out.append((w, lin.in_features, lin.out_features, None, lin.bias.detach().contiguous(), False))
+                i += 1
+            return out
+        self._fc = {k: pack(getattr(self, k)) for k in ("shared_fc_layers", "cls_layers", "reg_layers")}
+
+    @staticmethod
+    def _run(layers, x):
+        for w, cin, cout, s, t, relu in layers:
+            x = ops.gather_conv(x, cin, w, None, 1, x.shape[0], cout, s, t, None, relu)
+        return x
+
+    @torch.no_grad()
+    def forward(self, batch_dict):
+        if self.training:
+            raise NotImplementedError("VoxelRCNNHead: eval forward only")
+        if self._fc is None:
+            self._pack_fc()
+        rois, b = batch_dict["rois"], batch_dict["batch_size"]
+        levels = {}
+        for name in self.sources:
+            t = batch_dict["multi_scale_3d_features"][name]
+            levels[name] = t if isinstance(t, tuple) else (t.features, t.indices, list(t.spatial_shape))
+        pooled = roi_grid_pool(rois, levels, batch_dict["multi_scale_3d_strides"], dict(zip(self.sources, self.roi_grid_pool_layers)),
+                               self.grid_size, self.voxel_size, self.point_cloud_range, b)
+        x = pooled.reshape(pooled.shape[0], -1).contiguous()
+        shared = self._run(self._fc["shared_fc_layers"], x)
+        rcnn_cls = self._run(self._fc["cls_layers"], shared)
+        rcnn_reg = self._run(self._fc["reg_layers"], shared)
+        cls, boxes = self.generate_predicted_boxes(b, rois, rcnn_cls, rcnn_reg)
+        batch_dict.update(batch_box_preds=boxes, batch_cls_preds=cls, cls_preds_normalized=False)
+        return batch_dict
+
+    @staticmethod
+    def generate_predicted_boxes(batch_size, rois, cls_preds, box_preds):
+        """roi_head_template.py:269-299: decode the residuals against the RoI with its centre at the origin
+        (cpd_anchor_decode), rotate by the RoI heading, translate to the RoI centre."""
+        from . import anchor_head
+        flat = rois.reshape(-1, rois.shape[-1])[:, :7].contiguous().float()
+        local = flat.clone()
+        local[:, 0:3] = 0
+        n = flat.shape[0]
+        _, dec = anchor_head.generate_predicted_boxes(local, 1, cls_preds.reshape(1, n, -1), box_preds.reshape(1, n, 7))
+        dec = dec.view(n, 7)
+        ca, sa = torch.cos(flat[:, 6]), torch.sin(flat[:, 6])
+        x = dec[:, 0] * ca - dec[:, 1] * sa                          # rotate_points_along_z (common_utils.py:35-57)
+        y = dec[:, 0] * sa + dec[:, 1] * ca
+        out = torch.cat([(x + flat[:, 0])[:, None], (y + flat[:, 1])[:, None], (dec[:, 2] + flat[:, 2])[:, None], dec[:, 3:]], dim=1)
+        return cls_preds.view(batch_size, -1, cls_preds.shape[-1]), out.view(batch_size, -1, 7)

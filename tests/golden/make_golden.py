@@ -501,6 +501,69 @@ def main():
     ah_sd = {"ahs." + k: v.numpy() for k, v in head.state_dict().items()}
     np.savez_compressed(os.path.join(HERE, "anchor_head_single.npz"), points=pts_bev.numpy(), feat=feat2d.numpy(), mask=mask.numpy(),
                         batch_cls_preds=outd["batch_cls_preds"].numpy(), batch_box_preds=outd["batch_box_preds"].numpy(), pcr=pcr, **ah_sd)
+    # 11. VoxelRCNNHead eval forward (voxel_rcnn_head.py:664-760, 876-916; roi_head_template.py:269-299): RoI grid
+    #     pooling on two levels, shared FC / cls / reg layers, box decoding in the RoI frame. The real common_utils.py
+    #     and spconv_utils.py are loaded by file; pointnet2_stack_cuda stays the oracle-backed stub of section 8.
+    cu_real = _load("r.utils.common_utils", "cpd/utils/common_utils.py")
+    sys.modules["r.utils"].common_utils = cu_real
+    su = _load("r.utils.spconv_utils_probe", "cpd/utils/spconv_utils.py") if False else None
+    spu = _t.ModuleType("r.utils.spconv_utils")                       # generate_voxel2pinds only (the file imports spconv at top)
+
+    def generate_voxel2pinds(sparse_tensor):                            # cpd/utils/spconv_utils.py:4-21 semantics on the oracle
+        return torch.from_numpy(orc.voxel2pinds(sparse_tensor.indices.numpy().astype(np.int32), sparse_tensor.batch_size,
+                                                list(sparse_tensor.spatial_shape)))
+
+    spu.generate_voxel2pinds = generate_voxel2pinds
+    sys.modules["r.utils.spconv_utils"] = spu
+    sys.modules["r.utils"].spconv_utils = spu
+    for pkg in ["r.models.roi_heads.target_assigner"]:
+        _pkg(pkg)
+    _load("r.utils.bbloss", "cpd/utils/bbloss.py")
+    _load("r.models.roi_heads.target_assigner.proposal_target_layer", "cpd/models/roi_heads/target_assigner/proposal_target_layer.py")
+    _load("r.models.roi_heads.roi_head_template", "cpd/models/roi_heads/roi_head_template.py")
+    sys.modules["r.ops.pointnet2"].pointnet2_stack = sys.modules["r.ops.pointnet2.pointnet2_stack"]
+    sys.modules["r.ops.pointnet2.pointnet2_stack"].voxel_pool_modules = vp
+    vrh = _load("r.models.roi_heads.voxel_rcnn_head", "cpd/models/roi_heads/voxel_rcnn_head.py")
+    rcfg = AttrDict(
+        ROI_GRID_POOL=AttrDict(FEATURES_SOURCE=["x_conv3", "x_conv4"], PRE_MLP=True, GRID_SIZE=3, POOL_LAYERS=AttrDict(
+            x_conv3=AttrDict(MLPS=[[16, 16], [16, 16]], QUERY_RANGES=[[1, 1, 1], [2, 2, 2]], POOL_RADIUS=[0.6, 1.2], NSAMPLE=[8, 8],
+                             POOL_METHOD="max_pool"),
+            x_conv4=AttrDict(MLPS=[[16, 16], [16, 16]], QUERY_RANGES=[[1, 1, 1], [2, 2, 2]], POOL_RADIUS=[1.2, 2.4], NSAMPLE=[8, 8],
+                             POOL_METHOD="max_pool"))),
+        SHARED_FC=[64, 64], CLS_FC=[32], REG_FC=[32], DP_RATIO=0.3,
+        TARGET_CONFIG=AttrDict(BOX_CODER="ResidualCoder", ROI_PER_IMAGE=16, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True,
+                               CLS_SCORE_TYPE="roi_iou", CLS_FG_THRESH=0.6, CLS_BG_THRESH=0.25, CLS_BG_THRESH_LO=0.1,
+                               HARD_BG_RATIO=0.8, REG_FG_THRESH=0.55),
+        LOSS_CONFIG=AttrDict(LOSS_WEIGHTS=AttrDict(code_weights=[1.0] * 7)),
+        NMS_CONFIG=AttrDict(TEST=AttrDict(NMS_TYPE="nms_gpu", MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=1024, NMS_POST_MAXSIZE=100,
+                                          NMS_THRESH=0.7)))
+    torch.manual_seed(41)
+    rhead = vrh.VoxelRCNNHead(input_channels={"x_conv3": 24, "x_conv4": 32}, model_cfg=rcfg, point_cloud_range=pcr,
+                              voxel_size=[0.1, 0.1, 0.15], num_class=1).eval()
+    for mm in rhead.modules():
+        if isinstance(mm, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mm.weight.data.uniform_(0.6, 1.4); mm.bias.data.normal_(0, 0.2)
+            mm.running_mean.normal_(0, 0.2); mm.running_var.uniform_(0.6, 1.4)
+    with torch.no_grad():
+        rhead.cls_layers[-1].weight.normal_(0, 0.1); rhead.reg_layers[-1].weight.normal_(0, 0.05)
+    lv = {}
+    for name, shp, stride_l, ch, nvox in (("x_conv3", [11, 104, 104], 4, 24, 5000), ("x_conv4", [5, 52, 52], 8, 32, 2200)):
+        cl = np.unique(np.stack([g.integers(0, 2, nvox), g.integers(0, shp[0], nvox), g.integers(0, shp[1], nvox),
+                                 g.integers(0, shp[2], nvox)], 1), axis=0).astype(np.int32)
+        lv[name] = SimpleNamespace(indices=torch.from_numpy(cl), features=torch.randn(cl.shape[0], ch), spatial_shape=shp, batch_size=2)
+    rois_in = torch.tensor(np.concatenate([g.uniform(-18, 18, (2, 9, 2)), g.uniform(-0.5, 1.0, (2, 9, 1)), g.uniform(1.0, 4.5, (2, 9, 3)),
+                                           g.uniform(-3.1, 3.1, (2, 9, 1))], -1), dtype=torch.float32)
+    bd = {"batch_size": 2, "rois": rois_in.clone(), "roi_labels": torch.ones(2, 9).long(), "multi_scale_3d_features": lv,
+          "multi_scale_3d_strides": {"x_conv3": 4, "x_conv4": 8}}
+    with torch.no_grad():
+        od = rhead(bd)
+    rsd = {"rh." + k: v.numpy() for k, v in rhead.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "voxel_rcnn_head.npz"), rois=rois_in.numpy(), pcr=pcr,
+                        c3_idx=lv["x_conv3"].indices.numpy(), c3_feat=lv["x_conv3"].features.numpy(),
+                        c4_idx=lv["x_conv4"].indices.numpy(), c4_feat=lv["x_conv4"].features.numpy(),
+                        batch_cls_preds=od["batch_cls_preds"].numpy(), batch_box_preds=od["batch_box_preds"].numpy(), **rsd)
+    print("voxel_rcnn_head: %d rois -> cls %s box %s" % (rois_in.shape[0] * rois_in.shape[1], tuple(od["batch_cls_preds"].shape),
+                                                          tuple(od["batch_box_preds"].shape)))
     print("anchor_head_single: mask keeps %d of %d locations, %d boxes/sample" % (int(mask.sum()), mask.numel(), outd["batch_box_preds"].shape[1]))
     print("anchor_head: %d anchors, %d positives, %d ignored" % (n_anc, int((tgt["box_cls_labels"] > 0).sum()),
                                                                   int((tgt["box_cls_labels"] < 0).sum())))

@@ -142,3 +142,26 @@ def test_proposal_layer_matches_reference_nms_golden(golden, hip):
         assert float(rois[b, k:].abs().sum()) == 0.0
     assert (rl[0, :k] == 2).all()
     np.testing.assert_array_equal(rl[1, :k].cpu().numpy(), want % 3 + 1)
+
+
+def test_voxel_rcnn_head_eval_forward_matches_reference_module(golden, hip):
+    """Second stage end to end: the reference's own VoxelRCNNHead output (run on the oracle-backed extension) for the
+    same state_dict, RoIs and multi-scale features."""
+    from cpd_amd import roi_pool
+    g = golden("voxel_rcnn_head")
+    cfg = dict(ROI_GRID_POOL=dict(FEATURES_SOURCE=["x_conv3", "x_conv4"], GRID_SIZE=3, POOL_LAYERS=dict(
+        x_conv3=dict(MLPS=[[16, 16], [16, 16]], QUERY_RANGES=[[1, 1, 1], [2, 2, 2]], POOL_RADIUS=[0.6, 1.2], NSAMPLE=[8, 8], POOL_METHOD="max_pool"),
+        x_conv4=dict(MLPS=[[16, 16], [16, 16]], QUERY_RANGES=[[1, 1, 1], [2, 2, 2]], POOL_RADIUS=[1.2, 2.4], NSAMPLE=[8, 8], POOL_METHOD="max_pool"))),
+        SHARED_FC=[64, 64], CLS_FC=[32], REG_FC=[32], DP_RATIO=0.3)
+    head = roi_pool.VoxelRCNNHead({"x_conv3": 24, "x_conv4": 32}, cfg, point_cloud_range=g["pcr"].tolist(), voxel_size=[0.1, 0.1, 0.15], num_class=1)
+    sd = {k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("rh.")}
+    res = head.load_state_dict(sd, strict=False)
+    assert not res.missing_keys, res.missing_keys
+    head = head.cuda().eval()
+    lv = {"x_conv3": (torch.from_numpy(g["c3_feat"]).cuda(), torch.from_numpy(g["c3_idx"]).cuda(), [11, 104, 104]),
+          "x_conv4": (torch.from_numpy(g["c4_feat"]).cuda(), torch.from_numpy(g["c4_idx"]).cuda(), [5, 52, 52])}
+    bd = {"batch_size": 2, "rois": torch.from_numpy(g["rois"]).cuda(), "multi_scale_3d_features": lv,
+          "multi_scale_3d_strides": {"x_conv3": 4, "x_conv4": 8}}
+    out = head(bd)
+    np.testing.assert_allclose(out["batch_cls_preds"].cpu().numpy(), g["batch_cls_preds"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["batch_box_preds"].cpu().numpy(), g["batch_box_preds"], atol=2e-4, rtol=1e-5)

@@ -61,3 +61,13 @@ print("B %d x %d rois: %d grid points; roi_grid_pool (2 levels x 2 scales) dense
 print("x_conv3 (%d voxels, grid %s): voxel2pinds %.1f us (%.0f MB volume); 9^3-cell query dense %.1f us, index %.1f us "
       "(%.1f G cell tests/s)" % (c.shape[0], s, tv2p * 1e3, v2p.numel() * 4 / 1e6, tq_dense * 1e3, tq_index * 1e3,
                                  m * 729 / (tq_index * 1e-3) / 1e9))
+
+# whole second stage (reference cfg sizes: GRID_SIZE 6, MLPS [[32,32],[32,32]] per level, SHARED_FC/CLS_FC/REG_FC [256,256])
+head_cfg = dict(ROI_GRID_POOL=dict(FEATURES_SOURCE=["x_conv3", "x_conv4"], GRID_SIZE=6, POOL_LAYERS=dict(
+    x_conv3=dict(MLPS=[[32, 32], [32, 32]], QUERY_RANGES=[[2, 2, 2], [4, 4, 4]], POOL_RADIUS=[0.4, 0.8], NSAMPLE=[16, 16], POOL_METHOD="max_pool"),
+    x_conv4=dict(MLPS=[[32, 32], [32, 32]], QUERY_RANGES=[[2, 2, 2], [4, 4, 4]], POOL_RADIUS=[0.8, 1.6], NSAMPLE=[16, 16], POOL_METHOD="max_pool"))),
+    SHARED_FC=[256, 256], CLS_FC=[256, 256], REG_FC=[256, 256], DP_RATIO=0.3)
+head = roi_pool.VoxelRCNNHead({"x_conv3": 64, "x_conv4": 128}, head_cfg, point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size).cuda().eval()
+bd = {"batch_size": B, "rois": rois, "multi_scale_3d_features": it["levels"], "multi_scale_3d_strides": strides}
+t_head = timed(lambda: head(dict(bd)))
+print("VoxelRCNNHead eval forward (pool + 27648->256->256 shared FC + cls/reg stacks + decode), B %d x %d rois: %.2f ms" % (B, N, t_head))
