@@ -738,148 +738,6 @@ __global__ void __launch_bounds__(256) pack_weight_bf16_kernel(const float *__re
     pb[(blk + 2) * 4 * np * 8 + off] = l;
 }
 
-// 32x32x2 variant of the workgroup kernel: same LDS images, the wave tile is (BM/2) x (BN/2) made of
-// 32 x 32 MFMA tiles (v_mfma_f32_32x32x2_f32: 64 cycles, half as many matrix instructions per flop).
-// Operand mapping: lane (i = l & 31, h = l >> 5) holds channels 8*c8 + 4*h + q of row / column i.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <int BM, int BN>
-__global__ void __launch_bounds__(256) tile_conv32_kernel(GcParams p) {
-    constexpr int MS = BM / 64, NT = BN / 64;  // 32x32 tiles per wave
-    constexpr int AJ = BM / 32, BJ = BN / 32;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int item = xcd_remap(blockIdx.x, gridDim.x);
-    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
-    const int row0 = rb * BM, col0 = cb * BN;
-
-    f32x16 acc[MS][NT];
-#pragma unroll
-    for (int s = 0; s < MS; ++s)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[s][nt][e] = 0.f;
-
-    const int a_piece = tid & 7;
-    const int a_row = tid >> 3;
-    int a_rowc[AJ];
-    bool a_ok[AJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-        const int row = row0 + a_row + 32 * j;
-        a_ok[j] = row < p.n_out;
-        a_rowc[j] = a_ok[j] ? row : p.n_out - 1;
-    }
-    const int sk = p.kc >> 1;
-    const int n_stage = p.kv * sk;
-    const size_t w_chunk = (size_t)4 * p.np * 4;
-
-    int idx_cur[AJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr ? p.nbr[a_rowc[j]] : a_rowc[j];
-
-    f32x4 ra[AJ], rbv[BJ];
-    auto stage_load = [&](int st) {
-        const int t = st / sk, kk = st - t * sk;
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const int id = a_ok[j] ? idx_cur[j] : -1;
-            ra[j] = zero_if(load_a<true>(p, id, kk * 32 + a_piece * 4), id < 0);
-        }
-        const float *wt = p.w + ((size_t)t * p.kc + kk * 2) * w_chunk;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int id = j * 256 + tid;
-            const int cg = id / BN, n = id - cg * BN;
-            rbv[j] = *reinterpret_cast<const f32x4 *>(wt + ((size_t)cg * p.np + col0 + n) * 4);
-        }
-    };
-    auto stage_store = [&](int buf) {
-        char *sa = smem + buf * (A_BYTES + B_BYTES);
-        char *sb = sa + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const int m = a_row + 32 * j;
-            *reinterpret_cast<f32x4 *>(sa + ((a_piece * BM + (m ^ a_piece)) << 4)) = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4 *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
-    };
-
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int st = 0; st < n_stage; ++st) {
-        const int nx = st + 1;
-        if (nx < n_stage) {
-            const int t_nx = nx / sk;
-            if (nx - t_nx * sk == 0) {
-#pragma unroll
-                for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr[(size_t)t_nx * p.n_out + a_rowc[j]];
-            }
-            stage_load(nx);
-        }
-        {
-            const char *sa = smem + (st & 1) * (A_BYTES + B_BYTES);
-            const char *sb = sa + A_BYTES;
-#pragma unroll
-            for (int c8 = 0; c8 < 4; ++c8) {
-                const int piece = c8 * 2 + lh;
-                f32x4 a[MS], b[NT];
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    const int m = wr * (BM / 2) + 32 * s + li;
-                    a[s] = *reinterpret_cast<const f32x4 *>(sa + ((piece * BM + (m ^ piece)) << 4));
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int n = wc * (BN / 2) + 32 * nt + li;
-                    b[nt] = *reinterpret_cast<const f32x4 *>(sb + ((piece * BN + n) << 4));
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int s = 0; s < MS; ++s)
-                            acc[s][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][q], b[nt][q], acc[s][nt], 0, 0, 0);
-            }
-        }
-        if (nx < n_stage) stage_store(nx & 1);
-        __syncthreads();
-    }
-    // epilogue, 32x32 C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = col0 + wc * (BN / 2) + 32 * nt + li;
-        const float sc = (p.scale && col < p.c_out) ? p.scale[col] : 1.f;
-        const float sh = (p.shift && col < p.c_out) ? p.shift[col] : 0.f;
-#pragma unroll
-        for (int s = 0; s < MS; ++s) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = row0 + wr * (BM / 2) + 32 * s + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row >= p.n_out || col >= p.c_out) continue;
-                float v = acc[s][nt][e] * sc + sh;
-                if (p.residual) v += p.residual[(size_t)row * p.res_ld + col];
-                if (p.relu) v = v > 0.f ? v : 0.f;
-                if (p.col_group) {
-                    const int grp = col / p.col_group;
-                    const size_t drow = (size_t)p.out_row_map[(size_t)grp * p.n_out + row];
-                    p.out[drow * p.out_ld + (col - grp * p.col_group)] = v;
-                } else {
-                    const size_t orow = p.out_row_map ? (size_t)p.out_row_map[row] : (size_t)row;
-                    p.out[orow * p.out_ld + col] = v;
-                }
-            }
-        }
-    }
-}
 
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restrict__ w, int kv, int c_in, int c_out, int kc,
                                                           int np, float *__restrict__ packed) {
@@ -947,13 +805,6 @@ static gc_kernel_t pick(int ms, int nt, bool vec) {
         case 2: return pick_nt<2>(nt, vec);
         case 4: return pick_nt<4>(nt, vec);
     }
-    return nullptr;
-}
-static gc_kernel_t pick_tile32(int bm, int bn) {
-    if (bm == 128 && bn == 128) return tile_conv32_kernel<128, 128>;
-    if (bm == 64 && bn == 128) return tile_conv32_kernel<64, 128>;
-    if (bm == 128 && bn == 64) return tile_conv32_kernel<128, 64>;
-    if (bm == 64 && bn == 64) return tile_conv32_kernel<64, 64>;
     return nullptr;
 }
 static gc_kernel_t pick_tile(int bm, int bn) {
@@ -1154,8 +1005,7 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
         return cpd_check_launch();
     }
     if (pl.use_wg) {
-        const char *e32 = getenv("CPD_GC_MFMA32");
-        gc_kernel_t k = (e32 && atoi(e32)) ? pick_tile32(pl.a, pl.b) : pick_tile(pl.a, pl.b);
+        gc_kernel_t k = pick_tile(pl.a, pl.b);
         if (!k) return CPD_ERR_UNSUPPORTED;
         p.n_rb = (n_out + pl.a - 1) / pl.a;
         p.n_cb = c_out / pl.b;
