@@ -858,7 +858,7 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
     // split-bf16 path (CPD_GC_BF16X3): 128 x 128 tiles, needs whole 32-channel stages and 128-column tiles
     int allow_bf16 = (flags & 2) != 0;
     if (const char *e = getenv("CPD_GC_BF16X3")) allow_bf16 = atoi(e);
-    long long bf16_min_wgs = 256;       // at least one workgroup per CU (measured: tools/bf16x3_probe.py)
+    long long bf16_min_wgs = 600;       // > 2 workgroups per CU, else the narrower/shorter tile (measured: single-frame bench, train step)
     if (const char *e = getenv("CPD_GC_BF16_MIN")) bf16_min_wgs = atoll(e);
     int dense_rowwave = 0;
     if (const char *e = getenv("CPD_GC_DENSE_ROWWAVE")) dense_rowwave = atoi(e);
@@ -867,9 +867,16 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
         int force_bn = 0;
         if (const char *e = getenv("CPD_GC_ROWWAVE_BN")) force_bn = atoi(e);
         if ((force_bn == 64 || force_bn == 128) && c_out % force_bn == 0) { pl.use_wg = 3; pl.a = 128; pl.b = force_bn; return pl; }
-        if ((long long)((n_out + 127) / 128) * (c_out / bn) >= bf16_min_wgs) {
-            pl.use_wg = 3; pl.a = 128; pl.b = bn;
-            return pl;
+        // widest column tile that still gives every CU a workgroup: a narrower tile re-gathers the rows once per
+        // column tile, which small layers (the 1/4 and 1/8 stages of a single frame) can afford
+        int narrow = 1;
+        if (const char *e = getenv("CPD_GC_ROWWAVE_NARROW")) narrow = atoi(e);
+        for (int b = bn; b >= 32; b >>= 1) {
+            if ((long long)((n_out + 127) / 128) * (c_out / b) >= bf16_min_wgs) {
+                pl.use_wg = 3; pl.a = 128; pl.b = b;
+                return pl;
+            }
+            if (!narrow) break;
         }
     }
     if (allow_bf16 && (flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 64 == 0) {
@@ -968,6 +975,10 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
+    static const bool trace = getenv("CPD_GC_TRACE") != nullptr;    // one line per launch: which kernel a layer got
+    if (trace)
+        fprintf(stderr, "cpd_gather_conv n_out=%d kv=%d c_in=%d c_out=%d flags=%d masks=%d -> kind=%d tile=(%d,%d)\n", n_out, kv, c_in, c_out,
+                flags, tapmask != nullptr, pl.use_wg, pl.a, pl.b);
     if (pl.use_wg == 3) {
         p.wb = packed_w + packed_f32_floats(kv, c_in, c_out);
         p.n_rb = (n_out + 127) / 128;

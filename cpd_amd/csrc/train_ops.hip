@@ -372,6 +372,186 @@ __global__ void __launch_bounds__(256) wgrad_tile_kernel(WgParams p) {
             }
 }
 
+// Split-bf16 weight gradient (fp32-equivalent, see gather_conv.hip: x = h + m + l exactly, six bf16
+// MFMA products per fp32 multiply-add). The contraction runs over ROWS, so both MFMA operands are
+// "k-major": lane (i, kg) needs 8 consecutive rows of one channel. That transpose is free when a
+// lane stages one CHANNEL: a wave reads 64 consecutive channels of one row per load instruction
+// (256 B coalesced), a thread collects its channel's value from RA rows, splits them and writes
+// them as one 16-byte k-group of the operand image [piece][k-group][channel][8 rows].
+// Rows without a neighbour at the tap are dropped BEFORE staging: each 256-row block of the chunk
+// is compacted (ballot + prefix) into a ring of (row, neighbour) pairs in LDS and the stages eat 32
+// pairs at a time, so a sparse layer spends MFMAs on existing pairs only.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wsplit3(const f32x4 &x, wbf16x4 &h, wbf16x4 &m, wbf16x4 &l) {
+    h = __builtin_convertvector(x, wbf16x4);
+    const f32x4 r1 = x - __builtin_convertvector(h, f32x4);
+    m = __builtin_convertvector(r1, wbf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+    l = __builtin_convertvector(r2, wbf16x4);
+}
+
+// R rows (4, 8 or 16) of one channel -> the three piece images; `slot` = byte offset of k-group k0/8, channel ch
+template <int R, int IMG>
+__device__ __forceinline__ void wgrad_put(char *img, int slot, int k0, const float (&v)[R]) {
+    if constexpr (R == 4) {
+        wbf16x4 h, m, l;
+        wsplit3(f32x4{v[0], v[1], v[2], v[3]}, h, m, l);
+        char *dst = img + slot + ((k0 >> 2) & 1) * 8;
+        *reinterpret_cast<wbf16x4 *>(dst) = h;
+        *reinterpret_cast<wbf16x4 *>(dst + IMG) = m;
+        *reinterpret_cast<wbf16x4 *>(dst + 2 * IMG) = l;
+    } else {
+#pragma unroll
+        for (int q = 0; q < R / 8; ++q) {
+            wbf16x4 h0, m0, l0, h1, m1, l1;
+            wsplit3(f32x4{v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3]}, h0, m0, l0);
+            wsplit3(f32x4{v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]}, h1, m1, l1);
+            char *dst = img + slot + q * (IMG / 4);          // next k-group: T channels x 16 B further
+            *reinterpret_cast<wbf16x8 *>(dst) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<wbf16x8 *>(dst + IMG) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<wbf16x8 *>(dst + 2 * IMG) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+}
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgParams p) {
+    constexpr int KB = 32;                               // pairs per stage = K of one bf16 MFMA
+    constexpr int RING = 512;                            // >= KB - 1 + 256 pairs
+    constexpr int RA = TM / 8, RB = TN / 8;              // rows of a stage one thread stages per side
+    constexpr int A_IMG = TM * 64, B_IMG = TN * 64;      // bytes of one piece image: 4 k-groups x T channels x 16 B
+    constexpr int MS = TM / 32, NT = TN / 32;            // 2 x 2 waves, wave tile (TM/2) x (TN/2)
+    __shared__ __attribute__((aligned(16))) char sA[3 * A_IMG];
+    __shared__ __attribute__((aligned(16))) char sB[3 * B_IMG];
+    __shared__ __attribute__((aligned(16))) int ringJ[RING];
+    __shared__ __attribute__((aligned(16))) int ringI[RING];
+    __shared__ int wave_cnt[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ci0 = (blockIdx.x / p.co_tiles) * TM, co0 = (blockIdx.x % p.co_tiles) * TN;
+    const int t = blockIdx.y;
+    const int r0 = blockIdx.z * p.rows_per_chunk, r1 = min(p.n_out, r0 + p.rows_per_chunk);
+    const int a_ch = tid % TM, a_k0 = (tid / TM) * RA;
+    const int b_ch = tid % TN, b_k0 = (tid / TN) * RB;
+    const int a_slot = ((a_k0 >> 3) * TM + a_ch) << 4, b_slot = ((b_k0 >> 3) * TN + b_ch) << 4;
+    const float *a_base = p.in + ci0 + a_ch;
+    const float *b_base = p.dy + co0 + b_ch;
+    const int32_t *nbr_t = p.nbr ? p.nbr + (size_t)t * p.n_out : nullptr;
+
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto nbr_of = [&](int j) { return j < r1 ? (nbr_t ? nbr_t[j] : j) : -1; };
+    auto mma = [&]() {
+        wbf16x8 ah[MS], am[MS], al[MS];
+#pragma unroll
+        for (int s = 0; s < MS; ++s) {
+            const char *src = sA + ((g * TM + wm * (TM / 2) + 16 * s + r) << 4);
+            ah[s] = *reinterpret_cast<const wbf16x8 *>(src);
+            am[s] = *reinterpret_cast<const wbf16x8 *>(src + A_IMG);
+            al[s] = *reinterpret_cast<const wbf16x8 *>(src + 2 * A_IMG);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const char *src = sB + ((g * TN + wn * (TN / 2) + 16 * nt + r) << 4);
+            const wbf16x8 bh = *reinterpret_cast<const wbf16x8 *>(src);
+            const wbf16x8 bm = *reinterpret_cast<const wbf16x8 *>(src + B_IMG);
+            const wbf16x8 bl = *reinterpret_cast<const wbf16x8 *>(src + 2 * B_IMG);
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {          // smallest terms first
+                f32x4 c = acc[s][nt];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
+                acc[s][nt] = c;
+            }
+        }
+    };
+
+    int head = 0, tail = 0, jb = r0;       // ring positions (head stays a multiple of KB) and next block of rows
+    int idx_pref = nbr_of(jb + tid);
+    bool have = false;
+    for (;;) {
+        while (tail - head < KB && jb < r1) {            // compact the next 256 rows into the ring
+            const int j = jb + tid, idx = idx_pref;
+            jb += 256;
+            idx_pref = nbr_of(jb + tid);
+            const unsigned long long bal = __ballot(idx >= 0);
+            if (lane == 0) wave_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int off = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int c = wave_cnt[w];
+                off += w < wave ? c : 0;
+                total += c;
+            }
+            if (idx >= 0) {
+                const int pos = (tail + off + __popcll(bal & ((1ull << lane) - 1ull))) & (RING - 1);
+                ringJ[pos] = j;
+                ringI[pos] = idx;
+            }
+            tail += total;
+            __syncthreads();
+        }
+        const int cnt = min(KB, tail - head);
+        if (cnt <= 0) break;
+        // this stage's rows: global -> registers (in flight under the previous stage's MFMAs)
+        float va[RA], vb[RB];
+        {
+            const int base = head & (RING - 1);
+#pragma unroll
+            for (int q = 0; q < RA / 4; ++q) {
+                const int4 id = *reinterpret_cast<const int4 *>(&ringI[base + a_k0 + 4 * q]);
+                const int ids[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    va[4 * q + e] = (a_k0 + 4 * q + e < cnt) ? a_base[(size_t)ids[e] * p.in_ld] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < RB / 4; ++q) {
+                const int4 jd = *reinterpret_cast<const int4 *>(&ringJ[base + b_k0 + 4 * q]);
+                const int js[4] = {jd.x, jd.y, jd.z, jd.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    vb[4 * q + e] = (b_k0 + 4 * q + e < cnt) ? b_base[(size_t)js[e] * p.dy_ld] : 0.f;
+            }
+        }
+        head += KB;
+        if (have) {
+            mma();
+            __syncthreads();               // everyone is done reading the images before they are overwritten
+        }
+        wgrad_put<RA, A_IMG>(sA, a_slot, a_k0, va);
+        wgrad_put<RB, B_IMG>(sB, b_slot, b_k0, vb);
+        __syncthreads();
+        have = true;
+    }
+    if (have) mma();
+
+    // D[i][j]: i = 4g+e <-> channel ci0 + wm*TM/2 + 16s + i ; j = r <-> column co0 + wn*TN/2 + 16nt + j
+    float *out = p.part + ((size_t)blockIdx.z * p.kv + t) * p.c_in * p.c_out;
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = ci0 + wm * (TM / 2) + 16 * s + 4 * g + e, co = co0 + wn * (TN / 2) + 16 * nt + r;
+                out[(size_t)ci * p.c_out + co] = acc[s][nt][e];
+            }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int n_chunks, size_t elems,
                                                            float *__restrict__ dw, int accumulate) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -593,19 +773,36 @@ extern "C" int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, 
 }
 
 // Tile kernel plan: (TM, TN) in {64,128}^2 when both channel counts are multiples of 64.
+static void wgrad_chunks(int n_out, long long per_chunk, int min_rows, int round, WgParams *p) {
+    int chunks = (int)((512 + per_chunk - 1) / per_chunk);      // ~2 workgroups per CU
+    const int max_chunks = (n_out + min_rows - 1) / min_rows;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    p->rows_per_chunk = ((n_out + chunks - 1) / chunks + round - 1) / round * round;
+    p->n_chunks = (n_out + p->rows_per_chunk - 1) / p->rows_per_chunk;
+}
+
 static bool wgrad_tile_plan(int n_out, int c_in, int c_out, int kv, WgParams *p, int *tm, int *tn) {
     if (c_in % 64 || c_out % 64) return false;
     *tm = c_in % 128 ? 64 : 128;
     *tn = c_out % 128 ? 64 : 128;
     p->ci_tiles = c_in / *tm;
     p->co_tiles = c_out / *tn;
-    const long long per_chunk = (long long)kv * p->ci_tiles * p->co_tiles;
-    int chunks = (int)((512 + per_chunk - 1) / per_chunk);      // ~2 workgroups per CU
-    const int max_chunks = (n_out + 127) / 128;
-    if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks < 1) chunks = 1;
-    p->rows_per_chunk = ((n_out + chunks - 1) / chunks + 15) / 16 * 16;
-    p->n_chunks = (n_out + p->rows_per_chunk - 1) / p->rows_per_chunk;
+    wgrad_chunks(n_out, (long long)kv * p->ci_tiles * p->co_tiles, 128, 16, p);
+    return true;
+}
+
+// split-bf16 kernel: whole 32-channel tiles on both sides
+static int wgrad_bf16_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
+static bool wgrad_bf16_plan(int n_out, int c_in, int c_out, int kv, int flags, WgParams *p, int *tm, int *tn) {
+    int on = (flags & 2) != 0;
+    if (const char *e = getenv("CPD_WGRAD_BF16X3")) on = atoi(e);
+    if (!on || c_in % 32 || c_out % 32) return false;
+    *tm = wgrad_bf16_tile(c_in);
+    *tn = wgrad_bf16_tile(c_out);
+    p->ci_tiles = c_in / *tm;
+    p->co_tiles = c_out / *tn;
+    wgrad_chunks(n_out, (long long)kv * p->ci_tiles * p->co_tiles, 256, 256, p);
     return true;
 }
 
@@ -626,22 +823,44 @@ static void wgrad_plan(int n_out, int c_in, int c_out, int kv, WgParams *p, int 
     p->rows_per_chunk = ((n_out + chunks - 1) / chunks + 63) / 64 * 64;
     p->n_chunks = (n_out + p->rows_per_chunk - 1) / p->rows_per_chunk;
 }
+// the workspace holds the row-chunk partials of whichever kernel the flags select: size it for the larger plan
 extern "C" size_t cpd_conv_wgrad_workspace_bytes(int n_out, int c_in, int c_out, int kv) {
     if (n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0) return 0;
-    WgParams p; int va, vb;
+    WgParams p; int va, vb, tm, tn;
     wgrad_plan(n_out, c_in, c_out, kv, &p, &va, &vb);
-    return cpd_align((size_t)p.n_chunks * kv * c_in * c_out * sizeof(float));
+    int chunks = p.n_chunks;
+    if (wgrad_bf16_plan(n_out, c_in, c_out, kv, 2, &p, &tm, &tn) && p.n_chunks > chunks) chunks = p.n_chunks;
+    return cpd_align((size_t)chunks * kv * c_in * c_out * sizeof(float));
 }
+
+template <int TM>
+static void launch_wgrad_bf16(int tn, dim3 grid, hipStream_t s, const WgParams &p) {
+    if (tn == 128) wgrad_bf16_kernel<TM, 128><<<grid, 256, 0, s>>>(p);
+    else if (tn == 64) wgrad_bf16_kernel<TM, 64><<<grid, 256, 0, s>>>(p);
+    else wgrad_bf16_kernel<TM, 32><<<grid, 256, 0, s>>>(p);
+}
+
 extern "C" int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out, const int32_t *nbr,
-                              int kv, int n_out, float *dw_kio, int accumulate, void *ws, size_t ws_bytes, cpd_stream_t st) {
+                              int kv, int n_out, float *dw_kio, int flags, void *ws, size_t ws_bytes, cpd_stream_t st) {
     if (!in || !dy || !dw_kio || !ws || n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || (!nbr && kv != 1)) return CPD_ERR_ARG;
+    const int accumulate = flags & 1;
     WgParams p;
-    int va, vb;
-    wgrad_plan(n_out, c_in, c_out, kv, &p, &va, &vb);
-    if (ws_bytes < (size_t)p.n_chunks * kv * c_in * c_out * sizeof(float)) return CPD_ERR_WORKSPACE;
+    int va, vb, tm, tn;
     p.in = in; p.dy = dy; p.nbr = nbr; p.part = (float *)ws;
     p.in_ld = in_ld; p.dy_ld = dy_ld; p.c_in = c_in; p.c_out = c_out; p.kv = kv; p.n_out = n_out;
-    int tm, tn;
+    const size_t elems = (size_t)kv * c_in * c_out;
+    if (wgrad_bf16_plan(n_out, c_in, c_out, kv, flags, &p, &tm, &tn)) {
+        if (ws_bytes < (size_t)p.n_chunks * elems * sizeof(float)) return CPD_ERR_WORKSPACE;
+        if (p.n_chunks >= 65536 || kv >= 65536) return CPD_ERR_UNSUPPORTED;
+        const dim3 grid(p.ci_tiles * p.co_tiles, kv, p.n_chunks);
+        if (tm == 128) launch_wgrad_bf16<128>(tn, grid, cpd_s(st), p);
+        else if (tm == 64) launch_wgrad_bf16<64>(tn, grid, cpd_s(st), p);
+        else launch_wgrad_bf16<32>(tn, grid, cpd_s(st), p);
+        wgrad_reduce_kernel<<<cpd_div_up((long long)elems, 256), 256, 0, cpd_s(st)>>>(p.part, p.n_chunks, elems, dw_kio, accumulate);
+        return cpd_check_launch();
+    }
+    wgrad_plan(n_out, c_in, c_out, kv, &p, &va, &vb);
+    if (ws_bytes < (size_t)p.n_chunks * elems * sizeof(float)) return CPD_ERR_WORKSPACE;
     const bool aligned = ((((uintptr_t)in) | ((uintptr_t)dy)) & 15) == 0 && in_ld % 4 == 0 && dy_ld % 4 == 0;
     if (va == 0 && !aligned) {                        // tile kernel needs 16-byte rows: fall back to the wave kernel
         va = lanes_per_16(c_in); vb = lanes_per_16(c_out);
@@ -663,7 +882,6 @@ extern "C" int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float 
         if (blocks >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), 0, cpd_s(st), p);
     }
-    const size_t elems = (size_t)kv * c_in * c_out;
     wgrad_reduce_kernel<<<cpd_div_up((long long)elems, 256), 256, 0, cpd_s(st)>>>(p.part, p.n_chunks, elems, dw_kio, accumulate);
     return cpd_check_launch();
 }

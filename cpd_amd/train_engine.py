@@ -150,7 +150,7 @@ class _Conv:
         if self.mode == "up" and self.up > 1:
             u2 = self.up * self.up
             # dW[tap][co][ci] = sum_pix dz_up[map[tap][pix]][co] * x[pix][ci]  (roles of in/dy swapped)
-            tmp = train_ops.conv_wgrad(dz, self.c_bn, x, self.c_in, up_map, u2, n_out)
+            tmp = train_ops.conv_wgrad(dz, self.c_bn, x, self.c_in, up_map, u2, n_out, bf16x3=self.store.bf16x3)
             gw.view(self.c_in, u2, self.c_bn).copy_(tmp.permute(2, 0, 1))
             if not need_dx:
                 return None, dres
@@ -161,7 +161,7 @@ class _Conv:
             nbr_w = torch.arange(n_out, dtype=torch.int32, device=dz.device).view(1, -1)
         else:
             nbr_w = nbr
-        train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw)
+        train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, bf16x3=self.store.bf16x3)
         if not need_dx:
             return None, dres
         dx = ops.gather_conv(dz, self.c_out, self.pw_adj, nbr_adj, self.kv, n_in, self.c_in, None, None, add, False,

@@ -112,14 +112,14 @@ def relu_backward(dy, y):
     return dx
 
 
-def conv_wgrad(inp, c_in, dy, c_out, nbr, kv, n_out, dw=None, accumulate=False):
-    """dw[kv, c_in, c_out] (+)= sum_j inp[nbr[t][j]]^T dy[j]."""
+def conv_wgrad(inp, c_in, dy, c_out, nbr, kv, n_out, dw=None, accumulate=False, bf16x3=False):
+    """dw[kv, c_in, c_out] (+)= sum_j inp[nbr[t][j]]^T dy[j]; bf16x3: split-bf16 arithmetic (fp32-equivalent)."""
     if dw is None:
         dw = torch.empty((kv, c_in, c_out), dtype=torch.float32, device=inp.device)
         accumulate = False
     ws = _ws(lib().cpd_conv_wgrad_workspace_bytes(n_out, c_in, c_out, kv), inp.device)
     check(lib().cpd_conv_wgrad(_p(inp), _ld(inp), c_in, _p(dy), _ld(dy), c_out, ptr(nbr), kv, n_out, ptr(dw),
-                               int(bool(accumulate)), ptr(ws), ws.numel(), stream()), "cpd_conv_wgrad")
+                               int(bool(accumulate)) | (2 if bf16x3 else 0), ptr(ws), ws.numel(), stream()), "cpd_conv_wgrad")
     return dw
 
 

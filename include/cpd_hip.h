@@ -272,10 +272,13 @@ int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const f
 int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, int n, int c, float *dx,
                  int lddx, cpd_stream_t stream);
 /* Weight gradient of cpd_gather_conv: dw[t][ci][co] (+)= sum_j in[nbr[t][j]][ci] * dy[j][co]
- * (dense [kv][c_in][c_out] layout, the layout cpd_pack_weight consumes). fp32 MFMA, deterministic. */
+ * (dense [kv][c_in][c_out] layout, the layout cpd_pack_weight consumes). Deterministic (row-chunk
+ * partials in `ws`, summed in a fixed order). flags: bit 0 = accumulate into dw_kio, CPD_GC_BF16X3 =
+ * split-bf16 arithmetic (fp32-equivalent, as in cpd_gather_conv) when c_in and c_out are multiples
+ * of 32, with rows that lack the tap compacted away before staging; otherwise fp32 MFMA.        */
 size_t cpd_conv_wgrad_workspace_bytes(int n_out, int c_in, int c_out, int kv);
 int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out,
-                   const int32_t *nbr, int kv, int n_out, float *dw_kio, int accumulate, void *ws,
+                   const int32_t *nbr, int kv, int n_out, float *dw_kio, int flags, void *ws,
                    size_t ws_bytes, cpd_stream_t stream);
 /* Packed weights of the adjoint conv used for input gradients: Wd[t'][co][ci] = W[t][ci][co],
  * t = kv-1-t' if flip_taps (SubM / stride-1: the forward rulebook is its own transpose up to the

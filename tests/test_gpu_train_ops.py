@@ -92,6 +92,59 @@ def test_subm_conv_gradients_match_autograd(oracle, hip, cin, cout):
     np.testing.assert_allclose(dw2.cpu().numpy(), 2 * wt.grad.numpy(), rtol=1e-4, atol=4e-3)
 
 
+def wgrad_float64(x, dy, nbr):
+    out = np.zeros((nbr.shape[0], x.shape[1], dy.shape[1]))
+    for t in range(nbr.shape[0]):
+        j = np.nonzero(nbr[t] >= 0)[0]
+        out[t] = x[nbr[t, j]].astype(np.float64).T @ dy[j].astype(np.float64)
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,sites", [(32, 32, 2500), (32, 64, 2500), (64, 128, 2500), (128, 128, 9000), (128, 32, 2500),
+                                            (96, 160, 2500), (256, 64, 700)])
+def test_wgrad_split_bf16_is_fp32_equivalent(oracle, hip, cin, cout, sites):
+    """The split-bf16 weight gradient (flags CPD_GC_BF16X3): compacted pair ring, k-major staging, six bf16 products.
+    Against float64 it must be as accurate as the fp32-MFMA kernel (both accumulate in fp32)."""
+    rng = np.random.default_rng(cin + 3 * cout)
+    batch, shape = 2, [7, 40, 40]
+    idx = random_sites(rng, batch, shape, sites)
+    n = idx.shape[0]
+    nbr = oracle.subm_rulebook(idx, batch, shape, [3, 3, 3])
+    nbr[5] = -1                                     # a tap nobody has: its gradient is exactly zero
+    x = (rng.normal(size=(n, cin)) * np.exp(rng.normal(size=(n, 1)) * 2)).astype(np.float32)     # wide dynamic range
+    dy = rng.normal(size=(n, cout)).astype(np.float32)
+    want = wgrad_float64(x, dy, nbr)
+    nbr_d = dev(nbr)
+    got = T.conv_wgrad(dev(x), cin, dev(dy), cout, nbr_d, 27, n, bf16x3=True).cpu().numpy()
+    ref32 = T.conv_wgrad(dev(x), cin, dev(dy), cout, nbr_d, 27, n).cpu().numpy()
+    scale = np.abs(want).max()
+    err, err32 = np.abs(got - want).max() / scale, np.abs(ref32 - want).max() / scale
+    assert err <= max(2.0 * err32, 2e-7), (err, err32)
+    assert not got[5].any()
+    # accumulate + determinism (fixed-order chunk sum: bitwise repeatable)
+    again = T.conv_wgrad(dev(x), cin, dev(dy), cout, nbr_d, 27, n, bf16x3=True).cpu().numpy()
+    np.testing.assert_array_equal(got, again)
+    acc = T.conv_wgrad(dev(x), cin, dev(dy), cout, nbr_d, 27, n, dw=torch.from_numpy(got).cuda(), accumulate=True, bf16x3=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), 2 * got, rtol=1e-6, atol=1e-6 * scale)
+
+
+def test_wgrad_split_bf16_dense_and_1x1(hip):
+    """Dense pixel tables (borders only lack a tap) and the table-free 1x1 case, strided row pitch."""
+    rng = np.random.default_rng(12)
+    b, h, w, cin, cout = 2, 30, 33, 64, 128
+    nbr, _, _ = ops.rulebook_conv2d(b, h, w, 3, 3, 1, 1, "cuda")
+    n = b * h * w
+    buf = torch.from_numpy(rng.normal(size=(n, cin + 32)).astype(np.float32)).cuda()
+    x = buf[:, 32:]                                                              # row pitch != channel count
+    dy = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32)).cuda()
+    want = wgrad_float64(x.cpu().numpy(), dy.cpu().numpy(), nbr.cpu().numpy())
+    got = T.conv_wgrad(x, cin, dy, cout, nbr, 9, n, bf16x3=True).cpu().numpy()
+    assert np.abs(got - want).max() / np.abs(want).max() < 5e-7
+    one = T.conv_wgrad(x, cin, dy, cout, None, 1, n, bf16x3=True).cpu().numpy()
+    want1 = x.cpu().numpy().astype(np.float64).T @ dy.cpu().numpy().astype(np.float64)
+    assert np.abs(one[0] - want1).max() / np.abs(want1).max() < 5e-7
+
+
 def test_strided_sparse_conv_gradients(oracle, hip):
     rng = np.random.default_rng(5)
     batch, shape, cin, cout = 2, [9, 20, 22], 32, 64
