@@ -868,15 +868,21 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
         if (const char *e = getenv("CPD_GC_ROWWAVE_BN")) force_bn = atoi(e);
         if ((force_bn == 64 || force_bn == 128) && c_out % force_bn == 0) { pl.use_wg = 3; pl.a = 128; pl.b = force_bn; return pl; }
         // widest column tile that still gives every CU a workgroup: a narrower tile re-gathers the rows once per
-        // column tile, which small layers (the 1/4 and 1/8 stages of a single frame) can afford
-        int narrow = 1;
-        if (const char *e = getenv("CPD_GC_ROWWAVE_NARROW")) narrow = atoi(e);
+        // column tile, which small layers (the 1/4 and 1/8 stages of a single frame) can afford; below that, the
+        // narrowest tile as long as it covers half the chip (sweep: train step and single-frame bench, +-1%)
+        long long rw_min = 256, rw_floor = 128;
+        if (const char *e = getenv("CPD_GC_ROWWAVE_MIN")) rw_min = atoll(e);
+        if (const char *e = getenv("CPD_GC_ROWWAVE_FLOOR")) rw_floor = atoll(e);
+        const long long row_tiles = (n_out + 127) / 128;
         for (int b = bn; b >= 32; b >>= 1) {
-            if ((long long)((n_out + 127) / 128) * (c_out / b) >= bf16_min_wgs) {
+            if (row_tiles * (c_out / b) >= rw_min) {
                 pl.use_wg = 3; pl.a = 128; pl.b = b;
                 return pl;
             }
-            if (!narrow) break;
+        }
+        if (row_tiles * (c_out / 32) >= rw_floor) {
+            pl.use_wg = 3; pl.a = 128; pl.b = 32;
+            return pl;
         }
     }
     if (allow_bf16 && (flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 64 == 0) {
