@@ -421,7 +421,9 @@ __device__ __forceinline__ void split3(const f32x4 &x, bf16x4 &h, bf16x4 &m, bf1
 }
 
 template <int BM, int BN, bool DB>
-__global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BM == 128 && BN == 128 && !DB) ? 3 : 1, (BM == 128 && BN == 128 && !DB) ? 3 : 8)))
+tile_conv_bf16_kernel(GcParams p) {
+    constexpr bool OCC3 = BM == 128 && BN == 128 && !DB;   // the variant squeezed into 3 waves per SIMD (168 registers)
     constexpr int MS = BM / 32, NT = BN / 32;       // 2 x 2 waves, wave tile (BM/2) x (BN/2)
     constexpr int AJ = BM / 32;                     // fp32 A pieces (4 channels) staged per thread per stage
     constexpr int BJ = 3 * BN / 64;                 // 16-byte B pieces staged per thread per stage
@@ -463,6 +465,17 @@ __global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
     f32x4 ra[AJ];
     bool rz[AJ];                    // "no neighbour": applied when the piece is split, so that nothing
     f32x4u rbv[BJ];                 // between the loads and the MFMAs of the current stage waits on them
+    // OCC3: the weights are fetched AFTER the MFMA block, so their 24 registers are not live across it
+    auto stage_load_b = [&](int st) {
+        const int t = st / sk, kk = st - t * sk;
+        const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int id = j * 256 + tid;        // slot in the B stage image: (piece*4 + g)*BN + n
+            const int pg = id / BN, n = id - pg * BN;
+            rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+        }
+    };
     auto stage_load = [&](int st) {
         const int t = st / sk, kk = st - t * sk;
 #pragma unroll
@@ -471,13 +484,7 @@ __global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
             ra[j] = load_a<true>(p, id, kk * 32 + a_piece * 4);
             rz[j] = id < 0;
         }
-        const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int id = j * 256 + tid;        // slot in the B stage image: (piece*4 + g)*BN + n
-            const int pg = id / BN, n = id - pg * BN;
-            rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
-        }
+        if (!OCC3) stage_load_b(st);
     };
     auto stage_store = [&](int buf) {
         char *sa = smem + (DB ? buf : 0) * STAGE;
@@ -498,6 +505,7 @@ __global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
     };
 
     stage_load(0);
+    if (OCC3) stage_load_b(0);
     stage_store(0);
     __syncthreads();
     for (int st = 0; st < n_stage; ++st) {
@@ -513,36 +521,42 @@ __global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
         {
             const char *sa = smem + (DB ? (st & 1) : 0) * STAGE;
             const char *sb = sa + 3 * A_IMG;
-            bf16x8 ah[MS], am[MS], al[MS];
+            constexpr int SH = OCC3 ? 2 : MS;   // row sub-tiles whose fragments are live at once
 #pragma unroll
-            for (int s = 0; s < MS; ++s) {
-                const int m = wr * (BM / 2) + 16 * s + r;
-                const char *src = sa + ((g * BM + (m ^ (2 * g))) << 4);
-                ah[s] = *reinterpret_cast<const bf16x8 *>(src);
-                am[s] = *reinterpret_cast<const bf16x8 *>(src + A_IMG);
-                al[s] = *reinterpret_cast<const bf16x8 *>(src + 2 * A_IMG);
-            }
+            for (int s0 = 0; s0 < MS; s0 += SH) {
+                bf16x8 ah[SH], am[SH], al[SH];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = wc * (BN / 2) + 16 * nt + r;
-                const char *src = sb + ((g * BN + n) << 4);
-                const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
-                const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + 4 * BN * 16);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(src + 8 * BN * 16);
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {      // smallest terms first
-                    f32x4 c = acc[s][nt];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
-                    acc[s][nt] = c;
+                for (int s = 0; s < SH; ++s) {
+                    const int m = wr * (BM / 2) + 16 * (s0 + s) + r;
+                    const char *src = sa + ((g * BM + (m ^ (2 * g))) << 4);
+                    ah[s] = *reinterpret_cast<const bf16x8 *>(src);
+                    am[s] = *reinterpret_cast<const bf16x8 *>(src + A_IMG);
+                    al[s] = *reinterpret_cast<const bf16x8 *>(src + 2 * A_IMG);
                 }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = wc * (BN / 2) + 16 * nt + r;
+                    const char *src = sb + ((g * BN + n) << 4);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + 4 * BN * 16);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(src + 8 * BN * 16);
+#pragma unroll
+                    for (int s = 0; s < SH; ++s) {      // smallest terms first
+                        f32x4 c = acc[s0 + s][nt];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
+                        acc[s0 + s][nt] = c;
+                    }
+                }
+                if (SH < MS) asm volatile("" ::: "memory");     // keep the halves' LDS reads apart (register budget)
             }
         }
         if (!DB) __syncthreads();          // single buffer: everyone is done reading before it is overwritten
+        if (OCC3 && nx < n_stage) stage_load_b(nx);
         if (nx < n_stage) stage_store(nx & 1);
         __syncthreads();
     }
@@ -555,8 +569,10 @@ __global__ void __launch_bounds__(256) tile_conv_bf16_kernel(GcParams p) {
 // blocks straight into registers (4 lanes per row, 32 B each) and splits them there -- no row is
 // fetched or split twice. Taps that none of the workgroup's eight 16-row sub-tiles has are not
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
+// (BN = 128 sits 6 registers above the 3-waves-per-SIMD budget without the hint; it fits without spilling)
 template <int BN>
-__global__ void __launch_bounds__(256) rowwave_conv_bf16_kernel(GcParams p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
+rowwave_conv_bf16_kernel(GcParams p) {
     constexpr int MS = 2, NT = BN / 16;
     constexpr int B_SLOTS = 3 * 4 * BN;        // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
@@ -886,7 +902,8 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
         }
     }
     if (allow_bf16 && (flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 64 == 0) {
-        const int bn = c_out % 128 == 0 ? 128 : 64;
+        int bn = c_out % 128 == 0 ? 128 : 64;
+        if (const char *e = getenv("CPD_GC_BF16_BN")) { if (atoi(e) == 64) bn = 64; }
         if ((long long)((n_out + 127) / 128) * (c_out / bn) >= bf16_min_wgs) {
             pl.use_wg = 2; pl.a = 128; pl.b = bn;
             return pl;
