@@ -466,8 +466,10 @@ tile_conv_bf16_kernel(GcParams p) {
     bool rz[AJ];                    // "no neighbour": applied when the piece is split, so that nothing
     f32x4u rbv[BJ];                 // between the loads and the MFMAs of the current stage waits on them
     // OCC3: the weights are fetched AFTER the MFMA block, so their 24 registers are not live across it
+    // stage st = (32-channel block kk, tap t), TAP INNER: the nine taps of one channel block re-read (nearly) the
+    // same 128-byte row segments back to back, so the re-reads hit L2 instead of going out to the fabric
     auto stage_load_b = [&](int st) {
-        const int t = st / sk, kk = st - t * sk;
+        const int kk = st / p.kv, t = st - kk * p.kv;
         const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
@@ -477,7 +479,7 @@ tile_conv_bf16_kernel(GcParams p) {
         }
     };
     auto stage_load = [&](int st) {
-        const int t = st / sk, kk = st - t * sk;
+        const int kk = st / p.kv;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int id = a_ok[j] ? idx_cur[j] : -1;
@@ -504,19 +506,23 @@ tile_conv_bf16_kernel(GcParams p) {
         for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
     };
 
+    // the rulebook column of stage st + 1 is fetched while stage st's rows are (one step ahead of its use)
+    auto idx_load = [&](int st) {
+        if (!p.nbr) return;
+        const int t = st % p.kv;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr[(size_t)t * p.n_out + a_rowc[j]];
+    };
     stage_load(0);
+    if (n_stage > 1) idx_load(1);
     if (OCC3) stage_load_b(0);
     stage_store(0);
     __syncthreads();
     for (int st = 0; st < n_stage; ++st) {
         const int nx = st + 1;
         if (nx < n_stage) {
-            const int t_nx = nx / sk;
-            if (nx - t_nx * sk == 0) {
-#pragma unroll
-                for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr[(size_t)t_nx * p.n_out + a_rowc[j]];
-            }
             stage_load(nx);
+            if (nx + 1 < n_stage) idx_load(nx + 1);
         }
         {
             const char *sa = smem + (DB ? (st & 1) : 0) * STAGE;
@@ -571,7 +577,7 @@ tile_conv_bf16_kernel(GcParams p) {
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
 // (BN = 128 sits 6 registers above the 3-waves-per-SIMD budget without the hint; it fits without spilling)
 template <int BN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 8)))
 rowwave_conv_bf16_kernel(GcParams p) {
     constexpr int MS = 2, NT = BN / 16;
     constexpr int B_SLOTS = 3 * 4 * BN;        // 16-byte B pieces of one stage
