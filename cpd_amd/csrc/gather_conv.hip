@@ -421,9 +421,9 @@ __device__ __forceinline__ void split3(const f32x4 &x, bf16x4 &h, bf16x4 &m, bf1
 }
 
 template <int BM, int BN, bool DB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BM == 128 && BN == 128 && !DB) ? 3 : 1, (BM == 128 && BN == 128 && !DB) ? 3 : 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BM == 128 && !DB) ? (BN == 128 ? 3 : 4) : 1, (BM == 128 && !DB) ? (BN == 128 ? 3 : 4) : 8)))
 tile_conv_bf16_kernel(GcParams p) {
-    constexpr bool OCC3 = BM == 128 && BN == 128 && !DB;   // the variant squeezed into 3 waves per SIMD (168 registers)
+    constexpr bool OCC3 = BM == 128 && !DB;   // the variant squeezed into 3 waves per SIMD (168 registers)
     constexpr int MS = BM / 32, NT = BN / 32;       // 2 x 2 waves, wave tile (BM/2) x (BN/2)
     constexpr int AJ = BM / 32;                     // fp32 A pieces (4 channels) staged per thread per stage
     constexpr int BJ = 3 * BN / 64;                 // 16-byte B pieces staged per thread per stage
