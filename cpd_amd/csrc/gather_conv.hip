@@ -241,14 +241,18 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
                 else R.b[nt] = *reinterpret_cast<const f32x4 *>(wk + (size_t)nt * 64);
             }
         };
-        // move the load cursor to the next (tap, chunk); t_cur = -1 once the last step is loaded
+        // move the load cursor to the next (chunk, tap) -- taps INNER, so the taps of one 16-channel chunk re-read
+        // neighbouring rows' same 64-byte segments back to back (L2 hits rather than fabric traffic on the
+        // multi-chunk dense layers that land here). t_cur = -1 once the last step is loaded
         // (the cursor then keeps pointing at valid memory: the trailing load is a harmless dummy)
+        const int t_first = t_cur;
         auto advance = [&]() {
-            if (++kc_cur == p.kc) {
-                kc_cur = 0;
-                t_cur = next_tap(t_cur);
-                if (t_cur >= 0) t_ld = t_cur;
+            t_cur = next_tap(t_cur);
+            if (t_cur < 0 && kc_cur + 1 < p.kc) {
+                ++kc_cur;
+                t_cur = t_first;
             }
+            if (t_cur >= 0) t_ld = t_cur;
         };
         auto mma = [&](StepRegs<MS, NT> &R) {
             if constexpr (MS == 1) {
