@@ -97,7 +97,7 @@ class ConvProfiler:
         prof = self
 
         def wrapped(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
-            kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False), kw.get("bf16x3", False))
+            kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False), kw.get("bf16x3", False), nbr)
             flops = 2.0 * prof._pairs(nbr, n_out, c_in, c_out) * c_in * c_out
             if kw.get("out") is None:          # allocate before the window: an allocator miss (hipMalloc) stalls the host,
                 kw["out"] = torch.empty((n_out, c_out), dtype=torch.float32, device=inp.device)   # and the GPU idles meanwhile

@@ -28,6 +28,8 @@
 // Work items are laid out so each XCD's L2 sees a contiguous band of output rows (A halo reuse)
 // while all XCDs stream the same L2-resident weights.
 #include <stdlib.h>
+#include <string.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -54,6 +56,7 @@ struct GcParams {
     int kv, n_out, c_out, ntot, np;  // np = padded columns (16*ntot)
     int res_ld, relu, out_ld, col_group;
     int n_rb, n_cb, items, n_sub;
+    int img_h, img_w;         // window kernel only: the rows are frames x img_h x img_w pixels
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -573,6 +576,168 @@ tile_conv_bf16_kernel(GcParams p) {
     epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
 }
 
+// Split-bf16 kernel for the dense 3x3 / stride 1 / pad 1 convolutions (BaseBEVBackbone blocks, CenterHead convs) over
+// channels-last pixel rows [frames * H * W, C], WITHOUT a rulebook: the input row of output row R at tap (dy, dx) is
+// R + dy*W + dx whenever that pixel exists, so the three dx taps of one dy read the same 130-row WINDOW
+// [row0 + dy*W - 1, row0 + dy*W + 128] shifted by one row. The window is gathered, split and written to LDS ONCE per
+// (32-channel block, dy) and the three taps read their fragments from it at row offsets 0, 1, 2: a third of the
+// gathers, splits and LDS writes of tile_conv_bf16_kernel and no rulebook reads at all. Taps that leave the image
+// (y + dy or x + dx out of range; also what keeps frames apart) are zeroed on the A fragments of the affected
+// lanes -- a wave-uniform branch that is taken for ~1 in 6 (sub-tile, dx != 0) pairs at W = 188.
+// Same tile, fragment layout, XOR-2g swizzle (the image has 136 rows per k-group so that 129 ^ 6 stays inside), register
+// diet (two row sub-tiles live at a time, weights fetched after the MFMA block) and occupancy as tile_conv_bf16_kernel.
+template <int BN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
+window_conv_bf16_kernel(GcParams p) {
+    constexpr int BM = 128, MS = 4, NT = BN / 32;
+    constexpr int WROWS = BM + 2, BMW = BM + 8;
+    constexpr int AJ = (WROWS * 8 + 255) / 256;     // fp32 A pieces (4 channels) per thread per window
+    constexpr int BJ = 3 * BN / 64;                 // 16-byte B pieces per thread per stage
+    constexpr int A_IMG = BMW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const sa = smem;
+    char *const sb = smem + 3 * A_IMG;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
+    const int row0 = rb * BM, col0 = cb * BN;
+
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // which of the four directions exist for this lane's row of sub-tile s: bits 4s + {0 up, 1 down, 2 left, 3 right}
+    uint32_t dir_ok = 0;
+    {
+        const int hw = p.img_h * p.img_w;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) {
+            const int pix = (row0 + wr * (BM / 2) + 16 * s + r) % hw;
+            const int y = pix / p.img_w, x = pix - y * p.img_w;
+            const uint32_t b = (y > 0 ? 1u : 0u) | (y < p.img_h - 1 ? 2u : 0u) | (x > 0 ? 4u : 0u) | (x < p.img_w - 1 ? 8u : 0u);
+            dir_ok |= b << (4 * s);
+        }
+    }
+
+    const int a_piece = tid & 7;   // 4 channels: k-group a_piece >> 1, half a_piece & 1
+    const int a_row = tid >> 3;    // window row, + 32*j
+    const int sk = p.c_in >> 5;
+    // stage st = (32-channel block st / 9, tap st % 9): taps inner
+    const size_t b_stage = (size_t)3 * 4 * p.np * 16;
+
+    f32x4 ra[AJ];
+    f32x4u rbv[BJ];
+    auto load_window = [&](int kk, int dy) {
+        const long long base = (long long)row0 + (long long)dy * p.img_w - 1;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int w = a_row + 32 * j;
+            if (AJ * 32 <= WROWS || w < WROWS) {
+                long long rr = base + w;                          // rows outside the tensor only feed masked taps
+                rr = rr < 0 ? 0 : (rr >= p.n_out ? (long long)p.n_out - 1 : rr);
+                ra[j] = *reinterpret_cast<const f32x4 *>(p.in + (size_t)rr * p.in_ld + kk * 32 + a_piece * 4);
+            }
+        }
+    };
+    auto store_window = [&]() {
+        const int ag = a_piece >> 1, half = a_piece & 1;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int w = a_row + 32 * j;
+            if (AJ * 32 <= WROWS || w < WROWS) {
+                bf16x4 h, mm, l;
+                split3(ra[j], h, mm, l);
+                char *dst = sa + (((ag * BMW + (w ^ (2 * ag))) << 4) + half * 8);
+                *reinterpret_cast<bf16x4 *>(dst) = h;
+                *reinterpret_cast<bf16x4 *>(dst + A_IMG) = mm;
+                *reinterpret_cast<bf16x4 *>(dst + 2 * A_IMG) = l;
+            }
+        }
+    };
+    auto load_weights = [&](int st) {
+        const int kk = st / 9, t = st - kk * 9;
+        const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int id = j * 256 + tid;        // slot in the B stage image: (piece*4 + g)*BN + n
+            const int pg = id / BN, n = id - pg * BN;
+            rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+        }
+    };
+    auto store_weights = [&]() {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+    };
+
+    load_window(0, -1);
+    load_weights(0);
+    store_window();
+    store_weights();
+    __syncthreads();
+    const int n_stage = 9 * sk;
+    for (int st = 0; st < n_stage; ++st) {
+        const int t = st % 9, dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        const int nx = st + 1;
+        const bool new_window = nx < n_stage && nx % 3 == 0;     // the next stage starts another dy (or channel block)
+        if (new_window) load_window(nx / 9, (nx % 9) / 3 - 1);   // in flight under this stage's MFMAs
+        {
+            const bf16x8 zero = {};
+#pragma unroll
+            for (int s0 = 0; s0 < MS; s0 += 2) {
+                bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int w = wr * (BM / 2) + 16 * (s0 + s) + r + 1 + dx;
+                    const char *src = sa + ((g * BMW + (w ^ (2 * g))) << 4);
+                    ah[s] = *reinterpret_cast<const bf16x8 *>(src);
+                    am[s] = *reinterpret_cast<const bf16x8 *>(src + A_IMG);
+                    al[s] = *reinterpret_cast<const bf16x8 *>(src + 2 * A_IMG);
+                    const uint32_t b = dir_ok >> (4 * (s0 + s));
+                    const bool ok = (dy < 0 ? (b & 1u) : dy > 0 ? (b & 2u) : 1u) && (dx < 0 ? (b & 4u) : dx > 0 ? (b & 8u) : 1u);
+                    if (!__all(ok)) {
+                        ah[s] = ok ? ah[s] : zero;
+                        am[s] = ok ? am[s] : zero;
+                        al[s] = ok ? al[s] : zero;
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = wc * (BN / 2) + 16 * nt + r;
+                    const char *src = sb + ((g * BN + n) << 4);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + 4 * BN * 16);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(src + 8 * BN * 16);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {      // smallest terms first
+                        f32x4 c = acc[s0 + s][nt];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
+                        acc[s0 + s][nt] = c;
+                    }
+                }
+                asm volatile("" ::: "memory");     // keep the halves' LDS reads apart (register budget)
+            }
+        }
+        __syncthreads();                   // everyone is done reading the images before they are overwritten
+        if (nx < n_stage) {
+            load_weights(nx);
+            if (new_window) store_window();
+            store_weights();
+        }
+        __syncthreads();
+    }
+    epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
+}
+
 // Split-bf16 kernel for SPARSE layers: a workgroup owns 128 output rows x BN columns, wave w the
 // rows [32w, 32w+32) x all BN columns. Only the weights go through LDS (one (tap, 32-channel)
 // block of Pb per stage, shared by the four waves); a wave gathers ITS rows' 128-byte channel
@@ -1065,5 +1230,47 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     p.items = p.n_rb * p.n_cb;
     int blocks = (p.items + 3) / 4;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, cpd_s(stream), p);
+    return cpd_check_launch();
+}
+
+// ---- dense 3x3 / stride 1 / pad 1 over pixel rows, no rulebook (window_conv_bf16_kernel) ----
+static int window_bn(int frames, int h, int w, int c_in, int c_out, int flags) {
+    int on = (flags & 2) != 0;
+    if (const char *e = getenv("CPD_GC_BF16X3")) on = atoi(e);
+    if (const char *e = getenv("CPD_GC_WINDOW")) on = on && atoi(e);
+    if (!on || frames <= 0 || h < 2 || w < 2 || c_in <= 0 || c_out <= 0 || c_in % 32 || c_out % 64) return 0;
+    const long long rows = (long long)frames * h * w;
+    if (rows >= (1ll << 31)) return 0;
+    const int bn = c_out % 128 == 0 ? 128 : 64;
+    long long min_wgs = 600;                    // below that the rulebook path's 64-row tiles fill the chip better
+    if (const char *e = getenv("CPD_GC_BF16_MIN")) min_wgs = atoll(e);
+    if (((rows + 127) / 128) * (c_out / bn) < min_wgs) return 0;
+    return bn;
+}
+extern "C" int cpd_conv3x3_rows_supported(int frames, int h, int w, int c_in, int c_out, int flags) {
+    return window_bn(frames, h, w, c_in, c_out, flags) != 0;
+}
+extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
+                                const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
+                                int out_ld, int flags, cpd_stream_t stream) {
+    if (!in || !packed_w || !out || frames <= 0 || h <= 0 || w <= 0 || c_in <= 0 || c_out <= 0 || in_ld < c_in || out_ld < c_out ||
+        (residual && res_ld < c_out))
+        return CPD_ERR_ARG;
+    const int bn = window_bn(frames, h, w, c_in, c_out, flags);
+    if (!bn || in_ld % 4 || (((uintptr_t)in) & 15)) return CPD_ERR_UNSUPPORTED;
+    GcParams p;
+    memset(&p, 0, sizeof(p));
+    const int n_out = frames * h * w;
+    p.in = in; p.w = packed_w; p.wb = packed_w + packed_f32_floats(9, c_in, c_out);
+    p.scale = scale; p.shift = shift; p.residual = residual; p.out = out;
+    p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
+    p.kv = 9; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
+    p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld;
+    p.n_sub = (n_out + 15) / 16;
+    p.n_rb = (n_out + 127) / 128; p.n_cb = c_out / bn; p.items = p.n_rb * p.n_cb;
+    p.img_h = h; p.img_w = w;
+    const size_t lds = 3 * (size_t)(128 + 8) * 64 + 3 * (size_t)bn * 64;
+    if (bn == 128) hipLaunchKernelGGL((window_conv_bf16_kernel<128>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+    else hipLaunchKernelGGL((window_conv_bf16_kernel<64>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
     return cpd_check_launch();
 }

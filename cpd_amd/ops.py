@@ -211,6 +211,16 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     if residual is not None:
         assert residual.dim() == 2 and residual.stride(1) == 1
         res_ld = residual.stride(0)
+    flags = (1 if dense else 0) | (2 if bf16x3 else 0)
+    image = getattr(nbr, "image", None)             # 3x3 / stride 1 / pad 1 pixel table: the rulebook-free window kernel
+    if image is not None and out_row_map is None and kv == 9 and n_out == image[0] * image[1] * image[2] and inp.shape[0] == n_out:
+        rc = lib().cpd_conv3x3_rows(
+            ctypes.c_void_p(inp.data_ptr()), inp.stride(0), image[0], image[1], image[2], c_in, ptr(packed_w), c_out,
+            ptr(scale), ptr(shift), ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld,
+            int(bool(relu)), ctypes.c_void_p(out.data_ptr()), out.stride(0), flags, stream())
+        if rc != -4:                                # CPD_ERR_UNSUPPORTED: shape / alignment / size -> the table path below
+            check(rc, "cpd_conv3x3_rows")
+            return out
     check(lib().cpd_gather_conv(
         ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w),
         ptr(nbr), ptr(getattr(nbr, "tapmask", None)), kv, n_out, c_out, ptr(scale), ptr(shift),
@@ -246,6 +256,8 @@ def rulebook_conv2d(batch, h, w, kh, kw, stride, pad, device):
     wo = (w + 2 * pad - kw) // stride + 1
     nbr = torch.empty((kh * kw, batch * ho * wo), dtype=torch.int32, device=device)
     check(lib().cpd_rulebook_conv2d(batch, h, w, kh, kw, stride, pad, ptr(nbr), stream()), "cpd_rulebook_conv2d")
+    if (kh, kw, stride, pad) == (3, 3, 1, 1):
+        nbr.image = (batch, h, w)       # gather_conv may then run the rulebook-free kernel (cpd_conv3x3_rows)
     return nbr, ho, wo
 
 
@@ -351,8 +363,12 @@ def boxes_iou_bev_cpu(a, b):
     return out
 
 
-def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False):
-    """Name of the kernel instantiation cpd_gather_conv will run for this problem."""
+def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None):
+    """Name of the kernel instantiation gather_conv will run for this problem (`nbr`: the table it would be given)."""
+    image = getattr(nbr, "image", None)
+    if image is not None and n_out == image[0] * image[1] * image[2] and in_ld % 4 == 0 and lib().cpd_conv3x3_rows_supported(
+            image[0], image[1], image[2], int(c_in), int(c_out), (1 if dense else 0) | (2 if bf16x3 else 0)):
+        return "window_conv_bf16_kernel<%d>" % (128 if c_out % 128 == 0 else 64)
     wg, a, b, vec = (ctypes.c_int(0) for _ in range(4))
     check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), (1 if dense else 0) | (2 if bf16x3 else 0),
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),

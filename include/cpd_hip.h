@@ -149,6 +149,21 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
 #define CPD_GC_BF16X3 2 /* flags: the rulebook has (almost) no -1 entries -- prefer the LDS-tiled
                           workgroup kernel over the tap-skipping wave kernel */
 
+/* 3x3 / stride 1 / pad 1 convolution (+ folded BN / bias, residual, ReLU: same epilogue as
+ * cpd_gather_conv) over channels-last pixel rows in[frames*h*w][c_in] WITHOUT a rulebook -- the
+ * nn.Conv2d(3, padding=1) layers of BaseBEVBackbone (base_bev_backbone.py:38-62) and of
+ * CenterHead / SeparateHead (center_head.py:24-52,78-90). The input row of output row R at tap
+ * (dy, dx) is R + dy*w + dx when that pixel exists, so the three dx taps share one gathered and
+ * split 130-row window per (32-channel block, dy). packed_w = cpd_pack_weight image of the
+ * [9][c_in][c_out] weights (tap = ky*3 + kx). Split-bf16 arithmetic only: returns
+ * CPD_ERR_UNSUPPORTED unless flags has CPD_GC_BF16X3, c_in % 32 == 0, c_out % 64 == 0, `in` rows are
+ * 16-byte aligned and the problem fills the chip (cpd_conv3x3_rows_supported tells, pointers aside);
+ * the caller then uses cpd_rulebook_conv2d + cpd_gather_conv, which computes the same thing.     */
+int cpd_conv3x3_rows_supported(int frames, int h, int w, int c_in, int c_out, int flags);
+int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c_in,
+                     const float *packed_w, int c_out, const float *scale, const float *shift,
+                     const float *residual, int res_ld, int relu, float *out, int out_ld, int flags,
+                     cpd_stream_t stream);
 /* Introspection for benchmarks/profilers: which kernel instantiation cpd_gather_conv runs for
  * this problem: wg=1 -> tile_conv_kernel<a,b> (a x b workgroup tile), wg=0 ->
  * gather_conv_kernel<a,b,vec> ((16a) x (16b) wave tile; vec = 16-byte A pieces). HOST only.  */

@@ -191,3 +191,42 @@ def test_split_bf16_conv_is_fp32_accurate(hip, cin, cout, k, stride):
     small = ops.gather_conv(x * 1e-4, cin, pw, nbr, kv, n_out, cout, dense=True, bf16x3=True)
     e_small = (small[rows].double() - ref * 1e-4).abs().max().item()
     assert e_small <= 1.5e-4 * max(e_fast, e_exact) + 1e-12, (e_small, e_fast)
+
+
+@pytest.mark.parametrize("cin,cout,batch,h,w", [(128, 128, 3, 188, 188), (256, 256, 5, 94, 94), (64, 320, 2, 188, 188),
+                                                 (512, 64, 3, 188, 188), (32, 64, 3, 131, 200)])
+def test_window_conv_matches_the_table_path(hip, cin, cout, batch, h, w):
+    """cpd_conv3x3_rows (no rulebook: one gathered + split window per dy, image borders masked on the fragments)
+    against cpd_gather_conv on the pixel table, with the full epilogue, and against float64 on sampled rows --
+    rows at image corners / edges / frame boundaries included."""
+    from cpd_amd import ops
+    from cpd_amd._lib import lib
+    torch.manual_seed(cin * 3 + cout)
+    nbr, ho, wo = ops.rulebook_conv2d(batch, h, w, 3, 3, 1, 1, "cuda")
+    assert (ho, wo) == (h, w) and nbr.image == (batch, h, w)
+    n = batch * h * w
+    assert lib().cpd_conv3x3_rows_supported(batch, h, w, cin, cout, 3) == 1
+    assert ops.gather_conv_tile(n, cin, cout, cin, dense=True, bf16x3=True, nbr=nbr).startswith("window_conv_bf16_kernel")
+    x = torch.randn(n, cin, device="cuda") * 2.0
+    wgt = torch.randn(9, cin, cout, device="cuda") * (2.0 / (9 * cin)) ** 0.5
+    pw = ops.pack_weight(wgt)
+    scale = torch.rand(cout, device="cuda") + 0.5
+    shift = torch.randn(cout, device="cuda")
+    res = torch.randn(n, cout, device="cuda")
+    got = ops.gather_conv(x, cin, pw, nbr, 9, n, cout, scale, shift, res, True, dense=True, bf16x3=True)
+    plain = nbr.clone()                                  # same table without the geometry tag -> rulebook kernels
+    want = ops.gather_conv(x, cin, pw, plain, 9, n, cout, scale, shift, res, True, dense=True, bf16x3=True)
+    assert torch.allclose(got, want, rtol=1e-5, atol=2e-5), (got - want).abs().max().item()
+    edge = [0, 1, w - 1, w, 2 * w - 1, (h - 1) * w, h * w - 1, h * w, h * w + w - 1, n - w, n - 1, n // 2, 127, 128, 129]
+    rows = torch.cat([torch.tensor(edge, device="cuda"), torch.randint(0, n, (1024,), device="cuda")])
+    idx = nbr[:, rows].long()
+    xp = torch.cat([x, x.new_zeros(1, cin)]).double()
+    ref = sum(xp[torch.where(idx[t] < 0, n, idx[t])] @ wgt[t].double() for t in range(9))
+    ref = torch.relu(ref * scale.double() + shift.double() + res[rows].double())
+    assert (got[rows].double() - ref).abs().max().item() <= 1e-4
+    # strided input / output rows (the BEV concat buffer is written and read in column slices)
+    xin = torch.randn(n, cin + 32, device="cuda")
+    buf = torch.zeros(n, cout + 64, device="cuda")
+    ops.gather_conv(xin[:, 32:], cin, pw, nbr, 9, n, cout, dense=True, bf16x3=True, out=buf[:, 64:])
+    want2 = ops.gather_conv(xin[:, 32:], cin, pw, plain, 9, n, cout, dense=True, bf16x3=True)
+    assert torch.allclose(buf[:, 64:], want2, rtol=1e-5, atol=2e-5) and not buf[:, :64].any()
