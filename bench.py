@@ -230,6 +230,8 @@ def cpu_baseline(cfg, sd, points_np):
     from oracle import Oracle
     o = Oracle()
     cores = os.cpu_count() or 1
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():      # `OMP_NUM_THREADS=1 python bench.py` gives the 1-thread figure
+        cores = min(cores, max(1, int(os.environ["OMP_NUM_THREADS"])))
     # one untimed voxelizer call so that, as in the reference's generator object, the dense lookup
     # volume already exists (it is allocated once per worker, data_processor.py:133-144)
     o.voxelize(points_np[:1000], cfg.voxel_size, cfg.point_cloud_range, cfg.max_points_per_voxel, cfg.max_voxels)
