@@ -671,6 +671,157 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
     p[i] = w;
 }
 
+// ---------------------------------------------------------------------------------------------
+// CenterHead.get_loss (center_head.py:225-250) fused with its gradient: CornerNet focal loss on the
+// clamped sigmoid of the heatmap logits (loss_utils.py:265-300) + masked L1 on the regression maps
+// gathered at the object pixels (loss_utils.py:315-386). Three launches, deterministic:
+//   focal_partial: one pass over the B*H*W*C logits -> un-normalised d(loss)/d(logit) in d_rows and
+//                  per-block partial sums (pos loss, neg loss, positives);
+//   focal_final:   one block sums the partials in a fixed order (double) -> hm loss and 1/num_pos;
+//   loss_finish:   scales the heatmap gradient columns, adds the regression gradients (one thread per
+//                  (sample, box dimension) walks the objects in order: no atomics) and the loss parts.
+// ---------------------------------------------------------------------------------------------
+struct ClParams {
+    const float *rows;      // head outputs [B*HW][ld]
+    const float *heat;      // targets [B][C][HW]
+    const float *target;    // [B][K][8]
+    const long long *inds, *masks;   // [B][K]
+    float *d_rows;          // [B*HW][ld]
+    float *losses;          // [3] total, hm, loc
+    double *part;           // [blocks][3]
+    double *fin;            // [4] pos loss, neg loss, positives, scale
+    int ld, batch, hw, num_classes, hm_col, k;
+    float cw[8];
+    float loc_weight, cls_weight;
+};
+
+__global__ void __launch_bounds__(256) focal_partial_kernel(ClParams p) {
+    __shared__ double sm[3][256];
+    const long long total = (long long)p.batch * p.hw * p.ld;      // one thread per (row, column) of d_rows
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double pos = 0.0, neg = 0.0, cnt = 0.0;
+    if (i < total) {
+        const long long row = i / p.ld;
+        const int col = (int)(i - row * p.ld);
+        float grad = 0.f;
+        const int c = col - p.hm_col;
+        if (c >= 0 && c < p.num_classes) {
+            const long long b = row / p.hw, pix = row - b * p.hw;
+            const float x = p.rows[i];
+            const float sg = 1.0f / (1.0f + expf(-x));
+            const float lo = 1e-4f, hi = 1.0f - 1e-4f;
+            const float pr = fminf(fmaxf(sg, lo), hi);              // torch.clamp(sigmoid, 1e-4, 1 - 1e-4)
+            const float dpdx = (sg >= lo && sg <= hi) ? sg * (1.0f - sg) : 0.f;
+            const float g = p.heat[((size_t)b * p.num_classes + c) * p.hw + pix];
+            if (g == 1.0f) {
+                const float om = 1.0f - pr;
+                pos = (double)(logf(pr) * om * om);
+                cnt = 1.0;
+                grad = -(om * om / pr - 2.0f * logf(pr) * om) * dpdx;           // d(-log(p)(1-p)^2)/dx
+            } else if (g < 1.0f) {
+                const float w1 = 1.0f - g, w = (w1 * w1) * (w1 * w1);
+                const float l1 = logf(1.0f - pr);
+                neg = (double)(l1 * pr * pr * w);
+                grad = w * (pr * pr / (1.0f - pr) - 2.0f * pr * l1) * dpdx;     // d(-log(1-p) p^2 w)/dx
+            }
+        }
+        p.d_rows[i] = grad;
+    }
+    sm[0][threadIdx.x] = pos; sm[1][threadIdx.x] = neg; sm[2][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+            sm[2][threadIdx.x] += sm[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.part[(size_t)blockIdx.x * 3 + 0] = sm[0][0];
+        p.part[(size_t)blockIdx.x * 3 + 1] = sm[1][0];
+        p.part[(size_t)blockIdx.x * 3 + 2] = sm[2][0];
+    }
+}
+
+__global__ void __launch_bounds__(256) focal_final_kernel(ClParams p, int n_blocks) {
+    __shared__ double sm[3][256];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int k = threadIdx.x; k < n_blocks; k += 256) { a += p.part[(size_t)k * 3]; b += p.part[(size_t)k * 3 + 1]; c += p.part[(size_t)k * 3 + 2]; }
+    sm[0][threadIdx.x] = a; sm[1][threadIdx.x] = b; sm[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+            sm[2][threadIdx.x] += sm[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double pos = sm[0][0], neg = sm[1][0], np = sm[2][0];
+        const double scale = np > 0.0 ? 1.0 / np : 1.0;            // num_pos == 0: loss = -neg_loss
+        p.fin[0] = pos; p.fin[1] = neg; p.fin[2] = np; p.fin[3] = scale;
+        p.losses[1] = (float)(-(pos + neg) * scale) * p.cls_weight;
+    }
+}
+
+// blocks [0, scale_blocks): scale the heatmap gradient columns; last block: regression loss + gradient
+__global__ void __launch_bounds__(256) loss_finish_kernel(ClParams p, int scale_blocks) {
+    if ((int)blockIdx.x < scale_blocks) {
+        const long long total = (long long)p.batch * p.hw * p.num_classes;
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= total) return;
+        const long long row = i / p.num_classes;
+        const int c = (int)(i - row * p.num_classes);
+        float *g = p.d_rows + (size_t)row * p.ld + p.hm_col + c;
+        *g = *g * (float)p.fin[3] * p.cls_weight;
+        return;
+    }
+    __shared__ double snum[256];
+    __shared__ double sl1[256];
+    const long long bk = (long long)p.batch * p.k;
+    double num = 0.0;
+    for (long long e = threadIdx.x; e < bk; e += 256) num += p.masks[e] != 0 ? 1.0 : 0.0;
+    snum[threadIdx.x] = num;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) snum[threadIdx.x] += snum[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double n_obj = snum[0] < 1.0 ? 1.0 : snum[0];              // clamp_min(mask.sum(), 1)
+    double l1 = 0.0;                                                 // this thread's (sample, dimension) pairs, weighted
+    for (int pair = threadIdx.x; pair < p.batch * 8; pair += 256) {
+        const int b = pair >> 3, d = pair & 7;
+        const float gscale = p.cw[d] * p.loc_weight / (float)n_obj;
+        double acc = 0.0;
+        for (int k = 0; k < p.k; ++k) {
+            const size_t e = (size_t)b * p.k + k;
+            const float t = p.target[e * 8 + d];
+            const bool t_nan = t != t;
+            const float m = (p.masks[e] != 0 && !t_nan) ? 1.f : 0.f;         // mask * !isnan(target)
+            if (m == 0.f && !t_nan) continue;                                // |pred*0 - t*0| = 0, gradient 0
+            // as in the reference, a NaN target is NOT neutralised by its zero mask (NaN * 0 = NaN): NaN in, NaN out
+            const size_t row = (size_t)b * p.hw + (size_t)p.inds[e];
+            const float diff = p.rows[row * p.ld + d] * m - t * m;
+            acc += (double)fabsf(diff);
+            p.d_rows[row * p.ld + d] += t_nan ? diff : (diff > 0.f ? gscale : (diff < 0.f ? -gscale : 0.f));
+        }
+        l1 += acc * (double)p.cw[d];
+    }
+    sl1[threadIdx.x] = l1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sl1[threadIdx.x] += sl1[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float loc = (float)(sl1[0] / n_obj) * p.loc_weight;
+        p.losses[2] = loc;
+        p.losses[0] = p.losses[1] + loc;
+    }
+}
+
 }  // namespace
 
 enum { COL_MAX_CHUNKS = 512 };
@@ -922,5 +1073,35 @@ extern "C" int cpd_adam_step(float *param, const float *grad, float *exp_avg, fl
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     adam_kernel<<<cpd_div_up((long long)n, 256), 256, 0, cpd_s(st)>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                                                                      weight_decay, bc1, bc2, grad_scale);
+    return cpd_check_launch();
+}
+
+// ---- fused CenterHead loss + gradient ----
+static int center_loss_blocks(long long n_rows, int ld) { return (int)cpd_div_up(n_rows * ld, 256); }
+extern "C" size_t cpd_center_loss_workspace_bytes(int batch, int hw, int ld) {
+    if (batch <= 0 || hw <= 0 || ld <= 0) return 0;
+    return cpd_align(((size_t)center_loss_blocks((long long)batch * hw, ld) * 3 + 4) * sizeof(double));
+}
+extern "C" int cpd_center_loss(const float *rows, int ld, int batch, int hw, int num_classes, int hm_col, const float *heat,
+                               const float *target, const int64_t *inds, const int64_t *masks, int k, const float code_weights[8],
+                               float loc_weight, float cls_weight, float *d_rows, float *losses, void *ws, size_t ws_bytes,
+                               cpd_stream_t st) {
+    if (!rows || !heat || !target || !inds || !masks || !code_weights || !d_rows || !losses || !ws || batch <= 0 || hw <= 0 ||
+        num_classes <= 0 || hm_col < 8 || hm_col + num_classes > ld || k < 0)
+        return CPD_ERR_ARG;
+    const long long n_rows = (long long)batch * hw;
+    if (n_rows * ld >= (1ll << 40)) return CPD_ERR_UNSUPPORTED;
+    const int blocks = center_loss_blocks(n_rows, ld);
+    if (ws_bytes < ((size_t)blocks * 3 + 4) * sizeof(double)) return CPD_ERR_WORKSPACE;
+    ClParams p;
+    p.rows = rows; p.heat = heat; p.target = target; p.inds = (const long long *)inds; p.masks = (const long long *)masks;
+    p.d_rows = d_rows; p.losses = losses; p.part = (double *)ws; p.fin = (double *)ws + (size_t)blocks * 3;
+    p.ld = ld; p.batch = batch; p.hw = hw; p.num_classes = num_classes; p.hm_col = hm_col; p.k = k;
+    for (int d = 0; d < 8; ++d) p.cw[d] = code_weights[d];
+    p.loc_weight = loc_weight; p.cls_weight = cls_weight;
+    focal_partial_kernel<<<blocks, 256, 0, cpd_s(st)>>>(p);
+    focal_final_kernel<<<1, 256, 0, cpd_s(st)>>>(p, blocks);
+    const int scale_blocks = (int)cpd_div_up(n_rows * num_classes, 256);
+    loss_finish_kernel<<<scale_blocks + 1, 256, 0, cpd_s(st)>>>(p, scale_blocks);
     return cpd_check_launch();
 }

@@ -201,6 +201,7 @@ class CenterPointTrainer:
         self.pg, self.world = process_group, world_size
         self.num_max_objs = num_max_objs
         self.code_weights = code_weights
+        self.fused_loss = True
         self.steps_done = 0
         self.store = _Flat()
         self.store.bf16x3 = cfg.conv_math == "bf16x3"
@@ -468,7 +469,11 @@ class CenterPointTrainer:
         heat, tgt, inds, masks = center_loss.assign_targets(
             gt_boxes, (h, w), cfg.point_cloud_range, cfg.voxel_size, cfg.num_class, cfg.feature_map_stride,
             num_max_objs=self.num_max_objs)
-        leaf = rows.detach().requires_grad_(True)
+        if self.fused_loss:                     # one HIP launch group: loss parts + d(loss)/d(rows), no autograd graph
+            losses, d_rows = train_ops.center_loss(rows, batch, h * w, cfg.num_class, self.head_slices["hm"][0], heat, tgt, inds,
+                                                   masks, self.code_weights)
+            return losses[0], d_rows, {"hm_loss": losses[1], "loc_loss": losses[2]}
+        leaf = rows.detach().requires_grad_(True)           # torch restatement (tests compare the two)
         loss, parts = center_loss.center_head_loss(leaf, batch, h, w, heat, tgt, inds, masks, cfg.num_class,
                                                    hm_col=self.head_slices["hm"][0], code_weights=self.code_weights)
         loss.backward()

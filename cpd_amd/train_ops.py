@@ -3,7 +3,7 @@ import ctypes
 
 import torch
 
-from ._lib import check, iarr, lib, ptr, stream
+from ._lib import check, farr, iarr, lib, ptr, stream
 
 _ws_cache = {}
 
@@ -137,6 +137,23 @@ def rulebook_conv2d_transpose(batch, h, w, kh, kw, stride, pad, device):
     check(lib().cpd_rulebook_conv2d_transpose(batch, h, w, kh, kw, stride, pad, ptr(nbr_t), stream()),
           "cpd_rulebook_conv2d_transpose")
     return nbr_t
+
+
+def center_loss(rows, batch, hw, num_classes, hm_col, heat, target, inds, masks, code_weights, loc_weight=2.0, cls_weight=1.0):
+    """Fused CenterHead loss + gradient (cpd_center_loss) on contiguous head rows [batch*hw, ld].
+    Returns (losses[3] = total, hm, loc on the device, d_rows [batch*hw, ld])."""
+    assert rows.is_contiguous() and rows.dtype == torch.float32
+    ld = rows.shape[1]
+    heat = heat.contiguous().float(); target = target.contiguous().float()
+    inds = inds.contiguous().long(); masks = masks.contiguous().long()
+    k = inds.shape[1]
+    d_rows = torch.empty_like(rows)
+    losses = torch.empty(3, dtype=torch.float32, device=rows.device)
+    ws = _ws(lib().cpd_center_loss_workspace_bytes(batch, hw, ld), rows.device)
+    check(lib().cpd_center_loss(_p(rows), ld, batch, hw, num_classes, hm_col, _p(heat), _p(target), _p(inds), _p(masks), k,
+                                farr(code_weights if code_weights is not None else [1.0] * 8), float(loc_weight), float(cls_weight),
+                                _p(d_rows), _p(losses), ptr(ws), ws.numel(), stream()), "cpd_center_loss")
+    return losses, d_rows
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

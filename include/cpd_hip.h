@@ -308,6 +308,19 @@ int cpd_rulebook_conv_transpose(const int32_t *in_indices, int n_in, int batch,
                                 int32_t *nbr_t, cpd_stream_t stream);
 int cpd_rulebook_conv2d_transpose(int batch, int h, int w, int kh, int kw, int stride, int pad,
                                   int32_t *nbr_t, cpd_stream_t stream);
+/* CenterHead.get_loss (center_head.py:225-250) fused with its gradient, on channels-last head rows
+ * [batch*hw][ld] (columns 0..7 = center(2), center_z, dim(3), rot(2); columns hm_col.. = heatmap logits):
+ * hm loss = FocalLossCenterNet on clamp(sigmoid, 1e-4, 1-1e-4) (loss_utils.py:265-300) x cls_weight,
+ * loc loss = sum_d code_weights[d] * RegLossCenterNet_d (masked L1 at the object pixels / max(#objects, 1),
+ * loss_utils.py:315-386) x loc_weight. heat [batch][num_classes][hw], target [batch][k][8], inds / masks
+ * [batch][k] int64 as assign_targets builds them. Writes d(total)/d(rows) to d_rows [batch*hw][ld] (all
+ * columns) and losses[3] = {total, hm, loc} on the device; deterministic (fixed-order sums, no atomics). */
+size_t cpd_center_loss_workspace_bytes(int batch, int hw, int ld);
+int cpd_center_loss(const float *rows, int ld, int batch, int hw, int num_classes, int hm_col,
+                    const float *heat, const float *target, const int64_t *inds,
+                    const int64_t *masks, int k, const float code_weights[8], float loc_weight,
+                    float cls_weight, float *d_rows, float *losses, void *ws, size_t ws_bytes,
+                    cpd_stream_t stream);
 /* Adam with decoupled weight decay on a flat buffer (tools/train_utils/optimization/fastai_optim.py:
  * 132-150 true_wd semantics): grad is multiplied by grad_scale first (1/world after all-reduce,
  * clip factor). `step` counts from 1.                                                           */

@@ -277,3 +277,51 @@ def test_adjoint_packing_gives_input_gradient(hip):
     y.backward(dy)
     dx = ops.gather_conv(dy, cout, train_ops.pack_weight_adjoint(w, True), nbr, 27, n, cin)
     torch.testing.assert_close(dx, x.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("batch,n_obj", [(2, 30), (1, 0), (3, 120)])
+def test_fused_center_loss_matches_the_torch_restatement(hip, batch, n_obj):
+    """cpd_center_loss (loss parts + gradient in three launches) against cpd_amd.center_loss (torch autograd; itself
+    pinned on goldens produced by the reference's FocalLossCenterNet / RegLossCenterNet, tests/test_center_loss.py),
+    including: no objects at all (the num_pos == 0 branch), several objects on one pixel, saturated logits (clamped
+    sigmoid -> zero gradient). A NaN target gives a NaN loss in both (the reference multiplies NaN by its zero mask)."""
+    from cpd_amd import center_loss
+    rng = np.random.default_rng(batch * 100 + n_obj)
+    h, w, nc, ld, hm_col, K = 47, 52, 3, 16, 8, 150
+    n = batch * h * w
+    rows = torch.from_numpy(rng.normal(size=(n, ld)).astype(np.float32) * 2.0).cuda()
+    rows[::97, hm_col] = 15.0                       # sigmoid above 1 - 1e-4: clamped, gradient 0
+    rows[5::89, hm_col + 1] = -15.0                 # below 1e-4
+    heat = torch.from_numpy((rng.random((batch, nc, h, w)) ** 6).astype(np.float32)).cuda() * 0.999
+    tgt = torch.zeros((batch, K, 8), dtype=torch.float32, device="cuda")
+    inds = torch.zeros((batch, K), dtype=torch.int64, device="cuda")
+    masks = torch.zeros((batch, K), dtype=torch.int64, device="cuda")
+    if n_obj:
+        tgt[:, :n_obj] = torch.from_numpy(rng.normal(size=(batch, n_obj, 8)).astype(np.float32)).cuda()
+        inds[:, :n_obj] = torch.from_numpy(rng.integers(0, h * w, size=(batch, n_obj))).cuda()
+        inds[:, 1] = inds[:, 0]                     # two objects on one pixel: gradients add up
+        masks[:, :n_obj] = 1
+        masks[:, 2] = 0
+        b_i = torch.arange(batch, device="cuda")[:, None].expand(batch, n_obj)
+        cls = torch.from_numpy(rng.integers(0, nc, size=(batch, n_obj))).cuda()
+        heat.view(batch, nc, h * w)[b_i, cls, inds[:, :n_obj]] = 1.0          # the peaks
+    cw = [1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 2.0, 2.0]
+    leaf = rows.clone().requires_grad_(True)
+    want, parts = center_loss.center_head_loss(leaf, batch, h, w, heat, tgt, inds, masks, nc, hm_col=hm_col, code_weights=cw)
+    want.backward()
+    losses, d_rows = T.center_loss(rows, batch, h * w, nc, hm_col, heat, tgt, inds, masks, cw)
+    got = losses.cpu().numpy()
+    np.testing.assert_allclose(got[0], float(want.detach()), rtol=2e-6)
+    np.testing.assert_allclose(got[1], float(parts["hm_loss"]), rtol=2e-6)
+    np.testing.assert_allclose(got[2], float(parts["loc_loss"]), rtol=2e-6, atol=1e-12)
+    g = leaf.grad
+    scale = g.abs().max().item()
+    assert (d_rows - g).abs().max().item() <= 2e-6 * scale, ((d_rows - g).abs().max().item(), scale)
+    assert not d_rows[:, hm_col + nc:].any()        # padding columns carry no gradient
+    again_l, again_d = T.center_loss(rows, batch, h * w, nc, hm_col, heat, tgt, inds, masks, cw)
+    assert torch.equal(again_l, losses) and torch.equal(again_d, d_rows)        # deterministic
+    if n_obj:
+        tgt[0, 3, 4] = float("nan")
+        nan_want, _ = center_loss.center_head_loss(rows, batch, h, w, heat, tgt, inds, masks, nc, hm_col=hm_col, code_weights=cw)
+        nan_got, _ = T.center_loss(rows, batch, h * w, nc, hm_col, heat, tgt, inds, masks, cw)
+        assert torch.isnan(nan_want) and torch.isnan(nan_got[0]) and torch.isnan(nan_got[2]) and not torch.isnan(nan_got[1])
