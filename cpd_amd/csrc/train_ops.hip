@@ -925,7 +925,9 @@ extern "C" int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, 
 
 // Tile kernel plan: (TM, TN) in {64,128}^2 when both channel counts are multiples of 64.
 static void wgrad_chunks(int n_out, long long per_chunk, int min_rows, int round, WgParams *p) {
-    int chunks = (int)((512 + per_chunk - 1) / per_chunk);      // ~2 workgroups per CU
+    long long target = 1024;                                    // ~4 workgroups per CU (sweep on the train step: 256..4096)
+    if (const char *e = getenv("CPD_WGRAD_WGS")) target = atoll(e);
+    int chunks = (int)((target + per_chunk - 1) / per_chunk);
     const int max_chunks = (n_out + min_rows - 1) / min_rows;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
