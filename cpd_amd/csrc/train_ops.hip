@@ -924,8 +924,7 @@ extern "C" int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, 
 }
 
 // Tile kernel plan: (TM, TN) in {64,128}^2 when both channel counts are multiples of 64.
-static void wgrad_chunks(int n_out, long long per_chunk, int min_rows, int round, WgParams *p) {
-    long long target = 1024;                                    // ~4 workgroups per CU (sweep on the train step: 256..4096)
+static void wgrad_chunks(int n_out, long long per_chunk, int min_rows, int round, WgParams *p, long long target = 512) {
     if (const char *e = getenv("CPD_WGRAD_WGS")) target = atoll(e);
     int chunks = (int)((target + per_chunk - 1) / per_chunk);
     const int max_chunks = (n_out + min_rows - 1) / min_rows;
@@ -955,7 +954,8 @@ static bool wgrad_bf16_plan(int n_out, int c_in, int c_out, int kv, int flags, W
     *tn = wgrad_bf16_tile(c_out);
     p->ci_tiles = c_in / *tm;
     p->co_tiles = c_out / *tn;
-    wgrad_chunks(n_out, (long long)kv * p->ci_tiles * p->co_tiles, 256, 256, p);
+    // workgroups to aim for: 2 per CU for the 128 x 128 tile (its partial sums are the largest), 4 per CU for the smaller tiles
+    wgrad_chunks(n_out, (long long)kv * p->ci_tiles * p->co_tiles, 256, 256, p, (*tm) * (*tn) >= 128 * 128 ? 512 : 1024);
     return true;
 }
 
