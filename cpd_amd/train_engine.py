@@ -17,6 +17,7 @@ SURVEY Appendix B:
 There is no autograd graph: each layer object keeps what its backward needs from the forward.
 """
 import math
+import os
 from typing import Dict, List
 
 import torch
@@ -33,6 +34,25 @@ class _Flat:
         self.slots = {}
         self.flat = self.grad = self.m = self.v = None
         self.bf16x3 = True      # conv arithmetic of layers with >= 32 input channels (ModelConfig.conv_math)
+        self.side = None        # HIP stream for the weight gradients (independent of the input gradients of the same layer)
+
+    def on_side(self, fn, *tensors):
+        """Run fn() on the side stream, ordered after everything issued so far on the current one; `tensors` are the
+        current-stream tensors it reads (kept alive for the side stream). Without a side stream: fn() in place."""
+        if self.side is None:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            return fn()
+
+    def join_side(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def add(self, name, t):
         assert name not in self.slots
@@ -150,8 +170,10 @@ class _Conv:
         if self.mode == "up" and self.up > 1:
             u2 = self.up * self.up
             # dW[tap][co][ci] = sum_pix dz_up[map[tap][pix]][co] * x[pix][ci]  (roles of in/dy swapped)
-            tmp = train_ops.conv_wgrad(dz, self.c_bn, x, self.c_in, up_map, u2, n_out, bf16x3=self.store.bf16x3)
-            gw.view(self.c_in, u2, self.c_bn).copy_(tmp.permute(2, 0, 1))
+            def wgrad_up():
+                tmp = train_ops.conv_wgrad(dz, self.c_bn, x, self.c_in, up_map, u2, n_out, bf16x3=self.store.bf16x3)
+                gw.view(self.c_in, u2, self.c_bn).copy_(tmp.permute(2, 0, 1))
+            st.on_side(wgrad_up, dz, x)
             if not need_dx:
                 return None, dres
             dx = ops.gather_conv(dz, self.c_bn, self.pw_adj, up_map, u2, n_out, self.c_in, None, None, add, False,
@@ -161,7 +183,10 @@ class _Conv:
             nbr_w = torch.arange(n_out, dtype=torch.int32, device=dz.device).view(1, -1)
         else:
             nbr_w = nbr
-        train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, bf16x3=self.store.bf16x3)
+        # the weight gradient needs (x, dz), the input gradient (dz, W): independent, so they run on two streams and
+        # share the chip (at one frame per GPU neither fills it)
+        st.on_side(lambda: train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, bf16x3=self.store.bf16x3),
+                   x, dz, nbr_w)
         if not need_dx:
             return None, dres
         dx = ops.gather_conv(dz, self.c_out, self.pw_adj, nbr_adj, self.kv, n_in, self.c_in, None, None, add, False,
@@ -205,6 +230,8 @@ class CenterPointTrainer:
         self.steps_done = 0
         self.store = _Flat()
         self.store.bf16x3 = cfg.conv_math == "bf16x3"
+        if self.device.type == "cuda" and os.environ.get("CPD_TRAIN_SIDE_STREAM", "1") != "0":
+            self.store.side = torch.cuda.Stream(device=self.device)
         self._voxelizers = []
         self._bev_cache = {}
         self._build(state_dict)
@@ -459,6 +486,7 @@ class CenterPointTrainer:
                 dx, _ = S[stage + ".down"].backward(dx, nbr_dn_t, n_in)
         dx = self._blocks_bwd(S["conv1"], dx, tp["nbr0"])
         S["conv_input"].backward(dx, None, 0, need_dx=False)
+        self.store.join_side()                  # every weight gradient is in the flat buffer from here on
         self.tape = None
 
     def loss(self, rows, gt_boxes):
