@@ -387,26 +387,31 @@ class CenterPointTrainer:
         batch = len(points_list)
         feats, coords = self._voxelize(points_list)
         shape = cfg.sparse_shape
+        # every rulebook first (they depend on coordinates only): the output-set sizes are the step's host read-backs,
+        # and taking them before any convolution is queued keeps the conv chain free of launch bubbles
         index = ops.SiteIndex.build(coords, batch, shape)
-        nbr = ops.rulebook_subm(coords, index)
-        tape = {"nbr0": nbr, "stages": []}
-        x = S["conv_input"].forward(feats, nbr, coords.shape[0])
-        x = self._blocks_fwd(S["conv1"], x, nbr)
+        nbr0 = ops.rulebook_subm(coords, index)
+        n0 = coords.shape[0]
+        tables = []
         for stage in ["conv2", "conv3", "conv4", "conv_out"]:
             k, s, pd = _DOWN[stage]
             out_idx, out_index, out_shape = ops.conv_outset(coords, batch, shape, k, s, pd)
             nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
             nbr_dn_t = train_ops.rulebook_conv_transpose(coords, batch, shape, k, s, pd, out_index)
+            nbr_sub = None if stage == "conv_out" else ops.rulebook_subm(out_idx, out_index)
+            tables.append((stage, nbr_dn, nbr_dn_t, nbr_sub, out_idx.shape[0]))
+            coords, index, shape = out_idx, out_index, out_shape
+        tape = {"nbr0": nbr0, "stages": []}
+        x = S["conv_input"].forward(feats, nbr0, n0)
+        x = self._blocks_fwd(S["conv1"], x, nbr0)
+        for stage, nbr_dn, nbr_dn_t, nbr_sub, n_stage in tables:
             n_in = x.shape[0]
             if stage == "conv_out":
-                x = S["conv_out"].forward(x, nbr_dn, out_idx.shape[0])
-                tape["stages"].append((stage, None, nbr_dn_t, n_in))
+                x = S["conv_out"].forward(x, nbr_dn, n_stage)
             else:
-                x = S[stage + ".down"].forward(x, nbr_dn, out_idx.shape[0])
-                nbr = ops.rulebook_subm(out_idx, out_index)
-                x = self._blocks_fwd(S[stage], x, nbr)
-                tape["stages"].append((stage, nbr, nbr_dn_t, n_in))
-            coords, index, shape = out_idx, out_index, out_shape
+                x = S[stage + ".down"].forward(x, nbr_dn, n_stage)
+                x = self._blocks_fwd(S[stage], x, nbr_sub)
+            tape["stages"].append((stage, nbr_sub, nbr_dn_t, n_in))
         d, h, w = shape
         C = x.shape[1]
         dense = ops.densify_nhwc(x, coords, batch, shape).view(batch * h * w, d * C)
