@@ -658,9 +658,11 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float *__restric
 
 __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, size_t n, float lr, float b1, float b2, float eps,
-                                                   float wd, float bc1, float bc2, float gscale) {
+                                                   float wd, float bc1, float bc2, float gscale,
+                                                   const float *__restrict__ gscale_dev) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (gscale_dev) gscale *= *gscale_dev;              // e.g. the clip factor, computed on the device: no host read-back
     const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -1069,12 +1071,13 @@ extern "C" int cpd_rulebook_conv2d_transpose(int batch, int h, int w, int kh, in
 }
 
 extern "C" int cpd_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int step, float grad_scale, cpd_stream_t st) {
+                             float beta2, float eps, float weight_decay, int step, float grad_scale, const float *grad_scale_dev,
+                             cpd_stream_t st) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || step <= 0) return CPD_ERR_ARG;
     if (n == 0) return CPD_OK;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     adam_kernel<<<cpd_div_up((long long)n, 256), 256, 0, cpd_s(st)>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                                                                     weight_decay, bc1, bc2, grad_scale);
+                                                                     weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
     return cpd_check_launch();
 }
 

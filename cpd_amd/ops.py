@@ -188,12 +188,14 @@ def rulebook_conv(out_indices, in_index, ksize, stride, pad):
     return nbr
 
 
-def pack_weight(w_kio):
+def pack_weight(w_kio, out=None):
     """w_kio: [kv, c_in, c_out] f32 device tensor -> packed MFMA-fragment weights."""
     _need_cuda(w_kio, "weight")
     w_kio = w_kio.contiguous().float()
     kv, cin, cout = w_kio.shape
-    packed = torch.empty((lib().cpd_packed_weight_floats(kv, cin, cout),), dtype=torch.float32, device=w_kio.device)
+    n = lib().cpd_packed_weight_floats(kv, cin, cout)
+    packed = out if out is not None else torch.empty((n,), dtype=torch.float32, device=w_kio.device)
+    assert packed.numel() == n and packed.is_contiguous()
     check(lib().cpd_pack_weight(ptr(w_kio), kv, cin, cout, ptr(packed), stream()), "cpd_pack_weight")
     return packed
 

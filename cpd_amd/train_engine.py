@@ -121,13 +121,14 @@ class _Conv:
     def repack(self):
         """Forward and adjoint packed images of the current weights (after every optimiser step)."""
         w = self.store.p(self.wn)
-        self.pw = ops.pack_weight(w)
+        # the images are rewritten in place (no allocation per step)
+        self.pw = ops.pack_weight(w, out=getattr(self, "pw", None))
         if self.mode == "up" and self.up > 1:
             u2 = self.up * self.up
             w_t = w.view(self.c_in, u2, self.c_bn).permute(1, 2, 0).contiguous()     # [tap, co, ci]
-            self.pw_adj = ops.pack_weight(w_t)
+            self.pw_adj = ops.pack_weight(w_t, out=getattr(self, "pw_adj", None))
         else:
-            self.pw_adj = train_ops.pack_weight_adjoint(w, flip_taps=(self.mode == "same"))
+            self.pw_adj = train_ops.pack_weight_adjoint(w, flip_taps=(self.mode == "same"), out=getattr(self, "pw_adj", None))
 
     # ---------------------------------------------------------------- forward
     def forward(self, x, nbr, n_out, residual=None, dense=False, out=None, up_map=None, n_up=None, update_stats=True):
@@ -521,16 +522,16 @@ class CenterPointTrainer:
     def optimizer_step(self):
         st = self.store
         scale = dist_utils.reduce_gradients(st.grad, self.world, self.pg)   # the one collective (no-op without a process group)
-        if self.grad_clip:
-            norm = float(st.grad.norm()) * scale                     # clip_grad_norm_, train_utils.py:43
-            if norm > self.grad_clip:
-                scale *= self.grad_clip / (norm + 1e-6)
+        clip = None
+        if self.grad_clip:                                           # clip_grad_norm_, train_utils.py:43 -- factor stays on the device
+            norm = st.grad.norm() * scale
+            clip = torch.clamp(self.grad_clip / (norm + 1e-6), max=1.0).reshape(1).float()
         lr, b1 = self.lr, self.betas[0]
         if self.total_steps:
             lr, b1 = one_cycle(min(self.steps_done, self.total_steps - 1), self.total_steps, self.lr)
         self.steps_done += 1
         train_ops.adam_step(st.flat, st.grad, st.m, st.v, lr, b1, self.betas[1], 1e-8, self.weight_decay,
-                            self.steps_done, grad_scale=scale)
+                            self.steps_done, grad_scale=scale, grad_scale_dev=clip)
         for c in self.layers:
             c.repack()
 

@@ -67,9 +67,11 @@ def bn_stats_finalize(x, eps, momentum, gamma, beta, running_mean=None, running_
     return out[0], out[1], out[2], out[3]
 
 
-def pack_weight_adjoint(w_kio, flip_taps):
+def pack_weight_adjoint(w_kio, flip_taps, out=None):
     kv, cin, cout = w_kio.shape
-    packed = torch.empty((lib().cpd_packed_weight_floats(kv, cout, cin),), dtype=torch.float32, device=w_kio.device)
+    n = lib().cpd_packed_weight_floats(kv, cout, cin)
+    packed = out if out is not None else torch.empty((n,), dtype=torch.float32, device=w_kio.device)
+    assert packed.numel() == n
     check(lib().cpd_pack_weight_adjoint(ptr(w_kio), kv, cin, cout, int(bool(flip_taps)), ptr(packed), stream()),
           "cpd_pack_weight_adjoint")
     return packed
@@ -156,7 +158,9 @@ def center_loss(rows, batch, hw, num_classes, hm_col, heat, target, inds, masks,
     return losses, d_rows
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, grad_scale_dev=None):
+    """grad_scale_dev: optional 1-element float32 device tensor multiplied into grad_scale inside the kernel."""
     check(lib().cpd_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr), float(beta1),
-                              float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), stream()),
+                              float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), ptr(grad_scale_dev),
+                              stream()),
           "cpd_adam_step")

@@ -322,11 +322,13 @@ int cpd_center_loss(const float *rows, int ld, int batch, int hw, int num_classe
                     float cls_weight, float *d_rows, float *losses, void *ws, size_t ws_bytes,
                     cpd_stream_t stream);
 /* Adam with decoupled weight decay on a flat buffer (tools/train_utils/optimization/fastai_optim.py:
- * 132-150 true_wd semantics): grad is multiplied by grad_scale first (1/world after all-reduce,
- * clip factor). `step` counts from 1.                                                           */
+ * 132-150 true_wd semantics): grad is multiplied first by grad_scale (1/world after all-reduce) and,
+ * when grad_scale_dev is not NULL, by the float it points to in device memory (the clip factor of
+ * clip_grad_norm_, computed on the device so that the step needs no host read-back). `step` counts
+ * from 1.                                                                                        */
 int cpd_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                  float grad_scale, cpd_stream_t stream);
+                  float grad_scale, const float *grad_scale_dev, cpd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * RoI-head feature pooling: the pointnet2_stack CUDA extension's voxel query and
