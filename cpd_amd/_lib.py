@@ -90,6 +90,8 @@ SIGNATURES = {
     "cpd_rulebook_conv2d_transpose": (_I, [_I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
     "cpd_center_loss_workspace_bytes": (_SZ, [_I, _I, _I]),
     "cpd_center_loss": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _FP, _F, _F, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_anchor_loss_workspace_bytes": (_SZ, [_I, _I]),
+    "cpd_anchor_loss": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _FP, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_adam_step": (_I, [_VP, _VP, _VP, _VP, _SZ, _F, _F, _F, _F, _F, _I, _F, _VP, _VP]),
 }
 

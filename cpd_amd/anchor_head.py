@@ -4,12 +4,16 @@
   box_utils.boxes3d_nearest_bev_iou           cpd/utils/box_utils.py:275-287
   AxisAlignedTargetAssigner.assign_targets    cpd/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:46-243
   AnchorHeadTemplate.generate_predicted_boxes cpd/models/dense_heads/anchor_head_template.py:336-383
+  AnchorHeadTemplate.get_loss                 cpd/models/dense_heads/anchor_head_template.py:179-334 (+ cpd/utils/loss_utils.py:10-206)
 
 The assigner never materialises the anchors x GT IoU matrix: `cpd_anchor_assign` keeps the per-anchor
 max / argmax and the per-GT max on chip (212k anchors x 100 GT boxes would be 85 MB per sample and class)."""
-import torch
+import math
 
-from ._lib import check, lib, ptr, stream
+import torch
+import torch.nn.functional as F
+
+from ._lib import check, farr, lib, ptr, stream
 
 
 class AnchorGenerator:
@@ -124,8 +128,82 @@ def generate_predicted_boxes(anchors, batch_size, cls_preds, box_preds, dir_cls_
     return cls_preds.reshape(batch_size, n, -1).float(), out
 
 
+def _flat_anchors(anchors):
+    if isinstance(anchors, list):
+        anchors = torch.cat(anchors, dim=-3)
+    return anchors.reshape(-1, anchors.shape[-1]).contiguous().float()
+
+
+def anchor_head_loss_torch(anchors, cls_preds, box_preds, dir_cls_preds, box_cls_labels, box_reg_targets, num_class,
+                           cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, code_weights=None, dir_offset=0.78539, num_dir_bins=2):
+    """Torch restatement of get_cls_layer_loss + get_box_reg_layer_loss (autograd-capable, any device): the form the fused
+    kernel is tested against, itself pinned on tests/golden/anchor_loss.npz (the reference's own get_loss and gradients).
+    Returns (total, {"rpn_loss_cls", "rpn_loss_loc", "rpn_loss_dir"})."""
+    a = _flat_anchors(anchors).to(cls_preds.device)
+    n = a.shape[0]
+    B = cls_preds.shape[0]
+    labels = box_cls_labels.reshape(B, n).long()
+    pos = labels > 0
+    norm = pos.sum(1, keepdim=True).float().clamp(min=1.0)
+    # classification: focal-weighted sigmoid cross entropy against the one-hot class (all zeros for background / ignored)
+    x = cls_preds.reshape(B, n, num_class).float()
+    t = F.one_hot(labels.clamp(min=0), num_class + 1)[..., 1:].to(x.dtype)
+    pr = torch.sigmoid(x)
+    focal = (t * 0.25 + (1 - t) * 0.75) * (t * (1 - pr) + (1 - t) * pr) ** 2
+    bce = x.clamp(min=0) - x * t + torch.log1p(torch.exp(-x.abs()))
+    w_cls = (labels >= 0).float() / norm
+    cls_loss = (focal * bce * w_cls.unsqueeze(-1)).sum() / B * cls_weight
+    # box regression: heading enters as sin(pred - target), written out so that both factors carry gradient
+    bp = box_preds.reshape(B, n, 7).float()
+    rt = box_reg_targets.reshape(B, n, 7).float()
+    enc_p = torch.cat([bp[..., :6], torch.sin(bp[..., 6:7]) * torch.cos(rt[..., 6:7])], -1)
+    enc_t = torch.cat([rt[..., :6], torch.cos(bp[..., 6:7]) * torch.sin(rt[..., 6:7])], -1)
+    enc_t = torch.where(torch.isnan(enc_t), enc_p, enc_t)
+    cw = bp.new_tensor(code_weights if code_weights is not None else [1.0] * 7)
+    d = ((enc_p - enc_t) * cw).abs()
+    beta = 1.0 / 9.0
+    w_reg = pos.float() / norm
+    loc_loss = (torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta) * w_reg.unsqueeze(-1)).sum() / B * loc_weight
+    parts = {"rpn_loss_cls": cls_loss.detach(), "rpn_loss_loc": loc_loss.detach()}
+    total = cls_loss + loc_loss
+    if dir_cls_preds is not None:
+        rot = rt[..., 6] + a[:, 6].unsqueeze(0)
+        v = rot - dir_offset
+        off = v - torch.floor(v / (2 * math.pi)) * (2 * math.pi)
+        bins = torch.floor(off / (2 * math.pi / num_dir_bins)).long().clamp(0, num_dir_bins - 1)
+        logits = dir_cls_preds.reshape(B, n, num_dir_bins).float()
+        ce = F.cross_entropy(logits.reshape(-1, num_dir_bins), bins.reshape(-1), reduction="none").view(B, n)
+        dir_loss = (ce * w_reg).sum() / B * dir_weight
+        parts["rpn_loss_dir"] = dir_loss.detach()
+        total = total + dir_loss
+    return total, parts
+
+
+def anchor_head_loss(anchors, cls_preds, box_preds, dir_cls_preds, box_cls_labels, box_reg_targets, num_class,
+                     cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, code_weights=None, dir_offset=0.78539, num_dir_bins=2):
+    """get_loss fused with its gradient on the device (cpd_anchor_loss). Returns (losses[4] = total, cls, loc, dir;
+    (d_cls_preds, d_box_preds, d_dir_cls_preds)) with the gradients shaped like the predictions."""
+    a = _flat_anchors(anchors)
+    n = a.shape[0]
+    B = cls_preds.shape[0]
+    cp = cls_preds.reshape(B, n, num_class).contiguous().float()
+    bp = box_preds.reshape(B, n, 7).contiguous().float()
+    dp = dir_cls_preds.reshape(B, n, num_dir_bins).contiguous().float() if dir_cls_preds is not None else None
+    lab = box_cls_labels.reshape(B, n).to(torch.int32).contiguous()
+    rt = box_reg_targets.reshape(B, n, 7).contiguous().float()
+    d_cls, d_box = torch.empty_like(cp), torch.empty_like(bp)
+    d_dir = torch.empty_like(dp) if dp is not None else None
+    losses = torch.empty(4, dtype=torch.float32, device=cp.device)
+    ws = torch.empty(lib().cpd_anchor_loss_workspace_bytes(B, n), dtype=torch.uint8, device=cp.device)
+    check(lib().cpd_anchor_loss(ptr(cp), ptr(bp), ptr(dp), ptr(lab), ptr(rt), ptr(a), B, n, num_class, num_dir_bins, float(dir_offset),
+                                farr(code_weights if code_weights is not None else [1.0] * 7), float(cls_weight), float(loc_weight),
+                                float(dir_weight), ptr(d_cls), ptr(d_box), ptr(d_dir), ptr(losses), ptr(ws), ws.numel(), stream()),
+          "cpd_anchor_loss")
+    return losses, (d_cls.view_as(cls_preds), d_box.view_as(box_preds), d_dir.view_as(dir_cls_preds) if d_dir is not None else None)
+
+
 class AnchorHeadSingle(torch.nn.Module):
-    """Inference path of AnchorHeadSingle (cpd/models/dense_heads/anchor_head_single.py:194-356): occupancy anchor
+    """Inference path of AnchorHeadSingle (cpd/models/dense_heads/anchor_head_single.py:194-356) + get_loss: occupancy anchor
     mask, the 1x1 conv_cls / conv_box / conv_dir_cls (cpd_gather_conv through cpd_amd.models.Conv2d; state_dict
     names as in the reference), masked anchors, generate_predicted_boxes (cpd_anchor_decode)."""
 
@@ -164,6 +242,17 @@ class AnchorHeadSingle(torch.nn.Module):
         mask = torch.zeros(h, w, device=dev)
         mask[rows, cols] = 1
         return mask.bool()
+
+    def get_loss(self, forward_ret_dict, anchors=None):
+        """AnchorHeadTemplate.get_loss (anchor_head_template.py:321-334) for a forward_ret_dict with the reference's keys
+        (cls_preds, box_preds, dir_cls_preds, box_cls_labels, box_reg_targets). Fused loss + gradient kernel; returns
+        (losses[4] = rpn_loss, cls, loc, dir on the device, (d_cls_preds, d_box_preds, d_dir_cls_preds))."""
+        lw = self.model_cfg["LOSS_CONFIG"]["LOSS_WEIGHTS"]
+        f = forward_ret_dict
+        return anchor_head_loss(anchors if anchors is not None else self.anchors_root, f["cls_preds"], f["box_preds"],
+                                f.get("dir_cls_preds"), f["box_cls_labels"], f["box_reg_targets"], self.num_class,
+                                lw["cls_weight"], lw["loc_weight"], lw.get("dir_weight", 0.2), lw["code_weights"],
+                                self.model_cfg.get("DIR_OFFSET", 0.78539), self.num_dir_bins)
 
     @torch.no_grad()
     def forward(self, data_dict):

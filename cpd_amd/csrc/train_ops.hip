@@ -824,6 +824,150 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(ClParams p, int scale_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// AnchorHeadTemplate.get_loss (anchor_head_template.py:179-334) fused with its gradient, one thread
+// per (sample, anchor): sigmoid focal classification loss (alpha 0.25, gamma 2; loss_utils.py:10-75),
+// smooth-L1 (beta 1/9) on the residual-coded box with the sin-difference heading encoding
+// (l.219-226, 243-271; loss_utils.py:77-150) and cross entropy on the direction bins (l.228-241,
+// 273-293; loss_utils.py:182-206). Normalisers are per sample: 1 / max(#positives, 1).
+//   anchor_count: positives per sample (integer atomics: exact);
+//   anchor_loss:  losses + gradients, per-block partial sums (double);
+//   anchor_final: one block sums the partials in a fixed order -> losses[4] = total, cls, loc, dir.
+// ---------------------------------------------------------------------------------------------
+struct AlParams {
+    const float *cls, *box, *dir;       // [B][A][C], [B][A][7], [B][A][NB] (dir may be null)
+    const int32_t *labels;              // [B][A]: -1 don't care, 0 background, k > 0 class k
+    const float *reg;                   // [B][A][7]
+    const float *anchors;               // [A][7]
+    float *d_cls, *d_box, *d_dir;
+    float *losses;
+    int *pos;                           // [B]
+    double *part;                       // [blocks][3]
+    int batch, n_anchors, num_class, num_bins;
+    float dir_offset, cw[7], cls_weight, loc_weight, dir_weight;
+};
+
+__global__ void __launch_bounds__(256) anchor_count_kernel(AlParams p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)p.batch * p.n_anchors;
+    const bool is_pos = i < total && p.labels[i] > 0;
+    // blocks never straddle samples when n_anchors % 256 == 0; in general count per lane's own sample
+    if (is_pos) atomicAdd(&p.pos[i / p.n_anchors], 1);
+}
+
+__global__ void __launch_bounds__(256) anchor_loss_kernel(AlParams p) {
+    __shared__ double sm[3][256];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)p.batch * p.n_anchors;
+    double l_cls = 0.0, l_loc = 0.0, l_dir = 0.0;
+    if (i < total) {
+        const int b = (int)(i / p.n_anchors);
+        const int a = (int)(i - (long long)b * p.n_anchors);
+        const int label = p.labels[i];
+        const float norm = 1.0f / fmaxf((float)p.pos[b], 1.0f);
+        const float inv_b = 1.0f / (float)p.batch;
+        // ---- classification: weight 1/norm for background and positives, 0 for don't-care
+        const float w_cls = label >= 0 ? norm : 0.f;
+        for (int c = 0; c < p.num_class; ++c) {
+            const float x = p.cls[i * p.num_class + c];
+            const float t = (label == c + 1) ? 1.f : 0.f;
+            const float pr = 1.0f / (1.0f + expf(-x));
+            const float alpha = t * 0.25f + (1.f - t) * 0.75f;
+            const float pt = t * (1.f - pr) + (1.f - t) * pr;
+            const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            const float fw = alpha * pt * pt;
+            l_cls += (double)(fw * bce * w_cls);
+            const float dpt = (t > 0.5f ? -1.f : 1.f) * pr * (1.f - pr);
+            const float g = alpha * 2.f * pt * dpt * bce + fw * (pr - t);
+            p.d_cls[i * p.num_class + c] = g * w_cls * p.cls_weight * inv_b;
+        }
+        // ---- box regression + direction: positives only
+        const float w_reg = label > 0 ? norm : 0.f;
+        float gb[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float beta = 1.0f / 9.0f;
+        if (w_reg > 0.f) {
+            const float *bp = p.box + i * 7, *tp = p.reg + i * 7;
+            for (int k = 0; k < 7; ++k) {
+                float pv = bp[k], tv = tp[k], dd = 1.f;             // dd = d(encoded diff)/d(pred)
+                if (k == 6) {
+                    const float sp = sinf(pv), cp = cosf(pv), st = sinf(tv), ct = cosf(tv);
+                    pv = sp * ct; tv = cp * st;                         // sin(a - b) = sin a cos b - cos a sin b
+                    dd = cp * ct + sp * st;
+                }
+                float diff = (tv != tv) ? 0.f : (pv - tv);              // NaN target -> replaced by the prediction
+                if (tv != tv) dd = 0.f;
+                diff *= p.cw[k];
+                const float n = fabsf(diff);
+                l_loc += (double)((n < beta ? 0.5f * n * n / beta : n - 0.5f * beta) * w_reg);
+                const float ds = n < beta ? diff / beta : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+                gb[k] = ds * p.cw[k] * dd * w_reg * p.loc_weight * inv_b;
+            }
+        }
+        for (int k = 0; k < 7; ++k) p.d_box[i * 7 + k] = gb[k];
+        if (p.dir) {
+            const int nb = p.num_bins;
+            const float *dp = p.dir + i * nb;
+            float *gd = p.d_dir + i * nb;
+            if (w_reg > 0.f) {
+                const float two_pi = 6.283185307179586f;
+                const float rot = p.reg[i * 7 + 6] + p.anchors[(size_t)a * 7 + 6];
+                const float v = rot - p.dir_offset;
+                const float off = v - floorf(v / two_pi + 0.f) * two_pi;       // limit_period(v, 0, 2 pi)
+                int bin = (int)floorf(off / (two_pi / (float)nb));
+                bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
+                float mx = dp[0];
+                for (int k = 1; k < nb; ++k) mx = fmaxf(mx, dp[k]);
+                float se = 0.f;
+                for (int k = 0; k < nb; ++k) se += expf(dp[k] - mx);
+                const float lse = logf(se) + mx;
+                l_dir += (double)((lse - dp[bin]) * w_reg);
+                for (int k = 0; k < nb; ++k)
+                    gd[k] = (expf(dp[k] - lse) - (k == bin ? 1.f : 0.f)) * w_reg * p.dir_weight * inv_b;
+            } else {
+                for (int k = 0; k < nb; ++k) gd[k] = 0.f;
+            }
+        }
+    }
+    sm[0][threadIdx.x] = l_cls; sm[1][threadIdx.x] = l_loc; sm[2][threadIdx.x] = l_dir;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+            sm[2][threadIdx.x] += sm[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.part[(size_t)blockIdx.x * 3 + 0] = sm[0][0];
+        p.part[(size_t)blockIdx.x * 3 + 1] = sm[1][0];
+        p.part[(size_t)blockIdx.x * 3 + 2] = sm[2][0];
+    }
+}
+
+__global__ void __launch_bounds__(256) anchor_final_kernel(AlParams p, int n_blocks) {
+    __shared__ double sm[3][256];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int k = threadIdx.x; k < n_blocks; k += 256) { a += p.part[(size_t)k * 3]; b += p.part[(size_t)k * 3 + 1]; c += p.part[(size_t)k * 3 + 2]; }
+    sm[0][threadIdx.x] = a; sm[1][threadIdx.x] = b; sm[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+            sm[2][threadIdx.x] += sm[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float lc = (float)(sm[0][0] / p.batch) * p.cls_weight;
+        const float ll = (float)(sm[1][0] / p.batch) * p.loc_weight;
+        const float ld = p.dir ? (float)(sm[2][0] / p.batch) * p.dir_weight : 0.f;
+        p.losses[1] = lc; p.losses[2] = ll; p.losses[3] = ld;
+        p.losses[0] = lc + ll + ld;
+    }
+}
+
 }  // namespace
 
 enum { COL_MAX_CHUNKS = 512 };
@@ -1108,5 +1252,37 @@ extern "C" int cpd_center_loss(const float *rows, int ld, int batch, int hw, int
     focal_final_kernel<<<1, 256, 0, cpd_s(st)>>>(p, blocks);
     const int scale_blocks = (int)cpd_div_up(n_rows * num_classes, 256);
     loss_finish_kernel<<<scale_blocks + 1, 256, 0, cpd_s(st)>>>(p, scale_blocks);
+    return cpd_check_launch();
+}
+
+// ---- fused anchor-head loss + gradient ----
+extern "C" size_t cpd_anchor_loss_workspace_bytes(int batch, int n_anchors) {
+    if (batch <= 0 || n_anchors <= 0) return 0;
+    const size_t blocks = (size_t)cpd_div_up((long long)batch * n_anchors, 256);
+    return cpd_align(blocks * 3 * sizeof(double)) + cpd_align((size_t)batch * sizeof(int));
+}
+extern "C" int cpd_anchor_loss(const float *cls_preds, const float *box_preds, const float *dir_preds, const int32_t *labels,
+                               const float *reg_targets, const float *anchors, int batch, int n_anchors, int num_class, int num_dir_bins,
+                               float dir_offset, const float code_weights[7], float cls_weight, float loc_weight, float dir_weight,
+                               float *d_cls, float *d_box, float *d_dir, float *losses, void *ws, size_t ws_bytes, cpd_stream_t st) {
+    if (!cls_preds || !box_preds || !labels || !reg_targets || !anchors || !code_weights || !d_cls || !d_box || !losses || !ws ||
+        batch <= 0 || n_anchors <= 0 || num_class <= 0 || (dir_preds && (!d_dir || num_dir_bins < 2 || num_dir_bins > 16)))
+        return CPD_ERR_ARG;
+    if (ws_bytes < cpd_anchor_loss_workspace_bytes(batch, n_anchors)) return CPD_ERR_WORKSPACE;
+    const long long total = (long long)batch * n_anchors;
+    const int blocks = (int)cpd_div_up(total, 256);
+    AlParams p;
+    p.cls = cls_preds; p.box = box_preds; p.dir = dir_preds; p.labels = labels; p.reg = reg_targets; p.anchors = anchors;
+    p.d_cls = d_cls; p.d_box = d_box; p.d_dir = d_dir; p.losses = losses;
+    p.part = (double *)ws;
+    p.pos = (int *)((char *)ws + cpd_align((size_t)blocks * 3 * sizeof(double)));
+    p.batch = batch; p.n_anchors = n_anchors; p.num_class = num_class; p.num_bins = num_dir_bins;
+    p.dir_offset = dir_offset;
+    for (int k = 0; k < 7; ++k) p.cw[k] = code_weights[k];
+    p.cls_weight = cls_weight; p.loc_weight = loc_weight; p.dir_weight = dir_weight;
+    if (hipMemsetAsync(p.pos, 0, (size_t)batch * sizeof(int), cpd_s(st)) != hipSuccess) return CPD_ERR_LAUNCH;
+    anchor_count_kernel<<<blocks, 256, 0, cpd_s(st)>>>(p);
+    anchor_loss_kernel<<<blocks, 256, 0, cpd_s(st)>>>(p);
+    anchor_final_kernel<<<1, 256, 0, cpd_s(st)>>>(p, blocks);
     return cpd_check_launch();
 }

@@ -321,6 +321,21 @@ int cpd_center_loss(const float *rows, int ld, int batch, int hw, int num_classe
                     const int64_t *masks, int k, const float code_weights[8], float loc_weight,
                     float cls_weight, float *d_rows, float *losses, void *ws, size_t ws_bytes,
                     cpd_stream_t stream);
+/* AnchorHeadTemplate.get_loss (anchor_head_template.py:179-334) fused with its gradient: sigmoid focal
+ * classification loss (alpha 0.25, gamma 2), smooth-L1 (beta 1/9, code_weights) on the residual-coded boxes
+ * with the sin-difference heading encoding, cross entropy on the direction bins (dir_preds NULL: no direction
+ * classifier); per-sample normalisation by max(#positive anchors, 1), sums divided by batch, times the three
+ * loss weights. cls_preds [batch][n_anchors][num_class], box_preds / reg_targets [batch][n_anchors][7],
+ * dir_preds [batch][n_anchors][num_dir_bins], labels [batch][n_anchors] (-1 ignore, 0 background, k class k:
+ * what cpd_anchor_assign emits), anchors [n_anchors][7]. Outputs: d_cls / d_box / d_dir (same shapes as the
+ * predictions) and losses[4] = {total, cls, loc, dir} on the device. Deterministic.                       */
+size_t cpd_anchor_loss_workspace_bytes(int batch, int n_anchors);
+int cpd_anchor_loss(const float *cls_preds, const float *box_preds, const float *dir_preds,
+                    const int32_t *labels, const float *reg_targets, const float *anchors, int batch,
+                    int n_anchors, int num_class, int num_dir_bins, float dir_offset,
+                    const float code_weights[7], float cls_weight, float loc_weight, float dir_weight,
+                    float *d_cls, float *d_box, float *d_dir, float *losses, void *ws,
+                    size_t ws_bytes, cpd_stream_t stream);
 /* Adam with decoupled weight decay on a flat buffer (tools/train_utils/optimization/fastai_optim.py:
  * 132-150 true_wd semantics): grad is multiplied first by grad_scale (1/world after all-reduce) and,
  * when grad_scale_dev is not NULL, by the float it points to in device memory (the clip factor of

@@ -501,6 +501,27 @@ def main():
     ah_sd = {"ahs." + k: v.numpy() for k, v in head.state_dict().items()}
     np.savez_compressed(os.path.join(HERE, "anchor_head_single.npz"), points=pts_bev.numpy(), feat=feat2d.numpy(), mask=mask.numpy(),
                         batch_cls_preds=outd["batch_cls_preds"].numpy(), batch_box_preds=outd["batch_box_preds"].numpy(), pcr=pcr, **ah_sd)
+    # 12. AnchorHeadTemplate.get_loss (anchor_head_template.py:179-334) on the real AnchorHeadSingle object of section 10,
+    #     fed with section 9's predictions and assigned targets: SigmoidFocalClassificationLoss, WeightedSmoothL1Loss with the
+    #     sin-difference encoding, WeightedCrossEntropyLoss on the direction bins (loss_utils.py:10-206), and the gradients
+    #     autograd gives w.r.t. the three prediction maps (every 5th anchor + whole-tensor sums, to keep the fixture small).
+    lp = [t.clone().requires_grad_(True) for t in (cls_preds, box_preds, dir_preds)]
+    # a fresh head (section 10's eval forward left its occupancy-masked anchors in head.anchors) with the full anchor set
+    head = ahs.AnchorHeadSingle(model_cfg=mcfg, num_frames=1, input_channels=24, num_class=3, class_names=["Vehicle", "Pedestrian", "Cyclist"],
+                                grid_size=np.array([416, 416, 40]), point_cloud_range=pcr, predict_boxes_when_training=False)
+    head.train()
+    head.anchors = [a.clone() for a in head.anchors_root]      # what forward() installs when no anchor is masked out
+    head.forward_ret_dict = {"cls_preds": lp[0], "box_preds": lp[1], "dir_cls_preds": lp[2],
+                             "box_cls_labels": tgt["box_cls_labels"].clone(), "box_reg_targets": tgt["box_reg_targets"].clone()}
+    rpn_loss, tb = head.get_loss()
+    rpn_loss.backward()
+    gl = [t.grad.reshape(2, n_anc, -1) for t in lp]
+    np.savez_compressed(os.path.join(HERE, "anchor_loss.npz"), rpn_loss=np.float32(rpn_loss.item()),
+                        cls_loss=np.float32(tb["rpn_loss_cls"]), loc_loss=np.float32(tb["rpn_loss_loc"]), dir_loss=np.float32(tb["rpn_loss_dir"]),
+                        weights=np.array([1.0, 2.0, 0.2], np.float32), dir_offset=np.float32(0.78539),
+                        g_cls=gl[0][:, ::5].numpy(), g_box=gl[1][:, ::5].numpy(), g_dir=gl[2][:, ::5].numpy(),
+                        g_sums=np.array([[g_.sum().item(), g_.abs().sum().item()] for g_ in gl], np.float64))
+    print("anchor_loss: rpn %.6f = cls %.6f + loc %.6f + dir %.6f" % (rpn_loss.item(), tb["rpn_loss_cls"], tb["rpn_loss_loc"], tb["rpn_loss_dir"]))
     # 11. VoxelRCNNHead eval forward (voxel_rcnn_head.py:664-760, 876-916; roi_head_template.py:269-299): RoI grid
     #     pooling on two levels, shared FC / cls / reg layers, box decoding in the RoI frame. The real common_utils.py
     #     and spconv_utils.py are loaded by file; pointnet2_stack_cuda stays the oracle-backed stub of section 8.

@@ -102,3 +102,68 @@ def test_anchor_head_single_forward_matches_reference_module(golden, hip):
     out = head(dd)
     np.testing.assert_allclose(out["batch_cls_preds"].cpu().numpy(), g["batch_cls_preds"], atol=1e-4, rtol=0)
     np.testing.assert_allclose(out["batch_box_preds"].cpu().numpy(), g["batch_box_preds"], atol=2e-4, rtol=1e-5)
+
+
+def test_anchor_loss_restatement_matches_reference_get_loss(golden):
+    """cpd_amd.anchor_head.anchor_head_loss_torch against the reference's own AnchorHeadTemplate.get_loss and the gradients its
+    autograd produced (tests/golden/anchor_loss.npz, section 12 of make_golden.py). CPU."""
+    import torch
+    from cpd_amd import anchor_head as ah
+    a, g = golden("anchor_head"), golden("anchor_loss")
+    preds = [torch.tensor(a[k], requires_grad=True) for k in ("cls_preds", "box_preds", "dir_preds")]
+    w = g["weights"]
+    total, parts = ah.anchor_head_loss_torch(torch.tensor(a["anchors"]), preds[0], preds[1], preds[2], torch.tensor(a["labels"]),
+                                             torch.tensor(a["reg_targets"]), 3, float(w[0]), float(w[1]), float(w[2]),
+                                             dir_offset=float(g["dir_offset"]))
+    total.backward()
+    np.testing.assert_allclose(float(total.detach()), g["rpn_loss"], rtol=1e-6)
+    for k, name in (("rpn_loss_cls", "cls_loss"), ("rpn_loss_loc", "loc_loss"), ("rpn_loss_dir", "dir_loss")):
+        np.testing.assert_allclose(float(parts[k]), g[name], rtol=1e-6)
+    n = a["labels"].shape[1]
+    for t, name, row in zip(preds, ("g_cls", "g_box", "g_dir"), range(3)):
+        full = t.grad.reshape(2, n, -1)
+        np.testing.assert_allclose(full[:, ::5].numpy(), g[name], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose([full.sum().item(), full.abs().sum().item()], g["g_sums"][row], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_fused_anchor_loss_matches_reference_get_loss(golden, hip):
+    """cpd_anchor_loss (three launches, loss + gradient) against the same reference goldens, and against the torch
+    restatement on a larger random problem with ignored anchors, empty samples and a NaN regression target."""
+    import torch
+    from cpd_amd import anchor_head as ah
+    a, g = golden("anchor_head"), golden("anchor_loss")
+    dev = lambda k: torch.tensor(a[k]).cuda()
+    w = g["weights"]
+    losses, grads = ah.anchor_head_loss(dev("anchors"), dev("cls_preds"), dev("box_preds"), dev("dir_preds"), dev("labels"),
+                                        dev("reg_targets"), 3, float(w[0]), float(w[1]), float(w[2]), dir_offset=float(g["dir_offset"]))
+    got = losses.cpu().numpy()
+    np.testing.assert_allclose(got, [g["rpn_loss"], g["cls_loss"], g["loc_loss"], g["dir_loss"]], rtol=3e-6)
+    n = a["labels"].shape[1]
+    for t, name, row in zip(grads, ("g_cls", "g_box", "g_dir"), range(3)):
+        assert t.shape == tuple(a[{"g_cls": "cls_preds", "g_box": "box_preds", "g_dir": "dir_preds"}[name]].shape)
+        full = t.reshape(2, n, -1)
+        ref = g[name]
+        assert np.abs(full[:, ::5].cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max()
+        np.testing.assert_allclose([full.sum().item(), full.abs().sum().item()], g["g_sums"][row], rtol=1e-4, atol=1e-6)
+    # larger random problem
+    torch.manual_seed(5)
+    B, n, nc = 3, 40000, 3
+    anchors = torch.randn(n, 7, device="cuda")
+    cls, box, dr = torch.randn(B, n, nc, device="cuda") * 2, torch.randn(B, n, 7, device="cuda"), torch.randn(B, n, 2, device="cuda")
+    labels = torch.randint(-1, nc + 1, (B, n), device="cuda", dtype=torch.int32)
+    labels[1] = torch.where(labels[1] > 0, torch.zeros_like(labels[1]), labels[1])          # a sample without positives
+    reg = torch.randn(B, n, 7, device="cuda") * 0.5
+    reg[0, 7, 2] = float("nan")
+    cw = [1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 2.0]
+    leaf = [t.clone().requires_grad_(True) for t in (cls, box, dr)]
+    want, parts = ah.anchor_head_loss_torch(anchors, leaf[0], leaf[1], leaf[2], labels, reg, nc, 1.0, 2.0, 0.2, cw)
+    want.backward()
+    losses, grads = ah.anchor_head_loss(anchors, cls, box, dr, labels, reg, nc, 1.0, 2.0, 0.2, cw)
+    got = losses.cpu().numpy()
+    np.testing.assert_allclose(got, [float(want.detach()), float(parts["rpn_loss_cls"]), float(parts["rpn_loss_loc"]),
+                                     float(parts["rpn_loss_dir"])], rtol=1e-5)
+    for t, l in zip(grads, leaf):
+        assert (t - l.grad).abs().max().item() <= 1e-5 * l.grad.abs().max().item()
+    again, _ = ah.anchor_head_loss(anchors, cls, box, dr, labels, reg, nc, 1.0, 2.0, 0.2, cw)
+    assert torch.equal(again, losses)

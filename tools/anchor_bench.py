@@ -45,3 +45,19 @@ print("assign_targets B=%d, %d anchors x %d GT per frame: %.2f ms (host loop ove
       "(fused, no IoU matrix): %.1f us = %.1f G IoU/s; IoU matrix alone %.1f us" %
       (B, n_anchor, M, t_assign, t_single * 1e3, 2 * a0.shape[0] * M / (t_single * 1e-3) / 1e9, t_matrix * 1e3))
 print("generate_predicted_boxes B=%d x %d anchors: %.1f us (%.0f GB/s)" % (B, n_anchor, t_dec * 1e3, B * n_anchor * (7 + 7 + 2) * 4 / (t_dec * 1e-3) / 1e9))
+tg = assigner.assign_targets(anchors, gt)
+lab, reg = tg["box_cls_labels"], tg["box_reg_targets"]
+t_loss = timed(lambda: ah.anchor_head_loss(anchors, cls, box, dr, lab, reg, 3), 20)
+leaf = [t.clone().requires_grad_(True) for t in (cls, box, dr)]
+
+
+def torch_loss():
+    for t in leaf:
+        t.grad = None
+    ah.anchor_head_loss_torch(anchors, leaf[0], leaf[1], leaf[2], lab, reg, 3)[0].backward()
+
+
+t_torch = timed(torch_loss, 5)
+nbytes = B * n_anchor * ((3 + 7 + 2) * 2 + 7 + 1) * 4
+print("get_loss + gradient B=%d x %d anchors: fused kernel %.1f us (%.0f GB/s algorithmic); torch autograd restatement on the same GPU %.2f ms"
+      % (B, n_anchor, t_loss * 1e3, nbytes / (t_loss * 1e-3) / 1e9, t_torch))
