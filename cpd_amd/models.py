@@ -134,6 +134,22 @@ class VoxelResBackBone8x(nn.Module):
         self.conv_out = spconv.SparseSequential(
             spconv.SparseConv3d(nf[3], self.out_features, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
                                 indice_key="spconv_down2"), norm_fn(self.out_features), nn.ReLU())
+        if model_cfg.get("MM", False):
+            # the prototype branch's own (lighter: one residual block per level) encoder over `voxel_features1`,
+            # spconv_backbone.py:456-486; run in training mode only (l.560-598)
+            self.conv_input_2 = spconv.SparseSequential(
+                spconv.SubMConv3d(input_channels, nf[0], 3, padding=1, bias=False, indice_key="subm1_2"), norm_fn(nf[0]), nn.ReLU())
+            self.conv1_2 = spconv.SparseSequential(SparseBasicBlock(nf[0], nf[0], norm_fn=norm_fn, indice_key="res1_2"),
+                                                   SparseBasicBlock(nf[0], nf[0], norm_fn=norm_fn, indice_key="res1_2"))
+            self.conv2_2 = spconv.SparseSequential(
+                block(nf[0], nf[1], 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv2_2", conv_type="spconv"),
+                SparseBasicBlock(nf[1], nf[1], norm_fn=norm_fn, indice_key="res2_2"))
+            self.conv3_2 = spconv.SparseSequential(
+                block(nf[1], nf[2], 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv3_2", conv_type="spconv"),
+                SparseBasicBlock(nf[2], nf[2], norm_fn=norm_fn, indice_key="res3_2"))
+            self.conv4_2 = spconv.SparseSequential(
+                block(nf[2], nf[3], 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key="spconv4_2", conv_type="spconv"),
+                SparseBasicBlock(nf[3], nf[3], norm_fn=norm_fn, indice_key="res4_2"))
         self.num_point_features = self.out_features
         if model_cfg.get("RETURN_NUM_FEATURES_AS_DICT", False):
             self.num_point_features = {"x_conv1": nf[0], "x_conv2": nf[1], "x_conv3": nf[2], "x_conv4": nf[3]}
@@ -150,6 +166,15 @@ class VoxelResBackBone8x(nn.Module):
         batch_dict.update({"encoded_spconv_tensor": out, "encoded_spconv_tensor_stride": 8})
         batch_dict.update({"multi_scale_3d_features": {"x_conv1": x_conv1, "x_conv2": x_conv2, "x_conv3": x_conv3, "x_conv4": x_conv4},
                            "multi_scale_3d_strides": {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}})
+        if self.training and self.model_cfg.get("MM", False):
+            m_in = spconv.SparseConvTensor(features=batch_dict["voxel_features1"], indices=batch_dict["voxel_coords1"].int(),
+                                           spatial_shape=self.sparse_shape, batch_size=batch_dict["batch_size"])
+            m1 = self.conv1_2(self.conv_input_2(m_in))
+            m2 = self.conv2_2(m1)
+            m3 = self.conv3_2(m2)
+            m4 = self.conv4_2(m3)
+            batch_dict.update({"encoded_spconv_tensor_stride_mm": 8,
+                               "multi_scale_3d_features_mm": {"x_conv1": m1, "x_conv2": m2, "x_conv3": m3, "x_conv4": m4}})
         return batch_dict
 
 

@@ -133,6 +133,37 @@ def test_module_api_matches_engine(oracle, hip):
     assert set(batch["multi_scale_3d_features"]) == {"x_conv1", "x_conv2", "x_conv3", "x_conv4"}
 
 
+def test_mm_branch_runs_in_training_mode_only(hip):
+    """VoxelResBackBone8x with MM: in training mode `voxel_features1 / voxel_coords1` go through the second encoder
+    (spconv_backbone.py:560-598) and come back as multi_scale_3d_features_mm; with the first encoder's weights copied
+    into it, its level-1 output equals the main branch's on the same voxels; eval mode does not touch it."""
+    from cpd_amd import models
+    cfg = models.waymo_centerpoint_cfg()
+    cfg.BACKBONE_3D.MM = True
+    torch.manual_seed(3)
+    bb = models.VoxelResBackBone8x(cfg.BACKBONE_3D, input_channels=5, grid_size=[1504, 1504, 40]).cuda()
+    sd = bb.state_dict()
+    for k in list(sd):
+        for src, dst in (("conv_input.", "conv_input_2."), ("conv1.", "conv1_2.")):
+            if k.startswith(src):
+                sd[dst + k[len(src):]] = sd[k].clone()
+    bb.load_state_dict(sd)
+    rng = np.random.default_rng(0)
+    zyx = np.unique(rng.integers([0, 700, 700], [41, 800, 800], size=(6000, 3)), axis=0)
+    coords = torch.from_numpy(np.pad(zyx, ((0, 0), (1, 0))).astype(np.float32)).cuda()
+    feats = torch.randn(coords.shape[0], 5, device="cuda")
+    batch = {"voxel_features": feats, "voxel_coords": coords, "voxel_features1": feats.clone(), "voxel_coords1": coords.clone(),
+             "batch_size": 1}
+    with torch.no_grad():
+        out = bb.train()(dict(batch))
+        mm, main = out["multi_scale_3d_features_mm"], out["multi_scale_3d_features"]
+        assert set(mm) == {"x_conv1", "x_conv2", "x_conv3", "x_conv4"} and out["encoded_spconv_tensor_stride_mm"] == 8
+        assert torch.equal(mm["x_conv1"].indices, main["x_conv1"].indices)
+        assert torch.allclose(mm["x_conv1"].features, main["x_conv1"].features, atol=1e-5)
+        assert mm["x_conv4"].features.shape[1] == 128 and mm["x_conv4"].spatial_shape == main["x_conv4"].spatial_shape
+        assert "multi_scale_3d_features_mm" not in bb.eval()(dict(batch))
+
+
 def test_empty_ragged_and_out_of_range_inputs(hip):
     """Edge cases of the batch contract: an empty cloud, a 5-point cloud and a cloud entirely outside the
     range, alone and mixed into a batch; a frame's detections do not depend on its neighbours."""

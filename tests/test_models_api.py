@@ -77,3 +77,17 @@ def test_center_head_training_branch_targets_and_loss():
     rows = torch.cat([pd[k] for k in ("center", "center_z", "dim", "rot", "hm")], 1).permute(0, 2, 3, 1).reshape(B * h * w, -1)
     want, _ = center_loss.center_head_loss(rows, B, h, w, heat, tgt, inds, masks, 3, hm_col=8)
     assert abs(float(loss) - float(want)) < 1e-6 and abs(tb["rpn_loss"] - float(want)) < 1e-6
+
+
+def test_mm_branch_layers_follow_the_reference_names():
+    """BACKBONE_3D.MM (voxel_rcnn_cproto_center.yaml:23): the prototype branch's encoder, spconv_backbone.py:456-486 --
+    conv_input_2, conv1_2 (two residual blocks), conv{2,3,4}_2 (strided conv + ONE residual block)."""
+    cfg = models.waymo_centerpoint_cfg()
+    cfg.BACKBONE_3D.MM = True
+    bb = models.VoxelResBackBone8x(cfg.BACKBONE_3D, input_channels=5, grid_size=[1504, 1504, 40])
+    keys = set(bb.state_dict())
+    assert {"conv_input_2.0.weight", "conv1_2.1.conv2.weight", "conv2_2.0.0.weight", "conv2_2.1.bn2.running_var", "conv4_2.1.conv1.bias"} <= keys
+    assert not any(k.startswith("conv2_2.2.") for k in keys)            # one residual block per strided level
+    assert tuple(bb.state_dict()["conv4_2.0.0.weight"].shape) == (128, 3, 3, 3, 64)
+    plain = models.VoxelResBackBone8x(models.waymo_centerpoint_cfg().BACKBONE_3D, input_channels=5, grid_size=[1504, 1504, 40])
+    assert not any("_2." in k for k in plain.state_dict())
