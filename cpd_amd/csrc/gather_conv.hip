@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
         const int total = p.kv * 16 * MS;
         for (int e = lane; e < total; e += 64) {
             const int t = e / (16 * MS), rr = e - t * (16 * MS);
+            if (t < 32 && !((any >> t) & 1u)) continue;      // a tap no sub-tile has: its column is never read
             const int row = row0 + rr;
             int v = -1;
             if (row < p.n_out) v = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
@@ -589,17 +590,21 @@ tile_conv_bf16_kernel(GcParams p) {
 template <int BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
 window_conv_bf16_kernel(GcParams p) {
-    constexpr int BM = 128, MS = 4, NT = BN / 32;
+    constexpr int BM = 128;
+    constexpr int WC = BN >= 64 ? 2 : 1, WR = 4 / WC;   // wave grid: 2 x 2, or 4 x 1 for the 16-column tile (tiny c_out heads)
+    constexpr int WM = BM / WR;                         // rows per wave
+    constexpr int MS = WM / 16, NT = BN / WC / 16;
     constexpr int WROWS = BM + 2, BMW = BM + 8;
     constexpr int AJ = (WROWS * 8 + 255) / 256;     // fp32 A pieces (4 channels) per thread per window
-    constexpr int BJ = 3 * BN / 64;                 // 16-byte B pieces per thread per stage
+    constexpr int B_SLOTS = 3 * 4 * BN;             // 16-byte B pieces of one stage
+    constexpr int BJ = (B_SLOTS + 255) / 256;       // ... per thread
     constexpr int A_IMG = BMW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const sa = smem;
     char *const sb = smem + 3 * A_IMG;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave - wr * WC;
     const int r = lane & 15, g = lane >> 4;
     const int item = xcd_remap(blockIdx.x, gridDim.x);
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
@@ -617,7 +622,7 @@ window_conv_bf16_kernel(GcParams p) {
         const int hw = p.img_h * p.img_w;
 #pragma unroll
         for (int s = 0; s < MS; ++s) {
-            const int pix = (row0 + wr * (BM / 2) + 16 * s + r) % hw;
+            const int pix = (row0 + wr * WM + 16 * s + r) % hw;
             const int y = pix / p.img_w, x = pix - y * p.img_w;
             const uint32_t b = (y > 0 ? 1u : 0u) | (y < p.img_h - 1 ? 2u : 0u) | (x > 0 ? 4u : 0u) | (x < p.img_w - 1 ? 8u : 0u);
             dir_ok |= b << (4 * s);
@@ -666,12 +671,14 @@ window_conv_bf16_kernel(GcParams p) {
         for (int j = 0; j < BJ; ++j) {
             const int id = j * 256 + tid;        // slot in the B stage image: (piece*4 + g)*BN + n
             const int pg = id / BN, n = id - pg * BN;
-            rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+            if (B_SLOTS % 256 == 0 || id < B_SLOTS)
+                rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
         }
     };
     auto store_weights = [&]() {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+        for (int j = 0; j < BJ; ++j)
+            if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
     };
 
     load_window(0, -1);
@@ -692,7 +699,7 @@ window_conv_bf16_kernel(GcParams p) {
                 bf16x8 ah[2], am[2], al[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const int w = wr * (BM / 2) + 16 * (s0 + s) + r + 1 + dx;
+                    const int w = wr * WM + 16 * (s0 + s) + r + 1 + dx;
                     const char *src = sa + ((g * BMW + (w ^ (2 * g))) << 4);
                     ah[s] = *reinterpret_cast<const bf16x8 *>(src);
                     am[s] = *reinterpret_cast<const bf16x8 *>(src + A_IMG);
@@ -707,7 +714,7 @@ window_conv_bf16_kernel(GcParams p) {
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int n = wc * (BN / 2) + 16 * nt + r;
+                    const int n = wc * (BN / WC) + 16 * nt + r;
                     const char *src = sb + ((g * BN + n) << 4);
                     const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
                     const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + 4 * BN * 16);
@@ -735,7 +742,7 @@ window_conv_bf16_kernel(GcParams p) {
         }
         __syncthreads();
     }
-    epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
+    epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g);
 }
 
 // Split-bf16 kernel for SPARSE layers: a workgroup owns 128 output rows x BN columns, wave w the
@@ -1238,13 +1245,15 @@ static int window_bn(int frames, int h, int w, int c_in, int c_out, int flags) {
     int on = (flags & 2) != 0;
     if (const char *e = getenv("CPD_GC_BF16X3")) on = atoi(e);
     if (const char *e = getenv("CPD_GC_WINDOW")) on = on && atoi(e);
-    if (!on || frames <= 0 || h < 2 || w < 2 || c_in <= 0 || c_out <= 0 || c_in % 32 || c_out % 64) return 0;
+    if (!on || frames <= 0 || h < 2 || w < 2 || c_in <= 0 || c_out <= 0 || c_in % 32 || (c_out % 64 && c_out > 16)) return 0;
     const long long rows = (long long)frames * h * w;
     if (rows >= (1ll << 31)) return 0;
-    const int bn = c_out % 128 == 0 ? 128 : 64;
+    // 16-column tile: the final head convs (c_out <= 16, e.g. 320 -> 11), which are bound by re-reading their wide input
+    // once per tap -- the window stages it once per dy
+    const int bn = c_out <= 16 ? 16 : (c_out % 128 == 0 ? 128 : 64);
     long long min_wgs = 600;                    // below that the rulebook path's 64-row tiles fill the chip better
     if (const char *e = getenv("CPD_GC_BF16_MIN")) min_wgs = atoll(e);
-    if (((rows + 127) / 128) * (c_out / bn) < min_wgs) return 0;
+    if (((rows + 127) / 128) * ((c_out + bn - 1) / bn) < min_wgs) return 0;
     return bn;
 }
 extern "C" int cpd_conv3x3_rows_supported(int frames, int h, int w, int c_in, int c_out, int flags) {
@@ -1267,10 +1276,11 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     p.kv = 9; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld;
     p.n_sub = (n_out + 15) / 16;
-    p.n_rb = (n_out + 127) / 128; p.n_cb = c_out / bn; p.items = p.n_rb * p.n_cb;
+    p.n_rb = (n_out + 127) / 128; p.n_cb = (c_out + bn - 1) / bn; p.items = p.n_rb * p.n_cb;
     p.img_h = h; p.img_w = w;
     const size_t lds = 3 * (size_t)(128 + 8) * 64 + 3 * (size_t)bn * 64;
     if (bn == 128) hipLaunchKernelGGL((window_conv_bf16_kernel<128>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
-    else hipLaunchKernelGGL((window_conv_bf16_kernel<64>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+    else if (bn == 64) hipLaunchKernelGGL((window_conv_bf16_kernel<64>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+    else hipLaunchKernelGGL((window_conv_bf16_kernel<16>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
     return cpd_check_launch();
 }

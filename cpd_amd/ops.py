@@ -370,7 +370,7 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=N
     image = getattr(nbr, "image", None)
     if image is not None and n_out == image[0] * image[1] * image[2] and in_ld % 4 == 0 and lib().cpd_conv3x3_rows_supported(
             image[0], image[1], image[2], int(c_in), int(c_out), (1 if dense else 0) | (2 if bf16x3 else 0)):
-        return "window_conv_bf16_kernel<%d>" % (128 if c_out % 128 == 0 else 64)
+        return "window_conv_bf16_kernel<%d>" % (16 if c_out <= 16 else (128 if c_out % 128 == 0 else 64))
     wg, a, b, vec = (ctypes.c_int(0) for _ in range(4))
     check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), (1 if dense else 0) | (2 if bf16x3 else 0),
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),

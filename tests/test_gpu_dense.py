@@ -194,7 +194,7 @@ def test_split_bf16_conv_is_fp32_accurate(hip, cin, cout, k, stride):
 
 
 @pytest.mark.parametrize("cin,cout,batch,h,w", [(128, 128, 3, 188, 188), (256, 256, 5, 94, 94), (64, 320, 2, 188, 188),
-                                                 (512, 64, 3, 188, 188), (32, 64, 3, 131, 200)])
+                                                 (512, 64, 3, 188, 188), (32, 64, 3, 131, 200), (320, 11, 3, 188, 188), (64, 3, 3, 188, 188)])
 def test_window_conv_matches_the_table_path(hip, cin, cout, batch, h, w):
     """cpd_conv3x3_rows (no rulebook: one gathered + split window per dy, image borders masked on the fragments)
     against cpd_gather_conv on the pixel table, with the full epilogue, and against float64 on sampled rows --
@@ -216,7 +216,8 @@ def test_window_conv_matches_the_table_path(hip, cin, cout, batch, h, w):
     got = ops.gather_conv(x, cin, pw, nbr, 9, n, cout, scale, shift, res, True, dense=True, bf16x3=True)
     plain = nbr.clone()                                  # same table without the geometry tag -> rulebook kernels
     want = ops.gather_conv(x, cin, pw, plain, 9, n, cout, scale, shift, res, True, dense=True, bf16x3=True)
-    assert torch.allclose(got, want, rtol=1e-5, atol=2e-5), (got - want).abs().max().item()
+    # narrow outputs take the fp32-MFMA wave kernel on the table path: two fp32-level results, different summation orders
+    assert torch.allclose(got, want, rtol=1e-5, atol=2e-5 if cout % 64 == 0 else 1e-4), (got - want).abs().max().item()
     edge = [0, 1, w - 1, w, 2 * w - 1, (h - 1) * w, h * w - 1, h * w, h * w + w - 1, n - w, n - 1, n // 2, 127, 128, 129]
     rows = torch.cat([torch.tensor(edge, device="cuda"), torch.randint(0, n, (1024,), device="cuda")])
     idx = nbr[:, rows].long()
@@ -229,4 +230,4 @@ def test_window_conv_matches_the_table_path(hip, cin, cout, batch, h, w):
     buf = torch.zeros(n, cout + 64, device="cuda")
     ops.gather_conv(xin[:, 32:], cin, pw, nbr, 9, n, cout, dense=True, bf16x3=True, out=buf[:, 64:])
     want2 = ops.gather_conv(xin[:, 32:], cin, pw, plain, 9, n, cout, dense=True, bf16x3=True)
-    assert torch.allclose(buf[:, 64:], want2, rtol=1e-5, atol=2e-5) and not buf[:, :64].any()
+    assert torch.allclose(buf[:, 64:], want2, rtol=1e-5, atol=2e-5 if cout % 64 == 0 else 1e-4) and not buf[:, :64].any()
