@@ -752,10 +752,13 @@ window_conv_bf16_kernel(GcParams p) {
 // fetched or split twice. Taps that none of the workgroup's eight 16-row sub-tiles has are not
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
 // (BN = 128 sits 6 registers above the 3-waves-per-SIMD budget without the hint; it fits without spilling)
-template <int BN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 8)))
+// MS = row sub-tiles per wave: 2 (128-row workgroups) or 1 (64-row workgroups, for layers too small to give every CU a
+// 128-row workgroup: twice the workgroups, each staging the same weights for half the rows).
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, BN == 128 && MS == 2 ? 3 : 8)))
 rowwave_conv_bf16_kernel(GcParams p) {
-    constexpr int MS = 2, NT = BN / 16;
+    constexpr int NT = BN / 16;
+    constexpr int WG_ROWS = 64 * MS, WG_SUBS = 4 * MS;
     constexpr int B_SLOTS = 3 * 4 * BN;        // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
@@ -765,19 +768,22 @@ rowwave_conv_bf16_kernel(GcParams p) {
     const int r = lane & 15, g = lane >> 4;
     const int item = xcd_remap(blockIdx.x, gridDim.x);
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
-    const int row0 = rb * 128 + wave * 32, col0 = cb * BN;
+    const int row0 = rb * WG_ROWS + wave * (16 * MS), col0 = cb * BN;
 
     // tap activity: workgroup-wide (which stages exist) and per sub-tile of this wave
-    uint32_t wg_mask = 0xffffffffu, my_mask[MS] = {0xffffffffu, 0xffffffffu};
+    uint32_t wg_mask = 0xffffffffu, my_mask[MS];
+#pragma unroll
+    for (int s = 0; s < MS; ++s) my_mask[s] = 0xffffffffu;
     if (p.tapmask) {
         wg_mask = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int sub = rb * 8 + i;
+        for (int i = 0; i < WG_SUBS; ++i) {
+            const int sub = rb * WG_SUBS + i;
             const uint32_t m = sub < p.n_sub ? p.tapmask[sub] : 0u;
             wg_mask |= m;
-            if (i == 2 * wave) my_mask[0] = m;
-            if (i == 2 * wave + 1) my_mask[1] = m;
+#pragma unroll
+            for (int s = 0; s < MS; ++s)
+                if (i == MS * wave + s) my_mask[s] = m;
         }
     }
     auto tap_on = [&](int t) { return t >= 32 || ((wg_mask >> t) & 1u); };
@@ -872,7 +878,7 @@ rowwave_conv_bf16_kernel(GcParams p) {
                 }
                 stage_load(tn, kn);
             }
-            const bool on0 = sub_on(0, t), on1 = sub_on(1, t);
+            const bool on0 = sub_on(0, t), on1 = MS > 1 && sub_on(MS - 1, t);
             if (on0 || on1) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -1072,14 +1078,25 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
         if (const char *e = getenv("CPD_GC_ROWWAVE_MIN")) rw_min = atoll(e);
         if (const char *e = getenv("CPD_GC_ROWWAVE_FLOOR")) rw_floor = atoll(e);
         const long long row_tiles = (n_out + 127) / 128;
-        for (int b = bn; b >= 32; b >>= 1) {
-            if (row_tiles * (c_out / b) >= rw_min) {
-                pl.use_wg = 3; pl.a = 128; pl.b = b;
+        if (row_tiles * (c_out / bn) >= rw_min) {
+            pl.use_wg = 3; pl.a = 128; pl.b = bn;
+            return pl;
+        }
+        int small_rows = 1;                     // 64-row workgroups before narrower column tiles
+        if (const char *e = getenv("CPD_GC_ROWWAVE_64")) small_rows = atoi(e);
+        const long long row_tiles64 = (n_out + 63) / 64;
+        if (small_rows && row_tiles64 * (c_out / bn) >= rw_min) {
+            pl.use_wg = 3; pl.a = 64; pl.b = bn;
+            return pl;
+        }
+        for (int b = bn >> 1; b >= 32; b >>= 1) {
+            if ((small_rows ? row_tiles64 : row_tiles) * (c_out / b) >= rw_min) {
+                pl.use_wg = 3; pl.a = small_rows ? 64 : 128; pl.b = b;
                 return pl;
             }
         }
-        if (row_tiles * (c_out / 32) >= rw_floor) {
-            pl.use_wg = 3; pl.a = 128; pl.b = 32;
+        if ((small_rows ? row_tiles64 : row_tiles) * (c_out / 32) >= rw_floor) {
+            pl.use_wg = 3; pl.a = small_rows ? 64 : 128; pl.b = 32;
             return pl;
         }
     }
@@ -1186,10 +1203,14 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
                 flags, tapmask != nullptr, pl.use_wg, pl.a, pl.b);
     if (pl.use_wg == 3) {
         p.wb = packed_w + packed_f32_floats(kv, c_in, c_out);
-        p.n_rb = (n_out + 127) / 128;
+        p.n_rb = (n_out + pl.a - 1) / pl.a;
         p.n_cb = c_out / pl.b;
         p.items = p.n_rb * p.n_cb;
-        if (pl.b == 32) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<32>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+        if (pl.a == 64) {
+            if (pl.b == 32) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<32, 1>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+            else if (pl.b == 64) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<64, 1>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+            else hipLaunchKernelGGL((rowwave_conv_bf16_kernel<128, 1>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+        } else if (pl.b == 32) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<32>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
         else if (pl.b == 64) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<64>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
         else hipLaunchKernelGGL((rowwave_conv_bf16_kernel<128>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
         return cpd_check_launch();

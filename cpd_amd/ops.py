@@ -376,7 +376,7 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=N
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
           "cpd_gather_conv_tile")
     if wg.value == 3:
-        return "rowwave_conv_bf16_kernel<%d>" % b.value
+        return "rowwave_conv_bf16_kernel<%d,%d>" % (b.value, a.value // 64)        # <column tile, row sub-tiles per wave>
     if wg.value == 2:
         return "tile_conv_bf16_kernel<%d,%d>" % (a.value, b.value)
     if wg.value:

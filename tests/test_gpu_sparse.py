@@ -197,3 +197,29 @@ def test_tapmask_skipping_is_exact(oracle, hip, cin, cout, n):
     np.testing.assert_array_equal(nbr2.cpu().numpy(), want2)
     got2 = ops.gather_conv(dev(feat), cin, ops.pack_weight(w_kio), nbr2, 27, o_d.shape[0], cout).cpu().numpy()
     np.testing.assert_allclose(got2, oracle.sparse_conv(feat, w, None, want2), atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("cin,cout,n,want", [(128, 128, 80000, "<128,2>"), (128, 128, 24000, "<128,1>"), (64, 64, 30000, "<64,1>"),
+                                             (32, 32, 30000, "<32,1>"), (32, 32, 80000, "<32,2>"), (64, 128, 12000, "<64,1>")])
+def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, cin, cout, n, want):
+    """The sparse split-bf16 kernel in each of its shapes -- 128-row workgroups, the 64-row ones small layers get, and the
+    narrower column tiles below that -- against the oracle, on clustered sites (tap skipping active) with BN/residual/ReLU."""
+    rng = np.random.default_rng(n + cin)
+    batch, shape = 2, [11, 96, 96]
+    idx = np.unique(np.concatenate([random_sites(rng, batch, [11, 40, 40], n // 2), random_sites(rng, batch, shape, n // 2)]), axis=0)
+    idx = idx.astype(np.int32)
+    rows = idx.shape[0]
+    feat = rng.normal(size=(rows, cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    scale = (rng.random(cout) + 0.5).astype(np.float32); shift = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(rows, cout)).astype(np.float32)
+    d_idx = dev(idx)
+    nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
+    name = ops.gather_conv_tile(rows, cin, cout, cin, dense=False, bf16x3=True)
+    assert name == "rowwave_conv_bf16_kernel" + want, (name, rows)
+    w_kio = torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda()
+    got = ops.gather_conv(dev(feat), cin, ops.pack_weight(w_kio), nbr, 27, rows, cout, dev(scale), dev(shift), dev(res), True,
+                          bf16x3=True).cpu().numpy()
+    ref = oracle.sparse_conv(feat, w, None, nbr.cpu().numpy())
+    ref = np.maximum(ref * scale + shift + res, 0)
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
