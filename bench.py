@@ -376,8 +376,8 @@ def main():
                    "parallelism": "frame-sharded replicas x%d, no data-path collective" % world,
                    "weights": "random-init (seed 0), eval-mode BN folded",
                    "conv_math": ("layers with >= 32 input channels: split-bf16 x3 (fp32 operands split exactly into 3 bf16 terms, "
-                                 "6 bf16 MFMA products per fp32 multiply-add, fp32-level error); 5/16-channel sparse layers and "
-                                 "the 320->11 head conv: fp32 MFMA") if cfg.conv_math == "bf16x3" else "fp32 MFMA everywhere"},
+                                 "6 bf16 MFMA products per fp32 multiply-add, fp32-level error); 5/16-channel sparse layers: "
+                                 "fp32 MFMA") if cfg.conv_math == "bf16x3" else "fp32 MFMA everywhere"},
     }
 
     if not args.no_roofline:
