@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/cpd_hip.h"
 
@@ -25,6 +26,14 @@ static inline int cpd_check_launch() {
             return CPD_ERR_LAUNCH;              \
         }                                       \
     } while (0)
+
+// Tuning / diagnostic knobs (CPD_GC_*, CPD_WGRAD_*) are read from the environment only when CPD_TUNE=1 is set:
+// a production launch costs one getenv instead of fifteen.
+static inline bool cpd_tuning() {
+    const char *e = getenv("CPD_TUNE");
+    return e && e[0] == '1';
+}
+static inline const char *cpd_knob(bool tuning, const char *name) { return tuning ? getenv(name) : nullptr; }
 
 static inline hipStream_t cpd_s(cpd_stream_t s) { return (hipStream_t)s; }
 static inline size_t cpd_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

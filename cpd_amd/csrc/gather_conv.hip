@@ -1056,34 +1056,35 @@ struct GcPlan {
 
 static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, int flags) {
     GcPlan pl;
+    const bool tn = cpd_tuning();
     const int ntot = (c_out + 15) / 16;
     pl.vec = (c_in % 16 == 0) && (in_ld % 4 == 0) && (((uintptr_t)in & 15) == 0);
     pl.use_wg = 0;
     // split-bf16 path (CPD_GC_BF16X3): 128 x 128 tiles, needs whole 32-channel stages and 128-column tiles
     int allow_bf16 = (flags & 2) != 0;
-    if (const char *e = getenv("CPD_GC_BF16X3")) allow_bf16 = atoi(e);
+    if (const char *e = cpd_knob(tn, "CPD_GC_BF16X3")) allow_bf16 = atoi(e);
     long long bf16_min_wgs = 600;       // > 2 workgroups per CU, else the narrower/shorter tile (measured: single-frame bench, train step)
-    if (const char *e = getenv("CPD_GC_BF16_MIN")) bf16_min_wgs = atoll(e);
+    if (const char *e = cpd_knob(tn, "CPD_GC_BF16_MIN")) bf16_min_wgs = atoll(e);
     int dense_rowwave = 0;
-    if (const char *e = getenv("CPD_GC_DENSE_ROWWAVE")) dense_rowwave = atoi(e);
+    if (const char *e = cpd_knob(tn, "CPD_GC_DENSE_ROWWAVE")) dense_rowwave = atoi(e);
     if (allow_bf16 && (!(flags & 1) || dense_rowwave) && pl.vec && c_in % 32 == 0 && c_out % 32 == 0) {     // sparse layers
         const int bn = c_out % 128 == 0 ? 128 : (c_out % 64 == 0 ? 64 : 32);
         int force_bn = 0;
-        if (const char *e = getenv("CPD_GC_ROWWAVE_BN")) force_bn = atoi(e);
+        if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_BN")) force_bn = atoi(e);
         if ((force_bn == 64 || force_bn == 128) && c_out % force_bn == 0) { pl.use_wg = 3; pl.a = 128; pl.b = force_bn; return pl; }
         // widest column tile that still gives every CU a workgroup: a narrower tile re-gathers the rows once per
         // column tile, which small layers (the 1/4 and 1/8 stages of a single frame) can afford; below that, the
         // narrowest tile as long as it covers half the chip (sweep: train step and single-frame bench, +-1%)
         long long rw_min = 256, rw_floor = 128;
-        if (const char *e = getenv("CPD_GC_ROWWAVE_MIN")) rw_min = atoll(e);
-        if (const char *e = getenv("CPD_GC_ROWWAVE_FLOOR")) rw_floor = atoll(e);
+        if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_MIN")) rw_min = atoll(e);
+        if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_FLOOR")) rw_floor = atoll(e);
         const long long row_tiles = (n_out + 127) / 128;
         if (row_tiles * (c_out / bn) >= rw_min) {
             pl.use_wg = 3; pl.a = 128; pl.b = bn;
             return pl;
         }
         int small_rows = 1;                     // 64-row workgroups before narrower column tiles
-        if (const char *e = getenv("CPD_GC_ROWWAVE_64")) small_rows = atoi(e);
+        if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_64")) small_rows = atoi(e);
         const long long row_tiles64 = (n_out + 63) / 64;
         if (small_rows && row_tiles64 * (c_out / bn) >= rw_min) {
             pl.use_wg = 3; pl.a = 64; pl.b = bn;
@@ -1102,31 +1103,31 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
     }
     if (allow_bf16 && (flags & 1) && pl.vec && c_in % 32 == 0 && c_out % 64 == 0) {
         int bn = c_out % 128 == 0 ? 128 : 64;
-        if (const char *e = getenv("CPD_GC_BF16_BN")) { if (atoi(e) == 64) bn = 64; }
+        if (const char *e = cpd_knob(tn, "CPD_GC_BF16_BN")) { if (atoi(e) == 64) bn = 64; }
         if ((long long)((n_out + 127) / 128) * (c_out / bn) >= bf16_min_wgs) {
             pl.use_wg = 2; pl.a = 128; pl.b = bn;
             return pl;
         }
         long long min64 = 256;                              // 64-row tiles when 128-row tiling would leave CUs idle
-        if (const char *e = getenv("CPD_GC_BF16_MIN64")) min64 = atoll(e);
+        if (const char *e = cpd_knob(tn, "CPD_GC_BF16_MIN64")) min64 = atoll(e);
         if ((long long)((n_out + 63) / 64) * (c_out / bn) >= min64) {
             pl.use_wg = 2; pl.a = 64; pl.b = bn;
             return pl;
         }
     }
     int force_wg = -1;
-    if (const char *e = getenv("CPD_GC_WG")) force_wg = atoi(e);
+    if (const char *e = cpd_knob(tn, "CPD_GC_WG")) force_wg = atoi(e);
     if (((flags & 1) && force_wg != 0) || force_wg > 0) {
         int bm, bn;
         choose_wg_tile(n_out, c_in, c_out, &bm, &bn);
         if (force_wg > 0 && !bm && c_in % 32 == 0 && c_out % 64 == 0) { bm = 64; bn = 64; }
-        if (const char *e = getenv("CPD_GC_BM")) { int v = atoi(e); if ((v == 64 || v == 128) && bm) bm = v; }
-        if (const char *e = getenv("CPD_GC_BN")) { int v = atoi(e); if ((v == 64 || v == 128) && bn && c_out % v == 0) bn = v; }
+        if (const char *e = cpd_knob(tn, "CPD_GC_BM")) { int v = atoi(e); if ((v == 64 || v == 128) && bm) bm = v; }
+        if (const char *e = cpd_knob(tn, "CPD_GC_BN")) { int v = atoi(e); if ((v == 64 || v == 128) && bn && c_out % v == 0) bn = v; }
         if (bm && bn && pl.vec) { pl.use_wg = 1; pl.a = bm; pl.b = bn; return pl; }
     }
     choose_wave_tile(n_out, ntot, &pl.a, &pl.b);
-    if (const char *e = getenv("CPD_GC_MS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) pl.a = v; }
-    if (const char *e = getenv("CPD_GC_NT")) { int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 5 || v == 8) && ntot % v == 0) pl.b = v; }
+    if (const char *e = cpd_knob(tn, "CPD_GC_MS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) pl.a = v; }
+    if (const char *e = cpd_knob(tn, "CPD_GC_NT")) { int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 5 || v == 8) && ntot % v == 0) pl.b = v; }
     return pl;
 }
 
@@ -1221,7 +1222,7 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
         p.n_cb = c_out / pl.b;
         p.items = p.n_rb * p.n_cb;
         int db = 0;
-        if (const char *e = getenv("CPD_GC_BF16_DB")) db = atoi(e);
+        if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_BF16_DB")) db = atoi(e);
         if (pl.b == 64) db = 0;
         if (pl.a == 64) {                                   // small-problem variant: 64-row tiles double the workgroup count
             const size_t lds64 = 3 * (size_t)(64 + pl.b) * 64;
@@ -1263,9 +1264,10 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
 
 // ---- dense 3x3 / stride 1 / pad 1 over pixel rows, no rulebook (window_conv_bf16_kernel) ----
 static int window_bn(int frames, int h, int w, int c_in, int c_out, int flags) {
+    const bool tn = cpd_tuning();
     int on = (flags & 2) != 0;
-    if (const char *e = getenv("CPD_GC_BF16X3")) on = atoi(e);
-    if (const char *e = getenv("CPD_GC_WINDOW")) on = on && atoi(e);
+    if (const char *e = cpd_knob(tn, "CPD_GC_BF16X3")) on = atoi(e);
+    if (const char *e = cpd_knob(tn, "CPD_GC_WINDOW")) on = on && atoi(e);
     if (!on || frames <= 0 || h < 2 || w < 2 || c_in <= 0 || c_out <= 0 || c_in % 32 || (c_out % 64 && c_out > 16)) return 0;
     const long long rows = (long long)frames * h * w;
     if (rows >= (1ll << 31)) return 0;
@@ -1273,7 +1275,7 @@ static int window_bn(int frames, int h, int w, int c_in, int c_out, int flags) {
     // once per tap -- the window stages it once per dy
     const int bn = c_out <= 16 ? 16 : (c_out % 128 == 0 ? 128 : 64);
     long long min_wgs = 600;                    // below that the rulebook path's 64-row tiles fill the chip better
-    if (const char *e = getenv("CPD_GC_BF16_MIN")) min_wgs = atoll(e);
+    if (const char *e = cpd_knob(tn, "CPD_GC_BF16_MIN")) min_wgs = atoll(e);
     if (((rows + 127) / 128) * ((c_out + bn - 1) / bn) < min_wgs) return 0;
     return bn;
 }

@@ -1071,7 +1071,7 @@ extern "C" int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, 
 
 // Tile kernel plan: (TM, TN) in {64,128}^2 when both channel counts are multiples of 64.
 static void wgrad_chunks(int n_out, long long per_chunk, int min_rows, int round, WgParams *p, long long target = 512) {
-    if (const char *e = getenv("CPD_WGRAD_WGS")) target = atoll(e);
+    if (const char *e = cpd_knob(cpd_tuning(), "CPD_WGRAD_WGS")) target = atoll(e);
     int chunks = (int)((target + per_chunk - 1) / per_chunk);
     const int max_chunks = (n_out + min_rows - 1) / min_rows;
     if (chunks > max_chunks) chunks = max_chunks;
@@ -1094,7 +1094,7 @@ static bool wgrad_tile_plan(int n_out, int c_in, int c_out, int kv, WgParams *p,
 static int wgrad_bf16_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
 static bool wgrad_bf16_plan(int n_out, int c_in, int c_out, int kv, int flags, WgParams *p, int *tm, int *tn) {
     int on = (flags & 2) != 0;
-    if (const char *e = getenv("CPD_WGRAD_BF16X3")) on = atoi(e);
+    if (const char *e = cpd_knob(cpd_tuning(), "CPD_WGRAD_BF16X3")) on = atoi(e);
     if (!on || c_in % 32 || c_out % 32) return false;
     *tm = wgrad_bf16_tile(c_in);
     *tn = wgrad_bf16_tile(c_out);

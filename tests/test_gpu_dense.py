@@ -137,6 +137,7 @@ def test_workgroup_kernel_matches_wave_kernel_and_oracle(oracle, hip, bm, bn, mo
     x = rng.normal(size=(b, cin, h, w)).astype(np.float32)
     wt = (rng.normal(size=(cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
     scale = rng.uniform(0.5, 1.5, cout).astype(np.float32); shift = rng.normal(size=cout).astype(np.float32)
+    monkeypatch.setenv("CPD_TUNE", "1")          # the knobs below are only read when this is set
     monkeypatch.setenv("CPD_GC_WG", "1"); monkeypatch.setenv("CPD_GC_BM", str(bm)); monkeypatch.setenv("CPD_GC_BN", str(bn))
     assert ops.gather_conv_tile(b * h * w, cin, cout, cin) == "tile_conv_kernel<%d,%d>" % (bm, bn)
     for stride in (1, 2):

@@ -118,6 +118,7 @@ def test_every_tile_shape_gives_the_same_conv(oracle, hip, ms, nt, monkeypatch):
     feat = rng.normal(size=(idx.shape[0], cin)).astype(np.float32)
     w = (rng.normal(size=(cout, 3, 3, 3, cin)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
     nbr = oracle.subm_rulebook(idx, batch, shape, [3, 3, 3])
+    monkeypatch.setenv("CPD_TUNE", "1")          # the knobs below are only read when this is set
     monkeypatch.setenv("CPD_GC_MS", str(ms)); monkeypatch.setenv("CPD_GC_NT", str(nt))
     np.testing.assert_allclose(run_conv(feat, w, nbr), oracle.sparse_conv(feat, w, None, nbr), atol=1e-4, rtol=0)
 

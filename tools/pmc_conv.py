@@ -2,6 +2,8 @@
 """Runs a few cpd_gather_conv launches of one BEV shape for rocprofv3 --pmc passes (GPU box only).
 usage: pmc_conv.py <batch> <hw> <cin> <cout> <wg 0|1> <a> <b>   (a,b = ms,nt or bm,bn)"""
 import os
+os.environ["CPD_TUNE"] = "1"      # CPD_GC_* knobs are only read with this set
+
 import sys
 
 import torch

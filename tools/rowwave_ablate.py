@@ -1,5 +1,6 @@
 """Ablation timing of rowwave_conv_bf16_kernel on a dense 128->128 3x3 layer (diagnostic libs in tools/probe)."""
 import os, sys, torch
+os.environ["CPD_TUNE"] = "1"      # CPD_GC_* knobs are only read with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CPD_GC_DENSE_ROWWAVE"] = "1"
 from cpd_amd import ops

@@ -4,6 +4,8 @@ For every (ms, nt) instantiation: average launch time (HIP events on the launch 
 algorithmic TFLOP/s. Output: one JSON line per shape."""
 import json
 import os
+os.environ["CPD_TUNE"] = "1"      # CPD_GC_* knobs are only read with this set
+
 import sys
 
 import torch
