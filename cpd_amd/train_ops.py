@@ -10,7 +10,7 @@ _ws_cache = {}
 
 def _ws(nbytes, device):
     """Grow-only scratch buffer per (device, stream) -- the kernels on one stream run in order."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, stream().value)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
