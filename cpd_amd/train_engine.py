@@ -36,13 +36,21 @@ class _Flat:
         self.bf16x3 = True      # conv arithmetic of layers with >= 32 input channels (ModelConfig.conv_math)
         self.side = None        # HIP stream for the weight gradients (independent of the input gradients of the same layer)
 
-    def on_side(self, fn, *tensors):
-        """Run fn() on the side stream, ordered after everything issued so far on the current one; `tensors` are the
-        current-stream tensors it reads (kept alive for the side stream). Without a side stream: fn() in place."""
+    def mark(self):
+        """An event at the current point of the current stream (None without a side stream)."""
         if self.side is None:
-            return fn()
+            return None
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
+        return ev
+
+    def on_side(self, fn, *tensors, after=None):
+        """Run fn() on the side stream, ordered after `after` (an event from mark(); default: everything issued so far
+        on the current stream); `tensors` are the current-stream tensors it reads (kept alive for the side stream).
+        Without a side stream: fn() in place."""
+        if self.side is None:
+            return fn()
+        ev = after if after is not None else self.mark()
         for t in tensors:
             if t is not None:
                 t.record_stream(self.side)
@@ -174,11 +182,12 @@ class _Conv:
             def wgrad_up():
                 tmp = train_ops.conv_wgrad(dz, self.c_bn, x, self.c_in, up_map, u2, n_out, bf16x3=self.store.bf16x3)
                 gw.view(self.c_in, u2, self.c_bn).copy_(tmp.permute(2, 0, 1))
-            st.on_side(wgrad_up, dz, x)
-            if not need_dx:
-                return None, dres
-            dx = ops.gather_conv(dz, self.c_bn, self.pw_adj, up_map, u2, n_out, self.c_in, None, None, add, False,
-                                 out=dx_out, dense=dense, bf16x3=self.store.bf16x3)
+            ready = st.mark()                   # dz is complete here; the input gradient is ISSUED first (it is on the
+            dx = None                           # critical path), the weight gradient after it but ordered on `ready`
+            if need_dx:
+                dx = ops.gather_conv(dz, self.c_bn, self.pw_adj, up_map, u2, n_out, self.c_in, None, None, add, False,
+                                     out=dx_out, dense=dense, bf16x3=self.store.bf16x3)
+            st.on_side(wgrad_up, dz, x, after=ready)
             return dx, dres
         if nbr is None:                                       # 1x1 conv: identity rulebook for the weight gradient
             nbr_w = torch.arange(n_out, dtype=torch.int32, device=dz.device).view(1, -1)
@@ -186,12 +195,13 @@ class _Conv:
             nbr_w = nbr
         # the weight gradient needs (x, dz), the input gradient (dz, W): independent, so they run on two streams and
         # share the chip (at one frame per GPU neither fills it)
+        ready = st.mark()
+        dx = None
+        if need_dx:
+            dx = ops.gather_conv(dz, self.c_out, self.pw_adj, nbr_adj, self.kv, n_in, self.c_in, None, None, add, False,
+                                 out=dx_out, dense=dense, bf16x3=self.store.bf16x3)
         st.on_side(lambda: train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, bf16x3=self.store.bf16x3),
-                   x, dz, nbr_w)
-        if not need_dx:
-            return None, dres
-        dx = ops.gather_conv(dz, self.c_out, self.pw_adj, nbr_adj, self.kv, n_in, self.c_in, None, None, add, False,
-                             out=dx_out, dense=dense, bf16x3=self.store.bf16x3)
+                   x, dz, nbr_w, after=ready)
         return dx, dres
 
 
