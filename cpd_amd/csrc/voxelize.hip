@@ -115,10 +115,12 @@ __global__ void __launch_bounds__(256) vox_first_kernel(int n, const int32_t *__
     if (i >= n) return;
     int32_t key = pkey[i];
     int32_t r = -1;
+    const int32_t prev = __shfl_up(key, 1);     // (all lanes of a wave reach this: the early return above is per block tail only)
     if (key >= 0) {
         uint64_t w = bitmap[key >> 6];
         r = (int32_t)(base[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1ull)));
-        atomicMin(&first[r], i);
+        // a lane whose left neighbour has the same key cannot hold the voxel's first point
+        if ((threadIdx.x & 63) == 0 || prev != key) atomicMin(&first[r], i);
     }
     prank[i] = r;
 }
@@ -238,10 +240,10 @@ __global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__rest
         cz[j] = ok ? (int32_t)f : 0;
     }
     int32_t key = -1;
-    if (ok) {
-        key = fo.frame_of(i) * cells + (cz[0] * geo.g[1] + cz[1]) * geo.g[2] + cz[2];
-        atomicOr((unsigned long long *)&bitmap[key >> 6], 1ull << (key & 63));
-    }
+    if (ok) key = fo.frame_of(i) * cells + (cz[0] * geo.g[1] + cz[1]) * geo.g[2] + cz[2];
+    // consecutive returns of a beam often share a voxel: the lane after an equal key leaves the bit to its neighbour
+    const int32_t prev = __shfl_up(key, 1);
+    if (ok && ((threadIdx.x & 63) == 0 || prev != key)) atomicOr((unsigned long long *)&bitmap[key >> 6], 1ull << (key & 63));
     pkey[i] = key;
 }
 
