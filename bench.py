@@ -5,10 +5,14 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
+  python bench.py --gpus N alone (no launcher, WORLD_SIZE unset) starts the N ranks itself.
+  Config 3 (train step, one RCCL gradient all-reduce per step):  python bench.py --mode train --gpus N
+
 A step = one pass of the whole hot path over one batch of `--frames` resident point clouds per GPU.
 Frames are sharded across ranks with NO data-path collective (forward-only inference shards by
 frame: SURVEY 8e); RCCL is used only for the timing barrier / max-over-ranks. Inputs are already in
-HBM when the timed region starts; outputs (boxes) stay on the device.
+HBM when the timed region starts; each step ends with the one D2H of its final boxes / scores /
+labels into pinned host memory (inside the timed region; --device-results leaves them in HBM).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : dominant kernel (gather_conv_kernel<ms,nt,vec>, fp32 MFMA bound) measured live with
@@ -44,13 +48,13 @@ def kernel_peak(kname):
         return PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS, "bf16 dense MFMA peak 2500 TFLOP/s / 6 partial products (split-bf16, fp32-level result)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32-input MFMA peak"
 
-POOL = 4                        # distinct synthetic frames per rank, cycled
+POOL = 8                        # distinct synthetic frames per rank (seeds rank*8 .. rank*8+7: SURVEY 8d), cycled
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: 16 infer, 1 train)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent frames in flight per GPU (worker threads, "
@@ -66,6 +70,11 @@ def parse():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE config 2 (the headline metric); train = config 3: forward + backward + "
                          "one RCCL gradient all-reduce + Adam, --frames (default 1) frames per GPU per step")
+    ap.add_argument("--device-results", action="store_true", help="leave the final boxes on the device (default: the one D2H "
+                    "of each step's boxes / scores / labels into pinned host memory is inside the timed region, SURVEY 8d)")
+    ap.add_argument("--launch-check", action="store_true", help="only launch the --gpus ranks, rendezvous, run the timing "
+                    "collectives (barrier, max over ranks) and print the n_gpus line: no GPU work (the CPU test of the N > 1 "
+                    "launcher, backend from CPD_DIST_BACKEND)")
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 16 if args.mode == "infer" else 1
@@ -223,6 +232,15 @@ def pmc_traffic(kernel):
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            names = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+        return "%s (%d hardware threads)" % (names[0], len(names)) if names else "unknown"
+    except OSError:
+        return "unknown"
+
+
 def cpu_baseline(cfg, sd, points_np):
     """The oracle's un-fused restatement of the reference graph on the host CPU, one full frame."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -238,7 +256,7 @@ def cpu_baseline(cfg, sd, points_np):
     t0 = time.perf_counter()
     ref_pipeline.forward(o, cfg, sd, [points_np])
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
             "sample": "1 full 160k-point frame through the whole path (oracle/cpd_oracle.c, OpenMP on %d threads), "
                       "%.1f s" % (cores, dt)}
 
@@ -302,9 +320,31 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
     dist_utils.shutdown()
 
 
+def launch_check(args):
+    """--launch-check: the N > 1 plumbing alone (ranks, rendezvous, barrier, max-over-ranks), any backend."""
+    rank, world, local = dist_utils.env_rank()
+    distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"))
+    dist_utils.barrier()
+    dev = "cuda" if (distributed and os.environ.get("CPD_DIST_BACKEND", "nccl") == "nccl") else "cpu"
+    slowest = dist_utils.max_over_ranks(1.0 + rank, device=dev)
+    seeds = dist_utils.frame_seeds(rank, POOL)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_arg": args.gpus, "max_over_ranks": slowest,
+                          "rank0_frame_seeds": seeds}))
+    dist_utils.shutdown()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher (N ranks of this same command under torch.distributed.run)
+        sys.exit(dist_utils.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     rank, world, local = dist_utils.env_rank()
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr)
+    if args.launch_check:
+        return launch_check(args)
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     # "nccl" is RCCL on ROCm; CPD_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests
@@ -316,7 +356,7 @@ def main():
     if args.mode == "train":
         return train_main(args, cfg, sd, dev, rank, world, distributed)
     S = max(1, args.streams)
-    engines = [CenterPointEngine(cfg, sd, device=dev) for _ in range(S)]
+    engines = [CenterPointEngine(cfg, sd, device=dev, host_results=not args.device_results) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     eng = engines[0]
     clouds_np = [waymo_cloud(sd_, n_points=args.points) for sd_ in dist_utils.frame_seeds(rank, POOL)]
@@ -370,6 +410,7 @@ def main():
         "value": world * args.steps * B / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (inputs in pinned host memory, H2D timed)" if args.host_input else ""),
+        "results": "left on the device" if args.device_results else "copied to pinned host memory inside the timed region",
         "config": {"workload": "configs[1]: Waymo-shape %d-point cloud, CPD VoxelResBackBone8x + HeightCompression + "
                                "BaseBEVBackbone + CenterHead + rotated NMS, forward-only" % args.points,
                    "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,

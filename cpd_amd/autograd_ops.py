@@ -1,0 +1,116 @@
+"""torch.autograd bridges of the C-ABI convolutions, so that the reference's own training loop -- `loss.backward()` over
+spconv.SubMConv3d / SparseConv3d modules (cpd/models/backbones_3d/spconv_backbone.py:108-136) and the BEV / head Conv2d
+stacks, driven by tools/train_utils/train_utils.py:41 -- trains through the drop-in modules.
+
+Forward is cpd_gather_conv; backward is the same three launches the hand-written train step uses
+(cpd_amd/train_engine.py::_Conv.backward):
+    d input  = cpd_gather_conv(dy, adjoint weights, adjoint rulebook)      (cpd_pack_weight_adjoint)
+    d weight = cpd_conv_wgrad(input, dy, rulebook)
+    d bias   = cpd_col_sum(dy)
+The weight enters as [kv, c_in, c_out] (a differentiable permute/reshape of the module's parameter in the reference's own
+layout), so torch maps the gradient back to the parameter layout itself. PyTorch is plumbing here: no torch arithmetic.
+"""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import ops, train_ops
+
+
+class ConvSpec:
+    """What one convolution call needs besides tensors.
+
+    mode 'same'    : SubM / stride-1 'same'-padded / 1x1 conv -- the adjoint runs on the SAME rulebook with flipped taps
+                     (nbr[t][i] = j  <=>  nbr[kv-1-t][j] = i);
+         'strided' : any other conv -- the adjoint runs on the transposed rulebook returned by `adjoint()` (built lazily,
+                     cached by the caller);
+         'up'      : ConvTranspose2d(k = s = u > 1) as one 1x1 GEMM whose u*u column groups scatter to rows `up_map`."""
+
+    __slots__ = ("nbr", "kv", "n_out", "dense", "math", "mode", "adjoint", "up_map", "up", "n_up", "packed")
+
+    def __init__(self, nbr, kv, n_out, dense=False, math="f32", mode="same", adjoint=None, up_map=None, up=1, n_up=0, packed=None):
+        self.nbr, self.kv, self.n_out, self.dense, self.math = nbr, int(kv), int(n_out), bool(dense), math
+        self.mode, self.adjoint, self.up_map, self.up, self.n_up, self.packed = mode, adjoint, up_map, int(up), int(n_up), packed
+
+
+class GatherConv(torch.autograd.Function):
+    """rows [n_in, c_in], w_kio [kv, c_in, c_out], bias [c_out] | None  ->  rows [n_out, c_out]
+    ('up': [n_up, c_out / u^2])."""
+
+    @staticmethod
+    def forward(ctx, inp, w_kio, bias, spec):
+        inp = inp.contiguous().float()
+        w = w_kio.detach().contiguous().float()
+        kv, c_in, c_out = w.shape
+        assert kv == spec.kv and inp.shape[1] == c_in
+        packed = spec.packed if spec.packed is not None else ops.pack_weight(w)
+        b = bias.detach().contiguous().float() if bias is not None else None
+        if spec.mode == "up":
+            u2 = spec.up * spec.up
+            c_bn = c_out // u2
+            out = torch.empty((spec.n_up, c_bn), dtype=torch.float32, device=inp.device)
+            ops.gather_conv(inp, c_in, packed, None, 1, spec.n_out, c_out, None, b.repeat(u2) if b is not None else None,
+                            out=out, out_row_map=spec.up_map, out_col_group=c_bn, dense=spec.dense, math=spec.math)
+        else:
+            out = ops.gather_conv(inp, c_in, packed, spec.nbr, kv, spec.n_out, c_out, None, b, dense=spec.dense, math=spec.math)
+        ctx.save_for_backward(inp, w)
+        ctx.spec = spec
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        inp, w = ctx.saved_tensors
+        spec = ctx.spec
+        kv, c_in, c_out = w.shape
+        dy = dy.contiguous().float()
+        n_in = inp.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = None
+        split = spec.math != "f32"
+        if need_b:
+            db = train_ops.col_sum(dy)
+        if spec.mode == "up":
+            u2 = spec.up * spec.up
+            c_bn = c_out // u2
+            if need_x:      # 4-tap gather over the scatter map, weights [tap, co, ci]
+                pw_adj = ops.pack_weight(w.view(c_in, u2, c_bn).permute(1, 2, 0).contiguous())
+                dx = ops.gather_conv(dy, c_bn, pw_adj, spec.up_map, u2, spec.n_out, c_in, dense=spec.dense, math=spec.math)
+            if need_w:      # dW[tap][co][ci] = sum_pix dy[map[tap][pix]][co] * x[pix][ci]: the roles of input and dy swap
+                tmp = train_ops.conv_wgrad(dy, c_bn, inp, c_in, spec.up_map, u2, spec.n_out, bf16x3=split)
+                dw = tmp.permute(2, 0, 1).reshape(1, c_in, c_out).contiguous()
+            return dx, dw, db, None
+        if need_x:
+            pw_adj = train_ops.pack_weight_adjoint(w, flip_taps=(spec.mode == "same"))
+            nbr_adj = spec.nbr if spec.mode == "same" else spec.adjoint()
+            dx = ops.gather_conv(dy, c_out, pw_adj, nbr_adj, kv, n_in, c_in, dense=spec.dense, math=spec.math)
+        if need_w:
+            nbr_w = spec.nbr
+            if nbr_w is None:                                    # 1x1: identity rulebook
+                nbr_w = torch.arange(spec.n_out, dtype=torch.int32, device=dy.device).view(1, -1)
+            dw = train_ops.conv_wgrad(inp, c_in, dy, c_out, nbr_w, kv, spec.n_out, bf16x3=split)
+        return dx, dw, db, None
+
+
+class Densify(torch.autograd.Function):
+    """SparseConvTensor.dense(): features [n, c] -> (B, C, D, H, W) (cpd_densify_nchw); backward gathers the rows back."""
+
+    @staticmethod
+    def forward(ctx, feats, indices, batch, shape_zyx):
+        ctx.save_for_backward(indices)
+        ctx.meta = (int(batch), [int(s) for s in shape_zyx], feats.shape[1])
+        out = ops.densify_nchw(feats.contiguous().float(), indices.contiguous(), batch, shape_zyx)
+        d, h, w = ctx.meta[1]
+        return out.view(batch, feats.shape[1], d, h, w)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        i = idx.long()
+        return g[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous(), None, None, None
+
+
+def gather_conv(inp, w_kio, bias, spec):
+    """Differentiable when any of (inp, w_kio, bias) requires grad and grad mode is on; otherwise the plain launch."""
+    return GatherConv.apply(inp, w_kio, bias, spec)

@@ -34,6 +34,12 @@ def assign_targets(gt_boxes, feature_map_size, point_cloud_range, voxel_size, nu
     H, W = int(feature_map_size[0]), int(feature_map_size[1])
     dev = gt_boxes.device
     K = num_max_objs
+    # the reference first keeps this head's boxes (class >= 1: padding rows are 'bg', center_head.py:180-196), THEN walks the
+    # first NUM_MAX_OBJS of that filtered list (l.113): compact the kept rows to the front, stably, before truncating
+    if M > 0:
+        drop = (gt_boxes[..., 7] < 1).to(torch.int8)
+        order = torch.sort(drop, dim=1, stable=True)[1]
+        gt_boxes = torch.gather(gt_boxes, 1, order.unsqueeze(-1).expand(-1, -1, gt_boxes.shape[2]))
     g = gt_boxes[:, :K].float()
     Mk = g.shape[1]
     x, y, z = g[..., 0], g[..., 1], g[..., 2]

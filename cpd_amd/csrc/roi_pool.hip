@@ -38,7 +38,10 @@ struct IndexLookup {
     const uint64_t *bitmap;
     const uint32_t *base;
     const int32_t *perm;
-    __device__ __forceinline__ int32_t operator()(long long key) const { return site_lookup(bitmap, base, perm, key); }
+    const int32_t *flags;     // the index's own record of its order: flags[0] != 0 -> row id = perm[rank], else row id = rank
+    __device__ __forceinline__ int32_t operator()(long long key) const {
+        return site_lookup(bitmap, base, flags[0] ? perm : nullptr, key);
+    }
 };
 
 struct QueryParams {
@@ -467,10 +470,12 @@ extern "C" int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, i
     if (m == 0) return CPD_OK;
     const int32_t shape[3] = {r1, r2, r3};
     // canonical site lists (cpd_conv_outset / cpd_index_emit) have rank == row; lists in arbitrary order
-    // (cpd_index_build) go through the permutation stored in the index
+    // (cpd_index_build) go through the permutation stored in the index. Which one this index is, is read from the
+    // index itself on the device (flags[0], as rulebook_kernel does); `use_perm` is kept in the signature but ignored.
+    (void)use_perm;
     IndexView v = index_carve(const_cast<void *>(index), batch, shape, n_sites);
     QueryParams p{m, r1, r2, r3, nsample, radius * radius, z_range, y_range, x_range, new_xyz, xyz, new_coords, idx};
-    voxel_query_kernel<IndexLookup><<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, use_perm ? v.perm : nullptr});
+    voxel_query_kernel<IndexLookup><<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags});
     return cpd_check_launch();
 }
 

@@ -13,6 +13,29 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, script, argv, env=None):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start N ranks of the same command, one per
+    GPU, under torch.distributed.run on this node -- the role of tools/dist_train.sh:3 (`torch.distributed.launch
+    --nproc_per_node=N`) and tools/train.py:63-65 (`init_dist_pytorch`) in the reference. Rendezvous on 127.0.0.1 (the
+    container hostname may not resolve). Returns the launcher's exit code."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=e)
+
+
 def init(backend="nccl", device=None):
     rank, world, _ = env_rank()
     if world == 1 and not os.environ.get("CPD_FORCE_DIST"):     # CPD_FORCE_DIST=1: exercise the collectives with one rank

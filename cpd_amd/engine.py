@@ -183,9 +183,13 @@ class CenterPointEngine:
     BEV_BN_EPS = 1e-3      # base_bev_backbone.py:38
     HEAD_BN_EPS = 1e-5     # nn.BatchNorm2d default, center_head.py:24,78
 
-    def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
+    def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], device="cuda", host_results=False):
         self.cfg = cfg
         self.device = torch.device(device)
+        # host_results: the final boxes / scores / labels are returned as HOST tensors -- one asynchronous D2H of the padded
+        # result block into pinned memory whose completion is the step's only stream synchronisation
+        self.host_results = bool(host_results)
+        self._pinned = {}
         self.sd = state_dict
         self.voxelizer = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features,
                                        cfg.max_points_per_voxel, cfg.max_voxels, device=self.device)
@@ -400,7 +404,17 @@ class CenterPointEngine:
         assert cfg.max_obj_per_sample <= cfg.nms_pre_maxsize
         keep, num_keep = ops.nms_batch(boxes, counts, cfg.nms_thresh)
         ob, os_, ol, on = ops.select_boxes(boxes, scores, labels, keep, num_keep, cfg.nms_post_maxsize, label_offset=1)
-        ns = on.tolist()                      # the one host read-back of the stage
+        if self.host_results:
+            pin = self._pinned.get(batch)
+            if pin is None:
+                pin = self._pinned[batch] = tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in (ob, os_, ol, on))
+            for dst, src in zip(pin, (ob, os_, ol, on)):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.current_stream().synchronize()      # results are on the host
+            ob, os_, ol = (t.clone() for t in pin[:3])    # the pinned block is reused by the next step
+            ns = pin[3].tolist()
+        else:
+            ns = on.tolist()                      # the one host read-back of the stage
         return [{"pred_boxes": ob[b, :ns[b]], "pred_scores": os_[b, :ns[b]], "pred_labels": ol[b, :ns[b]]}
                 for b in range(batch)]
 

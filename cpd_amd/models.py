@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import iou3d_nms_utils, ops
+from . import autograd_ops, iou3d_nms_utils, ops, train_ops
 from . import spconv as _spconv_pkg
 from .spconv import pytorch as spconv
 
@@ -221,8 +221,18 @@ class Conv2d(nn.Conv2d):
         if getattr(self, "_pk_ver", None) != ver:
             self._pk = ops.pack_weight(self.weight.detach().permute(2, 3, 1, 0).reshape(k * k, c, self.out_channels).contiguous())
             self._pk_ver = ver
-        out = ops.gather_conv(_rows(x.float()), c, self._pk, nbr, k * k, b * ho * wo, self.out_channels, None,
-                              self.bias.detach() if self.bias is not None else None, dense=True)
+
+        def adjoint():          # transposed pixel table of a strided / unpadded conv (input gradient)
+            tkey = key + ("t",)
+            if tkey not in Conv2d._tables:
+                Conv2d._tables[tkey] = train_ops.rulebook_conv2d_transpose(b, h, w, k, k, s, p, x.device)
+            return Conv2d._tables[tkey]
+
+        same = s == 1 and 2 * p == k - 1
+        spec = autograd_ops.ConvSpec(nbr, k * k, b * ho * wo, dense=True, math=getattr(self, "conv_math", "f32"),
+                                     mode="same" if same else "strided", adjoint=adjoint, packed=self._pk)
+        w_kio = self.weight.permute(2, 3, 1, 0).reshape(k * k, c, self.out_channels)
+        out = autograd_ops.gather_conv(_rows(x.float()), w_kio, self.bias, spec)
         return _nchw(out, b, ho, wo)
 
 
@@ -239,9 +249,11 @@ class ConvTranspose2d(nn.ConvTranspose2d):
             self._pk = ops.pack_weight(self.weight.detach().permute(0, 2, 3, 1).reshape(1, c, u * u * self.out_channels).contiguous())
             self._pk_ver = ver
         H, W = h * u, w * u
-        out = torch.empty((b * H * W, self.out_channels), dtype=torch.float32, device=x.device)
+        w_kio = self.weight.permute(0, 2, 3, 1).reshape(1, c, u * u * self.out_channels)
+        math = getattr(self, "conv_math", "f32")
         if u == 1:
-            ops.gather_conv(_rows(x.float()), c, self._pk, None, 1, b * h * w, self.out_channels, out=out, dense=True)
+            spec = autograd_ops.ConvSpec(None, 1, b * h * w, dense=True, math=math, mode="same", packed=self._pk)
+            out = autograd_ops.gather_conv(_rows(x.float()), w_kio, self.bias, spec)
         else:
             key = (b, h, w, u, x.device)
             if key not in ConvTranspose2d._maps:
@@ -250,8 +262,9 @@ class ConvTranspose2d(nn.ConvTranspose2d):
                 xx = torch.arange(w, device=x.device).view(1, 1, -1)
                 maps = [((bi * H + u * yy + a) * W + u * xx + bb).reshape(-1) for a in range(u) for bb in range(u)]
                 ConvTranspose2d._maps[key] = torch.stack(maps).to(torch.int32).contiguous()
-            ops.gather_conv(_rows(x.float()), c, self._pk, None, 1, b * h * w, u * u * self.out_channels, out=out,
-                            out_row_map=ConvTranspose2d._maps[key], out_col_group=self.out_channels, dense=True)
+            spec = autograd_ops.ConvSpec(None, 1, b * h * w, dense=True, math=math, mode="up", up_map=ConvTranspose2d._maps[key],
+                                         up=u, n_up=b * H * W, packed=self._pk)
+            out = autograd_ops.gather_conv(_rows(x.float()), w_kio, self.bias, spec)
         return _nchw(out, b, H, W)
 
 
@@ -385,9 +398,8 @@ class CenterHead(nn.Module):
         return ret
 
     def get_loss(self):
-        """center_head.py:225-250. The value is exact; gradients of the module API are not tracked through
-        the C-ABI convs -- the train step with hand-written backward is cpd_amd.train_engine
-        (CenterPoint.to_trainer())."""
+        """center_head.py:225-250 (differentiable: the head maps carry autograd history through the C-ABI convs; the fused,
+        graph-free train step with hand-written backward is cpd_amd.train_engine, CenterPoint.to_trainer())."""
         from . import center_loss
         pds, td = self.forward_ret_dict["pred_dicts"], self.forward_ret_dict["target_dicts"]
         lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
@@ -500,8 +512,13 @@ class CenterPoint(nn.Module):
         self.module_list = [self.vfe, self.backbone_3d, self.map_to_bev_module, self.backbone_2d, self.dense_head]
 
     def forward(self, batch_dict):
+        """centerpoint.py:9-22: training returns ({'loss': loss}, tb_dict, disp_dict) -- `loss.backward()` then reaches every
+        parameter through the differentiable C-ABI convs (cpd_amd/autograd_ops.py); eval returns (pred_dicts, recall_dicts)."""
         for m in self.module_list:
             batch_dict = m(batch_dict)
+        if self.training:
+            loss_rpn, tb_dict = self.dense_head.get_loss()
+            return {"loss": loss_rpn}, dict(loss_rpn=loss_rpn.item(), **tb_dict), {}
         return batch_dict["final_box_dicts"], {}
 
     def to_engine_config(self):

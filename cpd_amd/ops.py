@@ -200,10 +200,20 @@ def pack_weight(w_kio, out=None):
     return packed
 
 
+CONV_MATH = {"f32": 0, "bf16x3": 2, "f16x2": 4}     # CPD_GC_BF16X3 / CPD_GC_F16X2 of include/cpd_hip.h
+
+
+def _gc_flags(dense, bf16x3, math):
+    if math is not None:
+        return (1 if dense else 0) | CONV_MATH[math]
+    return (1 if dense else 0) | (2 if bf16x3 else 0)
+
+
 def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=None, residual=None, relu=False,
-                out=None, out_row_map=None, out_col_group=0, dense=False, bf16x3=False):
+                out=None, out_row_map=None, out_col_group=0, dense=False, bf16x3=False, math=None):
     """out[j,:c_out] = act((sum_t in[nbr[t][j]] . W[t]) * scale + shift + residual[j]).
-    `inp` / `out` / `residual` are 2-D row tensors whose row stride may exceed the channel count."""
+    `inp` / `out` / `residual` are 2-D row tensors whose row stride may exceed the channel count.
+    `math`: "f32" | "bf16x3" | "f16x2" (overrides the older `bf16x3` switch)."""
     _need_cuda(inp, "inp")
     assert inp.dim() == 2 and inp.stride(1) == 1
     if out is None:
@@ -213,7 +223,7 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     if residual is not None:
         assert residual.dim() == 2 and residual.stride(1) == 1
         res_ld = residual.stride(0)
-    flags = (1 if dense else 0) | (2 if bf16x3 else 0)
+    flags = _gc_flags(dense, bf16x3, math)
     image = getattr(nbr, "image", None)             # 3x3 / stride 1 / pad 1 pixel table: the rulebook-free window kernel
     if image is not None and out_row_map is None and kv == 9 and n_out == image[0] * image[1] * image[2] and inp.shape[0] == n_out:
         rc = lib().cpd_conv3x3_rows(
@@ -227,7 +237,7 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
         ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w),
         ptr(nbr), ptr(getattr(nbr, "tapmask", None)), kv, n_out, c_out, ptr(scale), ptr(shift),
         ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
-        ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), (1 if dense else 0) | (2 if bf16x3 else 0),
+        ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), flags,
         stream()),
         "cpd_gather_conv")
     return out
@@ -365,14 +375,15 @@ def boxes_iou_bev_cpu(a, b):
     return out
 
 
-def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None):
+def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None):
     """Name of the kernel instantiation gather_conv will run for this problem (`nbr`: the table it would be given)."""
     image = getattr(nbr, "image", None)
+    flags = _gc_flags(dense, bf16x3, math)
     if image is not None and n_out == image[0] * image[1] * image[2] and in_ld % 4 == 0 and lib().cpd_conv3x3_rows_supported(
-            image[0], image[1], image[2], int(c_in), int(c_out), (1 if dense else 0) | (2 if bf16x3 else 0)):
+            image[0], image[1], image[2], int(c_in), int(c_out), flags):
         return "window_conv_bf16_kernel<%d>" % (16 if c_out <= 16 else (128 if c_out % 128 == 0 else 64))
     wg, a, b, vec = (ctypes.c_int(0) for _ in range(4))
-    check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), (1 if dense else 0) | (2 if bf16x3 else 0),
+    check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), flags,
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
           "cpd_gather_conv_tile")
     if wg.value == 3:

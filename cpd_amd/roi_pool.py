@@ -38,7 +38,8 @@ def generate_voxel2pinds(indices, batch_size, spatial_shape):
 def voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices=None, index=None):
     """VoxelQuery.forward: (idx [M, nsample] i32 with empty balls zeroed, empty_ball_mask [M] bool).
     new_coords [M,4] = (b,z,y,x). Pass `point_indices` (dense volume) like the reference, or `index`
-    (an ops.SiteIndex of the sparse tensor; `index.canonical` tells whether rank == row)."""
+    (an ops.SiteIndex of the sparse tensor; whether its ranks are row ids or go through its permutation is recorded in the
+    index buffer itself and read on the device)."""
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and new_coords.is_contiguous()
     m = new_coords.shape[0]
     idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
@@ -46,7 +47,7 @@ def voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indi
     if index is not None:
         z, y, x = index.shape
         check(lib().cpd_voxel_query_index(m, index.batch, z, y, x, int(nsample), float(radius), zr, yr, xr, ptr(new_xyz), ptr(xyz),
-                                          ptr(new_coords), ptr(index.buf), 0 if getattr(index, "canonical", True) else 1,
+                                          ptr(new_coords), ptr(index.buf), 0,
                                           xyz.shape[0], ptr(idx), stream()), "cpd_voxel_query_index")
     else:
         assert point_indices.is_contiguous() and point_indices.dtype == torch.int32
@@ -137,7 +138,7 @@ class NeighborVoxelSAModuleMSG(nn.Module):
                 z, y, x = index.shape
                 check(lib().cpd_voxel_query_index(m, index.batch, z, y, x, self.nsamples[k], float(self.radii[k]), zr, yr, xr,
                                                   ptr(new_xyz), ptr(xyz), ptr(new_coords), ptr(index.buf),
-                                                  0 if getattr(index, "canonical", True) else 1, n, ptr(idx), stream()),
+                                                  0, n, ptr(idx), stream()),
                       "cpd_voxel_query_index")
             else:
                 b, z, y, x = voxel2point_indices.shape
@@ -202,7 +203,7 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize
     rotated NMS -> first NMS_POST_MAXSIZE. All samples go through ONE batched mask / scan / select launch set
     (cpd_nms_batch, cpd_select_boxes); nothing is read back. Returns (rois [B, post, 7+C], roi_scores [B, post],
     roi_labels [B, post] i64 = argmax class + 1); slots past a sample's kept count are zero like the reference's
-    new_zeros buffers."""
+    new_zeros buffers (their label is 1: the reference's `roi_labels + 1` applies to every slot)."""
     b, n, cdim = batch_box_preds.shape
     scores, labels = torch.max(batch_cls_preds, dim=-1)                       # l.94
     k = min(int(nms_pre_maxsize), n)
@@ -216,7 +217,8 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize
     valid = torch.arange(int(nms_post_maxsize), device=boxes.device)[None, :] < kept[:, None]
     rois7 = rois7 * valid[..., None]
     roi_scores = roi_scores * valid
-    roi_labels = roi_labels * valid                                            # the reference adds 1 to every slot (l.111)
+    # the reference adds 1 to EVERY slot of its zero-initialised buffer (roi_head_template.py:111): padded slots carry label 1
+    roi_labels = torch.where(valid, roi_labels, torch.ones_like(roi_labels))
     if cdim > 7:
         raise NotImplementedError("7+C box codes (velocity ...) are not used by the CPD configs")
     return rois7, roi_scores, roi_labels, kept

@@ -1,11 +1,13 @@
-"""SubMConv3d / SparseConv3d on cpd_gather_conv (forward). Weight layout is spconv-2.x
-(Cout, kD, kH, kW, Cin), so reference checkpoints load (detector3d_template.py:388-419)."""
+"""SubMConv3d / SparseConv3d on cpd_gather_conv, differentiable (cpd_amd/autograd_ops.py: the input gradient is the same
+kernel on the adjoint weights / rulebook, the weight gradient cpd_conv_wgrad), so the reference's `loss.backward()` loop
+(tools/train_utils/train_utils.py:41) trains through these modules. Weight layout is spconv-2.x (Cout, kD, kH, kW, Cin), so
+reference checkpoints load (detector3d_template.py:388-419)."""
 import math
 
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import autograd_ops, ops, train_ops
 from .core import SparseConvTensor
 from .modules import SparseModule
 
@@ -30,6 +32,7 @@ class SparseConvolution(SparseModule):
         self.reset_parameters()
         self._packed = None
         self._packed_version = None
+        self.conv_math = kwargs.get("conv_math", "f32")     # "f32" | "bf16x3" | "f16x2" (ops.CONV_MATH), layers with c_in % 32 == 0
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -72,8 +75,17 @@ class SparseConvolution(SparseModule):
                 if self.indice_key is not None:
                     x.indice_dict[self.indice_key] = cached
         nbr, out_indices = cached["nbr"], cached["out_indices"]
-        out_feats = ops.gather_conv(feats, self.in_channels, self._packed_weight(), nbr, kv, out_indices.shape[0],
-                                    self.out_channels, None, self.bias.detach() if self.bias is not None else None)
+
+        def adjoint():          # transposed rulebook of a regular conv (input gradient), built on first use, cached with the pairs
+            if "nbr_t" not in cached:
+                cached["nbr_t"] = train_ops.rulebook_conv_transpose(x.indices.contiguous(), x.batch_size, x.spatial_shape,
+                                                                    self.kernel_size, self.stride, self.padding, cached["out_index"])
+            return cached["nbr_t"]
+
+        spec = autograd_ops.ConvSpec(nbr, kv, out_indices.shape[0], dense=False, math=self.conv_math,
+                                     mode="same" if self.subm else "strided", adjoint=adjoint, packed=self._packed_weight())
+        w_kio = self.weight.reshape(self.out_channels, kv, self.in_channels).permute(1, 2, 0)
+        out_feats = autograd_ops.gather_conv(feats, w_kio, self.bias, spec)
         out = SparseConvTensor(out_feats, out_indices, cached["out_shape"], x.batch_size, x.grid, x.benchmark)
         out.indice_dict = x.indice_dict
         out._site_index = cached["out_index"]

@@ -39,10 +39,8 @@ class SparseConvTensor:
 
     def dense(self, channels_first=True):
         """(B, C, D, H, W) like spconv; height_compression.py:136-138 then views it (B, C*D, H, W)."""
-        out = ops.densify_nchw(self.features.contiguous(), self.indices.contiguous(), self.batch_size, self.spatial_shape)
-        c = self.features.shape[1]
-        d, h, w = self.spatial_shape
-        out = out.view(self.batch_size, c, d, h, w)
+        from ... import autograd_ops
+        out = autograd_ops.Densify.apply(self.features, self.indices, self.batch_size, self.spatial_shape)
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 
     def find_indice_pair(self, key):

@@ -34,6 +34,7 @@ class _Flat:
         self.slots = {}
         self.flat = self.grad = self.m = self.v = None
         self.bf16x3 = True      # conv arithmetic of layers with >= 32 input channels (ModelConfig.conv_math)
+        self.update_stats = True    # whether the current forward updates the BatchNorm running statistics
         self.side = None        # HIP stream for the weight gradients (independent of the input gradients of the same layer)
 
     def mark(self):
@@ -139,8 +140,10 @@ class _Conv:
             self.pw_adj = train_ops.pack_weight_adjoint(w, flip_taps=(self.mode == "same"), out=getattr(self, "pw_adj", None))
 
     # ---------------------------------------------------------------- forward
-    def forward(self, x, nbr, n_out, residual=None, dense=False, out=None, up_map=None, n_up=None, update_stats=True):
+    def forward(self, x, nbr, n_out, residual=None, dense=False, out=None, up_map=None, n_up=None, update_stats=None):
         st = self.store
+        if update_stats is None:                              # the trainer's per-forward switch (CenterPointTrainer.forward)
+            update_stats = st.update_stats
         bias = st.p(self.bn_) if self.bn_ else None
         if not self.has_bn:                                   # final head convs: conv + bias only
             y = ops.gather_conv(x, self.c_in, self.pw, nbr, self.kv, n_out, self.c_out, None, bias, None, self.relu,
@@ -393,8 +396,10 @@ class CenterPointTrainer:
         return dy
 
     def forward(self, points_list, update_stats=True):
-        """Training-mode forward; returns head rows [B*H*W, head_ld] and keeps the tape."""
+        """Training-mode forward; returns head rows [B*H*W, head_ld] and keeps the tape. update_stats=False (gradient
+        checks, evaluation passes on batch statistics) leaves every BatchNorm's running_mean / running_var untouched."""
         cfg, S = self.cfg, self.sparse
+        self.store.update_stats = bool(update_stats)
         batch = len(points_list)
         feats, coords = self._voxelize(points_list)
         shape = cfg.sparse_shape

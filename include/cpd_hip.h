@@ -362,8 +362,9 @@ int cpd_voxel_query(int m, int r1, int r2, int r3, int nsample, float radius, in
                     int x_range, const float *new_xyz, const float *xyz, const int32_t *new_coords,
                     const int32_t *point_indices, int32_t *idx, cpd_stream_t stream);
 /* Same query through a site index (cpd_index_build / cpd_conv_outset) of the sparse tensor instead
- * of the dense volume. use_perm: 1 for indices built by cpd_index_build over an arbitrary-order
- * site list of n_sites rows, 0 for canonical lists. */
+ * of the dense volume. Whether the index's ranks are row ids (canonical lists of cpd_conv_outset)
+ * or go through its rank -> row permutation (cpd_index_build over any row order) is recorded in
+ * the index and read on the device; `use_perm` is ignored (kept for ABI stability). */
 int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, int nsample, float radius,
                           int z_range, int y_range, int x_range, const float *new_xyz, const float *xyz,
                           const int32_t *new_coords, const void *index, int use_perm, int n_sites,

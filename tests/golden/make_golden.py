@@ -154,10 +154,93 @@ def borderline_free(iou, thr, margin=2e-4):
     return not np.any(np.abs(iou - thr) < margin)
 
 
+def nms_large(m):
+    """NMS_PRE_MAXSIZE-sized set (4096 boxes, 64 mask words per row: the multi-block scan of the device kernel) through the
+    reference's class_agnostic_nms. Own RNG: adding this section moves no other fixture."""
+    rng = np.random.default_rng(4096)
+    lib = m["lib"]
+    n, thr, span = 4096, 0.7, 96.0
+    for attempt in range(400):
+        bx = rand_boxes(rng, n, span=span)
+        k = n // 10
+        bx[n - k:] = bx[:k]
+        bx[n - k:, :2] += rng.normal(0, 0.25, (k, 2)).astype(np.float32)
+        bx[n - k:, 6] += rng.normal(0, 0.05, k).astype(np.float32)
+        sc = rng.permutation(n).astype(np.float32) / n + 0.001
+        order = np.argsort(-sc, kind="stable")
+        iou = ref_iou_bev(lib, bx[order], bx[order])
+        if borderline_free(iou[np.triu_indices(n, 1)], thr):
+            break
+    else:
+        raise RuntimeError("no borderline-free 4096-box set")
+    cfgn = AttrDict(NMS_TYPE="nms_gpu", NMS_THRESH=thr, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=4096)
+    sel, sel_sc = m["model_nms_utils"].class_agnostic_nms(
+        box_scores=torch.from_numpy(sc), box_preds=torch.from_numpy(bx), nms_config=cfgn, score_thresh=None)
+    np.savez_compressed(os.path.join(HERE, "nms_n4096.npz"), boxes=bx, scores=sc, thr=np.float32(thr), selected=sel.numpy(),
+                        selected_scores=sel_sc.numpy())
+    print("nms_n4096: %d boxes -> %d kept (attempt %d)" % (n, sel.shape[0], attempt))
+
+
+def _randomize_bn(mods, gen):
+    with torch.no_grad():
+        for mod in mods:
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.3)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) + 0.5)
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=gen) + 0.5)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.2)
+
+
+def wide_dense(m):
+    """BaseBEVBackbone / shared conv + SeparateHead at channel widths that are multiples of 32 / 64, so that the split-operand
+    workgroup and window kernels (the ones the benchmark runs) can execute these reference goldens; the `bev_backbone` /
+    `center_head` fixtures above have 16-channel layers those kernels do not take. Own generator: moves no other fixture."""
+    gen = torch.Generator().manual_seed(6464)
+    cfg = AttrDict(LAYER_NUMS=[1, 1], LAYER_STRIDES=[1, 2], NUM_FILTERS=[64, 128],
+                   UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[64, 64])
+    torch.manual_seed(6464)
+    net = m["bev"].BaseBEVBackbone(cfg, num_frames=1, input_channels=64)
+    _randomize_bn(net.modules(), gen)
+    net.eval()
+    x = torch.randn(2, 64, 24, 20, generator=gen)
+    with torch.no_grad():
+        y = net({"spatial_features": x})["st_features_2d"]
+    d = {"bev_in": x.numpy(), "bev_out": y.numpy(), "layer_nums": np.asarray(cfg.LAYER_NUMS)}
+    for k, v in net.state_dict().items():
+        d["sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "bev_backbone_wide.npz"), **d)
+
+    head_dict = {"center": dict(out_channels=2, num_conv=2), "center_z": dict(out_channels=1, num_conv=2),
+                 "dim": dict(out_channels=3, num_conv=2), "rot": dict(out_channels=2, num_conv=2),
+                 "hm": dict(out_channels=3, num_conv=2)}
+    sep = m["center_head"].SeparateHead(input_channels=64, sep_head_dict=head_dict, init_bias=-2.19, use_bias=True)
+    shared = torch.nn.Sequential(torch.nn.Conv2d(128, 64, 3, stride=1, padding=1, bias=True),
+                                 torch.nn.BatchNorm2d(64), torch.nn.ReLU())   # center_head.py:73-80
+    _randomize_bn(list(sep.modules()) + list(shared.modules()), gen)
+    sep.eval(); shared.eval()
+    xh = torch.randn(2, 128, 20, 24, generator=gen)
+    with torch.no_grad():
+        mid = shared(xh)
+        heads = sep(mid)
+    d = {"head_in": xh.numpy(), "shared_out": mid.numpy()}
+    for k, v in heads.items():
+        d["out." + k] = v.numpy()
+    for k, v in shared.state_dict().items():
+        d["shared." + k] = v.numpy()
+    for k, v in sep.state_dict().items():
+        d["sep." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "center_head_wide.npz"), **d)
+    print("wide_dense: bev out %s, head maps %s" % (tuple(y.shape), {k: tuple(v.shape) for k, v in heads.items()}))
+
+
 def main():
     torch.manual_seed(0)
     rng = np.random.default_rng(20240928)
     m = setup_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "nms_large":      # only this (independent) section
+        return nms_large(m)
+    if len(sys.argv) > 1 and sys.argv[1] == "wide_dense":
+        return wide_dense(m)
     lib = m["lib"]
     out = {}
 
@@ -588,6 +671,8 @@ def main():
     print("anchor_head_single: mask keeps %d of %d locations, %d boxes/sample" % (int(mask.sum()), mask.numel(), outd["batch_box_preds"].shape[1]))
     print("anchor_head: %d anchors, %d positives, %d ignored" % (n_anc, int((tgt["box_cls_labels"] > 0).sum()),
                                                                   int((tgt["box_cls_labels"] < 0).sum())))
+    nms_large(m)
+    wide_dense(m)
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -47,3 +47,20 @@ def test_center_head_loss_rows_equal_nchw_form(golden):
     np.testing.assert_allclose(loss.item(), want.item(), rtol=1e-6)
     loss.backward()
     assert rows.grad[:, 11:].abs().max() == 0 and rows.grad[:, :11].abs().sum() > 0
+
+
+def test_assign_targets_filters_before_truncating(golden):
+    """center_head.py:180-196 keeps a head's boxes first and l.113 then walks the first NUM_MAX_OBJS of THAT list: with
+    padding rows interleaved and more boxes than slots, the result is that of the compacted list."""
+    g = golden("center_loss")
+    real = torch.from_numpy(g["gt_boxes"])[:12]
+    assert (real[:, 7] >= 1).all()
+    mixed = torch.zeros((24, 8))
+    mixed[1::2] = real                                       # padding row, box, padding row, box, ...
+    args = ((188, 188), [-75.2, -75.2, -2, 75.2, 75.2, 4], [0.1, 0.1, 0.15], 3)
+    kw = dict(feature_map_stride=8, num_max_objs=10, gaussian_overlap=0.1, min_radius=2)
+    got = cl.assign_targets(mixed[None], *args, **kw)
+    want = cl.assign_targets(real[None], *args, **kw)       # already compact: its first 10 boxes
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert int(got[3].sum()) == 10

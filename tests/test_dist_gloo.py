@@ -46,3 +46,27 @@ def test_two_rank_frame_sharding_and_timing():
     assert set(s0).isdisjoint(s1) and len(s0) == len(s1) == 4      # disjoint frame shards
     assert m0 == m1 == 2.0                                          # max over ranks
     assert abs(t0 - 10.0) < 1e-9 and t0 == t1                       # 2 ranks * 10 units / 2.0 s
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (the flag used to be
+    parsed and ignored). --launch-check runs the launcher, the rendezvous and the timing collectives only (gloo here,
+    RCCL on the GPUs), so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CPD_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                     # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["gpus_arg"] == 2 and rec["max_over_ranks"] == 2.0
+    # and under an external launcher (the driver's way) the same command does not spawn again
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--launch-check"], env=env2,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1

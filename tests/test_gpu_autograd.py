@@ -1,0 +1,188 @@
+"""B2 training side: `loss.backward()` through the drop-in modules (cpd_amd.spconv SubMConv3d / SparseConv3d, cpd_amd.models
+Conv2d / ConvTranspose2d, SparseConvTensor.dense()) -- the way the reference trains (spconv_backbone.py:108-136 modules under
+tools/train_utils/train_utils.py:41). Per operator against a torch-CPU float64 autograd restatement (sparse convs in their
+defining gather-matmul form over the module's own rulebook, dense ones through F.conv2d / F.conv_transpose2d), and for the
+whole CenterPoint graph against the hand-written train step (CenterPointTrainer), whose gradients tests/test_gpu_train.py
+pins on the float64 reference graph."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cpd_amd.engine import ModelConfig, init_state_dict
+from cpd_amd.synthetic import waymo_cloud
+
+import ref_train_torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, want):
+    want = want.double().cpu()
+    return float((got.double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def _sparse_scene(seed, n=5000, shape=(21, 96, 88), batch=2, c=16):
+    rng = np.random.default_rng(seed)
+    zyx = rng.integers([0, 0, 0], shape, size=(n, 3))
+    b = rng.integers(0, batch, size=(n, 1))
+    idx = np.unique(np.concatenate([b, zyx], 1), axis=0).astype(np.int32)
+    rng.shuffle(idx)                                            # arbitrary row order, like voxelizer output
+    feats = rng.normal(size=(idx.shape[0], c)).astype(np.float32)
+    return torch.from_numpy(feats).cuda(), torch.from_numpy(idx).cuda(), list(shape), batch
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,stride,pad,bias", [
+    ("subm", 16, 32, 3, 1, 1, True), ("subm", 32, 32, 3, 1, 1, False), ("subm", 5, 16, 3, 1, 1, False),
+    ("spconv", 16, 32, 3, 2, 1, False), ("spconv", 32, 64, 3, 2, (0, 1, 1), True), ("spconv", 64, 64, (3, 1, 1), (2, 1, 1), 0, False)])
+def test_sparse_conv_gradients(hip, kind, cin, cout, k, stride, pad, bias):
+    from cpd_amd.spconv import pytorch as spconv
+    torch.manual_seed(cin * 7 + cout)
+    feats, idx, shape, batch = _sparse_scene(cin + cout, c=cin)
+    cls = spconv.SubMConv3d if kind == "subm" else spconv.SparseConv3d
+    conv = cls(cin, cout, k, stride=stride, padding=pad, bias=bias, indice_key="k").cuda()
+    x = feats.clone().requires_grad_(True)
+    st = spconv.SparseConvTensor(x, idx, shape, batch)
+    out = conv(st)
+    g = torch.randn_like(out.features)
+    (out.features * g).sum().backward()
+    # float64 restatement over the module's own rulebook (itself bit-exact vs the oracle: tests/test_gpu_sparse.py)
+    nbr = st.indice_dict["k"]["nbr"].cpu().numpy()
+    x64 = feats.double().cpu().requires_grad_(True)
+    w64 = conv.weight.detach().double().cpu().requires_grad_(True)
+    b64 = conv.bias.detach().double().cpu().requires_grad_(True) if bias else None
+    ref = ref_train_torch._gconv(x64, w64, nbr, b64)
+    assert rel_err(out.features.detach(), ref.detach()) <= 1e-5
+    (ref * g.double().cpu()).sum().backward()
+    assert rel_err(x.grad, x64.grad) <= 1e-4, "d input"
+    assert rel_err(conv.weight.grad, w64.grad) <= 1e-4, "d weight"
+    if bias:
+        assert rel_err(conv.bias.grad, b64.grad) <= 1e-4, "d bias"
+
+
+def test_dense_and_sequential_keep_the_graph(hip):
+    """SparseSequential(conv, BatchNorm1d, ReLU) + .dense(): gradients flow to the first conv's weight through torch's
+    own BatchNorm / ReLU and the densify scatter."""
+    from cpd_amd.spconv import pytorch as spconv
+    torch.manual_seed(1)
+    feats, idx, shape, batch = _sparse_scene(3, n=3000, shape=(5, 40, 36), c=16)
+    net = spconv.SparseSequential(spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="a"),
+                                  torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01), torch.nn.ReLU()).cuda().train()
+    out = net(spconv.SparseConvTensor(feats, idx, shape, batch)).dense()
+    assert out.shape == (batch, 32, 5, 40, 36)
+    gw = torch.randn_like(out)
+    (out * gw).sum().backward()
+    conv, bn = net[0], net[1]
+    nbr = None
+    # reference: same graph on the CPU in float64
+    x64 = feats.double().cpu()
+    w64 = conv.weight.detach().double().cpu().requires_grad_(True)
+    st = spconv.SparseConvTensor(feats, idx, shape, batch)
+    conv(st)
+    nbr = st.indice_dict["a"]["nbr"].cpu().numpy()
+    z = ref_train_torch._gconv(x64, w64, nbr)
+    y = F.relu(F.batch_norm(z, None, None, bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu(), training=True, eps=1e-3))
+    dense = ref_train_torch._scatter_dense(y.new_zeros(batch, 32, 5, 40, 36), idx.long().cpu(), y)
+    (dense * gw.double().cpu()).sum().backward()
+    assert rel_err(out.detach(), dense.detach()) <= 1e-5
+    assert rel_err(conv.weight.grad, w64.grad) <= 2e-4
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,zero_pad,bias", [(32, 64, 3, 1, 1, False, True), (64, 64, 3, 2, 0, True, False),
+                                                                  (16, 32, 3, 1, 1, False, False), (64, 3, 3, 1, 1, False, True)])
+def test_conv2d_gradients(hip, cin, cout, k, stride, pad, zero_pad, bias):
+    from cpd_amd import models
+    torch.manual_seed(cin + cout)
+    conv = models.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=bias).cuda()
+    x = torch.randn(2, cin, 21, 18, device="cuda", requires_grad=True)
+    xin = F.pad(x, (1, 1, 1, 1)) if zero_pad else x            # nn.ZeroPad2d(1) + pad-0 strided conv, base_bev_backbone.py:33
+    out = conv(xin)
+    g = torch.randn_like(out)
+    (out * g).sum().backward()
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = conv.weight.detach().double().cpu().requires_grad_(True)
+    b64 = conv.bias.detach().double().cpu().requires_grad_(True) if bias else None
+    ref = F.conv2d(F.pad(x64, (1, 1, 1, 1)) if zero_pad else x64, w64, b64, stride=stride, padding=pad)
+    assert out.shape == ref.shape and rel_err(out.detach(), ref.detach()) <= 1e-5
+    (ref * g.double().cpu()).sum().backward()
+    assert rel_err(x.grad, x64.grad) <= 1e-4
+    assert rel_err(conv.weight.grad, w64.grad) <= 1e-4
+    if bias:
+        assert rel_err(conv.bias.grad, b64.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("u", [1, 2])
+def test_conv_transpose2d_gradients(hip, u):
+    from cpd_amd import models
+    torch.manual_seed(u)
+    cin, cout = 64, 32
+    de = models.ConvTranspose2d(cin, cout, u, stride=u, bias=False).cuda()
+    x = torch.randn(2, cin, 11, 9, device="cuda", requires_grad=True)
+    out = de(x)
+    g = torch.randn_like(out)
+    (out * g).sum().backward()
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = de.weight.detach().double().cpu().requires_grad_(True)
+    ref = F.conv_transpose2d(x64, w64, None, stride=u)
+    assert out.shape == ref.shape and rel_err(out.detach(), ref.detach()) <= 1e-5
+    (ref * g.double().cpu()).sum().backward()
+    assert rel_err(x.grad, x64.grad) <= 1e-4
+    assert rel_err(de.weight.grad, w64.grad) <= 1e-4
+
+
+def test_reference_style_training_loop_matches_the_train_step(hip):
+    """The reference's loop -- model.train(); ret, tb, disp = model(batch_dict); ret['loss'].backward() (train_utils.py:29-41,
+    centerpoint.py:9-22) -- over the drop-in CenterPoint modules, against CenterPointTrainer (hand-written backward, pinned
+    on the float64 reference graph in tests/test_gpu_train.py) on the same weights, clouds and boxes: same loss, and every
+    parameter receives the same gradient (both sides are fp32 pipelines with different BatchNorm kernels, so a few
+    activations at a ReLU kink may take different branches: tolerance 1e-2 of each tensor's largest gradient)."""
+    from cpd_amd import models
+    from cpd_amd.train_engine import CenterPointTrainer
+    from cpd_amd.voxel_generator import VoxelGeneratorWrapper
+    from test_gpu_train import scene, small_cfg
+    cfg = small_cfg()
+    sd = init_state_dict(cfg, seed=3)
+    pts, gt = scene()
+    mcfg = models.waymo_centerpoint_cfg()
+    mcfg.BACKBONE_2D.LAYER_NUMS = cfg.bev_layer_nums
+    mcfg.BACKBONE_2D.NUM_FILTERS = cfg.bev_num_filters
+    mcfg.BACKBONE_2D.NUM_UPSAMPLE_FILTERS = cfg.bev_num_upsample_filters
+    mcfg.DENSE_HEAD.TARGET_ASSIGNER_CONFIG.NUM_MAX_OBJS = 50
+    net = models.CenterPoint(mcfg, point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size).cuda()
+    net.load_state_dict(sd)
+    net.train()
+    gen = VoxelGeneratorWrapper(cfg.voxel_size, cfg.point_cloud_range, 5, cfg.max_points_per_voxel, cfg.max_voxels)
+    vox, crd, num = [], [], []
+    for b, p in enumerate(pts):
+        v, c, n = gen.generate(p)
+        vox.append(v); num.append(n); crd.append(np.pad(c, ((0, 0), (1, 0)), constant_values=b))
+    batch = {"voxels": torch.from_numpy(np.concatenate(vox)).cuda(), "voxel_num_points": torch.from_numpy(np.concatenate(num)).float().cuda(),
+             "voxel_coords": torch.from_numpy(np.concatenate(crd)).float().cuda(), "batch_size": len(pts),
+             "gt_boxes": torch.from_numpy(gt).cuda()}
+    ret, tb, _ = net(batch)
+    ret["loss"].backward()
+    missing = [k for k, p in net.named_parameters() if p.grad is None]
+    assert not missing, missing
+
+    tr = CenterPointTrainer(cfg, sd, num_max_objs=50)
+    rows = tr.forward([torch.from_numpy(p).cuda() for p in pts], update_stats=False)
+    loss, d_rows, _ = tr.loss(rows, torch.from_numpy(gt).cuda())
+    tr.backward(d_rows)
+    want = tr.grad_dict()
+    assert abs(float(ret["loss"]) - float(loss)) <= 1e-4 * abs(float(loss))
+    worst = []
+    for k, p in net.named_parameters():
+        w = want[k].to(p.grad.device)
+        assert w.shape == p.grad.shape, k
+        scale = float(w.abs().max())
+        if scale < 1e-9:                                         # conv bias in front of a batch-stat BatchNorm: exactly zero
+            assert float(p.grad.abs().max()) <= 1e-3, k
+            continue
+        worst.append((float((p.grad - w).abs().max()) / scale, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 1e-2, worst[:8]
+    # update_stats=False left the trainer's running statistics alone
+    sd1 = tr.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert torch.equal(sd1[k].cpu(), v.float()), k

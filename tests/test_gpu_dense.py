@@ -19,29 +19,99 @@ def rows_nchw(rows, b, h, w):
     return rows.cpu().numpy().reshape(b, h, w, -1).transpose(0, 3, 1, 2)
 
 
-def conv2d_hip(x_rows, b, h, w, wt, bias=None, stride=1, scale=None, shift=None, relu=False):
+MATHS = ["f32", "bf16x3"]          # ModelConfig.conv_math values; the bench runs the second
+
+
+@pytest.fixture
+def small_tiles(monkeypatch):
+    """Let the split kernels (workgroup tiles, window kernel) take problems far below their production thresholds, so that
+    the small reference goldens run on the SAME kernel families the bench runs (the thresholds are speed-only)."""
+    monkeypatch.setenv("CPD_TUNE", "1")
+    monkeypatch.setenv("CPD_GC_BF16_MIN", "1")
+    monkeypatch.setenv("CPD_GC_BF16_MIN64", "1")
+
+
+def conv2d_hip(x_rows, b, h, w, wt, bias=None, stride=1, scale=None, shift=None, relu=False, math="f32", kernels=None):
+    """Conv2d(k, stride, pad 1) on channels-last rows exactly the way the engine issues it (dense flag, pixel table with its
+    image tag). `kernels`: list that collects the name of the kernel instantiation each call ran."""
     cout, cin, kh, kw = wt.shape
     nbr, ho, wo = ops.rulebook_conv2d(b, h, w, kh, kw, stride, 1, "cuda")
     packed = ops.pack_weight(torch.from_numpy(wt).permute(2, 3, 1, 0).reshape(kh * kw, cin, cout).contiguous().cuda())
     if shift is None and bias is not None:
         shift = bias
+    if kernels is not None:
+        kernels.append(ops.gather_conv_tile(b * ho * wo, cin, cout, x_rows.stride(0), dense=True, nbr=nbr, math=math))
     out = ops.gather_conv(x_rows, cin, packed, nbr, kh * kw, b * ho * wo, cout,
                           torch.from_numpy(scale).cuda() if scale is not None else None,
-                          torch.from_numpy(shift).cuda() if shift is not None else None, None, relu)
+                          torch.from_numpy(shift).cuda() if shift is not None else None, None, relu, dense=True, math=math)
     return out, ho, wo
 
 
 @pytest.mark.parametrize("cin,cout,stride,h,w", [(32, 16, 1, 24, 20), (64, 64, 1, 19, 23), (16, 32, 2, 24, 20), (128, 256, 2, 17, 17),
                                                  (256, 128, 1, 12, 12), (320, 11, 1, 16, 16)])
-def test_conv2d_matches_oracle(oracle, hip, cin, cout, stride, h, w):
+@pytest.mark.parametrize("math", MATHS)
+def test_conv2d_matches_oracle(oracle, hip, small_tiles, math, cin, cout, stride, h, w):
     rng = np.random.default_rng(cin + cout)
     b = 2
     x = rng.normal(size=(b, cin, h, w)).astype(np.float32)
     wt = (rng.normal(size=(cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
     bias = rng.normal(size=cout).astype(np.float32)
     want = oracle.conv2d(x, wt, bias, stride, 1)
-    got, ho, wo = conv2d_hip(nhwc_rows(x), b, h, w, wt, bias, stride)
+    got, ho, wo = conv2d_hip(nhwc_rows(x), b, h, w, wt, bias, stride, math=math)
     np.testing.assert_allclose(rows_nchw(got, b, ho, wo), want, atol=1e-4, rtol=0)
+
+
+# The layer shapes of BASELINE config 2's dense half at sizes where gather_conv picks the kernels the bench runs
+# (>= 600 workgroups), against the ORACLE's direct convolution: (cin, cout, k, stride, batch, h, w, expected kernel)
+BENCH_SHAPES = [
+    (128, 128, 3, 1, 3, 188, 188, "window_conv_bf16_kernel<128>"),      # BEV block 0, 5 layers
+    (256, 128, 3, 1, 3, 188, 188, "window_conv_bf16_kernel<128>"),      # BEV block 0, first conv
+    (256, 256, 3, 1, 5, 94, 94, "window_conv_bf16_kernel<128>"),        # BEV block 1, 5 layers
+    (128, 256, 3, 2, 5, 188, 188, "tile_conv_bf16_kernel<128,128>"),    # BEV block 1, strided conv
+    (512, 64, 3, 1, 5, 188, 188, "window_conv_bf16_kernel<64>"),        # CenterHead shared conv
+    (64, 320, 3, 1, 3, 188, 188, "window_conv_bf16_kernel<64>"),        # five SeparateHead first convs, fused
+    (320, 11, 3, 1, 3, 188, 188, "window_conv_bf16_kernel<16>"),        # five SeparateHead output convs, fused
+]
+
+
+@pytest.mark.parametrize("math", [m for m in MATHS if m != "f32"])
+@pytest.mark.parametrize("cin,cout,k,stride,batch,h,w,kernel", BENCH_SHAPES)
+def test_bench_kernels_match_oracle_at_full_size(oracle, hip, math, cin, cout, k, stride, batch, h, w, kernel):
+    """the kernels that carry the bench, at the bench's image sizes, against the oracle (not against
+    a self-authored reference): conv + bias, then the folded-BN affine + ReLU epilogue on top."""
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.normal(size=(batch, cin, h, w)).astype(np.float32)
+    wt = (rng.normal(size=(cout, cin, k, k)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32); shift = rng.normal(size=cout).astype(np.float32)
+    ran = []
+    got, ho, wo = conv2d_hip(nhwc_rows(x), batch, h, w, wt, None, stride, scale, shift, True, math=math, kernels=ran)
+    assert ran == [kernel], ran
+    want = np.maximum(oracle.conv2d(x, wt, None, stride, 1) * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    np.testing.assert_allclose(rows_nchw(got, batch, ho, wo), want, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("math", [m for m in MATHS if m != "f32"])
+@pytest.mark.parametrize("cin,cout,u,batch,h,w", [(128, 256, 1, 3, 188, 188), (256, 256, 2, 5, 94, 94)])
+def test_bench_deconv_kernels_match_oracle_at_full_size(oracle, hip, math, cin, cout, u, batch, h, w):
+    """The two deblocks (ConvTranspose2d k = s = u as one 1x1 GEMM with a column-group scatter) at bench size."""
+    rng = np.random.default_rng(cin + cout + u)
+    x = rng.normal(size=(batch, cin, h, w)).astype(np.float32)
+    wd = (rng.normal(size=(cin, cout, u, u)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    want = oracle.deconv2d(x, wd, u)
+    packed = ops.pack_weight(torch.from_numpy(wd).permute(0, 2, 3, 1).reshape(1, cin, u * u * cout).contiguous().cuda())
+    n = batch * h * w
+    assert ops.gather_conv_tile(n, cin, u * u * cout, cin, dense=True, math=math) == "tile_conv_bf16_kernel<128,128>"
+    H, W = h * u, w * u
+    out = torch.empty((batch * H * W, cout), device="cuda")
+    if u == 1:
+        ops.gather_conv(nhwc_rows(x), cin, packed, None, 1, n, cout, out=out, dense=True, math=math)
+    else:
+        bi = torch.arange(batch, device="cuda").view(-1, 1, 1); yy = torch.arange(h, device="cuda").view(1, -1, 1)
+        xx = torch.arange(w, device="cuda").view(1, 1, -1)
+        maps = torch.stack([((bi * H + 2 * yy + a) * W + 2 * xx + c).reshape(-1) for a in range(2) for c in range(2)])
+        ops.gather_conv(nhwc_rows(x), cin, packed, None, 1, n, 4 * cout, out=out, out_row_map=maps.to(torch.int32).contiguous(),
+                        out_col_group=cout, dense=True, math=math)
+    np.testing.assert_allclose(rows_nchw(out, batch, H, W), want, atol=1e-4, rtol=0)
 
 
 def test_deconv_k2s2_and_k1(oracle, hip):
@@ -77,21 +147,27 @@ def _fold(g, prefix, eps, bias=None):
     return s.astype(np.float32), t.astype(np.float32)
 
 
-def test_bev_backbone_matches_reference_golden(hip, golden):
-    """BaseBEVBackbone.forward (base_bev_backbone.py:85-122) reproduced on reference weights."""
-    g = golden("bev_backbone")
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("fixture,n_layers", [("bev_backbone", 2), ("bev_backbone_wide", 1)])
+def test_bev_backbone_matches_reference_golden(hip, golden, small_tiles, math, fixture, n_layers):
+    """BaseBEVBackbone.forward (base_bev_backbone.py:85-122) reproduced on reference weights, in every conv arithmetic.
+    The `_wide` fixture has 64/128-channel layers: with `small_tiles` the split modes run it on the workgroup / window
+    kernels the bench runs (asserted below); the narrow fixture's 16-channel layers take the fp32 kernels in every mode."""
+    ran = []
+    g = golden(fixture)
     x = g["bev_in"]
     b, _, h, w = x.shape
     rows = nhwc_rows(x)
     outs = []
     cur_h, cur_w = h, w
-    for lvl, (stride, n_layers, u) in enumerate([(1, 2, 1), (2, 2, 2)]):
+    for lvl, (stride, u) in enumerate([(1, 1), (2, 2)]):
         p = "sd.blocks.%d." % lvl
         s, t = _fold(g, p + "2", 1e-3)
-        rows, cur_h, cur_w = conv2d_hip(rows, b, cur_h, cur_w, g[p + "1.weight"], None, stride, s, t, True)
+        rows, cur_h, cur_w = conv2d_hip(rows, b, cur_h, cur_w, g[p + "1.weight"], None, stride, s, t, True, math=math, kernels=ran)
         for k in range(n_layers):
             s, t = _fold(g, p + "%d" % (5 + 3 * k), 1e-3)
-            rows, cur_h, cur_w = conv2d_hip(rows, b, cur_h, cur_w, g[p + "%d.weight" % (4 + 3 * k)], None, 1, s, t, True)
+            rows, cur_h, cur_w = conv2d_hip(rows, b, cur_h, cur_w, g[p + "%d.weight" % (4 + 3 * k)], None, 1, s, t, True, math=math,
+                                            kernels=ran)
         q = "sd.deblocks.%d." % lvl
         wd = g[q + "0.weight"]
         cin, cout = wd.shape[:2]
@@ -100,32 +176,40 @@ def test_bev_backbone_matches_reference_golden(hip, golden):
         sc, sh = torch.from_numpy(np.tile(s, u * u)).cuda(), torch.from_numpy(np.tile(t, u * u)).cuda()
         up = torch.empty((b * h * w, cout), device="cuda")
         if u == 1:
-            ops.gather_conv(rows, cin, packed, None, 1, b * cur_h * cur_w, cout, sc, sh, None, True, out=up)
+            ops.gather_conv(rows, cin, packed, None, 1, b * cur_h * cur_w, cout, sc, sh, None, True, out=up, dense=True, math=math)
         else:
             bi = torch.arange(b, device="cuda").view(-1, 1, 1); yy = torch.arange(cur_h, device="cuda").view(1, -1, 1)
             xx = torch.arange(cur_w, device="cuda").view(1, 1, -1)
             maps = torch.stack([((bi * h + 2 * yy + a) * w + 2 * xx + c).reshape(-1) for a in range(2) for c in range(2)])
             ops.gather_conv(rows, cin, packed, None, 1, b * cur_h * cur_w, 4 * cout, sc, sh, None, True, out=up,
-                            out_row_map=maps.to(torch.int32).contiguous(), out_col_group=cout)
+                            out_row_map=maps.to(torch.int32).contiguous(), out_col_group=cout, dense=True, math=math)
         outs.append(rows_nchw(up, b, h, w))
     got = np.concatenate(outs, 1)
     np.testing.assert_allclose(got, g["bev_out"], atol=1e-4, rtol=0)
+    if math != "f32" and fixture.endswith("_wide"):
+        assert all(k.startswith(("window_conv_", "tile_conv_bf16", "tile_conv_f16")) for k in ran), ran
 
 
-def test_center_head_matches_reference_golden(hip, golden):
-    """shared_conv + SeparateHead (center_head.py:11-45,73-80) on reference weights."""
-    g = golden("center_head")
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("fixture", ["center_head", "center_head_wide"])
+def test_center_head_matches_reference_golden(hip, golden, small_tiles, math, fixture):
+    """shared_conv + SeparateHead (center_head.py:11-45,73-80) on reference weights (`_wide`: 128 -> 64 -> 64 -> c channels,
+    which the split modes run on the window kernels: <64> for the 64-column convs, <16> for the output convs)."""
+    g = golden(fixture)
+    ran = []
     x = g["head_in"]
     b, _, h, w = x.shape
     s, t = _fold(g, "shared.1", 1e-5, g["shared.0.bias"])
-    mid, _, _ = conv2d_hip(nhwc_rows(x), b, h, w, g["shared.0.weight"], None, 1, s, t, True)
+    mid, _, _ = conv2d_hip(nhwc_rows(x), b, h, w, g["shared.0.weight"], None, 1, s, t, True, math=math, kernels=ran)
     np.testing.assert_allclose(rows_nchw(mid, b, h, w), g["shared_out"], atol=1e-4, rtol=0)
     for name in ["center", "center_z", "dim", "rot", "hm"]:
         p = "sep.%s." % name
         s, t = _fold(g, p + "0.1", 1e-5, g[p + "0.0.bias"])
-        hcur, _, _ = conv2d_hip(mid, b, h, w, g[p + "0.0.weight"], None, 1, s, t, True)
-        out, _, _ = conv2d_hip(hcur, b, h, w, g[p + "1.weight"], g[p + "1.bias"], 1)
+        hcur, _, _ = conv2d_hip(mid, b, h, w, g[p + "0.0.weight"], None, 1, s, t, True, math=math, kernels=ran)
+        out, _, _ = conv2d_hip(hcur, b, h, w, g[p + "1.weight"], g[p + "1.bias"], 1, math=math, kernels=ran)
         np.testing.assert_allclose(rows_nchw(out, b, h, w), g["out." + name], atol=1e-4, rtol=0)
+    if math != "f32" and fixture.endswith("_wide"):
+        assert all(k.startswith("window_conv_") for k in ran), ran
 
 
 @pytest.mark.parametrize("bm,bn", [(64, 64), (64, 128), (128, 64), (128, 128)])

@@ -65,6 +65,54 @@ def test_engine_matches_reference_graph(oracle, hip):
         np.testing.assert_allclose(got["pred_boxes"].cpu().numpy(), want["pred_boxes"], atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("math", ["bf16x3"])
+def test_full_size_config2_matches_oracle(oracle, hip, math):
+    """BASELINE config 2 at FULL size, features included: one 160k-point W-cloud through the oracle's
+    un-fused reference graph (seconds on the GPU box's host cores) against the engine on a batch of four frames -- three
+    other clouds plus that frame -- so that every layer runs the kernel instantiation the benchmark runs (the batched
+    voxelizer, 128-row row-wave tiles, the window / workgroup split kernels; a single frame would take the small-problem
+    variants). Indices bit-exact; every sparse level, the BEV map and the head maps <= 1e-4."""
+    cfg = ModelConfig(conv_math=math)
+    sd = init_state_dict(cfg, seed=0)
+    pts = waymo_cloud(0)
+    ref, rt = ref_pipeline.forward(oracle, cfg, sd, [pts])
+    eng = CenterPointEngine(cfg, sd)
+    clouds = [torch.from_numpy(waymo_cloud(k)).cuda() for k in (1, 2, 3)] + [torch.from_numpy(pts).cuda()]
+    fi = len(clouds) - 1                                           # the checked frame sits LAST: nonzero row offsets everywhere
+    res, it = eng.forward(clouds, return_intermediates=True)
+
+    vc = it["voxel_coords"].cpu().numpy()
+    mine = vc[:, 0] == fi
+    np.testing.assert_array_equal(vc[mine][:, 1:], rt["voxel_coords"][:, 1:])
+    np.testing.assert_allclose(it["voxel_features"].cpu().numpy()[mine], rt["voxel_features"], rtol=1e-6, atol=1e-6)
+    for name in ["x_conv1", "x_conv2", "x_conv3", "x_conv4"]:
+        f, i, s = it["levels"][name]
+        f0, i0, s0 = rt["levels"][name]
+        i = i.cpu().numpy()
+        mine = i[:, 0] == fi
+        np.testing.assert_array_equal(i[mine][:, 1:], i0[:, 1:])
+        np.testing.assert_allclose(f.cpu().numpy()[mine], f0, atol=1e-4, rtol=0, err_msg=name)
+    x, idx, shape = it["encoded"]
+    x0, idx0, shape0 = rt["encoded"]
+    idx = idx.cpu().numpy()
+    mine = idx[:, 0] == fi
+    assert list(shape) == list(shape0) == [2, 188, 188]
+    np.testing.assert_array_equal(idx[mine][:, 1:], idx0[:, 1:])
+    np.testing.assert_allclose(x.cpu().numpy()[mine], x0, atol=1e-4, rtol=0)
+    d, h, w = shape
+    B = len(clouds)
+    bev = it["bev_cat"].view(B, h, w, -1)[fi].permute(2, 0, 1).cpu().numpy()
+    np.testing.assert_allclose(bev, rt["bev"][0], atol=1e-4, rtol=0)
+    head = it["head_rows"].view(B, h, w, -1)[fi].permute(2, 0, 1).cpu().numpy()
+    for name, (c0, cn) in eng.head_slices.items():
+        np.testing.assert_allclose(head[c0:c0 + cn], rt["heads"][name][0], atol=1e-4, rtol=0, err_msg=name)
+    got, want = res[fi], ref[0]
+    assert got["pred_boxes"].shape[0] == want["pred_boxes"].shape[0]
+    np.testing.assert_array_equal(got["pred_labels"].cpu().numpy(), want["pred_labels"])
+    np.testing.assert_allclose(got["pred_scores"].cpu().numpy(), want["pred_scores"], atol=1e-5)
+    np.testing.assert_allclose(got["pred_boxes"].cpu().numpy(), want["pred_boxes"], atol=1e-3, rtol=1e-4)
+
+
 def test_full_size_properties(hip):
     """Config 2 (160k Waymo-shape cloud, full widths): shapes, determinism, batch consistency."""
     cfg = ModelConfig()

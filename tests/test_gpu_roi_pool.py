@@ -34,13 +34,11 @@ def test_voxel_query_dense_and_indexed_match_oracle(oracle, hip, max_range, radi
     np.testing.assert_array_equal(empty.cpu().numpy(), empty_want)
     np.testing.assert_array_equal(idx.cpu().numpy(), want)
     index = ops.SiteIndex.build(d_cells, batch, shape)           # cells are in canonical order: rank == row
-    index.canonical = True
     idx2, empty2 = roi_pool.voxel_query(max_range, radius, nsample, d_xyz, d_qxyz, d_q, index=index)
     np.testing.assert_array_equal(idx2.cpu().numpy(), want)
     # arbitrary row order goes through the index permutation
     perm = rng.permutation(cells.shape[0])
     index_p = ops.SiteIndex.build(torch.from_numpy(cells[perm]).cuda(), batch, shape)
-    index_p.canonical = False
     idx3, _ = roi_pool.voxel_query(max_range, radius, nsample, torch.from_numpy(xyz[perm]).cuda(), d_qxyz, d_q, index=index_p)
     v2p_p = oracle.voxel2pinds(cells[perm], batch, shape)
     want_p = oracle.voxel_query(max_range, radius, nsample, xyz[perm], qxyz, q, v2p_p)
@@ -85,7 +83,6 @@ def test_pool_module_reproduces_reference_module_output(golden, hip):
     out = mod(xyz.contiguous(), cnt, new_xyz, new_cnt, nc, feats, voxel2point_indices=v2p)
     np.testing.assert_allclose(out.cpu().numpy(), g["pooled"], atol=1e-4, rtol=0)
     index = ops.SiteIndex.build(cells, 2, shape)
-    index.canonical = True
     out2 = mod(xyz.contiguous(), cnt, new_xyz, new_cnt, nc, feats, index=index)
     assert torch.equal(out, out2)
 
@@ -116,7 +113,6 @@ def test_roi_grid_pool_on_engine_levels(hip):
     for name in layers:
         f, c, s = it["levels"][name]
         indexes[name] = ops.SiteIndex.build(c, 2, s)
-        indexes[name].canonical = True
     via_index = roi_pool.roi_grid_pool(rois, it["levels"], strides, layers, 6, cfg.voxel_size, cfg.point_cloud_range, 2, indexes=indexes)
     assert torch.equal(dense, via_index)
 

@@ -118,6 +118,16 @@ def test_nms_matches_reference(oracle, golden, tag):
     np.testing.assert_array_equal(scores[sel], g[tag + ".selected_scores"])
 
 
+def test_nms_4096_matches_reference(oracle, golden):
+    """NMS_PRE_MAXSIZE-sized set (64 mask words per row) through the reference's class_agnostic_nms."""
+    g = golden("nms_n4096")
+    boxes, scores, thr = g["boxes"], g["scores"], float(g["thr"])
+    order = np.argsort(-scores, kind="stable")[:4096]
+    sel = order[oracle.nms(boxes[order], thr)]
+    np.testing.assert_array_equal(sel, g["selected"])
+    np.testing.assert_array_equal(scores[sel], g["selected_scores"])
+
+
 def test_iou3d_composition(oracle, golden):
     """boxes_iou3d_gpu (iou3d_nms_utils.py:67-100) recomposed in numpy from oracle overlaps."""
     g = golden("iou_bev")

@@ -27,7 +27,6 @@ indexes = {}
 for name in layers:
     f, c, s = it["levels"][name]
     indexes[name] = ops.SiteIndex.build(c, B, s)
-    indexes[name].canonical = True
 
 
 def timed(fn, n=10):
