@@ -12,7 +12,7 @@ A step = one pass of the whole hot path over one batch of `--frames` resident po
 Frames are sharded across ranks with NO data-path collective (forward-only inference shards by
 frame: SURVEY 8e); RCCL is used only for the timing barrier / max-over-ranks. Inputs are already in
 HBM when the timed region starts; each step ends with the one D2H of its final boxes / scores /
-labels into pinned host memory (inside the timed region; --device-results leaves them in HBM).
+labels into host memory (inside the timed region; --device-results leaves them in HBM).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : dominant kernel (gather_conv_kernel<ms,nt,vec>, fp32 MFMA bound) measured live with
@@ -71,7 +71,7 @@ def parse():
                     help="infer = BASELINE config 2 (the headline metric); train = config 3: forward + backward + "
                          "one RCCL gradient all-reduce + Adam, --frames (default 1) frames per GPU per step")
     ap.add_argument("--device-results", action="store_true", help="leave the final boxes on the device (default: the one D2H "
-                    "of each step's boxes / scores / labels into pinned host memory is inside the timed region, SURVEY 8d)")
+                    "of each step's boxes / scores / labels into host memory is inside the timed region, SURVEY 8d)")
     ap.add_argument("--launch-check", action="store_true", help="only launch the --gpus ranks, rendezvous, run the timing "
                     "collectives (barrier, max over ranks) and print the n_gpus line: no GPU work (the CPU test of the N > 1 "
                     "launcher, backend from CPD_DIST_BACKEND)")
@@ -410,7 +410,7 @@ def main():
         "value": world * args.steps * B / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (inputs in pinned host memory, H2D timed)" if args.host_input else ""),
-        "results": "left on the device" if args.device_results else "copied to pinned host memory inside the timed region",
+        "results": "left on the device" if args.device_results else "copied to host memory inside the timed region",
         "config": {"workload": "configs[1]: Waymo-shape %d-point cloud, CPD VoxelResBackBone8x + HeightCompression + "
                                "BaseBEVBackbone + CenterHead + rotated NMS, forward-only" % args.points,
                    "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,

@@ -186,10 +186,9 @@ class CenterPointEngine:
     def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], device="cuda", host_results=False):
         self.cfg = cfg
         self.device = torch.device(device)
-        # host_results: the final boxes / scores / labels are returned as HOST tensors -- one asynchronous D2H of the padded
-        # result block into pinned memory whose completion is the step's only stream synchronisation
+        # host_results: the final boxes / scores / labels are returned as HOST tensors (the D2H of the padded result block
+        # follows the step's one count read-back)
         self.host_results = bool(host_results)
-        self._pinned = {}
         self.sd = state_dict
         self.voxelizer = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features,
                                        cfg.max_points_per_voxel, cfg.max_voxels, device=self.device)
@@ -405,14 +404,11 @@ class CenterPointEngine:
         keep, num_keep = ops.nms_batch(boxes, counts, cfg.nms_thresh)
         ob, os_, ol, on = ops.select_boxes(boxes, scores, labels, keep, num_keep, cfg.nms_post_maxsize, label_offset=1)
         if self.host_results:
-            pin = self._pinned.get(batch)
-            if pin is None:
-                pin = self._pinned[batch] = tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in (ob, os_, ol, on))
-            for dst, src in zip(pin, (ob, os_, ol, on)):
-                dst.copy_(src, non_blocking=True)
-            torch.cuda.current_stream().synchronize()      # results are on the host
-            ob, os_, ol = (t.clone() for t in pin[:3])    # the pinned block is reused by the next step
-            ns = pin[3].tolist()
+            # blocking copies: the first waits for the frame's last kernel, the rest are ~20 us each. (Asynchronous copies
+            # into pinned memory queued on the compute stream were measured 5-8 ms per step SLOWER on MI355X / ROCm 7.2 --
+            # tools/d2h_probe.py -- whatever the wait that followed them: event, stream or a later blocking read.)
+            ns = on.tolist()
+            ob, os_, ol = ob.cpu(), os_.cpu(), ol.cpu()
         else:
             ns = on.tolist()                      # the one host read-back of the stage
         return [{"pred_boxes": ob[b, :ns[b]], "pred_scores": os_[b, :ns[b]], "pred_labels": ol[b, :ns[b]]}

@@ -107,10 +107,15 @@ def test_full_size_config2_matches_oracle(oracle, hip, math):
     for name, (c0, cn) in eng.head_slices.items():
         np.testing.assert_allclose(head[c0:c0 + cn], rt["heads"][name][0], atol=1e-4, rtol=0, err_msg=name)
     got, want = res[fi], ref[0]
-    assert got["pred_boxes"].shape[0] == want["pred_boxes"].shape[0]
-    np.testing.assert_array_equal(got["pred_labels"].cpu().numpy(), want["pred_labels"])
+    a, b = got["pred_boxes"].cpu().numpy(), want["pred_boxes"]
+    assert a.shape == b.shape
     np.testing.assert_allclose(got["pred_scores"].cpu().numpy(), want["pred_scores"], atol=1e-5)
-    np.testing.assert_allclose(got["pred_boxes"].cpu().numpy(), want["pred_boxes"], atol=1e-3, rtol=1e-4)
+    # same detections; boxes whose scores tie to ~1e-6 may swap ranks between the two pipelines, so match by geometry
+    j = np.abs(a[:, None, :] - b[None, :, :]).max(-1).argmin(1)
+    assert sorted(j.tolist()) == list(range(len(b)))
+    np.testing.assert_allclose(a, b[j], atol=1e-3, rtol=1e-4)
+    np.testing.assert_array_equal(got["pred_labels"].cpu().numpy(), want["pred_labels"][j])
+    assert np.abs(j - np.arange(len(j))).max() <= 3           # only neighbours in the ranking swap
 
 
 def test_full_size_properties(hip):
