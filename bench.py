@@ -39,6 +39,7 @@ from cpd_amd.synthetic import waymo_cloud  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 BF16X3_PRODUCTS = 6             # bf16 MFMA products per fp32 multiply-add in the split-bf16 kernels
+F16X2_PRODUCTS = 3              # fp16 MFMA products per fp32 multiply-add in the split-fp16 kernels
 
 
 def kernel_peak(kname):
@@ -46,6 +47,8 @@ def kernel_peak(kname):
     per algorithmic fp32 multiply-add, so their ceiling is the bf16 peak / 6."""
     if "bf16" in kname:
         return PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS, "bf16 dense MFMA peak 2500 TFLOP/s / 6 partial products (split-bf16, fp32-level result)"
+    if "f16" in kname:
+        return PEAK_BF16_MFMA_TFLOPS / F16X2_PRODUCTS, "fp16 dense MFMA peak 2500 TFLOP/s / 3 partial products (split-fp16, fp32-level result)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32-input MFMA peak"
 
 POOL = 8                        # distinct synthetic frames per rank (seeds rank*8 .. rank*8+7: SURVEY 8d), cycled
@@ -63,8 +66,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-launch table of the conv kernels (stderr)")
-    ap.add_argument("--conv-math", choices=["bf16x3", "f32"], default="bf16x3",
-                    help="dense-layer arithmetic: split-bf16 x3 on the bf16 matrix pipe (fp32-level error) or fp32 MFMA")
+    ap.add_argument("--conv-math", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
+                    help="arithmetic of the layers with >= 32 input channels: split-fp16 x2 (3 products) or split-bf16 x3 (6 products) "
+                         "on the 16-bit matrix pipe (both fp32-level error), or fp32 MFMA")
     ap.add_argument("--host-input", action="store_true", help="points start in pinned HOST memory: the H2D copies are inside "
                     "the timed region (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
@@ -106,7 +110,8 @@ class ConvProfiler:
         prof = self
 
         def wrapped(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
-            kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False), kw.get("bf16x3", False), nbr)
+            kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False), kw.get("bf16x3", False), nbr,
+                                         math=kw.get("math"))
             flops = 2.0 * prof._pairs(nbr, n_out, c_in, c_out) * c_in * c_out
             if kw.get("out") is None:          # allocate before the window: an allocator miss (hipMalloc) stalls the host,
                 kw["out"] = torch.empty((n_out, c_out), dtype=torch.float32, device=inp.device)   # and the GPU idles meanwhile
@@ -416,9 +421,12 @@ def main():
                    "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
                    "parallelism": "frame-sharded replicas x%d, no data-path collective" % world,
                    "weights": "random-init (seed 0), eval-mode BN folded",
-                   "conv_math": ("layers with >= 32 input channels: split-bf16 x3 (fp32 operands split exactly into 3 bf16 terms, "
-                                 "6 bf16 MFMA products per fp32 multiply-add, fp32-level error); 5/16-channel sparse layers: "
-                                 "fp32 MFMA") if cfg.conv_math == "bf16x3" else "fp32 MFMA everywhere"},
+                   "conv_math": {"bf16x3": "layers with >= 32 input channels: split-bf16 x3 (fp32 operands split exactly into 3 bf16 terms, "
+                                           "6 bf16 MFMA products per fp32 multiply-add, fp32-level error); 5/16-channel sparse layers: fp32 MFMA",
+                                 "f16x2": "layers with >= 32 input channels: split-fp16 x2 (fp32 operands written as 2 fp16 terms, 3 fp16 MFMA "
+                                          "products per fp32 multiply-add, fp32 accumulation, fp32-level error); 5/16-channel sparse layers: "
+                                          "fp32 MFMA",
+                                 "f32": "fp32 MFMA everywhere"}[cfg.conv_math]},
     }
 
     if not args.no_roofline:

@@ -46,7 +46,8 @@ namespace {
 struct GcParams {
     const float *in;
     const float *w;
-    const void *wb;           // split-bf16 image of the weights (after the fp32 image) or NULL
+    const void *wb;           // split image of the weights (bf16x3 or f16x2, after the fp32 image) or NULL
+    const float *dsc;         // f16x2 only: per output column, the power of two that undoes the weights' pre-scale (or NULL)
     const int32_t *nbr;
     const uint32_t *tapmask;  // per 16-row sub-tile: bit t = some row has a neighbour at tap t (or NULL)
     const float *scale, *shift, *residual;
@@ -95,6 +96,7 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
     for (int nt = 0; nt < NT; ++nt) {
         const int col = col0 + nt * 16 + r;
         sc[nt] = (p.scale && col < p.c_out) ? p.scale[col] : 1.f;
+        if (p.dsc && col < p.np) sc[nt] *= p.dsc[col];       // exact (a power of two): (acc * 2^-e) * scale, bit for bit
         sh[nt] = (p.shift && col < p.c_out) ? p.shift[col] : 0.f;
     }
 #pragma unroll
@@ -403,40 +405,86 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(GcParams p) {
     epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
 }
 
-// ============================ split-bf16 workgroup kernel ====================================
-// fp32-equivalent convolution on the bf16 matrix pipe (16x the fp32 MFMA rate): every fp32 operand
-// is split EXACTLY into three bf16 terms, x = h + m + l (3 x 8 significand bits; h = rne(x),
-// m = rne(x - h), l = rne(x - h - m), each difference exact in fp32), and the six partial products
-// of relative weight >= 2^-18 (hh, hm, mh, hl, lh, mm) are accumulated in fp32 by
-// v_mfma_f32_16x16x32_bf16; the dropped terms (ml, lm, ll) are < 2^-26 of the product, below fp32's
-// own rounding. 6 MFMAs of K = 32 replace 8 fp32 MFMAs of K = 4 at 1/2 the cycles each: 2.67x.
-// Weights are split once at pack time (image Pb[t][k32][piece][g][n][8] after the fp32 image);
-// gathered activation rows are split while they are staged into LDS.
-// LDS images of one 32-channel stage, per piece in {h, m, l} (slots = 16 B = 8 channels):
+// ================================ split-operand arithmetic ==================================
+// fp32-equivalent convolution on the 16-bit matrix pipe (16x the fp32 MFMA rate). Two ways of writing an fp32
+// operand as a short sum of 16-bit terms whose pairwise products are EXACT in fp32:
+//
+//   SplitBf16x3: x = h + m + l, three bf16 terms (3 x 8 significand bits; h = rne(x), m = rne(x - h), l = rne(x - h - m),
+//     each difference exact in fp32: the split itself is exact over the whole fp32 range). Six partial products of
+//     relative weight >= 2^-18 (hh, hm, mh, hl, lh, mm) are accumulated in fp32 by v_mfma_f32_16x16x32_bf16; the dropped
+//     ones (ml, lm, ll) are < 2^-26 of the product. 6 MFMAs of K = 32 replace 8 fp32 MFMAs of K = 4 at half the cycles: 2.67x.
+//   SplitF16x2: x = h + l, two fp16 terms (2 x 11 significand bits + the sign of l: h = rne(x), l = rne(x - h) represent x to
+//     2^-24 relative, i.e. to fp32's own half-ulp, while |x| >= 2^-1; below that l enters fp16's subnormal range and the
+//     error is <= 2^-25 ABSOLUTE -- gfx950's MFMA honours fp16 subnormals, tools/f16_probe.hip). Three partial products
+//     (hh, hl, lh) on v_mfma_f32_16x16x32_f16; the dropped ll is <= 2^-24 of the product. 3 MFMAs instead of 6: 5.3x the
+//     fp32 pipe. fp16's RANGE is the price: activations must stay below 65504 in magnitude (an overflow gives inf / NaN in the
+//     output -- loud, not silent), and the weights are pre-scaled per output column by a power of two (exact; folded back
+//     in the epilogue) so that a column's largest weight sits in [2^13, 2^14) whatever its magnitude.
+// Weights are split once at pack time (images Pb / Ph [t][k32][piece][g][n][8] after the fp32 image); gathered activation
+// rows are split while they are staged.
+// LDS images of one 32-channel stage, per piece (slots = 16 B = 8 channels):
 //   A: k-group g of tile row m at (g*BM + (m ^ 2g)) * 16   (8-byte staging writes of two rows x
 //      8 lanes and 16-row fragment reads are both conflict-free)
 //   B: k-group g of tile col n at (g*BN + n) * 16          (lane-linear both ways)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split3(const f32x4 &x, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
-    h = __builtin_convertvector(x, bf16x4);
-    const f32x4 r1 = x - __builtin_convertvector(h, f32x4);
-    m = __builtin_convertvector(r1, bf16x4);
-    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
-    l = __builtin_convertvector(r2, bf16x4);
+struct SplitBf16x3 {
+    static constexpr int NP = 3;
+    typedef bf16x8 frag;
+    typedef bf16x4 half;
+    static __device__ __forceinline__ void split(const f32x4 &x, half (&p)[NP]) {
+        p[0] = __builtin_convertvector(x, bf16x4);
+        const f32x4 r1 = x - __builtin_convertvector(p[0], f32x4);
+        p[1] = __builtin_convertvector(r1, bf16x4);
+        const f32x4 r2 = r1 - __builtin_convertvector(p[1], f32x4);
+        p[2] = __builtin_convertvector(r2, bf16x4);
+    }
+    static __device__ __forceinline__ f32x4 mma(const frag (&a)[NP], const frag (&b)[NP], f32x4 c) {   // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+struct SplitF16x2 {
+    static constexpr int NP = 2;
+    typedef f16x8 frag;
+    typedef f16x4 half;
+    static __device__ __forceinline__ void split(const f32x4 &x, half (&p)[NP]) {
+        p[0] = __builtin_convertvector(x, f16x4);
+        const f32x4 r1 = x - __builtin_convertvector(p[0], f32x4);
+        p[1] = __builtin_convertvector(r1, f16x4);
+    }
+    static __device__ __forceinline__ f32x4 mma(const frag (&a)[NP], const frag (&b)[NP], f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+template <class S>
+__device__ __forceinline__ typename S::frag join_halves(const typename S::half &lo, const typename S::half &hi) {
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int BM, int BN, bool DB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BM == 128 && !DB) ? (BN == 128 ? 3 : 4) : 1, (BM == 128 && !DB) ? (BN == 128 ? 3 : 4) : 8)))
-tile_conv_bf16_kernel(GcParams p) {
-    constexpr bool OCC3 = BM == 128 && !DB;   // the variant squeezed into 3 waves per SIMD (168 registers)
+// ----------------------------- split workgroup kernel (rulebook) -----------------------------
+// SH = row sub-tiles of a wave whose A fragments are live at once (the B fragments are re-read MS / SH times per stage);
+// LATE_B = the weight stage is fetched AFTER the MFMA block, so its registers are not live across it.
+template <class S, int BM, int BN, bool DB, int SH, bool LATE_B>
+__device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
+    constexpr int NP = S::NP;
     constexpr int MS = BM / 32, NT = BN / 32;       // 2 x 2 waves, wave tile (BM/2) x (BN/2)
     constexpr int AJ = BM / 32;                     // fp32 A pieces (4 channels) staged per thread per stage
-    constexpr int BJ = 3 * BN / 64;                 // 16-byte B pieces staged per thread per stage
+    constexpr int BJ = NP * BN / 64;                // 16-byte B pieces staged per thread per stage
     constexpr int A_IMG = BM * 64, B_IMG = BN * 64; // bytes of one piece image
-    constexpr int STAGE = 3 * (A_IMG + B_IMG);
+    constexpr int STAGE = NP * (A_IMG + B_IMG);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -464,7 +512,7 @@ tile_conv_bf16_kernel(GcParams p) {
     }
     const int sk = p.c_in >> 5;    // 32-channel stages per tap
     const int n_stage = p.kv * sk;
-    const size_t b_stage = (size_t)3 * 4 * p.np * 16;   // bytes of one (tap, k32) block of Pb
+    const size_t b_stage = (size_t)NP * 4 * p.np * 16;   // bytes of one (tap, k32) block of the split image
 
     int idx_cur[AJ];
 #pragma unroll
@@ -473,7 +521,6 @@ tile_conv_bf16_kernel(GcParams p) {
     f32x4 ra[AJ];
     bool rz[AJ];                    // "no neighbour": applied when the piece is split, so that nothing
     f32x4u rbv[BJ];                 // between the loads and the MFMAs of the current stage waits on them
-    // OCC3: the weights are fetched AFTER the MFMA block, so their 24 registers are not live across it
     // stage st = (32-channel block kk, tap t), TAP INNER: the nine taps of one channel block re-read (nearly) the
     // same 128-byte row segments back to back, so the re-reads hit L2 instead of going out to the fabric
     auto stage_load_b = [&](int st) {
@@ -494,21 +541,20 @@ tile_conv_bf16_kernel(GcParams p) {
             ra[j] = load_a<true>(p, id, kk * 32 + a_piece * 4);
             rz[j] = id < 0;
         }
-        if (!OCC3) stage_load_b(st);
+        if (!LATE_B) stage_load_b(st);
     };
     auto stage_store = [&](int buf) {
         char *sa = smem + (DB ? buf : 0) * STAGE;
-        char *sb = sa + 3 * A_IMG;
+        char *sb = sa + NP * A_IMG;
         const int ag = a_piece >> 1, half = a_piece & 1;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int m = a_row + 32 * j;
-            bf16x4 h, mm, l;
-            split3(zero_if(ra[j], rz[j]), h, mm, l);
+            typename S::half pc[NP];
+            S::split(zero_if(ra[j], rz[j]), pc);
             char *dst = sa + (((ag * BM + (m ^ (2 * ag))) << 4) + half * 8);
-            *reinterpret_cast<bf16x4 *>(dst) = h;
-            *reinterpret_cast<bf16x4 *>(dst + A_IMG) = mm;
-            *reinterpret_cast<bf16x4 *>(dst + 2 * A_IMG) = l;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<typename S::half *>(dst + q * A_IMG) = pc[q];
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
@@ -523,7 +569,7 @@ tile_conv_bf16_kernel(GcParams p) {
     };
     stage_load(0);
     if (n_stage > 1) idx_load(1);
-    if (OCC3) stage_load_b(0);
+    if (LATE_B) stage_load_b(0);
     stage_store(0);
     __syncthreads();
     for (int st = 0; st < n_stage; ++st) {
@@ -534,74 +580,75 @@ tile_conv_bf16_kernel(GcParams p) {
         }
         {
             const char *sa = smem + (DB ? (st & 1) : 0) * STAGE;
-            const char *sb = sa + 3 * A_IMG;
-            constexpr int SH = OCC3 ? 2 : MS;   // row sub-tiles whose fragments are live at once
+            const char *sb = sa + NP * A_IMG;
 #pragma unroll
             for (int s0 = 0; s0 < MS; s0 += SH) {
-                bf16x8 ah[SH], am[SH], al[SH];
+                typename S::frag a[SH][NP];
 #pragma unroll
                 for (int s = 0; s < SH; ++s) {
                     const int m = wr * (BM / 2) + 16 * (s0 + s) + r;
                     const char *src = sa + ((g * BM + (m ^ (2 * g))) << 4);
-                    ah[s] = *reinterpret_cast<const bf16x8 *>(src);
-                    am[s] = *reinterpret_cast<const bf16x8 *>(src + A_IMG);
-                    al[s] = *reinterpret_cast<const bf16x8 *>(src + 2 * A_IMG);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) a[s][q] = *reinterpret_cast<const typename S::frag *>(src + q * A_IMG);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = wc * (BN / 2) + 16 * nt + r;
                     const char *src = sb + ((g * BN + n) << 4);
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
-                    const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + 4 * BN * 16);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(src + 8 * BN * 16);
+                    typename S::frag b[NP];
 #pragma unroll
-                    for (int s = 0; s < SH; ++s) {      // smallest terms first
-                        f32x4 c = acc[s0 + s][nt];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
-                        acc[s0 + s][nt] = c;
-                    }
+                    for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+#pragma unroll
+                    for (int s = 0; s < SH; ++s) acc[s0 + s][nt] = S::mma(a[s], b, acc[s0 + s][nt]);
                 }
-                if (SH < MS) asm volatile("" ::: "memory");     // keep the halves' LDS reads apart (register budget)
+                if (SH < MS) asm volatile("" ::: "memory");     // keep the groups' LDS reads apart (register budget)
             }
         }
         if (!DB) __syncthreads();          // single buffer: everyone is done reading before it is overwritten
-        if (OCC3 && nx < n_stage) stage_load_b(nx);
+        if (LATE_B && nx < n_stage) stage_load_b(nx);
         if (nx < n_stage) stage_store(nx & 1);
         __syncthreads();
     }
     epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
 }
 
-// Split-bf16 kernel for the dense 3x3 / stride 1 / pad 1 convolutions (BaseBEVBackbone blocks, CenterHead convs) over
+template <int BM, int BN, bool DB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BM == 128 && !DB) ? (BN == 128 ? 3 : 4) : 1, (BM == 128 && !DB) ? (BN == 128 ? 3 : 4) : 8)))
+tile_conv_bf16_kernel(GcParams p) {
+    constexpr bool OCC3 = BM == 128 && !DB;   // the variant squeezed into 3 waves per SIMD (168 registers)
+    tile_conv_split_body<SplitBf16x3, BM, BN, DB, OCC3 ? 2 : BM / 32, OCC3>(p);
+}
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && BM == 128 ? 3 : 4, BN == 128 && BM == 128 ? 3 : 8)))
+tile_conv_f16_kernel(GcParams p) {
+    tile_conv_split_body<SplitF16x2, BM, BN, false, BM / 32, true>(p);
+}
+
+// Split kernel for the dense 3x3 / stride 1 / pad 1 convolutions (BaseBEVBackbone blocks, CenterHead convs) over
 // channels-last pixel rows [frames * H * W, C], WITHOUT a rulebook: the input row of output row R at tap (dy, dx) is
 // R + dy*W + dx whenever that pixel exists, so the three dx taps of one dy read the same 130-row WINDOW
 // [row0 + dy*W - 1, row0 + dy*W + 128] shifted by one row. The window is gathered, split and written to LDS ONCE per
 // (32-channel block, dy) and the three taps read their fragments from it at row offsets 0, 1, 2: a third of the
-// gathers, splits and LDS writes of tile_conv_bf16_kernel and no rulebook reads at all. Taps that leave the image
+// gathers, splits and LDS writes of the rulebook kernel and no rulebook reads at all. Taps that leave the image
 // (y + dy or x + dx out of range; also what keeps frames apart) are zeroed on the A fragments of the affected
 // lanes -- a wave-uniform branch that is taken for ~1 in 6 (sub-tile, dx != 0) pairs at W = 188.
 // Same tile, fragment layout, XOR-2g swizzle (the image has 136 rows per k-group so that 129 ^ 6 stays inside), register
-// diet (two row sub-tiles live at a time, weights fetched after the MFMA block) and occupancy as tile_conv_bf16_kernel.
-template <int BN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
-window_conv_bf16_kernel(GcParams p) {
+// diet (SH row sub-tiles live at a time, weights fetched after the MFMA block) as the rulebook kernel.
+template <class S, int BN, int SH>
+__device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
+    constexpr int NP = S::NP;
     constexpr int BM = 128;
     constexpr int WC = BN >= 64 ? 2 : 1, WR = 4 / WC;   // wave grid: 2 x 2, or 4 x 1 for the 16-column tile (tiny c_out heads)
     constexpr int WM = BM / WR;                         // rows per wave
     constexpr int MS = WM / 16, NT = BN / WC / 16;
     constexpr int WROWS = BM + 2, BMW = BM + 8;
     constexpr int AJ = (WROWS * 8 + 255) / 256;     // fp32 A pieces (4 channels) per thread per window
-    constexpr int B_SLOTS = 3 * 4 * BN;             // 16-byte B pieces of one stage
+    constexpr int B_SLOTS = NP * 4 * BN;            // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;       // ... per thread
-    constexpr int A_IMG = BMW * 64;
+    constexpr int A_IMG = BMW * 64, B_IMG = BN * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const sa = smem;
-    char *const sb = smem + 3 * A_IMG;
+    char *const sb = smem + NP * A_IMG;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave - wr * WC;
@@ -633,7 +680,7 @@ window_conv_bf16_kernel(GcParams p) {
     const int a_row = tid >> 3;    // window row, + 32*j
     const int sk = p.c_in >> 5;
     // stage st = (32-channel block st / 9, tap st % 9): taps inner
-    const size_t b_stage = (size_t)3 * 4 * p.np * 16;
+    const size_t b_stage = (size_t)NP * 4 * p.np * 16;
 
     f32x4 ra[AJ];
     f32x4u rbv[BJ];
@@ -655,12 +702,11 @@ window_conv_bf16_kernel(GcParams p) {
         for (int j = 0; j < AJ; ++j) {
             const int w = a_row + 32 * j;
             if (AJ * 32 <= WROWS || w < WROWS) {
-                bf16x4 h, mm, l;
-                split3(ra[j], h, mm, l);
+                typename S::half pc[NP];
+                S::split(ra[j], pc);
                 char *dst = sa + (((ag * BMW + (w ^ (2 * ag))) << 4) + half * 8);
-                *reinterpret_cast<bf16x4 *>(dst) = h;
-                *reinterpret_cast<bf16x4 *>(dst + A_IMG) = mm;
-                *reinterpret_cast<bf16x4 *>(dst + 2 * A_IMG) = l;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<typename S::half *>(dst + q * A_IMG) = pc[q];
             }
         }
     };
@@ -693,45 +739,34 @@ window_conv_bf16_kernel(GcParams p) {
         const bool new_window = nx < n_stage && nx % 3 == 0;     // the next stage starts another dy (or channel block)
         if (new_window) load_window(nx / 9, (nx % 9) / 3 - 1);   // in flight under this stage's MFMAs
         {
-            const bf16x8 zero = {};
+            const typename S::frag zero = {};
 #pragma unroll
-            for (int s0 = 0; s0 < MS; s0 += 2) {
-                bf16x8 ah[2], am[2], al[2];
+            for (int s0 = 0; s0 < MS; s0 += SH) {
+                typename S::frag a[SH][NP];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < SH; ++s) {
                     const int w = wr * WM + 16 * (s0 + s) + r + 1 + dx;
                     const char *src = sa + ((g * BMW + (w ^ (2 * g))) << 4);
-                    ah[s] = *reinterpret_cast<const bf16x8 *>(src);
-                    am[s] = *reinterpret_cast<const bf16x8 *>(src + A_IMG);
-                    al[s] = *reinterpret_cast<const bf16x8 *>(src + 2 * A_IMG);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) a[s][q] = *reinterpret_cast<const typename S::frag *>(src + q * A_IMG);
                     const uint32_t b = dir_ok >> (4 * (s0 + s));
                     const bool ok = (dy < 0 ? (b & 1u) : dy > 0 ? (b & 2u) : 1u) && (dx < 0 ? (b & 4u) : dx > 0 ? (b & 8u) : 1u);
                     if (!__all(ok)) {
-                        ah[s] = ok ? ah[s] : zero;
-                        am[s] = ok ? am[s] : zero;
-                        al[s] = ok ? al[s] : zero;
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) a[s][q] = ok ? a[s][q] : zero;
                     }
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = wc * (BN / WC) + 16 * nt + r;
                     const char *src = sb + ((g * BN + n) << 4);
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
-                    const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + 4 * BN * 16);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(src + 8 * BN * 16);
+                    typename S::frag b[NP];
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {      // smallest terms first
-                        f32x4 c = acc[s0 + s][nt];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
-                        acc[s0 + s][nt] = c;
-                    }
+                    for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+#pragma unroll
+                    for (int s = 0; s < SH; ++s) acc[s0 + s][nt] = S::mma(a[s], b, acc[s0 + s][nt]);
                 }
-                asm volatile("" ::: "memory");     // keep the halves' LDS reads apart (register budget)
+                if (SH < MS) asm volatile("" ::: "memory");     // keep the groups' LDS reads apart (register budget)
             }
         }
         __syncthreads();                   // everyone is done reading the images before they are overwritten
@@ -745,24 +780,34 @@ window_conv_bf16_kernel(GcParams p) {
     epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g);
 }
 
-// Split-bf16 kernel for SPARSE layers: a workgroup owns 128 output rows x BN columns, wave w the
-// rows [32w, 32w+32) x all BN columns. Only the weights go through LDS (one (tap, 32-channel)
-// block of Pb per stage, shared by the four waves); a wave gathers ITS rows' 128-byte channel
+template <int BN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
+window_conv_bf16_kernel(GcParams p) {
+    window_conv_split_body<SplitBf16x3, BN, 2>(p);
+}
+template <int BN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
+window_conv_f16_kernel(GcParams p) {
+    window_conv_split_body<SplitF16x2, BN, BN >= 64 ? 4 : 2>(p);
+}
+
+// Split kernel for SPARSE layers: a workgroup owns 64*MS output rows x BN columns, wave w the
+// rows [16*MS*w, 16*MS*(w+1)) x all BN columns. Only the weights go through LDS (one (tap, 32-channel)
+// block of the split image per stage, shared by the four waves); a wave gathers ITS rows' 128-byte channel
 // blocks straight into registers (4 lanes per row, 32 B each) and splits them there -- no row is
-// fetched or split twice. Taps that none of the workgroup's eight 16-row sub-tiles has are not
+// fetched or split twice. Taps that none of the workgroup's 16-row sub-tiles has are not
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
-// (BN = 128 sits 6 registers above the 3-waves-per-SIMD budget without the hint; it fits without spilling)
 // MS = row sub-tiles per wave: 2 (128-row workgroups) or 1 (64-row workgroups, for layers too small to give every CU a
 // 128-row workgroup: twice the workgroups, each staging the same weights for half the rows).
-template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, BN == 128 && MS == 2 ? 3 : 8)))
-rowwave_conv_bf16_kernel(GcParams p) {
+template <class S, int BN, int MS>
+__device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
+    constexpr int NP = S::NP;
     constexpr int NT = BN / 16;
     constexpr int WG_ROWS = 64 * MS, WG_SUBS = 4 * MS;
-    constexpr int B_SLOTS = 3 * 4 * BN;        // 16-byte B pieces of one stage
+    constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
-    __shared__ __attribute__((aligned(16))) char sb[3 * B_IMG];
+    __shared__ __attribute__((aligned(16))) char sb[NP * B_IMG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -803,7 +848,7 @@ rowwave_conv_bf16_kernel(GcParams p) {
         rowc[s] = row_ok[s] ? row : p.n_out - 1;
     }
     const int sk = p.c_in >> 5;
-    const size_t b_stage = (size_t)3 * 4 * p.np * 16;
+    const size_t b_stage = (size_t)NP * 4 * p.np * 16;
 
     int t_first = 0;
     while (t_first < p.kv && !tap_on(t_first)) ++t_first;
@@ -842,7 +887,7 @@ rowwave_conv_bf16_kernel(GcParams p) {
                     rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
             }
         };
-        bf16x8 ah[MS], am[MS], al[MS];
+        typename S::frag a[MS][NP];
         auto stage_commit = [&](int t) {            // B -> LDS, A -> split fragments
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
@@ -850,12 +895,11 @@ rowwave_conv_bf16_kernel(GcParams p) {
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
-                    bf16x4 h0, m0, l0, h1, m1, l1;
-                    split3(zero_if(araw[s][0], az[s]), h0, m0, l0);
-                    split3(zero_if(araw[s][1], az[s]), h1, m1, l1);
-                    ah[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    am[s] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    al[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    typename S::half lo[NP], hi[NP];
+                    S::split(zero_if(araw[s][0], az[s]), lo);
+                    S::split(zero_if(araw[s][1], az[s]), hi);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
                 }
             }
         };
@@ -883,21 +927,12 @@ rowwave_conv_bf16_kernel(GcParams p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const char *src = sb + ((g * BN + 16 * nt + r) << 4);
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(src);
-                    const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(src + B_IMG);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(src + 2 * B_IMG);
+                    typename S::frag b[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
 #pragma unroll
                     for (int s = 0; s < MS; ++s) {
-                        if (s == 0 ? on0 : on1) {
-                            f32x4 c = acc[s][nt];
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
-                            acc[s][nt] = c;
-                        }
+                        if (s == 0 ? on0 : on1) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
                     }
                 }
             }
@@ -909,6 +944,18 @@ rowwave_conv_bf16_kernel(GcParams p) {
         }
     }
     epilogue<MS, NT>(p, acc, row0, col0, r, g);
+}
+
+// (bf16x3, BN = 128, MS = 2 sits 6 registers above the 3-waves-per-SIMD budget without the hint; it fits without spilling)
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, BN == 128 && MS == 2 ? 3 : 8)))
+rowwave_conv_bf16_kernel(GcParams p) {
+    rowwave_conv_split_body<SplitBf16x3, BN, MS>(p);
+}
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+rowwave_conv_f16_kernel(GcParams p) {
+    rowwave_conv_split_body<SplitF16x2, BN, MS>(p);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -940,6 +987,69 @@ __global__ void __launch_bounds__(256) pack_weight_bf16_kernel(const float *__re
     pb[(blk + 0) * 4 * np * 8 + off] = h;
     pb[(blk + 1) * 4 * np * 8 + off] = m;
     pb[(blk + 2) * 4 * np * 8 + off] = l;
+}
+
+
+// f16x2 image. Step 1: per output column n, the exponent e with max_t,ci |W[t][ci][n]| * 2^e in [2^13, 2^14) (so the
+// largest weight uses fp16's top binades, the low term of every weight down to 2^-11 of it stays a NORMAL fp16 number,
+// and nothing can overflow); dsc[n] = 2^-e is what the epilogue multiplies back (exact). One block per column.
+__global__ void __launch_bounds__(256) weight_col_scale_kernel(const float *__restrict__ w, int kv, int c_in, int c_out, int adjoint,
+                                                               float *__restrict__ dsc) {
+    // (c_in, c_out) are those of the conv the image is FOR; the source is [kv][c_in][c_out], or [kv][c_out][c_in] if adjoint
+    const int n = blockIdx.x;
+    float m = 0.f;
+    if (n < c_out) {
+        const int per = kv * c_in;
+        for (int i = threadIdx.x; i < per; i += 256) {
+            const int t = i / c_in, ch = i - t * c_in;
+            const float v = adjoint ? w[((size_t)t * c_out + n) * c_in + ch] : w[((size_t)t * c_in + ch) * c_out + n];
+            m = fmaxf(m, fabsf(v));                           // NaN weights: fmaxf drops them, the products still carry them
+        }
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        const float mx = red[0];
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);                            // mx = f * 2^ex, f in [0.5, 1)
+            e = 14 - ex;
+            e = e > 110 ? 110 : (e < -110 ? -110 : e);
+        }
+        dsc[n] = ldexpf(1.f, -e);
+    }
+}
+// Step 2: Ph[t][k32][piece][g][n][8], piece = h, l of W * 2^e[n].
+__global__ void __launch_bounds__(256) pack_weight_f16_kernel(const float *__restrict__ w, int kv, int c_in, int c_out, int np,
+                                                              int adjoint, int flip, const float *__restrict__ dsc,
+                                                              _Float16 *__restrict__ ph) {
+    const int k32 = c_in >> 5;
+    const size_t total = (size_t)kv * k32 * 4 * np * 8;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i & 7);
+    size_t rest = i >> 3;
+    const int n = (int)(rest % np); rest /= np;
+    const int g = (int)(rest & 3); rest >>= 2;
+    const int kk = (int)(rest % k32);
+    const int t = (int)(rest / k32);
+    const int ch = kk * 32 + g * 8 + q;
+    const int ts = flip ? kv - 1 - t : t;
+    float v = 0.f;
+    if (n < c_out) v = adjoint ? w[((size_t)ts * c_out + n) * c_in + ch] : w[((size_t)ts * c_in + ch) * c_out + n];
+    v = v / dsc[n];                                          // * 2^e, exact
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    const size_t blk = ((size_t)t * k32 + kk) * 2;          // (tap, k32) block: 2 pieces x 4 g x np x 8
+    const size_t off = ((size_t)g * np + n) * 8 + q;
+    ph[(blk + 0) * 4 * np * 8 + off] = h;
+    ph[(blk + 1) * 4 * np * 8 + off] = l;
 }
 
 
@@ -1050,9 +1160,17 @@ static void choose_wg_tile(int n_out, int c_in, int c_out, int *bm_out, int *bn_
 }
 
 struct GcPlan {
-    int use_wg;     // 1: tile_conv_kernel<a,b>, 0: gather_conv_kernel<a,b,vec>
+    int use_wg;     // 0: gather_conv_kernel<a,b,vec>, 1: tile_conv_kernel<a,b>, 2: split workgroup kernel, 3: split row-wave kernel
     int a, b, vec;  // (bm,bn) or (ms,nt)
+    int math;       // split kernels: 1 = bf16x3, 2 = f16x2
 };
+
+// which split arithmetic the flags (and, when tuning, CPD_GC_BF16X3 = 0 | 1 | 2) ask for: 0 none, 1 bf16x3, 2 f16x2
+static int split_math(int flags, bool tn) {
+    int m = (flags & CPD_GC_F16X2) ? 2 : ((flags & CPD_GC_BF16X3) ? 1 : 0);
+    if (const char *e = cpd_knob(tn, "CPD_GC_BF16X3")) m = atoi(e);
+    return m < 0 || m > 2 ? 0 : m;
+}
 
 static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, int flags) {
     GcPlan pl;
@@ -1060,9 +1178,9 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
     const int ntot = (c_out + 15) / 16;
     pl.vec = (c_in % 16 == 0) && (in_ld % 4 == 0) && (((uintptr_t)in & 15) == 0);
     pl.use_wg = 0;
-    // split-bf16 path (CPD_GC_BF16X3): 128 x 128 tiles, needs whole 32-channel stages and 128-column tiles
-    int allow_bf16 = (flags & 2) != 0;
-    if (const char *e = cpd_knob(tn, "CPD_GC_BF16X3")) allow_bf16 = atoi(e);
+    // split path (CPD_GC_BF16X3 / CPD_GC_F16X2): needs whole 32-channel stages
+    pl.math = split_math(flags, tn);
+    const int allow_bf16 = pl.math != 0;
     long long bf16_min_wgs = 600;       // > 2 workgroups per CU, else the narrower/shorter tile (measured: single-frame bench, train step)
     if (const char *e = cpd_knob(tn, "CPD_GC_BF16_MIN")) bf16_min_wgs = atoll(e);
     int dense_rowwave = 0;
@@ -1141,9 +1259,26 @@ static size_t packed_bf16_floats(int kv, int c_in, int c_out) {
     if (c_in % 32) return 0;
     return (size_t)kv * (c_in / 32) * 3 * 4 * (((c_out + 15) / 16) * 16) * 8 / 2;
 }
+// ... and so does the f16x2 image (4 bytes per weight) followed by its np per-column descale floats
+static size_t packed_f16_image_floats(int kv, int c_in, int c_out) {
+    if (c_in % 32) return 0;
+    return (size_t)kv * (c_in / 32) * 2 * 4 * (((c_out + 15) / 16) * 16) * 8 / 2;
+}
+static size_t packed_f16_floats(int kv, int c_in, int c_out) {
+    if (c_in % 32) return 0;
+    return packed_f16_image_floats(kv, c_in, c_out) + (size_t)(((c_out + 15) / 16) * 16);
+}
 extern "C" size_t cpd_packed_weight_floats(int kv, int c_in, int c_out) {
     if (kv <= 0 || c_in <= 0 || c_out <= 0) return 0;
-    return packed_f32_floats(kv, c_in, c_out) + packed_bf16_floats(kv, c_in, c_out);
+    return packed_f32_floats(kv, c_in, c_out) + packed_bf16_floats(kv, c_in, c_out) + packed_f16_floats(kv, c_in, c_out);
+}
+// where the images of one packed buffer start
+static const float *packed_bf16_ptr(const float *packed, int kv, int c_in, int c_out) { return packed + packed_f32_floats(kv, c_in, c_out); }
+static const float *packed_f16_ptr(const float *packed, int kv, int c_in, int c_out) {
+    return packed + packed_f32_floats(kv, c_in, c_out) + packed_bf16_floats(kv, c_in, c_out);
+}
+static const float *packed_dsc_ptr(const float *packed, int kv, int c_in, int c_out) {
+    return packed_f16_ptr(packed, kv, c_in, c_out) + packed_f16_image_floats(kv, c_in, c_out);
 }
 static void pack_bf16_image(const float *w, int kv, int c_in, int c_out, int adjoint, int flip, float *packed, hipStream_t s) {
     if (!packed_bf16_floats(kv, c_in, c_out)) return;
@@ -1151,6 +1286,10 @@ static void pack_bf16_image(const float *w, int kv, int c_in, int c_out, int adj
     const size_t total = (size_t)kv * (c_in / 32) * 4 * np * 8;
     pack_weight_bf16_kernel<<<cpd_div_up((long long)total, 256), 256, 0, s>>>(
         w, kv, c_in, c_out, np, adjoint, flip, reinterpret_cast<__bf16 *>(packed + packed_f32_floats(kv, c_in, c_out)));
+    float *dsc = const_cast<float *>(packed_dsc_ptr(packed, kv, c_in, c_out));
+    weight_col_scale_kernel<<<np, 256, 0, s>>>(w, kv, c_in, c_out, adjoint, dsc);
+    pack_weight_f16_kernel<<<cpd_div_up((long long)total, 256), 256, 0, s>>>(
+        w, kv, c_in, c_out, np, adjoint, flip, dsc, reinterpret_cast<_Float16 *>(const_cast<float *>(packed_f16_ptr(packed, kv, c_in, c_out))));
 }
 
 extern "C" int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *packed, cpd_stream_t stream) {
@@ -1177,7 +1316,8 @@ extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, i
                                     int *vec) {
     if (n_out <= 0 || c_in <= 0 || c_out <= 0 || !wg || !a || !b || !vec) return CPD_ERR_ARG;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, nullptr, flags);
-    *wg = pl.use_wg; *a = pl.a; *b = pl.b; *vec = pl.vec;
+    *wg = pl.use_wg + ((pl.use_wg >= 2 && pl.math == 2) ? 10 : 0);      // 12 / 13: the f16x2 instantiations of 2 / 3
+    *a = pl.a; *b = pl.b; *vec = pl.vec;
     return CPD_OK;
 }
 
@@ -1192,7 +1332,7 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
     GcParams p;
-    p.in = in; p.w = packed_w; p.wb = nullptr; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
@@ -1202,32 +1342,52 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     if (trace)
         fprintf(stderr, "cpd_gather_conv n_out=%d kv=%d c_in=%d c_out=%d flags=%d masks=%d -> kind=%d tile=(%d,%d)\n", n_out, kv, c_in, c_out,
                 flags, tapmask != nullptr, pl.use_wg, pl.a, pl.b);
-    if (pl.use_wg == 3) {
-        p.wb = packed_w + packed_f32_floats(kv, c_in, c_out);
+    if (pl.use_wg == 2 || pl.use_wg == 3) {
+        if (pl.math == 2) { p.wb = packed_f16_ptr(packed_w, kv, c_in, c_out); p.dsc = packed_dsc_ptr(packed_w, kv, c_in, c_out); }
+        else p.wb = packed_bf16_ptr(packed_w, kv, c_in, c_out);
         p.n_rb = (n_out + pl.a - 1) / pl.a;
         p.n_cb = c_out / pl.b;
         p.items = p.n_rb * p.n_cb;
+    }
+    const dim3 grid(p.items), block(256);
+    hipStream_t hs = cpd_s(stream);
+#define CPD_LAUNCH(K, LDS) hipLaunchKernelGGL((K), grid, block, (LDS), hs, p)
+    if (pl.use_wg == 3 && pl.math == 2) {
         if (pl.a == 64) {
-            if (pl.b == 32) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<32, 1>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
-            else if (pl.b == 64) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<64, 1>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
-            else hipLaunchKernelGGL((rowwave_conv_bf16_kernel<128, 1>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
-        } else if (pl.b == 32) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<32>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
-        else if (pl.b == 64) hipLaunchKernelGGL((rowwave_conv_bf16_kernel<64>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
-        else hipLaunchKernelGGL((rowwave_conv_bf16_kernel<128>), dim3(p.items), dim3(256), 0, cpd_s(stream), p);
+            if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 1>), 0);
+            else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 1>), 0);
+            else CPD_LAUNCH((rowwave_conv_f16_kernel<128, 1>), 0);
+        } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 2>), 0);
+        else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 2>), 0);
+        else CPD_LAUNCH((rowwave_conv_f16_kernel<128, 2>), 0);
+        return cpd_check_launch();
+    }
+    if (pl.use_wg == 3) {
+        if (pl.a == 64) {
+            if (pl.b == 32) CPD_LAUNCH((rowwave_conv_bf16_kernel<32, 1>), 0);
+            else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_bf16_kernel<64, 1>), 0);
+            else CPD_LAUNCH((rowwave_conv_bf16_kernel<128, 1>), 0);
+        } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_bf16_kernel<32, 2>), 0);
+        else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_bf16_kernel<64, 2>), 0);
+        else CPD_LAUNCH((rowwave_conv_bf16_kernel<128, 2>), 0);
+        return cpd_check_launch();
+    }
+    if (pl.use_wg == 2 && pl.math == 2) {
+        const size_t lds = 2 * (size_t)(pl.a + pl.b) * 64;
+        if (pl.a == 64 && pl.b == 128) CPD_LAUNCH((tile_conv_f16_kernel<64, 128>), lds);
+        else if (pl.a == 64) CPD_LAUNCH((tile_conv_f16_kernel<64, 64>), lds);
+        else if (pl.b == 64) CPD_LAUNCH((tile_conv_f16_kernel<128, 64>), lds);
+        else CPD_LAUNCH((tile_conv_f16_kernel<128, 128>), lds);
         return cpd_check_launch();
     }
     if (pl.use_wg == 2) {
-        p.wb = packed_w + packed_f32_floats(kv, c_in, c_out);
-        p.n_rb = (n_out + pl.a - 1) / pl.a;
-        p.n_cb = c_out / pl.b;
-        p.items = p.n_rb * p.n_cb;
         int db = 0;
         if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_BF16_DB")) db = atoi(e);
         if (pl.b == 64) db = 0;
         if (pl.a == 64) {                                   // small-problem variant: 64-row tiles double the workgroup count
             const size_t lds64 = 3 * (size_t)(64 + pl.b) * 64;
-            if (pl.b == 128) hipLaunchKernelGGL((tile_conv_bf16_kernel<64, 128, false>), dim3(p.items), dim3(256), lds64, cpd_s(stream), p);
-            else hipLaunchKernelGGL((tile_conv_bf16_kernel<64, 64, false>), dim3(p.items), dim3(256), lds64, cpd_s(stream), p);
+            if (pl.b == 128) CPD_LAUNCH((tile_conv_bf16_kernel<64, 128, false>), lds64);
+            else CPD_LAUNCH((tile_conv_bf16_kernel<64, 64, false>), lds64);
             return cpd_check_launch();
         }
         const size_t lds = (db ? 2 : 1) * 3 * (size_t)(pl.a + pl.b) * 64;
@@ -1237,11 +1397,12 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (128 + 128) * 64);
             attr_set = true;
         }
-        if (pl.b == 64) hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 64, false>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
-        else if (db) hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 128, true>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
-        else hipLaunchKernelGGL((tile_conv_bf16_kernel<128, 128, false>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        if (pl.b == 64) CPD_LAUNCH((tile_conv_bf16_kernel<128, 64, false>), lds);
+        else if (db) CPD_LAUNCH((tile_conv_bf16_kernel<128, 128, true>), lds);
+        else CPD_LAUNCH((tile_conv_bf16_kernel<128, 128, false>), lds);
         return cpd_check_launch();
     }
+#undef CPD_LAUNCH
     if (pl.use_wg) {
         gc_kernel_t k = pick_tile(pl.a, pl.b);
         if (!k) return CPD_ERR_UNSUPPORTED;
@@ -1265,8 +1426,7 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
 // ---- dense 3x3 / stride 1 / pad 1 over pixel rows, no rulebook (window_conv_bf16_kernel) ----
 static int window_bn(int frames, int h, int w, int c_in, int c_out, int flags) {
     const bool tn = cpd_tuning();
-    int on = (flags & 2) != 0;
-    if (const char *e = cpd_knob(tn, "CPD_GC_BF16X3")) on = atoi(e);
+    int on = split_math(flags, tn) != 0;
     if (const char *e = cpd_knob(tn, "CPD_GC_WINDOW")) on = on && atoi(e);
     if (!on || frames <= 0 || h < 2 || w < 2 || c_in <= 0 || c_out <= 0 || c_in % 32 || (c_out % 64 && c_out > 16)) return 0;
     const long long rows = (long long)frames * h * w;
@@ -1293,7 +1453,10 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     GcParams p;
     memset(&p, 0, sizeof(p));
     const int n_out = frames * h * w;
-    p.in = in; p.w = packed_w; p.wb = packed_w + packed_f32_floats(9, c_in, c_out);
+    const int math = split_math(flags, cpd_tuning());
+    p.in = in; p.w = packed_w;
+    if (math == 2) { p.wb = packed_f16_ptr(packed_w, 9, c_in, c_out); p.dsc = packed_dsc_ptr(packed_w, 9, c_in, c_out); }
+    else p.wb = packed_bf16_ptr(packed_w, 9, c_in, c_out);
     p.scale = scale; p.shift = shift; p.residual = residual; p.out = out;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
     p.kv = 9; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
@@ -1301,7 +1464,13 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     p.n_sub = (n_out + 15) / 16;
     p.n_rb = (n_out + 127) / 128; p.n_cb = (c_out + bn - 1) / bn; p.items = p.n_rb * p.n_cb;
     p.img_h = h; p.img_w = w;
-    const size_t lds = 3 * (size_t)(128 + 8) * 64 + 3 * (size_t)bn * 64;
+    const size_t lds = (math == 2 ? 2 : 3) * ((size_t)(128 + 8) * 64 + (size_t)bn * 64);
+    if (math == 2) {
+        if (bn == 128) hipLaunchKernelGGL((window_conv_f16_kernel<128>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        else if (bn == 64) hipLaunchKernelGGL((window_conv_f16_kernel<64>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        else hipLaunchKernelGGL((window_conv_f16_kernel<16>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        return cpd_check_launch();
+    }
     if (bn == 128) hipLaunchKernelGGL((window_conv_bf16_kernel<128>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
     else if (bn == 64) hipLaunchKernelGGL((window_conv_bf16_kernel<64>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
     else hipLaunchKernelGGL((window_conv_bf16_kernel<16>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);

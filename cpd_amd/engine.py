@@ -43,10 +43,11 @@ class ModelConfig:
     nms_thresh: float = 0.8
     nms_pre_maxsize: int = 4096
     nms_post_maxsize: int = 500
-    # arithmetic of the convolutions with >= 32 input channels: "bf16x3" = fp32 operands split exactly into three bf16 terms,
-    # six partial products accumulated in fp32 on the bf16 matrix pipe (fp32-level error, include/cpd_hip.h
-    # CPD_GC_BF16X3); "f32" = fp32-input MFMA everywhere (bitwise an fmaf chain)
-    conv_math: str = "bf16x3"
+    # arithmetic of the convolutions with >= 32 input channels (include/cpd_hip.h): "f16x2" = fp32 operands written as two fp16
+    # terms, three partial products accumulated in fp32 on the 16-bit matrix pipe (fp32-level error; activations must stay
+    # below 65504 in magnitude -- an overflow shows as inf / NaN, CPD_GC_F16X2); "bf16x3" = three bf16 terms, six partial
+    # products (exact split over the whole fp32 range, CPD_GC_BF16X3); "f32" = fp32-input MFMA everywhere (bitwise an fmaf chain)
+    conv_math: str = "f16x2"
 
     @property
     def grid_zyx(self):
@@ -291,7 +292,7 @@ class CenterPointEngine:
     def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False):
         return ops.gather_conv(x, layer.c_in, layer.w, nbr, layer.kv, n_out, layer.c_out, layer.scale, layer.shift,
                                residual, layer.relu, out=out, out_row_map=out_row_map, out_col_group=out_col_group,
-                               dense=dense, bf16x3=self.cfg.conv_math == "bf16x3")
+                               dense=dense, math=self.cfg.conv_math)
 
     def _blocks(self, blocks, x, nbr):
         n = x.shape[0]

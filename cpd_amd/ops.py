@@ -381,15 +381,15 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=N
     flags = _gc_flags(dense, bf16x3, math)
     if image is not None and n_out == image[0] * image[1] * image[2] and in_ld % 4 == 0 and lib().cpd_conv3x3_rows_supported(
             image[0], image[1], image[2], int(c_in), int(c_out), flags):
-        return "window_conv_bf16_kernel<%d>" % (16 if c_out <= 16 else (128 if c_out % 128 == 0 else 64))
+        return "window_conv_%s_kernel<%d>" % ("f16" if flags & 4 else "bf16", 16 if c_out <= 16 else (128 if c_out % 128 == 0 else 64))
     wg, a, b, vec = (ctypes.c_int(0) for _ in range(4))
     check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), flags,
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
           "cpd_gather_conv_tile")
-    if wg.value == 3:
-        return "rowwave_conv_bf16_kernel<%d,%d>" % (b.value, a.value // 64)        # <column tile, row sub-tiles per wave>
-    if wg.value == 2:
-        return "tile_conv_bf16_kernel<%d,%d>" % (a.value, b.value)
+    if wg.value in (3, 13):
+        return "rowwave_conv_%s_kernel<%d,%d>" % ("f16" if wg.value == 13 else "bf16", b.value, a.value // 64)   # <column tile, row sub-tiles per wave>
+    if wg.value in (2, 12):
+        return "tile_conv_%s_kernel<%d,%d>" % ("f16" if wg.value == 12 else "bf16", a.value, b.value)
     if wg.value:
         return "tile_conv_kernel<%d,%d>" % (a.value, b.value)
     return "gather_conv_kernel<%d,%d,%s>" % (a.value, b.value, "true" if vec.value else "false")

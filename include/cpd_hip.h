@@ -146,8 +146,14 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
 /* allow the split-bf16 matrix path: fp32 operands split exactly into 3 bf16 terms, 6 partial
  * products accumulated in fp32 (error <= 2^-22 relative per product, i.e. fp32-level); used for
  * dense layers with c_in % 32 == 0 and c_out % 64 == 0 */
-#define CPD_GC_BF16X3 2 /* flags: the rulebook has (almost) no -1 entries -- prefer the LDS-tiled
-                          workgroup kernel over the tap-skipping wave kernel */
+#define CPD_GC_BF16X3 2 /* (CPD_GC_DENSE: the rulebook has (almost) no -1 entries -- prefer the LDS-tiled
+                          workgroup kernel over the tap-skipping wave kernel) */
+/* allow the split-fp16 matrix path instead: fp32 operands written as h + l, two fp16 terms (2 x 11 bits + sign: x to
+ * 2^-24 relative, or 2^-25 absolute below 0.5), 3 partial products (hh, hl, lh) accumulated in fp32 -- fp32-level error at
+ * half the matrix work of CPD_GC_BF16X3. fp16's range is the contract: |activation| < 65504 (an overflow gives inf / NaN
+ * in the output, never a silently wrong number); weights of any magnitude (pre-scaled per output column by a power of two
+ * at pack time, undone exactly in the epilogue). Takes precedence over CPD_GC_BF16X3 when both are set. */
+#define CPD_GC_F16X2 4
 
 /* 3x3 / stride 1 / pad 1 convolution (+ folded BN / bias, residual, ReLU: same epilogue as
  * cpd_gather_conv) over channels-last pixel rows in[frames*h*w][c_in] WITHOUT a rulebook -- the

@@ -19,7 +19,7 @@ def rows_nchw(rows, b, h, w):
     return rows.cpu().numpy().reshape(b, h, w, -1).transpose(0, 3, 1, 2)
 
 
-MATHS = ["f32", "bf16x3"]          # ModelConfig.conv_math values; the bench runs the second
+MATHS = ["f32", "bf16x3", "f16x2"]          # ModelConfig.conv_math values
 
 
 @pytest.fixture
@@ -85,7 +85,7 @@ def test_bench_kernels_match_oracle_at_full_size(oracle, hip, math, cin, cout, k
     scale = rng.uniform(0.5, 1.5, cout).astype(np.float32); shift = rng.normal(size=cout).astype(np.float32)
     ran = []
     got, ho, wo = conv2d_hip(nhwc_rows(x), batch, h, w, wt, None, stride, scale, shift, True, math=math, kernels=ran)
-    assert ran == [kernel], ran
+    assert ran == [kernel.replace("bf16", "f16") if math == "f16x2" else kernel], ran
     want = np.maximum(oracle.conv2d(x, wt, None, stride, 1) * scale[None, :, None, None] + shift[None, :, None, None], 0)
     np.testing.assert_allclose(rows_nchw(got, batch, ho, wo), want, atol=1e-4, rtol=0)
 
@@ -100,7 +100,7 @@ def test_bench_deconv_kernels_match_oracle_at_full_size(oracle, hip, math, cin, 
     want = oracle.deconv2d(x, wd, u)
     packed = ops.pack_weight(torch.from_numpy(wd).permute(0, 2, 3, 1).reshape(1, cin, u * u * cout).contiguous().cuda())
     n = batch * h * w
-    assert ops.gather_conv_tile(n, cin, u * u * cout, cin, dense=True, math=math) == "tile_conv_bf16_kernel<128,128>"
+    assert ops.gather_conv_tile(n, cin, u * u * cout, cin, dense=True, math=math) == "tile_conv_%s_kernel<128,128>" % ("f16" if math == "f16x2" else "bf16")
     H, W = h * u, w * u
     out = torch.empty((batch * H * W, cout), device="cuda")
     if u == 1:
@@ -242,8 +242,9 @@ def test_workgroup_kernel_matches_wave_kernel_and_oracle(oracle, hip, bm, bn, mo
     np.testing.assert_allclose(rows_nchw(out, b, H, W), want, atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("cin,cout,k,stride", [(128, 128, 3, 1), (256, 256, 3, 1), (128, 256, 3, 2), (256, 1024, 1, 1)])
-def test_split_bf16_conv_is_fp32_accurate(hip, cin, cout, k, stride):
+def test_split_bf16_conv_is_fp32_accurate(hip, math, cin, cout, k, stride):
     """CPD_GC_BF16X3: fp32 operands split exactly into three bf16 terms, six partial products on the
     bf16 matrix pipe. Against a float64 reference it must be as accurate as the fp32-MFMA kernel
     (<= 1e-4 absolute at O(20) outputs, and within 1.5x of the fp32 kernel's own error)."""
@@ -258,8 +259,8 @@ def test_split_bf16_conv_is_fp32_accurate(hip, cin, cout, k, stride):
     x = torch.randn(n_in, cin, device="cuda") * 3.0
     w = torch.randn(kv, cin, cout, device="cuda") * (2.0 / (kv * cin)) ** 0.5
     pw = ops.pack_weight(w)
-    assert ops.gather_conv_tile(n_out, cin, cout, cin, dense=True, bf16x3=True).startswith("tile_conv_bf16_kernel")
-    fast = ops.gather_conv(x, cin, pw, nbr, kv, n_out, cout, dense=True, bf16x3=True)
+    assert ops.gather_conv_tile(n_out, cin, cout, cin, dense=True, math=math).startswith(("tile_conv_bf16_kernel", "tile_conv_f16_kernel"))
+    fast = ops.gather_conv(x, cin, pw, nbr, kv, n_out, cout, dense=True, math=math)
     exact = ops.gather_conv(x, cin, pw, nbr, kv, n_out, cout, dense=True, bf16x3=False)
     rows = torch.randint(0, n_out, (2048,), device="cuda")
     if nbr is None:
@@ -272,10 +273,26 @@ def test_split_bf16_conv_is_fp32_accurate(hip, cin, cout, k, stride):
     e_exact = (exact[rows].double() - ref).abs().max().item()
     assert e_fast <= 1e-4, (e_fast, e_exact)
     assert e_fast <= 1.5 * e_exact + 1e-6, (e_fast, e_exact)
-    # scale invariance: the split is exact at any magnitude (no bf16-level truncation of small values)
-    small = ops.gather_conv(x * 1e-4, cin, pw, nbr, kv, n_out, cout, dense=True, bf16x3=True)
+    # scale invariance of the weights: bf16x3 splits exactly at any magnitude; f16x2 pre-scales every output column by a power
+    # of two, so tiny / huge weights cost nothing either
+    for wscale in (1e-6, 1e+5):
+        pws = ops.pack_weight(w * wscale)
+        got = ops.gather_conv(x, cin, pws, nbr, kv, n_out, cout, dense=True, math=math)
+        e_w = (got[rows].double() - ref * wscale).abs().max().item()
+        assert e_w <= 1.5 * wscale * max(e_fast, e_exact) + 1e-30, (wscale, e_w, e_fast)
+    # scale of the activations: exact at any magnitude for bf16x3; f16x2 has an ABSOLUTE floor of 2^-25 per activation
+    # (fp16 subnormals), i.e. tiny activations lose relative -- never absolute -- accuracy
+    small = ops.gather_conv(x * 1e-4, cin, pw, nbr, kv, n_out, cout, dense=True, math=math)
     e_small = (small[rows].double() - ref * 1e-4).abs().max().item()
-    assert e_small <= 1.5e-4 * max(e_fast, e_exact) + 1e-12, (e_small, e_fast)
+    if math == "bf16x3":
+        assert e_small <= 1.5e-4 * max(e_fast, e_exact) + 1e-12, (e_small, e_fast)
+    else:
+        assert e_small <= 2e-7, (e_small, e_fast)
+        # the range contract: an activation beyond fp16's range is LOUD (inf / NaN in the rows it feeds), not silently wrong
+        xb = x.clone()
+        xb[rows[0]] = 7e4
+        bad = ops.gather_conv(xb, cin, pw, nbr, kv, n_out, cout, dense=True, math=math)
+        assert not torch.isfinite(bad).all()
 
 
 @pytest.mark.parametrize("cin,cout,batch,h,w", [(128, 128, 3, 188, 188), (256, 256, 5, 94, 94), (64, 320, 2, 188, 188),

@@ -65,7 +65,7 @@ def test_engine_matches_reference_graph(oracle, hip):
         np.testing.assert_allclose(got["pred_boxes"].cpu().numpy(), want["pred_boxes"], atol=1e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("math", ["bf16x3"])
+@pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
 def test_full_size_config2_matches_oracle(oracle, hip, math):
     """BASELINE config 2 at FULL size, features included: one 160k-point W-cloud through the oracle's
     un-fused reference graph (seconds on the GPU box's host cores) against the engine on a batch of four frames -- three

@@ -202,8 +202,9 @@ def test_tapmask_skipping_is_exact(oracle, hip, cin, cout, n):
 
 @pytest.mark.parametrize("cin,cout,n,want", [(128, 128, 80000, "<128,2>"), (128, 128, 24000, "<128,1>"), (64, 64, 30000, "<64,1>"),
                                              (32, 32, 30000, "<32,1>"), (32, 32, 80000, "<32,2>"), (64, 128, 12000, "<64,1>")])
-def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, cin, cout, n, want):
-    """The sparse split-bf16 kernel in each of its shapes -- 128-row workgroups, the 64-row ones small layers get, and the
+@pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
+def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, math, cin, cout, n, want):
+    """The sparse split kernel (both split arithmetics) in each of its shapes -- 128-row workgroups, the 64-row ones small layers get, and the
     narrower column tiles below that -- against the oracle, on clustered sites (tap skipping active) with BN/residual/ReLU."""
     rng = np.random.default_rng(n + cin)
     batch, shape = 2, [11, 96, 96]
@@ -216,11 +217,11 @@ def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, cin, cout, n, wan
     res = rng.normal(size=(rows, cout)).astype(np.float32)
     d_idx = dev(idx)
     nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
-    name = ops.gather_conv_tile(rows, cin, cout, cin, dense=False, bf16x3=True)
-    assert name == "rowwave_conv_bf16_kernel" + want, (name, rows)
+    name = ops.gather_conv_tile(rows, cin, cout, cin, dense=False, math=math)
+    assert name == "rowwave_conv_%s_kernel" % ("f16" if math == "f16x2" else "bf16") + want, (name, rows)
     w_kio = torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda()
     got = ops.gather_conv(dev(feat), cin, ops.pack_weight(w_kio), nbr, 27, rows, cout, dev(scale), dev(shift), dev(res), True,
-                          bf16x3=True).cpu().numpy()
+                          math=math).cpu().numpy()
     ref = oracle.sparse_conv(feat, w, None, nbr.cpu().numpy())
     ref = np.maximum(ref * scale + shift + res, 0)
     np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
