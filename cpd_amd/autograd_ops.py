@@ -68,6 +68,9 @@ class GatherConv(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = dw = db = None
         split = spec.math != "f32"
+        # gradients live far below fp16's normal range: whatever the forward arithmetic, backward uses split-bf16 (exact split
+        # at any magnitude) or fp32
+        gmath = "bf16x3" if split else "f32"
         if need_b:
             db = train_ops.col_sum(dy)
         if spec.mode == "up":
@@ -75,7 +78,7 @@ class GatherConv(torch.autograd.Function):
             c_bn = c_out // u2
             if need_x:      # 4-tap gather over the scatter map, weights [tap, co, ci]
                 pw_adj = ops.pack_weight(w.view(c_in, u2, c_bn).permute(1, 2, 0).contiguous())
-                dx = ops.gather_conv(dy, c_bn, pw_adj, spec.up_map, u2, spec.n_out, c_in, dense=spec.dense, math=spec.math)
+                dx = ops.gather_conv(dy, c_bn, pw_adj, spec.up_map, u2, spec.n_out, c_in, dense=spec.dense, math=gmath)
             if need_w:      # dW[tap][co][ci] = sum_pix dy[map[tap][pix]][co] * x[pix][ci]: the roles of input and dy swap
                 tmp = train_ops.conv_wgrad(dy, c_bn, inp, c_in, spec.up_map, u2, spec.n_out, bf16x3=split)
                 dw = tmp.permute(2, 0, 1).reshape(1, c_in, c_out).contiguous()
@@ -83,7 +86,7 @@ class GatherConv(torch.autograd.Function):
         if need_x:
             pw_adj = train_ops.pack_weight_adjoint(w, flip_taps=(spec.mode == "same"))
             nbr_adj = spec.nbr if spec.mode == "same" else spec.adjoint()
-            dx = ops.gather_conv(dy, c_out, pw_adj, nbr_adj, kv, n_in, c_in, dense=spec.dense, math=spec.math)
+            dx = ops.gather_conv(dy, c_out, pw_adj, nbr_adj, kv, n_in, c_in, dense=spec.dense, math=gmath)
         if need_w:
             nbr_w = spec.nbr
             if nbr_w is None:                                    # 1x1: identity rulebook

@@ -58,6 +58,7 @@ struct GcParams {
     int res_ld, relu, out_ld, col_group;
     int n_rb, n_cb, items, n_sub;
     int img_h, img_w;         // window kernel only: the rows are frames x img_h x img_w pixels
+    int taps_inner;           // row-wave kernel: stage order (32-channel block outer, tap inner)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -749,11 +750,13 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
                     const char *src = sa + ((g * BMW + (w ^ (2 * g))) << 4);
 #pragma unroll
                     for (int q = 0; q < NP; ++q) a[s][q] = *reinterpret_cast<const typename S::frag *>(src + q * A_IMG);
-                    const uint32_t b = dir_ok >> (4 * (s0 + s));
-                    const bool ok = (dy < 0 ? (b & 1u) : dy > 0 ? (b & 2u) : 1u) && (dx < 0 ? (b & 4u) : dx > 0 ? (b & 8u) : 1u);
-                    if (!__all(ok)) {
+                    if (!(CPD_GC_ABLATE & 16)) {
+                        const uint32_t b = dir_ok >> (4 * (s0 + s));
+                        const bool ok = (dy < 0 ? (b & 1u) : dy > 0 ? (b & 2u) : 1u) && (dx < 0 ? (b & 4u) : dx > 0 ? (b & 8u) : 1u);
+                        if (!__all(ok)) {
 #pragma unroll
-                        for (int q = 0; q < NP; ++q) a[s][q] = ok ? a[s][q] : zero;
+                            for (int q = 0; q < NP; ++q) a[s][q] = ok ? a[s][q] : zero;
+                        }
                     }
                 }
 #pragma unroll
@@ -860,20 +863,34 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
         };
         auto sub_on = [&](int s, int t) { return t >= 32 || ((my_mask[s] >> t) & 1u); };
 
-        int idx_cur[MS], idx_nxt[MS];
-        load_idx(t_first, idx_cur);
-        int t_after = next_tap(t_first);          // tap whose rulebook column sits in idx_nxt
-        if (t_after < p.kv) load_idx(t_after, idx_nxt);
+        // Stage order: (tap outer, 32-channel block inner), or -- p.taps_inner -- (block outer, tap inner): the taps of one
+        // channel block re-gather neighbouring rows' same 128-byte segments back to back, which hits L2 when the row order
+        // keeps neighbours close. Either way the stages form one flat sequence; the rulebook column of a stage is fetched
+        // two stages ahead of its use (one stage ahead of the gathers it addresses).
+        const bool inner = p.taps_inner != 0;
+        auto advance = [&](int &t, int &kk) -> bool {          // (t, kk) -> the stage after it; false at the end
+            if (!inner) {
+                if (++kk < sk) return true;
+                kk = 0;
+                t = next_tap(t);
+                return t < p.kv;
+            }
+            const int tn = next_tap(t);
+            if (tn < p.kv) { t = tn; return true; }
+            t = t_first;
+            return ++kk < sk;
+        };
 
         f32x4 araw[MS][2];
         bool az[MS];
         f32x4u rbv[BJ];
-        auto stage_load = [&](int t, int kk) {
+        auto stage_load = [&](int t, int kk, const int (&idx)[MS]) {
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
-                    const int id = row_ok[s] ? idx_cur[s] : -1;
+                    const int id = row_ok[s] ? idx[s] : -1;
                     az[s] = id < 0;
+                    if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; continue; }
                     araw[s][0] = load_a<true>(p, id, kk * 32 + g * 8);
                     araw[s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
                 }
@@ -883,8 +900,10 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
             for (int j = 0; j < BJ; ++j) {
                 const int id = j * 256 + tid;
                 const int pg = id / BN, n = id - pg * BN;
-                if (B_SLOTS % 256 == 0 || id < B_SLOTS)
-                    rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+                if (B_SLOTS % 256 == 0 || id < B_SLOTS) {
+                    if (CPD_GC_ABLATE & 1) rbv[j] = f32x4u{(float)t, 1.f, (float)kk, (float)n};
+                    else rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+                }
             }
         };
         typename S::frag a[MS][NP];
@@ -905,25 +924,25 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
         };
 
         int t = t_first, kk = 0;
-        stage_load(t, kk);
+        int idx_n[MS], idx_nn[MS];                 // rulebook columns of the next stage's tap / of the one after it
+        load_idx(t, idx_n);
+        stage_load(t, kk, idx_n);
+        int tn = t, kn = kk;
+        bool more = advance(tn, kn);               // (tn, kn) = next stage
+        if (more) load_idx(tn, idx_n);
+        int tnn = tn, knn = kn;
+        bool more2 = more && advance(tnn, knn);    // (tnn, knn) = the stage after next
         stage_commit(t);
         __syncthreads();
         while (true) {
-            // the stage after (t, kk)
-            int tn = t, kn = kk + 1;
-            if (kn == sk) { kn = 0; tn = t_after; }
-            const bool more = tn < p.kv;
             if (more) {
-                if (kn == 0) {                      // entering tap tn: its column was prefetched a tap ago
-#pragma unroll
-                    for (int s = 0; s < MS; ++s) idx_cur[s] = idx_nxt[s];
-                    t_after = next_tap(tn);
-                    if (t_after < p.kv) load_idx(t_after, idx_nxt);
-                }
-                stage_load(tn, kn);
+                if (more2) load_idx(tnn, idx_nn);
+                stage_load(tn, kn, idx_n);
             }
-            const bool on0 = sub_on(0, t), on1 = MS > 1 && sub_on(MS - 1, t);
-            if (on0 || on1) {
+            bool on[MS], any_on = false;
+#pragma unroll
+            for (int s = 0; s < MS; ++s) { on[s] = sub_on(s, t); any_on |= on[s]; }
+            if (any_on) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const char *src = sb + ((g * BN + 16 * nt + r) << 4);
@@ -932,15 +951,21 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
                     for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
 #pragma unroll
                     for (int s = 0; s < MS; ++s) {
-                        if (s == 0 ? on0 : on1) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
+                        if (CPD_GC_ABLATE & 4) {               // no MFMAs: keep the operands live
+                            if (on[s]) asm volatile("" :: "v"(a[s][0]), "v"(a[s][1]), "v"(b[0]), "v"(b[1]));
+                        } else if (on[s]) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
                     }
                 }
             }
             if (!more) break;
-            __syncthreads();                        // every wave is done with this stage's weights
+            if (!(CPD_GC_ABLATE & 8)) __syncthreads();                        // every wave is done with this stage's weights
             stage_commit(tn);
-            __syncthreads();
+            if (!(CPD_GC_ABLATE & 8)) __syncthreads();
             t = tn; kk = kn;
+            tn = tnn; kn = knn; more = more2;
+#pragma unroll
+            for (int s = 0; s < MS; ++s) idx_n[s] = idx_nn[s];
+            if (more2) more2 = advance(tnn, knn);
         }
     }
     epilogue<MS, NT>(p, acc, row0, col0, r, g);
@@ -953,7 +978,7 @@ rowwave_conv_bf16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitBf16x3, BN, MS>(p);
 }
 template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS == 4 ? 2 : (BN == 128 && MS == 2 ? 3 : 4), 8)))
 rowwave_conv_f16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitF16x2, BN, MS>(p);
 }
@@ -1197,6 +1222,12 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
         if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_MIN")) rw_min = atoll(e);
         if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_FLOOR")) rw_floor = atoll(e);
         const long long row_tiles = (n_out + 127) / 128;
+        int ms4 = 0;                                          // 256-row workgroups (4 row sub-tiles per wave), f16x2 only
+        if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_MS4")) ms4 = atoi(e);
+        if (ms4 && pl.math == 2 && bn >= 64 && (row_tiles / 2) * (c_out / bn) >= rw_min) {
+            pl.use_wg = 3; pl.a = 256; pl.b = bn;
+            return pl;
+        }
         if (row_tiles * (c_out / bn) >= rw_min) {
             pl.use_wg = 3; pl.a = 128; pl.b = bn;
             return pl;
@@ -1338,6 +1369,8 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
+    p.taps_inner = 1;       // measured (tools/order_probe.py): -6...-8 % on the 32- and 128-channel SubM layers, neutral at 64
+    if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_TAPS_INNER")) p.taps_inner = atoi(e);
     static const bool trace = getenv("CPD_GC_TRACE") != nullptr;    // one line per launch: which kernel a layer got
     if (trace)
         fprintf(stderr, "cpd_gather_conv n_out=%d kv=%d c_in=%d c_out=%d flags=%d masks=%d -> kind=%d tile=(%d,%d)\n", n_out, kv, c_in, c_out,
@@ -1353,7 +1386,10 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     hipStream_t hs = cpd_s(stream);
 #define CPD_LAUNCH(K, LDS) hipLaunchKernelGGL((K), grid, block, (LDS), hs, p)
     if (pl.use_wg == 3 && pl.math == 2) {
-        if (pl.a == 64) {
+        if (pl.a == 256) {
+            if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 4>), 0);
+            else CPD_LAUNCH((rowwave_conv_f16_kernel<128, 4>), 0);
+        } else if (pl.a == 64) {
             if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 1>), 0);
             else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 1>), 0);
             else CPD_LAUNCH((rowwave_conv_f16_kernel<128, 1>), 0);

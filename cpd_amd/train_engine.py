@@ -33,7 +33,12 @@ class _Flat:
         self._pending = []
         self.slots = {}
         self.flat = self.grad = self.m = self.v = None
-        self.bf16x3 = True      # conv arithmetic of layers with >= 32 input channels (ModelConfig.conv_math)
+        self.math = "f16x2"     # forward conv arithmetic of layers with >= 32 input channels (ModelConfig.conv_math)
+        # gradients span many orders of magnitude (1e-3 ... 1e-8), below fp16's normal range, so everything that consumes dz --
+        # the input gradient (cpd_gather_conv on the adjoint weights) and the weight gradient -- runs split-bf16, whose split
+        # is exact at any magnitude, whenever a split arithmetic is selected
+        self.dgrad_math = "bf16x3"
+        self.bf16x3 = True
         self.update_stats = True    # whether the current forward updates the BatchNorm running statistics
         self.side = None        # HIP stream for the weight gradients (independent of the input gradients of the same layer)
 
@@ -147,16 +152,16 @@ class _Conv:
         bias = st.p(self.bn_) if self.bn_ else None
         if not self.has_bn:                                   # final head convs: conv + bias only
             y = ops.gather_conv(x, self.c_in, self.pw, nbr, self.kv, n_out, self.c_out, None, bias, None, self.relu,
-                                out=out, dense=dense, bf16x3=self.store.bf16x3)
+                                out=out, dense=dense, math=self.store.math)
             self.saved = (x, nbr, n_out, None, y, None, None, False, dense, None)
             return y
         if self.mode == "up" and self.up > 1:
             z = torch.empty((n_up, self.c_bn), dtype=torch.float32, device=x.device)
             ops.gather_conv(x, self.c_in, self.pw, None, 1, n_out, self.c_out, None, None, None, False, out=z,
-                            out_row_map=up_map, out_col_group=self.c_bn, dense=dense, bf16x3=self.store.bf16x3)
+                            out_row_map=up_map, out_col_group=self.c_bn, dense=dense, math=self.store.math)
         else:
             z = ops.gather_conv(x, self.c_in, self.pw, nbr, self.kv, n_out, self.c_out, None, bias, None, False,
-                                dense=dense, bf16x3=self.store.bf16x3)
+                                dense=dense, math=self.store.math)
         mean, invstd, scale, shift = train_ops.bn_stats_finalize(
             z, self.eps, self.momentum, st.p(self.gn), st.p(self.be),
             self.running_mean if update_stats else None, self.running_var if update_stats else None)
@@ -189,7 +194,7 @@ class _Conv:
             dx = None                           # critical path), the weight gradient after it but ordered on `ready`
             if need_dx:
                 dx = ops.gather_conv(dz, self.c_bn, self.pw_adj, up_map, u2, n_out, self.c_in, None, None, add, False,
-                                     out=dx_out, dense=dense, bf16x3=self.store.bf16x3)
+                                     out=dx_out, dense=dense, math=self.store.dgrad_math)
             st.on_side(wgrad_up, dz, x, after=ready)
             return dx, dres
         if nbr is None:                                       # 1x1 conv: identity rulebook for the weight gradient
@@ -202,7 +207,7 @@ class _Conv:
         dx = None
         if need_dx:
             dx = ops.gather_conv(dz, self.c_out, self.pw_adj, nbr_adj, self.kv, n_in, self.c_in, None, None, add, False,
-                                 out=dx_out, dense=dense, bf16x3=self.store.bf16x3)
+                                 out=dx_out, dense=dense, math=self.store.dgrad_math)
         st.on_side(lambda: train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, bf16x3=self.store.bf16x3),
                    x, dz, nbr_w, after=ready)
         return dx, dres
@@ -243,7 +248,9 @@ class CenterPointTrainer:
         self.fused_loss = True
         self.steps_done = 0
         self.store = _Flat()
-        self.store.bf16x3 = cfg.conv_math == "bf16x3"
+        self.store.math = cfg.conv_math
+        self.store.dgrad_math = "f32" if cfg.conv_math == "f32" else "bf16x3"
+        self.store.bf16x3 = cfg.conv_math != "f32"
         if self.device.type == "cuda" and os.environ.get("CPD_TRAIN_SIDE_STREAM", "1") != "0":
             self.store.side = torch.cuda.Stream(device=self.device)
         self._voxelizers = []

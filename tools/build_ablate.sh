@@ -1,0 +1,15 @@
+#!/bin/bash
+# Diagnostic libraries tools/probe/libcpd_ablN.so: gather_conv.hip built with -DCPD_GC_ABLATE=N
+# (row-wave split kernel: 1 no weight loads, 2 no row gathers, 4 no MFMAs, 8 no barriers; sums combine), rest of the library unchanged.
+set -e
+cd "$(dirname "$0")/../cpd_amd/csrc"
+make -j8 >/dev/null
+mkdir -p ../../tools/probe
+for n in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DCPD_GC_ABLATE=$n -c gather_conv.hip -o /tmp/gc_abl$n.o &
+done
+wait
+for n in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probe/libcpd_abl$n.so voxelize.o site_index.o /tmp/gc_abl$n.o decode.o iou3d_nms.o train_ops.o roi_pool.o
+done
+ls -la ../../tools/probe/*.so

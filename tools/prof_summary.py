@@ -2,7 +2,15 @@
 """Summarise a rocprofv3 --kernel-trace --stats csv next to the bench JSON of the same run."""
 import csv
 import json
+import re
 import sys
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*$", "", n)
+
 
 stats, bench, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
 b = json.load(open(bench))
@@ -12,5 +20,5 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 conv = sum(float(r["TotalDurationNs"]) for r in rows if "conv_kernel" in r["Name"])
 print("kernel ms/step: total %.2f  conv %.2f  other %.2f" % (tot / 1e6 / steps, conv / 1e6 / steps, (tot - conv) / 1e6 / steps))
 for r in rows[:int(sys.argv[4]) if len(sys.argv) > 4 else 30]:
-    print("%-58s calls/step %6.1f  avg us %8.1f  ms/step %6.3f" % (r["Name"].split("(")[0][-58:], int(r["Calls"]) / steps,
+    print("%-58s calls/step %6.1f  avg us %8.1f  ms/step %6.3f" % (short(r["Name"])[:58], int(r["Calls"]) / steps,
                                                                   float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6 / steps))
