@@ -635,7 +635,7 @@ tile_conv_f16_kernel(GcParams p) {
 // lanes -- a wave-uniform branch that is taken for ~1 in 6 (sub-tile, dx != 0) pairs at W = 188.
 // Same tile, fragment layout, XOR-2g swizzle (the image has 136 rows per k-group so that 129 ^ 6 stays inside), register
 // diet (SH row sub-tiles live at a time, weights fetched after the MFMA block) as the rulebook kernel.
-template <class S, int BN, int SH>
+template <class S, int BN, int SH, bool GLDS = false>
 __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
     constexpr int NP = S::NP;
     constexpr int BM = 128;
@@ -649,7 +649,8 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
     constexpr int A_IMG = BMW * 64, B_IMG = BN * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const sa = smem;
-    char *const sb = smem + NP * A_IMG;
+    char *const sb = smem + NP * A_IMG;       // GLDS: two weight buffers, sb and sb + NP * B_IMG
+    static_assert(!GLDS || B_SLOTS % 256 == 0, "direct-to-LDS weight stages are whole wave instructions");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave - wr * WC;
@@ -676,6 +677,23 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
             dir_ok |= b << (4 * s);
         }
     }
+    // per (tap, sub-tile): does this lane's row have the tap's pixel (lane_ok, bit 4*tap + s), and -- wave-uniform, in
+    // scalar registers -- does any lane of the sub-tile lack it (need_mask, same bit)? Computed once: the stage loop then
+    // spends one scalar bit test per sub-tile on borders, and the selects only where an image edge crosses the sub-tile
+    uint64_t lane_ok = 0, need_mask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) {
+            const uint32_t b = dir_ok >> (4 * s);
+            const bool ok = (dy < 0 ? (b & 1u) : dy > 0 ? (b & 2u) : 1u) && (dx < 0 ? (b & 4u) : dx > 0 ? (b & 8u) : 1u);
+            lane_ok |= (uint64_t)(ok ? 1 : 0) << (4 * t + s);
+            need_mask |= (uint64_t)(__all(ok) ? 0 : 1) << (4 * t + s);
+        }
+    }
+    need_mask = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(need_mask >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)need_mask);
 
     const int a_piece = tid & 7;   // 4 channels: k-group a_piece >> 1, half a_piece & 1
     const int a_row = tid >> 3;    // window row, + 32*j
@@ -727,18 +745,35 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
         for (int j = 0; j < BJ; ++j)
             if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
     };
+    // GLDS: the weight stage goes global -> LDS directly (global_load_lds_dwordx4: per-lane source address, destination =
+    // wave-uniform base + 16 * lane; the stage image is lane-linear in its slot id), into the buffer the PREVIOUS stage read,
+    // under this stage's MFMAs: no staging registers, no ds_write pass, one barrier per stage
+    auto issue_weights = [&](int st, int buf) {
+        const int kk = st / 9, t = st - kk * 9;
+        const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int id = j * 256 + tid;
+            const int pg = id / BN, n = id - pg * BN;
+            char *lbase = sb + buf * (NP * B_IMG) + ((j * 256 + wave * 64) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wt + ((size_t)pg * p.np + col0 + n) * 16),
+                                             (__attribute__((address_space(3))) void *)lbase, 16, 0, 0);
+        }
+    };
 
     load_window(0, -1);
-    load_weights(0);
+    if (GLDS) issue_weights(0, 0); else load_weights(0);
     store_window();
-    store_weights();
+    if (!GLDS) store_weights();
     __syncthreads();
     const int n_stage = 9 * sk;
     for (int st = 0; st < n_stage; ++st) {
         const int t = st % 9, dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
         const int nx = st + 1;
         const bool new_window = nx < n_stage && nx % 3 == 0;     // the next stage starts another dy (or channel block)
+        if (GLDS && nx < n_stage) issue_weights(nx, nx & 1);
         if (new_window) load_window(nx / 9, (nx % 9) / 3 - 1);   // in flight under this stage's MFMAs
+        const char *const sbr = sb + (GLDS ? (st & 1) * (NP * B_IMG) : 0);
         {
             const typename S::frag zero = {};
 #pragma unroll
@@ -751,9 +786,9 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) a[s][q] = *reinterpret_cast<const typename S::frag *>(src + q * A_IMG);
                     if (!(CPD_GC_ABLATE & 16)) {
-                        const uint32_t b = dir_ok >> (4 * (s0 + s));
-                        const bool ok = (dy < 0 ? (b & 1u) : dy > 0 ? (b & 2u) : 1u) && (dx < 0 ? (b & 4u) : dx > 0 ? (b & 8u) : 1u);
-                        if (!__all(ok)) {
+                        if ((need_mask >> (4 * t + s0 + s)) & 1) {          // scalar test; rarely taken
+                            asm volatile("" ::: "memory");                  // keeps this a branch (no if-conversion into 8 selects)
+                            const bool ok = (lane_ok >> (4 * t + s0 + s)) & 1;
 #pragma unroll
                             for (int q = 0; q < NP; ++q) a[s][q] = ok ? a[s][q] : zero;
                         }
@@ -762,7 +797,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = wc * (BN / WC) + 16 * nt + r;
-                    const char *src = sb + ((g * BN + n) << 4);
+                    const char *src = sbr + ((g * BN + n) << 4);
                     typename S::frag b[NP];
 #pragma unroll
                     for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
@@ -772,13 +807,21 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
                 if (SH < MS) asm volatile("" ::: "memory");     // keep the groups' LDS reads apart (register budget)
             }
         }
-        __syncthreads();                   // everyone is done reading the images before they are overwritten
-        if (nx < n_stage) {
-            load_weights(nx);
-            if (new_window) store_window();
-            store_weights();
+        if (GLDS) {
+            if (new_window) {
+                __syncthreads();           // everyone is done reading the window before it is overwritten
+                store_window();
+            }
+            __syncthreads();               // the next stage's weights have landed (vmcnt(0) is part of it), window visible
+        } else {
+            __syncthreads();                   // everyone is done reading the images before they are overwritten
+            if (nx < n_stage) {
+                load_weights(nx);
+                if (new_window) store_window();
+                store_weights();
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g);
 }
@@ -788,10 +831,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
 window_conv_bf16_kernel(GcParams p) {
     window_conv_split_body<SplitBf16x3, BN, 2>(p);
 }
+// f16x2: all four row sub-tiles' fragments live at once (the weight fragments are read once per stage); for the 64- and
+// 128-column tiles the weight stage goes direct-to-LDS, double buffered (-4...-8 % on the 128-column layers, tools/conv_bench.py)
 template <int BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
 window_conv_f16_kernel(GcParams p) {
-    window_conv_split_body<SplitF16x2, BN, BN >= 64 ? 4 : 2>(p);
+    window_conv_split_body<SplitF16x2, BN, BN >= 64 ? 4 : 2, BN >= 64>(p);
 }
 
 // Split kernel for SPARSE layers: a workgroup owns 64*MS output rows x BN columns, wave w the
@@ -802,7 +847,7 @@ window_conv_f16_kernel(GcParams p) {
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
 // MS = row sub-tiles per wave: 2 (128-row workgroups) or 1 (64-row workgroups, for layers too small to give every CU a
 // 128-row workgroup: twice the workgroups, each staging the same weights for half the rows).
-template <class S, int BN, int MS>
+template <class S, int BN, int MS, int DEPTH = 1, bool LINES = false, bool GLDS = false>
 __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
     constexpr int NP = S::NP;
     constexpr int NT = BN / 16;
@@ -810,13 +855,23 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
     constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
-    __shared__ __attribute__((aligned(16))) char sb[NP * B_IMG];
+    // GLDS: two weight buffers, filled global -> LDS directly (global_load_lds_dwordx4) a stage ahead: no staging registers, no
+    // ds_write pass, one barrier per stage
+    __shared__ __attribute__((aligned(16))) char sb[(GLDS ? 2 : 1) * NP * B_IMG];
+    static_assert(!GLDS || B_SLOTS % 256 == 0, "direct-to-LDS weight stages are whole wave instructions");
+    // LINES: the rows are gathered as FULL 128-byte lines (8 lanes per row, 8 rows per instruction -- what the vector memory
+    // pipe moves at full rate; fragment-shaped loads of 16 rows x 16 bytes cost it 4 accesses per lane quad) and turned into
+    // MFMA fragments through a wave-private LDS image [row][piece ^ swz(row)] (written and read by the same wave: no barrier)
+    __shared__ __attribute__((aligned(16))) char sa_all[LINES ? 4 * 16 * MS * 128 : 16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int item = xcd_remap(blockIdx.x, gridDim.x);
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
     const int row0 = rb * WG_ROWS + wave * (16 * MS), col0 = cb * BN;
+    char *const sa = sa_all + (LINES ? wave * (16 * MS * 128) : 0);
+    auto swz = [](int rw) { return (((rw >> 1) & 3) * 2) ^ ((rw >> 3) & 1); };   // conflict-free fragment reads (bank model)
+    const int lq = lane >> 3, lp = lane & 7;       // LINES: row within an 8-row group, 16-byte piece of the 128-byte line
 
     // tap activity: workgroup-wide (which stages exist) and per sub-tile of this wave
     uint32_t wg_mask = 0xffffffffu, my_mask[MS];
@@ -857,9 +912,21 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
     while (t_first < p.kv && !tap_on(t_first)) ++t_first;
     if (t_first < p.kv) {
         auto next_tap = [&](int t) { do { ++t; } while (t < p.kv && !tap_on(t)); return t; };
-        auto load_idx = [&](int t, int (&idx)[MS]) {
+        constexpr int NI = LINES ? 2 * MS : MS;        // rulebook entries a lane needs per tap
+        auto load_idx = [&](int t, int (&idx)[NI]) {
+            if (LINES) {
 #pragma unroll
-            for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
+                for (int j = 0; j < NI; ++j) {
+                    int row = row0 + 8 * j + lq;
+                    const bool ok = row < p.n_out;
+                    row = ok ? row : p.n_out - 1;
+                    const int v = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
+                    idx[j] = ok ? v : -1;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
+            }
         };
         auto sub_on = [&](int s, int t) { return t >= 32 || ((my_mask[s] >> t) & 1u); };
 
@@ -881,21 +948,48 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
             return ++kk < sk;
         };
 
-        f32x4 araw[MS][2];
-        bool az[MS];
+        // DEPTH register sets of raw gathered rows: the rows of stage k + DEPTH are requested while stage k computes, so a
+        // gather has DEPTH stage times to land (the weights, L2-resident, stay one stage ahead)
+        f32x4 araw[DEPTH][MS][2];
+        bool az[DEPTH][MS];
         f32x4u rbv[BJ];
-        auto stage_load = [&](int t, int kk, const int (&idx)[MS]) {
+        auto load_rows = [&](auto SET, int t, int kk, const int (&idx)[NI]) {
+            constexpr int R = decltype(SET)::value;
+            if (LINES) {
+#pragma unroll
+                for (int j = 0; j < 2 * MS; ++j) {           // araw[R][j / 2][j % 2] = piece lp of row 8j + lq
+                    if (sub_on(j >> 1, t)) {
+                        const int id = idx[j];
+                        araw[R][j >> 1][j & 1] = zero_if(load_a<true>(p, id, kk * 32 + lp * 4), id < 0);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
                     const int id = row_ok[s] ? idx[s] : -1;
-                    az[s] = id < 0;
-                    if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; continue; }
-                    araw[s][0] = load_a<true>(p, id, kk * 32 + g * 8);
-                    araw[s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
+                    az[R][s] = id < 0;
+                    if (CPD_GC_ABLATE & 2) { araw[R][s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[R][s][1] = araw[R][s][0]; continue; }
+                    araw[R][s][0] = load_a<true>(p, id, kk * 32 + g * 8);
+                    araw[R][s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
                 }
             }
+        };
+        int wbuf = 0;                                   // GLDS: buffer holding the weights of the stage being computed
+        auto load_weights = [&](int t, int kk) {
             const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+            if (GLDS) {                                 // into the other buffer (its readers passed the last barrier)
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const int id = j * 256 + tid;
+                    const int pg = id / BN, n = id - pg * BN;
+                    char *lbase = sb + (wbuf ^ 1) * (NP * B_IMG) + ((j * 256 + wave * 64) << 4);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wt + ((size_t)pg * p.np + col0 + n) * 16),
+                                                     (__attribute__((address_space(3))) void *)lbase, 16, 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
                 const int id = j * 256 + tid;
@@ -907,45 +1001,54 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
             }
         };
         typename S::frag a[MS][NP];
-        auto stage_commit = [&](int t) {            // B -> LDS, A -> split fragments
+        auto stage_commit = [&](auto SET, int t) {            // B -> LDS, A (register set SET) -> split fragments
+            constexpr int R = decltype(SET)::value;
+            if (!GLDS) {
 #pragma unroll
-            for (int j = 0; j < BJ; ++j)
-                if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+                for (int j = 0; j < BJ; ++j)
+                    if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+            }
+            if (LINES) {
+#pragma unroll
+                for (int j = 0; j < 2 * MS; ++j)
+                    if (sub_on(j >> 1, t)) {
+                        const int rw = 8 * j + lq;
+                        *reinterpret_cast<f32x4 *>(sa + rw * 128 + ((lp ^ swz(rw)) << 4)) = araw[R][j >> 1][j & 1];
+                    }
+#pragma unroll
+                for (int s = 0; s < MS; ++s) {
+                    if (sub_on(s, t)) {
+                        const int rw = 16 * s + r;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(sa + rw * 128 + (((2 * g) ^ swz(rw)) << 4));
+                        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(sa + rw * 128 + (((2 * g + 1) ^ swz(rw)) << 4));
+                        typename S::half lo[NP], hi[NP];
+                        S::split(x0, lo);
+                        S::split(x1, hi);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
                     typename S::half lo[NP], hi[NP];
-                    S::split(zero_if(araw[s][0], az[s]), lo);
-                    S::split(zero_if(araw[s][1], az[s]), hi);
+                    S::split(zero_if(araw[R][s][0], az[R][s]), lo);
+                    S::split(zero_if(araw[R][s][1], az[R][s]), hi);
 #pragma unroll
                     for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
                 }
             }
         };
-
-        int t = t_first, kk = 0;
-        int idx_n[MS], idx_nn[MS];                 // rulebook columns of the next stage's tap / of the one after it
-        load_idx(t, idx_n);
-        stage_load(t, kk, idx_n);
-        int tn = t, kn = kk;
-        bool more = advance(tn, kn);               // (tn, kn) = next stage
-        if (more) load_idx(tn, idx_n);
-        int tnn = tn, knn = kn;
-        bool more2 = more && advance(tnn, knn);    // (tnn, knn) = the stage after next
-        stage_commit(t);
-        __syncthreads();
-        while (true) {
-            if (more) {
-                if (more2) load_idx(tnn, idx_nn);
-                stage_load(tn, kn, idx_n);
-            }
+        auto stage_mma = [&](int t) {
             bool on[MS], any_on = false;
 #pragma unroll
             for (int s = 0; s < MS; ++s) { on[s] = sub_on(s, t); any_on |= on[s]; }
             if (any_on) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const char *src = sb + ((g * BN + 16 * nt + r) << 4);
+                    const char *src = sb + (GLDS ? wbuf * (NP * B_IMG) : 0) + ((g * BN + 16 * nt + r) << 4);
                     typename S::frag b[NP];
 #pragma unroll
                     for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
@@ -957,15 +1060,65 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
                     }
                 }
             }
-            if (!more) break;
-            if (!(CPD_GC_ABLATE & 8)) __syncthreads();                        // every wave is done with this stage's weights
-            stage_commit(tn);
-            if (!(CPD_GC_ABLATE & 8)) __syncthreads();
-            t = tn; kk = kn;
-            tn = tnn; kn = knn; more = more2;
+        };
+        using Set0 = std::integral_constant<int, 0>;
+        using Set1 = std::integral_constant<int, DEPTH - 1>;     // == Set0 when DEPTH == 1
+
+        // stage cursors: c = computing, n1 .. n3 = the stages after it (ok = exists)
+        int tc = t_first, kc = 0;
+        int t1 = tc, k1 = kc; bool ok1 = advance(t1, k1);
+        int t2 = t1, k2 = k1; bool ok2 = ok1 && advance(t2, k2);
+        int t3 = t2, k3 = k2; bool ok3 = ok2 && advance(t3, k3);
+        int idx_a[NI], idx_b[NI];                  // rulebook columns, fetched one stage before the gathers they address
+        load_idx(tc, idx_a);
+        load_rows(Set0{}, tc, kc, idx_a);
+        load_weights(tc, kc);
+        if (GLDS) wbuf ^= 1;                        // the first stage's weights land in the buffer it will read
+        if (DEPTH == 2) {
+            if (ok1) { load_idx(t1, idx_a); load_rows(Set1{}, t1, k1, idx_a); }
+            if (ok2) load_idx(t2, idx_b);          // idx_b: column of the next stage to be gathered (c + 2)
+        } else {
+            if (ok1) load_idx(t1, idx_b);          // idx_b: column of the next stage to be gathered (c + 1)
+        }
+        stage_commit(Set0{}, tc);
+        __syncthreads();
+        // one pipeline step with the register set of the stage being requested fixed at compile time
+        auto step = [&](auto REQ, auto NEXT) -> bool {
+            // REQ: set that receives the rows requested now (free: its rows were committed); NEXT: set holding stage c + 1
+            if (ok1) load_weights(t1, k1);
+            if (DEPTH == 2) {
+                if (ok2) load_rows(REQ, t2, k2, idx_b);
+                if (ok3) load_idx(t3, idx_a);
+            } else {
+                if (ok1) load_rows(REQ, t1, k1, idx_b);
+                if (ok2) load_idx(t2, idx_a);
+            }
+            stage_mma(tc);
+            if (!ok1) return false;
+            if (GLDS) {
+                stage_commit(NEXT, t1);             // rows -> fragments (registers only)
+                __syncthreads();                    // the next stage's weights have landed (vmcnt(0) is part of it) and are visible
+                wbuf ^= 1;
+            } else {
+                if (!(CPD_GC_ABLATE & 8)) __syncthreads();                        // every wave is done with this stage's weights
+                stage_commit(NEXT, t1);
+                if (!(CPD_GC_ABLATE & 8)) __syncthreads();
+            }
+            tc = t1; kc = k1;
+            t1 = t2; k1 = k2; ok1 = ok2;
+            t2 = t3; k2 = k3; ok2 = ok3;
+            if (ok3) ok3 = advance(t3, k3);
 #pragma unroll
-            for (int s = 0; s < MS; ++s) idx_n[s] = idx_nn[s];
-            if (more2) more2 = advance(tnn, knn);
+            for (int s = 0; s < NI; ++s) idx_b[s] = idx_a[s];
+            return true;
+        };
+        if (DEPTH == 2) {
+            while (true) {
+                if (!step(Set0{}, Set1{})) break;      // set 0 was committed in the prologue / previous step: request into it
+                if (!step(Set1{}, Set0{})) break;
+            }
+        } else {
+            while (step(Set0{}, Set0{})) {}
         }
     }
     epilogue<MS, NT>(p, acc, row0, col0, r, g);
@@ -981,6 +1134,24 @@ template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS == 4 ? 2 : (BN == 128 && MS == 2 ? 3 : 4), 8)))
 rowwave_conv_f16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitF16x2, BN, MS>(p);
+}
+// gathers two stages ahead (two register sets of raw rows)
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+rowwave2_conv_f16_kernel(GcParams p) {
+    rowwave_conv_split_body<SplitF16x2, BN, MS, 2>(p);
+}
+// weights direct-to-LDS, double buffered
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+rowwaveG_conv_f16_kernel(GcParams p) {
+    rowwave_conv_split_body<SplitF16x2, BN, MS, 1, false, true>(p);
+}
+// full-line gathers through a wave-private LDS image
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+rowwaveL_conv_f16_kernel(GcParams p) {
+    rowwave_conv_split_body<SplitF16x2, BN, MS, 1, true>(p);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -1385,6 +1556,30 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     const dim3 grid(p.items), block(256);
     hipStream_t hs = cpd_s(stream);
 #define CPD_LAUNCH(K, LDS) hipLaunchKernelGGL((K), grid, block, (LDS), hs, p)
+    int rw_depth = 1;
+    if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_ROWWAVE_DEPTH")) rw_depth = atoi(e);
+    if (pl.use_wg == 3 && pl.math == 2 && rw_depth == 4 && (pl.a == 128 || pl.a == 64)) {
+        if (pl.a == 64) {
+            if (pl.b == 32) CPD_LAUNCH((rowwaveG_conv_f16_kernel<32, 1>), 0);
+            else if (pl.b == 64) CPD_LAUNCH((rowwaveG_conv_f16_kernel<64, 1>), 0);
+            else CPD_LAUNCH((rowwaveG_conv_f16_kernel<128, 1>), 0);
+        } else if (pl.b == 32) CPD_LAUNCH((rowwaveG_conv_f16_kernel<32, 2>), 0);
+        else if (pl.b == 64) CPD_LAUNCH((rowwaveG_conv_f16_kernel<64, 2>), 0);
+        else CPD_LAUNCH((rowwaveG_conv_f16_kernel<128, 2>), 0);
+        return cpd_check_launch();
+    }
+    if (pl.use_wg == 3 && pl.math == 2 && rw_depth == 3 && pl.a == 128) {
+        if (pl.b == 32) CPD_LAUNCH((rowwaveL_conv_f16_kernel<32, 2>), 0);
+        else if (pl.b == 64) CPD_LAUNCH((rowwaveL_conv_f16_kernel<64, 2>), 0);
+        else CPD_LAUNCH((rowwaveL_conv_f16_kernel<128, 2>), 0);
+        return cpd_check_launch();
+    }
+    if (pl.use_wg == 3 && pl.math == 2 && rw_depth == 2 && pl.a == 128) {
+        if (pl.b == 32) CPD_LAUNCH((rowwave2_conv_f16_kernel<32, 2>), 0);
+        else if (pl.b == 64) CPD_LAUNCH((rowwave2_conv_f16_kernel<64, 2>), 0);
+        else CPD_LAUNCH((rowwave2_conv_f16_kernel<128, 2>), 0);
+        return cpd_check_launch();
+    }
     if (pl.use_wg == 3 && pl.math == 2) {
         if (pl.a == 256) {
             if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 4>), 0);
@@ -1502,8 +1697,9 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     p.img_h = h; p.img_w = w;
     const size_t lds = (math == 2 ? 2 : 3) * ((size_t)(128 + 8) * 64 + (size_t)bn * 64);
     if (math == 2) {
-        if (bn == 128) hipLaunchKernelGGL((window_conv_f16_kernel<128>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
-        else if (bn == 64) hipLaunchKernelGGL((window_conv_f16_kernel<64>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        const size_t lds2 = 2 * (size_t)(128 + 8) * 64 + 2 * 2 * (size_t)bn * 64;    // window image + two weight buffers
+        if (bn == 128) hipLaunchKernelGGL((window_conv_f16_kernel<128>), dim3(p.items), dim3(256), lds2, cpd_s(stream), p);
+        else if (bn == 64) hipLaunchKernelGGL((window_conv_f16_kernel<64>), dim3(p.items), dim3(256), lds2, cpd_s(stream), p);
         else hipLaunchKernelGGL((window_conv_f16_kernel<16>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
         return cpd_check_launch();
     }
