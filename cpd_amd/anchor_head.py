@@ -13,6 +13,7 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from ._lib import check, farr, lib, ptr, stream
 
 
@@ -268,4 +269,148 @@ class AnchorHeadSingle(torch.nn.Module):
                                               self.model_cfg.get("DIR_OFFSET", 0.78539), self.model_cfg.get("DIR_LIMIT_OFFSET", 0.0),
                                               self.num_dir_bins)
         data_dict.update(batch_cls_preds=cls, batch_box_preds=boxes, cls_preds_normalized=False)
+        return data_dict
+
+
+def get_layer(dim, out_dim, init=None):
+    """anchor_head_single.py:9-29: Conv3x3(dim, dim) + BatchNorm2d + ReLU + Conv1x1(dim, out_dim), reference init."""
+    from .models import Conv2d
+    conv = Conv2d(dim, dim, kernel_size=3, padding=1, bias=True)
+    torch.nn.init.normal_(conv.weight, mean=0, std=0.001)
+    conv2 = Conv2d(dim, out_dim, kernel_size=1, bias=True)
+    if init is None:
+        torch.nn.init.normal_(conv2.weight, mean=0, std=0.001)
+    else:
+        conv2.bias.data.fill_(init)
+    return torch.nn.Sequential(conv, torch.nn.BatchNorm2d(dim), torch.nn.ReLU(), conv2)
+
+
+class AnchorHeadSingleV2(AnchorHeadSingle):
+    """AnchorHeadSingleV2 (cpd/models/dense_heads/anchor_head_single.py:31-192), the dense head both shipped dbscan / oyster
+    configs select (tools/cfgs/models/waymo_unsupervised/voxel_rcnn_{dbscan,oyster}_single_train.yaml:37): a shared 3x3
+    conv (input -> 64) + BN + ReLU, five `get_layer` branches on it (cls / reg / height / dim / ang), the 1x1 direction
+    classifier on the input map, occupancy-masked anchors, generate_predicted_boxes. Same parameters and state_dict names as
+    the reference (shared_conv.0/1, conv_cls.0/1/3, conv_reg..., conv_dir_cls).
+
+    Eval forward = four C-ABI launches on channels-last rows, BatchNorm folded: the shared conv, the five branches' 3x3 convs
+    fused along their output columns (64 -> 320), their five 1x1 convs as ONE block-diagonal 320 -> (A*nc + 7A) GEMM whose
+    column order is the reference's torch.cat([reg, height, dim, ang]) order, and the direction classifier. Training mode runs
+    the modules one by one (differentiable, cpd_amd/autograd_ops.py)."""
+
+    SHARD_C = 64
+
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, conv_math="f16x2", **kwargs):
+        torch.nn.Module.__init__(self)
+        from .models import Conv2d
+        self.model_cfg, self.num_class, self.class_names = model_cfg, num_class, list(class_names)
+        self.range = [float(v) for v in point_cloud_range]
+        self.voxel_size = (self.range[3] - self.range[0]) / float(grid_size[0])
+        agc = model_cfg["ANCHOR_GENERATOR_CONFIG"]
+        fms = [[int(grid_size[0]) // c["feature_map_stride"], int(grid_size[1]) // c["feature_map_stride"]] for c in agc]
+        self._gen = (AnchorGenerator(self.range, agc), fms)
+        self.anchors_root = None
+        a = sum(len(c["anchor_rotations"]) * len(c["anchor_sizes"]) * len(c["anchor_bottom_heights"]) for c in agc)
+        self.num_anchors_per_location = a
+        c = self.SHARD_C
+        self.shared_conv = torch.nn.Sequential(Conv2d(input_channels, c, kernel_size=3, padding=1, bias=True),
+                                               torch.nn.BatchNorm2d(c), torch.nn.ReLU(inplace=True))
+        self.conv_cls = get_layer(c, a * num_class, -4.59)
+        self.conv_reg = get_layer(c, a * 2)
+        self.conv_height = get_layer(c, a * 1)
+        self.conv_dim = get_layer(c, a * 3)
+        self.conv_ang = get_layer(c, a * 1)
+        self.num_dir_bins = model_cfg.get("NUM_DIR_BINS", 2)
+        self.conv_dir_cls = Conv2d(input_channels, a * self.num_dir_bins, kernel_size=1) \
+            if model_cfg.get("USE_DIRECTION_CLASSIFIER", None) is not None else None
+        self.conv_math = conv_math
+        self.forward_ret_dict = {}
+        self._fused = None
+
+    BRANCHES = ("conv_cls", "conv_reg", "conv_height", "conv_dim", "conv_ang")
+
+    def _fuse(self, dev):
+        """Folded / fused weight images of the eval path (rebuilt when a parameter changes)."""
+        from .engine import _fold_bn
+        params = list(self.parameters()) + list(self.buffers())
+        key = tuple((p._version, p.data_ptr()) for p in params)
+        if self._fused is not None and self._fused[0] == key:
+            return self._fused[1]
+        sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
+        c = self.SHARD_C
+
+        def kio(w):                                                  # (Cout, Cin, k, k) -> [k*k, Cin, Cout]
+            return w.permute(2, 3, 1, 0).reshape(w.shape[2] * w.shape[3], w.shape[1], w.shape[0]).contiguous()
+
+        f = {}
+        s, t = _fold_bn(sd, "shared_conv.1", 1e-5, sd["shared_conv.0.bias"])
+        f["shared"] = (ops.pack_weight(kio(sd["shared_conv.0.weight"]).to(dev)), s.to(dev), t.to(dev), sd["shared_conv.0.weight"].shape[1], c)
+        w1, s1, t1 = [], [], []
+        outs = [sd[b + ".3.weight"].shape[0] for b in self.BRANCHES]
+        w2 = torch.zeros(1, c * len(self.BRANCHES), sum(outs))
+        b2 = torch.zeros(sum(outs))
+        col = 0
+        for i, b in enumerate(self.BRANCHES):
+            w1.append(kio(sd[b + ".0.weight"]))
+            s, t = _fold_bn(sd, b + ".1", 1e-5, sd[b + ".0.bias"])
+            s1.append(s); t1.append(t)
+            w2[0, i * c:(i + 1) * c, col:col + outs[i]] = sd[b + ".3.weight"].reshape(outs[i], c).t()
+            b2[col:col + outs[i]] = sd[b + ".3.bias"]
+            col += outs[i]
+        f["first"] = (ops.pack_weight(torch.cat(w1, dim=2).to(dev)), torch.cat(s1).to(dev), torch.cat(t1).to(dev), c, c * len(self.BRANCHES))
+        f["second"] = (ops.pack_weight(w2.to(dev)), None, b2.to(dev), c * len(self.BRANCHES), sum(outs))
+        f["n_cls"] = outs[0]
+        if self.conv_dir_cls is not None:
+            wd = sd["conv_dir_cls.weight"]
+            f["dir"] = (ops.pack_weight(kio(wd).to(dev)), None, sd["conv_dir_cls.bias"].to(dev), wd.shape[1], wd.shape[0])
+        self._fused = (key, f)
+        return f
+
+    def _heads_eval(self, x):
+        """(cls rows, box rows, dir rows | None), each [B*H*W, channels], through the fused launches."""
+        from .models import _rows
+        b, cin, h, w = x.shape
+        dev = x.device
+        f = self._fuse(dev)
+        rows = _rows(x.float())
+        n = b * h * w
+        nbr, _, _ = ops.rulebook_conv2d(b, h, w, 3, 3, 1, 1, dev)
+        m = self.conv_math
+
+        def run(name, inp, table, kv, relu):
+            pw, s, t, ci, co = f[name]
+            return ops.gather_conv(inp, ci, pw, table, kv, n, co, s, t, None, relu, dense=True, math=m)
+
+        shared = run("shared", rows, nbr, 9, True)
+        first = run("first", shared, nbr, 9, True)
+        second = run("second", first, None, 1, False)
+        dirs = run("dir", rows, None, 1, False) if "dir" in f else None
+        return second[:, :f["n_cls"]], second[:, f["n_cls"]:], dirs
+
+    def forward(self, data_dict):
+        x = data_dict["st_features_2d"]
+        b, _, h, w = x.shape
+        if self.anchors_root is None:
+            self.anchors_root = self._gen[0].generate_anchors(self._gen[1], device=x.device)[0]
+        mask = self.get_anchor_mask(data_dict["points"], x.shape)
+        self.anchors = [a[:, mask, ...] for a in self.anchors_root]
+        if self.training:
+            shard = self.shared_conv(x)
+            pick = lambda t: t.permute(0, 2, 3, 1).contiguous()[:, mask, :]
+            cls_preds = pick(self.conv_cls(shard))
+            box_preds = pick(torch.cat([self.conv_reg(shard), self.conv_height(shard), self.conv_dim(shard), self.conv_ang(shard)], dim=1))
+            dir_preds = pick(self.conv_dir_cls(x)) if self.conv_dir_cls is not None else None
+        else:
+            with torch.no_grad():
+                cls_r, box_r, dir_r = self._heads_eval(x)
+                pick = lambda r: r.reshape(b, h, w, r.shape[1])[:, mask, :]
+                cls_preds, box_preds = pick(cls_r), pick(box_r)
+                dir_preds = pick(dir_r) if dir_r is not None else None
+        self.forward_ret_dict.update(cls_preds=cls_preds, box_preds=box_preds, dir_cls_preds=dir_preds)
+        if not self.training or self.model_cfg.get("PREDICT_BOXES_WHEN_TRAINING", False):
+            with torch.no_grad():
+                cls, boxes = generate_predicted_boxes(self.anchors, data_dict["batch_size"], cls_preds.detach(), box_preds.detach(),
+                                                      dir_preds.detach() if dir_preds is not None else None,
+                                                      self.model_cfg.get("DIR_OFFSET", 0.78539), self.model_cfg.get("DIR_LIMIT_OFFSET", 0.0),
+                                                      self.num_dir_bins)
+            data_dict.update(batch_cls_preds=cls, batch_box_preds=boxes, cls_preds_normalized=False)
         return data_dict

@@ -96,16 +96,41 @@ rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd
     int t = 0;
     uint32_t my_mask = 0;  // lanes 0..3 of a wave collect the tap masks of its four 16-row sub-tiles
     const int lane = threadIdx.x & 63;
+    const int x0 = q.w * sw - pw;
+    const int xlo = x0 < 0 ? 0 : x0, xhi = x0 + kw - 1 < gin.w ? x0 + kw - 1 : gin.w - 1;
     for (int tz = 0; tz < kd; ++tz) {
         int z = q.y * sd - pd + tz;
         for (int ty = 0; ty < kh; ++ty) {
             int y = q.z * sh - ph + ty;
+            // the kw taps of one (z, y) row are consecutive cells: they share one bitmap word and its prefix (two when the
+            // run crosses a 64-cell boundary), fetched once per row instead of once per tap
+            const bool row_ok = (unsigned)z < (unsigned)gin.d && (unsigned)y < (unsigned)gin.h && (unsigned)q.x < (unsigned)gin.b &&
+                                xlo <= xhi;
+            long long rowkey = 0;
+            uint64_t wa = 0, wb = 0;
+            uint32_t ba = 0, bb = 0;
+            long long wia = 0;
+            if (row_ok) {
+                rowkey = gin.key(q.x, z, y, 0);
+                wia = (rowkey + xlo) >> 6;
+                const long long wib = (rowkey + xhi) >> 6;
+                wa = bitmap[wia]; ba = base[wia];
+                wb = wa; bb = ba;
+                if (wib != wia) { wb = bitmap[wib]; bb = base[wib]; }
+            }
             for (int tx = 0; tx < kw; ++tx, ++t) {
-                int x = q.w * sw - pw + tx;
+                int x = x0 + tx;
                 int32_t r = -1;
-                if ((unsigned)z < (unsigned)gin.d && (unsigned)y < (unsigned)gin.h && (unsigned)x < (unsigned)gin.w &&
-                    (unsigned)q.x < (unsigned)gin.b)
-                    r = site_lookup(bitmap, base, perm, gin.key(q.x, z, y, x));
+                if (row_ok && (unsigned)x < (unsigned)gin.w) {
+                    const long long k = rowkey + x;
+                    const bool first = (k >> 6) == wia;
+                    const uint64_t w = first ? wa : wb;
+                    const uint64_t bit = 1ull << (k & 63);
+                    if (w & bit) {
+                        r = (int32_t)((first ? ba : bb) + __popcll(w & (bit - 1ull)));
+                        if (perm) r = perm[r];
+                    }
+                }
                 if (live) nbr[(size_t)t * n_out + j] = r;
                 const unsigned long long hit = __ballot(live && r >= 0);
                 if (lane < 4 && t < 32 && ((hit >> (16 * lane)) & 0xffffull)) my_mask |= 1u << t;

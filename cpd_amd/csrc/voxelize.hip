@@ -18,6 +18,7 @@
 //   6 gather    : coalesced copy of the kept points into voxels[M,P,C], count, mean
 // HBM traffic is ~ the points read 3x (12 B/pt keys + rows) + outputs; see DESIGN.md.
 #include "common.h"
+#include "site_index_layout.h"
 
 thread_local int g_cpd_last_hip_error = 0;
 
@@ -398,16 +399,22 @@ extern "C" size_t cpd_voxelize_batch_workspace_bytes(int n_total, int n_frames, 
     return carve(nullptr, n_total, max_points, cap, (long long)n_frames * cells).bytes + cpd_align(2 * (CPD_VOX_MAX_FRAMES + 1) * 4 + 16);
 }
 
-extern "C" int cpd_voxelize_batch(const float *points, const int32_t *frame_offsets, int n_frames, int c,
-                                  const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
-                                  float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
-                                  int32_t *n_voxels, void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
-    if (!frame_offsets || c < 3 || max_points <= 0 || max_voxels <= 0 || !coords || !num_points || !n_voxels || !workspace)
+// `index` != NULL: the occupancy bitmap, its popcount prefix and the rank -> row map are built INSIDE that site index (of
+// the grid with z_extra more z-levels -- the backbone's sparse_shape = grid + [1,0,0], spconv_backbone.py:412), which is
+// then the level-0 index of the sparse tensor as it stands: no second bitmap, mark, scan and permutation pass.
+static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+                               const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
+                               float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
+                               int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index, size_t index_bytes,
+                               int z_extra, cpd_stream_t stream) {
+    if (!frame_offsets || c < 3 || max_points <= 0 || max_voxels <= 0 || !coords || !num_points || !n_voxels || !workspace ||
+        z_extra < 0)
         return CPD_ERR_ARG;
     VoxGeom geo;
     long long cells;
     int rc = vox_geom(vsize_xyz, range_xyz, &geo, &cells);
     if (rc) return rc;
+    if (index) cells = (long long)(geo.g[0] + z_extra) * geo.g[1] * geo.g[2];   // keys run over the index's (deeper) grid
     if (n_frames <= 0 || n_frames > CPD_VOX_MAX_FRAMES) return CPD_ERR_UNSUPPORTED;
     FrameOffsets fo;
     fo.nf = n_frames;
@@ -422,13 +429,28 @@ extern "C" int cpd_voxelize_batch(const float *points, const int32_t *frame_offs
     rc = batch_caps(n, n_frames, max_voxels, cells, &cap);
     if (rc) return rc;
     hipStream_t s = cpd_s(stream);
-    VoxWs w = carve(workspace, n, max_points, cap, (long long)n_frames * cells);
+    // with an index the bitmap / prefix / scan spine live there: the workspace (sized by cpd_voxelize_batch_workspace_bytes for
+    // the plain grid) then carries no bitmap at all
+    VoxWs w = carve(workspace, n, max_points, cap, index ? 0 : (long long)n_frames * cells);
     if (workspace_bytes < w.bytes + cpd_align(2 * (CPD_VOX_MAX_FRAMES + 1) * 4 + 16)) return CPD_ERR_WORKSPACE;
+    if (index) {
+        const int32_t shape[3] = {geo.g[0] + z_extra, geo.g[1], geo.g[2]};
+        IndexView v = index_carve(index, n_frames, shape, n > 0 ? n : 1);       // ranks <= occupied cells <= points
+        if (index_bytes < v.bytes) return CPD_ERR_WORKSPACE;
+        w.words = v.words;
+        w.bitmap = v.bitmap; w.base = v.base; w.bsum_bm = v.bsum; w.vid = v.perm;
+        CPD_HIP_TRY(hipMemsetAsync(v.flags, 0, 4, s));
+        CPD_HIP_TRY(hipMemsetAsync(v.flags, 1, 1, s));                          // flags[0] = 1: row id = perm[rank]
+    }
     int32_t *frame_base = (int32_t *)((char *)workspace + w.bytes);
     int32_t *out_base = frame_base + CPD_VOX_MAX_FRAMES + 1;
     int32_t *total = out_base + CPD_VOX_MAX_FRAMES + 1;
     if (n == 0) {
         CPD_HIP_TRY(hipMemsetAsync(n_voxels, 0, (size_t)(n_frames + 1) * 4, s));
+        if (index) {                                          // an empty but valid index
+            CPD_HIP_TRY(hipMemsetAsync(w.bitmap, 0, (size_t)w.words * 8, s));
+            CPD_HIP_TRY(hipMemsetAsync(w.base, 0, (size_t)w.words * 4, s));
+        }
         return CPD_OK;
     }
     CPD_HIP_TRY(hipMemsetAsync(w.bitmap, 0, (size_t)w.words * 8, s));
@@ -451,4 +473,22 @@ extern "C" int cpd_voxelize_batch(const float *points, const int32_t *frame_offs
     vox_gather_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(points, c, max_points, cap, n_voxels + n_frames, w.slots, w.counts,
                                                                voxels, num_points, mean_features);
     return cpd_check_launch();
+}
+
+extern "C" int cpd_voxelize_batch(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+                                  const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
+                                  float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
+                                  int32_t *n_voxels, void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
+    return voxelize_batch_impl(points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
+                               num_points, mean_features, n_voxels, workspace, workspace_bytes, nullptr, 0, 0, stream);
+}
+
+extern "C" int cpd_voxelize_batch_index(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+                                        const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
+                                        float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
+                                        int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index,
+                                        size_t index_bytes, int z_extra, cpd_stream_t stream) {
+    if (!index) return CPD_ERR_ARG;
+    return voxelize_batch_impl(points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
+                               num_points, mean_features, n_voxels, workspace, workspace_bytes, index, index_bytes, z_extra, stream);
 }

@@ -301,12 +301,14 @@ class CenterPointEngine:
             x = self._conv(c2, y, nbr, n, residual=x)
         return x
 
-    def backbone3d(self, feats, coords, batch):
+    def backbone3d(self, feats, coords, batch, index=None):
         """VoxelResBackBone8x.forward (spconv_backbone.py:502-558). Returns per-level
-        {name: (features, indices, spatial_shape)} and the stride-8 output."""
+        {name: (features, indices, spatial_shape)} and the stride-8 output. `index`: the level-0 site index when the
+        voxelizer already built it (cpd_voxelize_batch_index)."""
         L = self.sparse
         shape = self.cfg.sparse_shape
-        index = ops.SiteIndex.build(coords, batch, shape)
+        if index is None:
+            index = ops.SiteIndex.build(coords, batch, shape)
         nbr = ops.rulebook_subm(coords, index)               # 'subm1' and 'res1' are the same L0 table
         x = self._conv(L["conv_input"], feats, nbr, coords.shape[0])
         x = self._blocks(L["conv1"], x, nbr)
@@ -422,9 +424,12 @@ class CenterPointEngine:
         if isinstance(points_list, torch.Tensor):
             points_list = [points_list]
         batch = len(points_list)
-        if batch > 1 and self.voxelizer.batch_supported(batch):
-            # one set of voxelizer launches for the whole batch; rows come out frame after frame
-            _, coords, _, feats, nvox = self.voxelizer.batch(points_list)
+        index0 = None
+        z_extra = self.cfg.sparse_shape[0] - self.cfg.grid_zyx[0]
+        if batch > 1 and self.voxelizer.batch_supported(batch, z_extra):
+            # one set of voxelizer launches for the whole batch; rows come out frame after frame; the voxelizer's occupancy
+            # bitmap / prefix / rank -> row map ARE the level-0 site index of the backbone
+            _, coords, _, feats, nvox, index0 = self.voxelizer.batch(points_list, index_z_extra=z_extra)
             total = int(nvox[batch].item())                 # the one read-back
             feats, coords = feats[:total], coords[:total]
         else:
@@ -437,7 +442,7 @@ class CenterPointEngine:
             ms = torch.cat([o[4] for o in outs]).tolist() if batch > 1 else [int(outs[0][4].item())]   # one read-back
             feats = torch.cat([o[3][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][3][:ms[0]]
             coords = torch.cat([o[1][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][1][:ms[0]]
-        levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch)
+        levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0)
         d, h, w = out_shape
         dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
         cat, head = self.bev_and_head(dense, batch, h, w)

@@ -461,8 +461,24 @@ def _decode_separate(views, nc, h, w, pp, stride, voxel_size, pcr):
 
 
 # --------------------------------------------------------------------------------- detector
-__all__ = {"MeanVFE": MeanVFE, "VoxelResBackBone8x": VoxelResBackBone8x, "HeightCompression": HeightCompression,
-           "BaseBEVBackbone": BaseBEVBackbone, "CenterHead": CenterHead}
+def _anchor_heads():
+    from . import anchor_head                        # (imports this module's Conv2d lazily)
+    return {"AnchorHeadSingle": anchor_head.AnchorHeadSingle, "AnchorHeadSingleV2": anchor_head.AnchorHeadSingleV2}
+
+
+class _Registry(dict):
+    """`__all__[NAME]` like the reference's registries (dense_heads/__init__.py); the anchor heads resolve on first use."""
+
+    def __missing__(self, name):
+        heads = _anchor_heads()
+        if name in heads:
+            self.update(heads)
+            return heads[name]
+        raise KeyError(name)
+
+
+__all__ = _Registry({"MeanVFE": MeanVFE, "VoxelResBackBone8x": VoxelResBackBone8x, "HeightCompression": HeightCompression,
+                     "BaseBEVBackbone": BaseBEVBackbone, "CenterHead": CenterHead})
 
 
 def waymo_centerpoint_cfg():

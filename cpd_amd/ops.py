@@ -76,14 +76,16 @@ class Voxelizer:
                 mean[:m] if mean is not None else None, m)
 
 
-    def batch_supported(self, n_frames):
+    def batch_supported(self, n_frames, z_extra=0):
         g = voxel_grid_size(self.vs, self.rg)
-        return 0 < n_frames <= 64 and n_frames * g[0] * g[1] * g[2] < (1 << 31)
+        return 0 < n_frames <= 64 and n_frames * (g[0] + z_extra) * g[1] * g[2] < (1 << 31)
 
-    def batch(self, points_list, want_voxels=False, want_mean=True):
+    def batch(self, points_list, want_voxels=False, want_mean=True, index_z_extra=None):
         """All frames in one set of launches (cpd_voxelize_batch). Returns capacity-sized device tensors
         (voxels|None, coords [cap,4] (b,z,y,x), num_points, mean|None, n_voxels [B+1] = per frame + total);
-        rows of frame f follow those of frame f-1. No host synchronisation."""
+        rows of frame f follow those of frame f-1. No host synchronisation.
+        index_z_extra = k: also returns, as a sixth value, the SiteIndex of the voxel list over the grid with k more
+        z-levels (the backbone's sparse_shape for k = 1), built by the voxelizer itself (cpd_voxelize_batch_index)."""
         for p in points_list:
             _need_cuda(p, "points")
         pts = torch.cat([p.contiguous() for p in points_list]) if len(points_list) > 1 else points_list[0].contiguous()
@@ -105,6 +107,14 @@ class Voxelizer:
             raise _lib.CpdHipError("cpd_voxelize_batch: unsupported batch (%d frames)" % nf)
         if self._wsb is None or self._wsb.numel() < nbytes:
             self._wsb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if index_z_extra is not None:
+            g = self.grid_zyx
+            index = SiteIndex(nf, [g[0] + int(index_z_extra), g[1], g[2]], max(n, 1), dev)
+            check(lib().cpd_voxelize_batch_index(ptr(pts), iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
+                                                 ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
+                                                 self._wsb.numel(), ptr(index.buf), index.buf.numel(), int(index_z_extra), stream()),
+                  "cpd_voxelize_batch_index")
+            return voxels, coords, num, mean, nvox, index
         check(lib().cpd_voxelize_batch(ptr(pts), iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
                                        ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
                                        self._wsb.numel(), stream()), "cpd_voxelize_batch")

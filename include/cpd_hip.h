@@ -74,6 +74,16 @@ int cpd_voxelize_batch(const float *points, const int32_t *frame_offsets, int n_
                        int max_voxels, float *voxels, int32_t *coords, int32_t *num_points,
                        float *mean_features, int32_t *n_voxels, void *workspace, size_t workspace_bytes,
                        cpd_stream_t stream);
+/* cpd_voxelize_batch that builds its occupancy bitmap, popcount prefix and rank -> row map INSIDE the caller's site index
+ * (cpd_index_bytes(n_frames, {grid_z + z_extra, grid_y, grid_x}, n_total) bytes) instead of its own workspace: the index is
+ * then the level-0 site index of the voxel list (what cpd_index_build would produce from `coords`) at no extra cost.
+ * z_extra = 1 gives the backbone's sparse_shape = grid_size[::-1] + [1,0,0] (spconv_backbone.py:412). Voxels beyond a
+ * frame's max_voxels cap are not sites (their lookups return -1). */
+int cpd_voxelize_batch_index(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+                             const float vsize_xyz[3], const float range_xyz[6], int max_points_per_voxel,
+                             int max_voxels, float *voxels, int32_t *coords, int32_t *num_points,
+                             float *mean_features, int32_t *n_voxels, void *workspace, size_t workspace_bytes,
+                             void *index, size_t index_bytes, int z_extra, cpd_stream_t stream);
 
 /* ===== B2. Sparse convolution ==============================================================
  * Replaces [SPCONV] SparseConvTensor / SubMConv3d / SparseConv3d / .dense() as called from

@@ -671,6 +671,38 @@ def main():
     print("anchor_head_single: mask keeps %d of %d locations, %d boxes/sample" % (int(mask.sum()), mask.numel(), outd["batch_box_preds"].shape[1]))
     print("anchor_head: %d anchors, %d positives, %d ignored" % (n_anc, int((tgt["box_cls_labels"] > 0).sum()),
                                                                   int((tgt["box_cls_labels"] < 0).sum())))
+    # 13. AnchorHeadSingleV2.forward in eval mode (anchor_head_single.py:9-29,31-192) -- the head both shipped dbscan / oyster
+    #     configs select: shared 3x3 conv + BN + ReLU, five get_layer branches (3x3 conv + BN + ReLU + 1x1 conv), the 1x1
+    #     direction classifier on the input map, occupancy-masked anchors, generate_predicted_boxes. Own generators: this
+    #     section moves no other fixture.
+    gen2 = torch.Generator().manual_seed(2222)
+    g2 = np.random.default_rng(2222)
+    torch.manual_seed(2222)
+    head2 = ahs.AnchorHeadSingleV2(model_cfg=mcfg, num_frames=1, input_channels=32, num_class=3,
+                                   class_names=["Vehicle", "Pedestrian", "Cyclist"], grid_size=np.array([416, 416, 40]),
+                                   point_cloud_range=pcr, predict_boxes_when_training=False).eval()
+    with torch.no_grad():
+        for name, prm in head2.named_parameters():                   # the reference's init (std 0.001) would hide layout mistakes
+            if prm.dim() == 4:
+                prm.copy_(torch.randn(prm.shape, generator=gen2) * (2.0 / (prm.shape[1] * prm.shape[2] * prm.shape[3])) ** 0.5)
+            elif "bias" in name and prm.numel() > 1 and not name.endswith("3.bias"):
+                prm.copy_(torch.randn(prm.shape, generator=gen2) * 0.1)
+        _randomize_bn(head2.modules(), gen2)
+    pts2 = torch.cat([torch.zeros(260, 1), torch.from_numpy(g2.uniform(-20.5, 20.5, (260, 3)).astype(np.float32))], 1)
+    pts2[:120, 1:3] *= 0.4
+    pts2 = pts2[(pts2[:, 1].abs() < 10) | (pts2[:, 2] > 11)]
+    feat2 = torch.randn(2, 32, H, W, generator=gen2)
+    dd2 = {"points": pts2, "st_features_2d": feat2, "batch_size": 2}
+    with torch.no_grad():
+        mask2 = head2.get_anchor_mask(dd2, feat2.shape)
+        out2 = head2(dict(dd2))
+    sd2 = {"v2." + k: v.numpy() for k, v in head2.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "anchor_head_single_v2.npz"), points=pts2.numpy(), feat=feat2.numpy(), mask=mask2.numpy(),
+                        cls_preds=head2.forward_ret_dict["cls_preds"].numpy(), box_preds=head2.forward_ret_dict["box_preds"].numpy(),
+                        dir_cls_preds=head2.forward_ret_dict["dir_cls_preds"].numpy(),
+                        batch_cls_preds=out2["batch_cls_preds"].numpy(), batch_box_preds=out2["batch_box_preds"].numpy(), pcr=pcr, **sd2)
+    print("anchor_head_single_v2: mask keeps %d of %d locations, %d boxes/sample" % (int(mask2.sum()), mask2.numel(),
+                                                                                     out2["batch_box_preds"].shape[1]))
     nms_large(m)
     wide_dense(m)
     print("golden fixtures written to", HERE)

@@ -104,6 +104,44 @@ def test_anchor_head_single_forward_matches_reference_module(golden, hip):
     np.testing.assert_allclose(out["batch_box_preds"].cpu().numpy(), g["batch_box_preds"], atol=2e-4, rtol=1e-5)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["f32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_anchor_head_single_v2_forward_matches_reference_module(golden, hip, math, mode):
+    """AnchorHeadSingleV2 (anchor_head_single.py:31-192), the head the shipped dbscan / oyster configs select: state_dict of the
+    reference module loads by name, same anchor mask, and the raw cls / box / dir maps plus the decoded boxes equal the
+    reference's own eval forward -- through the fused four-launch eval path (every conv arithmetic) and through the
+    differentiable module-by-module path train mode takes (BatchNorm put in eval so that both see the running statistics)."""
+    import torch
+    from cpd_amd import anchor_head as ah
+    g = golden("anchor_head_single_v2")
+    cfgs = [dict(class_name=n, anchor_sizes=[s], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0], align_center=False,
+                 feature_map_stride=8, matched_threshold=0.5, unmatched_threshold=0.35)
+            for n, s in (("Vehicle", [4.7, 2.1, 1.7]), ("Pedestrian", [0.91, 0.86, 1.73]), ("Cyclist", [1.78, 0.84, 1.78]))]
+    mcfg = dict(ANCHOR_GENERATOR_CONFIG=cfgs, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
+                PREDICT_BOXES_WHEN_TRAINING=True)
+    head = ah.AnchorHeadSingleV2(mcfg, 32, 3, CLASSES, np.array([416, 416, 40]), g["pcr"].tolist(), conv_math=math)
+    sd = {k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("v2.")}
+    res = head.load_state_dict(sd, strict=True)                      # same parameter / buffer names as the reference class
+    assert not res.missing_keys and not res.unexpected_keys
+    head = head.cuda().eval()
+    if mode == "train":
+        head.training = True                                         # forward takes the module path; BatchNorms stay in eval
+    dd = {"points": torch.from_numpy(g["points"]).cuda(), "st_features_2d": torch.from_numpy(g["feat"]).cuda(), "batch_size": 2}
+    mask = head.get_anchor_mask(dd["points"], dd["st_features_2d"].shape)
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])
+    out = head(dd)
+    f = head.forward_ret_dict
+    np.testing.assert_allclose(f["cls_preds"].detach().cpu().numpy(), g["cls_preds"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(f["box_preds"].detach().cpu().numpy(), g["box_preds"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(f["dir_cls_preds"].detach().cpu().numpy(), g["dir_cls_preds"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["batch_cls_preds"].cpu().numpy(), g["batch_cls_preds"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["batch_box_preds"].cpu().numpy(), g["batch_box_preds"], atol=5e-4, rtol=1e-4)
+    if mode == "train":                                              # the module path is differentiable end to end
+        (f["cls_preds"].sum() + f["box_preds"].sum()).backward()
+        assert all(p.grad is not None for n, p in head.named_parameters() if not n.startswith("conv_dir_cls"))
+
+
 def test_anchor_loss_restatement_matches_reference_get_loss(golden):
     """cpd_amd.anchor_head.anchor_head_loss_torch against the reference's own AnchorHeadTemplate.get_loss and the gradients its
     autograd produced (tests/golden/anchor_loss.npz, section 12 of make_golden.py). CPU."""

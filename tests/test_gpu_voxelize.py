@@ -99,3 +99,26 @@ def test_batched_voxelizer_equals_per_frame(hip, max_voxels):
         assert torch.equal(voxels[row:row + k], v1) and torch.equal(mean[row:row + k], m1)
         row += k
     assert counts[len(frames)] == row
+
+
+def test_batched_voxelizer_builds_the_level0_site_index(oracle, hip):
+    """cpd_voxelize_batch_index: same voxels as cpd_voxelize_batch, and the site index it leaves behind (over the grid with one
+    more z-level, the backbone's sparse_shape) answers every neighbour lookup like an index built from the coordinates
+    (cpd_index_build) -- with and without the max_voxels cap dropping voxels (dropped voxels are not sites)."""
+    from cpd_amd.synthetic import waymo_cloud
+    vs, rg = [0.1, 0.1, 0.15], [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    clouds = [torch.from_numpy(waymo_cloud(s, n_points=40000 + 7000 * s)).cuda() for s in range(3)] + [torch.zeros((0, 5), device="cuda")]
+    for max_voxels in (1000000, 9000):
+        vox = ops.Voxelizer(vs, rg, 5, 5, max_voxels)
+        g = vox.grid_zyx
+        shape = [g[0] + 1, g[1], g[2]]
+        _, c0, n0, m0, nv0 = vox.batch(clouds)
+        _, c1, n1, m1, nv1, index = vox.batch(clouds, index_z_extra=1)
+        total = int(nv0[-1])
+        assert torch.equal(nv0, nv1) and torch.equal(c0[:total], c1[:total]) and torch.equal(n0[:total], n1[:total])
+        assert torch.equal(m0[:total], m1[:total])
+        coords = c1[:total].contiguous()
+        want = ops.rulebook_subm(coords, ops.SiteIndex.build(coords, len(clouds), shape))
+        got = ops.rulebook_subm(coords, index)
+        assert torch.equal(got, want) and torch.equal(got.tapmask, want.tapmask)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.subm_rulebook(coords.cpu().numpy(), len(clouds), shape, [3, 3, 3]))
