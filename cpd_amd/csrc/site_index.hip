@@ -143,34 +143,77 @@ rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd
     }
 }
 
+// Output sites of a regular (strided) sparse conv: every input site marks the output cells whose receptive field holds it.
+// One thread per input site; for each (z', y') output row it reaches, the x' cells it reaches form a mask inside ONE 64-cell
+// bitmap word (two at a word boundary: the second part goes out on its own). Neighbouring sites of a row -- consecutive lanes
+// in canonical order -- hit the same word, so the masks of a run of lanes with equal word index are OR-ed together in the
+// wave (log-step shuffles) and only the run's last lane touches memory: one test (+ one atomic when a bit is new) per run
+// instead of one per site and tap.
+__device__ __forceinline__ void outset_flush(uint64_t *bitmap, long long word, uint64_t mask, bool valid) {
+    const int lane = threadIdx.x & 63;
+    long long key = valid ? word : -1 - lane;             // invalid lanes get unique keys: they never join a run
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long k2 = __shfl_up(key, d, 64);
+        const uint64_t m2 = __shfl_up(mask, d, 64);
+        if (lane >= d && k2 == key) mask |= m2;             // runs are contiguous: equal keys d apart lie in one run
+    }
+    const long long kn = __shfl_down(key, 1, 64);
+    const bool tail = lane == 63 || kn != key;
+    if (valid && tail && (bitmap[word] & mask) != mask) atomicOr((unsigned long long *)&bitmap[word], (unsigned long long)mask);
+}
+
 __global__ void __launch_bounds__(256)
 outset_mark_kernel(const int32_t *__restrict__ in_idx, int n_in, Grid gout, int kd, int kh, int kw, int sd, int sh, int sw,
                    int pd, int ph, int pw, uint64_t *bitmap) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_in) return;
-    int4 q = reinterpret_cast<const int4 *>(in_idx)[i];
-    if ((unsigned)q.x >= (unsigned)gout.b) return;
+    const bool live = i < n_in;
+    int4 q = make_int4(0, 0, 0, 0);
+    if (live) q = reinterpret_cast<const int4 *>(in_idx)[i];
+    const bool ok = live && (unsigned)q.x < (unsigned)gout.b;
+    // x' cells reached: nx = (q.w + pw - tx) / sw for the taps tx with the right parity: a short ascending run of cells
+    int xlo = 0x7fffffff, xhi = -1;
+    for (int tx = 0; tx < kw; ++tx) {
+        int nx = q.w + pw - tx;
+        if (nx < 0 || nx % sw) continue;
+        nx /= sw;
+        if (nx >= gout.w) continue;
+        xlo = nx < xlo ? nx : xlo;
+        xhi = nx > xhi ? nx : xhi;
+    }
+    // (all lanes of a wave walk the same (tz, ty) loop; a lane without a valid cell for a pair joins the shuffles as invalid)
     for (int tz = 0; tz < kd; ++tz) {
         int nz = q.y + pd - tz;
-        if (nz < 0 || nz % sd) continue;
+        const bool zok = nz >= 0 && nz % sd == 0 && nz / sd < gout.d;
         nz /= sd;
-        if (nz >= gout.d) continue;
         for (int ty = 0; ty < kh; ++ty) {
             int ny = q.z + ph - ty;
-            if (ny < 0 || ny % sh) continue;
+            const bool yok = ny >= 0 && ny % sh == 0 && ny / sh < gout.h;
             ny /= sh;
-            if (ny >= gout.h) continue;
-            for (int tx = 0; tx < kw; ++tx) {
-                int nx = q.w + pw - tx;
-                if (nx < 0 || nx % sw) continue;
-                nx /= sw;
-                if (nx >= gout.w) continue;
-                long long k = gout.key(q.x, nz, ny, nx);
-                uint64_t bit = 1ull << (k & 63);
-                // most marks hit an already-set bit: test first to keep atomics off the hot path
-                if (!(bitmap[k >> 6] & bit))
-                    atomicOr((unsigned long long *)&bitmap[k >> 6], bit);
+            const bool v = ok && zok && yok && xlo <= xhi;
+            if (!__any(v)) continue;
+            long long k0 = 0;
+            uint64_t m0 = 0, m1 = 0;
+            if (v) {
+                k0 = gout.key(q.x, nz, ny, xlo);
+                const int b0 = (int)(k0 & 63), cnt = xhi - xlo + 1;      // cells xlo..xhi are consecutive for sw <= 2 ... (else per cell below)
+                if (sw <= 2 || cnt == 1) {
+                    const uint64_t run = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+                    m0 = run << b0;
+                    m1 = b0 + cnt > 64 ? run >> (64 - b0) : 0ull;
+                } else {                                                  // sparse x' set (stride > 2): mark cell by cell
+                    for (int tx = 0; tx < kw; ++tx) {
+                        int nx = q.w + pw - tx;
+                        if (nx < 0 || nx % sw) continue;
+                        nx /= sw;
+                        if (nx >= gout.w) continue;
+                        const int b = b0 + (nx - xlo);
+                        if (b < 64) m0 |= 1ull << b; else m1 |= 1ull << (b - 64);
+                    }
+                }
             }
+            outset_flush(bitmap, k0 >> 6, m0, v);
+            if (__any(v && m1)) outset_flush(bitmap, (k0 >> 6) + 1, m1, v && m1);
         }
     }
 }
@@ -316,6 +359,7 @@ extern "C" int cpd_conv_outset(const int32_t *in_indices, int n_in, int batch, c
     Grid g{batch, os[0], os[1], os[2]};
     CPD_HIP_TRY(hipMemsetAsync(v.bitmap, 0, (size_t)v.words * 8, s));
     CPD_HIP_TRY(hipMemsetAsync(v.flags, 0, 4, s));  // canonical: rank == row id, perm unused
+    if (ksize[2] > 32) return CPD_ERR_UNSUPPORTED;            // (a site's x' cells must fit two bitmap words)
     if (n_in > 0)
         outset_mark_kernel<<<cpd_div_up(n_in, 256), 256, 0, s>>>(in_indices, n_in, g, ksize[0], ksize[1], ksize[2],
                                                                  stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],

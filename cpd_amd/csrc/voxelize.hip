@@ -298,16 +298,31 @@ __global__ void __launch_bounds__(256) vox_assign_batch_kernel(int n, int32_t ce
     o[0] = f; o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
 }
 
+// Consecutive returns of a beam often fall into one voxel: lanes of a wave with the same voxel form a RUN (in point order).
+// The run's last lane adds the run length to the voxel's count in one atomic, and a lane that has max_points earlier lanes of
+// its own run can never hold one of the voxel's max_points smallest indices, so it skips the cascade altogether.
 __global__ void __launch_bounds__(256) vox_insert_batch_kernel(int n, int P, const int32_t *__restrict__ prank,
                                                                const int32_t *__restrict__ vid, int32_t *slots,
                                                                int32_t *counts) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t r = prank[i];
-    if (r < 0) return;
-    const int32_t v = vid[r];
-    if (v < 0) return;                                          // voxel beyond its frame's max_voxels
-    atomicAdd(&counts[v], 1);
+    const int lane = threadIdx.x & 63;
+    int32_t v = -1;
+    if (i < n) {
+        const int32_t r = prank[i];
+        if (r >= 0) v = vid[r];                                  // < 0: voxel beyond its frame's max_voxels
+    }
+    const int32_t key = v >= 0 ? v : -1 - lane;                  // invalid lanes never join a run
+    int pos = 0;                                                 // lanes before this one in its run
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t k2 = __shfl_up(key, d, 64);
+        const int p2 = __shfl_up(pos, d, 64);
+        if (lane >= d && k2 == key && pos == d - 1) pos += p2 + 1;   // the run reaches back at least d lanes: append the earlier part
+    }
+    const int32_t kn = __shfl_down(key, 1, 64);
+    if (v < 0) return;
+    if (lane == 63 || kn != key) atomicAdd(&counts[v], pos + 1);
+    if (pos >= P) return;
     int32_t x = i;
     int32_t *s = slots + (size_t)v * P;
     for (int p = 0; p < P; ++p) {
