@@ -93,6 +93,7 @@ class ConvProfiler:
         self.records = []
         self.pairs_cache = {}
         self._orig = None
+        self.bytes_total = 0.0
 
     def _pairs(self, nbr, n_out, c_in=0, c_out=0):
         if nbr is None:
@@ -112,7 +113,16 @@ class ConvProfiler:
         def wrapped(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
             kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False), kw.get("bf16x3", False), nbr,
                                          math=kw.get("math"))
-            flops = 2.0 * prof._pairs(nbr, n_out, c_in, c_out) * c_in * c_out
+            pairs = prof._pairs(nbr, n_out, c_in, c_out)
+            flops = 2.0 * pairs * c_in * c_out
+            # algorithmic HBM bytes of the layer: every feature row once in and once out, the weights, the
+            # residual when there is one, and -- sparse layers only -- 8 bytes per (input, output) pair of the rulebook
+            dense = bool(kw.get("dense", False))
+            res = kw.get("residual", a[2] if len(a) > 2 else None)
+            nbytes = 4.0 * (inp.shape[0] * c_in + n_out * c_out) + 4.0 * kv * c_in * c_out + (0.0 if dense or nbr is None else 8.0 * pairs)
+            if res is not None:
+                nbytes += 4.0 * n_out * c_out
+            prof.bytes_total += nbytes
             if kw.get("out") is None:          # allocate before the window: an allocator miss (hipMalloc) stalls the host,
                 kw["out"] = torch.empty((n_out, c_out), dtype=torch.float32, device=inp.device)   # and the GPU idles meanwhile
             s = torch.cuda.current_stream()
@@ -227,10 +237,10 @@ class HbmStageProfiler:
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_summary.json: 2 x FETCH_SIZE + WRITE_SIZE, per MI355X_MICROARCH.md), or None.
+    (profiles/r02_pmc_summary.json: 2 x FETCH_SIZE + WRITE_SIZE, per MI355X_MICROARCH.md), or None.
     bench.py cannot run the counters itself; the number is from the same command's PMC run."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r02_pmc_summary.json")) as f:
             k = json.load(f)["kernels"].get(kernel)
         return k["hbm_bytes_per_launch_corrected"] if k else None
     except Exception:
@@ -437,6 +447,7 @@ def main():
             run_steps(max(S, POOL // max(1, B) + 1))      # settle the allocator with the profiler's own temporaries in play
             torch.cuda.synchronize()
             prof.records.clear()
+            prof.bytes_total = 0.0
             run_steps(n_prof)
             agg, conv_ms = prof.summary()
             if args.layers and rank == 0:
@@ -449,12 +460,14 @@ def main():
         key, (flops, ms, launches) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12
         conv_flops = sum(v[0] for v in agg.values()) / (n_prof * B)        # algorithmic conv flop per frame
+        conv_bytes = prof.bytes_total / (n_prof * B)                       # algorithmic conv HBM bytes per frame
         peak, peak_basis = kernel_peak(key)
         out["roofline"] = {
             "bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "peak_basis": peak_basis, "achieved_over_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
             "traffic": pmc_traffic(key),
-            "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_summary.json)",
+            "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 --pmc passes of this "
+                            "command, profiles/r02_pmc_summary.json; bench.py cannot collect counters itself)",
             "launches_per_frame": launches / (n_prof * B), "avg_launch_us": 1e3 * ms / launches,
             "algorithmic_gflop_per_launch": flops / launches / 1e9,
             "note": "per-launch figures measured with %d concurrent stream(s): a launch shares the chip with the other "
@@ -472,6 +485,15 @@ def main():
         with HbmStageProfiler() as hp:
             run_steps(max(S, 2))
             out["hbm_stages"] = hp.summary(max(S, 2) * B)
+        # the whole path against the HBM roofline (north_star): all algorithmic bytes of a frame -- voxelizer, rulebooks, every
+        # conv layer (sparse and dense), densify -- over the measured time per frame and the 8 TB/s peak. The path is bound by
+        # the matrix pipe in its dense half, so this fraction is small by construction; the conv kernels' own ceiling is `frac`.
+        stage_bytes = sum(v["algorithmic_MB_per_frame"] * 1e6 for k, v in out["hbm_stages"].items() if k != "sparse_conv_c<=16")
+        path_bytes = conv_bytes + stage_bytes
+        sec_per_frame = 1.0 / (out["value"] / world)
+        out["roofline"]["path_hbm_frac"] = path_bytes / sec_per_frame / 8.0e12
+        out["roofline"]["path_algorithmic_MB_per_frame"] = path_bytes / 1e6
+        out["roofline"]["path_hbm_floor_ms_per_frame"] = path_bytes / 8.0e12 * 1e3
         out["hbm_stages"]["note"] = ("algorithmic bytes (SURVEY 8d) / HIP-event time of each call (one call = all its launches), "
                                      "single stream; peak = 8 TB/s nominal HBM3E")
 

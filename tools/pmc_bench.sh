@@ -1,12 +1,13 @@
 #!/bin/bash
-# Round profile set for the default bench (run on the GPU box through gpurun, from the repo root):
-#   gpurun_out/r01_pmc_summary.json         three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy), done FIRST and
-#                                           copied to profiles/ so that the bench lines below carry the fresh `traffic`
-#   gpurun_out/r01_bench.json               python bench.py
-#   gpurun_out/r01_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/r01_bench_under_rocprof.json bench line of that profiled run
+# Round profile set for the default bench (run on the GPU box through gpurun, from the repo root):  tools/pmc_bench.sh r02
+#   profiles/<tag>_pmc_summary.json          three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy), done FIRST so
+#                                            that the bench lines below carry the fresh `traffic`
+#   profiles/<tag>_bench.json                python bench.py
+#   profiles/<tag>_bench_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
+#   profiles/<tag>_bench_under_rocprof.json  bench line of that profiled run
+tag=${1:-r02}
 R=$PWD
-mkdir -p $R/gpurun_out
+mkdir -p $R/gpurun_out $R/profiles
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/pmc
 CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
@@ -14,10 +15,18 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc/write -o p -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $R/gpurun_out/pmc/mfma -o p -- $CMD > /dev/null 2>&1
 cd $R
-python tools/pmc_summary.py gpurun_out/pmc gpurun_out/r01_pmc_summary.json
-cp gpurun_out/r01_pmc_summary.json profiles/r01_pmc_summary.json
-python bench.py > $R/gpurun_out/r01_bench.json 2> $R/gpurun_out/r01_bench.err
+python tools/pmc_summary.py gpurun_out/pmc gpurun_out/${tag}_pmc_summary.json > /dev/null
+cp gpurun_out/${tag}_pmc_summary.json profiles/${tag}_pmc_summary.json
+python bench.py > $R/gpurun_out/${tag}_bench.json 2> $R/gpurun_out/${tag}_bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/r01_bench_under_rocprof.json 2>/dev/null
-cp $(ls $R/gpurun_out/prof_stats/*/*kernel_stats.csv | head -1) $R/gpurun_out/r01_bench_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
+cp $(ls $R/gpurun_out/prof_stats/*/*kernel_stats.csv | head -1) $R/gpurun_out/${tag}_bench_kernel_stats.csv
 cd $R
+python tools/prof_summary.py gpurun_out/${tag}_bench_kernel_stats.csv gpurun_out/${tag}_bench_under_rocprof.json 52 16
+python - <<PY
+import json
+d = json.load(open("gpurun_out/${tag}_bench.json")); r = d["roofline"]
+print("bench: %.1f frames/s, %.2f ms/step; dominant %s: %.1f TF = %.3f of %.0f, launch %.1f us, traffic %s; path_hbm_frac %.3f" %
+      (d["value"], d["ms_per_step"], r["kernel"], r["achieved"], r["frac"], r["peak"], r["avg_launch_us"], r["traffic"], r.get("path_hbm_frac", -1)))
+print("cpu_baseline", d.get("cpu_baseline"))
+PY
