@@ -68,6 +68,7 @@ SIGNATURES = {
     "cpd_bn_stats": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_mask_points_workspace_bytes": (_SZ, [_I]),
     "cpd_mask_points_by_range": (_I, [_VP, _I, _I, _FP, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_merge_sweeps": (_I, [_VP, _I3, _I, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _VP, _VP]),
     "cpd_points_in_boxes": (_I, [_I, _I, _I, _VP, _VP, _I, _F, _VP, _VP]),
     "cpd_nearest_bev_iou": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
     "cpd_anchor_assign_workspace_bytes": (_SZ, [_I, _I]),

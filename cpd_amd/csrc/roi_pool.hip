@@ -421,6 +421,60 @@ extern "C" int cpd_mask_points_by_range(const float *points, int n, int c, const
                        CompactRowsFn{points, out, c}, (uint32_t *)workspace, n_out, -1, cpd_s(st));
 }
 
+// Multi-sweep merge (waymo_unsupervised_dataset.py:192-202 points_rigid_transform, 333-360 get_frame): every sweep's points go
+// sweep -> world (its own pose) and world -> current frame (inverse of the current pose), each product formed in float64 from
+// the float32 coordinates and rounded to float32 -- the reference's np.mat arithmetic on float32 clouds --, intensity
+// (column 3) and the last column are zeroed, sweeps are concatenated in order.
+#define CPD_MAX_SWEEPS 16
+struct SweepPoses {
+    int32_t n;
+    int32_t off[CPD_MAX_SWEEPS + 1];
+    double pose[CPD_MAX_SWEEPS][12];      // rows 0..2 of the 4x4 sweep -> world matrices
+    double cur_inv[12];                   // rows 0..2 of inverse(current pose)
+};
+__device__ __forceinline__ void rigid3(const double (&m)[12], float x, float y, float z, float &ox, float &oy, float &oz) {
+    // no fused multiply-add: (a*b) rounded, then added, like a scalar dgemm without FMA contraction
+    const double dx = x, dy = y, dz = z;
+    ox = (float)(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m[0], dx), __dmul_rn(m[1], dy)), __dmul_rn(m[2], dz)), m[3]));
+    oy = (float)(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m[4], dx), __dmul_rn(m[5], dy)), __dmul_rn(m[6], dz)), m[7]));
+    oz = (float)(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m[8], dx), __dmul_rn(m[9], dy)), __dmul_rn(m[10], dz)), m[11]));
+}
+__global__ void __launch_bounds__(256) merge_sweeps_kernel(const float *__restrict__ pts, int n, int c, SweepPoses sp,
+                                                           float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s = 0;
+    while (s + 1 < sp.n && i >= sp.off[s + 1]) ++s;
+    const float *p = pts + (size_t)i * c;
+    float x, y, z, x2, y2, z2;
+    rigid3(sp.pose[s], p[0], p[1], p[2], x, y, z);
+    rigid3(sp.cur_inv, x, y, z, x2, y2, z2);
+    float *o = out + (size_t)i * c;
+    o[0] = x2; o[1] = y2; o[2] = z2;
+    for (int k = 3; k < c; ++k) o[k] = (k == 3 || k == c - 1) ? 0.f : p[k];
+}
+
+extern "C" int cpd_merge_sweeps(const float *points, const int32_t *sweep_offsets, int n_sweeps, int c, const double *poses,
+                                const double *cur_pose_inv, float *out, cpd_stream_t st) {
+    if (!sweep_offsets || n_sweeps <= 0 || c < 4 || !poses || !cur_pose_inv) return CPD_ERR_ARG;
+    if (n_sweeps > CPD_MAX_SWEEPS) return CPD_ERR_UNSUPPORTED;
+    SweepPoses sp;
+    sp.n = n_sweeps;
+    for (int s = 0; s <= n_sweeps; ++s) {
+        sp.off[s] = sweep_offsets[s];
+        if (sweep_offsets[s] < 0 || (s > 0 && sweep_offsets[s] < sweep_offsets[s - 1])) return CPD_ERR_ARG;
+    }
+    if (sweep_offsets[0] != 0) return CPD_ERR_ARG;
+    for (int s = 0; s < n_sweeps; ++s)
+        for (int k = 0; k < 12; ++k) sp.pose[s][k] = poses[(size_t)s * 16 + k];
+    for (int k = 0; k < 12; ++k) sp.cur_inv[k] = cur_pose_inv[k];
+    const int n = sweep_offsets[n_sweeps];
+    if (n == 0) return CPD_OK;
+    if (!points || !out) return CPD_ERR_ARG;
+    merge_sweeps_kernel<<<cpd_div_up(n, 256), 256, 0, cpd_s(st)>>>(points, n, c, sp, out);
+    return cpd_check_launch();
+}
+
 extern "C" int cpd_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts, int pts_ld,
                                    float margin, int32_t *box_idx_of_points, cpd_stream_t st) {
     if (batch < 0 || boxes_num < 0 || pts_num < 0 || pts_ld < 3 || !box_idx_of_points ||

@@ -5,10 +5,15 @@ voxelizer, so the voxelizer consumes device points directly.
   shuffle_points            data_processor.py:103-120 (np.random.permutation; the permutation is an input)
   points_in_boxes_gpu       cpd/ops/roiaware_pool3d/roiaware_pool3d_utils.py (points_in_boxes_gpu) ->
                             roiaware_pool3d_kernel.cu:313-336
+  merge_sweeps              waymo_unsupervised_dataset.py:333-360 (get_frame: every sweep through its own pose and the
+                            inverse of the current pose, points_rigid_transform l.192-202; intensity / last column zeroed)
 """
+import ctypes
+
+import numpy as np
 import torch
 
-from ._lib import check, farr, lib, ptr, stream
+from ._lib import check, farr, iarr, lib, ptr, stream
 
 
 def mask_points_by_range(points, limit_range):
@@ -37,4 +42,22 @@ def points_in_boxes_gpu(points, boxes, margin=1e-5):
     out = torch.empty((b, m), dtype=torch.int32, device=points.device)
     check(lib().cpd_points_in_boxes(b, boxes.shape[1], m, ptr(boxes), ptr(points), 3, float(margin), ptr(out), stream()),
           "cpd_points_in_boxes")
+    return out
+
+
+def merge_sweeps(sweeps, poses, cur_pose):
+    """get_frame's multi-sweep merge on the device: `sweeps` = list of [N_i, C] f32 device tensors (oldest first), `poses` their
+    4x4 sweep -> world matrices, `cur_pose` the current frame's pose (its inverse is taken here in float64 like the
+    reference's np.linalg.inv). Returns the concatenated [sum N_i, C] cloud in the current frame."""
+    assert len(sweeps) == len(poses) and len(sweeps) > 0
+    pts = torch.cat([s.contiguous().float() for s in sweeps]) if len(sweeps) > 1 else sweeps[0].contiguous().float()
+    offs = [0]
+    for s in sweeps:
+        offs.append(offs[-1] + s.shape[0])
+    P = np.ascontiguousarray(np.stack([np.asarray(p, np.float64).reshape(4, 4) for p in poses]))
+    inv = np.ascontiguousarray(np.linalg.inv(np.asarray(cur_pose, np.float64).reshape(4, 4)))
+    out = torch.empty_like(pts)
+    dp = ctypes.POINTER(ctypes.c_double)
+    check(lib().cpd_merge_sweeps(ptr(pts), iarr(offs), len(sweeps), pts.shape[1], P.ctypes.data_as(dp), inv.ctypes.data_as(dp),
+                                 ptr(out), stream()), "cpd_merge_sweeps")
     return out

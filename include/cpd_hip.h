@@ -408,6 +408,13 @@ int cpd_voxel_pool_max(int m, int c, int nsample, const float *features_in, int 
 size_t cpd_mask_points_workspace_bytes(int n);
 int cpd_mask_points_by_range(const float *points, int n, int c, const float range_xyz[6], float *out,
                              int32_t *n_out, void *workspace, size_t workspace_bytes, cpd_stream_t stream);
+/* Multi-sweep merge (waymo_unsupervised_dataset.py:333-360 get_frame with 192-202 points_rigid_transform): the sweeps'
+ * points [sweep_offsets[n_sweeps], c] (sweeps back to back; sweep_offsets, poses and cur_pose_inv are HOST arrays) are taken
+ * sweep -> world by poses[s] (row-major 4x4 float64) and world -> current frame by cur_pose_inv = inverse(current pose),
+ * each product formed in float64 from the float32 coordinates and rounded to float32 as the reference's np.mat arithmetic
+ * does; column 3 (intensity) and the last column are set to 0 (l.347-351); other columns are copied. n_sweeps <= 16. */
+int cpd_merge_sweeps(const float *points, const int32_t *sweep_offsets, int n_sweeps, int c, const double *poses,
+                     const double *cur_pose_inv, float *out, cpd_stream_t stream);
 /* points_in_boxes_gpu (roiaware_pool3d_kernel.cu:313-336; check_pt_in_box3d l.23-35 uses MARGIN
  * 1e-5, the CPU twin roiaware_pool3d.cpp:128-140 1e-2): boxes [batch, boxes_num, 7], pts
  * [batch, pts_num, pts_ld >= 3] -> box_idx_of_points [batch, pts_num] = first containing box or -1. */

@@ -75,3 +75,50 @@ def test_hip_prefilter_matches_oracle(oracle, hip):
         np.testing.assert_array_equal(got[b][ok], want[b][ok])
         assert ok.mean() > 0.9
     assert (want >= 0).mean() > 0.3
+
+
+@pytest.mark.gpu
+def test_merge_sweeps_matches_the_reference_arithmetic(hip):
+    """cpd_merge_sweeps against the arithmetic of get_frame / points_rigid_transform (waymo_unsupervised_dataset.py:192-202,
+    333-360) restated with the same numpy operations: float32 coordinates in a float32 [N, 4] matrix, np.mat products with the
+    float64 pose (sweep -> world, then inverse of the current pose), each result cast to float32; intensity and the last
+    column zeroed; sweeps concatenated oldest first. Coordinates agree to float32 rounding (the 4-term float64 dot products
+    may be summed in another order by BLAS), everything else exactly."""
+    import torch
+    from cpd_amd import prefilter
+    rng = np.random.default_rng(5)
+
+    def pose(yaw, t):
+        m = np.eye(4)
+        m[:2, :2] = [[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]
+        m[:3, 3] = t
+        return m
+
+    poses = [pose(0.3 + 0.01 * i, [1200.5 + 1.7 * i, -830.25 + 0.4 * i, 12.0 + 0.02 * i]) for i in range(4)]
+    sweeps = [np.concatenate([rng.uniform(-75, 75, (n, 2)), rng.uniform(-2, 4, (n, 1)), rng.uniform(0, 1, (n, 3))], 1).astype(np.float32)
+              for n in (5000, 0, 3333, 4097)]
+
+    def rigid(cloud, P):                                     # the reference's points_rigid_transform, operation for operation
+        if cloud.shape[0] == 0:
+            return cloud
+        mat = np.ones((cloud.shape[0], 4), np.float32)
+        mat[:, 0:3] = cloud[:, 0:3]
+        return np.array((np.asmatrix(P) * np.asmatrix(mat).T).T, dtype=np.float32)[:, 0:3]     # np.mat == np.asmatrix (NumPy < 2)
+
+    cur_inv = np.linalg.inv(poses[-1])
+    want = []
+    for s, P in zip(sweeps, poses):
+        q = s.copy()
+        q[:, 3] = 0
+        q[:, 0:3] = rigid(q[:, 0:3], P)
+        q[:, 0:3] = rigid(q[:, 0:3], cur_inv)
+        q[:, -1] = 0
+        want.append(q)
+    want = np.concatenate(want)
+    got = prefilter.merge_sweeps([torch.from_numpy(s).cuda() for s in sweeps], poses, poses[-1]).cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got[:, 3:], want[:, 3:])
+    np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=0, atol=2e-5)     # world coordinates ~1e3: float32 ulp 1.2e-4 before the second product
+    assert np.mean(got[:, :3] == want[:, :3]) > 0.99
+    # the current sweep maps onto itself up to the two roundings
+    np.testing.assert_allclose(got[-4097:, :3], sweeps[-1][:, :3], atol=2e-4)
