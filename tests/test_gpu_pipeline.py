@@ -217,6 +217,69 @@ def test_mm_branch_runs_in_training_mode_only(hip):
         assert "multi_scale_3d_features_mm" not in bb.eval()(dict(batch))
 
 
+def test_mm_branch_all_levels_match_oracle(oracle, hip):
+    """The `MM: True` prototype encoder (spconv_backbone.py:456-486,560-598: conv_input_2, conv1_2 with two residual blocks,
+    conv2_2 / conv3_2 / conv4_2 with a strided conv and ONE residual block each) runs in training mode, i.e. on batch-statistics
+    BatchNorm: all four levels of multi_scale_3d_features_mm against the same graph walked on the CPU oracle (its rulebooks and
+    sparse convolutions, batch-stat BatchNorm in numpy) -- indices bit-exact in canonical order, features <= 1e-4."""
+    from cpd_amd import models
+    cfg = models.waymo_centerpoint_cfg()
+    cfg.BACKBONE_3D.MM = True
+    torch.manual_seed(11)
+    grid = [400, 400, 40]
+    bb = models.VoxelResBackBone8x(cfg.BACKBONE_3D, input_channels=5, grid_size=grid).cuda().train()
+    with torch.no_grad():
+        for mod in bb.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.uniform_(0.6, 1.4); mod.bias.normal_(0, 0.2)
+    rng = np.random.default_rng(4)
+    zyx = np.unique(np.concatenate([rng.integers([0, 100, 100], [41, 260, 260], size=(9000, 3)),
+                                    rng.integers([5, 150, 150], [20, 200, 200], size=(6000, 3))]), axis=0)
+    rng.shuffle(zyx)
+    b = rng.integers(0, 2, (zyx.shape[0], 1))
+    coords = np.concatenate([b, zyx], 1).astype(np.int32)
+    feats = rng.normal(size=(coords.shape[0], 5)).astype(np.float32)
+    batch = {"voxel_features": torch.from_numpy(feats).cuda(), "voxel_coords": torch.from_numpy(coords).float().cuda(),
+             "voxel_features1": torch.from_numpy(feats).cuda(), "voxel_coords1": torch.from_numpy(coords).float().cuda(), "batch_size": 2}
+    with torch.no_grad():
+        mm = bb(batch)["multi_scale_3d_features_mm"]
+    sd = {k: v.detach().cpu().numpy() for k, v in bb.state_dict().items()}
+
+    def bn_train(x, name):
+        mean = x.astype(np.float64).mean(0)
+        var = x.astype(np.float64).var(0)                                  # biased, as BatchNorm normalises in training mode
+        y = (x - mean) / np.sqrt(var + 1e-3) * sd[name + ".weight"] + sd[name + ".bias"]
+        return y.astype(np.float32)
+
+    relu = lambda v: np.maximum(v, np.float32(0))
+    conv = lambda name, x, nbr: oracle.sparse_conv(x, sd[name + ".weight"], sd.get(name + ".bias"), nbr)
+
+    def block(name, x, nbr):
+        y = relu(bn_train(conv(name + ".conv1", x, nbr), name + ".bn1"))
+        y = bn_train(conv(name + ".conv2", y, nbr), name + ".bn2")
+        return relu(y + x)
+
+    shape = [41, 400, 400]
+    nbr = oracle.subm_rulebook(coords, 2, shape, [3, 3, 3])
+    x = relu(bn_train(conv("conv_input_2.0", feats, nbr), "conv_input_2.1"))
+    x = block("conv1_2.0", x, nbr)
+    x = block("conv1_2.1", x, nbr)
+    want = {"x_conv1": (x, coords)}
+    cur = coords
+    for i, (stage, k, s, pd) in enumerate([("conv2_2", [3, 3, 3], [2, 2, 2], [1, 1, 1]), ("conv3_2", [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                                           ("conv4_2", [3, 3, 3], [2, 2, 2], [0, 1, 1])], start=2):
+        out_idx = oracle.conv_outset(cur, 2, shape, k, s, pd)
+        nbr_dn = oracle.conv_rulebook(cur, out_idx, 2, shape, k, s, pd)
+        x = relu(bn_train(conv(stage + ".0.0", x, nbr_dn), stage + ".0.1"))
+        shape = oracle.conv_out_shape(shape, k, s, pd)
+        cur = out_idx
+        x = block(stage + ".1", x, oracle.subm_rulebook(cur, 2, shape, [3, 3, 3]))
+        want["x_conv%d" % i] = (x, cur)
+    for name, (f0, i0) in want.items():
+        np.testing.assert_array_equal(mm[name].indices.cpu().numpy(), i0, err_msg=name)
+        np.testing.assert_allclose(mm[name].features.cpu().numpy(), f0, atol=1e-4, rtol=0, err_msg=name)
+
+
 def test_empty_ragged_and_out_of_range_inputs(hip):
     """Edge cases of the batch contract: an empty cloud, a 5-point cloud and a cloud entirely outside the
     range, alone and mixed into a batch; a frame's detections do not depend on its neighbours."""
