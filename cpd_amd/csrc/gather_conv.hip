@@ -1008,6 +1008,19 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
                 for (int j = 0; j < BJ; ++j)
                     if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
             }
+            if (LINES && (CPD_GC_ABLATE & 64)) {          // timing only: full-line gathers fed to the MFMAs untransposed (wrong results)
+#pragma unroll
+                for (int s = 0; s < MS; ++s) {
+                    if (sub_on(s, t)) {
+                        typename S::half lo[NP], hi[NP];
+                        S::split(araw[R][s][0], lo);
+                        S::split(araw[R][s][1], hi);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
+                    }
+                }
+                return;
+            }
             if (LINES) {
 #pragma unroll
                 for (int j = 0; j < 2 * MS; ++j)
@@ -1131,7 +1144,7 @@ rowwave_conv_bf16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitBf16x3, BN, MS>(p);
 }
 template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS == 4 ? 2 : (BN == 128 && MS == 2 ? 3 : 4), 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS == 4 && BN >= 64 ? 2 : (BN == 128 && MS == 2 ? 3 : 4), 8)))
 rowwave_conv_f16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitF16x2, BN, MS>(p);
 }
@@ -1152,6 +1165,130 @@ template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
 rowwaveL_conv_f16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitF16x2, BN, MS, 1, true>(p);
+}
+
+// Split WAVE kernel for narrow sparse layers (32 channels): one wave64 owns 16*MS rows x 16*NT columns over all taps, like the
+// fp32 wave kernel -- no LDS, no barriers. With so few columns a (tap, 32-channel) weight block is 4 KB: every wave reads its
+// B fragments straight from the L1/L2-resident split image (a lane's fragment of one piece is one 16-byte load) instead of
+// meeting the other waves at two barriers per tap around an LDS copy, and the row-wave kernel's per-stage skeleton goes away.
+// Rows are gathered one stage ahead into a second register set; stage order (channel block outer, tap inner).
+template <class S, int MS, int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) wavesplit_conv_f16_kernel(GcParams p) {
+    constexpr int NP = S::NP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (item >= p.items) return;
+    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = rb * (16 * MS), col0 = cb * (16 * NT);
+
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t my_mask[MS], any = 0;
+    int rowc[MS];
+    bool row_ok[MS];
+#pragma unroll
+    for (int s = 0; s < MS; ++s) {
+        const int sub = rb * MS + s;
+        uint32_t m = 0xffffffffu;
+        if (p.tapmask) m = sub < p.n_sub ? p.tapmask[sub] : 0u;
+        else if (row0 + 16 * s >= p.n_out) m = 0u;
+        my_mask[s] = __builtin_amdgcn_readfirstlane(m);
+        any |= my_mask[s];
+        const int row = row0 + 16 * s + r;
+        row_ok[s] = row < p.n_out;
+        rowc[s] = row_ok[s] ? row : p.n_out - 1;
+    }
+    if (p.kv < 32) any &= (1u << p.kv) - 1u;
+    const int sk = p.c_in >> 5;
+    const size_t b_stage = (size_t)NP * 4 * p.np * 16;          // bytes of one (tap, k32) block of the split image
+    const size_t b_piece = (size_t)4 * p.np * 16;
+    const char *const wlane = reinterpret_cast<const char *>(p.wb) + ((size_t)g * p.np + col0 + r) * 16;
+
+    if (any) {
+        const int t_first = __builtin_ctz(any);
+        auto next_tap = [&](int t) -> int {
+            const uint32_t m = t >= 31 ? 0u : (any & ~((2u << t) - 1u));
+            return m ? __builtin_ctz(m) : -1;
+        };
+        auto advance = [&](int &t, int &kk) -> bool {            // channel block outer, tap inner
+            const int tn = next_tap(t);
+            if (tn >= 0) { t = tn; return true; }
+            t = t_first;
+            return ++kk < sk;
+        };
+        auto sub_on = [&](int s, int t) { return (my_mask[s] >> t) & 1u; };
+        auto load_idx = [&](int t, int (&idx)[MS]) {
+#pragma unroll
+            for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
+        };
+        f32x4 araw[2][MS][2];
+        bool az[2][MS];
+        auto load_rows = [&](auto SET, int t, int kk, const int (&idx)[MS]) {
+            constexpr int R = decltype(SET)::value;
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                if (sub_on(s, t)) {
+                    const int id = row_ok[s] ? idx[s] : -1;
+                    az[R][s] = id < 0;
+                    araw[R][s][0] = load_a<true>(p, id, kk * 32 + g * 8);
+                    araw[R][s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
+                }
+            }
+        };
+        auto compute = [&](auto SET, int t, int kk) {
+            constexpr int R = decltype(SET)::value;
+            const char *wt = wlane + ((size_t)t * sk + kk) * b_stage;
+            typename S::frag b[NT][NP];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b[nt][q] = *reinterpret_cast<const typename S::frag *>(wt + q * b_piece + (size_t)nt * 256);
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                if (sub_on(s, t)) {
+                    typename S::half lo[NP], hi[NP];
+                    S::split(zero_if(araw[R][s][0], az[R][s]), lo);
+                    S::split(zero_if(araw[R][s][1], az[R][s]), hi);
+                    typename S::frag a[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) a[q] = join_halves<S>(lo[q], hi[q]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[s][nt] = S::mma(a, b[nt], acc[s][nt]);
+                }
+            }
+        };
+        using Set0 = std::integral_constant<int, 0>;
+        using Set1 = std::integral_constant<int, 1>;
+        int tc = t_first, kc = 0;
+        int t1 = tc, k1 = kc; bool ok1 = advance(t1, k1);
+        int t2 = t1, k2 = k1; bool ok2 = ok1 && advance(t2, k2);
+        int idx_a[MS], idx_b[MS];
+        load_idx(tc, idx_a);
+        load_rows(Set0{}, tc, kc, idx_a);
+        if (ok1) load_idx(t1, idx_b);
+        auto step = [&](auto CUR, auto NXT) -> bool {
+            if (ok1) load_rows(NXT, t1, k1, idx_b);
+            if (ok2) load_idx(t2, idx_a);
+            compute(CUR, tc, kc);
+            if (!ok1) return false;
+            tc = t1; kc = k1;
+            t1 = t2; k1 = k2; ok1 = ok2;
+            if (ok2) ok2 = advance(t2, k2);
+#pragma unroll
+            for (int s = 0; s < MS; ++s) idx_b[s] = idx_a[s];
+            return true;
+        };
+        while (true) {
+            if (!step(Set0{}, Set1{})) break;
+            if (!step(Set1{}, Set0{})) break;
+        }
+    }
+    epilogue<MS, NT>(p, acc, row0, col0, r, g);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -1392,10 +1529,16 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
         long long rw_min = 256, rw_floor = 128;
         if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_MIN")) rw_min = atoll(e);
         if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_FLOOR")) rw_floor = atoll(e);
+        int wsplit = 0;                                       // barrier-free split wave kernel for 32-column layers (f16x2)
+        if (const char *e = cpd_knob(tn, "CPD_GC_WAVESPLIT")) wsplit = atoi(e);
+        if (wsplit && pl.math == 2 && c_out == 32 && (n_out + 31) / 32 >= 1024) {
+            pl.use_wg = 4; pl.a = 2; pl.b = 2;
+            return pl;
+        }
         const long long row_tiles = (n_out + 127) / 128;
         int ms4 = 0;                                          // 256-row workgroups (4 row sub-tiles per wave), f16x2 only
         if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_MS4")) ms4 = atoi(e);
-        if (ms4 && pl.math == 2 && bn >= 64 && (row_tiles / 2) * (c_out / bn) >= rw_min) {
+        if (ms4 && pl.math == 2 && (row_tiles / 2) * (c_out / bn) >= rw_min) {
             pl.use_wg = 3; pl.a = 256; pl.b = bn;
             return pl;
         }
@@ -1546,6 +1689,14 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     if (trace)
         fprintf(stderr, "cpd_gather_conv n_out=%d kv=%d c_in=%d c_out=%d flags=%d masks=%d -> kind=%d tile=(%d,%d)\n", n_out, kv, c_in, c_out,
                 flags, tapmask != nullptr, pl.use_wg, pl.a, pl.b);
+    if (pl.use_wg == 4) {
+        p.wb = packed_f16_ptr(packed_w, kv, c_in, c_out); p.dsc = packed_dsc_ptr(packed_w, kv, c_in, c_out);
+        p.n_rb = (n_out + 16 * pl.a - 1) / (16 * pl.a);
+        p.n_cb = c_out / (16 * pl.b);
+        p.items = p.n_rb * p.n_cb;
+        hipLaunchKernelGGL((wavesplit_conv_f16_kernel<SplitF16x2, 2, 2>), dim3((p.items + 3) / 4), dim3(256), 0, cpd_s(stream), p);
+        return cpd_check_launch();
+    }
     if (pl.use_wg == 2 || pl.use_wg == 3) {
         if (pl.math == 2) { p.wb = packed_f16_ptr(packed_w, kv, c_in, c_out); p.dsc = packed_dsc_ptr(packed_w, kv, c_in, c_out); }
         else p.wb = packed_bf16_ptr(packed_w, kv, c_in, c_out);
@@ -1582,7 +1733,8 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     }
     if (pl.use_wg == 3 && pl.math == 2) {
         if (pl.a == 256) {
-            if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 4>), 0);
+            if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 4>), 0);
+            else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 4>), 0);
             else CPD_LAUNCH((rowwave_conv_f16_kernel<128, 4>), 0);
         } else if (pl.a == 64) {
             if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 1>), 0);
