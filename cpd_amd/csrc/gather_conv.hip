@@ -847,7 +847,7 @@ window_conv_f16_kernel(GcParams p) {
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
 // MS = row sub-tiles per wave: 2 (128-row workgroups) or 1 (64-row workgroups, for layers too small to give every CU a
 // 128-row workgroup: twice the workgroups, each staging the same weights for half the rows).
-template <class S, int BN, int MS, int DEPTH = 1, bool LINES = false, bool GLDS = false>
+template <class S, int BN, int MS>
 __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
     constexpr int NP = S::NP;
     constexpr int NT = BN / 16;
@@ -855,23 +855,13 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
     constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
-    // GLDS: two weight buffers, filled global -> LDS directly (global_load_lds_dwordx4) a stage ahead: no staging registers, no
-    // ds_write pass, one barrier per stage
-    __shared__ __attribute__((aligned(16))) char sb[(GLDS ? 2 : 1) * NP * B_IMG];
-    static_assert(!GLDS || B_SLOTS % 256 == 0, "direct-to-LDS weight stages are whole wave instructions");
-    // LINES: the rows are gathered as FULL 128-byte lines (8 lanes per row, 8 rows per instruction -- what the vector memory
-    // pipe moves at full rate; fragment-shaped loads of 16 rows x 16 bytes cost it 4 accesses per lane quad) and turned into
-    // MFMA fragments through a wave-private LDS image [row][piece ^ swz(row)] (written and read by the same wave: no barrier)
-    __shared__ __attribute__((aligned(16))) char sa_all[LINES ? 4 * 16 * MS * 128 : 16];
+    __shared__ __attribute__((aligned(16))) char sb[NP * B_IMG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int item = xcd_remap(blockIdx.x, gridDim.x);
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
     const int row0 = rb * WG_ROWS + wave * (16 * MS), col0 = cb * BN;
-    char *const sa = sa_all + (LINES ? wave * (16 * MS * 128) : 0);
-    auto swz = [](int rw) { return (((rw >> 1) & 3) * 2) ^ ((rw >> 3) & 1); };   // conflict-free fragment reads (bank model)
-    const int lq = lane >> 3, lp = lane & 7;       // LINES: row within an 8-row group, 16-byte piece of the 128-byte line
 
     // tap activity: workgroup-wide (which stages exist) and per sub-tile of this wave
     uint32_t wg_mask = 0xffffffffu, my_mask[MS];
@@ -912,28 +902,16 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
     while (t_first < p.kv && !tap_on(t_first)) ++t_first;
     if (t_first < p.kv) {
         auto next_tap = [&](int t) { do { ++t; } while (t < p.kv && !tap_on(t)); return t; };
-        constexpr int NI = LINES ? 2 * MS : MS;        // rulebook entries a lane needs per tap
-        auto load_idx = [&](int t, int (&idx)[NI]) {
-            if (LINES) {
+        auto load_idx = [&](int t, int (&idx)[MS]) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    int row = row0 + 8 * j + lq;
-                    const bool ok = row < p.n_out;
-                    row = ok ? row : p.n_out - 1;
-                    const int v = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
-                    idx[j] = ok ? v : -1;
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
-            }
+            for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
         };
         auto sub_on = [&](int s, int t) { return t >= 32 || ((my_mask[s] >> t) & 1u); };
 
-        // Stage order: (tap outer, 32-channel block inner), or -- p.taps_inner -- (block outer, tap inner): the taps of one
-        // channel block re-gather neighbouring rows' same 128-byte segments back to back, which hits L2 when the row order
-        // keeps neighbours close. Either way the stages form one flat sequence; the rulebook column of a stage is fetched
-        // two stages ahead of its use (one stage ahead of the gathers it addresses).
+        // Stage order: (tap outer, 32-channel block inner), or -- p.taps_inner, the default -- (block outer, tap inner): the
+        // taps of one channel block re-gather neighbouring rows' same 128-byte segments back to back (-6...-8 % on the 32- and
+        // 128-channel layers). Either way the stages form one flat sequence; the rulebook column of a stage is fetched two
+        // stages ahead of its use (one stage ahead of the gathers it addresses).
         const bool inner = p.taps_inner != 0;
         auto advance = [&](int &t, int &kk) -> bool {          // (t, kk) -> the stage after it; false at the end
             if (!inner) {
@@ -948,48 +926,23 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
             return ++kk < sk;
         };
 
-        // DEPTH register sets of raw gathered rows: the rows of stage k + DEPTH are requested while stage k computes, so a
-        // gather has DEPTH stage times to land (the weights, L2-resident, stay one stage ahead)
-        f32x4 araw[DEPTH][MS][2];
-        bool az[DEPTH][MS];
+        f32x4 araw[MS][2];
+        bool az[MS];
         f32x4u rbv[BJ];
-        auto load_rows = [&](auto SET, int t, int kk, const int (&idx)[NI]) {
-            constexpr int R = decltype(SET)::value;
-            if (LINES) {
-#pragma unroll
-                for (int j = 0; j < 2 * MS; ++j) {           // araw[R][j / 2][j % 2] = piece lp of row 8j + lq
-                    if (sub_on(j >> 1, t)) {
-                        const int id = idx[j];
-                        araw[R][j >> 1][j & 1] = zero_if(load_a<true>(p, id, kk * 32 + lp * 4), id < 0);
-                    }
-                }
-                return;
-            }
+        auto load_rows = [&](int t, int kk, const int (&idx)[MS]) {
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
                     const int id = row_ok[s] ? idx[s] : -1;
-                    az[R][s] = id < 0;
-                    if (CPD_GC_ABLATE & 2) { araw[R][s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[R][s][1] = araw[R][s][0]; continue; }
-                    araw[R][s][0] = load_a<true>(p, id, kk * 32 + g * 8);
-                    araw[R][s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
+                    az[s] = id < 0;
+                    if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; continue; }
+                    araw[s][0] = load_a<true>(p, id, kk * 32 + g * 8);
+                    araw[s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
                 }
             }
         };
-        int wbuf = 0;                                   // GLDS: buffer holding the weights of the stage being computed
         auto load_weights = [&](int t, int kk) {
             const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
-            if (GLDS) {                                 // into the other buffer (its readers passed the last barrier)
-#pragma unroll
-                for (int j = 0; j < BJ; ++j) {
-                    const int id = j * 256 + tid;
-                    const int pg = id / BN, n = id - pg * BN;
-                    char *lbase = sb + (wbuf ^ 1) * (NP * B_IMG) + ((j * 256 + wave * 64) << 4);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wt + ((size_t)pg * p.np + col0 + n) * 16),
-                                                     (__attribute__((address_space(3))) void *)lbase, 16, 0, 0);
-                }
-                return;
-            }
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
                 const int id = j * 256 + tid;
@@ -1001,54 +954,16 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
             }
         };
         typename S::frag a[MS][NP];
-        auto stage_commit = [&](auto SET, int t) {            // B -> LDS, A (register set SET) -> split fragments
-            constexpr int R = decltype(SET)::value;
-            if (!GLDS) {
+        auto stage_commit = [&](int t) {            // B -> LDS, A -> split fragments
 #pragma unroll
-                for (int j = 0; j < BJ; ++j)
-                    if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
-            }
-            if (LINES && (CPD_GC_ABLATE & 64)) {          // timing only: full-line gathers fed to the MFMAs untransposed (wrong results)
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    if (sub_on(s, t)) {
-                        typename S::half lo[NP], hi[NP];
-                        S::split(araw[R][s][0], lo);
-                        S::split(araw[R][s][1], hi);
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
-                    }
-                }
-                return;
-            }
-            if (LINES) {
-#pragma unroll
-                for (int j = 0; j < 2 * MS; ++j)
-                    if (sub_on(j >> 1, t)) {
-                        const int rw = 8 * j + lq;
-                        *reinterpret_cast<f32x4 *>(sa + rw * 128 + ((lp ^ swz(rw)) << 4)) = araw[R][j >> 1][j & 1];
-                    }
-#pragma unroll
-                for (int s = 0; s < MS; ++s) {
-                    if (sub_on(s, t)) {
-                        const int rw = 16 * s + r;
-                        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(sa + rw * 128 + (((2 * g) ^ swz(rw)) << 4));
-                        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(sa + rw * 128 + (((2 * g + 1) ^ swz(rw)) << 4));
-                        typename S::half lo[NP], hi[NP];
-                        S::split(x0, lo);
-                        S::split(x1, hi);
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
-                    }
-                }
-                return;
-            }
+            for (int j = 0; j < BJ; ++j)
+                if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
                     typename S::half lo[NP], hi[NP];
-                    S::split(zero_if(araw[R][s][0], az[R][s]), lo);
-                    S::split(zero_if(araw[R][s][1], az[R][s]), hi);
+                    S::split(zero_if(araw[s][0], az[s]), lo);
+                    S::split(zero_if(araw[s][1], az[s]), hi);
 #pragma unroll
                     for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
                 }
@@ -1061,7 +976,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
             if (any_on) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const char *src = sb + (GLDS ? wbuf * (NP * B_IMG) : 0) + ((g * BN + 16 * nt + r) << 4);
+                    const char *src = sb + ((g * BN + 16 * nt + r) << 4);
                     typename S::frag b[NP];
 #pragma unroll
                     for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
@@ -1074,221 +989,49 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
                 }
             }
         };
-        using Set0 = std::integral_constant<int, 0>;
-        using Set1 = std::integral_constant<int, DEPTH - 1>;     // == Set0 when DEPTH == 1
 
-        // stage cursors: c = computing, n1 .. n3 = the stages after it (ok = exists)
+        // stage cursors: c = computing, 1 / 2 = the stages after it (ok = exists)
         int tc = t_first, kc = 0;
         int t1 = tc, k1 = kc; bool ok1 = advance(t1, k1);
         int t2 = t1, k2 = k1; bool ok2 = ok1 && advance(t2, k2);
-        int t3 = t2, k3 = k2; bool ok3 = ok2 && advance(t3, k3);
-        int idx_a[NI], idx_b[NI];                  // rulebook columns, fetched one stage before the gathers they address
+        int idx_a[MS], idx_b[MS];                  // rulebook columns, fetched one stage before the gathers they address
         load_idx(tc, idx_a);
-        load_rows(Set0{}, tc, kc, idx_a);
+        load_rows(tc, kc, idx_a);
         load_weights(tc, kc);
-        if (GLDS) wbuf ^= 1;                        // the first stage's weights land in the buffer it will read
-        if (DEPTH == 2) {
-            if (ok1) { load_idx(t1, idx_a); load_rows(Set1{}, t1, k1, idx_a); }
-            if (ok2) load_idx(t2, idx_b);          // idx_b: column of the next stage to be gathered (c + 2)
-        } else {
-            if (ok1) load_idx(t1, idx_b);          // idx_b: column of the next stage to be gathered (c + 1)
-        }
-        stage_commit(Set0{}, tc);
+        if (ok1) load_idx(t1, idx_b);              // idx_b: column of the next stage to be gathered
+        stage_commit(tc);
         __syncthreads();
-        // one pipeline step with the register set of the stage being requested fixed at compile time
-        auto step = [&](auto REQ, auto NEXT) -> bool {
-            // REQ: set that receives the rows requested now (free: its rows were committed); NEXT: set holding stage c + 1
-            if (ok1) load_weights(t1, k1);
-            if (DEPTH == 2) {
-                if (ok2) load_rows(REQ, t2, k2, idx_b);
-                if (ok3) load_idx(t3, idx_a);
-            } else {
-                if (ok1) load_rows(REQ, t1, k1, idx_b);
+        while (true) {
+            if (ok1) {
+                load_weights(t1, k1);
+                load_rows(t1, k1, idx_b);
                 if (ok2) load_idx(t2, idx_a);
             }
             stage_mma(tc);
-            if (!ok1) return false;
-            if (GLDS) {
-                stage_commit(NEXT, t1);             // rows -> fragments (registers only)
-                __syncthreads();                    // the next stage's weights have landed (vmcnt(0) is part of it) and are visible
-                wbuf ^= 1;
-            } else {
-                if (!(CPD_GC_ABLATE & 8)) __syncthreads();                        // every wave is done with this stage's weights
-                stage_commit(NEXT, t1);
-                if (!(CPD_GC_ABLATE & 8)) __syncthreads();
-            }
+            if (!ok1) break;
+            if (!(CPD_GC_ABLATE & 8)) __syncthreads();                        // every wave is done with this stage's weights
+            stage_commit(t1);
+            if (!(CPD_GC_ABLATE & 8)) __syncthreads();
             tc = t1; kc = k1;
             t1 = t2; k1 = k2; ok1 = ok2;
-            t2 = t3; k2 = k3; ok2 = ok3;
-            if (ok3) ok3 = advance(t3, k3);
+            if (ok2) ok2 = advance(t2, k2);
 #pragma unroll
-            for (int s = 0; s < NI; ++s) idx_b[s] = idx_a[s];
-            return true;
-        };
-        if (DEPTH == 2) {
-            while (true) {
-                if (!step(Set0{}, Set1{})) break;      // set 0 was committed in the prologue / previous step: request into it
-                if (!step(Set1{}, Set0{})) break;
-            }
-        } else {
-            while (step(Set0{}, Set0{})) {}
+            for (int s = 0; s < MS; ++s) idx_b[s] = idx_a[s];
         }
     }
     epilogue<MS, NT>(p, acc, row0, col0, r, g);
 }
 
-// (bf16x3, BN = 128, MS = 2 sits 6 registers above the 3-waves-per-SIMD budget without the hint; it fits without spilling)
+// (bf16x3, BN = 128, MS = 2 sits at the 3-waves-per-SIMD budget)
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, BN == 128 && MS == 2 ? 3 : 8)))
 rowwave_conv_bf16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitBf16x3, BN, MS>(p);
 }
 template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS == 4 && BN >= 64 ? 2 : (BN == 128 && MS == 2 ? 3 : 4), 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
 rowwave_conv_f16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitF16x2, BN, MS>(p);
-}
-// gathers two stages ahead (two register sets of raw rows)
-template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
-rowwave2_conv_f16_kernel(GcParams p) {
-    rowwave_conv_split_body<SplitF16x2, BN, MS, 2>(p);
-}
-// weights direct-to-LDS, double buffered
-template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
-rowwaveG_conv_f16_kernel(GcParams p) {
-    rowwave_conv_split_body<SplitF16x2, BN, MS, 1, false, true>(p);
-}
-// full-line gathers through a wave-private LDS image
-template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
-rowwaveL_conv_f16_kernel(GcParams p) {
-    rowwave_conv_split_body<SplitF16x2, BN, MS, 1, true>(p);
-}
-
-// Split WAVE kernel for narrow sparse layers (32 channels): one wave64 owns 16*MS rows x 16*NT columns over all taps, like the
-// fp32 wave kernel -- no LDS, no barriers. With so few columns a (tap, 32-channel) weight block is 4 KB: every wave reads its
-// B fragments straight from the L1/L2-resident split image (a lane's fragment of one piece is one 16-byte load) instead of
-// meeting the other waves at two barriers per tap around an LDS copy, and the row-wave kernel's per-stage skeleton goes away.
-// Rows are gathered one stage ahead into a second register set; stage order (channel block outer, tap inner).
-template <class S, int MS, int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) wavesplit_conv_f16_kernel(GcParams p) {
-    constexpr int NP = S::NP;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-    if (item >= p.items) return;
-    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
-    const int r = lane & 15, g = lane >> 4;
-    const int row0 = rb * (16 * MS), col0 = cb * (16 * NT);
-
-    f32x4 acc[MS][NT];
-#pragma unroll
-    for (int s = 0; s < MS; ++s)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    uint32_t my_mask[MS], any = 0;
-    int rowc[MS];
-    bool row_ok[MS];
-#pragma unroll
-    for (int s = 0; s < MS; ++s) {
-        const int sub = rb * MS + s;
-        uint32_t m = 0xffffffffu;
-        if (p.tapmask) m = sub < p.n_sub ? p.tapmask[sub] : 0u;
-        else if (row0 + 16 * s >= p.n_out) m = 0u;
-        my_mask[s] = __builtin_amdgcn_readfirstlane(m);
-        any |= my_mask[s];
-        const int row = row0 + 16 * s + r;
-        row_ok[s] = row < p.n_out;
-        rowc[s] = row_ok[s] ? row : p.n_out - 1;
-    }
-    if (p.kv < 32) any &= (1u << p.kv) - 1u;
-    const int sk = p.c_in >> 5;
-    const size_t b_stage = (size_t)NP * 4 * p.np * 16;          // bytes of one (tap, k32) block of the split image
-    const size_t b_piece = (size_t)4 * p.np * 16;
-    const char *const wlane = reinterpret_cast<const char *>(p.wb) + ((size_t)g * p.np + col0 + r) * 16;
-
-    if (any) {
-        const int t_first = __builtin_ctz(any);
-        auto next_tap = [&](int t) -> int {
-            const uint32_t m = t >= 31 ? 0u : (any & ~((2u << t) - 1u));
-            return m ? __builtin_ctz(m) : -1;
-        };
-        auto advance = [&](int &t, int &kk) -> bool {            // channel block outer, tap inner
-            const int tn = next_tap(t);
-            if (tn >= 0) { t = tn; return true; }
-            t = t_first;
-            return ++kk < sk;
-        };
-        auto sub_on = [&](int s, int t) { return (my_mask[s] >> t) & 1u; };
-        auto load_idx = [&](int t, int (&idx)[MS]) {
-#pragma unroll
-            for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
-        };
-        f32x4 araw[2][MS][2];
-        bool az[2][MS];
-        auto load_rows = [&](auto SET, int t, int kk, const int (&idx)[MS]) {
-            constexpr int R = decltype(SET)::value;
-#pragma unroll
-            for (int s = 0; s < MS; ++s) {
-                if (sub_on(s, t)) {
-                    const int id = row_ok[s] ? idx[s] : -1;
-                    az[R][s] = id < 0;
-                    araw[R][s][0] = load_a<true>(p, id, kk * 32 + g * 8);
-                    araw[R][s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
-                }
-            }
-        };
-        auto compute = [&](auto SET, int t, int kk) {
-            constexpr int R = decltype(SET)::value;
-            const char *wt = wlane + ((size_t)t * sk + kk) * b_stage;
-            typename S::frag b[NT][NP];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) b[nt][q] = *reinterpret_cast<const typename S::frag *>(wt + q * b_piece + (size_t)nt * 256);
-#pragma unroll
-            for (int s = 0; s < MS; ++s) {
-                if (sub_on(s, t)) {
-                    typename S::half lo[NP], hi[NP];
-                    S::split(zero_if(araw[R][s][0], az[R][s]), lo);
-                    S::split(zero_if(araw[R][s][1], az[R][s]), hi);
-                    typename S::frag a[NP];
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) a[q] = join_halves<S>(lo[q], hi[q]);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[s][nt] = S::mma(a, b[nt], acc[s][nt]);
-                }
-            }
-        };
-        using Set0 = std::integral_constant<int, 0>;
-        using Set1 = std::integral_constant<int, 1>;
-        int tc = t_first, kc = 0;
-        int t1 = tc, k1 = kc; bool ok1 = advance(t1, k1);
-        int t2 = t1, k2 = k1; bool ok2 = ok1 && advance(t2, k2);
-        int idx_a[MS], idx_b[MS];
-        load_idx(tc, idx_a);
-        load_rows(Set0{}, tc, kc, idx_a);
-        if (ok1) load_idx(t1, idx_b);
-        auto step = [&](auto CUR, auto NXT) -> bool {
-            if (ok1) load_rows(NXT, t1, k1, idx_b);
-            if (ok2) load_idx(t2, idx_a);
-            compute(CUR, tc, kc);
-            if (!ok1) return false;
-            tc = t1; kc = k1;
-            t1 = t2; k1 = k2; ok1 = ok2;
-            if (ok2) ok2 = advance(t2, k2);
-#pragma unroll
-            for (int s = 0; s < MS; ++s) idx_b[s] = idx_a[s];
-            return true;
-        };
-        while (true) {
-            if (!step(Set0{}, Set1{})) break;
-            if (!step(Set1{}, Set0{})) break;
-        }
-    }
-    epilogue<MS, NT>(p, acc, row0, col0, r, g);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -1529,19 +1272,7 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
         long long rw_min = 256, rw_floor = 128;
         if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_MIN")) rw_min = atoll(e);
         if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_FLOOR")) rw_floor = atoll(e);
-        int wsplit = 0;                                       // barrier-free split wave kernel for 32-column layers (f16x2)
-        if (const char *e = cpd_knob(tn, "CPD_GC_WAVESPLIT")) wsplit = atoi(e);
-        if (wsplit && pl.math == 2 && c_out == 32 && (n_out + 31) / 32 >= 1024) {
-            pl.use_wg = 4; pl.a = 2; pl.b = 2;
-            return pl;
-        }
         const long long row_tiles = (n_out + 127) / 128;
-        int ms4 = 0;                                          // 256-row workgroups (4 row sub-tiles per wave), f16x2 only
-        if (const char *e = cpd_knob(tn, "CPD_GC_ROWWAVE_MS4")) ms4 = atoi(e);
-        if (ms4 && pl.math == 2 && (row_tiles / 2) * (c_out / bn) >= rw_min) {
-            pl.use_wg = 3; pl.a = 256; pl.b = bn;
-            return pl;
-        }
         if (row_tiles * (c_out / bn) >= rw_min) {
             pl.use_wg = 3; pl.a = 128; pl.b = bn;
             return pl;
@@ -1689,14 +1420,6 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     if (trace)
         fprintf(stderr, "cpd_gather_conv n_out=%d kv=%d c_in=%d c_out=%d flags=%d masks=%d -> kind=%d tile=(%d,%d)\n", n_out, kv, c_in, c_out,
                 flags, tapmask != nullptr, pl.use_wg, pl.a, pl.b);
-    if (pl.use_wg == 4) {
-        p.wb = packed_f16_ptr(packed_w, kv, c_in, c_out); p.dsc = packed_dsc_ptr(packed_w, kv, c_in, c_out);
-        p.n_rb = (n_out + 16 * pl.a - 1) / (16 * pl.a);
-        p.n_cb = c_out / (16 * pl.b);
-        p.items = p.n_rb * p.n_cb;
-        hipLaunchKernelGGL((wavesplit_conv_f16_kernel<SplitF16x2, 2, 2>), dim3((p.items + 3) / 4), dim3(256), 0, cpd_s(stream), p);
-        return cpd_check_launch();
-    }
     if (pl.use_wg == 2 || pl.use_wg == 3) {
         if (pl.math == 2) { p.wb = packed_f16_ptr(packed_w, kv, c_in, c_out); p.dsc = packed_dsc_ptr(packed_w, kv, c_in, c_out); }
         else p.wb = packed_bf16_ptr(packed_w, kv, c_in, c_out);
@@ -1707,36 +1430,8 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     const dim3 grid(p.items), block(256);
     hipStream_t hs = cpd_s(stream);
 #define CPD_LAUNCH(K, LDS) hipLaunchKernelGGL((K), grid, block, (LDS), hs, p)
-    int rw_depth = 1;
-    if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_ROWWAVE_DEPTH")) rw_depth = atoi(e);
-    if (pl.use_wg == 3 && pl.math == 2 && rw_depth == 4 && (pl.a == 128 || pl.a == 64)) {
-        if (pl.a == 64) {
-            if (pl.b == 32) CPD_LAUNCH((rowwaveG_conv_f16_kernel<32, 1>), 0);
-            else if (pl.b == 64) CPD_LAUNCH((rowwaveG_conv_f16_kernel<64, 1>), 0);
-            else CPD_LAUNCH((rowwaveG_conv_f16_kernel<128, 1>), 0);
-        } else if (pl.b == 32) CPD_LAUNCH((rowwaveG_conv_f16_kernel<32, 2>), 0);
-        else if (pl.b == 64) CPD_LAUNCH((rowwaveG_conv_f16_kernel<64, 2>), 0);
-        else CPD_LAUNCH((rowwaveG_conv_f16_kernel<128, 2>), 0);
-        return cpd_check_launch();
-    }
-    if (pl.use_wg == 3 && pl.math == 2 && rw_depth == 3 && pl.a == 128) {
-        if (pl.b == 32) CPD_LAUNCH((rowwaveL_conv_f16_kernel<32, 2>), 0);
-        else if (pl.b == 64) CPD_LAUNCH((rowwaveL_conv_f16_kernel<64, 2>), 0);
-        else CPD_LAUNCH((rowwaveL_conv_f16_kernel<128, 2>), 0);
-        return cpd_check_launch();
-    }
-    if (pl.use_wg == 3 && pl.math == 2 && rw_depth == 2 && pl.a == 128) {
-        if (pl.b == 32) CPD_LAUNCH((rowwave2_conv_f16_kernel<32, 2>), 0);
-        else if (pl.b == 64) CPD_LAUNCH((rowwave2_conv_f16_kernel<64, 2>), 0);
-        else CPD_LAUNCH((rowwave2_conv_f16_kernel<128, 2>), 0);
-        return cpd_check_launch();
-    }
     if (pl.use_wg == 3 && pl.math == 2) {
-        if (pl.a == 256) {
-            if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 4>), 0);
-            else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 4>), 0);
-            else CPD_LAUNCH((rowwave_conv_f16_kernel<128, 4>), 0);
-        } else if (pl.a == 64) {
+        if (pl.a == 64) {
             if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 1>), 0);
             else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 1>), 0);
             else CPD_LAUNCH((rowwave_conv_f16_kernel<128, 1>), 0);

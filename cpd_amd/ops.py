@@ -396,8 +396,6 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=N
     check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), flags,
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
           "cpd_gather_conv_tile")
-    if wg.value == 14:
-        return "wavesplit_conv_f16_kernel<%d,%d>" % (a.value, b.value)                # <row sub-tiles, column tiles> per wave
     if wg.value in (3, 13):
         return "rowwave_conv_%s_kernel<%d,%d>" % ("f16" if wg.value == 13 else "bf16", b.value, a.value // 64)   # <column tile, row sub-tiles per wave>
     if wg.value in (2, 12):
