@@ -46,6 +46,7 @@ SIGNATURES = {
     "cpd_pack_weight": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "cpd_gather_conv": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _I, _VP]),
     "cpd_gather_conv_tile": (_I, [_I, _I, _I, _I, _I] + [ctypes.POINTER(_I)] * 4),
+    "cpd_conv3x3_rows_tile": (_I, [_I, _I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "cpd_conv3x3_rows_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "cpd_conv3x3_rows": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     "cpd_densify_nchw": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),

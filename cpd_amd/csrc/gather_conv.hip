@@ -635,11 +635,12 @@ tile_conv_f16_kernel(GcParams p) {
 // lanes -- a wave-uniform branch that is taken for ~1 in 6 (sub-tile, dx != 0) pairs at W = 188.
 // Same tile, fragment layout, XOR-2g swizzle (the image has 136 rows per k-group so that 129 ^ 6 stays inside), register
 // diet (SH row sub-tiles live at a time, weights fetched after the MFMA block) as the rulebook kernel.
-template <class S, int BN, int SH, bool GLDS = false>
+template <class S, int BN, int SH, bool GLDS = false, int BM = 128>
 __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
     constexpr int NP = S::NP;
-    constexpr int BM = 128;
-    constexpr int WC = BN >= 64 ? 2 : 1, WR = 4 / WC;   // wave grid: 2 x 2, or 4 x 1 for the 16-column tile (tiny c_out heads)
+    // wave grid: 2 x 2 (128 rows x 64 / 128 columns), or 4 x 1: the 16-column tile (tiny c_out heads) and the 256-row tiles
+    // (single-column-tile layers, c_out = 64 or <= 16: a wave gets 64 rows instead of 32, twice the MFMAs per staged byte)
+    constexpr int WC = (BN >= 64 && BM == 128) ? 2 : 1, WR = 4 / WC;
     constexpr int WM = BM / WR;                         // rows per wave
     constexpr int MS = WM / 16, NT = BN / WC / 16;
     constexpr int WROWS = BM + 2, BMW = BM + 8;
@@ -833,10 +834,10 @@ window_conv_bf16_kernel(GcParams p) {
 }
 // f16x2: all four row sub-tiles' fragments live at once (the weight fragments are read once per stage); for the 64- and
 // 128-column tiles the weight stage goes direct-to-LDS, double buffered (-4...-8 % on the 128-column layers, tools/conv_bench.py)
-template <int BN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 3 : 4, BN == 128 ? 3 : 4)))
+template <int BN, int BM = 128>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 || BM == 256 ? 3 : 4, BN == 128 || BM == 256 ? 3 : 4)))
 window_conv_f16_kernel(GcParams p) {
-    window_conv_split_body<SplitF16x2, BN, BN >= 64 ? 4 : 2, BN >= 64>(p);
+    window_conv_split_body<SplitF16x2, BN, (BN >= 64 && BM == 128) || (BM == 256 && BN < 64) ? 4 : 2, BN >= 64, BM>(p);
 }
 
 // Split kernel for SPARSE layers: a workgroup owns 64*MS output rows x BN columns, wave w the
@@ -1517,8 +1518,24 @@ static int window_bn(int frames, int h, int w, int c_in, int c_out, int flags) {
     if (((rows + 127) / 128) * ((c_out + bn - 1) / bn) < min_wgs) return 0;
     return bn;
 }
+// rows per workgroup of the window kernel: 256 when the layer has a single column tile (c_out = 64 or <= 16), f16x2 arithmetic
+// and still >= 4 workgroups per CU that way
+static int window_bm(int frames, int h, int w, int c_out, int bn, int flags) {
+    const bool tn = cpd_tuning();
+    int want = 1;
+    if (const char *e = cpd_knob(tn, "CPD_GC_WINDOW_BM256")) want = atoi(e);
+    const long long rows = (long long)frames * h * w;
+    if (want && split_math(flags, tn) == 2 && (c_out + bn - 1) / bn == 1 && bn <= 64 && (rows + 255) / 256 >= 1024) return 256;
+    return 128;
+}
 extern "C" int cpd_conv3x3_rows_supported(int frames, int h, int w, int c_in, int c_out, int flags) {
     return window_bn(frames, h, w, c_in, c_out, flags) != 0;
+}
+extern "C" int cpd_conv3x3_rows_tile(int frames, int h, int w, int c_in, int c_out, int flags, int *bm, int *bn) {
+    if (!bm || !bn) return CPD_ERR_ARG;
+    *bn = window_bn(frames, h, w, c_in, c_out, flags);
+    *bm = *bn ? window_bm(frames, h, w, c_out, *bn, flags) : 0;
+    return *bn ? CPD_OK : CPD_ERR_UNSUPPORTED;
 }
 extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
                                 const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
@@ -1540,9 +1557,16 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     p.kv = 9; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld;
     p.n_sub = (n_out + 15) / 16;
-    p.n_rb = (n_out + 127) / 128; p.n_cb = (c_out + bn - 1) / bn; p.items = p.n_rb * p.n_cb;
+    const int bm = window_bm(frames, h, w, c_out, bn, flags);
+    p.n_rb = (n_out + bm - 1) / bm; p.n_cb = (c_out + bn - 1) / bn; p.items = p.n_rb * p.n_cb;
     p.img_h = h; p.img_w = w;
     const size_t lds = (math == 2 ? 2 : 3) * ((size_t)(128 + 8) * 64 + (size_t)bn * 64);
+    if (math == 2 && bm == 256) {
+        const size_t ldsa = 2 * (size_t)(256 + 8) * 64;
+        if (bn == 64) hipLaunchKernelGGL((window_conv_f16_kernel<64, 256>), dim3(p.items), dim3(256), ldsa + 2 * 2 * 64 * 64, cpd_s(stream), p);
+        else hipLaunchKernelGGL((window_conv_f16_kernel<16, 256>), dim3(p.items), dim3(256), ldsa + 2 * 16 * 64, cpd_s(stream), p);
+        return cpd_check_launch();
+    }
     if (math == 2) {
         const size_t lds2 = 2 * (size_t)(128 + 8) * 64 + 2 * 2 * (size_t)bn * 64;    // window image + two weight buffers
         if (bn == 128) hipLaunchKernelGGL((window_conv_f16_kernel<128>), dim3(p.items), dim3(256), lds2, cpd_s(stream), p);

@@ -391,7 +391,10 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=N
     flags = _gc_flags(dense, bf16x3, math)
     if image is not None and n_out == image[0] * image[1] * image[2] and in_ld % 4 == 0 and lib().cpd_conv3x3_rows_supported(
             image[0], image[1], image[2], int(c_in), int(c_out), flags):
-        return "window_conv_%s_kernel<%d>" % ("f16" if flags & 4 else "bf16", 16 if c_out <= 16 else (128 if c_out % 128 == 0 else 64))
+        bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib().cpd_conv3x3_rows_tile(image[0], image[1], image[2], int(c_in), int(c_out), flags, ctypes.byref(bm), ctypes.byref(bn)),
+              "cpd_conv3x3_rows_tile")
+        return "window_conv_%s_kernel<%s>" % ("f16" if flags & 4 else "bf16", "%d" % bn.value if bm.value == 128 else "%d,%d" % (bn.value, bm.value))
     wg, a, b, vec = (ctypes.c_int(0) for _ in range(4))
     check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), flags,
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),

@@ -176,6 +176,8 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
  * 16-byte aligned and the problem fills the chip (cpd_conv3x3_rows_supported tells, pointers aside);
  * the caller then uses cpd_rulebook_conv2d + cpd_gather_conv, which computes the same thing.     */
 int cpd_conv3x3_rows_supported(int frames, int h, int w, int c_in, int c_out, int flags);
+/* Introspection: the (rows x columns) workgroup tile cpd_conv3x3_rows runs for this problem. HOST only. */
+int cpd_conv3x3_rows_tile(int frames, int h, int w, int c_in, int c_out, int flags, int *bm, int *bn);
 int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c_in,
                      const float *packed_w, int c_out, const float *scale, const float *shift,
                      const float *residual, int res_ld, int relu, float *out, int out_ld, int flags,

@@ -90,6 +90,21 @@ def test_bench_kernels_match_oracle_at_full_size(oracle, hip, math, cin, cout, k
     np.testing.assert_allclose(rows_nchw(got, batch, ho, wo), want, atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("cin,cout,batch,kernel", [(512, 64, 8, "window_conv_f16_kernel<64,256>"), (320, 11, 8, "window_conv_f16_kernel<16,256>")])
+def test_bench_256_row_window_tiles_match_oracle(oracle, hip, cin, cout, batch, kernel):
+    """The 256-row window tiles the single-column-tile layers (CenterHead shared conv, fused output convs) get at the bench's
+    batch size (>= 1024 such workgroups), against the oracle at 188 x 188."""
+    rng = np.random.default_rng(cin + cout + 256)
+    h = w = 188
+    x = rng.normal(size=(batch, cin, h, w)).astype(np.float32)
+    wt = (rng.normal(size=(cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    ran = []
+    got, ho, wo = conv2d_hip(nhwc_rows(x), batch, h, w, wt, bias, 1, math="f16x2", kernels=ran)
+    assert ran == [kernel], ran
+    np.testing.assert_allclose(rows_nchw(got, batch, ho, wo), oracle.conv2d(x, wt, bias, 1, 1), atol=1e-4, rtol=0)
+
+
 @pytest.mark.parametrize("math", [m for m in MATHS if m != "f32"])
 @pytest.mark.parametrize("cin,cout,u,batch,h,w", [(128, 256, 1, 3, 188, 188), (256, 256, 2, 5, 94, 94)])
 def test_bench_deconv_kernels_match_oracle_at_full_size(oracle, hip, math, cin, cout, u, batch, h, w):
