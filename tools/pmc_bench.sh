@@ -30,3 +30,16 @@ print("bench: %.1f frames/s, %.2f ms/step; dominant %s: %.1f TF = %.3f of %.0f, 
       (d["value"], d["ms_per_step"], r["kernel"], r["achieved"], r["frac"], r["peak"], r["avg_launch_us"], r["traffic"], r.get("path_hbm_frac", -1)))
 print("cpu_baseline", d.get("cpu_baseline"))
 PY
+# variants quoted in DESIGN.md §5 (one bench line each; no CPU baseline, no roofline pass)
+if [ "${2:-}" = "variants" ]; then
+  for v in "bf16x3:--conv-math bf16x3" "f32:--conv-math f32" "streams2:--streams 2" "device_results:--device-results" "1frame:--frames 1"; do
+    python bench.py --no-cpu-baseline --no-roofline ${v#*:} > gpurun_out/${tag}_bench_${v%%:*}.json 2>> gpurun_out/${tag}_bench.err
+    python -c "import json,sys; d=json.load(open('gpurun_out/${tag}_bench_${v%%:*}.json')); print('${v%%:*}', round(d['value'],1), 'frames/s', round(d['ms_per_step'],2), 'ms/step')"
+  done
+  python bench.py --mode train > gpurun_out/${tag}_train_bench.json 2>> gpurun_out/${tag}_bench.err
+  python -c "import json; d=json.load(open('gpurun_out/${tag}_train_bench.json')); print('train', round(d['value'],1), 'frames/s', round(d['ms_per_step'],2), 'ms/step')"
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -- python $R/bench.py --mode train > $R/gpurun_out/${tag}_train_bench_under_rocprof.json 2>/dev/null
+  cp $(ls $R/gpurun_out/prof_train/*/*kernel_stats.csv | head -1) $R/gpurun_out/${tag}_train_kernel_stats.csv
+  cd $R
+fi
