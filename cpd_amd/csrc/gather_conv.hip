@@ -643,7 +643,13 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
     constexpr int WC = (BN >= 64 && BM == 128) ? 2 : 1, WR = 4 / WC;
     constexpr int WM = BM / WR;                         // rows per wave
     constexpr int MS = WM / 16, NT = BN / WC / 16;
-    constexpr int WROWS = BM + 2, BMW = BM + 8;
+    // A window image per piece: [k-group g][window row w][16 B], k-group stride BMW = 0 (mod 16) slots and NO swizzle: a
+    // ds_read_b128 lane group is 8 rows of an even k-group and the complementary 8 rows of the odd one out of 16 CONSECUTIVE
+    // window rows, so its 16 slots are distinct (mod 16) at every row offset -- the three dx taps read at offsets 0 / 1 / 2
+    // (an XOR swizzle is conflict-free only at aligned offsets: 23 % of this kernel's LDS cycles were conflicts with it).
+    // The 8-byte writes stay conflict-free through the thread -> piece map instead: 16 consecutive lanes = one k-group,
+    // both halves, 8 consecutive rows = 128 contiguous bytes
+    constexpr int WROWS = BM + 2, BMW = BM + 16;
     constexpr int AJ = (WROWS * 8 + 255) / 256;     // fp32 A pieces (4 channels) per thread per window
     constexpr int B_SLOTS = NP * 4 * BN;            // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;       // ... per thread
@@ -696,8 +702,8 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
     need_mask = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(need_mask >> 32)) << 32) |
                 __builtin_amdgcn_readfirstlane((uint32_t)need_mask);
 
-    const int a_piece = tid & 7;   // 4 channels: k-group a_piece >> 1, half a_piece & 1
-    const int a_row = tid >> 3;    // window row, + 32*j
+    const int a_piece = ((lane >> 4) << 1) | (lane & 1);   // 4 channels: k-group a_piece >> 1, half a_piece & 1
+    const int a_row = wave * 8 + ((lane >> 1) & 7);        // window row, + 32*j
     const int sk = p.c_in >> 5;
     // stage st = (32-channel block st / 9, tap st % 9): taps inner
     const size_t b_stage = (size_t)NP * 4 * p.np * 16;
@@ -724,7 +730,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
             if (AJ * 32 <= WROWS || w < WROWS) {
                 typename S::half pc[NP];
                 S::split(ra[j], pc);
-                char *dst = sa + (((ag * BMW + (w ^ (2 * ag))) << 4) + half * 8);
+                char *dst = sa + (((ag * BMW + w) << 4) + half * 8);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<typename S::half *>(dst + q * A_IMG) = pc[q];
             }
@@ -762,6 +768,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
         }
     };
 
+    typename S::frag abl_a[(CPD_GC_ABLATE & 256) ? MS : 1][NP], abl_b[(CPD_GC_ABLATE & 256) ? NT : 1][NP];   // diagnostic builds only
     load_window(0, -1);
     if (GLDS) issue_weights(0, 0); else load_weights(0);
     store_window();
@@ -772,8 +779,10 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
         const int t = st % 9, dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
         const int nx = st + 1;
         const bool new_window = nx < n_stage && nx % 3 == 0;     // the next stage starts another dy (or channel block)
-        if (GLDS && nx < n_stage) issue_weights(nx, nx & 1);
-        if (new_window) load_window(nx / 9, (nx % 9) / 3 - 1);   // in flight under this stage's MFMAs
+        // CPD_GC_ABLATE (diagnostic builds only, wrong results): 64 no weight stages, 128 no window loads / splits / stores,
+        // 256 fragments read from LDS in the first stage only, 512 no MFMAs
+        if (GLDS && nx < n_stage && !(CPD_GC_ABLATE & 64)) issue_weights(nx, nx & 1);
+        if (new_window && !(CPD_GC_ABLATE & 128)) load_window(nx / 9, (nx % 9) / 3 - 1);   // in flight under this stage's MFMAs
         const char *const sbr = sb + (GLDS ? (st & 1) * (NP * B_IMG) : 0);
         {
             const typename S::frag zero = {};
@@ -783,9 +792,18 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
 #pragma unroll
                 for (int s = 0; s < SH; ++s) {
                     const int w = wr * WM + 16 * (s0 + s) + r + 1 + dx;
-                    const char *src = sa + ((g * BMW + (w ^ (2 * g))) << 4);
+                    const char *src = sa + ((g * BMW + w) << 4);
+                    if (!(CPD_GC_ABLATE & 256) || st == 0) {
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) a[s][q] = *reinterpret_cast<const typename S::frag *>(src + q * A_IMG);
+                        for (int q = 0; q < NP; ++q) a[s][q] = *reinterpret_cast<const typename S::frag *>(src + q * A_IMG);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) a[s][q] = abl_a[s0 + s][q];
+                    }
+                    if (CPD_GC_ABLATE & 256) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) { abl_a[s0 + s][q] = a[s][q]; asm volatile("" : "+v"(abl_a[s0 + s][q])); }
+                    }
                     if (!(CPD_GC_ABLATE & 16)) {
                         if ((need_mask >> (4 * t + s0 + s)) & 1) {          // scalar test; rarely taken
                             asm volatile("" ::: "memory");                  // keeps this a branch (no if-conversion into 8 selects)
@@ -800,16 +818,32 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
                     const int n = wc * (BN / WC) + 16 * nt + r;
                     const char *src = sbr + ((g * BN + n) << 4);
                     typename S::frag b[NP];
+                    if (!(CPD_GC_ABLATE & 256) || st == 0) {
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+                        for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+                    } else {
 #pragma unroll
-                    for (int s = 0; s < SH; ++s) acc[s0 + s][nt] = S::mma(a[s], b, acc[s0 + s][nt]);
+                        for (int q = 0; q < NP; ++q) b[q] = abl_b[nt][q];
+                    }
+                    if (CPD_GC_ABLATE & 256) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) { abl_b[nt][q] = b[q]; asm volatile("" : "+v"(abl_b[nt][q])); }
+                    }
+                    if (CPD_GC_ABLATE & 512) {
+#pragma unroll
+                        for (int s = 0; s < SH; ++s)
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(a[s][q]), "v"(b[q]));
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < SH; ++s) acc[s0 + s][nt] = S::mma(a[s], b, acc[s0 + s][nt]);
+                    }
                 }
                 if (SH < MS) asm volatile("" ::: "memory");     // keep the groups' LDS reads apart (register budget)
             }
         }
         if (GLDS) {
-            if (new_window) {
+            if (new_window && !(CPD_GC_ABLATE & 128)) {
                 __syncthreads();           // everyone is done reading the window before it is overwritten
                 store_window();
             }
@@ -823,6 +857,15 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
             }
             __syncthreads();
         }
+    }
+    if (CPD_GC_ABLATE & 1024) {             // diagnostic builds only: no epilogue (one store keeps the accumulators live)
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < MS; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) t += acc[s][nt][0] + acc[s][nt][1] + acc[s][nt][2] + acc[s][nt][3];
+        if (t == 123.456f) p.out[tid] = t;
+        return;
     }
     epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g);
 }
@@ -1560,15 +1603,15 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     const int bm = window_bm(frames, h, w, c_out, bn, flags);
     p.n_rb = (n_out + bm - 1) / bm; p.n_cb = (c_out + bn - 1) / bn; p.items = p.n_rb * p.n_cb;
     p.img_h = h; p.img_w = w;
-    const size_t lds = (math == 2 ? 2 : 3) * ((size_t)(128 + 8) * 64 + (size_t)bn * 64);
+    const size_t lds = (math == 2 ? 2 : 3) * ((size_t)(128 + 16) * 64 + (size_t)bn * 64);
     if (math == 2 && bm == 256) {
-        const size_t ldsa = 2 * (size_t)(256 + 8) * 64;
+        const size_t ldsa = 2 * (size_t)(256 + 16) * 64;
         if (bn == 64) hipLaunchKernelGGL((window_conv_f16_kernel<64, 256>), dim3(p.items), dim3(256), ldsa + 2 * 2 * 64 * 64, cpd_s(stream), p);
         else hipLaunchKernelGGL((window_conv_f16_kernel<16, 256>), dim3(p.items), dim3(256), ldsa + 2 * 16 * 64, cpd_s(stream), p);
         return cpd_check_launch();
     }
     if (math == 2) {
-        const size_t lds2 = 2 * (size_t)(128 + 8) * 64 + 2 * 2 * (size_t)bn * 64;    // window image + two weight buffers
+        const size_t lds2 = 2 * (size_t)(128 + 16) * 64 + 2 * 2 * (size_t)bn * 64;    // window image + two weight buffers
         if (bn == 128) hipLaunchKernelGGL((window_conv_f16_kernel<128>), dim3(p.items), dim3(256), lds2, cpd_s(stream), p);
         else if (bn == 64) hipLaunchKernelGGL((window_conv_f16_kernel<64>), dim3(p.items), dim3(256), lds2, cpd_s(stream), p);
         else hipLaunchKernelGGL((window_conv_f16_kernel<16>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
