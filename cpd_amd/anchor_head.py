@@ -112,6 +112,64 @@ class AxisAlignedTargetAssigner:
         return {k: torch.stack(v, dim=0) for k, v in out.items()}
 
 
+class ATSSTargetAssigner:
+    """ATSSTargetAssigner (atss_target_assigner.py:8-141) with the reference's constructor and `assign_targets` contract:
+    anchors_list = one tensor or a list of per-class anchor tensors, gt_boxes_with_classes (B, M, 8); every anchor set is
+    matched against ALL boxes of a frame (no class filter, as in the reference); returns box_cls_labels (B, N) float class
+    ids, box_reg_targets (B, N, 7), reg_weights (B, N). One `cpd_atss_assign` call per (frame, anchor set); no N x M
+    matrices. box_coder is accepted for signature compatibility (ResidualCoder, code_size 7, is what the kernel encodes)."""
+
+    def __init__(self, topk, box_coder=None, match_height=False, **kwargs):
+        # **kwargs: AnchorHeadTemplate.get_target_assigner (anchor_head_template.py:64-69) passes use_multihead= here, which the
+        # reference's own constructor does not take (its ATSS branch raises TypeError as shipped); accepted and ignored
+        self.topk = int(topk)
+        self.box_coder = box_coder
+        self.match_height = bool(match_height)
+        assert box_coder is None or getattr(box_coder, "code_size", 7) == 7
+
+    def assign_targets(self, anchors_list, gt_boxes_with_classes, use_multihead=False):
+        if not isinstance(anchors_list, list):
+            anchors_list = [anchors_list]
+        gt = gt_boxes_with_classes.contiguous().float()
+        B, M, ld = gt.shape
+        assert ld >= 8
+        # trailing all-zero boxes are padding, at least one row stays (l.40-45): one host read for the whole batch
+        nz = (gt[:, :, :-1].sum(-1) != 0)
+        last = torch.where(nz.any(1), M - 1 - nz.flip(1).float().argmax(1), torch.zeros(B, device=gt.device, dtype=torch.long))
+        counts = (last + 1).tolist()
+        outs = {"box_cls_labels": [], "box_reg_targets": [], "reg_weights": []}
+        for anchors in anchors_list:
+            if use_multihead:
+                a = anchors.permute(3, 4, 0, 1, 2, 5).contiguous().view(-1, anchors.shape[-1])
+            else:
+                a = anchors.reshape(-1, anchors.shape[-1])
+            a = a[:, :7].contiguous().float()
+            n = a.shape[0]
+            labels = torch.empty((B, n), dtype=torch.float32, device=gt.device)
+            targets = torch.empty((B, n, 7), dtype=torch.float32, device=gt.device)
+            weights = torch.empty((B, n), dtype=torch.float32, device=gt.device)
+            for b in range(B):
+                m = int(counts[b])
+                ws = torch.empty((lib().cpd_atss_workspace_bytes(m, self.topk),), dtype=torch.uint8, device=gt.device)
+                check(lib().cpd_atss_assign(ptr(a), n, ptr(gt[b]), ld, m, self.topk, int(self.match_height), ptr(labels[b]),
+                                            ptr(targets[b]), ptr(weights[b]), ptr(ws), ws.numel(), stream()), "cpd_atss_assign")
+            outs["box_cls_labels"].append(labels)
+            outs["box_reg_targets"].append(targets)
+            outs["reg_weights"].append(weights)
+        return {k: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for k, v in outs.items()}
+
+
+def get_target_assigner(anchor_target_cfg, anchor_generator_cfg=None, class_names=None, box_coder=None):
+    """AnchorHeadTemplate.get_target_assigner (anchor_head_template.py:62-81): TARGET_ASSIGNER_CONFIG.NAME selects the class."""
+    get = (lambda k, d=None: anchor_target_cfg.get(k, d)) if hasattr(anchor_target_cfg, "get") else (lambda k, d=None: getattr(anchor_target_cfg, k, d))
+    name = get("NAME")
+    if name == "ATSS":
+        return ATSSTargetAssigner(topk=get("TOPK"), box_coder=box_coder, match_height=bool(get("MATCH_HEIGHT", False)))
+    if name == "AxisAlignedTargetAssigner":
+        return AxisAlignedTargetAssigner(anchor_generator_cfg, class_names, norm_by_num_examples=bool(get("NORM_BY_NUM_EXAMPLES", False)))
+    raise NotImplementedError(name)
+
+
 def generate_predicted_boxes(anchors, batch_size, cls_preds, box_preds, dir_cls_preds=None, dir_offset=0.78539,
                              dir_limit_offset=0.0, num_dir_bins=2):
     """anchors: list of per-class anchor tensors (or one tensor); cls/box/dir preds (B, H, W, C*). Returns

@@ -444,6 +444,19 @@ int cpd_anchor_decode(const float *box_preds, const float *anchors, const float 
                       int n, int num_dir_bins, float dir_offset, float dir_limit_offset, float *out,
                       cpd_stream_t stream);
 
+/* ATSSTargetAssigner.assign_targets_single (atss_target_assigner.py:76-141) for ONE frame and ONE anchor set, without the
+ * n x m IoU / distance / "ious_inf" matrices the reference builds: per GT the `topk` nearest anchors (ties: lower index; the
+ * reference's torch.topk leaves them unspecified), their IoUs (boxes_iou_bev, or boxes_iou3d_gpu when match_height), the
+ * mean + std threshold and the centre-in-box test; per anchor the candidate GT of highest IoU; then every GT's argmax anchor
+ * (lowest index on ties, anchor 0 when nothing overlaps) is forced to it, in GT order. gt_boxes [m][gt_ld], columns 0-6 the
+ * box, column gt_ld-1 the class (float, as in gt_boxes_with_classes), trailing all-zero rows already trimmed (l.40-45).
+ * Outputs (zeroed here): labels [n] float class ids (0 = background), reg_targets [n][7] (ResidualCoder.encode_torch),
+ * reg_weights [n]. topk <= 64, topk * m <= 4096. */
+size_t cpd_atss_workspace_bytes(int m, int topk);
+int cpd_atss_assign(const float *anchors, int n_anchors, const float *gt_boxes, int gt_ld, int m, int topk,
+                    int match_height, float *labels, float *reg_targets, float *reg_weights, void *workspace,
+                    size_t workspace_bytes, cpd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -287,6 +287,63 @@ class Oracle:
                                                    _fp(w), _fp(ious)), "anchor_assign")
         return labels, tgt, w, ious
 
+    def atss_assign(self, anchors, gt_with_classes, topk, match_height=False):
+        """ATSSTargetAssigner.assign_targets_single (atss_target_assigner.py:76-141) on the full anchors x GT matrices, fp32
+        operation by operation (numpy; the IoU matrices come from this oracle's C restatement of the reference kernels).
+        gt_with_classes [M, 8] with trailing padding already trimmed (l.40-45). Where torch leaves the result unspecified
+        the rule is spelled out: top-k ties -> lower anchor index; argmax ties -> first index; duplicate forced anchors ->
+        the later GT. Returns labels [N] float32, reg_targets [N, 7], reg_weights [N]."""
+        f = np.float32
+        a = _f32(anchors)[:, :7]
+        gt = _f32(gt_with_classes)
+        g, cls = np.ascontiguousarray(gt[:, :7]), gt[:, -1]
+        n, m, k = a.shape[0], g.shape[0], int(topk)
+        ious = self.boxes_iou3d(a, g) if match_height else self.boxes_iou_bev(a, g)                 # (N, M), l.89-92
+        d = a[:, None, :3] - g[None, :, :3]
+        dist = np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(f)   # l.94
+        idx = np.stack([np.lexsort((np.arange(n), dist[:, j]))[:k] for j in range(m)], 1)            # (K, M), l.95
+        cand = ious[idx, np.arange(m)[None, :]]                                                      # l.96
+        total, mean, m2 = np.zeros(m, f), np.zeros(m, f), np.zeros(m, f)
+        for j in range(k):                                         # sum / k; Welford M2 as torch.std accumulates it
+            x = cand[j]
+            total = (total + x).astype(f)
+            delta = (x - mean).astype(f)
+            mean = (mean + delta / f(j + 1)).astype(f)
+            m2 = (m2 + delta * (x - mean).astype(f)).astype(f)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            std = np.sqrt(m2 / f(k - 1)).astype(f)
+        thresh = ((total / f(k)).astype(f) + std).astype(f) + f(1e-6)                                # l.97-99
+        is_pos = cand >= thresh[None, :]
+        ca = a[idx.reshape(-1)]                                                                      # (K*M, 7), l.103
+        gg = np.tile(g, (k, 1))
+        loc = (ca[:, :3] - gg[:, :3]).astype(f)
+        ang = (-gg[:, 6]).astype(f)
+        c, s_ = np.cos(ang).astype(f), np.sin(ang).astype(f)
+        xr = ((loc[:, 0] * c).astype(f) + (loc[:, 1] * (-s_)).astype(f)).astype(f) + (loc[:, 2] * f(0)).astype(f)
+        yr = ((loc[:, 0] * s_).astype(f) + (loc[:, 1] * c).astype(f)).astype(f) + (loc[:, 2] * f(0)).astype(f)
+        hx, hy = (gg[:, 4] / f(2)).astype(f), (gg[:, 3] / f(2)).astype(f)                            # "lw": x vs dy, y vs dx
+        inside = ((xr <= hx) & (xr >= -hx) & (yr <= hy) & (yr >= -hy)).reshape(k, m)
+        is_pos &= inside
+        best_v = np.full(n, -np.inf, f)
+        best_g = np.zeros(n, np.int64)
+        for kk in range(k):                                        # ious_inf.max(dim=1): highest IoU, then lowest GT index
+            for j in range(m):
+                if is_pos[kk, j]:
+                    i, v = idx[kk, j], ious[idx[kk, j], j]
+                    if v > best_v[i] or (v == best_v[i] and j < best_g[i]):
+                        best_v[i], best_g[i] = v, j
+        amax = np.argmax(ious, axis=0)                                                               # l.126, first maximum
+        for j in range(m):                                                                           # l.127-128
+            best_g[amax[j]], best_v[amax[j]] = j, ious[amax[j], j]
+        labels = cls[best_g].astype(f)
+        labels[np.isneginf(best_v)] = 0
+        pos = labels > 0
+        tgt, w = np.zeros((n, 7), f), np.zeros(n, f)
+        if pos.any():
+            tgt[pos] = self.residual_encode(g[best_g[pos]], a[pos])
+            w[pos] = 1
+        return labels, tgt, w
+
     # ---- dense BEV convs ---------------------------------------------------------------------
     def conv2d(self, x, w, bias=None, stride=1, pad=1):
         x = _f32(x)

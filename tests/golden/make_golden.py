@@ -181,6 +181,65 @@ def nms_large(m):
     print("nms_n4096: %d boxes -> %d kept (attempt %d)" % (n, sel.shape[0], attempt))
 
 
+def atss(m):
+    """ATSSTargetAssigner.assign_targets (atss_target_assigner.py:16-141) run as the reference wrote it, on the reference's own
+    AnchorGenerator / ResidualCoder / common_utils.rotate_points_along_z; its CUDA-only boxes_iou_bev is served by the
+    reference's CPU implementation (iou3d_cpu.cpp compiled in oracle/_ref). Two cases: topk = 8 on the usual anchors (two
+    rotations per location: the pair is equidistant from every box, an even k never cuts through a pair) and topk = 9 on
+    one-rotation anchors (no ties) -- an odd k on two-rotation anchors cuts a tied pair, torch.topk leaves that order
+    unspecified, and the choice moves the mean + std threshold (seen: 1 label of 16,224 differs from the lower-index rule).
+    Own RNG: adding this section moves no other fixture."""
+    lib = m["lib"]
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for pkg in ["r.models.dense_heads.target_assigner"]:
+        if pkg not in sys.modules:
+            _pkg(pkg)
+    cu = _load("r.utils.common_utils", "cpd/utils/common_utils.py")
+    sys.modules["r.utils"].common_utils = cu
+    bc = _load("r.utils.box_coder_utils", "cpd/utils/box_coder_utils.py")
+    ag = _load("r.models.dense_heads.target_assigner.anchor_generator",
+               "cpd/models/dense_heads/target_assigner/anchor_generator.py")
+    nms_mod = sys.modules["r.ops.iou3d_nms.iou3d_nms_utils"]
+    nms_mod.boxes_iou_bev = lambda a, b: torch.from_numpy(ref_iou_bev(lib, a.contiguous().numpy(), b.contiguous().numpy()))
+    at = _load("r.models.dense_heads.target_assigner.atss_target_assigner",
+               "cpd/models/dense_heads/target_assigner/atss_target_assigner.py")
+    g = np.random.default_rng(1912)
+    pcr = np.array([-20.8, -20.8, -2.0, 20.8, 20.8, 4.0], np.float32)
+    agc = [AttrDict(class_name="Vehicle", anchor_sizes=[[4.7, 2.1, 1.7]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0],
+                    align_center=False, feature_map_stride=8),
+           AttrDict(class_name="Pedestrian", anchor_sizes=[[0.91, 0.86, 1.73]], anchor_rotations=[0, 1.57],
+                    anchor_bottom_heights=[0], align_center=False, feature_map_stride=8),
+           AttrDict(class_name="Cyclist", anchor_sizes=[[1.78, 0.84, 1.78]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0],
+                    align_center=False, feature_map_stride=8)]
+    H = W = 52
+    anchors_list, _ = ag.AnchorGenerator(anchor_range=pcr, anchor_generator_config=agc).generate_anchors([[W, H]] * 3)
+    n_gt = 11
+    sizes = np.array([[4.7, 2.1, 1.7], [0.91, 0.86, 1.73], [1.78, 0.84, 1.78]])
+    gt = np.zeros((2, n_gt + 3, 8), np.float32)
+    for b in range(2):
+        cls = g.integers(1, 4, n_gt)
+        for i in range(n_gt - b * 2):                                 # the second frame has two more padding rows
+            gt[b, i] = [g.uniform(-19, 19), g.uniform(-19, 19), g.uniform(-0.5, 0.5), *(sizes[cls[i] - 1] * g.uniform(0.85, 1.15, 3)),
+                        g.uniform(-3.1, 3.1), cls[i]]
+    gt[0, 3, :2] = gt[0, 2, :2] + 0.3                                 # two boxes that compete for the same anchors
+    gt[0, 3, 3:6] = gt[0, 2, 3:6]
+    agc1 = [AttrDict(dict(c, anchor_rotations=[0.6 + 0.3 * i])) for i, c in enumerate(agc)]        # one rotation: no tied pairs
+    anchors_1rot, _ = ag.AnchorGenerator(anchor_range=pcr, anchor_generator_config=agc1).generate_anchors([[W, H]] * 3)
+    out = {"pcr": pcr, "hw": np.array([H, W]), "gt": gt, "anchors_k8": torch.stack(anchors_list).numpy(),
+           "anchors_k9": torch.stack(anchors_1rot).numpy()}
+    coder = bc.ResidualCoder()
+    for k, alist in ((8, anchors_list), (9, anchors_1rot)):
+        asg = at.ATSSTargetAssigner(topk=k, box_coder=coder, match_height=False)
+        t = asg.assign_targets([a.clone() for a in alist], torch.from_numpy(gt.copy()))
+        t1 = asg.assign_targets(alist[0].clone(), torch.from_numpy(gt.copy()))
+        out["labels_k%d" % k] = t["box_cls_labels"].numpy()
+        out["reg_targets_k%d" % k] = t["box_reg_targets"].numpy()
+        out["reg_weights_k%d" % k] = t["reg_weights"].numpy()
+        out["labels_single_k%d" % k] = t1["box_cls_labels"].numpy()
+        print("atss k=%d: %d positive anchors of %d" % (k, int((t["box_cls_labels"] > 0).sum()), t["box_cls_labels"].numel()))
+    np.savez_compressed(os.path.join(HERE, "atss.npz"), **out)
+
+
 def _randomize_bn(mods, gen):
     with torch.no_grad():
         for mod in mods:
@@ -241,6 +300,8 @@ def main():
         return nms_large(m)
     if len(sys.argv) > 1 and sys.argv[1] == "wide_dense":
         return wide_dense(m)
+    if len(sys.argv) > 1 and sys.argv[1] == "atss":
+        return atss(m)
     lib = m["lib"]
     out = {}
 
@@ -705,6 +766,7 @@ def main():
                                                                                      out2["batch_box_preds"].shape[1]))
     nms_large(m)
     wide_dense(m)
+    atss(m)
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

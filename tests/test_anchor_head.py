@@ -205,3 +205,72 @@ def test_fused_anchor_loss_matches_reference_get_loss(golden, hip):
         assert (t - l.grad).abs().max().item() <= 1e-5 * l.grad.abs().max().item()
     again, _ = ah.anchor_head_loss(anchors, cls, box, dr, labels, reg, nc, 1.0, 2.0, 0.2, cw)
     assert torch.equal(again, losses)
+
+
+def _trim(gt):
+    nz = np.nonzero(gt[:, :7].sum(1))[0]
+    return gt[:(nz[-1] + 1 if len(nz) else 1)]
+
+
+@pytest.mark.parametrize("k", [8, 9])
+def test_oracle_atss_reproduces_reference_assigner(oracle, golden, k):
+    """atss.npz = the reference's ATSSTargetAssigner itself (CPU torch, reference CPU IoU): k = 8 on two-rotation anchors,
+    k = 9 on one-rotation anchors (an odd k on tied same-centre pairs is unspecified in torch.topk: make_golden.py::atss)."""
+    g = golden("atss")
+    apc = g["anchors_k%d" % k]
+    for b in range(2):
+        gt = _trim(g["gt"][b])
+        lab, tgt, w = zip(*[oracle.atss_assign(apc[c].reshape(-1, 7), gt, k) for c in range(3)])
+        np.testing.assert_array_equal(np.concatenate(lab), g["labels_k%d" % k][b])
+        np.testing.assert_array_equal(np.concatenate(w), g["reg_weights_k%d" % k][b])
+        np.testing.assert_allclose(np.concatenate(tgt), g["reg_targets_k%d" % k][b], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(lab[0], g["labels_single_k%d" % k][b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [8, 9])
+def test_hip_atss_matches_reference_golden(golden, hip, k):
+    import torch
+    from cpd_amd import anchor_head as ah
+    g = golden("atss")
+    anchors = [torch.from_numpy(a).cuda() for a in g["anchors_k%d" % k]]
+    asg = ah.ATSSTargetAssigner(topk=k, match_height=False)
+    t = asg.assign_targets(anchors, torch.from_numpy(g["gt"]).cuda())
+    np.testing.assert_array_equal(t["box_cls_labels"].cpu().numpy(), g["labels_k%d" % k])
+    np.testing.assert_array_equal(t["reg_weights"].cpu().numpy(), g["reg_weights_k%d" % k])
+    np.testing.assert_allclose(t["box_reg_targets"].cpu().numpy(), g["reg_targets_k%d" % k], rtol=0, atol=1e-6)
+    t1 = asg.assign_targets(anchors[0], torch.from_numpy(g["gt"]).cuda())
+    np.testing.assert_array_equal(t1["box_cls_labels"].cpu().numpy(), g["labels_single_k%d" % k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("match_height", [False, True])
+def test_hip_atss_matches_oracle_at_head_size(oracle, hip, match_height):
+    """One class of a 188 x 188 head (70,688 anchors) against 40 boxes, incl. a box no anchor overlaps, near-duplicate boxes
+    that compete for the same anchors and an all-zero frame (the reference keeps at least one row): the device path never
+    builds the 2.8 M-entry matrices the oracle (and the reference) work on."""
+    import torch
+    from cpd_amd import anchor_head as ah
+    rng = np.random.default_rng(7 + int(match_height))
+    cfg = [dict(class_name="Vehicle", anchor_sizes=[[4.7, 2.1, 1.7]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0])]
+    pcr = [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    anchors, _ = ah.AnchorGenerator(pcr, cfg).generate_anchors([[188, 188]])
+    a = anchors[0].reshape(-1, 7)
+    m = 40
+    gt = np.zeros((1, m + 2, 8), np.float32)
+    for i in range(m):
+        gt[0, i] = [rng.uniform(-70, 70), rng.uniform(-70, 70), rng.uniform(-1.5, 0.5), *(np.array([4.7, 2.1, 1.7]) * rng.uniform(0.7, 1.3, 3)),
+                    rng.uniform(-3.1, 3.1), rng.integers(1, 4)]
+    gt[0, 5, :3] = [300.0, 300.0, 0.0]                                 # outside the anchor grid: IoU 0 with everything
+    gt[0, 8, :7] = gt[0, 7, :7]
+    gt[0, 8, 0] += 0.05                                                # near-duplicate boxes
+    t = ah.ATSSTargetAssigner(topk=9, match_height=match_height).assign_targets(anchors[0], torch.from_numpy(gt).cuda())
+    lab, tgt, w = oracle.atss_assign(a.cpu().numpy(), gt[0, :m], 9, match_height)
+    got = t["box_cls_labels"][0].cpu().numpy()
+    assert (got > 0).sum() >= m - 2
+    np.testing.assert_array_equal(got, lab)
+    np.testing.assert_array_equal(t["reg_weights"][0].cpu().numpy(), w)
+    np.testing.assert_allclose(t["box_reg_targets"][0].cpu().numpy(), tgt, rtol=0, atol=1e-5)
+    zero = np.zeros((1, 3, 8), np.float32)                             # no boxes at all: one all-zero row survives the trim
+    t0 = ah.ATSSTargetAssigner(topk=9).assign_targets(anchors[0], torch.from_numpy(zero).cuda())
+    assert float(t0["box_cls_labels"].abs().sum()) == 0 and float(t0["reg_weights"].sum()) == 0

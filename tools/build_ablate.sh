@@ -12,6 +12,6 @@ for n in "$@"; do
 done
 wait
 for n in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probe/libcpd_abl$n.so voxelize.o site_index.o /tmp/gc_abl$n.o decode.o iou3d_nms.o train_ops.o roi_pool.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probe/libcpd_abl$n.so voxelize.o site_index.o /tmp/gc_abl$n.o decode.o iou3d_nms.o train_ops.o roi_pool.o atss.o
 done
 ls -la ../../tools/probe/*.so
