@@ -75,6 +75,10 @@ SIGNATURES = {
     "cpd_anchor_assign_workspace_bytes": (_SZ, [_I, _I]),
     "cpd_anchor_assign": (_I, [_VP, _I, _VP, _I, _VP, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_anchor_decode": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP]),
+    "cpd_points_in_boxes_mask": (_I, [_VP, _I, _VP, _I, _I, _VP, _VP]),
+    "cpd_crop_boxes_workspace_bytes": (_SZ, [_I]),
+    "cpd_crop_boxes": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_transform_points": (_I, [_VP, _I, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _I, _VP, _VP]),
     "cpd_atss_workspace_bytes": (_SZ, [_I, _I]),
     "cpd_atss_assign": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_voxel2pinds": (_I, [_VP, _I, _I, _I3, _VP, _VP]),

@@ -475,6 +475,138 @@ extern "C" int cpd_merge_sweeps(const float *points, const int32_t *sweep_offset
     return cpd_check_launch();
 }
 
+// ---- prototype box crop (waymo_unsupervised_dataset.py:205-331 sample_prototype_cpu) ------------------------------------
+// check_pt_in_box3d_cpu (roiaware_pool3d.cpp:128-140): |z - cz| > dz / 2.0 rejects; the rectangle test compares
+// fabs(local) with d / 2.0 + MARGIN in DOUBLE (MARGIN = (float)1e-2 promoted), local coordinates from fp32
+// lidar_to_local_coords_cpu (cos / sin of -rz, no contraction).
+__device__ __forceinline__ bool pt_in_box_cpu(float x, float y, float z, const float *q, float ca, float sa) {
+    // q = cx, cy, cz, dx, dy, dz; ca / sa = cos / sin(-rz)
+    if ((double)fabsf(z - q[2]) > (double)q[5] / 2.0) return false;
+    const float sx = x - q[0], sy = y - q[1];
+    const float lx = __fadd_rn(__fmul_rn(sx, ca), __fmul_rn(sy, -sa));
+    const float ly = __fadd_rn(__fmul_rn(sx, sa), __fmul_rn(sy, ca));
+    const double margin = (double)1e-2f;
+    return (double)fabsf(lx) < (double)q[3] / 2.0 + margin && (double)fabsf(ly) < (double)q[4] / 2.0 + margin;
+}
+
+// roiaware_pool3d_utils.points_in_boxes_cpu: out[box][point] = 1 / 0
+__global__ void __launch_bounds__(256) points_in_boxes_mask_kernel(const float *__restrict__ boxes, int k, const float *__restrict__ pts,
+                                                                   int n, int pts_ld, int32_t *__restrict__ out) {
+    __shared__ float s_cs[2];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const float *q = boxes + 7 * (size_t)b;
+    // the host libm's cosf / sinf are correctly rounded in all but rare cases; so is the double routine rounded to float
+    if (threadIdx.x == 0) { s_cs[0] = (float)cos((double)(-q[6])); s_cs[1] = (float)sin((double)(-q[6])); }
+    __syncthreads();
+    if (i >= n) return;
+    const float *p = pts + (size_t)i * pts_ld;
+    out[(size_t)b * n + i] = pt_in_box_cpu(p[0], p[1], p[2], q, s_cs[0], s_cs[1]) ? 1 : 0;
+}
+
+// The two retain masks of sample_prototype_cpu without the boxes x points matrix: bit 0 = the point lies in NO box
+// (retain_mask_no_object), bit 1 = it lies in no box flagged `discard` (retain_mask_good_object). Boxes in LDS, 12 floats each.
+__global__ void __launch_bounds__(256) crop_flags_kernel(const float *__restrict__ pts, int n, int c, const float *__restrict__ boxes,
+                                                         const int32_t *__restrict__ discard, int k, uint8_t *__restrict__ flags) {
+    extern __shared__ float sbox[];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < n) { const float *p = pts + (size_t)i * c; x = p[0]; y = p[1]; z = p[2]; }
+    bool any = false, any_discard = false;
+    for (int k0 = 0; k0 < k; k0 += 512) {
+        const int nk = min(512, k - k0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < nk; j += blockDim.x) {
+            const float *bq = boxes + 7 * (size_t)(k0 + j);
+            for (int q = 0; q < 6; ++q) sbox[12 * j + q] = bq[q];
+            sbox[12 * j + 6] = (float)cos((double)(-bq[6]));
+            sbox[12 * j + 7] = (float)sin((double)(-bq[6]));
+            sbox[12 * j + 8] = discard[k0 + j] ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (i < n) {
+            for (int j = 0; j < nk; ++j) {
+                const float *bq = sbox + 12 * j;
+                if (!pt_in_box_cpu(x, y, z, bq, bq[6], bq[7])) continue;
+                any = true;
+                if (bq[8] != 0.f) any_discard = true;
+            }
+        }
+    }
+    if (i < n) flags[i] = (any ? 0 : 1) | (any_discard ? 0 : 2);
+}
+struct ByteFlagFn {
+    const uint8_t *flags;
+    int bit;
+    __device__ uint32_t operator()(long long i) const { return (flags[i] >> bit) & 1u; }
+};
+
+// Prototype placement (l.277-305): (x, y, z, 1) times A^T, then times B^T, both products in float64 without contraction (numpy
+// matmul of a float64 cloud with float32 matrices promoted to float64); the result goes to columns 0-2 of a zeroed row, rounded
+// to fp32 (the dtype the voxelizer consumes; the reference keeps float64 until its own cast).
+struct TwoMats { double a[16], b[16]; };
+__global__ void __launch_bounds__(256) transform_rows_kernel(const float *__restrict__ pts, int n, int ld, TwoMats m, int c_out,
+                                                             float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pts + (size_t)i * ld;
+    double v[4] = {(double)p[0], (double)p[1], (double)p[2], 1.0}, t[4], u[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        t[r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(v[0], m.a[4 * r]), __dmul_rn(v[1], m.a[4 * r + 1])), __dmul_rn(v[2], m.a[4 * r + 2])),
+                         __dmul_rn(v[3], m.a[4 * r + 3]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        u[r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(t[0], m.b[4 * r]), __dmul_rn(t[1], m.b[4 * r + 1])), __dmul_rn(t[2], m.b[4 * r + 2])),
+                         __dmul_rn(t[3], m.b[4 * r + 3]));
+    float *o = out + (size_t)i * c_out;
+    o[0] = (float)u[0]; o[1] = (float)u[1]; o[2] = (float)u[2];
+    for (int q = 3; q < c_out; ++q) o[q] = 0.f;
+}
+
+extern "C" int cpd_points_in_boxes_mask(const float *boxes, int k, const float *pts, int n, int pts_ld, int32_t *out,
+                                        cpd_stream_t st) {
+    if (k < 0 || n < 0 || pts_ld < 3 || ((size_t)k * n > 0 && (!boxes || !pts || !out))) return CPD_ERR_ARG;
+    if (k == 0 || n == 0) return CPD_OK;
+    points_in_boxes_mask_kernel<<<dim3(cpd_div_up(n, 256), k), 256, 0, cpd_s(st)>>>(boxes, k, pts, n, pts_ld, out);
+    return cpd_check_launch();
+}
+
+extern "C" size_t cpd_crop_boxes_workspace_bytes(int n) {
+    return cpd_align((size_t)(n > 0 ? n : 1)) + cpd_align((size_t)scan_num_blocks(n > 0 ? n : 1) * 4 + 16);
+}
+
+extern "C" int cpd_crop_boxes(const float *points, int n, int c, const float *boxes, const int32_t *discard, int k,
+                              float *out_no_object, int32_t *n_no_object, float *out_good_object, int32_t *n_good_object,
+                              void *workspace, size_t workspace_bytes, cpd_stream_t st) {
+    if (n < 0 || c < 3 || k < 0 || !n_no_object || !n_good_object || !workspace || (k > 0 && (!boxes || !discard)) ||
+        (n > 0 && (!points || !out_no_object || !out_good_object)))
+        return CPD_ERR_ARG;
+    if (workspace_bytes < cpd_crop_boxes_workspace_bytes(n)) return CPD_ERR_WORKSPACE;
+    if (n == 0) {
+        CPD_HIP_TRY(hipMemsetAsync(n_no_object, 0, 4, cpd_s(st)));
+        CPD_HIP_TRY(hipMemsetAsync(n_good_object, 0, 4, cpd_s(st)));
+        return CPD_OK;
+    }
+    uint8_t *flags = static_cast<uint8_t *>(workspace);
+    uint32_t *scan_ws = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + cpd_align((size_t)n));
+    crop_flags_kernel<<<cpd_div_up(n, 256), 256, 512 * 12 * sizeof(float), cpd_s(st)>>>(points, n, c, boxes, discard, k, flags);
+    int rc = cpd_check_launch();
+    if (rc != CPD_OK) return rc;
+    rc = device_scan(n, ByteFlagFn{flags, 0}, CompactRowsFn{points, out_no_object, c}, scan_ws, n_no_object, -1, cpd_s(st));
+    if (rc != CPD_OK) return rc;
+    return device_scan(n, ByteFlagFn{flags, 1}, CompactRowsFn{points, out_good_object, c}, scan_ws, n_good_object, -1, cpd_s(st));
+}
+
+extern "C" int cpd_transform_points(const float *points, int n, int ld, const double a[16], const double b[16], int c_out,
+                                    float *out, cpd_stream_t st) {
+    if (n < 0 || ld < 3 || c_out < 3 || !a || !b || (n > 0 && (!points || !out))) return CPD_ERR_ARG;
+    if (n == 0) return CPD_OK;
+    TwoMats m;
+    for (int q = 0; q < 16; ++q) { m.a[q] = a[q]; m.b[q] = b[q]; }
+    transform_rows_kernel<<<cpd_div_up(n, 256), 256, 0, cpd_s(st)>>>(points, n, ld, m, c_out, out);
+    return cpd_check_launch();
+}
+
 extern "C" int cpd_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts, int pts_ld,
                                    float margin, int32_t *box_idx_of_points, cpd_stream_t st) {
     if (batch < 0 || boxes_num < 0 || pts_num < 0 || pts_ld < 3 || !box_idx_of_points ||

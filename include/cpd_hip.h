@@ -423,6 +423,24 @@ int cpd_merge_sweeps(const float *points, const int32_t *sweep_offsets, int n_sw
 int cpd_points_in_boxes(int batch, int boxes_num, int pts_num, const float *boxes, const float *pts,
                         int pts_ld, float margin, int32_t *box_idx_of_points, cpd_stream_t stream);
 
+/* Prototype box crop, the point work of sample_prototype_cpu (waymo_unsupervised_dataset.py:205-331).
+ * cpd_points_in_boxes_mask = roiaware_pool3d_utils.points_in_boxes_cpu (roiaware_pool3d.cpp:128-168, MARGIN 1e-2, double
+ * comparisons): out [k][n] = 1 where point n lies in box k. */
+int cpd_points_in_boxes_mask(const float *boxes, int k, const float *pts, int n, int pts_ld, int32_t *out,
+                             cpd_stream_t stream);
+/* The two retained clouds of l.255-259 / l.317-318 in one pass, without the k x n matrix: out_no_object = the rows of
+ * points [n][c] that lie in NO box, out_good_object = the rows that lie in no box with discard[k] != 0; both stable
+ * (order preserved), counts on the device. Same in-box test as cpd_points_in_boxes_mask. */
+size_t cpd_crop_boxes_workspace_bytes(int n);
+int cpd_crop_boxes(const float *points, int n, int c, const float *boxes, const int32_t *discard, int k,
+                   float *out_no_object, int32_t *n_no_object, float *out_good_object, int32_t *n_good_object,
+                   void *workspace, size_t workspace_bytes, cpd_stream_t stream);
+/* Prototype placement (l.277-305): rows (x, y, z, 1) of points [n][ld] times A^T, then times B^T (row-major 4x4 doubles:
+ * A = inverse of the prototype box's pose, B = the target box's pose), float64 products without contraction; out [n][c_out]
+ * gets the first three components rounded to fp32 and zeros in the other columns. */
+int cpd_transform_points(const float *points, int n, int ld, const double a[16], const double b[16], int c_out,
+                         float *out, cpd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Anchor head: anchor_head_template.py / axis_aligned_target_assigner.py / box_utils.py.
  * ------------------------------------------------------------------------------------------ */

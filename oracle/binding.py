@@ -252,6 +252,22 @@ class Oracle:
         return out
 
     # ---- anchor head ---------------------------------------------------------------
+    def points_in_boxes_mask(self, boxes, pts):
+        """roiaware_pool3d.cpp:128-168 (points_in_boxes_cpu): mask [K, N] int32. fp32 local coordinates (cos / sin of -rz),
+        comparisons in double against d / 2.0 + (double)(float)1e-2, z against dz / 2.0 without margin."""
+        f = np.float32
+        b, p = _f32(boxes)[:, :7], _f32(pts)[:, :3]
+        out = np.zeros((b.shape[0], p.shape[0]), np.int32)
+        for i, q in enumerate(b):
+            zin = ~(np.abs((p[:, 2] - q[2]).astype(f)).astype(np.float64) > np.float64(q[5]) / 2.0)
+            sx, sy = (p[:, 0] - q[0]).astype(f), (p[:, 1] - q[1]).astype(f)
+            ca, sa = f(np.cos(f(-q[6]))), f(np.sin(f(-q[6])))
+            lx = ((sx * ca).astype(f) + (sy * f(-sa)).astype(f)).astype(f)
+            ly = ((sx * sa).astype(f) + (sy * ca).astype(f)).astype(f)
+            mg = np.float64(f(1e-2))
+            out[i] = zin & (np.abs(lx).astype(np.float64) < np.float64(q[3]) / 2.0 + mg) & (np.abs(ly).astype(np.float64) < np.float64(q[4]) / 2.0 + mg)
+        return out
+
     def nearest_bev_iou(self, a, b):
         a, b = _f32(a), _f32(b)
         out = np.zeros((a.shape[0], b.shape[0]), np.float32)

@@ -240,6 +240,103 @@ def atss(m):
     np.savez_compressed(os.path.join(HERE, "atss.npz"), **out)
 
 
+PROTO_NAMES = ["Vehicle", "Pedestrian", "Cyclist", "Dis_Small", "Sign"]
+
+
+def proto_crop(m):
+    """sample_prototype_cpu (waymo_unsupervised_dataset.py:205-331) executed from the reference file itself (the method's source
+    is cut out of the file at generation time -- the dataset module's import chain is not needed for it -- and run with numpy,
+    a temporary prototype pickle and the reference's compiled points_in_boxes_cpu from oracle/_ref). Two scenes: coin 0 and 1.
+    Class names are stored as indices into PROTO_NAMES. Own RNG: adding this section moves no other fixture."""
+    import ast
+    import pickle
+    import tempfile
+    sys.path.insert(0, REPO)
+    from oracle.binding import load_reference_points_in_boxes
+    ref_pib = load_reference_points_in_boxes()
+    if ref_pib is None:
+        raise SystemExit("build oracle/_ref first: make -C oracle ref")
+    path = os.path.join(REF, "cpd/datasets/waymo_unsupervised/waymo_unsupervised_dataset.py")
+    src = open(path).read()
+    fn = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "sample_prototype_cpu"][0]
+    import textwrap
+    ns = {"np": np, "os": os, "pickle": pickle,
+          "roiaware_pool3d_utils": types.SimpleNamespace(points_in_boxes_cpu=lambda pts, boxes: ref_pib(np.asarray(boxes)[:, :7], np.asarray(pts)[:, :3]))}
+    exec(textwrap.dedent(ast.get_source_segment(src, fn)), ns)
+    sample = ns["sample_prototype_cpu"]
+    rng = np.random.default_rng(205)
+    sizes = {"Vehicle": [4.7, 2.1, 1.7], "Pedestrian": [0.9, 0.85, 1.7], "Cyclist": [1.8, 0.85, 1.75], "Dis_Small": [0.5, 0.5, 0.6],
+             "Sign": [0.3, 0.3, 2.0]}
+    proto_set = {"proto_points_set": {}}
+    for name in ("Vehicle", "Pedestrian", "Cyclist"):
+        proto_set["proto_points_set"][name] = {}
+        for pid in range(3):
+            box = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-0.5, 0.5), *(np.array(sizes[name]) * rng.uniform(0.9, 1.1, 3)),
+                            rng.uniform(-3.1, 3.1)])
+            loc = rng.uniform(-0.62, 0.62, (150, 3)) * box[3:6]           # some points fall outside the box and are cropped
+            c, s_ = np.cos(box[6]), np.sin(box[6])
+            pts = np.stack([loc[:, 0] * c - loc[:, 1] * s_ + box[0], loc[:, 0] * s_ + loc[:, 1] * c + box[1], loc[:, 2] + box[2],
+                            rng.uniform(0, 1, 150)], 1).astype(np.float32)
+            proto_set["proto_points_set"][name][pid] = {"points": pts, "box": box}
+    cfg = AttrDict(InitLabelGenerator="gen", RefinerConfig=AttrDict(
+        DiscardThreshMax={"Vehicle": 0.8, "Pedestrian": 0.7, "Cyclist": 0.7}, DiscardThreshMin={"Vehicle": 0.3, "Pedestrian": 0.2, "Cyclist": 0.25}))
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        os.makedirs(os.path.join(root, "seq"))
+        with open(os.path.join(root, "seq", "seq_outline_gen_CSS_proto.pkl"), "wb") as f:
+            pickle.dump(proto_set, f)
+        for scene in range(2):
+            k = 14
+            names = [PROTO_NAMES[i] for i in rng.integers(0, 5, k)]
+            names[0], names[1], names[2] = "Vehicle", "Pedestrian", "Cyclist"
+            boxes = np.zeros((k, 7))
+            for i, nme in enumerate(names):
+                boxes[i] = [rng.uniform(-60, 60), rng.uniform(-60, 60), rng.uniform(-0.5, 0.5), *(np.array(sizes[nme]) * rng.uniform(0.9, 1.1, 3)),
+                            rng.uniform(-3.1, 3.1)]
+            boxes[3, :2] = [70.0, 40.0]                                 # beyond 75 m: dropped, and its points are discarded
+            score = rng.uniform(0.05, 0.95, k)
+            score[0], score[1] = 0.9, 0.1                               # clamped above / rejected below the thresholds
+            pid = rng.integers(-1, 3, k)
+            pid[0], pid[2] = 1, 2
+            bg = np.concatenate([rng.uniform(-75, 75, (2500, 2)), rng.uniform(-2, 3, (2500, 1)), rng.uniform(0, 1, (2500, 2))], 1)
+            obj = []
+            for b in boxes:                                             # clusters in and around every box
+                loc = rng.uniform(-0.7, 0.7, (60, 3)) * b[3:6]
+                c, s_ = np.cos(b[6]), np.sin(b[6])
+                obj.append(np.stack([loc[:, 0] * c - loc[:, 1] * s_ + b[0], loc[:, 0] * s_ + loc[:, 1] * c + b[1], loc[:, 2] + b[2],
+                                     rng.uniform(0, 1, 60), rng.uniform(0, 1, 60)], 1))
+            points = np.concatenate([bg] + obj).astype(np.float32)
+            points = points[rng.permutation(len(points))]
+            for seed in range(1000):                                    # a seed whose coin is `scene`
+                np.random.seed(seed)
+                if np.random.randint(2) == scene:
+                    break
+            np.random.seed(seed)
+            good, proto, nb, nc, nsc, nid = sample(None, "seq", root, points, boxes, names, score, pid, cfg)
+            np.random.seed(seed)
+            coin = np.random.randint(2)
+            crop = ref_pib(boxes, points[:, :3])
+            disc = np.ones(k, bool)
+            disc[[i for i in range(k) if any((boxes[i] == b).all() for b in nb)]] = False
+            n_good_full = int((crop[disc].sum(0) == 0).sum()) if disc.any() else len(points)
+            perm = np.random.permutation(n_good_full) if coin else np.zeros(0, np.int64)
+            pre = "s%d_" % scene
+            out.update({pre + "points": points, pre + "boxes": boxes, pre + "names": np.array([PROTO_NAMES.index(n) for n in names]),
+                        pre + "score": score, pre + "proto_id": pid, pre + "coin": np.int64(coin), pre + "perm": perm,
+                        pre + "good": good, pre + "proto": proto.astype(np.float32), pre + "new_boxes": nb,   # proto: float64 in the reference, stored rounded
+                        pre + "new_names": np.array([PROTO_NAMES.index(n) for n in nc]), pre + "new_score": nsc, pre + "new_id": nid})
+            print("proto_crop scene %d: coin %d, %d points -> good %d, proto %d (%d boxes kept of %d)" % (scene, coin, len(points), len(good),
+                                                                                                   len(proto), len(nb), k))
+    for name in ("Vehicle", "Pedestrian", "Cyclist"):
+        for pid_ in range(3):
+            e = proto_set["proto_points_set"][name][pid_]
+            out["set_%s_%d_points" % (name, pid_)] = e["points"]
+            out["set_%s_%d_box" % (name, pid_)] = e["box"]
+    out["thr_max"] = np.array([0.8, 0.7, 0.7])
+    out["thr_min"] = np.array([0.3, 0.2, 0.25])
+    np.savez_compressed(os.path.join(HERE, "proto_crop.npz"), **out)
+
+
 def _randomize_bn(mods, gen):
     with torch.no_grad():
         for mod in mods:
@@ -302,6 +399,8 @@ def main():
         return wide_dense(m)
     if len(sys.argv) > 1 and sys.argv[1] == "atss":
         return atss(m)
+    if len(sys.argv) > 1 and sys.argv[1] == "proto_crop":
+        return proto_crop(m)
     lib = m["lib"]
     out = {}
 
@@ -767,6 +866,7 @@ def main():
     nms_large(m)
     wide_dense(m)
     atss(m)
+    proto_crop(m)
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

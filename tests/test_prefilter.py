@@ -122,3 +122,95 @@ def test_merge_sweeps_matches_the_reference_arithmetic(hip):
     assert np.mean(got[:, :3] == want[:, :3]) > 0.99
     # the current sweep maps onto itself up to the two roundings
     np.testing.assert_allclose(got[-4097:, :3], sweeps[-1][:, :3], atol=2e-4)
+
+
+PROTO_NAMES = ["Vehicle", "Pedestrian", "Cyclist", "Dis_Small", "Sign"]
+
+
+def _proto_set(g, to_torch=None):
+    ps = {}
+    for name in PROTO_NAMES[:3]:
+        ps[name] = {}
+        for pid in range(3):
+            pts = g["set_%s_%d_points" % (name, pid)]
+            ps[name][pid] = {"points": to_torch(pts) if to_torch else pts, "box": g["set_%s_%d_box" % (name, pid)]}
+    return ps
+
+
+@pytest.mark.gpu
+def test_sample_prototype_matches_reference_method(golden, hip):
+    """proto_crop.npz = the reference's sample_prototype_cpu itself (its source run from the reference file on the reference's
+    compiled points_in_boxes_cpu). Retained clouds: the same rows in the same order, bit for bit; placed prototypes: the
+    reference's float64 result rounded to fp32, <= 1 ulp-level (1e-5 m)."""
+    import torch
+    from cpd_amd import prefilter
+    g = golden("proto_crop")
+    thr_max = dict(zip(PROTO_NAMES[:3], g["thr_max"].tolist()))
+    thr_min = dict(zip(PROTO_NAMES[:3], g["thr_min"].tolist()))
+    ps = _proto_set(g, lambda a: torch.from_numpy(a).cuda())
+    for scene in range(2):
+        pre = "s%d_" % scene
+        pts = torch.from_numpy(g[pre + "points"]).cuda()
+        names = [PROTO_NAMES[i] for i in g[pre + "names"]]
+        good, proto, nb, nc, nsc, nid = prefilter.sample_prototype(pts, g[pre + "boxes"], names, g[pre + "score"], g[pre + "proto_id"], ps,
+                                                                    thr_max, thr_min, coin=int(g[pre + "coin"]), permutation=g[pre + "perm"])
+        assert int(g[pre + "coin"]) == scene
+        np.testing.assert_array_equal(good.cpu().numpy(), g[pre + "good"])
+        want = g[pre + "proto"]
+        got = proto.cpu().numpy()
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
+        tail = got[-1000:]
+        np.testing.assert_array_equal(tail, want[-1000:])                      # the no-object rows at the end are copies: exact
+        np.testing.assert_array_equal(nb, g[pre + "new_boxes"])
+        np.testing.assert_array_equal([PROTO_NAMES.index(n) for n in nc], g[pre + "new_names"])
+        np.testing.assert_allclose(nsc, g[pre + "new_score"], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(nid, g[pre + "new_id"])
+
+
+@pytest.mark.gpu
+def test_points_in_boxes_cpu_and_crop_match_compiled_reference(oracle, hip):
+    """roiaware_pool3d.cpp's points_in_boxes_cpu compiled from the reference (oracle/_ref) against the device mask, incl. points on
+    the MARGIN shell and the z faces; crop_boxes against masks built from that matrix."""
+    import torch
+    from oracle.binding import load_reference_points_in_boxes
+    from cpd_amd import prefilter
+    ref = load_reference_points_in_boxes()
+    rng = np.random.default_rng(11)
+    k, n = 37, 20000
+    boxes = np.concatenate([rng.uniform(-40, 40, (k, 2)), rng.uniform(-1, 1, (k, 1)), rng.uniform(0.5, 6, (k, 3)), rng.uniform(-3.2, 3.2, (k, 1))], 1).astype(np.float32)
+    pts = np.concatenate([rng.uniform(-45, 45, (n, 2)), rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)
+    for i in range(k):                                                  # points on / next to every face, incl. the 1e-2 margin shell
+        b = boxes[i]
+        c, s = np.cos(b[6]), np.sin(b[6])
+        for j, (fx, fy, fz) in enumerate([(0.5, 0, 0), (0.5 + 0.01 / b[3], 0, 0), (0, 0.5 + 0.0099 / b[4], 0), (0, 0, 0.5), (0, 0, 0.50001), (0.499, 0.499, -0.5)]):
+            lx, ly, lz = fx * b[3], fy * b[4], fz * b[5]
+            pts[i * 6 + j] = [lx * c - ly * s + b[0], lx * s + ly * c + b[1], lz + b[2]]
+    want = ref(boxes, pts) if ref is not None else oracle.points_in_boxes_mask(boxes, pts)
+    got = prefilter.points_in_boxes_cpu(torch.from_numpy(pts).cuda(), torch.from_numpy(boxes).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    full = np.concatenate([pts, rng.uniform(0, 1, (n, 2)).astype(np.float32)], 1)
+    discard = rng.integers(0, 2, k).astype(bool)
+    a, b_ = prefilter.crop_boxes(torch.from_numpy(full).cuda(), torch.from_numpy(boxes).cuda(), discard)
+    np.testing.assert_array_equal(a.cpu().numpy(), full[want.sum(0) == 0])
+    np.testing.assert_array_equal(b_.cpu().numpy(), full[want[discard].sum(0) == 0])
+    e0, e1 = prefilter.crop_boxes(torch.from_numpy(full).cuda(), torch.zeros((0, 7)).cuda(), np.zeros(0, bool))   # no boxes: everything stays
+    assert e0.shape[0] == n and e1.shape[0] == n
+
+
+def test_oracle_points_in_boxes_mask_matches_compiled_reference(oracle):
+    from oracle.binding import load_reference_points_in_boxes
+    ref = load_reference_points_in_boxes()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(3)
+    k, n = 25, 6000
+    boxes = np.concatenate([rng.uniform(-20, 20, (k, 2)), rng.uniform(-1, 1, (k, 1)), rng.uniform(0.5, 6, (k, 3)), rng.uniform(-3.2, 3.2, (k, 1))], 1).astype(np.float32)
+    pts = np.concatenate([rng.uniform(-24, 24, (n, 2)), rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)
+    for i in range(k):
+        b = boxes[i]
+        c, s = np.cos(b[6]), np.sin(b[6])
+        for j, (fx, fy, fz) in enumerate([(0.5, 0, 0), (0.5 + 0.01 / b[3], 0, 0), (0, 0.5 + 0.0099 / b[4], 0), (0, 0, 0.5), (0, 0, 0.50001)]):
+            lx, ly, lz = fx * b[3], fy * b[4], fz * b[5]
+            pts[i * 5 + j] = [lx * c - ly * s + b[0], lx * s + ly * c + b[1], lz + b[2]]
+    np.testing.assert_array_equal(oracle.points_in_boxes_mask(boxes, pts), ref(boxes, pts))
