@@ -123,6 +123,25 @@ __global__ void __launch_bounds__(256) group_points_kernel(int nb, int m, int c,
     out[i] = feat[(start + idx[(size_t)pt * nsample + s]) * c + ci];
 }
 
+// group_points_grad_kernel_stack (group_points_gpu.cu:9-36): grad_features[start + idx[pt][s]][c] += grad_out[pt][c][s].
+// Thread = (pt, s, c) with c fastest, so the atomics of a wave land on consecutive floats of one feature row.
+__global__ void __launch_bounds__(256) group_points_grad_kernel(int nb, int m, int c, int nsample, const float *__restrict__ grad_out,
+                                                                const int32_t *__restrict__ feat_cnt, const int32_t *__restrict__ idx,
+                                                                const int32_t *__restrict__ idx_cnt, float *__restrict__ grad_feat) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)m * c * nsample) return;
+    const int ci = (int)(i % c), s = (int)((i / c) % nsample), pt = (int)(i / c / nsample);
+    int bs = 0, cnt = idx_cnt[0];
+    for (int k = 1; k < nb; ++k) {
+        if (pt < cnt) break;
+        cnt += idx_cnt[k];
+        bs = k;
+    }
+    long long start = 0;
+    for (int k = 0; k < bs; ++k) start += feat_cnt[k];
+    atomicAdd(&grad_feat[(start + idx[(size_t)pt * nsample + s]) * c + ci], grad_out[((size_t)pt * c + ci) * nsample + s]);
+}
+
 // out[m][ch] = max_s relu(fin[idx[m][s]][ch] + (xyz[idx[m][s]] - new_xyz[m]) . Wpos[:, ch] + bpos[ch]);
 // an empty ball (idx[m][0] < 0) gives relu(bpos[ch]) -- grouped features and offsets are zeroed
 // (voxel_pool_modules.py:99,105) before the position MLP. One thread per (m, ch).
@@ -673,6 +692,19 @@ extern "C" int cpd_group_points(int b, int m, int c, int nsample, const float *f
     const long long total = (long long)m * c * nsample;
     group_points_kernel<<<cpd_div_up(total, 256), 256, 0, cpd_s(st)>>>(b, m, c, nsample, features, features_batch_cnt, idx,
                                                                         idx_batch_cnt, out);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_group_points_grad(int b, int m, int c, int nsample, int n, const float *grad_out, const int32_t *features_batch_cnt,
+                                     const int32_t *idx, const int32_t *idx_batch_cnt, float *grad_features, cpd_stream_t st) {
+    if (b <= 0 || m < 0 || c <= 0 || nsample <= 0 || n < 0 || !features_batch_cnt || !idx_batch_cnt || (n > 0 && !grad_features) ||
+        (m > 0 && (!grad_out || !idx)))
+        return CPD_ERR_ARG;
+    if (n > 0) CPD_HIP_TRY(hipMemsetAsync(grad_features, 0, (size_t)n * c * sizeof(float), cpd_s(st)));
+    if (m == 0 || n == 0) return CPD_OK;
+    const long long total = (long long)m * c * nsample;
+    group_points_grad_kernel<<<cpd_div_up(total, 256), 256, 0, cpd_s(st)>>>(b, m, c, nsample, grad_out, features_batch_cnt, idx,
+                                                                             idx_batch_cnt, grad_features);
     return cpd_check_launch();
 }
 

@@ -463,11 +463,14 @@ def _decode_separate(views, nc, h, w, pp, stride, voxel_size, pcr):
 # --------------------------------------------------------------------------------- detector
 def _anchor_heads():
     from . import anchor_head                        # (imports this module's Conv2d lazily)
-    return {"AnchorHeadSingle": anchor_head.AnchorHeadSingle, "AnchorHeadSingleV2": anchor_head.AnchorHeadSingleV2}
+    from . import roi_head_train, roi_pool
+    return {"AnchorHeadSingle": anchor_head.AnchorHeadSingle, "AnchorHeadSingleV2": anchor_head.AnchorHeadSingleV2,
+            "VoxelRCNNHead": roi_pool.VoxelRCNNHead, "VoxelRCNNProtoHead": roi_head_train.VoxelRCNNProtoHead}
 
 
 class _Registry(dict):
-    """`__all__[NAME]` like the reference's registries (dense_heads/__init__.py); the anchor heads resolve on first use."""
+    """`__all__[NAME]` like the reference's registries (dense_heads/__init__.py, roi_heads/__init__.py); the anchor heads and
+    the RoI heads resolve on first use."""
 
     def __missing__(self, name):
         heads = _anchor_heads()

@@ -7,10 +7,11 @@ csrc/roi_pool.hip. Mirrors, name for name:
   NeighborVoxelSAModuleMSG                     cpd/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:8-131
   get_global_grid_points_of_roi, roi_grid_pool cpd/models/roi_heads/voxel_rcnn_head.py:186-273, 365-386
 
-The module runs eval-mode (BatchNorm folded): the per-voxel MLP (mlps_in) and the output MLP
+In eval mode (BatchNorm folded) the per-voxel MLP (mlps_in) and the output MLP
 (mlps_out) are 1x1 `cpd_gather_conv` GEMMs; grouping, position encoding, ReLU and max-pool are one
 fused kernel (`cpd_voxel_pool_max`), so the (M, C, nsample) grouped tensors of the reference are
-never materialised. The neighbour query can use the sparse tensor's own site index
+never materialised. In training mode the module follows the reference's sequence with the differentiable
+`GroupingOperation` (`cpd_group_points` / `cpd_group_points_grad`); see cpd_amd/roi_head_train.py. The neighbour query can use the sparse tensor's own site index
 (`cpd_voxel_query_index`) instead of a dense (B,Z,Y,X) volume.
 """
 import ctypes
@@ -70,6 +71,45 @@ def grouping_operation(features, features_batch_cnt, idx, idx_batch_cnt):
     return out
 
 
+class GroupingOperation(torch.autograd.Function):
+    """pointnet2_utils.GroupingOperation (pointnet2_utils.py:48-108): forward `cpd_group_points`, backward
+    `cpd_group_points_grad` (the scatter-add of the grouped gradient back to the feature rows)."""
+
+    @staticmethod
+    def forward(ctx, features, features_batch_cnt, idx, idx_batch_cnt):
+        out = grouping_operation(features, features_batch_cnt, idx, idx_batch_cnt)
+        ctx.n = features.shape[0]
+        ctx.save_for_backward(features_batch_cnt.int().contiguous(), idx.contiguous(), idx_batch_cnt.int().contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        fcnt, idx, icnt = ctx.saved_tensors
+        grad_out = grad_out.contiguous().float()
+        m, c, ns = grad_out.shape
+        g = torch.empty((ctx.n, c), dtype=torch.float32, device=grad_out.device)
+        check(lib().cpd_group_points_grad(int(fcnt.shape[0]), m, c, ns, ctx.n, ptr(grad_out), ptr(fcnt), ptr(idx), ptr(icnt), ptr(g),
+                                          stream()), "cpd_group_points_grad")
+        return g, None, None, None
+
+
+def voxel_query_and_grouping(max_range, radius, nsample, new_coords, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features,
+                             voxel2point_indices=None, index=None):
+    """VoxelQueryAndGrouping.forward (voxel_query_utils.py:61-110): (grouped_features (M, C, ns), grouped_xyz (M, 3, ns),
+    empty_ball_mask (M)); differentiable in `features`. The query returns global rows; they are made per-sample like the
+    reference does before grouping."""
+    idx, empty = voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, voxel2point_indices, index)
+    batch = xyz_batch_cnt.shape[0]
+    starts = torch.cumsum(xyz_batch_cnt.int(), 0) - xyz_batch_cnt.int()
+    per_pt = torch.repeat_interleave(starts, new_xyz_batch_cnt.long()) if batch > 1 else None
+    if per_pt is not None:
+        idx = idx - per_pt[:, None].int()
+    idx[empty] = 0
+    grouped_xyz = GroupingOperation.apply(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)
+    grouped_features = GroupingOperation.apply(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
+    return grouped_features, grouped_xyz, empty
+
+
 def voxel_pool_max(features_in, xyz, new_xyz, idx_raw, w_pos, b_pos):
     """Fused grouping + position MLP + ReLU + max over samples -> [M, C]. idx_raw: kernel output
     (global rows, idx[m,0] == -1 for an empty ball)."""
@@ -87,7 +127,10 @@ def _fold(bn):
 
 
 class NeighborVoxelSAModuleMSG(nn.Module):
-    """State-dict compatible with the reference module (mlps_in / mlps_pos / mlps_out); eval mode only."""
+    """State-dict compatible with the reference module (mlps_in / mlps_pos / mlps_out). Eval mode: BatchNorm folded, three
+    launches per scale (see the module docstring). Training mode: the reference's own sequence (voxel_pool_modules.py:86-128) --
+    torch Conv / BatchNorm modules with batch statistics on the device, the neighbour query and the differentiable grouping
+    (`GroupingOperation`) on the C-ABI kernels --, so gradients reach the MLPs and, through `features`, the sparse backbone."""
 
     def __init__(self, *, query_ranges, radii, nsamples, mlps, use_xyz=True, pool_method="max_pool"):
         super().__init__()
@@ -120,11 +163,31 @@ class NeighborVoxelSAModuleMSG(nn.Module):
                            c0=w_in.shape[1], c1=w_in.shape[2], c2=w_out.shape[2]))
         self._packed = pk
 
-    @torch.no_grad()
+    def _forward_train(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index):
+        new_coords = new_coords[:, [0, 3, 2, 1]].contiguous()
+        outs = []
+        for k in range(len(self.nsamples)):
+            fin = self.mlps_in[k](features.permute(1, 0).unsqueeze(0))                       # (1, C1, N)
+            fin = fin.permute(0, 2, 1).contiguous().view(-1, fin.shape[1])                   # (N, C1)
+            gf, gx, empty = voxel_query_and_grouping(self.query_ranges[k], self.radii[k], self.nsamples[k], new_coords, xyz,
+                                                     xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, fin, voxel2point_indices, index)
+            keep = (~empty).to(gf.dtype)[:, None, None]
+            gf = (gf * keep).permute(1, 0, 2).unsqueeze(0)                                   # zeroed empty balls, (1, C1, M, ns)
+            gx = ((gx - new_xyz.unsqueeze(-1)) * keep).permute(1, 0, 2).unsqueeze(0)         # (1, 3, M, ns)
+            x = torch.relu(gf + self.mlps_pos[k](gx))
+            x = x.max(dim=3)[0]                                                              # max_pool2d over the samples
+            outs.append(self.mlps_out[k](x).squeeze(0).permute(1, 0))
+        return torch.cat(outs, dim=1)
+
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices=None,
                 index=None):
         if self.training:
-            raise NotImplementedError("the pooling module runs eval-mode (BatchNorm folded)")
+            self._packed = None
+            return self._forward_train(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index)
+        with torch.no_grad():
+            return self._forward_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index)
+
+    def _forward_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index):
         if self._packed is None:
             self._pack()
         new_coords = new_coords[:, [0, 3, 2, 1]].contiguous()                 # (b,x,y,z) -> (b,z,y,x), l.84
@@ -228,7 +291,8 @@ class VoxelRCNNHead(nn.Module):
     """Eval forward of VoxelRCNNHead (cpd/models/roi_heads/voxel_rcnn_head.py:664-760, 876-916): RoI grid pooling,
     shared FC / cls / reg stacks (Linear + eval BatchNorm1d + ReLU folded into `cpd_gather_conv` GEMM epilogues) and
     RoIHeadTemplate.generate_predicted_boxes (roi_head_template.py:269-299). Same constructor arguments and
-    state_dict names as the reference module; the training branch (proposal target sampling, losses) is not built."""
+    state_dict names as the reference module; the training branch lives in cpd_amd/roi_head_train.py (VoxelRCNNProtoHead, the
+    head the shipped config selects)."""
 
     def __init__(self, input_channels, model_cfg, point_cloud_range=None, voxel_size=None, num_frames=1, num_class=1, **kwargs):
         super().__init__()

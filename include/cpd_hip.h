@@ -392,6 +392,12 @@ int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, int nsample,
 int cpd_group_points(int b, int m, int c, int nsample, const float *features,
                      const int32_t *features_batch_cnt, const int32_t *idx, const int32_t *idx_batch_cnt,
                      float *out, cpd_stream_t stream);
+/* group_points_grad_wrapper (group_points_gpu.cu:9-66): grad_features [n, c] (zeroed here) += grad_out [m, c, nsample]
+ * scattered through idx; the backward of cpd_group_points. Float atomics: the summation order is not fixed, as in the
+ * reference. */
+int cpd_group_points_grad(int b, int m, int c, int nsample, int n, const float *grad_out,
+                          const int32_t *features_batch_cnt, const int32_t *idx, const int32_t *idx_batch_cnt,
+                          float *grad_features, cpd_stream_t stream);
 /* Fused grouping + position encoding + ReLU + max-pool of NeighborVoxelSAModuleMSG.forward
  * (voxel_pool_modules.py:96-117): out[m][ch] = max_s relu(features_in[idx[m][s]][ch] +
  * (xyz[idx[m][s]] - new_xyz[m]) . w_pos[:, ch] + b_pos[ch]), relu(b_pos[ch]) for an empty ball

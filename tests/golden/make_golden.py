@@ -240,6 +240,175 @@ def atss(m):
     np.savez_compressed(os.path.join(HERE, "atss.npz"), **out)
 
 
+def _load_roi_stack(m):
+    """The reference's second-stage Python stack on CPU: voxel_pool_modules / voxel_query_utils / pointnet2_utils,
+    proposal_target_layer, roi_head_template, voxel_rcnn_head, bbloss, loss_utils + box_utils, common_utils -- all loaded by
+    file path. The CUDA extensions they call are served by the oracle (voxel query, grouping and its scatter-add backward, 3-D
+    IoU) and by the reference's compiled CPU IoU (proposal NMS). Module loading only: no random numbers are drawn here."""
+    import types as _t
+    sys.path.insert(0, REPO)
+    from oracle.binding import Oracle
+    orc = Oracle()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for pkg in ["r.ops.pointnet2", "r.ops.pointnet2.pointnet2_stack", "r.models.roi_heads", "r.models.roi_heads.target_assigner"]:
+        if pkg not in sys.modules:
+            _pkg(pkg)
+    ext = _t.ModuleType("r.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda")
+
+    def voxel_query_wrapper(M, Z, Y, X, nsample, radius, zr, yr, xr, new_xyz, xyz, new_coords, point_indices, idx):
+        idx.copy_(torch.from_numpy(orc.voxel_query([zr, yr, xr], radius, nsample, xyz.numpy(), new_xyz.numpy(), new_coords.numpy(),
+                                                   point_indices.numpy())))
+
+    def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, output):
+        output.copy_(torch.from_numpy(orc.group_points(features.detach().numpy(), features_batch_cnt.numpy(), idx.numpy(),
+                                                       idx_batch_cnt.numpy())))
+
+    def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
+        # group_points_grad_kernel_stack (group_points_gpu.cu:9-36): scatter-add of the grouped gradient, in float64 here
+        go, ix = grad_out.numpy().astype(np.float64), idx.numpy()
+        starts_f = np.concatenate([[0], np.cumsum(features_batch_cnt.numpy())[:-1]])
+        pt_batch = np.repeat(np.arange(B), idx_batch_cnt.numpy())
+        rows = starts_f[pt_batch][:, None] + ix                                        # (M, nsample)
+        acc = np.zeros((N, C))
+        np.add.at(acc, rows.reshape(-1), go.transpose(0, 2, 1).reshape(-1, C))
+        grad_features.copy_(torch.from_numpy(acc.astype(np.float32)))
+
+    ext.voxel_query_wrapper, ext.group_points_wrapper, ext.group_points_grad_wrapper = voxel_query_wrapper, group_points_wrapper, group_points_grad_wrapper
+    sys.modules[ext.__name__] = ext
+    sys.modules["r.ops.pointnet2.pointnet2_stack"].pointnet2_stack_cuda = ext
+    torch.cuda.IntTensor = lambda *sz: torch.zeros(*sz, dtype=torch.int32)
+    torch.cuda.FloatTensor = lambda *sz: torch.zeros(*sz, dtype=torch.float32)
+    stack = sys.modules["r.ops.pointnet2.pointnet2_stack"]
+    stack.pointnet2_utils = _load("r.ops.pointnet2.pointnet2_stack.pointnet2_utils", "cpd/ops/pointnet2/pointnet2_stack/pointnet2_utils.py")
+    stack.voxel_query_utils = _load("r.ops.pointnet2.pointnet2_stack.voxel_query_utils", "cpd/ops/pointnet2/pointnet2_stack/voxel_query_utils.py")
+    vp = _load("r.ops.pointnet2.pointnet2_stack.voxel_pool_modules", "cpd/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py")
+    stack.voxel_pool_modules = vp
+    sys.modules["r.ops.pointnet2"].pointnet2_stack = stack
+    cu = _load("r.utils.common_utils", "cpd/utils/common_utils.py")
+    sys.modules["r.utils"].common_utils = cu
+    for stub in ["r.ops.roiaware_pool3d", "r.ops.roiaware_pool3d.roiaware_pool3d_utils"]:
+        sys.modules.setdefault(stub, _t.ModuleType(stub))
+    sys.modules["r.ops"].roiaware_pool3d = sys.modules["r.ops.roiaware_pool3d"]
+    sys.modules["r.ops.roiaware_pool3d"].roiaware_pool3d_utils = sys.modules["r.ops.roiaware_pool3d.roiaware_pool3d_utils"]
+    sys.modules["scipy.spatial"] = __import__("scipy.spatial").spatial
+    bu = _load("r.utils.box_utils", "cpd/utils/box_utils.py")
+    sys.modules["r.utils"].box_utils = bu
+    m["loss_utils"].box_utils = bu                                     # setup_reference() loaded loss_utils against an empty stub
+    sys.modules["r.utils"].box_coder_utils = _load("r.utils.box_coder_utils", "cpd/utils/box_coder_utils.py")
+    spu = _t.ModuleType("r.utils.spconv_utils")                        # generate_voxel2pinds only (the file imports spconv at top)
+    spu.generate_voxel2pinds = lambda t: torch.from_numpy(orc.voxel2pinds(t.indices.numpy().astype(np.int32), t.batch_size, list(t.spatial_shape)))
+    sys.modules["r.utils.spconv_utils"] = spu
+    sys.modules["r.utils"].spconv_utils = spu
+    nms_mod = sys.modules["r.ops.iou3d_nms.iou3d_nms_utils"]
+    nms_mod.boxes_iou3d_gpu = lambda a, b: torch.from_numpy(orc.boxes_iou3d(a.contiguous().numpy(), b.contiguous().numpy()))
+    _load("r.utils.bbloss", "cpd/utils/bbloss.py")
+    _load("r.utils.odiou_loss", "cpd/utils/odiou_loss.py")
+    ptl = _load("r.models.roi_heads.target_assigner.proposal_target_layer", "cpd/models/roi_heads/target_assigner/proposal_target_layer.py")
+    rht = _load("r.models.roi_heads.roi_head_template", "cpd/models/roi_heads/roi_head_template.py")
+    vrh = _load("r.models.roi_heads.voxel_rcnn_head", "cpd/models/roi_heads/voxel_rcnn_head.py")
+    return dict(orc=orc, vp=vp, ptl=ptl, rht=rht, vrh=vrh, cu=cu)
+
+
+def proto_head(m):
+    """VoxelRCNNProtoHead in TRAINING mode (voxel_rcnn_head.py:16-662): proposal layer (class-agnostic NMS), proposal target
+    sampling (np.random / torch.randint under recorded seeds), canonical targets, both pooling branches with batch-statistics
+    BatchNorm, get_loss and its autograd gradients, all from the reference's own classes on CPU (_load_roi_stack). DP_RATIO = 0:
+    dropout masks are not reproducible across devices. Own RNG: adding this section moves no other fixture."""
+    R = _load_roi_stack(m)
+    pool = lambda: AttrDict(FEATURES_SOURCE=["x_conv3", "x_conv4"], PRE_MLP=True, GRID_SIZE=2, POOL_LAYERS=AttrDict(
+        x_conv3=AttrDict(MLPS=[[16, 16], [16, 16]], QUERY_RANGES=[[1, 1, 1], [2, 2, 2]], POOL_RADIUS=[0.6, 1.2], NSAMPLE=[8, 8], POOL_METHOD="max_pool"),
+        x_conv4=AttrDict(MLPS=[[16, 16], [16, 16]], QUERY_RANGES=[[1, 1, 1], [2, 2, 2]], POOL_RADIUS=[1.2, 2.4], NSAMPLE=[8, 8], POOL_METHOD="max_pool")))
+    cfg = AttrDict(
+        CLASS_AGNOSTIC=True, ROI_GRID_POOL=pool(), ROI_GRID_POOL_PROTO=pool(), SHARED_FC=[48, 48], CLS_FC=[32, 32], REG_FC=[32, 32], DP_RATIO=0.0,
+        TARGET_CONFIG=AttrDict(BOX_CODER="ResidualCoder", ROI_PER_IMAGE=24, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True, CLS_SCORE_TYPE="roi_iou",
+                               CLS_FG_THRESH=0.6, CLS_BG_THRESH=0.02, CLS_BG_THRESH_LO=0.01, HARD_BG_RATIO=0.1, REG_FG_THRESH=0.3),
+        LOSS_CONFIG=AttrDict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="smooth-l1", CORNER_LOSS_REGULARIZATION=True, GRID_3D_IOU_LOSS=False,
+                             LOSS_WEIGHTS=AttrDict(rcnn_proto_weight=1.0, rcnn_cls_weight=1.0, rcnn_reg_weight=1.0, rcnn_corner_weight=1.0,
+                                                   rcnn_iou3d_weight=1.0, code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.8])),
+        NMS_CONFIG=AttrDict(TRAIN=AttrDict(NMS_TYPE="nms_gpu", MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=400, NMS_POST_MAXSIZE=60, NMS_THRESH=0.8)))
+    pcr = np.array([-20.8, -20.8, -2.0, 20.8, 20.8, 4.0], np.float32)
+    g = np.random.default_rng(1662)
+    torch.manual_seed(1662)
+    head = R["vrh"].VoxelRCNNProtoHead(input_channels={"x_conv3": 8, "x_conv4": 12}, model_cfg=cfg, point_cloud_range=pcr,
+                                       voxel_size=[0.1, 0.1, 0.15], num_class=1).train()
+    with torch.no_grad():
+        for mm in head.modules():
+            if isinstance(mm, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mm.weight.uniform_(0.6, 1.4); mm.bias.normal_(0, 0.2)
+        for stack in (head.cls_layers, head.reg_layers, head.cls_layers_P, head.reg_layers_P):
+            stack[-1].weight.normal_(0, 0.08)
+    from types import SimpleNamespace
+    B, n_gt = 2, 7
+    gt = np.zeros((B, n_gt + 2, 8), np.float32)
+    sizes = np.array([[4.6, 2.0, 1.7], [0.9, 0.8, 1.7], [1.8, 0.8, 1.7]])
+    for b in range(B):
+        for i in range(n_gt - b):
+            c = g.integers(1, 4)
+            gt[b, i] = [g.uniform(-17, 17), g.uniform(-17, 17), g.uniform(-0.3, 0.6), *(sizes[c - 1] * g.uniform(0.9, 1.1, 3)), g.uniform(-3.1, 3.1), c]
+    css = np.zeros((B, n_gt + 2), np.float32)
+    css[:, :n_gt] = g.uniform(0.2, 1.0, (B, n_gt))
+    css[0, 1] = 0.0                                                    # a box whose prototype confidence switches its RoIs off
+    # dense-head output the proposal layer sees: jittered copies of the boxes (several IoU levels) + clutter
+    n_prop = 420
+    boxes = np.zeros((B, n_prop, 7), np.float32)
+    cls = g.normal(-2.0, 1.0, (B, n_prop, 3)).astype(np.float32)
+    for b in range(B):
+        ng = n_gt - b
+        for j in range(n_prop):
+            if j < 300:
+                src = gt[b, j % ng, :7].copy()
+                lvl = [0.03, 0.12, 0.35][(j // ng) % 3]
+                src[:3] += g.normal(0, lvl, 3) * [1.0, 1.0, 0.3]
+                src[3:6] *= g.uniform(1 - lvl, 1 + lvl, 3)
+                src[6] += g.normal(0, lvl)
+                boxes[b, j] = src
+                cls[b, j, int(gt[b, j % ng, 7]) - 1] = g.normal(1.5, 1.0)
+            else:
+                boxes[b, j] = [g.uniform(-18, 18), g.uniform(-18, 18), g.uniform(-0.3, 0.6), *g.uniform(0.7, 4.5, 3), g.uniform(-3.1, 3.1)]
+    lv, lv_mm = {}, {}
+    for name, shp, ch, nvox in (("x_conv3", [11, 104, 104], 8, 1800), ("x_conv4", [5, 52, 52], 12, 700)):
+        st = 4 if name == "x_conv3" else 8
+        cells = [np.stack([g.integers(0, B, nvox), g.integers(0, shp[0], nvox), g.integers(0, shp[1], nvox), g.integers(0, shp[2], nvox)], 1)]
+        for b in range(B):                                             # dense clusters of voxels inside every box: no empty balls there
+            for i in range(n_gt - b):
+                ctr = ((gt[b, i, :3] - pcr[:3]) / (np.array([0.1, 0.1, 0.15]) * st))
+                pts = ctr[None] + g.uniform(-1, 1, (40, 3)) * (gt[b, i, 3:6] / (np.array([0.1, 0.1, 0.15]) * st)) * 0.6
+                cz = np.clip(np.floor(pts[:, [2, 1, 0]]).astype(int), 0, np.array(shp) - 1)
+                cells.append(np.concatenate([np.full((40, 1), b), cz], 1))
+        cl = np.unique(np.concatenate(cells), axis=0).astype(np.int32)
+        for d, seed in ((lv, 1), (lv_mm, 2)):
+            f = torch.randn(cl.shape[0], ch, generator=torch.Generator().manual_seed(1662 + seed + ch)).requires_grad_(True)
+            d[name] = SimpleNamespace(indices=torch.from_numpy(cl), features=f, spatial_shape=shp, batch_size=B)
+    bd = {"batch_size": B, "batch_box_preds": torch.from_numpy(boxes), "batch_cls_preds": torch.from_numpy(cls), "gt_boxes": torch.from_numpy(gt),
+          "css_score": torch.from_numpy(css), "multi_scale_3d_features": lv, "multi_scale_3d_features_mm": lv_mm,
+          "multi_scale_3d_strides": {"x_conv3": 4, "x_conv4": 8}}
+    sd0 = {"h." + k: v.detach().clone().numpy() for k, v in head.state_dict().items()}
+    np.random.seed(77)
+    torch.manual_seed(77)
+    head(bd)
+    loss, tb = head.get_loss()
+    loss.backward()
+    t0, t1 = head.forward_ret_dict["targets_dict0"], head.forward_ret_dict["targets_dict1"]
+    out = dict(sd0)
+    out.update(pcr=pcr, gt=gt, css=css, boxes=boxes, cls=cls, seed=np.int64(77), loss=np.float64(loss.item()), rcnn_loss=np.float64(tb["rcnn_loss"]))
+    for name in ("x_conv3", "x_conv4"):
+        out[name + "_idx"] = lv[name].indices.numpy()
+        out[name + "_feat"], out[name + "_feat_mm"] = lv[name].features.detach().numpy(), lv_mm[name].features.detach().numpy()
+        out[name + "_grad4"], out[name + "_grad4_mm"] = lv[name].features.grad.numpy()[::4], lv_mm[name].features.grad.numpy()[::4]   # every 4th row
+    for k in ("rois", "gt_of_rois", "gt_of_rois_src", "gt_iou_of_rois", "roi_scores", "roi_labels", "reg_valid_mask", "rcnn_cls_labels"):
+        out["t_" + k] = t0[k].detach().numpy()
+    out["t_css"] = t0["additional_data"]["css_score"].numpy()
+    for i, t in enumerate((t0, t1)):
+        for k in ("rcnn_cls", "rcnn_reg", "shared_features"):
+            out["o%d_%s" % (i, k)] = t[k].detach().numpy()
+    for k, prm in head.named_parameters():
+        if prm.grad is not None and (k.endswith("3.weight") or "mlps_pos" in k or k.startswith("shared_fc_layers.0") or k.endswith("0.0.weight")):
+            out["g." + k] = prm.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "proto_head.npz"), **out)
+    print("proto_head: loss %.6f, %d fg of %d rois, %d gradient arrays" % (loss.item(), int(t0["reg_valid_mask"].sum()),
+                                                                           t0["reg_valid_mask"].numel(), sum(k.startswith("g.") for k in out)))
+
+
 PROTO_NAMES = ["Vehicle", "Pedestrian", "Cyclist", "Dis_Small", "Sign"]
 
 
@@ -401,6 +570,8 @@ def main():
         return atss(m)
     if len(sys.argv) > 1 and sys.argv[1] == "proto_crop":
         return proto_crop(m)
+    if len(sys.argv) > 1 and sys.argv[1] == "proto_head":
+        return proto_head(m)
     lib = m["lib"]
     out = {}
 
@@ -867,6 +1038,7 @@ def main():
     wide_dense(m)
     atss(m)
     proto_crop(m)
+    proto_head(m)
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
