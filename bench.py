@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-launch table of the conv kernels (stderr)")
+    ap.add_argument("--row-order", choices=["taps", "canonical"], default="taps",
+                    help="internal row order of the strided sparse levels (ModelConfig.row_order)")
+    ap.add_argument("--row-order-chunk", type=int, default=4096)
     ap.add_argument("--conv-math", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
                     help="arithmetic of the layers with >= 32 input channels: split-fp16 x2 (3 products) or split-bf16 x3 (6 products) "
                          "on the 16-bit matrix pipe (both fp32-level error), or fp32 MFMA")
@@ -365,7 +368,7 @@ def main():
     # "nccl" is RCCL on ROCm; CPD_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests
     distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"), torch.device("cuda", local))
 
-    cfg = ModelConfig(conv_math=args.conv_math)
+    cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk)
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local
     if args.mode == "train":

@@ -37,6 +37,8 @@ SIGNATURES = {
     "cpd_voxelize": (_I, [_VP, _I, _I, _FP, _FP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_index_bytes": (_SZ, [_I, _I3, _I]),
     "cpd_index_build": (_I, [_VP, _I, _I, _I3, _VP, _SZ, _VP]),
+    "cpd_order_rows_by_taps": (_I, [_VP, _I, _I, _I3, _I3, _VP, _I, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_index_set_order": (_I, [_VP, _VP, _VP]),
     "cpd_rulebook_subm": (_I, [_VP, _I, _I, _I3, _I3, _VP, _VP, _VP, _VP]),
     "cpd_conv_out_shape": (_I, [_I3, _I3, _I3, _I3, _I3]),
     "cpd_conv_outset": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _SZ, _VP, _VP]),

@@ -40,7 +40,7 @@ struct IndexLookup {
     const int32_t *perm;
     const int32_t *flags;     // the index's own record of its order: flags[0] != 0 -> row id = perm[rank], else row id = rank
     __device__ __forceinline__ int32_t operator()(long long key) const {
-        return site_lookup(bitmap, base, flags[0] ? perm : nullptr, key);
+        return site_lookup(bitmap, base, index_order(flags, perm), key);
     }
 };
 

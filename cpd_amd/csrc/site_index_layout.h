@@ -11,7 +11,7 @@ struct IndexView {
     uint32_t *base;
     uint32_t *bsum;
     int32_t *perm;    // rank -> row id
-    int32_t *flags;   // [0] = 1 when perm is in use
+    int32_t *flags;   // [0]: 0 canonical, 1 perm in use, 2 external rank -> row map at [2..3] (index_order below)
     long long cells, words;
     size_t bytes;
 };
@@ -42,6 +42,16 @@ struct Grid {
         return (((long long)bi * d + z) * h + y) * w + x;
     }
 };
+
+// Which rank -> row map an index uses is recorded in its own flags block and read on the device: flags[0] = 0 canonical
+// (row id = rank), 1 the map stored in the index (cpd_index_build over an arbitrary-order list), 2 a caller-owned map whose
+// device address sits in flags[2..3] (cpd_index_set_order: rows of a level re-ordered after the index was built).
+__device__ __forceinline__ const int32_t *index_order(const int32_t *__restrict__ flags, const int32_t *__restrict__ own_perm) {
+    const int f = flags[0];
+    if (f == 0) return nullptr;
+    if (f == 1) return own_perm;
+    return *reinterpret_cast<const int32_t *const *>(flags + 2);
+}
 
 __device__ __forceinline__ int32_t site_lookup(const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
                                                const int32_t *__restrict__ perm, long long key) {

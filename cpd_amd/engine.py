@@ -48,6 +48,12 @@ class ModelConfig:
     # below 65504 in magnitude -- an overflow shows as inf / NaN, CPD_GC_F16X2); "bf16x3" = three bf16 terms, six partial
     # products (exact split over the whole fp32 range, CPD_GC_BF16X3); "f32" = fp32-input MFMA everywhere (bitwise an fmaf chain)
     conv_math: str = "f16x2"
+    # internal row order of the strided levels: "taps" = every chunk of `row_order_chunk` canonical rows sorted by neighbour
+    # pattern, so that the conv kernels' 16-row tap skipping is nearly exact (ops.order_rows_by_taps; a level's exported
+    # (features, indices) pair is in that order -- any order is a valid sparse tensor); "canonical" = ascending (b, z, y, x)
+    row_order: str = "taps"
+    row_order_chunk: int = 4096
+    row_order_min_rows: int = 65536        # below this a level does not fill the chip either way
 
     @property
     def grid_zyx(self):
@@ -313,17 +319,25 @@ class CenterPointEngine:
         x = self._conv(L["conv_input"], feats, nbr, coords.shape[0])
         x = self._blocks(L["conv1"], x, nbr)
         levels = {"x_conv1": (x, coords, shape)}
+        coords_c = coords                  # the list the next level's output set is marked from: canonical order wherever one exists
         for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
             k, s, pd = _DOWN[stage]
-            out_idx, out_index, out_shape = ops.conv_outset(coords, batch, shape, k, s, pd)
+            out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
+            out_c = out_idx
+            if self.cfg.row_order == "taps" and out_idx.shape[0] >= self.cfg.row_order_min_rows:
+                # rows of the level sorted, chunk by chunk, by their neighbour pattern (ops.order_rows_by_taps): the level's
+                # site list in the new order + the rank -> row map installed in its index re-order everything that follows
+                # (both rulebooks, the features, the exported level) without any kernel knowing
+                out_idx, _, old_to_new = ops.order_rows_by_taps(out_c, out_index, chunk_rows=self.cfg.row_order_chunk)
+                out_index.set_order(old_to_new)
             nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
             x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0])
             nbr = ops.rulebook_subm(out_idx, out_index)
             x = self._blocks(L[stage], x, nbr)
-            coords, index, shape = out_idx, out_index, out_shape
+            coords, coords_c, index, shape = out_idx, out_c, out_index, out_shape
             levels["x_conv%d" % i] = (x, coords, shape)
         k, s, pd = _DOWN["conv_out"]
-        out_idx, out_index, out_shape = ops.conv_outset(coords, batch, shape, k, s, pd)
+        out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
         nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
         x = self._conv(L["conv_out"], x, nbr_dn, out_idx.shape[0])
         return levels, (x, out_idx, out_shape)

@@ -144,6 +144,29 @@ class SiteIndex:
         return idx
 
 
+    def set_order(self, rank_to_row):
+        """Install a caller-owned rank -> row map (cpd_index_set_order; None = canonical again): lookups through this index
+        then return rows in that order. The tensor is kept alive here."""
+        self.order = rank_to_row.contiguous() if rank_to_row is not None else None
+        check(lib().cpd_index_set_order(ptr(self.buf), ptr(self.order), stream()), "cpd_index_set_order")
+        return self
+
+
+def order_rows_by_taps(indices, index, ksize=(3, 3, 3), chunk_rows=4096):
+    """For a level's canonical site list [n, 4] and its SiteIndex: (indices in the new order, new_to_old, old_to_new) -- the rows
+    of every `chunk_rows` consecutive rows sorted by their sub-manifold neighbour pattern (cpd_order_rows_by_taps)."""
+    indices = indices.contiguous()
+    n = indices.shape[0]
+    dev = indices.device
+    new_to_old = torch.empty((n,), dtype=torch.int32, device=dev)
+    old_to_new = torch.empty((n,), dtype=torch.int32, device=dev)
+    out = torch.empty_like(indices)
+    ws = torch.empty((max(n, 1) * 4,), dtype=torch.uint8, device=dev)
+    check(lib().cpd_order_rows_by_taps(ptr(indices), n, index.batch, iarr(index.shape), iarr(ksize), ptr(index.buf), int(chunk_rows),
+                                       ptr(new_to_old), ptr(old_to_new), ptr(out), ptr(ws), ws.numel(), stream()), "cpd_order_rows_by_taps")
+    return out, new_to_old, old_to_new
+
+
 def _new_tapmask(n, kv, device):
     if kv > 32 or n == 0:
         return None

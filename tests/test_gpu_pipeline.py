@@ -65,6 +65,14 @@ def test_engine_matches_reference_graph(oracle, hip):
         np.testing.assert_allclose(got["pred_boxes"].cpu().numpy(), want["pred_boxes"], atol=1e-3, rtol=1e-4)
 
 
+def _canonical(f, i, shape):
+    """rows of a level sorted by (b, z, y, x); third value: was the level stored in another order?"""
+    i = i.cpu().numpy()
+    key = ((i[:, 0].astype(np.int64) * shape[0] + i[:, 1]) * shape[1] + i[:, 2]) * shape[2] + i[:, 3]
+    o = np.argsort(key, kind="stable")
+    return f.cpu().numpy()[o], i[o], bool((o != np.arange(len(o))).any())
+
+
 @pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
 def test_full_size_config2_matches_oracle(oracle, hip, math):
     """BASELINE config 2 at FULL size, features included: one 160k-point W-cloud through the oracle's
@@ -85,13 +93,18 @@ def test_full_size_config2_matches_oracle(oracle, hip, math):
     mine = vc[:, 0] == fi
     np.testing.assert_array_equal(vc[mine][:, 1:], rt["voxel_coords"][:, 1:])
     np.testing.assert_allclose(it["voxel_features"].cpu().numpy()[mine], rt["voxel_features"], rtol=1e-6, atol=1e-6)
+    reordered = 0
     for name in ["x_conv1", "x_conv2", "x_conv3", "x_conv4"]:
         f, i, s = it["levels"][name]
         f0, i0, s0 = rt["levels"][name]
-        i = i.cpu().numpy()
+        # the engine keeps the strided levels in tap-pattern order (ModelConfig.row_order): a level is a set of (site, feature)
+        # pairs -- compared here in canonical (b, z, y, x) order, where the site LIST must equal the oracle's bit for bit
+        f, i, moved = _canonical(f, i, s)
+        reordered += int(moved)
         mine = i[:, 0] == fi
         np.testing.assert_array_equal(i[mine][:, 1:], i0[:, 1:])
-        np.testing.assert_allclose(f.cpu().numpy()[mine], f0, atol=1e-4, rtol=0, err_msg=name)
+        np.testing.assert_allclose(f[mine], f0, atol=1e-4, rtol=0, err_msg=name)
+    assert reordered == 3                                           # x_conv2..4 really ran in the bench's row order
     x, idx, shape = it["encoded"]
     x0, idx0, shape0 = rt["encoded"]
     idx = idx.cpu().numpy()

@@ -225,3 +225,41 @@ def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, math, cin, cout, 
     ref = oracle.sparse_conv(feat, w, None, nbr.cpu().numpy())
     ref = np.maximum(ref * scale + shift + res, 0)
     np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [1024, 4096, 8192, 16384])
+def test_tap_pattern_row_order(oracle, hip, chunk):
+    """ops.order_rows_by_taps: a permutation that stays inside chunks of `chunk` canonical rows, sorts every chunk by the rows'
+    27-bit neighbour pattern (ties by canonical position: deterministic), and -- installed in the level's index -- makes the
+    sub-manifold rulebook built over the re-ordered site list the canonical rulebook seen through the permutation."""
+    import torch
+    from cpd_amd import ops
+    rng = np.random.default_rng(chunk)
+    shape, B = [9, 70, 80], 2
+    cells = np.unique(np.stack([rng.integers(0, B, 40000), rng.integers(0, shape[0], 40000), rng.integers(0, shape[1], 40000),
+                                rng.integers(0, shape[2], 40000)], 1), axis=0).astype(np.int32)
+    idx = torch.from_numpy(cells).cuda()
+    index = ops.SiteIndex.build(idx, B, shape)
+    nbr_c = ops.rulebook_subm(idx, index).cpu().numpy()
+    new_idx, n2o, o2n = ops.order_rows_by_taps(idx, index, chunk_rows=chunk)
+    n2o, o2n = n2o.cpu().numpy(), o2n.cpu().numpy()
+    n = len(cells)
+    assert np.array_equal(np.sort(n2o), np.arange(n)) and np.array_equal(o2n[n2o], np.arange(n))
+    assert np.array_equal(n2o // chunk, np.arange(n) // chunk)                         # rows stay in their chunk
+    np.testing.assert_array_equal(new_idx.cpu().numpy(), cells[n2o])
+    pattern = ((nbr_c >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)
+    key = (np.arange(n) // chunk) * (1 << 44) + pattern * (1 << 16) + np.arange(n) % chunk
+    np.testing.assert_array_equal(n2o, np.argsort(key, kind="stable"))
+    index.set_order(torch.from_numpy(o2n).cuda())
+    nbr_p = ops.rulebook_subm(new_idx, index)
+    want = nbr_c[:, n2o]
+    want = np.where(want >= 0, o2n[np.clip(want, 0, None)], -1)
+    np.testing.assert_array_equal(nbr_p.cpu().numpy(), want)
+    groups = (n + 15) // 16
+    hit = np.zeros((27, groups * 16), bool)
+    hit[:, :n] = want >= 0
+    tm = (hit.reshape(27, groups, 16).any(-1).astype(np.int64) << np.arange(27)[:, None]).sum(0)
+    np.testing.assert_array_equal(nbr_p.tapmask.cpu().numpy().astype(np.int64) & ((1 << 27) - 1), tm)
+    index.set_order(None)                                                               # canonical again
+    np.testing.assert_array_equal(ops.rulebook_subm(idx, index).cpu().numpy(), nbr_c)

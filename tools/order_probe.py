@@ -61,6 +61,15 @@ for lvl, (k, s, p, c) in enumerate([([3, 3, 3], [2, 2, 2], [1, 1, 1], 32), ([3, 
         orders["tile %dx%d z-major" % (ty, tx)] = ((((b_ * ((H + ty - 1) // ty) + y_ // ty) * ((W + tx - 1) // tx) + x_ // tx) * D + z_) * ty + y_ % ty) * tx + x_ % tx
         orders["tile %dx%d y,z,x" % (ty, tx)] = ((((b_ * ((H + ty - 1) // ty) + y_ // ty) * ((W + tx - 1) // tx) + x_ // tx) * ty + y_ % ty) * D + z_) * tx + x_ % tx
     orders["(b,y,x,z) z innermost"] = ((b_ * H + y_) * W + x_) * D + z_
+    if os.environ.get("ORDER_SET", "") == "mask":
+        # rows of a chunk of R canonical rows sorted by their 27-bit neighbour pattern: 16-row groups with uniform tap sets
+        orders = {"canonical (b,z,y,x)": None}
+        mask = ((nbr >= 0).long() << torch.arange(27, device=nbr.device).view(-1, 1)).sum(0)
+        rank = torch.arange(n_out, device=nbr.device)
+        for R in (256, 1024, 4096, 16384, 1 << 30):
+            orders["mask-sorted in chunks of %d" % R] = (rank // R) * (1 << 27) + mask
+        pop = ((nbr >= 0).long()).sum(0)
+        orders["popcount-sorted in chunks of 1024"] = (rank // 1024) * 32 + pop
     for name, key in orders.items():
         if key is None:
             nb, xin = nbr, x
