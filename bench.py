@@ -57,9 +57,9 @@ POOL = 8                        # distinct synthetic frames per rank (seeds rank
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: 16 infer, 1 train)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: 48 infer = three batched-voxelizer groups of 16, 1 train)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent frames in flight per GPU (worker threads, "
                     "one HIP stream + engine workspace each)")
     ap.add_argument("--points", type=int, default=160000)
@@ -84,7 +84,7 @@ def parse():
                     "launcher, backend from CPD_DIST_BACKEND)")
     args = ap.parse_args()
     if args.frames is None:
-        args.frames = 16 if args.mode == "infer" else 1
+        args.frames = 48 if args.mode == "infer" else 1
     return args
 
 
@@ -434,6 +434,8 @@ def main():
                    "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
                    "parallelism": "frame-sharded replicas x%d, no data-path collective" % world,
                    "weights": "random-init (seed 0), eval-mode BN folded",
+                   "sparse_row_order": ("strided levels in tap-pattern order (chunks of %d canonical rows sorted by neighbour pattern)" % cfg.row_order_chunk
+                                        if cfg.row_order == "taps" else "canonical (b, z, y, x)"),
                    "conv_math": {"bf16x3": "layers with >= 32 input channels: split-bf16 x3 (fp32 operands split exactly into 3 bf16 terms, "
                                            "6 bf16 MFMA products per fp32 multiply-add, fp32-level error); 5/16-channel sparse layers: fp32 MFMA",
                                  "f16x2": "layers with >= 32 input channels: split-fp16 x2 (fp32 operands written as 2 fp16 terms, 3 fp16 MFMA "

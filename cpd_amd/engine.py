@@ -51,6 +51,7 @@ class ModelConfig:
     # internal row order of the strided levels: "taps" = every chunk of `row_order_chunk` canonical rows sorted by neighbour
     # pattern, so that the conv kernels' 16-row tap skipping is nearly exact (ops.order_rows_by_taps; a level's exported
     # (features, indices) pair is in that order -- any order is a valid sparse tensor); "canonical" = ascending (b, z, y, x)
+    voxelizer_group: int = 16             # frames per batched-voxelizer call when a batch exceeds its 31-bit cell keys
     row_order: str = "taps"
     row_order_chunk: int = 4096
     row_order_min_rows: int = 65536        # below this a level does not fill the chip either way
@@ -200,6 +201,7 @@ class CenterPointEngine:
         self.voxelizer = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features,
                                        cfg.max_points_per_voxel, cfg.max_voxels, device=self.device)
         self._voxelizers = [self.voxelizer]
+        self._group_voxelizers = []
         self._build_sparse()
         self._bev_cache = {}
         self._build_dense()
@@ -446,6 +448,25 @@ class CenterPointEngine:
             _, coords, _, feats, nvox, index0 = self.voxelizer.batch(points_list, index_z_extra=z_extra)
             total = int(nvox[batch].item())                 # the one read-back
             feats, coords = feats[:total], coords[:total]
+        elif batch > 1 and self.voxelizer.batch_supported(self.cfg.voxelizer_group, z_extra):
+            # more frames than the batched voxelizer's 31-bit cell keys hold: groups of `voxelizer_group` frames, one voxelizer
+            # (workspace) per group, rows concatenated with the frame index offset; the level-0 index is built over the whole list
+            g = self.cfg.voxelizer_group
+            groups = [points_list[i:i + g] for i in range(0, batch, g)]
+            while len(self._group_voxelizers) < len(groups):
+                self._group_voxelizers.append(ops.Voxelizer(self.cfg.voxel_size, self.cfg.point_cloud_range, self.cfg.num_point_features,
+                                                            self.cfg.max_points_per_voxel, self.cfg.max_voxels, device=self.device))
+            outs = [vz.batch(grp) if len(grp) > 1 else None for vz, grp in zip(self._group_voxelizers, groups)]
+            if any(o is None for o in outs):
+                raise NotImplementedError("batch size %d leaves a group of one frame (voxelizer_group %d)" % (batch, g))
+            totals = torch.stack([o[4][len(grp)] for o, grp in zip(outs, groups)]).tolist()       # the one read-back
+            feats = torch.cat([o[3][:m] for o, m in zip(outs, totals)])
+            parts = []
+            for k, (o, m) in enumerate(zip(outs, totals)):
+                c = o[1][:m].clone()
+                c[:, 0] += k * g
+                parts.append(c)
+            coords = torch.cat(parts)
         else:
             while len(self._voxelizers) < batch:           # one workspace per in-flight frame of the batch
                 self._voxelizers.append(ops.Voxelizer(self.cfg.voxel_size, self.cfg.point_cloud_range,

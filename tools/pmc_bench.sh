@@ -22,7 +22,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
 cp $(ls $R/gpurun_out/prof_stats/*/*kernel_stats.csv | head -1) $R/gpurun_out/${tag}_bench_kernel_stats.csv
 cd $R
-python tools/prof_summary.py gpurun_out/${tag}_bench_kernel_stats.csv gpurun_out/${tag}_bench_under_rocprof.json 52 16
+python tools/prof_summary.py gpurun_out/${tag}_bench_kernel_stats.csv gpurun_out/${tag}_bench_under_rocprof.json auto 16
 python - <<PY
 import json
 d = json.load(open("gpurun_out/${tag}_bench.json")); r = d["roofline"]
@@ -32,7 +32,7 @@ print("cpu_baseline", d.get("cpu_baseline"))
 PY
 # variants quoted in DESIGN.md §5 (one bench line each; no CPU baseline, no roofline pass)
 if [ "${2:-}" = "variants" ]; then
-  for v in "bf16x3:--conv-math bf16x3" "f32:--conv-math f32" "streams2:--streams 2" "device_results:--device-results" "1frame:--frames 1"; do
+  for v in "bf16x3:--conv-math bf16x3" "f32:--conv-math f32" "streams2:--streams 2" "device_results:--device-results" "1frame:--frames 1 --steps 100" "16frames:--frames 16 --steps 48" "canonical_rows:--row-order canonical"; do
     python bench.py --no-cpu-baseline --no-roofline ${v#*:} > gpurun_out/${tag}_bench_${v%%:*}.json 2>> gpurun_out/${tag}_bench.err
     python -c "import json,sys; d=json.load(open('gpurun_out/${tag}_bench_${v%%:*}.json')); print('${v%%:*}', round(d['value'],1), 'frames/s', round(d['ms_per_step'],2), 'ms/step')"
   done
