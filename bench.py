@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: 48 infer = three batched-voxelizer groups of 16, 1 train)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: 48 infer, 1 train)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent frames in flight per GPU (worker threads, "
                     "one HIP stream + engine workspace each)")
     ap.add_argument("--points", type=int, default=160000)

@@ -226,8 +226,11 @@ struct FrameOffsets {
     }
 };
 
+// Batched form: pkey holds the point's cell INSIDE its frame (< cells, 31 bits); the bitmap position frame * cells + cell is
+// formed in 64 bits where it is needed (the frame of a point follows from its index), so a batch is bounded by the 64 frames
+// of FrameOffsets, not by 2^31 cells.
 __global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__restrict__ pts, int n, int c, VoxGeom geo,
-                                                             int32_t cells, FrameOffsets fo, int32_t *__restrict__ pkey,
+                                                             long long cells, FrameOffsets fo, int32_t *__restrict__ pkey,
                                                              uint64_t *bitmap) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -240,12 +243,30 @@ __global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__rest
         if (!(f >= 0.0f) || !(f < (float)geo.g[j])) ok = false;
         cz[j] = ok ? (int32_t)f : 0;
     }
-    int32_t key = -1;
-    if (ok) key = fo.frame_of(i) * cells + (cz[0] * geo.g[1] + cz[1]) * geo.g[2] + cz[2];
+    long long key = -1;
+    const int32_t local = ok ? (cz[0] * geo.g[1] + cz[1]) * geo.g[2] + cz[2] : -1;
+    if (ok) key = (long long)fo.frame_of(i) * cells + local;
     // consecutive returns of a beam often share a voxel: the lane after an equal key leaves the bit to its neighbour
-    const int32_t prev = __shfl_up(key, 1);
+    const long long prev = __shfl_up(key, 1);
     if (ok && ((threadIdx.x & 63) == 0 || prev != key)) atomicOr((unsigned long long *)&bitmap[key >> 6], 1ull << (key & 63));
-    pkey[i] = key;
+    pkey[i] = local;
+}
+
+__global__ void __launch_bounds__(256) vox_first_batch_kernel(int n, long long cells, FrameOffsets fo, const int32_t *__restrict__ pkey,
+                                                              const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
+                                                              int32_t *__restrict__ prank, int32_t *first) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t local = pkey[i];
+    const long long key = local >= 0 ? (long long)fo.frame_of(i) * cells + local : -1;
+    int32_t r = -1;
+    const long long prev = __shfl_up(key, 1);
+    if (key >= 0) {
+        const uint64_t w = bitmap[key >> 6];
+        r = (int32_t)(base[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1ull)));
+        if ((threadIdx.x & 63) == 0 || prev != key) atomicMin(&first[r], i);
+    }
+    prank[i] = r;
 }
 
 struct AssignGlobalFn {  // flagged point i starts the voxel with GLOBAL id = prefix; frame starts record their base
@@ -277,7 +298,7 @@ __global__ void vox_frames_kernel(FrameOffsets fo, int n, int max_voxels, int32_
     n_voxels[fo.nf] = acc;
 }
 
-__global__ void __launch_bounds__(256) vox_assign_batch_kernel(int n, int32_t cells, FrameOffsets fo, int max_voxels,
+__global__ void __launch_bounds__(256) vox_assign_batch_kernel(int n, FrameOffsets fo, int max_voxels,
                                                                const int32_t *__restrict__ pkey,
                                                                const int32_t *__restrict__ prank,
                                                                const int32_t *__restrict__ first,
@@ -293,7 +314,7 @@ __global__ void __launch_bounds__(256) vox_assign_batch_kernel(int n, int32_t ce
     if (local >= max_voxels) { vid[r] = -1; return; }
     const int32_t row = out_base[f] + local;
     vid[r] = row;
-    const int32_t key = pkey[i] - f * cells;
+    const int32_t key = pkey[i];                                // the cell inside the frame
     int32_t *o = coords + (size_t)row * 4;
     o[0] = f; o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
 }
@@ -397,7 +418,7 @@ extern "C" int cpd_voxelize(const float *points, int n_points, int c, const floa
 // ---- batched entry points ---------------------------------------------------------------------
 static int batch_caps(int n_total, int n_frames, int max_voxels, long long cells, int *cap) {
     if (n_frames <= 0 || n_frames > CPD_VOX_MAX_FRAMES) return CPD_ERR_UNSUPPORTED;
-    if ((long long)n_frames * cells >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
+    if (cells >= (1ll << 31) || (long long)n_frames * cells >= (1ll << 40)) return CPD_ERR_UNSUPPORTED;
     long long c = (long long)n_frames * max_voxels;
     *cap = (int)(c < n_total ? c : n_total);
     return CPD_OK;
@@ -474,14 +495,14 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
     CPD_HIP_TRY(hipMemsetAsync(w.counts, 0, (size_t)cap * 4, s));
     CPD_HIP_TRY(hipMemsetAsync(frame_base, 0, (CPD_VOX_MAX_FRAMES + 1) * 4, s));
     const int nb = cpd_div_up(n, 256);
-    vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, (int32_t)cells, fo, w.pkey, w.bitmap);
+    vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap);
     rc = device_scan(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
     if (rc) return rc;
-    vox_first_kernel<<<nb, 256, 0, s>>>(n, w.pkey, w.bitmap, w.base, w.prank, w.first);
+    vox_first_batch_kernel<<<nb, 256, 0, s>>>(n, cells, fo, w.pkey, w.bitmap, w.base, w.prank, w.first);
     rc = device_scan(n, FlagFn{w.prank, w.first}, AssignGlobalFn{w.prank, w.vid, frame_base, fo}, w.bsum_pt, total, -1, s);
     if (rc) return rc;
     vox_frames_kernel<<<1, 64, 0, s>>>(fo, n, max_voxels, frame_base, total, out_base, n_voxels);
-    vox_assign_batch_kernel<<<nb, 256, 0, s>>>(n, (int32_t)cells, fo, max_voxels, w.pkey, w.prank, w.first, frame_base, out_base,
+    vox_assign_batch_kernel<<<nb, 256, 0, s>>>(n, fo, max_voxels, w.pkey, w.prank, w.first, frame_base, out_base,
                                                w.vid, coords, geo.g[1], geo.g[2]);
     vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, w.vid, w.slots, w.counts);
     const long long threads = (long long)cap * c;

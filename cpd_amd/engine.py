@@ -51,7 +51,7 @@ class ModelConfig:
     # internal row order of the strided levels: "taps" = every chunk of `row_order_chunk` canonical rows sorted by neighbour
     # pattern, so that the conv kernels' 16-row tap skipping is nearly exact (ops.order_rows_by_taps; a level's exported
     # (features, indices) pair is in that order -- any order is a valid sparse tensor); "canonical" = ascending (b, z, y, x)
-    voxelizer_group: int = 16             # frames per batched-voxelizer call when a batch exceeds its 31-bit cell keys
+    voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
     row_order: str = "taps"
     row_order_chunk: int = 4096
     row_order_min_rows: int = 65536        # below this a level does not fill the chip either way
@@ -449,7 +449,7 @@ class CenterPointEngine:
             total = int(nvox[batch].item())                 # the one read-back
             feats, coords = feats[:total], coords[:total]
         elif batch > 1 and self.voxelizer.batch_supported(self.cfg.voxelizer_group, z_extra):
-            # more frames than the batched voxelizer's 31-bit cell keys hold: groups of `voxelizer_group` frames, one voxelizer
+            # more frames than one batched-voxelizer call takes: groups of `voxelizer_group` frames, one voxelizer
             # (workspace) per group, rows concatenated with the frame index offset; the level-0 index is built over the whole list
             g = self.cfg.voxelizer_group
             groups = [points_list[i:i + g] for i in range(0, batch, g)]

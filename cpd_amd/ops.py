@@ -78,7 +78,8 @@ class Voxelizer:
 
     def batch_supported(self, n_frames, z_extra=0):
         g = voxel_grid_size(self.vs, self.rg)
-        return 0 < n_frames <= 64 and n_frames * (g[0] + z_extra) * g[1] * g[2] < (1 << 31)
+        cells = (g[0] + z_extra) * g[1] * g[2]
+        return 0 < n_frames <= 64 and cells < (1 << 31) and n_frames * cells < (1 << 40)
 
     def batch(self, points_list, want_voxels=False, want_mean=True, index_z_extra=None):
         """All frames in one set of launches (cpd_voxelize_batch). Returns capacity-sized device tensors
