@@ -122,3 +122,34 @@ def test_batched_voxelizer_builds_the_level0_site_index(oracle, hip):
         got = ops.rulebook_subm(coords, index)
         assert torch.equal(got, want) and torch.equal(got.tapmask, want.tapmask)
         np.testing.assert_array_equal(got.cpu().numpy(), oracle.subm_rulebook(coords.cpu().numpy(), len(clouds), shape, [3, 3, 3]))
+
+
+def test_batched_voxelizer_beyond_2_to_31_cells(hip):
+    """30 frames of the Waymo grid = 2.8e9 cells: bitmap positions are formed in 64 bits (frame x cells-per-frame + cell). Every
+    frame of the batch must equal the per-frame voxelizer, the last ones (positions above 2^31) in particular, and the index
+    built in place must answer lookups like one built from the coordinates."""
+    import torch
+    from cpd_amd import ops
+    from cpd_amd.synthetic import WAYMO, waymo_cloud
+    vs, rg = WAYMO["voxel_size"], WAYMO["point_cloud_range"]
+    nf = 30
+    dev = [torch.from_numpy(waymo_cloud(s % 5, n_points=6000 + 500 * (s % 7))).cuda() for s in range(nf)]
+    vox = ops.Voxelizer(vs, rg, 5, 5, 1000000)
+    g = vox.grid_zyx
+    assert nf * (g[0] + 1) * g[1] * g[2] > (1 << 31) and vox.batch_supported(nf, 1)
+    voxels, coords, num, mean, nvox, index = vox.batch(dev, want_voxels=True, index_z_extra=1)
+    counts = nvox.cpu().numpy()
+    one = ops.Voxelizer(vs, rg, 5, 5, 1000000)
+    row = 0
+    for b in (0, 11, 23, 24, nf - 1):
+        row = int(counts[:b].sum())
+        v1, c1, n1, m1, k = one(dev[b], batch_idx=b, coord_cols=4, want_voxels=True, want_mean=True, sync=True)
+        assert counts[b] == k
+        assert torch.equal(coords[row:row + k], c1) and torch.equal(num[row:row + k], n1)
+        assert torch.equal(voxels[row:row + k], v1) and torch.equal(mean[row:row + k], m1)
+    total = int(counts[nf])
+    cc = coords[:total].contiguous()
+    shape = [g[0] + 1, g[1], g[2]]
+    want = ops.rulebook_subm(cc, ops.SiteIndex.build(cc, nf, shape))
+    got = ops.rulebook_subm(cc, index)
+    assert torch.equal(got, want)
