@@ -166,8 +166,8 @@ struct StoreBaseFn {
 
 __global__ void __launch_bounds__(256) vox_insert_kernel(int n, int P, int max_voxels,
                                                          const int32_t *__restrict__ prank,
-                                                         const int32_t *__restrict__ vid, int32_t *slots,
-                                                         int32_t *counts) {
+                                                         const int32_t *__restrict__ vid, const int32_t *__restrict__ first,
+                                                         int32_t *slots, int32_t *counts) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int32_t r = prank[i];
@@ -175,11 +175,12 @@ __global__ void __launch_bounds__(256) vox_insert_kernel(int n, int P, int max_v
     int32_t v = vid[r];
     if (v >= max_voxels) return;
     atomicAdd(&counts[v], 1);
-    // Insertion cascade: slot p ends up holding the (p+1)-th smallest point index of the voxel.
-    // Every value enters slot 0; whatever loses an atomicMin moves on to the next slot.
+    // Insertion cascade: slot p ends up holding the (p+1)-th smallest point index of the voxel. Slot 0 is the voxel's first
+    // point (known from vox_first: a plain store); every other value enters at slot 1, whatever loses an atomicMin moves on.
     int32_t x = i;
     int32_t *s = slots + (size_t)v * P;
-    for (int p = 0; p < P; ++p) {
+    if (first[r] == i) { s[0] = i; return; }
+    for (int p = 1; p < P; ++p) {
         int32_t old = atomicMin(&s[p], x);
         if (old == 0x7f7f7f7f) break;  // slot was empty: nothing displaced
         x = old > x ? old : x;
@@ -323,14 +324,18 @@ __global__ void __launch_bounds__(256) vox_assign_batch_kernel(int n, FrameOffse
 // The run's last lane adds the run length to the voxel's count in one atomic, and a lane that has max_points earlier lanes of
 // its own run can never hold one of the voxel's max_points smallest indices, so it skips the cascade altogether.
 __global__ void __launch_bounds__(256) vox_insert_batch_kernel(int n, int P, const int32_t *__restrict__ prank,
-                                                               const int32_t *__restrict__ vid, int32_t *slots,
-                                                               int32_t *counts) {
+                                                               const int32_t *__restrict__ vid, const int32_t *__restrict__ first,
+                                                               int32_t *slots, int32_t *counts) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int32_t v = -1;
+    bool is_first = false;
     if (i < n) {
         const int32_t r = prank[i];
-        if (r >= 0) v = vid[r];                                  // < 0: voxel beyond its frame's max_voxels
+        if (r >= 0) {
+            v = vid[r];                                          // < 0: voxel beyond its frame's max_voxels
+            is_first = first[r] == i;
+        }
     }
     const int32_t key = v >= 0 ? v : -1 - lane;                  // invalid lanes never join a run
     int pos = 0;                                                 // lanes before this one in its run
@@ -346,7 +351,10 @@ __global__ void __launch_bounds__(256) vox_insert_batch_kernel(int n, int P, con
     if (pos >= P) return;
     int32_t x = i;
     int32_t *s = slots + (size_t)v * P;
-    for (int p = 0; p < P; ++p) {
+    // slot 0 is already known: the voxel's first point (vox_first) owns it with a plain store; everybody else starts the
+    // cascade at slot 1 -- one returning atomic less per point, none at all for the single-point voxels
+    if (is_first) { s[0] = i; return; }
+    for (int p = 1; p < P; ++p) {
         int32_t old = atomicMin(&s[p], x);
         if (old == 0x7f7f7f7f) break;
         x = old > x ? old : x;
@@ -408,7 +416,7 @@ extern "C" int cpd_voxelize(const float *points, int n_points, int c, const floa
                      AssignVoxelFn{w.prank, w.pkey, w.vid, coords, coord_cols, batch_idx, max_voxels, geo.g[1], geo.g[2]},
                      w.bsum_pt, n_voxels, max_voxels, s);
     if (rc) return rc;
-    vox_insert_kernel<<<nb, 256, 0, s>>>(n, max_points, max_voxels, w.prank, w.vid, w.slots, w.counts);
+    vox_insert_kernel<<<nb, 256, 0, s>>>(n, max_points, max_voxels, w.prank, w.vid, w.first, w.slots, w.counts);
     const long long threads = (long long)cap * c;
     vox_gather_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(points, c, max_points, cap, n_voxels, w.slots, w.counts,
                                                                voxels, num_points, mean_features);
@@ -504,7 +512,7 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
     vox_frames_kernel<<<1, 64, 0, s>>>(fo, n, max_voxels, frame_base, total, out_base, n_voxels);
     vox_assign_batch_kernel<<<nb, 256, 0, s>>>(n, fo, max_voxels, w.pkey, w.prank, w.first, frame_base, out_base,
                                                w.vid, coords, geo.g[1], geo.g[2]);
-    vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, w.vid, w.slots, w.counts);
+    vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, w.vid, w.first, w.slots, w.counts);
     const long long threads = (long long)cap * c;
     vox_gather_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(points, c, max_points, cap, n_voxels + n_frames, w.slots, w.counts,
                                                                voxels, num_points, mean_features);
