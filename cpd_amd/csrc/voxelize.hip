@@ -220,10 +220,13 @@ __global__ void __launch_bounds__(256) vox_gather_kernel(const float *__restrict
 struct FrameOffsets {
     int32_t nf;
     int32_t off[CPD_VOX_MAX_FRAMES + 1];
-    __device__ __forceinline__ int frame_of(int i) const {
-        int f = 0;
-        while (f + 1 < nf && i >= off[f + 1]) ++f;
-        return f;
+    __device__ __forceinline__ int frame_of(int i) const {        // the last frame that starts at or before point i
+        int lo = 0, hi = nf - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (i >= off[mid]) lo = mid; else hi = mid - 1;
+        }
+        return lo;
     }
 };
 
@@ -276,8 +279,8 @@ struct AssignGlobalFn {  // flagged point i starts the voxel with GLOBAL id = pr
     int32_t *frame_base;
     FrameOffsets fo;
     __device__ void operator()(long long i, uint32_t flag, uint32_t prefix) const {
-        for (int f = 0; f < fo.nf; ++f)
-            if ((int32_t)i == fo.off[f]) frame_base[f] = (int32_t)prefix;   // empty frames share an offset: all get it
+        // the point that starts a frame records its base; empty frames share an offset with the next non-empty one: all get it
+        for (int f = fo.frame_of((int)i); f >= 0 && fo.off[f] == (int32_t)i; --f) frame_base[f] = (int32_t)prefix;
         if (flag) gid[prank[i]] = (int32_t)prefix;
     }
 };
