@@ -323,6 +323,36 @@ __global__ void __launch_bounds__(256) vox_assign_batch_kernel(int n, FrameOffse
     o[0] = f; o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
 }
 
+// Canonical row order (engine-internal; the boundary's order is first appearance): row = rank of the voxel's cell in the occupancy
+// bitmap = ascending (frame, z, y, x). No first-appearance scan over the points, no rank -> row map: the site index is canonical.
+// Frame f owns the ranks between the prefix at its first cell and at the next frame's.
+__global__ void vox_frames_canonical_kernel(int nf, long long cells, const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
+                                            const int32_t *__restrict__ total, int32_t *n_voxels) {
+    if (threadIdx.x != 0) return;
+    int32_t prev = 0;
+    for (int f = 1; f <= nf; ++f) {
+        int32_t r = *total;
+        if (f < nf) {
+            const long long key = (long long)f * cells;
+            r = (int32_t)(base[key >> 6] + __popcll(bitmap[key >> 6] & ((1ull << (key & 63)) - 1ull)));
+        }
+        n_voxels[f - 1] = r - prev;
+        prev = r;
+    }
+    n_voxels[nf] = *total;
+}
+__global__ void __launch_bounds__(256) vox_assign_canonical_kernel(int n, FrameOffsets fo, const int32_t *__restrict__ pkey,
+                                                                   const int32_t *__restrict__ prank, const int32_t *__restrict__ first,
+                                                                   int32_t *coords, int32_t gy, int32_t gx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = prank[i];
+    if (r < 0 || first[r] != i) return;
+    const int32_t key = pkey[i];
+    int32_t *o = coords + (size_t)r * 4;
+    o[0] = fo.frame_of(i); o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
+}
+
 // Consecutive returns of a beam often fall into one voxel: lanes of a wave with the same voxel form a RUN (in point order).
 // The run's last lane adds the run length to the voxel's count in one atomic, and a lane that has max_points earlier lanes of
 // its own run can never hold one of the voxel's max_points smallest indices, so it skips the cascade altogether.
@@ -336,7 +366,7 @@ __global__ void __launch_bounds__(256) vox_insert_batch_kernel(int n, int P, con
     if (i < n) {
         const int32_t r = prank[i];
         if (r >= 0) {
-            v = vid[r];                                          // < 0: voxel beyond its frame's max_voxels
+            v = vid ? vid[r] : r;                                // < 0: voxel beyond its frame's max_voxels; no map: row = rank
             is_first = first[r] == i;
         }
     }
@@ -453,7 +483,7 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
                                const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
                                float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
                                int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index, size_t index_bytes,
-                               int z_extra, cpd_stream_t stream) {
+                               int z_extra, int canonical, cpd_stream_t stream) {
     if (!frame_offsets || c < 3 || max_points <= 0 || max_voxels <= 0 || !coords || !num_points || !n_voxels || !workspace ||
         z_extra < 0)
         return CPD_ERR_ARG;
@@ -475,6 +505,7 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
     int cap;
     rc = batch_caps(n, n_frames, max_voxels, cells, &cap);
     if (rc) return rc;
+    if (canonical && cap < n) return CPD_ERR_UNSUPPORTED;     // rows are ranks (< n): the row capacity must not be cap-limited
     hipStream_t s = cpd_s(stream);
     // with an index the bitmap / prefix / scan spine live there: the workspace (sized by cpd_voxelize_batch_workspace_bytes for
     // the plain grid) then carries no bitmap at all
@@ -487,7 +518,7 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
         w.words = v.words;
         w.bitmap = v.bitmap; w.base = v.base; w.bsum_bm = v.bsum; w.vid = v.perm;
         CPD_HIP_TRY(hipMemsetAsync(v.flags, 0, 4, s));
-        CPD_HIP_TRY(hipMemsetAsync(v.flags, 1, 1, s));                          // flags[0] = 1: row id = perm[rank]
+        if (!canonical) CPD_HIP_TRY(hipMemsetAsync(v.flags, 1, 1, s));          // flags[0] = 1: row id = perm[rank]; canonical: rank
     }
     int32_t *frame_base = (int32_t *)((char *)workspace + w.bytes);
     int32_t *out_base = frame_base + CPD_VOX_MAX_FRAMES + 1;
@@ -510,12 +541,20 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
     rc = device_scan(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
     if (rc) return rc;
     vox_first_batch_kernel<<<nb, 256, 0, s>>>(n, cells, fo, w.pkey, w.bitmap, w.base, w.prank, w.first);
-    rc = device_scan(n, FlagFn{w.prank, w.first}, AssignGlobalFn{w.prank, w.vid, frame_base, fo}, w.bsum_pt, total, -1, s);
-    if (rc) return rc;
-    vox_frames_kernel<<<1, 64, 0, s>>>(fo, n, max_voxels, frame_base, total, out_base, n_voxels);
-    vox_assign_batch_kernel<<<nb, 256, 0, s>>>(n, fo, max_voxels, w.pkey, w.prank, w.first, frame_base, out_base,
-                                               w.vid, coords, geo.g[1], geo.g[2]);
-    vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, w.vid, w.first, w.slots, w.counts);
+    if (canonical) {
+        // rows = ranks: the max_voxels cap (defined on first-appearance order) is NOT applied -- the caller checks the per-frame
+        // counts and falls back to the exact path if a frame exceeds it
+        vox_frames_canonical_kernel<<<1, 64, 0, s>>>(n_frames, cells, w.bitmap, w.base, w.nocc, n_voxels);
+        vox_assign_canonical_kernel<<<nb, 256, 0, s>>>(n, fo, w.pkey, w.prank, w.first, coords, geo.g[1], geo.g[2]);
+        vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, nullptr, w.first, w.slots, w.counts);
+    } else {
+        rc = device_scan(n, FlagFn{w.prank, w.first}, AssignGlobalFn{w.prank, w.vid, frame_base, fo}, w.bsum_pt, total, -1, s);
+        if (rc) return rc;
+        vox_frames_kernel<<<1, 64, 0, s>>>(fo, n, max_voxels, frame_base, total, out_base, n_voxels);
+        vox_assign_batch_kernel<<<nb, 256, 0, s>>>(n, fo, max_voxels, w.pkey, w.prank, w.first, frame_base, out_base,
+                                                   w.vid, coords, geo.g[1], geo.g[2]);
+        vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, w.vid, w.first, w.slots, w.counts);
+    }
     const long long threads = (long long)cap * c;
     vox_gather_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(points, c, max_points, cap, n_voxels + n_frames, w.slots, w.counts,
                                                                voxels, num_points, mean_features);
@@ -527,7 +566,7 @@ extern "C" int cpd_voxelize_batch(const float *points, const int32_t *frame_offs
                                   float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
                                   int32_t *n_voxels, void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
     return voxelize_batch_impl(points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
-                               num_points, mean_features, n_voxels, workspace, workspace_bytes, nullptr, 0, 0, stream);
+                               num_points, mean_features, n_voxels, workspace, workspace_bytes, nullptr, 0, 0, 0, stream);
 }
 
 extern "C" int cpd_voxelize_batch_index(const float *points, const int32_t *frame_offsets, int n_frames, int c,
@@ -537,5 +576,15 @@ extern "C" int cpd_voxelize_batch_index(const float *points, const int32_t *fram
                                         size_t index_bytes, int z_extra, cpd_stream_t stream) {
     if (!index) return CPD_ERR_ARG;
     return voxelize_batch_impl(points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
-                               num_points, mean_features, n_voxels, workspace, workspace_bytes, index, index_bytes, z_extra, stream);
+                               num_points, mean_features, n_voxels, workspace, workspace_bytes, index, index_bytes, z_extra, 0, stream);
+}
+
+extern "C" int cpd_voxelize_batch_canonical(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+                                            const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
+                                            float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
+                                            int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index,
+                                            size_t index_bytes, int z_extra, cpd_stream_t stream) {
+    if (!index) return CPD_ERR_ARG;
+    return voxelize_batch_impl(points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
+                               num_points, mean_features, n_voxels, workspace, workspace_bytes, index, index_bytes, z_extra, 1, stream);
 }

@@ -51,6 +51,10 @@ class ModelConfig:
     # internal row order of the strided levels: "taps" = every chunk of `row_order_chunk` canonical rows sorted by neighbour
     # pattern, so that the conv kernels' 16-row tap skipping is nearly exact (ops.order_rows_by_taps; a level's exported
     # (features, indices) pair is in that order -- any order is a valid sparse tensor); "canonical" = ascending (b, z, y, x)
+    # rows of level 0 inside the engine: "canonical" = ascending (frame, z, y, x), straight from the occupancy bitmap's ranks
+    # (no first-appearance scan, canonical level-0 index, coherent lookups for the rulebooks built on it); "appearance" = the
+    # voxelizer's boundary order (Point2VoxelCPU3d). Same voxels and features either way.
+    voxel_row_order: str = "canonical"
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
     row_order: str = "taps"
     row_order_chunk: int = 4096
@@ -445,8 +449,15 @@ class CenterPointEngine:
         if batch > 1 and self.voxelizer.batch_supported(batch, z_extra):
             # one set of voxelizer launches for the whole batch; rows come out frame after frame; the voxelizer's occupancy
             # bitmap / prefix / rank -> row map ARE the level-0 site index of the backbone
-            _, coords, _, feats, nvox, index0 = self.voxelizer.batch(points_list, index_z_extra=z_extra)
-            total = int(nvox[batch].item())                 # the one read-back
+            n_pts = sum(int(p.shape[0]) for p in points_list)
+            canonical = self.cfg.voxel_row_order == "canonical" and batch * self.cfg.max_voxels >= n_pts
+            _, coords, _, feats, nvox, index0 = self.voxelizer.batch(points_list, index_z_extra=z_extra, canonical=canonical)
+            counts = nvox.tolist()                          # the one read-back: per-frame counts + total
+            if canonical and max(counts[:batch]) > self.cfg.max_voxels:
+                # a frame above its max_voxels cap: which voxels survive is defined on first-appearance order -- the exact path
+                _, coords, _, feats, nvox, index0 = self.voxelizer.batch(points_list, index_z_extra=z_extra)
+                counts = nvox.tolist()
+            total = counts[batch]
             feats, coords = feats[:total], coords[:total]
         elif batch > 1 and self.voxelizer.batch_supported(self.cfg.voxelizer_group, z_extra):
             # more frames than one batched-voxelizer call takes: groups of `voxelizer_group` frames, one voxelizer

@@ -81,12 +81,14 @@ class Voxelizer:
         cells = (g[0] + z_extra) * g[1] * g[2]
         return 0 < n_frames <= 64 and cells < (1 << 31) and n_frames * cells < (1 << 40)
 
-    def batch(self, points_list, want_voxels=False, want_mean=True, index_z_extra=None):
+    def batch(self, points_list, want_voxels=False, want_mean=True, index_z_extra=None, canonical=False):
         """All frames in one set of launches (cpd_voxelize_batch). Returns capacity-sized device tensors
         (voxels|None, coords [cap,4] (b,z,y,x), num_points, mean|None, n_voxels [B+1] = per frame + total);
         rows of frame f follow those of frame f-1. No host synchronisation.
         index_z_extra = k: also returns, as a sixth value, the SiteIndex of the voxel list over the grid with k more
-        z-levels (the backbone's sparse_shape for k = 1), built by the voxelizer itself (cpd_voxelize_batch_index)."""
+        z-levels (the backbone's sparse_shape for k = 1), built by the voxelizer itself (cpd_voxelize_batch_index).
+        canonical = True (with index_z_extra): rows in ascending (frame, z, y, x) order instead of first appearance, canonical
+        index, max_voxels cap not applied (cpd_voxelize_batch_canonical; the caller checks n_voxels against the cap)."""
         for p in points_list:
             _need_cuda(p, "points")
         pts = torch.cat([p.contiguous() for p in points_list]) if len(points_list) > 1 else points_list[0].contiguous()
@@ -111,11 +113,13 @@ class Voxelizer:
         if index_z_extra is not None:
             g = self.grid_zyx
             index = SiteIndex(nf, [g[0] + int(index_z_extra), g[1], g[2]], max(n, 1), dev)
-            check(lib().cpd_voxelize_batch_index(ptr(pts), iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
-                                                 ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
-                                                 self._wsb.numel(), ptr(index.buf), index.buf.numel(), int(index_z_extra), stream()),
-                  "cpd_voxelize_batch_index")
+            fn = lib().cpd_voxelize_batch_canonical if canonical else lib().cpd_voxelize_batch_index
+            check(fn(ptr(pts), iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
+                     ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
+                     self._wsb.numel(), ptr(index.buf), index.buf.numel(), int(index_z_extra), stream()),
+                  "cpd_voxelize_batch_canonical" if canonical else "cpd_voxelize_batch_index")
             return voxels, coords, num, mean, nvox, index
+        assert not canonical, "canonical rows come with the in-place index (index_z_extra)"
         check(lib().cpd_voxelize_batch(ptr(pts), iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
                                        ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
                                        self._wsb.numel(), stream()), "cpd_voxelize_batch")

@@ -84,6 +84,19 @@ int cpd_voxelize_batch_index(const float *points, const int32_t *frame_offsets, 
                              int max_voxels, float *voxels, int32_t *coords, int32_t *num_points,
                              float *mean_features, int32_t *n_voxels, void *workspace, size_t workspace_bytes,
                              void *index, size_t index_bytes, int z_extra, cpd_stream_t stream);
+/* cpd_voxelize_batch_index with the voxel rows in CANONICAL order -- ascending (frame, z, y, x) = the rank of the voxel's cell in
+ * the occupancy bitmap -- instead of first appearance. Same voxels, same points per voxel (the max_points smallest point indices),
+ * same means; only the row order differs, the site index left behind is canonical (row = rank, no map) and the first-appearance
+ * scan over the points is not run. The order at the B1 boundary (Point2VoxelCPU3d) is first appearance: this form is for hosts
+ * that consume the rows themselves (CenterPointEngine). The max_voxels cap is defined on first-appearance order and is NOT
+ * applied here: n_voxels [n_frames + 1] reports the true counts, a caller that sees a frame above its cap falls back to
+ * cpd_voxelize_batch_index. Outputs need min(n_frames * max_voxels, n_total) rows as there (a frame above the cap may exceed
+ * that: check the workspace-sized capacity n_total instead when caps can bind). */
+int cpd_voxelize_batch_canonical(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+                                 const float vsize_xyz[3], const float range_xyz[6], int max_points_per_voxel,
+                                 int max_voxels, float *voxels, int32_t *coords, int32_t *num_points,
+                                 float *mean_features, int32_t *n_voxels, void *workspace, size_t workspace_bytes,
+                                 void *index, size_t index_bytes, int z_extra, cpd_stream_t stream);
 
 /* ===== B2. Sparse convolution ==============================================================
  * Replaces [SPCONV] SparseConvTensor / SubMConv3d / SparseConv3d / .dense() as called from

@@ -34,14 +34,21 @@ def test_engine_matches_reference_graph(oracle, hip):
     res, it = eng.forward([torch.from_numpy(p).cuda() for p in pts], return_intermediates=True)
     ref, rt = ref_pipeline.forward(oracle, cfg, sd, pts)
 
-    np.testing.assert_array_equal(it["voxel_coords"].cpu().numpy(), rt["voxel_coords"])
-    np.testing.assert_allclose(it["voxel_features"].cpu().numpy(), rt["voxel_features"], rtol=1e-6, atol=1e-6)
+    # the engine keeps its rows in its own order (level 0: canonical instead of first appearance, ModelConfig.voxel_row_order;
+    # strided levels: tap-pattern order above row_order_min_rows): voxel list and levels are compared as sets, both sides sorted
+    shape0 = cfg.sparse_shape
+    vf, vc, _ = _canonical(it["voxel_features"], it["voxel_coords"], shape0)
+    vf0, vc0, _ = _canonical(rt["voxel_features"], rt["voxel_coords"], shape0)
+    np.testing.assert_array_equal(vc, vc0)
+    np.testing.assert_allclose(vf, vf0, rtol=1e-6, atol=1e-6)
     for name in ["x_conv1", "x_conv2", "x_conv3", "x_conv4"]:
         f, i, s = it["levels"][name]
         f0, i0, s0 = rt["levels"][name]
         assert list(s) == list(s0)
-        np.testing.assert_array_equal(i.cpu().numpy(), i0)            # canonical order natively
-        np.testing.assert_allclose(f.cpu().numpy(), f0, atol=1e-4, rtol=0, err_msg=name)
+        f, i, _ = _canonical(f, i, s)
+        f0, i0, _ = _canonical(f0, i0, s0)
+        np.testing.assert_array_equal(i, i0)
+        np.testing.assert_allclose(f, f0, atol=1e-4, rtol=0, err_msg=name)
     x, idx, shape = it["encoded"]
     x0, idx0, shape0 = rt["encoded"]
     np.testing.assert_array_equal(idx.cpu().numpy(), idx0)
@@ -67,10 +74,11 @@ def test_engine_matches_reference_graph(oracle, hip):
 
 def _canonical(f, i, shape):
     """rows of a level sorted by (b, z, y, x); third value: was the level stored in another order?"""
-    i = i.cpu().numpy()
+    i = i.cpu().numpy() if hasattr(i, "cpu") else np.asarray(i)
+    f = f.cpu().numpy() if hasattr(f, "cpu") else np.asarray(f)
     key = ((i[:, 0].astype(np.int64) * shape[0] + i[:, 1]) * shape[1] + i[:, 2]) * shape[2] + i[:, 3]
     o = np.argsort(key, kind="stable")
-    return f.cpu().numpy()[o], i[o], bool((o != np.arange(len(o))).any())
+    return f[o], i[o], bool((o != np.arange(len(o))).any())
 
 
 @pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
@@ -89,21 +97,20 @@ def test_full_size_config2_matches_oracle(oracle, hip, math):
     fi = len(clouds) - 1                                           # the checked frame sits LAST: nonzero row offsets everywhere
     res, it = eng.forward(clouds, return_intermediates=True)
 
-    vc = it["voxel_coords"].cpu().numpy()
+    vf, vc, _ = _canonical(it["voxel_features"], it["voxel_coords"], cfg.sparse_shape)
+    vf0, vc0, _ = _canonical(rt["voxel_features"], rt["voxel_coords"], cfg.sparse_shape)
     mine = vc[:, 0] == fi
-    np.testing.assert_array_equal(vc[mine][:, 1:], rt["voxel_coords"][:, 1:])
-    np.testing.assert_allclose(it["voxel_features"].cpu().numpy()[mine], rt["voxel_features"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(vc[mine][:, 1:], vc0[:, 1:])
+    np.testing.assert_allclose(vf[mine], vf0, rtol=1e-6, atol=1e-6)
     reordered = 0
     for name in ["x_conv1", "x_conv2", "x_conv3", "x_conv4"]:
         f, i, s = it["levels"][name]
         f0, i0, s0 = rt["levels"][name]
         # the engine keeps the strided levels in tap-pattern order (ModelConfig.row_order): a level is a set of (site, feature)
         # pairs -- compared here in canonical (b, z, y, x) order, where the site LIST must equal the oracle's bit for bit
-        if name == "x_conv1":                                       # level 0 keeps the voxelizer's first-appearance order on both sides
-            f, i = f.cpu().numpy(), i.cpu().numpy()
-        else:
-            f, i, moved = _canonical(f, i, s)
-            reordered += int(moved)
+        f, i, moved = _canonical(f, i, s)
+        f0, i0, _ = _canonical(f0, i0, s0)                          # (the oracle's level 0 is in first-appearance order)
+        reordered += int(moved and name != "x_conv1")
         mine = i[:, 0] == fi
         np.testing.assert_array_equal(i[mine][:, 1:], i0[:, 1:])
         np.testing.assert_allclose(f[mine], f0, atol=1e-4, rtol=0, err_msg=name)

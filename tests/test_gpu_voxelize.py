@@ -153,3 +153,34 @@ def test_batched_voxelizer_beyond_2_to_31_cells(hip):
     want = ops.rulebook_subm(cc, ops.SiteIndex.build(cc, nf, shape))
     got = ops.rulebook_subm(cc, index)
     assert torch.equal(got, want)
+
+
+def test_batched_voxelizer_canonical_rows(oracle, hip):
+    """cpd_voxelize_batch_canonical: the same voxels, point counts and means as the first-appearance form, rows in ascending
+    (frame, z, y, x) order, and a canonical site index (row = rank) whose rulebook is the oracle's on the sorted list."""
+    import torch
+    from cpd_amd import ops
+    from cpd_amd.synthetic import waymo_cloud
+    vs, rg = [0.1, 0.1, 0.15], [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    clouds = [torch.from_numpy(waymo_cloud(s, n_points=30000 + 9000 * s)).cuda() for s in range(3)]
+    clouds += [torch.zeros((0, 5), device="cuda"), torch.from_numpy(waymo_cloud(7, n_points=12000)).cuda()]
+    nf = len(clouds)
+    vox = ops.Voxelizer(vs, rg, 5, 5, 1000000)
+    g = vox.grid_zyx
+    shape = [g[0] + 1, g[1], g[2]]
+    v0, c0, n0, m0, nv0, _ = vox.batch(clouds, want_voxels=True, index_z_extra=1)
+    v1, c1, n1, m1, nv1, index = vox.batch(clouds, want_voxels=True, index_z_extra=1, canonical=True)
+    assert torch.equal(nv0, nv1)
+    total = int(nv0[-1])
+    key = lambda c: ((c[:, 0].long() * shape[0] + c[:, 1]) * shape[1] + c[:, 2]) * shape[2] + c[:, 3]
+    k1 = key(c1[:total])
+    assert bool((k1[1:] > k1[:-1]).all())                                        # strictly ascending: canonical, no duplicates
+    order = torch.argsort(key(c0[:total]))
+    assert torch.equal(c0[:total][order], c1[:total]) and torch.equal(n0[:total][order], n1[:total])
+    assert torch.equal(m0[:total][order], m1[:total]) and torch.equal(v0[:total][order], v1[:total])
+    cc = c1[:total].contiguous()
+    got = ops.rulebook_subm(cc, index)
+    np.testing.assert_array_equal(got.cpu().numpy(), oracle.subm_rulebook(cc.cpu().numpy(), nf, shape, [3, 3, 3]))
+    small = ops.Voxelizer(vs, rg, 5, 5, 900)                                    # row capacity limited by the cap: refused, not wrong
+    with pytest.raises(Exception):
+        small.batch(clouds, index_z_extra=1, canonical=True)
