@@ -36,6 +36,24 @@ static inline bool cpd_tuning() {
 static inline const char *cpd_knob(bool tuning, const char *name) { return tuning ? getenv(name) : nullptr; }
 
 static inline hipStream_t cpd_s(cpd_stream_t s) { return (hipStream_t)s; }
+// Fill of a large 16-byte-aligned buffer with one 32-bit pattern (occupancy bitmaps: 11.6 MB per frame; voxel slot tables).
+// hipMemsetAsync's fill kernel reached 2.3 TB/s on the 556 MB level-0 bitmap of a 48-frame batch; a plain grid-stride loop of
+// 16-byte stores runs at the write rate of the memory system (7 TB/s for that buffer).
+static __global__ void __launch_bounds__(256) cpd_fill_kernel(uint4 *__restrict__ p, size_t n16, uint32_t v) {
+    const uint4 z = {v, v, v, v};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+}
+static inline int cpd_fill_bytes(void *p, uint8_t byte, size_t bytes, hipStream_t s) {   // memset semantics
+    if (bytes == 0) return 0;
+    if (((uintptr_t)p & 15) || (bytes & 15) || bytes < (1u << 20)) return (int)hipMemsetAsync(p, byte, bytes, s);
+    const size_t n16 = bytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    cpd_fill_kernel<<<(unsigned)blocks, 256, 0, s>>>(static_cast<uint4 *>(p), n16, 0x01010101u * byte);
+    return (int)hipGetLastError();
+}
+static inline int cpd_zero_fill(void *p, size_t bytes, hipStream_t s) { return cpd_fill_bytes(p, 0, bytes, s); }
+
 static inline size_t cpd_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int cpd_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 

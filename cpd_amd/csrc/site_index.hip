@@ -294,7 +294,7 @@ extern "C" int cpd_index_build(const int32_t *indices, int n, int batch, const i
     if (index_bytes < v.bytes) return CPD_ERR_WORKSPACE;
     hipStream_t s = cpd_s(stream);
     Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
-    CPD_HIP_TRY(hipMemsetAsync(v.bitmap, 0, (size_t)v.words * 8, s));
+    if (cpd_zero_fill(v.bitmap, (size_t)v.words * 8, s)) return CPD_ERR_LAUNCH;
     CPD_HIP_TRY(hipMemsetAsync(v.flags, 0, 4, s));
     CPD_HIP_TRY(hipMemsetAsync(v.flags, 1, 1, s));  // flags[0] = 1 (little endian): perm in use
     if (n > 0) index_mark_kernel<<<cpd_div_up(n, 256), 256, 0, s>>>(indices, n, g, v.bitmap);
@@ -437,7 +437,7 @@ extern "C" int cpd_conv_outset(const int32_t *in_indices, int n_in, int batch, c
     if (out_index_bytes < v.bytes) return CPD_ERR_WORKSPACE;
     hipStream_t s = cpd_s(stream);
     Grid g{batch, os[0], os[1], os[2]};
-    CPD_HIP_TRY(hipMemsetAsync(v.bitmap, 0, (size_t)v.words * 8, s));
+    if (cpd_zero_fill(v.bitmap, (size_t)v.words * 8, s)) return CPD_ERR_LAUNCH;
     CPD_HIP_TRY(hipMemsetAsync(v.flags, 0, 4, s));  // canonical: rank == row id, perm unused
     if (ksize[2] > 32) return CPD_ERR_UNSUPPORTED;            // (a site's x' cells must fit two bitmap words)
     if (n_in > 0)

@@ -531,10 +531,10 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
         }
         return CPD_OK;
     }
-    CPD_HIP_TRY(hipMemsetAsync(w.bitmap, 0, (size_t)w.words * 8, s));
-    CPD_HIP_TRY(hipMemsetAsync(w.first, 0x7f, (size_t)n * 4, s));
-    CPD_HIP_TRY(hipMemsetAsync(w.slots, 0x7f, (size_t)cap * max_points * 4, s));
-    CPD_HIP_TRY(hipMemsetAsync(w.counts, 0, (size_t)cap * 4, s));
+    if (cpd_zero_fill(w.bitmap, (size_t)w.words * 8, s)) return CPD_ERR_LAUNCH;
+    if (cpd_fill_bytes(w.first, 0x7f, (size_t)n * 4, s)) return CPD_ERR_LAUNCH;
+    if (cpd_fill_bytes(w.slots, 0x7f, (size_t)cap * max_points * 4, s)) return CPD_ERR_LAUNCH;
+    if (cpd_zero_fill(w.counts, (size_t)cap * 4, s)) return CPD_ERR_LAUNCH;
     CPD_HIP_TRY(hipMemsetAsync(frame_base, 0, (CPD_VOX_MAX_FRAMES + 1) * 4, s));
     const int nb = cpd_div_up(n, 256);
     vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap);
