@@ -1569,6 +1569,8 @@ static int window_bm(int frames, int h, int w, int c_out, int bn, int flags) {
     if (const char *e = cpd_knob(tn, "CPD_GC_WINDOW_BM256")) want = atoi(e);
     const long long rows = (long long)frames * h * w;
     if (want && split_math(flags, tn) == 2 && (c_out + bn - 1) / bn == 1 && bn <= 64 && (rows + 255) / 256 >= 1024) return 256;
+    // several 64-column tiles (the fused 64 -> 320 head convs): 256-row tiles as well (want = 2 turns this off)
+    if (want == 1 && split_math(flags, tn) == 2 && bn == 64 && (rows + 255) / 256 >= 1024) return 256;
     return 128;
 }
 extern "C" int cpd_conv3x3_rows_supported(int frames, int h, int w, int c_in, int c_out, int flags) {

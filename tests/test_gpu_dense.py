@@ -90,10 +90,11 @@ def test_bench_kernels_match_oracle_at_full_size(oracle, hip, math, cin, cout, k
     np.testing.assert_allclose(rows_nchw(got, batch, ho, wo), want, atol=1e-4, rtol=0)
 
 
-@pytest.mark.parametrize("cin,cout,batch,kernel", [(512, 64, 8, "window_conv_f16_kernel<64,256>"), (320, 11, 8, "window_conv_f16_kernel<16,256>")])
+@pytest.mark.parametrize("cin,cout,batch,kernel", [(512, 64, 8, "window_conv_f16_kernel<64,256>"), (320, 11, 8, "window_conv_f16_kernel<16,256>"),
+                                                   (64, 320, 8, "window_conv_f16_kernel<64,256>")])
 def test_bench_256_row_window_tiles_match_oracle(oracle, hip, cin, cout, batch, kernel):
-    """The 256-row window tiles the single-column-tile layers (CenterHead shared conv, fused output convs) get at the bench's
-    batch size (>= 1024 such workgroups), against the oracle at 188 x 188."""
+    """The 256-row window tiles the 64- and 16-column layers (CenterHead shared conv, the fused 64 -> 320 first head convs with their
+    five column tiles, the fused output convs) get at the bench's batch size (>= 1024 such row tiles), against the oracle at 188 x 188."""
     rng = np.random.default_rng(cin + cout + 256)
     h = w = 188
     x = rng.normal(size=(batch, cin, h, w)).astype(np.float32)
