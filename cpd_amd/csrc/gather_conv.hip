@@ -93,12 +93,15 @@ __device__ __forceinline__ f32x4 zero_if(f32x4 a, bool z) {
 template <int MS, int NT>
 __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT], int row0, int col0, int r, int g) {
     float sc[NT], sh[NT];
+    int grp[NT], cloc[NT];            // column-group scatter (ConvTranspose as one GEMM): group and column inside it, per column tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = col0 + nt * 16 + r;
         sc[nt] = (p.scale && col < p.c_out) ? p.scale[col] : 1.f;
         if (p.dsc && col < p.np) sc[nt] *= p.dsc[col];       // exact (a power of two): (acc * 2^-e) * scale, bit for bit
         sh[nt] = (p.shift && col < p.c_out) ? p.shift[col] : 0.f;
+        grp[nt] = p.col_group ? col / p.col_group : 0;
+        cloc[nt] = col - grp[nt] * p.col_group;
     }
 #pragma unroll
     for (int s = 0; s < MS; ++s) {
@@ -108,6 +111,8 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
             if (row >= p.n_out) continue;
             size_t orow = (size_t)row;
             if (p.out_row_map && !p.col_group) orow = (size_t)p.out_row_map[row];
+            int grp_have = -1;
+            size_t drow = 0;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = col0 + nt * 16 + r;
@@ -117,9 +122,11 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
                 if (p.residual) v += p.residual[(size_t)row * p.res_ld + col];
                 if (p.relu) v = v > 0.f ? v : 0.f;
                 if (p.col_group) {
-                    const int grp = col / p.col_group;
-                    const size_t drow = (size_t)p.out_row_map[(size_t)grp * p.n_out + row];
-                    p.out[drow * p.out_ld + (col - grp * p.col_group)] = v;
+                    if (grp[nt] != grp_have) {                 // one map entry per (row, group): a column tile rarely spans two
+                        grp_have = grp[nt];
+                        drow = (size_t)p.out_row_map[(size_t)grp_have * p.n_out + row];
+                    }
+                    p.out[drow * p.out_ld + cloc[nt]] = v;
                 } else {
                     p.out[orow * p.out_ld + col] = v;
                 }
