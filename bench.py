@@ -470,6 +470,9 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "peak_basis": peak_basis, "achieved_over_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "power_cap_note": "peak is the nominal 2.4 GHz figure; measured on this part (tools/mfma_power_probe.hip, tools/power_probe.py): a "
+                              "loop of nothing but f16 MFMAs on register operands sustains 0.65 (random data) to 0.74 (half zeros) of it under "
+                              "the 1400 W socket cap, and this kernel runs at 1.9-2.1 GHz for the same reason (DESIGN.md 4.1)",
             "traffic": pmc_traffic(key),
             "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 --pmc passes of this "
                             "command, profiles/r02_pmc_summary.json; bench.py cannot collect counters itself)",
