@@ -48,10 +48,12 @@ SIGNATURES = {
     "cpd_packed_weight_floats": (_SZ, [_I, _I, _I]),
     "cpd_pack_weight": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "cpd_gather_conv": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _I, _VP]),
+    "cpd_gather_conv_scaled": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _I, _VP, _VP]),
     "cpd_gather_conv_tile": (_I, [_I, _I, _I, _I, _I] + [ctypes.POINTER(_I)] * 4),
     "cpd_conv3x3_rows_tile": (_I, [_I, _I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "cpd_conv3x3_rows_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "cpd_conv3x3_rows": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
+    "cpd_conv3x3_rows_scaled": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     "cpd_densify_nchw": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_densify_nhwc": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_rulebook_conv2d": (_I, [_I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
@@ -95,10 +97,11 @@ SIGNATURES = {
     "cpd_pack_weight_adjoint": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "cpd_affine_rows": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),
     "cpd_bn_bwd_reduce": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
-    "cpd_bn_bwd_apply": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP]),
+    "cpd_bn_bwd_apply": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP]),
     "cpd_relu_bwd": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
     "cpd_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cpd_conv_wgrad": (_I, [_VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _VP, _I, _VP, _SZ, _VP]),
+    "cpd_conv_wgrad_scaled": (_I, [_VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _VP, _I, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_rulebook_conv_transpose": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _VP, _VP]),
     "cpd_rulebook_conv2d_transpose": (_I, [_I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
     "cpd_center_loss_workspace_bytes": (_SZ, [_I, _I, _I]),

@@ -47,6 +47,8 @@ struct GcParams {
     const float *in;
     const float *w;
     const void *wb;           // split image of the weights (bf16x3 or f16x2, after the fp32 image) or NULL
+    const uint32_t *in_absmax; // f16x2 only, or NULL: device word holding the bits of max |in| -- the kernel scales `in` by the power of two
+                              // that puts it at [2^14, 2^15) before the split and undoes it in the epilogue (gradients: fp16's range)
     const float *dsc;         // f16x2 only: per output column, the power of two that undoes the weights' pre-scale (or NULL)
     const int32_t *nbr;
     const uint32_t *tapmask;  // per 16-row sub-tile: bit t = some row has a neighbour at tap t (or NULL)
@@ -90,8 +92,22 @@ __device__ __forceinline__ f32x4 zero_if(f32x4 a, bool z) {
 }
 
 // Shared epilogue. C/D layout of 16x16x4: col = lane & 15, row = 4*(lane >> 4) + i.
+// Power-of-two pre-scale of the input for the fp16 split: s = 2^(14 - floor(log2 max|in|)), inv = 1 / s (both exact)
+__device__ __forceinline__ void in_pow2_scale(const uint32_t *absmax, float &s, float &inv) {
+    s = 1.f; inv = 1.f;
+    if (absmax) {
+        const int e = (int)((*absmax >> 23) & 0xffu);          // biased exponent of max |in|
+        if (e != 0 && e != 255) {                              // zero / denormal / inf / nan maximum: left alone
+            int se = 268 - e;                                  // 127 + 14 - (e - 127)
+            se = se < 1 ? 1 : (se > 253 ? 253 : se);
+            s = __uint_as_float((uint32_t)se << 23);
+            inv = __uint_as_float((uint32_t)(254 - se) << 23);
+        }
+    }
+}
+
 template <int MS, int NT>
-__device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT], int row0, int col0, int r, int g) {
+__device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT], int row0, int col0, int r, int g, float acc_scale = 1.f) {
     float sc[NT], sh[NT];
     int grp[NT], cloc[NT];            // column-group scatter (ConvTranspose as one GEMM): group and column inside it, per column tile
 #pragma unroll
@@ -99,6 +115,7 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
         const int col = col0 + nt * 16 + r;
         sc[nt] = (p.scale && col < p.c_out) ? p.scale[col] : 1.f;
         if (p.dsc && col < p.np) sc[nt] *= p.dsc[col];       // exact (a power of two): (acc * 2^-e) * scale, bit for bit
+        sc[nt] *= acc_scale;                                 // the input's pre-scale (a power of two; 1 when unused)
         sh[nt] = (p.shift && col < p.c_out) ? p.shift[col] : 0.f;
         grp[nt] = p.col_group ? col / p.col_group : 0;
         cloc[nt] = col - grp[nt] * p.col_group;
@@ -471,7 +488,7 @@ struct SplitF16x2 {
         p[1] = __builtin_convertvector(r1, f16x4);
     }
     static __device__ __forceinline__ f32x4 mma(const frag (&a)[NP], const frag (&b)[NP], f32x4 c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], c, 0, 0, 0);
+        if (!(CPD_GC_ABLATE & 2048)) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], c, 0, 0, 0);   // 2048: two of three products (timing only)
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], c, 0, 0, 0);
         return c;
@@ -485,8 +502,10 @@ __device__ __forceinline__ typename S::frag join_halves(const typename S::half &
 // ----------------------------- split workgroup kernel (rulebook) -----------------------------
 // SH = row sub-tiles of a wave whose A fragments are live at once (the B fragments are re-read MS / SH times per stage);
 // LATE_B = the weight stage is fetched AFTER the MFMA block, so its registers are not live across it.
-template <class S, int BM, int BN, bool DB, int SH, bool LATE_B>
+template <class S, int BM, int BN, bool DB, int SH, bool LATE_B, bool SC = false>
 __device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
+    float in_s = 1.f, in_inv = 1.f;
+    if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
     constexpr int NP = S::NP;
     constexpr int MS = BM / 32, NT = BN / 32;       // 2 x 2 waves, wave tile (BM/2) x (BN/2)
     constexpr int AJ = BM / 32;                     // fp32 A pieces (4 channels) staged per thread per stage
@@ -559,7 +578,7 @@ __device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
         for (int j = 0; j < AJ; ++j) {
             const int m = a_row + 32 * j;
             typename S::half pc[NP];
-            S::split(zero_if(ra[j], rz[j]), pc);
+            S::split(SC ? zero_if(ra[j], rz[j]) * in_s : zero_if(ra[j], rz[j]), pc);
             char *dst = sa + (((ag * BM + (m ^ (2 * ag))) << 4) + half * 8);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<typename S::half *>(dst + q * A_IMG) = pc[q];
@@ -617,7 +636,7 @@ __device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
         if (nx < n_stage) stage_store(nx & 1);
         __syncthreads();
     }
-    epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g);
+    epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g, in_inv);
 }
 
 template <int BM, int BN, bool DB>
@@ -631,6 +650,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
 tile_conv_f16_kernel(GcParams p) {
     tile_conv_split_body<SplitF16x2, BM, BN, false, BM / 32, true>(p);
 }
+// ... with the input pre-scaled into fp16's range (GcParams::in_absmax; gradients). A separate kernel, not a branch: the
+// unscaled kernels stay exactly what they were (both paths in one kernel cost the inference bench 1.8 %)
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && BM == 128 ? 3 : 4, BN == 128 && BM == 128 ? 3 : 8)))
+tile_conv_f16s_kernel(GcParams p) {
+    tile_conv_split_body<SplitF16x2, BM, BN, false, BM / 32, true, true>(p);
+}
 
 // Split kernel for the dense 3x3 / stride 1 / pad 1 convolutions (BaseBEVBackbone blocks, CenterHead convs) over
 // channels-last pixel rows [frames * H * W, C], WITHOUT a rulebook: the input row of output row R at tap (dy, dx) is
@@ -642,8 +668,10 @@ tile_conv_f16_kernel(GcParams p) {
 // lanes -- a wave-uniform branch that is taken for ~1 in 6 (sub-tile, dx != 0) pairs at W = 188.
 // Same tile, fragment layout, XOR-2g swizzle (the image has 136 rows per k-group so that 129 ^ 6 stays inside), register
 // diet (SH row sub-tiles live at a time, weights fetched after the MFMA block) as the rulebook kernel.
-template <class S, int BN, int SH, bool GLDS = false, int BM = 128>
+template <class S, int BN, int SH, bool GLDS = false, int BM = 128, bool SC = false>
 __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
+    float in_s = 1.f, in_inv = 1.f;
+    if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
     constexpr int NP = S::NP;
     // wave grid: 2 x 2 (128 rows x 64 / 128 columns), or 4 x 1: the 16-column tile (tiny c_out heads) and the 256-row tiles
     // (single-column-tile layers, c_out = 64 or <= 16: a wave gets 64 rows instead of 32, twice the MFMAs per staged byte)
@@ -736,7 +764,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
             const int w = a_row + 32 * j;
             if (AJ * 32 <= WROWS || w < WROWS) {
                 typename S::half pc[NP];
-                S::split(ra[j], pc);
+                S::split(SC ? ra[j] * in_s : ra[j], pc);
                 char *dst = sa + (((ag * BMW + w) << 4) + half * 8);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<typename S::half *>(dst + q * A_IMG) = pc[q];
@@ -783,7 +811,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
     __syncthreads();
     const int n_stage = 9 * sk;
     for (int st = 0; st < n_stage; ++st) {
-        const int t = st % 9, dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        const int t = st % 9, dx = t - (t / 3) * 3 - 1;
         const int nx = st + 1;
         const bool new_window = nx < n_stage && nx % 3 == 0;     // the next stage starts another dy (or channel block)
         // CPD_GC_ABLATE (diagnostic builds only, wrong results): 64 no weight stages, 128 no window loads / splits / stores,
@@ -874,7 +902,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
         if (t == 123.456f) p.out[tid] = t;
         return;
     }
-    epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g);
+    epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g, in_inv);
 }
 
 template <int BN>
@@ -889,6 +917,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
 window_conv_f16_kernel(GcParams p) {
     window_conv_split_body<SplitF16x2, BN, (BN >= 64 && BM == 128) || (BM == 256 && BN < 64) ? 4 : 2, BN >= 64, BM>(p);
 }
+template <int BN, int BM = 128>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 || BM == 256 ? 3 : 4, BN == 128 || BM == 256 ? 3 : 4)))
+window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_conv_f16s_kernel)
+    window_conv_split_body<SplitF16x2, BN, (BN >= 64 && BM == 128) || (BM == 256 && BN < 64) ? 4 : 2, BN >= 64, BM, true>(p);
+}
 
 // Split kernel for SPARSE layers: a workgroup owns 64*MS output rows x BN columns, wave w the
 // rows [16*MS*w, 16*MS*(w+1)) x all BN columns. Only the weights go through LDS (one (tap, 32-channel)
@@ -898,15 +931,16 @@ window_conv_f16_kernel(GcParams p) {
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
 // MS = row sub-tiles per wave: 2 (128-row workgroups) or 1 (64-row workgroups, for layers too small to give every CU a
 // 128-row workgroup: twice the workgroups, each staging the same weights for half the rows).
-template <class S, int BN, int MS>
-__device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
+template <class S, int BN, int MS, bool SC = false>
+__device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb) {
+    float in_s = 1.f, in_inv = 1.f;
+    if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
     constexpr int NP = S::NP;
     constexpr int NT = BN / 16;
     constexpr int WG_ROWS = 64 * MS, WG_SUBS = 4 * MS;
     constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
-    __shared__ __attribute__((aligned(16))) char sb[NP * B_IMG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -1013,8 +1047,8 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
                     typename S::half lo[NP], hi[NP];
-                    S::split(zero_if(araw[s][0], az[s]), lo);
-                    S::split(zero_if(araw[s][1], az[s]), hi);
+                    S::split(SC ? zero_if(araw[s][0], az[s]) * in_s : zero_if(araw[s][0], az[s]), lo);
+                    S::split(SC ? zero_if(araw[s][1], az[s]) * in_s : zero_if(araw[s][1], az[s]), hi);
 #pragma unroll
                     for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
                 }
@@ -1070,19 +1104,27 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p) {
             for (int s = 0; s < MS; ++s) idx_b[s] = idx_a[s];
         }
     }
-    epilogue<MS, NT>(p, acc, row0, col0, r, g);
+    epilogue<MS, NT>(p, acc, row0, col0, r, g, in_inv);
 }
 
 // (bf16x3, BN = 128, MS = 2 sits at the 3-waves-per-SIMD budget)
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, BN == 128 && MS == 2 ? 3 : 8)))
 rowwave_conv_bf16_kernel(GcParams p) {
-    rowwave_conv_split_body<SplitBf16x3, BN, MS>(p);
+    __shared__ __attribute__((aligned(16))) char sb[SplitBf16x3::NP * BN * 64];     // one weight stage: pieces x 4 k-groups x BN x 16 B
+    rowwave_conv_split_body<SplitBf16x3, BN, MS>(p, sb);
 }
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
 rowwave_conv_f16_kernel(GcParams p) {
-    rowwave_conv_split_body<SplitF16x2, BN, MS>(p);
+    __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
+    rowwave_conv_split_body<SplitF16x2, BN, MS>(p, sb);
+}
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+rowwave_conv_f16s_kernel(GcParams p) {            // pre-scaled input (see tile_conv_f16s_kernel)
+    __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
+    rowwave_conv_split_body<SplitF16x2, BN, MS, true>(p, sb);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -1448,10 +1490,10 @@ extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, i
     return CPD_OK;
 }
 
-extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
-                               const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
-                               const float *residual, int res_ld, int relu, float *out, int out_ld,
-                               const int32_t *out_row_map, int out_col_group, int flags, cpd_stream_t stream) {
+static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
+                            const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
+                            const float *residual, int res_ld, int relu, float *out, int out_ld,
+                            const int32_t *out_row_map, int out_col_group, int flags, const uint32_t *in_absmax, cpd_stream_t stream) {
     if (n_out == 0 && n_in >= 0 && c_in > 0 && c_out > 0 && kv > 0) return CPD_OK;   // an empty site set is a valid (empty) result
     if (!in || !packed_w || !out || n_in < 0 || n_out < 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || in_ld < c_in ||
         (residual && res_ld < c_out) || (!nbr && kv != 1) || (tapmask && kv > 32) || out_col_group < 0 || (out_col_group > 0 && !out_row_map) ||
@@ -1459,7 +1501,7 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
     GcParams p;
-    p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.in_absmax = in_absmax; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
@@ -1481,6 +1523,16 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     const dim3 grid(p.items), block(256);
     hipStream_t hs = cpd_s(stream);
 #define CPD_LAUNCH(K, LDS) hipLaunchKernelGGL((K), grid, block, (LDS), hs, p)
+    if (pl.use_wg == 3 && pl.math == 2 && in_absmax) {
+        if (pl.a == 64) {
+            if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16s_kernel<32, 1>), 0);
+            else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16s_kernel<64, 1>), 0);
+            else CPD_LAUNCH((rowwave_conv_f16s_kernel<128, 1>), 0);
+        } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16s_kernel<32, 2>), 0);
+        else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16s_kernel<64, 2>), 0);
+        else CPD_LAUNCH((rowwave_conv_f16s_kernel<128, 2>), 0);
+        return cpd_check_launch();
+    }
     if (pl.use_wg == 3 && pl.math == 2) {
         if (pl.a == 64) {
             if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 1>), 0);
@@ -1503,6 +1555,13 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
     }
     if (pl.use_wg == 2 && pl.math == 2) {
         const size_t lds = 2 * (size_t)(pl.a + pl.b) * 64;
+        if (in_absmax) {
+            if (pl.a == 64 && pl.b == 128) CPD_LAUNCH((tile_conv_f16s_kernel<64, 128>), lds);
+            else if (pl.a == 64) CPD_LAUNCH((tile_conv_f16s_kernel<64, 64>), lds);
+            else if (pl.b == 64) CPD_LAUNCH((tile_conv_f16s_kernel<128, 64>), lds);
+            else CPD_LAUNCH((tile_conv_f16s_kernel<128, 128>), lds);
+            return cpd_check_launch();
+        }
         if (pl.a == 64 && pl.b == 128) CPD_LAUNCH((tile_conv_f16_kernel<64, 128>), lds);
         else if (pl.a == 64) CPD_LAUNCH((tile_conv_f16_kernel<64, 64>), lds);
         else if (pl.b == 64) CPD_LAUNCH((tile_conv_f16_kernel<128, 64>), lds);
@@ -1589,9 +1648,9 @@ extern "C" int cpd_conv3x3_rows_tile(int frames, int h, int w, int c_in, int c_o
     *bm = *bn ? window_bm(frames, h, w, c_out, *bn, flags) : 0;
     return *bn ? CPD_OK : CPD_ERR_UNSUPPORTED;
 }
-extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
-                                const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
-                                int out_ld, int flags, cpd_stream_t stream) {
+static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
+                             const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
+                             int out_ld, int flags, const uint32_t *in_absmax, cpd_stream_t stream) {
     if (!in || !packed_w || !out || frames <= 0 || h <= 0 || w <= 0 || c_in <= 0 || c_out <= 0 || in_ld < c_in || out_ld < c_out ||
         (residual && res_ld < c_out))
         return CPD_ERR_ARG;
@@ -1601,7 +1660,7 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     memset(&p, 0, sizeof(p));
     const int n_out = frames * h * w;
     const int math = split_math(flags, cpd_tuning());
-    p.in = in; p.w = packed_w;
+    p.in = in; p.w = packed_w; p.in_absmax = in_absmax;
     if (math == 2) { p.wb = packed_f16_ptr(packed_w, 9, c_in, c_out); p.dsc = packed_dsc_ptr(packed_w, 9, c_in, c_out); }
     else p.wb = packed_bf16_ptr(packed_w, 9, c_in, c_out);
     p.scale = scale; p.shift = shift; p.residual = residual; p.out = out;
@@ -1613,6 +1672,19 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     p.n_rb = (n_out + bm - 1) / bm; p.n_cb = (c_out + bn - 1) / bn; p.items = p.n_rb * p.n_cb;
     p.img_h = h; p.img_w = w;
     const size_t lds = (math == 2 ? 2 : 3) * ((size_t)(128 + 16) * 64 + (size_t)bn * 64);
+    if (math == 2 && bm == 256 && in_absmax) {
+        const size_t ldsa = 2 * (size_t)(256 + 16) * 64;
+        if (bn == 64) hipLaunchKernelGGL((window_conv_f16s_kernel<64, 256>), dim3(p.items), dim3(256), ldsa + 2 * 2 * 64 * 64, cpd_s(stream), p);
+        else hipLaunchKernelGGL((window_conv_f16s_kernel<16, 256>), dim3(p.items), dim3(256), ldsa + 2 * 16 * 64, cpd_s(stream), p);
+        return cpd_check_launch();
+    }
+    if (math == 2 && in_absmax) {
+        const size_t lds2 = 2 * (size_t)(128 + 16) * 64 + 2 * 2 * (size_t)bn * 64;
+        if (bn == 128) hipLaunchKernelGGL((window_conv_f16s_kernel<128>), dim3(p.items), dim3(256), lds2, cpd_s(stream), p);
+        else if (bn == 64) hipLaunchKernelGGL((window_conv_f16s_kernel<64>), dim3(p.items), dim3(256), lds2, cpd_s(stream), p);
+        else hipLaunchKernelGGL((window_conv_f16s_kernel<16>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
+        return cpd_check_launch();
+    }
     if (math == 2 && bm == 256) {
         const size_t ldsa = 2 * (size_t)(256 + 16) * 64;
         if (bn == 64) hipLaunchKernelGGL((window_conv_f16_kernel<64, 256>), dim3(p.items), dim3(256), ldsa + 2 * 2 * 64 * 64, cpd_s(stream), p);
@@ -1630,4 +1702,32 @@ extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, i
     else if (bn == 64) hipLaunchKernelGGL((window_conv_bf16_kernel<64>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
     else hipLaunchKernelGGL((window_conv_bf16_kernel<16>), dim3(p.items), dim3(256), lds, cpd_s(stream), p);
     return cpd_check_launch();
+}
+
+extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
+                               const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
+                               const float *residual, int res_ld, int relu, float *out, int out_ld,
+                               const int32_t *out_row_map, int out_col_group, int flags, cpd_stream_t stream) {
+    return gather_conv_impl(in, in_ld, n_in, c_in, packed_w, nbr, tapmask, kv, n_out, c_out, scale, shift, residual, res_ld, relu, out,
+                            out_ld, out_row_map, out_col_group, flags, nullptr, stream);
+}
+extern "C" int cpd_gather_conv_scaled(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
+                                      const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
+                                      const float *residual, int res_ld, int relu, float *out, int out_ld,
+                                      const int32_t *out_row_map, int out_col_group, int flags, const uint32_t *in_absmax,
+                                      cpd_stream_t stream) {
+    return gather_conv_impl(in, in_ld, n_in, c_in, packed_w, nbr, tapmask, kv, n_out, c_out, scale, shift, residual, res_ld, relu, out,
+                            out_ld, out_row_map, out_col_group, flags, in_absmax, stream);
+}
+extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
+                                const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
+                                int out_ld, int flags, cpd_stream_t stream) {
+    return conv3x3_rows_impl(in, in_ld, frames, h, w, c_in, packed_w, c_out, scale, shift, residual, res_ld, relu, out, out_ld, flags,
+                             nullptr, stream);
+}
+extern "C" int cpd_conv3x3_rows_scaled(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
+                                       const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
+                                       int out_ld, int flags, const uint32_t *in_absmax, cpd_stream_t stream) {
+    return conv3x3_rows_impl(in, in_ld, frames, h, w, c_in, packed_w, c_out, scale, shift, residual, res_ld, relu, out, out_ld, flags,
+                             in_absmax, stream);
 }

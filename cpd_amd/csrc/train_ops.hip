@@ -164,23 +164,66 @@ __global__ void __launch_bounds__(256) affine_rows_kernel(const float *__restric
 
 // dx = a * (dy_m - s1/n - xhat * s2/n), a = gamma*invstd ; dy_m = dy masked by (y > 0);
 // dres (optional) = dy_m, the gradient flowing into a residual input added before the ReLU.
+// V = 4: 16-byte accesses (c and every row pitch multiples of 4, 16-byte aligned bases), else V = 1. Grid-stride: a few
+// thousand workgroups however large the tensor, so the max |dx| word costs one atomic per workgroup at most.
+template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ y,
                                                            int ldy, const float *__restrict__ x, int ldx, int n, int c,
                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
                                                            const float *__restrict__ gamma, const float *__restrict__ s1,
                                                            const float *__restrict__ s2, float *__restrict__ dx, int lddx,
-                                                           float *__restrict__ dres, int lddres) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)n * c;
-    if (i >= total) return;
-    const int r = (int)(i / c), col = (int)(i - (long long)r * c);
-    float g = dy[(size_t)r * lddy + col];
-    if (y && !(y[(size_t)r * ldy + col] > 0.f)) g = 0.f;
-    if (dres) dres[(size_t)r * lddres + col] = g;
-    const float is = invstd[col];
-    const float xh = (x[(size_t)r * ldx + col] - mean[col]) * is;
+                                                           float *__restrict__ dres, int lddres, uint32_t *__restrict__ dx_absmax) {
+    const int cv = c / V;
+    const long long total = (long long)n * cv;
     const float inv_n = 1.0f / (float)n;
-    dx[(size_t)r * lddx + col] = gamma[col] * is * (g - s1[col] * inv_n - xh * s2[col] * inv_n);
+    float vmax = 0.f;
+    bool bad = false;                       // a NaN anywhere must reach the word (it switches the fp16 scaling off, loudly)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cv), col = (int)(i - (long long)r * cv) * V;
+        float g[V], yv[V], xv[V], o[V];
+        if (V == 4) {
+            *reinterpret_cast<f32x4 *>(g) = *reinterpret_cast<const f32x4 *>(dy + (size_t)r * lddy + col);
+            if (y) *reinterpret_cast<f32x4 *>(yv) = *reinterpret_cast<const f32x4 *>(y + (size_t)r * ldy + col);
+            *reinterpret_cast<f32x4 *>(xv) = *reinterpret_cast<const f32x4 *>(x + (size_t)r * ldx + col);
+        } else {
+            g[0] = dy[(size_t)r * lddy + col];
+            if (y) yv[0] = y[(size_t)r * ldy + col];
+            xv[0] = x[(size_t)r * ldx + col];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (y && !(yv[e] > 0.f)) g[e] = 0.f;
+            const float is = invstd[col + e];
+            const float xh = (xv[e] - mean[col + e]) * is;
+            o[e] = gamma[col + e] * is * (g[e] - s1[col + e] * inv_n - xh * s2[col + e] * inv_n);
+            vmax = fmaxf(vmax, fabsf(o[e]));
+            bad |= o[e] != o[e];
+        }
+        if (V == 4) {
+            if (dres) *reinterpret_cast<f32x4 *>(dres + (size_t)r * lddres + col) = *reinterpret_cast<const f32x4 *>(g);
+            *reinterpret_cast<f32x4 *>(dx + (size_t)r * lddx + col) = *reinterpret_cast<const f32x4 *>(o);
+        } else {
+            if (dres) dres[(size_t)r * lddres + col] = g[0];
+            dx[(size_t)r * lddx + col] = o[0];
+        }
+    }
+    // max |dx| of the whole tensor (bits of a non-negative float order like unsigned integers): the split-fp16 gradient
+    // kernels that consume dx scale it by a power of two derived from this word (cpd_gather_conv_scaled, cpd_conv_wgrad_scaled)
+    if (dx_absmax) {
+        __shared__ uint32_t wave_max[4];
+        uint32_t m = bad ? 0x7fc00000u : __float_as_uint(vmax);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+            m = t > m ? t : m;
+        }
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+            if (m > *reinterpret_cast<volatile uint32_t *>(dx_absmax)) atomicMax(dx_absmax, m);
+        }
+    }
 }
 
 // ReLU backward for layers without BatchNorm in between: dx = dy * (y > 0)
@@ -206,6 +249,7 @@ struct WgParams {
     float *part;
     int in_ld, dy_ld, c_in, c_out, kv, n_out;
     int rows_per_chunk, n_chunks, ci_tiles, co_tiles;
+    const uint32_t *in_absmax, *dy_absmax;   // split-fp16 kernel only (or NULL): bits of max |in| / max |dy|, see in_pow2_scale
 };
 
 template <int VA, int VB>
@@ -383,51 +427,96 @@ __global__ void __launch_bounds__(256) wgrad_tile_kernel(WgParams p) {
 // pairs at a time, so a sparse layer spends MFMAs on existing pairs only.
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wf16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void wsplit3(const f32x4 &x, wbf16x4 &h, wbf16x4 &m, wbf16x4 &l) {
-    h = __builtin_convertvector(x, wbf16x4);
-    const f32x4 r1 = x - __builtin_convertvector(h, f32x4);
-    m = __builtin_convertvector(r1, wbf16x4);
-    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
-    l = __builtin_convertvector(r2, wbf16x4);
-}
+// x = h + m + l exactly (three bf16 terms), six products
+struct WSplitBf16x3 {
+    static constexpr int NP = 3;
+    typedef wbf16x4 q4;
+    typedef wbf16x8 q8;
+    static __device__ __forceinline__ void split(const f32x4 &x, q4 (&p)[NP]) {
+        p[0] = __builtin_convertvector(x, wbf16x4);
+        const f32x4 r1 = x - __builtin_convertvector(p[0], f32x4);
+        p[1] = __builtin_convertvector(r1, wbf16x4);
+        const f32x4 r2 = r1 - __builtin_convertvector(p[1], f32x4);
+        p[2] = __builtin_convertvector(r2, wbf16x4);
+    }
+    static __device__ __forceinline__ f32x4 mma(const q8 (&a)[NP], const q8 (&b)[NP], f32x4 c) {   // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+// x = h + l (two fp16 terms: 2^-24 relative, 2^-25 absolute below 0.5), three products -- the operands are pre-scaled into
+// fp16's range by a power of two (WgParams::in_absmax / dy_absmax), undone exactly on the partial sums
+struct WSplitF16x2 {
+    static constexpr int NP = 2;
+    typedef wf16x4 q4;
+    typedef wf16x8 q8;
+    static __device__ __forceinline__ void split(const f32x4 &x, q4 (&p)[NP]) {
+        p[0] = __builtin_convertvector(x, wf16x4);
+        const f32x4 r1 = x - __builtin_convertvector(p[0], f32x4);
+        p[1] = __builtin_convertvector(r1, wf16x4);
+    }
+    static __device__ __forceinline__ f32x4 mma(const q8 (&a)[NP], const q8 (&b)[NP], f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
 
-// R rows (4, 8 or 16) of one channel -> the three piece images; `slot` = byte offset of k-group k0/8, channel ch
-template <int R, int IMG>
-__device__ __forceinline__ void wgrad_put(char *img, int slot, int k0, const float (&v)[R]) {
-    if constexpr (R == 4) {
-        wbf16x4 h, m, l;
-        wsplit3(f32x4{v[0], v[1], v[2], v[3]}, h, m, l);
-        char *dst = img + slot + ((k0 >> 2) & 1) * 8;
-        *reinterpret_cast<wbf16x4 *>(dst) = h;
-        *reinterpret_cast<wbf16x4 *>(dst + IMG) = m;
-        *reinterpret_cast<wbf16x4 *>(dst + 2 * IMG) = l;
-    } else {
-#pragma unroll
-        for (int q = 0; q < R / 8; ++q) {
-            wbf16x4 h0, m0, l0, h1, m1, l1;
-            wsplit3(f32x4{v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3]}, h0, m0, l0);
-            wsplit3(f32x4{v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]}, h1, m1, l1);
-            char *dst = img + slot + q * (IMG / 4);          // next k-group: T channels x 16 B further
-            *reinterpret_cast<wbf16x8 *>(dst) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-            *reinterpret_cast<wbf16x8 *>(dst + IMG) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-            *reinterpret_cast<wbf16x8 *>(dst + 2 * IMG) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+// Power-of-two pre-scale for the fp16 split (same rule as gather_conv.hip): s = 2^(14 - floor(log2 max|x|)), inv = 1 / s
+__device__ __forceinline__ void in_pow2_scale(const uint32_t *absmax, float &s, float &inv) {
+    s = 1.f; inv = 1.f;
+    if (absmax) {
+        const int e = (int)((*absmax >> 23) & 0xffu);
+        if (e != 0 && e != 255) {
+            int se = 268 - e;
+            se = se < 1 ? 1 : (se > 253 ? 253 : se);
+            s = __uint_as_float((uint32_t)se << 23);
+            inv = __uint_as_float((uint32_t)(254 - se) << 23);
         }
     }
 }
 
-template <int TM, int TN>
-__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgParams p) {
-    constexpr int KB = 32;                               // pairs per stage = K of one bf16 MFMA
+// R rows (4, 8 or 16) of one channel -> the piece images; `slot` = byte offset of k-group k0/8, channel ch
+template <class S, int R, int IMG>
+__device__ __forceinline__ void wgrad_put(char *img, int slot, int k0, const float (&v)[R], float scale) {
+    if constexpr (R == 4) {
+        typename S::q4 pc[S::NP];
+        S::split(f32x4{v[0], v[1], v[2], v[3]} * scale, pc);
+        char *dst = img + slot + ((k0 >> 2) & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < S::NP; ++q) *reinterpret_cast<typename S::q4 *>(dst + q * IMG) = pc[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < R / 8; ++q) {
+            typename S::q4 p0[S::NP], p1[S::NP];
+            S::split(f32x4{v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3]} * scale, p0);
+            S::split(f32x4{v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]} * scale, p1);
+            char *dst = img + slot + q * (IMG / 4);          // next k-group: T channels x 16 B further
+#pragma unroll
+            for (int w = 0; w < S::NP; ++w)
+                *reinterpret_cast<typename S::q8 *>(dst + w * IMG) = __builtin_shufflevector(p0[w], p1[w], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+}
+
+template <class S, int TM, int TN>
+__device__ __forceinline__ void wgrad_split_body(const WgParams &p, char *const sA, char *const sB, int *const ringJ, int *const ringI,
+                                                 int *const wave_cnt) {
+    constexpr int NP = S::NP;
+    constexpr int KB = 32;                               // pairs per stage = K of one MFMA
     constexpr int RING = 512;                            // >= KB - 1 + 256 pairs
     constexpr int RA = TM / 8, RB = TN / 8;              // rows of a stage one thread stages per side
     constexpr int A_IMG = TM * 64, B_IMG = TN * 64;      // bytes of one piece image: 4 k-groups x T channels x 16 B
     constexpr int MS = TM / 32, NT = TN / 32;            // 2 x 2 waves, wave tile (TM/2) x (TN/2)
-    __shared__ __attribute__((aligned(16))) char sA[3 * A_IMG];
-    __shared__ __attribute__((aligned(16))) char sB[3 * B_IMG];
-    __shared__ __attribute__((aligned(16))) int ringJ[RING];
-    __shared__ __attribute__((aligned(16))) int ringI[RING];
-    __shared__ int wave_cnt[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -441,6 +530,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgParams p) {
     const float *a_base = p.in + ci0 + a_ch;
     const float *b_base = p.dy + co0 + b_ch;
     const int32_t *nbr_t = p.nbr ? p.nbr + (size_t)t * p.n_out : nullptr;
+    float sa_ = 1.f, ia_ = 1.f, sb_ = 1.f, ib_ = 1.f;
+    if (NP == 2) { in_pow2_scale(p.in_absmax, sa_, ia_); in_pow2_scale(p.dy_absmax, sb_, ib_); }
 
     f32x4 acc[MS][NT];
 #pragma unroll
@@ -450,31 +541,21 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgParams p) {
 
     auto nbr_of = [&](int j) { return j < r1 ? (nbr_t ? nbr_t[j] : j) : -1; };
     auto mma = [&]() {
-        wbf16x8 ah[MS], am[MS], al[MS];
+        typename S::q8 a[MS][NP];
 #pragma unroll
         for (int s = 0; s < MS; ++s) {
             const char *src = sA + ((g * TM + wm * (TM / 2) + 16 * s + r) << 4);
-            ah[s] = *reinterpret_cast<const wbf16x8 *>(src);
-            am[s] = *reinterpret_cast<const wbf16x8 *>(src + A_IMG);
-            al[s] = *reinterpret_cast<const wbf16x8 *>(src + 2 * A_IMG);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) a[s][q] = *reinterpret_cast<const typename S::q8 *>(src + q * A_IMG);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const char *src = sB + ((g * TN + wn * (TN / 2) + 16 * nt + r) << 4);
-            const wbf16x8 bh = *reinterpret_cast<const wbf16x8 *>(src);
-            const wbf16x8 bm = *reinterpret_cast<const wbf16x8 *>(src + B_IMG);
-            const wbf16x8 bl = *reinterpret_cast<const wbf16x8 *>(src + 2 * B_IMG);
+            typename S::q8 b[NP];
 #pragma unroll
-            for (int s = 0; s < MS; ++s) {          // smallest terms first
-                f32x4 c = acc[s][nt];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[s], bh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, c, 0, 0, 0);
-                acc[s][nt] = c;
-            }
+            for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::q8 *>(src + q * B_IMG);
+#pragma unroll
+            for (int s = 0; s < MS; ++s) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
         }
     };
 
@@ -532,14 +613,15 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgParams p) {
             mma();
             __syncthreads();               // everyone is done reading the images before they are overwritten
         }
-        wgrad_put<RA, A_IMG>(sA, a_slot, a_k0, va);
-        wgrad_put<RB, B_IMG>(sB, b_slot, b_k0, vb);
+        wgrad_put<S, RA, A_IMG>(sA, a_slot, a_k0, va, sa_);
+        wgrad_put<S, RB, B_IMG>(sB, b_slot, b_k0, vb, sb_);
         __syncthreads();
         have = true;
     }
     if (have) mma();
 
     // D[i][j]: i = 4g+e <-> channel ci0 + wm*TM/2 + 16s + i ; j = r <-> column co0 + wn*TN/2 + 16nt + j
+    const float undo = ia_ * ib_;          // exact: powers of two
     float *out = p.part + ((size_t)blockIdx.z * p.kv + t) * p.c_in * p.c_out;
 #pragma unroll
     for (int s = 0; s < MS; ++s)
@@ -548,8 +630,27 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ci = ci0 + wm * (TM / 2) + 16 * s + 4 * g + e, co = co0 + wn * (TN / 2) + 16 * nt + r;
-                out[(size_t)ci * p.c_out + co] = acc[s][nt][e];
+                out[(size_t)ci * p.c_out + co] = acc[s][nt][e] * undo;
             }
+}
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgParams p) {
+    __shared__ __attribute__((aligned(16))) char sA[3 * TM * 64];
+    __shared__ __attribute__((aligned(16))) char sB[3 * TN * 64];
+    __shared__ __attribute__((aligned(16))) int ringJ[512];
+    __shared__ __attribute__((aligned(16))) int ringI[512];
+    __shared__ int wave_cnt[4];
+    wgrad_split_body<WSplitBf16x3, TM, TN>(p, sA, sB, ringJ, ringI, wave_cnt);
+}
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) wgrad_f16_kernel(WgParams p) {
+    __shared__ __attribute__((aligned(16))) char sA[2 * TM * 64];
+    __shared__ __attribute__((aligned(16))) char sB[2 * TN * 64];
+    __shared__ __attribute__((aligned(16))) int ringJ[512];
+    __shared__ __attribute__((aligned(16))) int ringI[512];
+    __shared__ int wave_cnt[4];
+    wgrad_split_body<WSplitF16x2, TM, TN>(p, sA, sB, ringJ, ringI, wave_cnt);
 }
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int n_chunks, size_t elems,
@@ -1055,10 +1156,17 @@ extern "C" int cpd_affine_rows(const float *x, int ldx, int n, int c, const floa
 }
 extern "C" int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, int n, int c,
                                 const float *mean, const float *invstd, const float *gamma, const float *dbeta,
-                                const float *dgamma, float *dx, int lddx, float *dres, int lddres, cpd_stream_t st) {
+                                const float *dgamma, float *dx, int lddx, float *dres, int lddres, uint32_t *dx_absmax,
+                                cpd_stream_t st) {
     if (!dy || !x || !mean || !invstd || !gamma || !dbeta || !dgamma || !dx || n <= 0 || c <= 0) return CPD_ERR_ARG;
-    bn_bwd_apply_kernel<<<cpd_div_up((long long)n * c, 256), 256, 0, cpd_s(st)>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd,
-                                                                                 gamma, dbeta, dgamma, dx, lddx, dres, lddres);
+    const bool vec = c % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y || ldy % 4 == 0) && (!dres || lddres % 4 == 0) &&
+                     ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15) == 0;
+    const long long items = (long long)n * (vec ? c / 4 : c);
+    const int blocks = (int)std::min<long long>(cpd_div_up(items, 256), 4096);
+    if (vec) bn_bwd_apply_kernel<4><<<blocks, 256, 0, cpd_s(st)>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, dbeta, dgamma, dx, lddx,
+                                                                  dres, lddres, dx_absmax);
+    else bn_bwd_apply_kernel<1><<<blocks, 256, 0, cpd_s(st)>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, dbeta, dgamma, dx, lddx,
+                                                              dres, lddres, dx_absmax);
     return cpd_check_launch();
 }
 extern "C" int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, int n, int c, float *dx, int lddx,
@@ -1093,7 +1201,7 @@ static bool wgrad_tile_plan(int n_out, int c_in, int c_out, int kv, WgParams *p,
 // split-bf16 kernel: whole 32-channel tiles on both sides
 static int wgrad_bf16_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
 static bool wgrad_bf16_plan(int n_out, int c_in, int c_out, int kv, int flags, WgParams *p, int *tm, int *tn) {
-    int on = (flags & 2) != 0;
+    int on = (flags & (2 | 4)) != 0;
     if (const char *e = cpd_knob(cpd_tuning(), "CPD_WGRAD_BF16X3")) on = atoi(e);
     if (!on || c_in % 32 || c_out % 32) return false;
     *tm = wgrad_bf16_tile(c_in);
@@ -1138,21 +1246,32 @@ static void launch_wgrad_bf16(int tn, dim3 grid, hipStream_t s, const WgParams &
     else if (tn == 64) wgrad_bf16_kernel<TM, 64><<<grid, 256, 0, s>>>(p);
     else wgrad_bf16_kernel<TM, 32><<<grid, 256, 0, s>>>(p);
 }
+template <int TM>
+static void launch_wgrad_f16(int tn, dim3 grid, hipStream_t s, const WgParams &p) {
+    if (tn == 128) wgrad_f16_kernel<TM, 128><<<grid, 256, 0, s>>>(p);
+    else if (tn == 64) wgrad_f16_kernel<TM, 64><<<grid, 256, 0, s>>>(p);
+    else wgrad_f16_kernel<TM, 32><<<grid, 256, 0, s>>>(p);
+}
 
-extern "C" int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out, const int32_t *nbr,
-                              int kv, int n_out, float *dw_kio, int flags, void *ws, size_t ws_bytes, cpd_stream_t st) {
+static int conv_wgrad_impl(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out, const int32_t *nbr,
+                           int kv, int n_out, float *dw_kio, int flags, const uint32_t *in_absmax, const uint32_t *dy_absmax,
+                           void *ws, size_t ws_bytes, cpd_stream_t st) {
     if (!in || !dy || !dw_kio || !ws || n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || (!nbr && kv != 1)) return CPD_ERR_ARG;
     const int accumulate = flags & 1;
     WgParams p;
     int va, vb, tm, tn;
-    p.in = in; p.dy = dy; p.nbr = nbr; p.part = (float *)ws;
+    p.in = in; p.dy = dy; p.nbr = nbr; p.part = (float *)ws; p.in_absmax = in_absmax; p.dy_absmax = dy_absmax;
     p.in_ld = in_ld; p.dy_ld = dy_ld; p.c_in = c_in; p.c_out = c_out; p.kv = kv; p.n_out = n_out;
     const size_t elems = (size_t)kv * c_in * c_out;
     if (wgrad_bf16_plan(n_out, c_in, c_out, kv, flags, &p, &tm, &tn)) {
         if (ws_bytes < (size_t)p.n_chunks * elems * sizeof(float)) return CPD_ERR_WORKSPACE;
         if (p.n_chunks >= 65536 || kv >= 65536) return CPD_ERR_UNSUPPORTED;
         const dim3 grid(p.ci_tiles * p.co_tiles, kv, p.n_chunks);
-        if (tm == 128) launch_wgrad_bf16<128>(tn, grid, cpd_s(st), p);
+        if (flags & 4) {
+            if (tm == 128) launch_wgrad_f16<128>(tn, grid, cpd_s(st), p);
+            else if (tm == 64) launch_wgrad_f16<64>(tn, grid, cpd_s(st), p);
+            else launch_wgrad_f16<32>(tn, grid, cpd_s(st), p);
+        } else if (tm == 128) launch_wgrad_bf16<128>(tn, grid, cpd_s(st), p);
         else if (tm == 64) launch_wgrad_bf16<64>(tn, grid, cpd_s(st), p);
         else launch_wgrad_bf16<32>(tn, grid, cpd_s(st), p);
         wgrad_reduce_kernel<<<cpd_div_up((long long)elems, 256), 256, 0, cpd_s(st)>>>(p.part, p.n_chunks, elems, dw_kio, accumulate);
@@ -1183,6 +1302,16 @@ extern "C" int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float 
     }
     wgrad_reduce_kernel<<<cpd_div_up((long long)elems, 256), 256, 0, cpd_s(st)>>>(p.part, p.n_chunks, elems, dw_kio, accumulate);
     return cpd_check_launch();
+}
+
+extern "C" int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out, const int32_t *nbr,
+                              int kv, int n_out, float *dw_kio, int flags, void *ws, size_t ws_bytes, cpd_stream_t st) {
+    return conv_wgrad_impl(in, in_ld, c_in, dy, dy_ld, c_out, nbr, kv, n_out, dw_kio, flags, nullptr, nullptr, ws, ws_bytes, st);
+}
+extern "C" int cpd_conv_wgrad_scaled(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out, const int32_t *nbr,
+                                     int kv, int n_out, float *dw_kio, int flags, const uint32_t *in_absmax, const uint32_t *dy_absmax,
+                                     void *ws, size_t ws_bytes, cpd_stream_t st) {
+    return conv_wgrad_impl(in, in_ld, c_in, dy, dy_ld, c_out, nbr, kv, n_out, dw_kio, flags, in_absmax, dy_absmax, ws, ws_bytes, st);
 }
 
 extern "C" int cpd_rulebook_conv_transpose(const int32_t *in_indices, int n_in, int batch, const int32_t in_shape[3],

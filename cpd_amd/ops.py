@@ -248,10 +248,12 @@ def _gc_flags(dense, bf16x3, math):
 
 
 def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=None, residual=None, relu=False,
-                out=None, out_row_map=None, out_col_group=0, dense=False, bf16x3=False, math=None):
+                out=None, out_row_map=None, out_col_group=0, dense=False, bf16x3=False, math=None, in_absmax=None):
     """out[j,:c_out] = act((sum_t in[nbr[t][j]] . W[t]) * scale + shift + residual[j]).
     `inp` / `out` / `residual` are 2-D row tensors whose row stride may exceed the channel count.
-    `math`: "f32" | "bf16x3" | "f16x2" (overrides the older `bf16x3` switch)."""
+    `math`: "f32" | "bf16x3" | "f16x2" (overrides the older `bf16x3` switch).
+    `in_absmax`: one-element int32 device tensor holding the bits of max |inp| (train_ops.bn_backward fills it): the
+    split-fp16 kernels then pre-scale `inp` into fp16's range by a power of two -- how gradients take that path."""
     _need_cuda(inp, "inp")
     assert inp.dim() == 2 and inp.stride(1) == 1
     if out is None:
@@ -264,19 +266,19 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     flags = _gc_flags(dense, bf16x3, math)
     image = getattr(nbr, "image", None)             # 3x3 / stride 1 / pad 1 pixel table: the rulebook-free window kernel
     if image is not None and out_row_map is None and kv == 9 and n_out == image[0] * image[1] * image[2] and inp.shape[0] == n_out:
-        rc = lib().cpd_conv3x3_rows(
+        rc = lib().cpd_conv3x3_rows_scaled(
             ctypes.c_void_p(inp.data_ptr()), inp.stride(0), image[0], image[1], image[2], c_in, ptr(packed_w), c_out,
             ptr(scale), ptr(shift), ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld,
-            int(bool(relu)), ctypes.c_void_p(out.data_ptr()), out.stride(0), flags, stream())
+            int(bool(relu)), ctypes.c_void_p(out.data_ptr()), out.stride(0), flags, ptr(in_absmax), stream())
         if rc != -4:                                # CPD_ERR_UNSUPPORTED: shape / alignment / size -> the table path below
             check(rc, "cpd_conv3x3_rows")
             return out
-    check(lib().cpd_gather_conv(
+    check(lib().cpd_gather_conv_scaled(
         ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w),
         ptr(nbr), ptr(getattr(nbr, "tapmask", None)), kv, n_out, c_out, ptr(scale), ptr(shift),
         ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
         ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), flags,
-        stream()),
+        ptr(in_absmax), stream()),
         "cpd_gather_conv")
     return out
 

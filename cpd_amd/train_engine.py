@@ -34,11 +34,18 @@ class _Flat:
         self.slots = {}
         self.flat = self.grad = self.m = self.v = None
         self.math = "f16x2"     # forward conv arithmetic of layers with >= 32 input channels (ModelConfig.conv_math)
-        # gradients span many orders of magnitude (1e-3 ... 1e-8), below fp16's normal range, so everything that consumes dz --
-        # the input gradient (cpd_gather_conv on the adjoint weights) and the weight gradient -- runs split-bf16, whose split
-        # is exact at any magnitude, whenever a split arithmetic is selected
-        self.dgrad_math = "bf16x3"
+        # gradients span many orders of magnitude (1e-3 ... 1e-8), below fp16's normal range. Everything that consumes dz -- the
+        # input gradient (cpd_gather_conv on the adjoint weights) and the weight gradient -- therefore either runs split-bf16
+        # (exact split at any magnitude, six products), or -- grad_math "f16x2" -- split-fp16 (three products) with dz
+        # PRE-SCALED by a power of two: the BatchNorm backward that produces dz also leaves the bits of max |dz| in a device
+        # word (`absmax`, one slot per layer, zeroed at the start of every backward pass) and the consuming kernels derive
+        # the scale from it (cpd_gather_conv_scaled / cpd_conv_wgrad_scaled). Layers whose dz does not come out of a
+        # BatchNorm backward (the head's output convs, <= 3 channels) are not split-arithmetic layers anyway.
+        self.grad_math = "f16x2"
+        self.dgrad_math = "bf16x3"      # arithmetic of gradient convs WITHOUT an absmax word
         self.bf16x3 = True
+        self.n_absmax = 0
+        self.absmax = None
         self.update_stats = True    # whether the current forward updates the BatchNorm running statistics
         self.side = None        # HIP stream for the weight gradients (independent of the input gradients of the same layer)
 
@@ -84,6 +91,7 @@ class _Flat:
         for name, t in self._pending:
             self.p(name).copy_(t)
         self.grad = torch.zeros_like(self.flat)
+        self.absmax = torch.zeros(max(self.n_absmax, 1), dtype=torch.int32, device=device)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self._pending = None
@@ -124,6 +132,8 @@ class _Conv:
             self.running_mean = bn["running_mean"].clone().float()
             self.running_var = bn["running_var"].clone().float()
         self.c_bn = self.c_out // (up * up)                # channels after the column-group scatter
+        self.am_slot = store.n_absmax                      # this layer's max |dz| word (see _Flat.grad_math)
+        store.n_absmax += 1
         self.pw = self.pw_adj = None
         self.saved = None
 
@@ -176,9 +186,14 @@ class _Conv:
         x, nbr, n_out, z, y, mean, invstd, has_res, dense, up_map = self.saved
         self.saved = None
         dres = None
+        am = None                                 # device word with the bits of max |dz|: the gradient convs may run split-fp16
+        gmath, wmath = st.dgrad_math, ("bf16x3" if st.bf16x3 else "f32")
         if self.has_bn:
+            if st.grad_math == "f16x2" and st.math != "f32":
+                am = st.absmax[self.am_slot:self.am_slot + 1]
+                gmath = wmath = "f16x2"
             dz, _, _, dres = train_ops.bn_backward(dy, y if self.relu else None, z, mean, invstd, st.p(self.gn),
-                                                   want_dres=has_res, dgamma=st.g(self.gn), dbeta=st.g(self.be))
+                                                   want_dres=has_res, dgamma=st.g(self.gn), dbeta=st.g(self.be), dx_absmax=am)
         else:
             dz = train_ops.relu_backward(dy, y) if self.relu else dy
         if self.bn_:
@@ -188,13 +203,13 @@ class _Conv:
             u2 = self.up * self.up
             # dW[tap][co][ci] = sum_pix dz_up[map[tap][pix]][co] * x[pix][ci]  (roles of in/dy swapped)
             def wgrad_up():
-                tmp = train_ops.conv_wgrad(dz, self.c_bn, x, self.c_in, up_map, u2, n_out, bf16x3=self.store.bf16x3)
+                tmp = train_ops.conv_wgrad(dz, self.c_bn, x, self.c_in, up_map, u2, n_out, math=wmath, in_absmax=am)
                 gw.view(self.c_in, u2, self.c_bn).copy_(tmp.permute(2, 0, 1))
             ready = st.mark()                   # dz is complete here; the input gradient is ISSUED first (it is on the
             dx = None                           # critical path), the weight gradient after it but ordered on `ready`
             if need_dx:
                 dx = ops.gather_conv(dz, self.c_bn, self.pw_adj, up_map, u2, n_out, self.c_in, None, None, add, False,
-                                     out=dx_out, dense=dense, math=self.store.dgrad_math)
+                                     out=dx_out, dense=dense, math=gmath, in_absmax=am)
             st.on_side(wgrad_up, dz, x, after=ready)
             return dx, dres
         if nbr is None:                                       # 1x1 conv: identity rulebook for the weight gradient
@@ -207,8 +222,8 @@ class _Conv:
         dx = None
         if need_dx:
             dx = ops.gather_conv(dz, self.c_out, self.pw_adj, nbr_adj, self.kv, n_in, self.c_in, None, None, add, False,
-                                 out=dx_out, dense=dense, math=self.store.dgrad_math)
-        st.on_side(lambda: train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, bf16x3=self.store.bf16x3),
+                                 out=dx_out, dense=dense, math=gmath, in_absmax=am)
+        st.on_side(lambda: train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, math=wmath, dy_absmax=am),
                    x, dz, nbr_w, after=ready)
         return dx, dres
 
@@ -251,6 +266,7 @@ class CenterPointTrainer:
         self.store.math = cfg.conv_math
         self.store.dgrad_math = "f32" if cfg.conv_math == "f32" else "bf16x3"
         self.store.bf16x3 = cfg.conv_math != "f32"
+        self.store.grad_math = os.environ.get("CPD_TRAIN_GRAD_MATH", "f16x2" if cfg.conv_math == "f16x2" else "bf16x3")
         if self.device.type == "cuda" and os.environ.get("CPD_TRAIN_SIDE_STREAM", "1") != "0":
             self.store.side = torch.cuda.Stream(device=self.device)
         self._voxelizers = []
@@ -491,6 +507,7 @@ class CenterPointTrainer:
         cfg, S, tp = self.cfg, self.sparse, self.tape
         s1, n_full = tp["s1"], tp["n_full"]
         sc = cfg.shared_conv_channel
+        self.store.absmax.zero_()                               # the layers' max |dz| words (raised by their BatchNorm backward)
         d_h1 = torch.empty((n_full, tp["h1_cols"]), dtype=torch.float32, device=self.device)
         for c, in_col, out_col in self.head2:
             c.backward(d_rows[:, out_col:out_col + c.c_out], s1, n_full, dx_out=d_h1[:, in_col:in_col + sc])

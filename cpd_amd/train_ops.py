@@ -87,9 +87,10 @@ def affine_rows(x, scale=None, shift=None, residual=None, relu=False, out=None):
     return out
 
 
-def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False, dgamma=None, dbeta=None):
+def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False, dgamma=None, dbeta=None, dx_absmax=None):
     """BatchNorm(+ReLU when y is given) backward. Returns (dx, dgamma, dbeta, dres|None);
-    dgamma / dbeta may be caller-provided (views of a flat gradient buffer)."""
+    dgamma / dbeta may be caller-provided (views of a flat gradient buffer). `dx_absmax`: a ZEROED one-element int32 device
+    tensor that receives the bits of max |dx| (for the split-fp16 gradient convolutions)."""
     n, c = x.shape
     dev = x.device
     if dbeta is None:
@@ -103,7 +104,7 @@ def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False, dgamma=None, dbe
     dres = torch.empty((n, c), dtype=torch.float32, device=dev) if want_dres else None
     check(lib().cpd_bn_bwd_apply(_p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(x), _ld(x), n, c, ptr(mean),
                                  ptr(invstd), ptr(gamma), ptr(dbeta), ptr(dgamma), _p(dx), _ld(dx), _p(dres),
-                                 _ld(dres) if dres is not None else 0, stream()), "cpd_bn_bwd_apply")
+                                 _ld(dres) if dres is not None else 0, ptr(dx_absmax), stream()), "cpd_bn_bwd_apply")
     return dx, dgamma, dbeta, dres
 
 
@@ -114,14 +115,20 @@ def relu_backward(dy, y):
     return dx
 
 
-def conv_wgrad(inp, c_in, dy, c_out, nbr, kv, n_out, dw=None, accumulate=False, bf16x3=False):
-    """dw[kv, c_in, c_out] (+)= sum_j inp[nbr[t][j]]^T dy[j]; bf16x3: split-bf16 arithmetic (fp32-equivalent)."""
+def conv_wgrad(inp, c_in, dy, c_out, nbr, kv, n_out, dw=None, accumulate=False, bf16x3=False, math=None, in_absmax=None,
+               dy_absmax=None):
+    """dw[kv, c_in, c_out] (+)= sum_j inp[nbr[t][j]]^T dy[j]; bf16x3: split-bf16 arithmetic (fp32-equivalent).
+    math = "f16x2": split-fp16 (half the matrix work); an operand that is a gradient then needs its `*_absmax` word
+    (bits of its max |value|, see bn_backward) so that the kernel can bring it into fp16's range."""
+    if math is not None:
+        bf16x3 = math == "bf16x3"
     if dw is None:
         dw = torch.empty((kv, c_in, c_out), dtype=torch.float32, device=inp.device)
         accumulate = False
     ws = _ws(lib().cpd_conv_wgrad_workspace_bytes(n_out, c_in, c_out, kv), inp.device)
-    check(lib().cpd_conv_wgrad(_p(inp), _ld(inp), c_in, _p(dy), _ld(dy), c_out, ptr(nbr), kv, n_out, ptr(dw),
-                               int(bool(accumulate)) | (2 if bf16x3 else 0), ptr(ws), ws.numel(), stream()), "cpd_conv_wgrad")
+    check(lib().cpd_conv_wgrad_scaled(_p(inp), _ld(inp), c_in, _p(dy), _ld(dy), c_out, ptr(nbr), kv, n_out, ptr(dw),
+                               int(bool(accumulate)) | (2 if bf16x3 else 0) | (4 if math == "f16x2" else 0), ptr(in_absmax),
+                                      ptr(dy_absmax), ptr(ws), ws.numel(), stream()), "cpd_conv_wgrad")
     return dw
 
 

@@ -328,7 +328,9 @@ int cpd_bn_bwd_reduce(const float *dy, int lddy, const float *y, int ldy, const 
 int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx,
                      int n, int c, const float *mean, const float *invstd, const float *gamma,
                      const float *dbeta, const float *dgamma, float *dx, int lddx, float *dres,
-                     int lddres, cpd_stream_t stream);
+                     int lddres, uint32_t *dx_absmax, cpd_stream_t stream);
+/* dx_absmax (optional): a device word the kernel raises (atomic max; the caller zeroes it beforehand) to the bits of
+ * max |dx| -- what cpd_gather_conv_scaled / cpd_conv_wgrad_scaled need to run a gradient through the split-fp16 path. */
 int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, int n, int c, float *dx,
                  int lddx, cpd_stream_t stream);
 /* Weight gradient of cpd_gather_conv: dw[t][ci][co] (+)= sum_j in[nbr[t][j]][ci] * dy[j][co]
@@ -340,6 +342,26 @@ size_t cpd_conv_wgrad_workspace_bytes(int n_out, int c_in, int c_out, int kv);
 int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out,
                    const int32_t *nbr, int kv, int n_out, float *dw_kio, int flags, void *ws,
                    size_t ws_bytes, cpd_stream_t stream);
+/* The same with flags CPD_GC_F16X2 allowed: split-fp16 arithmetic (three products instead of six). Gradients do not live in
+ * fp16's range, so each operand may come with a device word holding the bits of its max |value| (in_absmax for `in`,
+ * dy_absmax for `dy`; NULL = use as is): the kernel multiplies the operand by the power of two that puts that maximum at
+ * [2^14, 2^15) before splitting and divides the partial sums by it again -- exact, and an element 2^-18 of the maximum or
+ * larger keeps its full 2^-24 relative precision (smaller ones 2^-43 of the maximum absolute). */
+int cpd_conv_wgrad_scaled(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out,
+                          const int32_t *nbr, int kv, int n_out, float *dw_kio, int flags,
+                          const uint32_t *in_absmax, const uint32_t *dy_absmax, void *ws, size_t ws_bytes,
+                          cpd_stream_t stream);
+/* Input-gradient convolutions through the split-fp16 kernels: cpd_gather_conv / cpd_conv3x3_rows with `in` pre-scaled the
+ * same way (in_absmax as above; ignored by the fp32 and split-bf16 kernels, which need no range help). */
+int cpd_gather_conv_scaled(const float *in, int in_ld, int n_in, int c_in, const float *packed_w,
+                           const int32_t *nbr, const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale,
+                           const float *shift, const float *residual, int res_ld, int relu, float *out,
+                           int out_ld, const int32_t *out_row_map, int out_col_group, int flags,
+                           const uint32_t *in_absmax, cpd_stream_t stream);
+int cpd_conv3x3_rows_scaled(const float *in, int in_ld, int frames, int h, int w, int c_in,
+                            const float *packed_w, int c_out, const float *scale, const float *shift,
+                            const float *residual, int res_ld, int relu, float *out, int out_ld, int flags,
+                            const uint32_t *in_absmax, cpd_stream_t stream);
 /* Packed weights of the adjoint conv used for input gradients: Wd[t'][co][ci] = W[t][ci][co],
  * t = kv-1-t' if flip_taps (SubM / stride-1: the forward rulebook is its own transpose up to the
  * tap flip) else t = t' (use with a transposed rulebook). Size: cpd_packed_weight_floats(kv, c_out, c_in). */

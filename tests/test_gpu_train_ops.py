@@ -325,3 +325,94 @@ def test_fused_center_loss_matches_the_torch_restatement(hip, batch, n_obj):
         nan_want, _ = center_loss.center_head_loss(rows, batch, h, w, heat, tgt, inds, masks, nc, hm_col=hm_col, code_weights=cw)
         nan_got, _ = T.center_loss(rows, batch, h * w, nc, hm_col, heat, tgt, inds, masks, cw)
         assert torch.isnan(nan_want) and torch.isnan(nan_got[0]) and torch.isnan(nan_got[2]) and not torch.isnan(nan_got[1])
+
+
+def _absmax_word(t):
+    """What cpd_bn_bwd_apply leaves behind for its dx: the bits of max |t| in a one-element int32 device tensor."""
+    return t.abs().max().reshape(1).contiguous().view(torch.int32)
+
+
+@pytest.mark.parametrize("mag", [1e-12, 1e-7, 1e-3, 1.0, 1e4])
+def test_scaled_split_fp16_gradient_convs(oracle, hip, monkeypatch, mag):
+    """Gradients through the split-fp16 kernels (cpd_gather_conv_scaled / cpd_conv3x3_rows_scaled / cpd_conv_wgrad_scaled):
+    dz of ANY magnitude -- far below fp16's range here -- pre-scaled by the power of two derived from its max |dz| word.
+    Input gradient (row-wave, tile and window kernels) and weight gradient against float64, to the accuracy of the
+    split-bf16 kernels they replace in the train step."""
+    monkeypatch.setenv("CPD_TUNE", "1")
+    monkeypatch.setenv("CPD_GC_BF16_MIN", "1")
+    monkeypatch.setenv("CPD_GC_BF16_MIN64", "1")
+    rng = np.random.default_rng(7)
+    # --- sparse: SubM 64 -> 64 over clustered sites
+    batch, shape, cin, cout = 2, [9, 48, 48], 64, 64
+    idx = random_sites(rng, batch, shape, 9000)
+    n = idx.shape[0]
+    d_idx = dev(idx)
+    nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
+    x = (rng.normal(size=(n, cin)) * np.exp(rng.normal(size=(n, 1)))).astype(np.float32)
+    dz = (rng.normal(size=(n, cout)) * np.exp(rng.normal(size=(n, 1)) * 2) * mag).astype(np.float32)    # wide dynamic range
+    w = (rng.normal(size=(27, cin, cout)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    d_x, d_dz, d_w = dev(x), dev(dz), dev(w)
+    am = _absmax_word(d_dz)
+    nbr_h = nbr.cpu().numpy()
+    want_dw = wgrad_float64(x, dz, nbr_h)
+    got = T.conv_wgrad(d_x, cin, d_dz, cout, nbr, 27, n, math="f16x2", dy_absmax=am).cpu().numpy()
+    ref = T.conv_wgrad(d_x, cin, d_dz, cout, nbr, 27, n, math="bf16x3").cpu().numpy()
+    s = np.abs(want_dw).max()
+    e16, e3 = np.abs(got - want_dw).max() / s, np.abs(ref - want_dw).max() / s
+    assert e16 <= max(2.0 * e3, 3e-7), (e16, e3)
+    # roles swapped (ConvTranspose weight gradient: the GRADIENT is the gathered operand)
+    got_t = T.conv_wgrad(d_dz, cout, d_x, cin, nbr, 27, n, math="f16x2", in_absmax=am).cpu().numpy()
+    want_t = wgrad_float64(dz, x, nbr_h)
+    assert np.abs(got_t - want_t).max() / np.abs(want_t).max() <= max(2.0 * e3, 3e-7)
+    # input gradient = gather_conv on the adjoint weights, same rulebook
+    pw_adj = T.pack_weight_adjoint(d_w, flip_taps=True)
+    name = ops.gather_conv_tile(n, cout, cin, cout, dense=False, math="f16x2")
+    assert name.startswith("rowwave_conv_f16_kernel"), name
+    dx16 = ops.gather_conv(d_dz, cout, pw_adj, nbr, 27, n, cin, math="f16x2", in_absmax=am).double().cpu().numpy()
+    dx3 = ops.gather_conv(d_dz, cout, pw_adj, nbr, 27, n, cin, math="bf16x3").double().cpu().numpy()
+    idx_t = np.where(nbr_h < 0, n, nbr_h)
+    dzp = np.concatenate([dz.astype(np.float64), np.zeros((1, cout))])
+    want_dx = sum(dzp[idx_t[t]] @ w[26 - t].astype(np.float64).T for t in range(27))
+    s = np.abs(want_dx).max()
+    e16, e3 = np.abs(dx16 - want_dx).max() / s, np.abs(dx3 - want_dx).max() / s
+    assert e16 <= max(2.0 * e3, 3e-7), (e16, e3)
+    # without the word the same call loses the small gradients (what kept the gradient convs on split-bf16 before)
+    if mag <= 1e-12:
+        raw = ops.gather_conv(d_dz, cout, pw_adj, nbr, 27, n, cin, math="f16x2").double().cpu().numpy()
+        assert np.abs(raw - want_dx).max() / s > 1e-3
+    # --- dense 3x3 128 -> 128: window kernel (pixel table with the geometry tag) and tile kernel (plain table)
+    b, h, wd, c = 2, 40, 44, 128
+    nb2, _, _ = ops.rulebook_conv2d(b, h, wd, 3, 3, 1, 1, "cuda")
+    n2 = b * h * wd
+    dz2 = torch.from_numpy((rng.normal(size=(n2, c)) * np.exp(rng.normal(size=(n2, 1)) * 2) * mag).astype(np.float32)).cuda()
+    w2 = torch.from_numpy((rng.normal(size=(9, c, c)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)).cuda()
+    pw2 = T.pack_weight_adjoint(w2, flip_taps=True)
+    am2 = _absmax_word(dz2)
+    assert ops.gather_conv_tile(n2, c, c, c, dense=True, math="f16x2", nbr=nb2).startswith("window_conv_f16_kernel")
+    plain = nb2.clone()
+    assert ops.gather_conv_tile(n2, c, c, c, dense=True, math="f16x2", nbr=plain).startswith("tile_conv_f16_kernel")
+    rows = torch.cat([torch.tensor([0, 1, wd - 1, wd, h * wd - 1, h * wd, n2 - 1], device="cuda"), torch.randint(0, n2, (1500,), device="cuda")])
+    ii = nb2[:, rows].long()
+    dzp2 = torch.cat([dz2, dz2.new_zeros(1, c)]).double()
+    want2 = sum(dzp2[torch.where(ii[t] < 0, n2, ii[t])] @ w2[8 - t].double().T for t in range(9))
+    s2 = want2.abs().max().item()
+    for table in (nb2, plain):
+        got2 = ops.gather_conv(dz2, c, pw2, table, 9, n2, c, dense=True, math="f16x2", in_absmax=am2)
+        ref2 = ops.gather_conv(dz2, c, pw2, table, 9, n2, c, dense=True, math="bf16x3")
+        e16 = (got2[rows].double() - want2).abs().max().item() / s2
+        e3 = (ref2[rows].double() - want2).abs().max().item() / s2
+        assert e16 <= max(2.0 * e3, 3e-7), (e16, e3)
+
+
+def test_bn_backward_leaves_the_absmax_word(hip):
+    torch.manual_seed(5)
+    n, c = 30000, 96
+    x = torch.randn(n, c, device="cuda") * 3 + 1
+    dy = torch.randn(n, c, device="cuda") * 1e-6
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    invstd = (var + 1e-3).rsqrt()
+    gamma = torch.rand(c, device="cuda") + 0.5
+    y = torch.relu((x - mean) * invstd * gamma)
+    am = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dx, _, _, _ = T.bn_backward(dy, y, x, mean, invstd, gamma, dx_absmax=am)
+    assert am.view(torch.float32).item() == dx.abs().max().item()
