@@ -95,6 +95,9 @@ SIGNATURES = {
     "cpd_bn_stats_finalize": (_I, [_VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_bn_finalize": (_I, [_VP, _VP, _I, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_pack_weight_adjoint": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+    "cpd_pack_batch_table_bytes": (_SZ, [_I]),
+    "cpd_pack_batch_prepare": (_I, [_VP, _I, _VP, _SZ, _VP]),
+    "cpd_pack_batch_run": (_I, [_VP, _I, _VP, _I, _VP]),
     "cpd_affine_rows": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),
     "cpd_bn_bwd_reduce": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_bn_bwd_apply": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP]),

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -1478,6 +1479,163 @@ extern "C" int cpd_pack_weight_adjoint(const float *w_kio, int kv, int c_in, int
     pack_weight_adjoint_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, flip_taps,
                                                                                             kc_o, np_o, packed);
     pack_bf16_image(w_kio, kv, c_out, c_in, 1, flip_taps, packed, cpd_s(stream));
+    return cpd_check_launch();
+}
+
+// ---- all packed images of a model in three launches (the train step rewrites ~70 of them after every optimiser step) ----
+// A job = one packed buffer to rebuild from one [kv][c_in][c_out] tensor (forward image, or -- adjoint -- the image of the
+// input-gradient conv, tap-flipped or not). The device table carries, per job, its first block in each of the three grids.
+namespace {
+struct PackJobDev {
+    const float *w;
+    float *packed;
+    int kv, c_in, c_out, adjoint, flip;     // c_in / c_out of the SOURCE tensor
+    int ci, co, kc, np;                     // of the conv the image is for; kc = 16-channel chunks, np = padded columns
+    int split;                              // has the split images (ci % 32 == 0)
+    unsigned b_f32, b_scale, b_split;       // first block of the job in the fp32-image / column-scale / split-image grids
+    size_t off_bf16, off_f16, off_dsc;      // float offsets of the images inside `packed`
+};
+template <unsigned PackJobDev::*FIRST>
+__device__ __forceinline__ int pack_job_of(const PackJobDev *jobs, int n_jobs, unsigned block) {
+    int lo = 0, hi = n_jobs - 1;            // last job whose first block <= block (jobs without blocks in this grid share a start)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].*FIRST <= block) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ void __launch_bounds__(256) pack_batch_f32_kernel(const PackJobDev *__restrict__ jobs, int n_jobs) {
+    const PackJobDev j = jobs[pack_job_of<&PackJobDev::b_f32>(jobs, n_jobs, blockIdx.x)];
+    const size_t total = (size_t)j.kv * j.kc * 4 * j.np * 4;
+    const size_t i = (size_t)(blockIdx.x - j.b_f32) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i & 3);
+    size_t rest = i >> 2;
+    const int n = (int)(rest % j.np); rest /= j.np;
+    const int g = (int)(rest & 3); rest >>= 2;
+    const int k = (int)(rest % j.kc);
+    const int tp = (int)(rest / j.kc);
+    const int ch = k * 16 + 4 * g + q;
+    float v = 0.f;
+    if (ch < j.ci && n < j.co) {
+        const int t = j.flip ? j.kv - 1 - tp : tp;
+        v = j.adjoint ? j.w[((size_t)t * j.c_in + n) * j.c_out + ch] : j.w[((size_t)t * j.c_in + ch) * j.c_out + n];
+    }
+    j.packed[i] = v;
+}
+// one block per (job, padded column): dsc = 2^-e, as weight_col_scale_kernel
+__global__ void __launch_bounds__(256) pack_batch_scale_kernel(const PackJobDev *__restrict__ jobs, int n_jobs) {
+    const PackJobDev j = jobs[pack_job_of<&PackJobDev::b_scale>(jobs, n_jobs, blockIdx.x)];
+    const int n = (int)(blockIdx.x - j.b_scale);
+    if (!j.split || n >= j.np) return;
+    float m = 0.f;
+    if (n < j.co) {
+        const int per = j.kv * j.ci;
+        for (int i = threadIdx.x; i < per; i += 256) {
+            const int t = i / j.ci, ch = i - t * j.ci;
+            const float v = j.adjoint ? j.w[((size_t)t * j.c_in + n) * j.c_out + ch] : j.w[((size_t)t * j.c_in + ch) * j.c_out + n];
+            m = fmaxf(m, fabsf(v));
+        }
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        const float mx = red[0];
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);
+            e = 14 - ex;
+            e = e > 110 ? 110 : (e < -110 ? -110 : e);
+        }
+        j.packed[j.off_dsc + n] = ldexpf(1.f, -e);
+    }
+}
+// images: bit 0 = the split-bf16 image, bit 1 = the split-fp16 image (needs the column scales of the launch before)
+__global__ void __launch_bounds__(256) pack_batch_split_kernel(const PackJobDev *__restrict__ jobs, int n_jobs, int images) {
+    const PackJobDev j = jobs[pack_job_of<&PackJobDev::b_split>(jobs, n_jobs, blockIdx.x)];
+    if (!j.split) return;
+    const int k32 = j.ci >> 5;
+    const size_t total = (size_t)j.kv * k32 * 4 * j.np * 8;
+    const size_t i = (size_t)(blockIdx.x - j.b_split) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i & 7);
+    size_t rest = i >> 3;
+    const int n = (int)(rest % j.np); rest /= j.np;
+    const int g = (int)(rest & 3); rest >>= 2;
+    const int kk = (int)(rest % k32);
+    const int t = (int)(rest / k32);
+    const int ch = kk * 32 + g * 8 + q;
+    const int ts = j.flip ? j.kv - 1 - t : t;
+    float v = 0.f;
+    if (n < j.co) v = j.adjoint ? j.w[((size_t)ts * j.c_in + n) * j.c_out + ch] : j.w[((size_t)ts * j.c_in + ch) * j.c_out + n];
+    const size_t off = ((size_t)g * j.np + n) * 8 + q;
+    if (images & 1) {
+        __bf16 *pb = reinterpret_cast<__bf16 *>(j.packed + j.off_bf16);
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        const size_t blk = ((size_t)t * k32 + kk) * 3;
+        pb[(blk + 0) * 4 * j.np * 8 + off] = h;
+        pb[(blk + 1) * 4 * j.np * 8 + off] = m;
+        pb[(blk + 2) * 4 * j.np * 8 + off] = l;
+    }
+    if (images & 2) {
+        _Float16 *ph = reinterpret_cast<_Float16 *>(j.packed + j.off_f16);
+        const float vs = v / j.packed[j.off_dsc + n];                 // * 2^e, exact
+        const _Float16 h = (_Float16)vs;
+        const _Float16 l = (_Float16)(vs - (float)h);
+        const size_t blk = ((size_t)t * k32 + kk) * 2;
+        ph[(blk + 0) * 4 * j.np * 8 + off] = h;
+        ph[(blk + 1) * 4 * j.np * 8 + off] = l;
+    }
+}
+}  // namespace
+
+extern "C" size_t cpd_pack_batch_table_bytes(int n_jobs) { return n_jobs > 0 ? cpd_align((size_t)n_jobs * sizeof(PackJobDev)) : 0; }
+
+extern "C" int cpd_pack_batch_prepare(const cpd_pack_job *jobs, int n_jobs, void *table, size_t table_bytes, int32_t grid_blocks[3]) {
+    if (!jobs || n_jobs <= 0 || !table || !grid_blocks || table_bytes < (size_t)n_jobs * sizeof(PackJobDev)) return CPD_ERR_ARG;
+    std::vector<PackJobDev> host((size_t)n_jobs);
+    unsigned long long b0 = 0, b1 = 0, b2 = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const cpd_pack_job &s = jobs[i];
+        if (!s.w || !s.packed || s.kv <= 0 || s.c_in <= 0 || s.c_out <= 0) return CPD_ERR_ARG;
+        PackJobDev &d = host[(size_t)i];
+        d.w = s.w; d.packed = s.packed; d.kv = s.kv; d.c_in = s.c_in; d.c_out = s.c_out; d.adjoint = s.adjoint != 0; d.flip = s.flip_taps != 0;
+        d.ci = d.adjoint ? s.c_out : s.c_in;
+        d.co = d.adjoint ? s.c_in : s.c_out;
+        d.kc = (d.ci + 15) / 16; d.np = ((d.co + 15) / 16) * 16;
+        d.split = d.ci % 32 == 0;
+        d.off_bf16 = packed_f32_floats(d.kv, d.ci, d.co);
+        d.off_f16 = d.off_bf16 + packed_bf16_floats(d.kv, d.ci, d.co);
+        d.off_dsc = d.off_f16 + packed_f16_image_floats(d.kv, d.ci, d.co);
+        d.b_f32 = (unsigned)b0; d.b_scale = (unsigned)b1; d.b_split = (unsigned)b2;
+        b0 += (unsigned long long)cpd_div_up((long long)packed_f32_floats(d.kv, d.ci, d.co), 256);
+        if (d.split) {
+            b1 += (unsigned long long)d.np;
+            b2 += (unsigned long long)cpd_div_up((long long)d.kv * (d.ci / 32) * 4 * d.np * 8, 256);
+        }
+        if (b0 >= (1ull << 31) || b2 >= (1ull << 31)) return CPD_ERR_UNSUPPORTED;
+    }
+    grid_blocks[0] = (int32_t)b0; grid_blocks[1] = (int32_t)b1; grid_blocks[2] = (int32_t)b2;
+    if (hipMemcpy(table, host.data(), (size_t)n_jobs * sizeof(PackJobDev), hipMemcpyHostToDevice) != hipSuccess) return CPD_ERR_LAUNCH;
+    return CPD_OK;
+}
+
+extern "C" int cpd_pack_batch_run(const void *table, int n_jobs, const int32_t grid_blocks[3], int images, cpd_stream_t stream) {
+    if (!table || n_jobs <= 0 || !grid_blocks || (images & ~3)) return CPD_ERR_ARG;
+    const PackJobDev *jobs = reinterpret_cast<const PackJobDev *>(table);
+    hipStream_t s = cpd_s(stream);
+    if (grid_blocks[0] > 0) pack_batch_f32_kernel<<<grid_blocks[0], 256, 0, s>>>(jobs, n_jobs);
+    if ((images & 2) && grid_blocks[1] > 0) pack_batch_scale_kernel<<<grid_blocks[1], 256, 0, s>>>(jobs, n_jobs);
+    if (images && grid_blocks[2] > 0) pack_batch_split_kernel<<<grid_blocks[2], 256, 0, s>>>(jobs, n_jobs, images);
     return cpd_check_launch();
 }
 

@@ -267,6 +267,15 @@ class CenterPointTrainer:
         self.store.dgrad_math = "f32" if cfg.conv_math == "f32" else "bf16x3"
         self.store.bf16x3 = cfg.conv_math != "f32"
         self.store.grad_math = os.environ.get("CPD_TRAIN_GRAD_MATH", "f16x2" if cfg.conv_math == "f16x2" else "bf16x3")
+        # which split images the step reads: the fp16 one (forward and -- with their max |dz| word -- gradient convs), the bf16
+        # one only when some gradient conv still runs split-bf16. A layer without a BatchNorm behind it has no such word; with
+        # everything else on fp16 those (the head's <= 3-channel output convs) take the fp32 kernels rather than keep a third
+        # image of every weight fresh.
+        self._pack_images = {"f32": 0, "bf16x3": 1, "f16x2": 2}[cfg.conv_math]
+        if cfg.conv_math == "f16x2" and self.store.grad_math == "f16x2":
+            self.store.dgrad_math, self.store.bf16x3 = "f32", False
+        elif cfg.conv_math != "f32":
+            self._pack_images |= 1
         if self.device.type == "cuda" and os.environ.get("CPD_TRAIN_SIDE_STREAM", "1") != "0":
             self.store.side = torch.cuda.Stream(device=self.device)
         self._voxelizers = []
@@ -275,7 +284,21 @@ class CenterPointTrainer:
         self.store.finalize(self.device)
         for c in self.layers:
             c.to(self.device)
-            c.repack()
+        # every packed image (forward + adjoint) of every layer is rebuilt after each optimiser step: three launches for all of
+        # them (train_ops.PackBatch) instead of eight per layer; ConvTranspose(k = s > 1) layers, whose adjoint image is built
+        # from a permuted copy of the weights, keep their own repack()
+        jobs, self._repack_single = [], []
+        for c in self.layers:
+            if c.mode == "up" and c.up > 1:
+                self._repack_single.append(c)
+                continue
+            w = self.store.p(c.wn)
+            c.pw = torch.empty((train_ops.packed_floats(c.kv, c.c_in, c.c_out),), dtype=torch.float32, device=self.device)
+            c.pw_adj = torch.empty((train_ops.packed_floats(c.kv, c.c_out, c.c_in),), dtype=torch.float32, device=self.device)
+            jobs.append((w, c.pw, False, False))
+            jobs.append((w, c.pw_adj, True, c.mode == "same"))
+        self._pack = train_ops.PackBatch(jobs) if (jobs and self.device.type == "cuda") else None
+        self._repack_all()
 
     # ------------------------------------------------------------------ graph
     @staticmethod
@@ -571,7 +594,15 @@ class CenterPointTrainer:
         self.steps_done += 1
         train_ops.adam_step(st.flat, st.grad, st.m, st.v, lr, b1, self.betas[1], 1e-8, self.weight_decay,
                             self.steps_done, grad_scale=scale, grad_scale_dev=clip)
-        for c in self.layers:
+        self._repack_all()
+
+    def _repack_all(self):
+        if self._pack is None:
+            for c in self.layers:
+                c.repack()
+            return
+        self._pack.run(self._pack_images)
+        for c in self._repack_single:
             c.repack()
 
     def step(self, points_list, gt_boxes):

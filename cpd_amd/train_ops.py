@@ -77,6 +77,40 @@ def pack_weight_adjoint(w_kio, flip_taps, out=None):
     return packed
 
 
+class _PackJob(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("kv", ctypes.c_int32), ("c_in", ctypes.c_int32),
+                ("c_out", ctypes.c_int32), ("adjoint", ctypes.c_int32), ("flip_taps", ctypes.c_int32)]
+
+
+class PackBatch:
+    """Every packed weight image of a model rebuilt in three launches (cpd_pack_batch_*): `jobs` = [(w_kio, packed, adjoint,
+    flip_taps)] with w_kio [kv, c_in, c_out] views whose storage never moves (the trainer's flat parameter buffer) and
+    `packed` buffers sized by packed_floats(). images: 1 = split-bf16, 2 = split-fp16, 3 = both (the fp32 image always)."""
+
+    def __init__(self, jobs):
+        self.n = len(jobs)
+        self.keep = jobs
+        arr = (_PackJob * self.n)()
+        for i, (w, packed, adjoint, flip) in enumerate(jobs):
+            assert w.is_contiguous() and w.dtype == torch.float32 and w.is_cuda and packed.is_contiguous()
+            kv, cin, cout = w.shape
+            need = lib().cpd_packed_weight_floats(kv, cout if adjoint else cin, cin if adjoint else cout)
+            assert packed.numel() == need, (packed.numel(), need)
+            arr[i] = _PackJob(w.data_ptr(), packed.data_ptr(), kv, cin, cout, int(bool(adjoint)), int(bool(flip)))
+        self.table = torch.empty((lib().cpd_pack_batch_table_bytes(self.n),), dtype=torch.uint8, device=jobs[0][0].device)
+        self.grid = (ctypes.c_int32 * 3)()
+        check(lib().cpd_pack_batch_prepare(ctypes.cast(arr, ctypes.c_void_p), self.n, ptr(self.table), self.table.numel(),
+                                           ctypes.cast(self.grid, ctypes.c_void_p)), "cpd_pack_batch_prepare")
+
+    def run(self, images=3):
+        check(lib().cpd_pack_batch_run(ptr(self.table), self.n, ctypes.cast(self.grid, ctypes.c_void_p), int(images), stream()),
+              "cpd_pack_batch_run")
+
+
+def packed_floats(kv, c_in, c_out):
+    return lib().cpd_packed_weight_floats(kv, c_in, c_out)
+
+
 def affine_rows(x, scale=None, shift=None, residual=None, relu=False, out=None):
     n, c = x.shape
     if out is None:

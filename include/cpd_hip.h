@@ -362,6 +362,23 @@ int cpd_conv3x3_rows_scaled(const float *in, int in_ld, int frames, int h, int w
                             const float *packed_w, int c_out, const float *scale, const float *shift,
                             const float *residual, int res_ld, int relu, float *out, int out_ld, int flags,
                             const uint32_t *in_absmax, cpd_stream_t stream);
+/* All packed images of a model in three launches (a train step rewrites every one of them after the optimiser step; one
+ * cpd_pack_weight / cpd_pack_weight_adjoint call is four launches). A job names one packed buffer (sized by
+ * cpd_packed_weight_floats for the conv the image is FOR) and the [kv][c_in][c_out] tensor it is built from: adjoint = 0
+ * is cpd_pack_weight, adjoint = 1 cpd_pack_weight_adjoint(flip_taps). cpd_pack_batch_prepare (HOST call, synchronous copy)
+ * writes the device table once -- the pointers must stay valid -- and returns the three grid sizes; cpd_pack_batch_run
+ * rebuilds every image: images bit 0 = split-bf16, bit 1 = split-fp16 (the fp32 image always). Results are identical to
+ * the per-tensor calls. */
+typedef struct {
+    const float *w;
+    float *packed;
+    int32_t kv, c_in, c_out, adjoint, flip_taps;
+} cpd_pack_job;
+size_t cpd_pack_batch_table_bytes(int n_jobs);
+int cpd_pack_batch_prepare(const cpd_pack_job *jobs, int n_jobs, void *table, size_t table_bytes,
+                           int32_t grid_blocks[3]);
+int cpd_pack_batch_run(const void *table, int n_jobs, const int32_t grid_blocks[3], int images,
+                       cpd_stream_t stream);
 /* Packed weights of the adjoint conv used for input gradients: Wd[t'][co][ci] = W[t][ci][co],
  * t = kv-1-t' if flip_taps (SubM / stride-1: the forward rulebook is its own transpose up to the
  * tap flip) else t = t' (use with a transposed rulebook). Size: cpd_packed_weight_floats(kv, c_out, c_in). */

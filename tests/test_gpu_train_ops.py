@@ -416,3 +416,28 @@ def test_bn_backward_leaves_the_absmax_word(hip):
     am = torch.zeros(1, dtype=torch.int32, device="cuda")
     dx, _, _, _ = T.bn_backward(dy, y, x, mean, invstd, gamma, dx_absmax=am)
     assert am.view(torch.float32).item() == dx.abs().max().item()
+
+
+def test_batched_weight_packing_matches_the_per_tensor_calls(hip):
+    """cpd_pack_batch_run (three launches for every image of a model) against cpd_pack_weight / cpd_pack_weight_adjoint,
+    bit for bit: channel counts with and without split images, flipped and unflipped adjoints, 1x1 and 27-tap kernels."""
+    torch.manual_seed(11)
+    shapes = [(27, 5, 16), (27, 16, 16), (27, 32, 64), (9, 128, 128), (1, 128, 256), (9, 64, 3), (27, 64, 64), (4, 256, 96)]
+    flat = torch.randn(sum(k * a * b for k, a, b in shapes), device="cuda") * 0.1
+    jobs, want, off = [], [], 0
+    for k, a, b in shapes:
+        w = flat[off:off + k * a * b].view(k, a, b)
+        off += k * a * b
+        for adjoint, flip in ((False, False), (True, True), (True, False)):
+            packed = torch.full((T.packed_floats(k, b if adjoint else a, a if adjoint else b),), float("nan"), device="cuda")
+            jobs.append((w, packed, adjoint, flip))
+            want.append(T.pack_weight_adjoint(w, flip) if adjoint else ops.pack_weight(w))
+    batch = T.PackBatch(jobs)
+    batch.run(3)
+    for (w, packed, adjoint, flip), ref in zip(jobs, want):
+        assert torch.equal(packed.view(torch.int32), ref.view(torch.int32)), (tuple(w.shape), adjoint, flip)
+    flat.mul_(1.7)                                    # new weights, same table
+    batch.run(3)
+    for (w, packed, adjoint, flip) in jobs:
+        ref = T.pack_weight_adjoint(w, flip) if adjoint else ops.pack_weight(w)
+        assert torch.equal(packed.view(torch.int32), ref.view(torch.int32))
