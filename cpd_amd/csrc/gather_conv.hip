@@ -97,7 +97,15 @@ __device__ __forceinline__ f32x4 zero_if(f32x4 a, bool z) {
 __device__ __forceinline__ void in_pow2_scale(const uint32_t *absmax, float &s, float &inv) {
     s = 1.f; inv = 1.f;
     if (absmax) {
-        const int e = (int)((*absmax >> 23) & 0xffu);          // biased exponent of max |in|
+        // the maximum is kept as CPD_ABSMAX_SLOTS partial maxima, one per 128-byte line (same-line atomics serialise)
+        uint32_t m = absmax[(threadIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE];
+#pragma unroll
+        for (int o = CPD_ABSMAX_SLOTS / 2; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+            m = t > m ? t : m;
+        }
+        m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+        const int e = (int)((m >> 23) & 0xffu);                // biased exponent of max |in|
         if (e != 0 && e != 255) {                              // zero / denormal / inf / nan maximum: left alone
             int se = 268 - e;                                  // 127 + 14 - (e - 127)
             se = se < 1 ? 1 : (se > 253 ? 253 : se);

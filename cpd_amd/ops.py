@@ -252,7 +252,7 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     """out[j,:c_out] = act((sum_t in[nbr[t][j]] . W[t]) * scale + shift + residual[j]).
     `inp` / `out` / `residual` are 2-D row tensors whose row stride may exceed the channel count.
     `math`: "f32" | "bf16x3" | "f16x2" (overrides the older `bf16x3` switch).
-    `in_absmax`: one-element int32 device tensor holding the bits of max |inp| (train_ops.bn_backward fills it): the
+    `in_absmax`: the absmax block of `inp` (int32 device tensor, train_ops.bn_backward fills it; train_ops.absmax_block): the
     split-fp16 kernels then pre-scale `inp` into fp16's range by a power of two -- how gradients take that path."""
     _need_cuda(inp, "inp")
     assert inp.dim() == 2 and inp.stride(1) == 1

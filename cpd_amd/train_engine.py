@@ -38,7 +38,7 @@ class _Flat:
         # input gradient (cpd_gather_conv on the adjoint weights) and the weight gradient -- therefore either runs split-bf16
         # (exact split at any magnitude, six products), or -- grad_math "f16x2" -- split-fp16 (three products) with dz
         # PRE-SCALED by a power of two: the BatchNorm backward that produces dz also leaves the bits of max |dz| in a device
-        # word (`absmax`, one slot per layer, zeroed at the start of every backward pass) and the consuming kernels derive
+        # block of words (`absmax`, one block per layer, zeroed at the start of every backward pass) and the consuming kernels derive
         # the scale from it (cpd_gather_conv_scaled / cpd_conv_wgrad_scaled). Layers whose dz does not come out of a
         # BatchNorm backward (the head's output convs, <= 3 channels) are not split-arithmetic layers anyway.
         self.grad_math = "f16x2"
@@ -91,7 +91,7 @@ class _Flat:
         for name, t in self._pending:
             self.p(name).copy_(t)
         self.grad = torch.zeros_like(self.flat)
-        self.absmax = torch.zeros(max(self.n_absmax, 1), dtype=torch.int32, device=device)
+        self.absmax = torch.zeros(max(self.n_absmax, 1) * train_ops.ABSMAX_WORDS, dtype=torch.int32, device=device)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self._pending = None
@@ -190,7 +190,7 @@ class _Conv:
         gmath, wmath = st.dgrad_math, ("bf16x3" if st.bf16x3 else "f32")
         if self.has_bn:
             if st.grad_math == "f16x2" and st.math != "f32":
-                am = st.absmax[self.am_slot:self.am_slot + 1]
+                am = st.absmax[self.am_slot * train_ops.ABSMAX_WORDS:(self.am_slot + 1) * train_ops.ABSMAX_WORDS]
                 gmath = wmath = "f16x2"
             dz, _, _, dres = train_ops.bn_backward(dy, y if self.relu else None, z, mean, invstd, st.p(self.gn),
                                                    want_dres=has_res, dgamma=st.g(self.gn), dbeta=st.g(self.be), dx_absmax=am)

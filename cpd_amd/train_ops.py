@@ -6,6 +6,14 @@ import torch
 from ._lib import check, farr, iarr, lib, ptr, stream
 
 _ws_cache = {}
+ABSMAX_WORDS = 16 * 32       # CPD_ABSMAX_WORDS of include/cpd_hip.h: an absmax block (16 words, one per 128-byte line)
+
+
+def absmax_block(t):
+    """The absmax block of a tensor whose maximum the caller computes itself (what bn_backward leaves behind for its dx)."""
+    blk = torch.zeros(ABSMAX_WORDS, dtype=torch.int32, device=t.device)
+    blk[:1] = t.abs().max().reshape(1).contiguous().view(torch.int32)
+    return blk
 
 
 def _ws(nbytes, device):
@@ -123,8 +131,8 @@ def affine_rows(x, scale=None, shift=None, residual=None, relu=False, out=None):
 
 def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False, dgamma=None, dbeta=None, dx_absmax=None):
     """BatchNorm(+ReLU when y is given) backward. Returns (dx, dgamma, dbeta, dres|None);
-    dgamma / dbeta may be caller-provided (views of a flat gradient buffer). `dx_absmax`: a ZEROED one-element int32 device
-    tensor that receives the bits of max |dx| (for the split-fp16 gradient convolutions)."""
+    dgamma / dbeta may be caller-provided (views of a flat gradient buffer). `dx_absmax`: a ZEROED int32 device
+    tensor of ABSMAX_WORDS words (an absmax block) that receives the bits of max |dx| (for the split-fp16 gradient convolutions)."""
     n, c = x.shape
     dev = x.device
     if dbeta is None:
@@ -153,7 +161,7 @@ def conv_wgrad(inp, c_in, dy, c_out, nbr, kv, n_out, dw=None, accumulate=False, 
                dy_absmax=None):
     """dw[kv, c_in, c_out] (+)= sum_j inp[nbr[t][j]]^T dy[j]; bf16x3: split-bf16 arithmetic (fp32-equivalent).
     math = "f16x2": split-fp16 (half the matrix work); an operand that is a gradient then needs its `*_absmax` word
-    (bits of its max |value|, see bn_backward) so that the kernel can bring it into fp16's range."""
+    (an absmax block, see bn_backward / absmax_block) so that the kernel can bring it into fp16's range."""
     if math is not None:
         bf16x3 = math == "bf16x3"
     if dw is None:

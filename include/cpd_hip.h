@@ -329,8 +329,13 @@ int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const f
                      int n, int c, const float *mean, const float *invstd, const float *gamma,
                      const float *dbeta, const float *dgamma, float *dx, int lddx, float *dres,
                      int lddres, uint32_t *dx_absmax, cpd_stream_t stream);
-/* dx_absmax (optional): a device word the kernel raises (atomic max; the caller zeroes it beforehand) to the bits of
- * max |dx| -- what cpd_gather_conv_scaled / cpd_conv_wgrad_scaled need to run a gradient through the split-fp16 path. */
+/* dx_absmax (optional): an "absmax block" -- CPD_ABSMAX_SLOTS device words CPD_ABSMAX_STRIDE uint32 apart (one per
+ * 128-byte line: atomics on one line serialise), zeroed by the caller beforehand -- whose words the kernel raises (atomic
+ * max) so that their maximum is the bits of max |dx|: what cpd_gather_conv_scaled / cpd_conv_wgrad_scaled need to run a
+ * gradient through the split-fp16 path. A caller that knows the maximum writes it to word 0 of a zeroed block. */
+#define CPD_ABSMAX_SLOTS 16
+#define CPD_ABSMAX_STRIDE 32
+#define CPD_ABSMAX_WORDS (CPD_ABSMAX_SLOTS * CPD_ABSMAX_STRIDE)
 int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, int n, int c, float *dx,
                  int lddx, cpd_stream_t stream);
 /* Weight gradient of cpd_gather_conv: dw[t][ci][co] (+)= sum_j in[nbr[t][j]][ci] * dy[j][co]
@@ -343,8 +348,8 @@ int cpd_conv_wgrad(const float *in, int in_ld, int c_in, const float *dy, int dy
                    const int32_t *nbr, int kv, int n_out, float *dw_kio, int flags, void *ws,
                    size_t ws_bytes, cpd_stream_t stream);
 /* The same with flags CPD_GC_F16X2 allowed: split-fp16 arithmetic (three products instead of six). Gradients do not live in
- * fp16's range, so each operand may come with a device word holding the bits of its max |value| (in_absmax for `in`,
- * dy_absmax for `dy`; NULL = use as is): the kernel multiplies the operand by the power of two that puts that maximum at
+ * fp16's range, so each operand may come with an absmax block (see cpd_bn_bwd_apply) holding the bits of its max |value|
+ * (in_absmax for `in`, dy_absmax for `dy`; NULL = use as is): the kernel multiplies the operand by the power of two that puts that maximum at
  * [2^14, 2^15) before splitting and divides the partial sums by it again -- exact, and an element 2^-18 of the maximum or
  * larger keeps its full 2^-24 relative precision (smaller ones 2^-43 of the maximum absolute). */
 int cpd_conv_wgrad_scaled(const float *in, int in_ld, int c_in, const float *dy, int dy_ld, int c_out,

@@ -328,8 +328,8 @@ def test_fused_center_loss_matches_the_torch_restatement(hip, batch, n_obj):
 
 
 def _absmax_word(t):
-    """What cpd_bn_bwd_apply leaves behind for its dx: the bits of max |t| in a one-element int32 device tensor."""
-    return t.abs().max().reshape(1).contiguous().view(torch.int32)
+    """What cpd_bn_bwd_apply leaves behind for its dx: an absmax block whose largest word is the bits of max |t|."""
+    return T.absmax_block(t)
 
 
 @pytest.mark.parametrize("mag", [1e-12, 1e-7, 1e-3, 1.0, 1e4])
@@ -413,9 +413,11 @@ def test_bn_backward_leaves_the_absmax_word(hip):
     invstd = (var + 1e-3).rsqrt()
     gamma = torch.rand(c, device="cuda") + 0.5
     y = torch.relu((x - mean) * invstd * gamma)
-    am = torch.zeros(1, dtype=torch.int32, device="cuda")
+    am = torch.zeros(T.ABSMAX_WORDS, dtype=torch.int32, device="cuda")
     dx, _, _, _ = T.bn_backward(dy, y, x, mean, invstd, gamma, dx_absmax=am)
-    assert am.view(torch.float32).item() == dx.abs().max().item()
+    words = am.view(16, 32)
+    assert not words[:, 1:].any()                                   # one word per 128-byte line, nothing else touched
+    assert words[:, 0].max().view(torch.float32).item() == dx.abs().max().item()
 
 
 def test_batched_weight_packing_matches_the_per_tensor_calls(hip):

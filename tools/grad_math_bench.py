@@ -27,7 +27,7 @@ for hw, c in ((188, 128), (94, 256)):
     mean, invstd = x.mean(0), (x.var(0, unbiased=False) + 1e-3).rsqrt()
     gamma = torch.rand(c, device="cuda") + 0.5
     y = torch.relu((x - mean) * invstd * gamma)
-    am = torch.zeros(1, dtype=torch.int32, device="cuda")
+    am = torch.zeros(T.ABSMAX_WORDS, dtype=torch.int32, device="cuda")
     w = torch.randn(9, c, c, device="cuda") * 0.03
     pw = T.pack_weight_adjoint(w, flip_taps=True)
     dw = torch.zeros(9, c, c, device="cuda")
