@@ -146,20 +146,34 @@ __global__ void __launch_bounds__(256) col_final_kernel(const float *__restrict_
     }
 }
 
+// V = 4: 16-byte accesses (c and the row pitches multiples of 4, 16-byte aligned bases), else V = 1
+template <int V>
 __global__ void __launch_bounds__(256) affine_rows_kernel(const float *__restrict__ x, int ldx, int n, int c,
                                                           const float *__restrict__ scale, const float *__restrict__ shift,
                                                           const float *__restrict__ res, int ldr, int relu,
                                                           float *__restrict__ out, int ldo) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)n * c;
+    const int cv = c / V;
+    const long long total = (long long)n * cv;
     if (i >= total) return;
-    const int r = (int)(i / c), col = (int)(i - (long long)r * c);
-    float v = x[(size_t)r * ldx + col];
-    if (scale) v *= scale[col];
-    if (shift) v += shift[col];
-    if (res) v += res[(size_t)r * ldr + col];
-    if (relu && !(v > 0.f)) v = 0.f;
-    out[(size_t)r * ldo + col] = v;
+    const int r = (int)(i / cv), col = (int)(i - (long long)r * cv) * V;
+    float v[V], rv[V];
+    if (V == 4) {
+        *reinterpret_cast<f32x4 *>(v) = *reinterpret_cast<const f32x4 *>(x + (size_t)r * ldx + col);
+        if (res) *reinterpret_cast<f32x4 *>(rv) = *reinterpret_cast<const f32x4 *>(res + (size_t)r * ldr + col);
+    } else {
+        v[0] = x[(size_t)r * ldx + col];
+        if (res) rv[0] = res[(size_t)r * ldr + col];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        if (scale) v[e] *= scale[col + e];
+        if (shift) v[e] += shift[col + e];
+        if (res) v[e] += rv[e];
+        if (relu && !(v[e] > 0.f)) v[e] = 0.f;
+    }
+    if (V == 4) *reinterpret_cast<f32x4 *>(out + (size_t)r * ldo + col) = *reinterpret_cast<const f32x4 *>(v);
+    else out[(size_t)r * ldo + col] = v[0];
 }
 
 // dx = a * (dy_m - s1/n - xhat * s2/n), a = gamma*invstd ; dy_m = dy masked by (y > 0);
@@ -665,13 +679,27 @@ __global__ void __launch_bounds__(256) wgrad_f16_kernel(WgParams p) {
     wgrad_split_body<WSplitF16x2, TM, TN>(p, sA, sB, ringJ, ringI, wave_cnt);
 }
 
+// (same summation order per element in both forms: chunk 0, 1, 2, ...)
+template <int V>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int n_chunks, size_t elems,
                                                            float *__restrict__ dw, int accumulate) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= elems) return;
-    float s = accumulate ? dw[i] : 0.f;
-    for (int k = 0; k < n_chunks; ++k) s += part[(size_t)k * elems + i];
-    dw[i] = s;
+    if (V == 4) {
+        f32x4 s = accumulate ? *reinterpret_cast<const f32x4 *>(dw + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < n_chunks; ++k) s += *reinterpret_cast<const f32x4 *>(part + (size_t)k * elems + i);
+        *reinterpret_cast<f32x4 *>(dw + i) = s;
+    } else {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int k = 0; k < n_chunks; ++k) s += part[(size_t)k * elems + i];
+        dw[i] = s;
+    }
+}
+static void launch_wgrad_reduce(const float *part, int n_chunks, size_t elems, float *dw, int accumulate, hipStream_t s) {
+    if (elems % 4 == 0 && (((uintptr_t)part | (uintptr_t)dw) & 15) == 0)
+        wgrad_reduce_kernel<4><<<cpd_div_up((long long)(elems / 4), 256), 256, 0, s>>>(part, n_chunks, elems, dw, accumulate);
+    else wgrad_reduce_kernel<1><<<cpd_div_up((long long)elems, 256), 256, 0, s>>>(part, n_chunks, elems, dw, accumulate);
 }
 
 typedef void (*wg_kernel_t)(WgParams);
@@ -1162,8 +1190,12 @@ extern "C" int cpd_affine_rows(const float *x, int ldx, int n, int c, const floa
                                const float *residual, int ldr, int relu, float *out, int ldo, cpd_stream_t st) {
     if (!x || !out || n < 0 || c <= 0) return CPD_ERR_ARG;
     if (n == 0) return CPD_OK;
-    affine_rows_kernel<<<cpd_div_up((long long)n * c, 256), 256, 0, cpd_s(st)>>>(x, ldx, n, c, scale, shift, residual, ldr, relu,
-                                                                                out, ldo);
+    const bool vec = c % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!residual || ldr % 4 == 0) &&
+                     ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)residual)) & 15) == 0;
+    if (vec) affine_rows_kernel<4><<<cpd_div_up((long long)n * (c / 4), 256), 256, 0, cpd_s(st)>>>(x, ldx, n, c, scale, shift, residual, ldr,
+                                                                                                    relu, out, ldo);
+    else affine_rows_kernel<1><<<cpd_div_up((long long)n * c, 256), 256, 0, cpd_s(st)>>>(x, ldx, n, c, scale, shift, residual, ldr, relu,
+                                                                                        out, ldo);
     return cpd_check_launch();
 }
 extern "C" int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, int n, int c,
@@ -1288,7 +1320,7 @@ static int conv_wgrad_impl(const float *in, int in_ld, int c_in, const float *dy
         } else if (tm == 128) launch_wgrad_bf16<128>(tn, grid, cpd_s(st), p);
         else if (tm == 64) launch_wgrad_bf16<64>(tn, grid, cpd_s(st), p);
         else launch_wgrad_bf16<32>(tn, grid, cpd_s(st), p);
-        wgrad_reduce_kernel<<<cpd_div_up((long long)elems, 256), 256, 0, cpd_s(st)>>>(p.part, p.n_chunks, elems, dw_kio, accumulate);
+        launch_wgrad_reduce(p.part, p.n_chunks, elems, dw_kio, accumulate, cpd_s(st));
         return cpd_check_launch();
     }
     wgrad_plan(n_out, c_in, c_out, kv, &p, &va, &vb);
@@ -1314,7 +1346,7 @@ static int conv_wgrad_impl(const float *in, int in_ld, int c_in, const float *dy
         if (blocks >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), 0, cpd_s(st), p);
     }
-    wgrad_reduce_kernel<<<cpd_div_up((long long)elems, 256), 256, 0, cpd_s(st)>>>(p.part, p.n_chunks, elems, dw_kio, accumulate);
+    launch_wgrad_reduce(p.part, p.n_chunks, elems, dw_kio, accumulate, cpd_s(st));
     return cpd_check_launch();
 }
 

@@ -196,13 +196,17 @@ class _Conv:
                                                    want_dres=has_res, dgamma=st.g(self.gn), dbeta=st.g(self.be), dx_absmax=am)
         else:
             dz = train_ops.relu_backward(dy, y) if self.relu else dy
-        if self.bn_:
-            train_ops.col_sum(dz, out=st.g(self.bn_))
         gw = st.g(self.wn)
+        gb = st.g(self.bn_) if self.bn_ else None              # bias gradient = column sums of dz: rides with the weight gradient
+        if gb is not None and os.environ.get("CPD_TRAIN_BIAS_SIDE", "1") == "0":
+            train_ops.col_sum(dz, out=gb)
+            gb = None
         if self.mode == "up" and self.up > 1:
             u2 = self.up * self.up
             # dW[tap][co][ci] = sum_pix dz_up[map[tap][pix]][co] * x[pix][ci]  (roles of in/dy swapped)
             def wgrad_up():
+                if gb is not None:
+                    train_ops.col_sum(dz, out=gb)
                 tmp = train_ops.conv_wgrad(dz, self.c_bn, x, self.c_in, up_map, u2, n_out, math=wmath, in_absmax=am)
                 gw.view(self.c_in, u2, self.c_bn).copy_(tmp.permute(2, 0, 1))
             ready = st.mark()                   # dz is complete here; the input gradient is ISSUED first (it is on the
@@ -223,8 +227,11 @@ class _Conv:
         if need_dx:
             dx = ops.gather_conv(dz, self.c_out, self.pw_adj, nbr_adj, self.kv, n_in, self.c_in, None, None, add, False,
                                  out=dx_out, dense=dense, math=gmath, in_absmax=am)
-        st.on_side(lambda: train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, math=wmath, dy_absmax=am),
-                   x, dz, nbr_w, after=ready)
+        def wgrad():                                          # everything that only needs (x, dz): off the input-gradient chain
+            if gb is not None:
+                train_ops.col_sum(dz, out=gb)
+            train_ops.conv_wgrad(x, self.c_in, dz, self.c_out, nbr_w, self.kv, n_out, dw=gw, math=wmath, dy_absmax=am)
+        st.on_side(wgrad, x, dz, nbr_w, after=ready)
         return dx, dres
 
 
