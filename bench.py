@@ -316,6 +316,11 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
                    "frames_per_step_per_gpu": B, "parallelism": "data-parallel x%d, one RCCL all-reduce of the flat "
                    "gradient buffer (%.1f MB fp32) per step" % (world, tr.store.grad.numel() * 4 / 1e6),
                    "optimizer": "Adam(betas=(0.9,0.99)) + decoupled wd 1e-5 + OneCycle lr 3e-3 + grad-norm clip 32",
+                   "batch_norm": "training mode: batch statistics + running-stat update, local to the rank (no SyncBN, as the reference default)",
+                   "arithmetic": {"forward": tr.store.math, "input_and_weight_gradients": tr.store.grad_math if tr.store.math != "f32" else "f32",
+                                  "note": "f16x2 = fp32 operands as two fp16 terms, three MFMA products, fp32 accumulation (fp32-level "
+                                          "result); gradient tensors are pre-scaled into fp16's range by a power of two taken from "
+                                          "their max |value| (exact; DESIGN.md 5a). Layers below 32 channels: fp32 MFMA."},
                    "final_loss": float(loss)},
     }
     if prof is not None:
