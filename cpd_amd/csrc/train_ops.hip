@@ -587,8 +587,11 @@ __device__ __forceinline__ void wgrad_split_body(const WgParams &p, char *const 
 
     int head = 0, tail = 0, jb = r0;       // ring positions (head stays a multiple of KB) and next block of rows
     int idx_pref = nbr_of(jb + tid);
-    bool have = false;
-    for (;;) {
+    // Two register sets: the rows of stage s + 2 are requested before stage s's MFMAs and used after stage s + 1's -- two
+    // MFMA blocks of cover for the gather latency (with one set, 4 us per 32-pair stage went mostly to waiting).
+    float va[2][RA], vb[2][RB];
+    int cnts[2] = {0, 0};
+    auto fill_and_load = [&](const int u) {
         while (tail - head < KB && jb < r1) {            // compact the next 256 rows into the ring
             const int j = jb + tid, idx = idx_pref;
             jb += 256;
@@ -612,39 +615,41 @@ __device__ __forceinline__ void wgrad_split_body(const WgParams &p, char *const 
             __syncthreads();
         }
         const int cnt = min(KB, tail - head);
-        if (cnt <= 0) break;
-        // this stage's rows: global -> registers (in flight under the previous stage's MFMAs)
-        float va[RA], vb[RB];
-        {
-            const int base = head & (RING - 1);
+        cnts[u] = cnt;
+        if (cnt <= 0) return;
+        const int base = head & (RING - 1);
 #pragma unroll
-            for (int q = 0; q < RA / 4; ++q) {
-                const int4 id = *reinterpret_cast<const int4 *>(&ringI[base + a_k0 + 4 * q]);
-                const int ids[4] = {id.x, id.y, id.z, id.w};
+        for (int q = 0; q < RA / 4; ++q) {
+            const int4 id = *reinterpret_cast<const int4 *>(&ringI[base + a_k0 + 4 * q]);
+            const int ids[4] = {id.x, id.y, id.z, id.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    va[4 * q + e] = (a_k0 + 4 * q + e < cnt) ? a_base[(size_t)ids[e] * p.in_ld] : 0.f;
-            }
+            for (int e = 0; e < 4; ++e)
+                va[u][4 * q + e] = (a_k0 + 4 * q + e < cnt) ? a_base[(size_t)ids[e] * p.in_ld] : 0.f;
+        }
 #pragma unroll
-            for (int q = 0; q < RB / 4; ++q) {
-                const int4 jd = *reinterpret_cast<const int4 *>(&ringJ[base + b_k0 + 4 * q]);
-                const int js[4] = {jd.x, jd.y, jd.z, jd.w};
+        for (int q = 0; q < RB / 4; ++q) {
+            const int4 jd = *reinterpret_cast<const int4 *>(&ringJ[base + b_k0 + 4 * q]);
+            const int js[4] = {jd.x, jd.y, jd.z, jd.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    vb[4 * q + e] = (b_k0 + 4 * q + e < cnt) ? b_base[(size_t)js[e] * p.dy_ld] : 0.f;
-            }
+            for (int e = 0; e < 4; ++e)
+                vb[u][4 * q + e] = (b_k0 + 4 * q + e < cnt) ? b_base[(size_t)js[e] * p.dy_ld] : 0.f;
         }
         head += KB;
-        if (have) {
+    };
+    fill_and_load(0);
+    fill_and_load(1);
+    for (bool more = true; more;) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (cnts[u] <= 0) { more = false; break; }      // uniform: the chunk is used up
+            wgrad_put<S, RA, A_IMG>(sA, a_slot, a_k0, va[u], sa_);
+            wgrad_put<S, RB, B_IMG>(sB, b_slot, b_k0, vb[u], sb_);
+            __syncthreads();
+            fill_and_load(u);                                // stage s + 2 into the set just emptied
             mma();
-            __syncthreads();               // everyone is done reading the images before they are overwritten
+            __syncthreads();                                 // everyone is done reading the images before they are overwritten
         }
-        wgrad_put<S, RA, A_IMG>(sA, a_slot, a_k0, va, sa_);
-        wgrad_put<S, RB, B_IMG>(sB, b_slot, b_k0, vb, sb_);
-        __syncthreads();
-        have = true;
     }
-    if (have) mma();
 
     // D[i][j]: i = 4g+e <-> channel ci0 + wm*TM/2 + 16s + i ; j = r <-> column co0 + wn*TN/2 + 16nt + j
     const float undo = ia_ * ib_;          // exact: powers of two
