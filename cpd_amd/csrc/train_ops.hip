@@ -13,6 +13,10 @@
 // convs, tap-flipped) weights with the same or the transposed rulebook.
 #include "common.h"
 
+#ifndef CPD_WG_ABLATE
+#define CPD_WG_ABLATE 0      // diagnostic builds of the split weight-gradient kernel (wrong results, timing only): 1 no row loads, 2 no MFMAs, 4 no split / LDS image writes
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -581,7 +585,10 @@ __device__ __forceinline__ void wgrad_split_body(const WgParams &p, char *const 
 #pragma unroll
             for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::q8 *>(src + q * B_IMG);
 #pragma unroll
-            for (int s = 0; s < MS; ++s) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
+            for (int s = 0; s < MS; ++s) {
+                if (CPD_WG_ABLATE & 2) { asm volatile("" :: "v"(a[s][0]), "v"(a[s][1]), "v"(b[0]), "v"(b[1])); }
+                else acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
+            }
         }
     };
 
@@ -624,7 +631,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgParams &p, char *const 
             const int ids[4] = {id.x, id.y, id.z, id.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                va[u][4 * q + e] = (a_k0 + 4 * q + e < cnt) ? a_base[(size_t)ids[e] * p.in_ld] : 0.f;
+                va[u][4 * q + e] = (CPD_WG_ABLATE & 1) ? (float)ids[e] : ((a_k0 + 4 * q + e < cnt) ? a_base[(size_t)ids[e] * p.in_ld] : 0.f);
         }
 #pragma unroll
         for (int q = 0; q < RB / 4; ++q) {
@@ -632,7 +639,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgParams &p, char *const 
             const int js[4] = {jd.x, jd.y, jd.z, jd.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                vb[u][4 * q + e] = (b_k0 + 4 * q + e < cnt) ? b_base[(size_t)js[e] * p.dy_ld] : 0.f;
+                vb[u][4 * q + e] = (CPD_WG_ABLATE & 1) ? (float)js[e] : ((b_k0 + 4 * q + e < cnt) ? b_base[(size_t)js[e] * p.dy_ld] : 0.f);
         }
         head += KB;
     };
@@ -642,8 +649,15 @@ __device__ __forceinline__ void wgrad_split_body(const WgParams &p, char *const 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (cnts[u] <= 0) { more = false; break; }      // uniform: the chunk is used up
-            wgrad_put<S, RA, A_IMG>(sA, a_slot, a_k0, va[u], sa_);
-            wgrad_put<S, RB, B_IMG>(sB, b_slot, b_k0, vb[u], sb_);
+            if (CPD_WG_ABLATE & 4) {
+#pragma unroll
+                for (int e = 0; e < RA; ++e) asm volatile("" :: "v"(va[u][e]));
+#pragma unroll
+                for (int e = 0; e < RB; ++e) asm volatile("" :: "v"(vb[u][e]));
+            } else {
+                wgrad_put<S, RA, A_IMG>(sA, a_slot, a_k0, va[u], sa_);
+                wgrad_put<S, RB, B_IMG>(sB, b_slot, b_k0, vb[u], sb_);
+            }
             __syncthreads();
             fill_and_load(u);                                // stage s + 2 into the set just emptied
             mma();
