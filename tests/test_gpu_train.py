@@ -170,14 +170,23 @@ def test_training_reduces_loss_and_exports_to_engine(hip):
     assert len(res) == 2 and all(torch.isfinite(r["pred_boxes"]).all() for r in res)
 
 
-def test_every_layer_backward_is_locally_exact(hip):
+@pytest.mark.parametrize("conv_math,grad_math", [("f16x2", "f16x2"), ("f16x2", "bf16x3"), ("bf16x3", None), ("f32", None)])
+def test_every_layer_backward_is_locally_exact(hip, monkeypatch, conv_math, grad_math):
     """Inside a real step: each layer's BatchNorm backward sums, weight gradient and input gradient
     against float64 torch formulas evaluated on that layer's own saved tensors (no ReLU-kink or
-    error-propagation effects): 1e-4 of the tensor's max magnitude."""
+    error-propagation effects): 1e-4 of the tensor's max magnitude. In every arithmetic the trainer offers: split-fp16
+    forward with scaled split-fp16 gradients (the default) or split-bf16 gradients, split-bf16 throughout, fp32 MFMA."""
     from cpd_amd.train_engine import CenterPointTrainer, _Conv
+    if grad_math is not None:
+        monkeypatch.setenv("CPD_TRAIN_GRAD_MATH", grad_math)
+    monkeypatch.setenv("CPD_TUNE", "1")              # the split kernels also for this small scene (they are sized for full frames)
+    monkeypatch.setenv("CPD_GC_BF16_MIN", "1")
+    monkeypatch.setenv("CPD_GC_BF16_MIN64", "1")
     cfg = small_cfg()
+    cfg.conv_math = conv_math
     pts, gt = scene(seed=2)
     tr = CenterPointTrainer(cfg, init_state_dict(cfg, seed=7), num_max_objs=50)
+    assert tr.store.grad_math == (grad_math or ("f16x2" if conv_math == "f16x2" else "bf16x3"))
     orig = _Conv.backward
     report = []
 
@@ -189,6 +198,7 @@ def test_every_layer_backward_is_locally_exact(hip):
         st = self.store
         dyc = dy.clone()
         res = orig(self, dy, nbr_adj, n_in, need_dx, add, dx_out)
+        torch.cuda.synchronize()                  # the weight gradient runs on the trainer's second stream
         if not self.has_bn or (self.mode == "up" and self.up > 1):
             return res
         g = dyc.double() * (y > 0) if self.relu else dyc.double()
