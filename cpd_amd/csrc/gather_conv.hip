@@ -1055,6 +1055,14 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if (sub_on(s, t)) {
+                    if (CPD_GC_ABLATE & 4096) {      // timing only: the gathered bits taken as they are (what pre-split storage would allow)
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            const f32x4 v = az[s] ? f32x4{0.f, 0.f, 0.f, 0.f} : araw[s][q & 1];
+                            a[s][q] = __builtin_bit_cast(typename S::frag, v);
+                        }
+                        continue;
+                    }
                     typename S::half lo[NP], hi[NP];
                     S::split(SC ? zero_if(araw[s][0], az[s]) * in_s : zero_if(araw[s][0], az[s]), lo);
                     S::split(SC ? zero_if(araw[s][1], az[s]) * in_s : zero_if(araw[s][1], az[s]), hi);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Diagnostic libraries tools/probe/libcpd_ablN.so: gather_conv.hip built with -DCPD_GC_ABLATE=N
 # (row-wave split kernel: 1 no weight loads, 2 no row gathers, 4 no MFMAs, 8 no barriers; window kernel: 16 no border masks,
-# 64 no weight stages, 128 no window loads/splits/stores, 256 fragment LDS reads in the first stage only, 512 no MFMAs; sums combine),
+# 64 no weight stages, 128 no window loads/splits/stores, 256 fragment LDS reads in the first stage only, 512 no MFMAs, 1024 no epilogue;
+# both: 2048 two of the three split-fp16 products; row-wave: 4096 no split (gathered bits used as fragments); sums combine),
 # rest of the library unchanged.
 set -e
 cd "$(dirname "$0")/../cpd_amd/csrc"
