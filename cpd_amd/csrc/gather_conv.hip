@@ -951,16 +951,20 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
     constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave id in a SCALAR register: everything derived from it (this wave's tap masks, its row range) then branches on SCC
+    // instead of masking EXEC -- the stage loop of the 32-column kernel spent 156 scalar instructions per 12 MFMAs, most of them
+    // EXEC bookkeeping around conditions the compiler could not prove wave-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int item = xcd_remap(blockIdx.x, gridDim.x);
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
     const int row0 = rb * WG_ROWS + wave * (16 * MS), col0 = cb * BN;
 
     // tap activity: workgroup-wide (which stages exist) and per sub-tile of this wave
-    uint32_t wg_mask = 0xffffffffu, my_mask[MS];
+    // (no tap masks: every tap of every sub-tile -- kv <= 32 here, the launcher sends larger kernels elsewhere)
+    uint32_t wg_mask = p.kv >= 32 ? 0xffffffffu : ((1u << p.kv) - 1u), my_mask[MS];
 #pragma unroll
-    for (int s = 0; s < MS; ++s) my_mask[s] = 0xffffffffu;
+    for (int s = 0; s < MS; ++s) my_mask[s] = wg_mask;
     if (p.tapmask) {
         wg_mask = 0;
 #pragma unroll
@@ -972,8 +976,10 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             for (int s = 0; s < MS; ++s)
                 if (i == MS * wave + s) my_mask[s] = m;
         }
+#pragma unroll
+        for (int s = 0; s < MS; ++s) my_mask[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_mask[s]);
+        wg_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_mask);
     }
-    auto tap_on = [&](int t) { return t >= 32 || ((wg_mask >> t) & 1u); };
 
     f32x4 acc[MS][NT];
 #pragma unroll
@@ -992,41 +998,45 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
     const int sk = p.c_in >> 5;
     const size_t b_stage = (size_t)NP * 4 * p.np * 16;
 
-    int t_first = 0;
-    while (t_first < p.kv && !tap_on(t_first)) ++t_first;
-    if (t_first < p.kv) {
-        auto next_tap = [&](int t) { do { ++t; } while (t < p.kv && !tap_on(t)); return t; };
+    // Stage bookkeeping in plain integer / bit arithmetic on scalar registers: the scalar unit is shared by the CU's four
+    // SIMDs (one instruction per clock for ~20 resident waves), and with loops over taps and bool-valued lambdas the stage
+    // loop of the 32-column kernel cost 166 scalar instructions per 12 MFMAs -- the kernel was bound by THAT.
+    if (wg_mask) {
+        auto sub_bits = [&](int t) -> uint32_t {           // bit s: this wave's sub-tile s has a neighbour at tap t
+            uint32_t b = 0;
+#pragma unroll
+            for (int s = 0; s < MS; ++s) b |= ((my_mask[s] >> t) & 1u) << s;
+            return b;
+        };
         auto load_idx = [&](int t, int (&idx)[MS]) {
 #pragma unroll
             for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
         };
-        auto sub_on = [&](int s, int t) { return t >= 32 || ((my_mask[s] >> t) & 1u); };
 
         // Stage order: (tap outer, 32-channel block inner), or -- p.taps_inner, the default -- (block outer, tap inner): the
         // taps of one channel block re-gather neighbouring rows' same 128-byte segments back to back (-6...-8 % on the 32- and
         // 128-channel layers). Either way the stages form one flat sequence; the rulebook column of a stage is fetched two
         // stages ahead of its use (one stage ahead of the gathers it addresses).
+        // A stage cursor is (rem, kk): the taps still to come in this round as a bit set (its lowest bit = the cursor's tap) and
+        // the 32-channel block; stepping it is a handful of scalar instructions.
         const bool inner = p.taps_inner != 0;
-        auto advance = [&](int &t, int &kk) -> bool {          // (t, kk) -> the stage after it; false at the end
-            if (!inner) {
-                if (++kk < sk) return true;
-                kk = 0;
-                t = next_tap(t);
-                return t < p.kv;
+        auto advance = [&](uint32_t &rem, int &kk) -> bool {    // -> the stage after it; false at the end
+            if (inner) {
+                rem &= rem - 1u;
+                if (!rem) { rem = wg_mask; ++kk; }
+                return kk < sk;
             }
-            const int tn = next_tap(t);
-            if (tn < p.kv) { t = tn; return true; }
-            t = t_first;
-            return ++kk < sk;
+            if (++kk == sk) { kk = 0; rem &= rem - 1u; }
+            return rem != 0u;
         };
 
         f32x4 araw[MS][2];
         bool az[MS];
         f32x4u rbv[BJ];
-        auto load_rows = [&](int t, int kk, const int (&idx)[MS]) {
+        auto load_rows = [&](uint32_t on, int kk, const int (&idx)[MS]) {
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
-                if (sub_on(s, t)) {
+                if ((on >> s) & 1u) {
                     const int id = row_ok[s] ? idx[s] : -1;
                     az[s] = id < 0;
                     if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; continue; }
@@ -1048,13 +1058,13 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             }
         };
         typename S::frag a[MS][NP];
-        auto stage_commit = [&](int t) {            // B -> LDS, A -> split fragments
+        auto stage_commit = [&](uint32_t on) {      // B -> LDS, A -> split fragments
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
                 if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
-                if (sub_on(s, t)) {
+                if ((on >> s) & 1u) {
                     if (CPD_GC_ABLATE & 4096) {      // timing only: the gathered bits taken as they are (what pre-split storage would allow)
 #pragma unroll
                         for (int q = 0; q < NP; ++q) {
@@ -1071,11 +1081,8 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                 }
             }
         };
-        auto stage_mma = [&](int t) {
-            bool on[MS], any_on = false;
-#pragma unroll
-            for (int s = 0; s < MS; ++s) { on[s] = sub_on(s, t); any_on |= on[s]; }
-            if (any_on) {
+        auto stage_mma = [&](uint32_t on) {
+            if (on) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const char *src = sb + ((g * BN + 16 * nt + r) << 4);
@@ -1085,38 +1092,48 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
 #pragma unroll
                     for (int s = 0; s < MS; ++s) {
                         if (CPD_GC_ABLATE & 4) {               // no MFMAs: keep the operands live
-                            if (on[s]) asm volatile("" :: "v"(a[s][0]), "v"(a[s][1]), "v"(b[0]), "v"(b[1]));
-                        } else if (on[s]) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
+                            if ((on >> s) & 1u) asm volatile("" :: "v"(a[s][0]), "v"(a[s][1]), "v"(b[0]), "v"(b[1]));
+                        } else if ((on >> s) & 1u) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
                     }
                 }
             }
         };
 
-        // stage cursors: c = computing, 1 / 2 = the stages after it (ok = exists)
-        int tc = t_first, kc = 0;
-        int t1 = tc, k1 = kc; bool ok1 = advance(t1, k1);
-        int t2 = t1, k2 = k1; bool ok2 = ok1 && advance(t2, k2);
+        // stage cursors: c = computing, 1 / 2 = the stages after it (ok = exists); on* = the stage's sub-tile activity bits
+        uint32_t rem = wg_mask;                    // cursor of stage 2 (two ahead); t* = the taps of the three stages in flight
+        int k2 = 0;
+        int tc = __builtin_ctz(rem), kc = 0;
+        uint32_t onc = sub_bits(tc);
+        bool ok1 = advance(rem, k2);
+        int t1 = ok1 ? __builtin_ctz(rem) : 0, k1 = k2;
+        uint32_t on1 = ok1 ? sub_bits(t1) : 0u;
+        bool ok2 = ok1 && advance(rem, k2);
+        int t2 = ok2 ? __builtin_ctz(rem) : 0;
         int idx_a[MS], idx_b[MS];                  // rulebook columns, fetched one stage before the gathers they address
         load_idx(tc, idx_a);
-        load_rows(tc, kc, idx_a);
+        load_rows(onc, kc, idx_a);
         load_weights(tc, kc);
         if (ok1) load_idx(t1, idx_b);              // idx_b: column of the next stage to be gathered
-        stage_commit(tc);
+        stage_commit(onc);
         __syncthreads();
         while (true) {
             if (ok1) {
                 load_weights(t1, k1);
-                load_rows(t1, k1, idx_b);
+                load_rows(on1, k1, idx_b);
                 if (ok2) load_idx(t2, idx_a);
             }
-            stage_mma(tc);
+            stage_mma(onc);
             if (!ok1) break;
             if (!(CPD_GC_ABLATE & 8)) __syncthreads();                        // every wave is done with this stage's weights
-            stage_commit(t1);
+            stage_commit(on1);
             if (!(CPD_GC_ABLATE & 8)) __syncthreads();
-            tc = t1; kc = k1;
+            tc = t1; kc = k1; onc = on1;
             t1 = t2; k1 = k2; ok1 = ok2;
-            if (ok2) ok2 = advance(t2, k2);
+            on1 = ok1 ? sub_bits(t1) : 0u;
+            if (ok2) {
+                ok2 = advance(rem, k2);
+                t2 = ok2 ? __builtin_ctz(rem) : 0;
+            }
 #pragma unroll
             for (int s = 0; s < MS; ++s) idx_b[s] = idx_a[s];
         }
@@ -1681,6 +1698,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
+    if (pl.use_wg == 3 && kv > 32) pl = plan(n_out, c_in, c_out, in_ld, in, flags | CPD_GC_DENSE);   // the row-wave kernel keeps its taps in 32-bit sets
     p.taps_inner = 1;       // measured (tools/order_probe.py): -6...-8 % on the 32- and 128-channel SubM layers, neutral at 64
     if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_TAPS_INNER")) p.taps_inner = atoi(e);
     static const bool trace = getenv("CPD_GC_TRACE") != nullptr;    // one line per launch: which kernel a layer got
