@@ -193,7 +193,7 @@ __device__ __forceinline__ void step_mma(StepRegs<MS, NT> &R, f32x4 (&acc)[MS][N
 template <int MS, int NT, bool VEC>
 __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: item, row0, col0 and the weight / mask addresses stay scalar
     const int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (item >= p.items) return;
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(GcParams p) {
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: what derives from it stays scalar
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 15, g = lane >> 4;
     const int item = xcd_remap(blockIdx.x, gridDim.x);
@@ -523,7 +523,7 @@ __device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
     constexpr int STAGE = NP * (A_IMG + B_IMG);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: what derives from it stays scalar
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 15, g = lane >> 4;
     const int item = xcd_remap(blockIdx.x, gridDim.x);
@@ -703,7 +703,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
     char *const sb = smem + NP * A_IMG;       // GLDS: two weight buffers, sb and sb + NP * B_IMG
     static_assert(!GLDS || B_SLOTS % 256 == 0, "direct-to-LDS weight stages are whole wave instructions");
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // (a scalar wave id cost the 16-column instantiation a third of its speed)
     const int wr = wave / WC, wc = wave - wr * WC;
     const int r = lane & 15, g = lane >> 4;
     const int item = xcd_remap(blockIdx.x, gridDim.x);
