@@ -83,13 +83,18 @@ struct EmitFn {  // write the coordinates of every set bit in canonical order
     }
 };
 
-// One thread per output row, all taps: nbr[t][j] coalesced over j.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"      // the unroll requests below only bind in the K3 instantiation
+// One thread per output row, all taps: nbr[t][j] coalesced over j. K3: the 3 x 3 x 3 kernel of every SubM / strided layer of
+// the backbone with its tap loops unrolled (tap numbers, mask bits and table rows become constants); else runtime extents.
+template <bool K3>
 __global__ void __launch_bounds__(256)
-rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd, int kh, int kw, int sd, int sh, int sw,
+rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd_, int kh_, int kw_, int sd, int sh, int sw,
                 int pd, int ph, int pw, const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
                 const int32_t *__restrict__ perm_in, const int32_t *__restrict__ flags, int32_t *__restrict__ nbr,
                 uint32_t *__restrict__ tapmask, uint32_t *__restrict__ row_pattern) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int kd = K3 ? 3 : kd_, kh = K3 ? 3 : kh_, kw = K3 ? 3 : kw_;
     const bool live = j < n_out;
     if (!live) j = n_out - 1;  // keep whole waves alive for the ballots below
     // canonical list: row id = rank; otherwise row id = map[rank] (the index's own map or the caller's: index_order)
@@ -102,8 +107,10 @@ rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd
     const int lane = threadIdx.x & 63;
     const int x0 = q.w * sw - pw;
     const int xlo = x0 < 0 ? 0 : x0, xhi = x0 + kw - 1 < gin.w ? x0 + kw - 1 : gin.w - 1;
+#pragma unroll
     for (int tz = 0; tz < kd; ++tz) {
         int z = q.y * sd - pd + tz;
+#pragma unroll
         for (int ty = 0; ty < kh; ++ty) {
             int y = q.z * sh - ph + ty;
             // the kw taps of one (z, y) row are consecutive cells: they share one bitmap word and its prefix (two when the
@@ -122,6 +129,7 @@ rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd
                 wb = wa; bb = ba;
                 if (wib != wia) { wb = bitmap[wib]; bb = base[wib]; }
             }
+#pragma unroll
             for (int tx = 0; tx < kw; ++tx, ++t) {
                 int x = x0 + tx;
                 int32_t r = -1;
@@ -148,6 +156,8 @@ rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd
     }
     if (row_pattern && live) row_pattern[j] = pattern;
 }
+
+#pragma clang diagnostic pop
 
 // Output sites of a regular (strided) sparse conv: every input site marks the output cells whose receptive field holds it.
 // One thread per input site; for each (z', y') output row it reaches, the x' cells it reaches form a mask inside ONE 64-cell
@@ -362,8 +372,13 @@ extern "C" int cpd_order_rows_by_taps(const int32_t *indices, int n, int batch, 
     IndexView v = index_carve(const_cast<void *>(index), batch, shape_zyx, 1);
     Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
     // pattern pass: the rulebook walk without the table (ranks are not even resolved to rows)
-    rulebook_kernel<<<cpd_div_up(n, 256), 256, 0, s>>>(indices, n, g, ksize[0], ksize[1], ksize[2], 1, 1, 1, ksize[0] / 2, ksize[1] / 2,
-                                                       ksize[2] / 2, v.bitmap, v.base, v.perm, v.flags, nullptr, nullptr, pattern);
+    if (ksize[0] == 3 && ksize[1] == 3 && ksize[2] == 3)
+        rulebook_kernel<true><<<cpd_div_up(n, 256), 256, 0, s>>>(indices, n, g, 3, 3, 3, 1, 1, 1, 1, 1, 1, v.bitmap, v.base, v.perm, v.flags,
+                                                                 nullptr, nullptr, pattern);
+    else
+        rulebook_kernel<false><<<cpd_div_up(n, 256), 256, 0, s>>>(indices, n, g, ksize[0], ksize[1], ksize[2], 1, 1, 1, ksize[0] / 2,
+                                                                  ksize[1] / 2, ksize[2] / 2, v.bitmap, v.base, v.perm, v.flags, nullptr,
+                                                                  nullptr, pattern);
     const int blocks = cpd_div_up(n, chunk_rows);
     if (chunk_rows == 1024) order_rows_kernel<256, 4><<<blocks, 256, 0, s>>>(pattern, indices, n, new_to_old, old_to_new, indices_out);
     else if (chunk_rows == 4096) order_rows_kernel<1024, 4><<<blocks, 1024, 0, s>>>(pattern, indices, n, new_to_old, old_to_new, indices_out);
@@ -395,11 +410,14 @@ static int rulebook_launch(const int32_t *out_idx, int n_out, int batch, const i
     // the index was carved with some capacity; pointers before perm do not depend on it
     IndexView v = index_carve(const_cast<void *>(index), batch, in_shape, 1);
     Grid g{batch, in_shape[0], in_shape[1], in_shape[2]};
-    if (n_out > 0)
-        rulebook_kernel<<<cpd_div_up(n_out, 256), 256, 0, s>>>(out_idx, n_out, g, k[0], k[1], k[2], st[0], st[1], st[2],
-                                                               pd[0], pd[1], pd[2], v.bitmap, v.base,
-                                                               v.perm, v.flags, nbr,
-                                                               (k[0] * k[1] * k[2] <= 32) ? tapmask : nullptr, nullptr);
+    if (n_out > 0 && k[0] == 3 && k[1] == 3 && k[2] == 3)
+        rulebook_kernel<true><<<cpd_div_up(n_out, 256), 256, 0, s>>>(out_idx, n_out, g, 3, 3, 3, st[0], st[1], st[2], pd[0], pd[1], pd[2],
+                                                                     v.bitmap, v.base, v.perm, v.flags, nbr, tapmask, nullptr);
+    else if (n_out > 0)
+        rulebook_kernel<false><<<cpd_div_up(n_out, 256), 256, 0, s>>>(out_idx, n_out, g, k[0], k[1], k[2], st[0], st[1], st[2],
+                                                                      pd[0], pd[1], pd[2], v.bitmap, v.base,
+                                                                      v.perm, v.flags, nbr,
+                                                                      (k[0] * k[1] * k[2] <= 32) ? tapmask : nullptr, nullptr);
     return cpd_check_launch();
 }
 
