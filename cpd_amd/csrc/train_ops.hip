@@ -1143,7 +1143,13 @@ static int col_reduce(int mode, const float *a, int lda, const float *y, int ldy
     const int cq = cq_total < 16 ? cq_total : 16;
     const int rl = 256 / cq;
     const int col_tiles = (cq_total + cq - 1) / cq;
-    int chunks = 2048 / col_tiles;
+    // partial workgroups to aim for: one per CU. Measured on the train step (one frame per GPU, 97 reductions per step):
+    // 2048 workgroups 10.85 ms/step, 1024 10.82, 512 10.77, 256 10.66, 128 10.58, 64 11.07, 32 12.2 -- the final sum over the
+    // chunks (a dependent second launch) is the part that shrinks. (Folding that sum into this kernel -- last-workgroup-done
+    // tickets -- was measured twice, at 512 and at 128 chunks per tile: 16.9 / 12.5 ms per step. Not done.)
+    int col_blocks = 256;
+    if (const char *e = cpd_knob(cpd_tuning(), "CPD_COL_BLOCKS")) col_blocks = atoi(e);
+    int chunks = col_blocks / col_tiles;
     const int max_chunks = (n + 4 * rl - 1) / (4 * rl);           // at least four rows per thread
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks > COL_MAX_CHUNKS) chunks = COL_MAX_CHUNKS;
