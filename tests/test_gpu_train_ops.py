@@ -443,3 +443,39 @@ def test_batched_weight_packing_matches_the_per_tensor_calls(hip):
     for (w, packed, adjoint, flip) in jobs:
         ref = T.pack_weight_adjoint(w, flip) if adjoint else ops.pack_weight(w)
         assert torch.equal(packed.view(torch.int32), ref.view(torch.int32))
+
+
+def test_scaled_gradient_convs_do_not_hide_nan_or_overflow(hip, monkeypatch):
+    """A NaN (or inf) in dz must reach the input gradient, and a maximum word that is too small (stale) must show as inf / NaN,
+    never as a silently wrong finite number: the contract of the pre-scaled split-fp16 path."""
+    monkeypatch.setenv("CPD_TUNE", "1")
+    monkeypatch.setenv("CPD_GC_BF16_MIN", "1")
+    monkeypatch.setenv("CPD_GC_BF16_MIN64", "1")
+    torch.manual_seed(3)
+    b, h, w, c = 1, 24, 24, 64
+    nbr, _, _ = ops.rulebook_conv2d(b, h, w, 3, 3, 1, 1, "cuda")
+    n = b * h * w
+    dz = torch.randn(n, c, device="cuda") * 1e-6
+    wgt = torch.randn(9, c, c, device="cuda") * 0.05
+    pw = T.pack_weight_adjoint(wgt, flip_taps=True)
+    x = torch.randn(n, c, device="cuda")
+    # NaN in the gradient: BatchNorm backward would leave a NaN maximum -> scaling off, NaN propagates
+    bad = dz.clone()
+    bad[100, 7] = float("nan")
+    am = torch.zeros(T.ABSMAX_WORDS, dtype=torch.int32, device="cuda")
+    am[0] = 0x7fc00000
+    dx = ops.gather_conv(bad, c, pw, nbr, 9, n, c, dense=True, math="f16x2", in_absmax=am)
+    assert torch.isnan(dx).any()
+    dw = T.conv_wgrad(x, c, bad, c, nbr, 9, n, math="f16x2", dy_absmax=am)
+    assert torch.isnan(dw).any()
+    # a maximum word 2^20 too small: the scaled values leave fp16's range -> inf / NaN in the result, not a finite lie
+    stale = T.absmax_block(dz * 2.0 ** -20)
+    dx = ops.gather_conv(dz, c, pw, nbr, 9, n, c, dense=True, math="f16x2", in_absmax=stale)
+    assert not torch.isfinite(dx).all()
+    # and the honest word gives the float64 answer
+    good = T.absmax_block(dz)
+    dx = ops.gather_conv(dz, c, pw, nbr, 9, n, c, dense=True, math="f16x2", in_absmax=good)
+    idx = torch.where(nbr < 0, n, nbr).long()
+    dzp = torch.cat([dz, dz.new_zeros(1, c)]).double()
+    want = sum(dzp[idx[t]] @ wgt[8 - t].double().T for t in range(9))
+    assert (dx.double() - want).abs().max().item() <= 1e-6 * want.abs().max().item()
