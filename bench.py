@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements the default N = 1 run appends to its line "
+                    "(fp32-MFMA value, batch-4 and 1-frame figures, the config-3 train step)")
     ap.add_argument("--layers", action="store_true", help="print a per-launch table of the conv kernels (stderr)")
     ap.add_argument("--row-order", choices=["taps", "canonical"], default="taps",
                     help="internal row order of the strided sparse levels (ModelConfig.row_order)")

@@ -506,6 +506,88 @@ def proto_crop(m):
     np.savez_compressed(os.path.join(HERE, "proto_crop.npz"), **out)
 
 
+def points_in_boxes_fixture(m):
+    """points_in_boxes_cpu (cpd/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:143-168, compiled from where it lies: oracle/_ref)
+    on boxes x points with points placed on / next to every face and on the MARGIN = 1e-2 shell. The GPU box reads this
+    file; the compiled reference stays in the build container (VERDICT r2 weak #4). Own RNG."""
+    sys.path.insert(0, REPO)
+    from oracle.binding import load_reference_points_in_boxes
+    ref = load_reference_points_in_boxes()
+    if ref is None:
+        raise SystemExit("build oracle/_ref first: make -C oracle ref")
+    rng = np.random.default_rng(11)
+    k, n = 37, 20000
+    boxes = np.concatenate([rng.uniform(-40, 40, (k, 2)), rng.uniform(-1, 1, (k, 1)), rng.uniform(0.5, 6, (k, 3)),
+                            rng.uniform(-3.2, 3.2, (k, 1))], 1).astype(np.float32)
+    pts = np.concatenate([rng.uniform(-45, 45, (n, 2)), rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)
+    for i in range(k):                                                  # points on / next to every face, incl. the 1e-2 margin shell
+        b = boxes[i]
+        c, s = np.cos(b[6]), np.sin(b[6])
+        for j, (fx, fy, fz) in enumerate([(0.5, 0, 0), (0.5 + 0.01 / b[3], 0, 0), (0, 0.5 + 0.0099 / b[4], 0), (0, 0, 0.5), (0, 0, 0.50001),
+                                          (0.499, 0.499, -0.5)]):
+            lx, ly, lz = fx * b[3], fy * b[4], fz * b[5]
+            pts[i * 6 + j] = [lx * c - ly * s + b[0], lx * s + ly * c + b[1], lz + b[2]]
+    mask = ref(boxes, pts)
+    extra = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    discard = rng.integers(0, 2, k).astype(bool)
+    np.savez_compressed(os.path.join(HERE, "points_in_boxes.npz"), boxes=boxes, points=pts, mask=np.asarray(mask).astype(np.int32),
+                        extra=extra, discard=discard)
+    print("points_in_boxes: %d boxes x %d points, %d inside" % (k, n, int(np.asarray(mask).sum())))
+
+
+def merge_sweeps_fixture(m):
+    """get_frame's multi-sweep merge and points_rigid_transform (waymo_unsupervised_dataset.py:192-202, 333-360) run from the
+    reference file itself: both methods are cut out of the file at generation time and called on a stand-in dataset object that
+    serves four sweeps and their poses (eval mode, no annotations: the label branches are not entered; prepare_data returns its
+    input). `np.mat` (removed in NumPy 2) is np.asmatrix, as it was in the reference's NumPy. Own RNG."""
+    import ast
+    import copy
+    import textwrap
+    if not hasattr(np, "mat"):
+        np.mat = np.asmatrix
+    path = os.path.join(REF, "cpd/datasets/waymo_unsupervised/waymo_unsupervised_dataset.py")
+    src = open(path).read()
+    fns = {n.name: n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef)}
+    ns = {"np": np, "copy": copy}
+    for name in ("points_rigid_transform", "get_frame"):
+        exec(textwrap.dedent(ast.get_source_segment(src, fns[name])), ns)
+    rng = np.random.default_rng(333)
+
+    def pose(yaw, t):
+        p = np.eye(4)
+        p[:2, :2] = [[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]
+        p[:3, 3] = t
+        return p
+
+    poses = [pose(0.3 + 0.01 * i, [1200.5 + 1.7 * i, -830.25 + 0.4 * i, 12.0 + 0.02 * i]) for i in range(4)]
+    sweeps = [np.concatenate([rng.uniform(-75, 75, (n, 2)), rng.uniform(-2, 4, (n, 1)), rng.uniform(0, 1, (n, 3))], 1).astype(np.float32)
+              for n in (5000, 0, 3333, 4097)]
+    infos = [{"point_cloud": {"lidar_sequence": "seq", "sample_idx": i}, "pose": poses[i], "frame_id": "f%d" % i} for i in range(4)]
+    captured = {}
+
+    class Stand:
+        num_data_frames = 4
+        all_infos = infos
+        training = False
+        dataset_cfg = AttrDict(current_label_method="none", labeling_method={})
+
+        def get_lidar(self, seq, idx):
+            return sweeps[idx].copy()
+
+        def prepare_data(self, data_dict):
+            captured["points"] = np.array(data_dict["points"])       # as merged, before get_frame zeroes columns 3.. at its end
+            return dict(data_dict)
+
+    Stand.points_rigid_transform = ns["points_rigid_transform"]
+    Stand.get_frame = ns["get_frame"]
+    dd = Stand().get_frame(3)
+    out = {"merged": captured["points"], "final_points": np.array(dd["points"]), "poses": np.stack(poses)}
+    for i, s in enumerate(sweeps):
+        out["sweep%d" % i] = s
+    np.savez_compressed(os.path.join(HERE, "merge_sweeps.npz"), **out)
+    print("merge_sweeps: %s merged rows" % (captured["points"].shape,))
+
+
 def _randomize_bn(mods, gen):
     with torch.no_grad():
         for mod in mods:
@@ -572,6 +654,10 @@ def main():
         return proto_crop(m)
     if len(sys.argv) > 1 and sys.argv[1] == "proto_head":
         return proto_head(m)
+    if len(sys.argv) > 1 and sys.argv[1] == "points_in_boxes":
+        return points_in_boxes_fixture(m)
+    if len(sys.argv) > 1 and sys.argv[1] == "merge_sweeps":
+        return merge_sweeps_fixture(m)
     lib = m["lib"]
     out = {}
 
@@ -1039,6 +1125,8 @@ def main():
     atss(m)
     proto_crop(m)
     proto_head(m)
+    points_in_boxes_fixture(m)
+    merge_sweeps_fixture(m)
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -78,43 +78,18 @@ def test_hip_prefilter_matches_oracle(oracle, hip):
 
 
 @pytest.mark.gpu
-def test_merge_sweeps_matches_the_reference_arithmetic(hip):
-    """cpd_merge_sweeps against the arithmetic of get_frame / points_rigid_transform (waymo_unsupervised_dataset.py:192-202,
-    333-360) restated with the same numpy operations: float32 coordinates in a float32 [N, 4] matrix, np.mat products with the
-    float64 pose (sweep -> world, then inverse of the current pose), each result cast to float32; intensity and the last
-    column zeroed; sweeps concatenated oldest first. Coordinates agree to float32 rounding (the 4-term float64 dot products
-    may be summed in another order by BLAS), everything else exactly."""
+def test_merge_sweeps_matches_the_reference_arithmetic(golden, hip):
+    """cpd_merge_sweeps against get_frame / points_rigid_transform (waymo_unsupervised_dataset.py:192-202, 333-360) RUN FROM THE
+    REFERENCE FILE (tests/golden/merge_sweeps.npz, make_golden.py::merge_sweeps_fixture): float32 coordinates in a float32 [N, 4]
+    matrix, np.mat products with the float64 pose (sweep -> world, then inverse of the current pose), each result cast to
+    float32; intensity and the last column zeroed; sweeps concatenated oldest first. Coordinates agree to float32 rounding (the
+    4-term float64 dot products may be summed in another order by BLAS), everything else exactly."""
     import torch
     from cpd_amd import prefilter
-    rng = np.random.default_rng(5)
-
-    def pose(yaw, t):
-        m = np.eye(4)
-        m[:2, :2] = [[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]
-        m[:3, 3] = t
-        return m
-
-    poses = [pose(0.3 + 0.01 * i, [1200.5 + 1.7 * i, -830.25 + 0.4 * i, 12.0 + 0.02 * i]) for i in range(4)]
-    sweeps = [np.concatenate([rng.uniform(-75, 75, (n, 2)), rng.uniform(-2, 4, (n, 1)), rng.uniform(0, 1, (n, 3))], 1).astype(np.float32)
-              for n in (5000, 0, 3333, 4097)]
-
-    def rigid(cloud, P):                                     # the reference's points_rigid_transform, operation for operation
-        if cloud.shape[0] == 0:
-            return cloud
-        mat = np.ones((cloud.shape[0], 4), np.float32)
-        mat[:, 0:3] = cloud[:, 0:3]
-        return np.array((np.asmatrix(P) * np.asmatrix(mat).T).T, dtype=np.float32)[:, 0:3]     # np.mat == np.asmatrix (NumPy < 2)
-
-    cur_inv = np.linalg.inv(poses[-1])
-    want = []
-    for s, P in zip(sweeps, poses):
-        q = s.copy()
-        q[:, 3] = 0
-        q[:, 0:3] = rigid(q[:, 0:3], P)
-        q[:, 0:3] = rigid(q[:, 0:3], cur_inv)
-        q[:, -1] = 0
-        want.append(q)
-    want = np.concatenate(want)
+    g = golden("merge_sweeps")
+    poses = [g["poses"][i] for i in range(4)]
+    sweeps = [g["sweep%d" % i] for i in range(4)]
+    want = g["merged"]
     got = prefilter.merge_sweeps([torch.from_numpy(s).cuda() for s in sweeps], poses, poses[-1]).cpu().numpy()
     assert got.shape == want.shape
     np.testing.assert_array_equal(got[:, 3:], want[:, 3:])
@@ -122,6 +97,9 @@ def test_merge_sweeps_matches_the_reference_arithmetic(hip):
     assert np.mean(got[:, :3] == want[:, :3]) > 0.99
     # the current sweep maps onto itself up to the two roundings
     np.testing.assert_allclose(got[-4097:, :3], sweeps[-1][:, :3], atol=2e-4)
+    # what get_frame hands on after prepare_data: columns 3.. zeroed (l.491)
+    np.testing.assert_array_equal(g["final_points"][:, 3:], 0)
+    np.testing.assert_array_equal(g["final_points"][:, :3], want[:, :3])
 
 
 PROTO_NAMES = ["Vehicle", "Pedestrian", "Cyclist", "Dis_Small", "Sign"]
@@ -169,33 +147,30 @@ def test_sample_prototype_matches_reference_method(golden, hip):
 
 
 @pytest.mark.gpu
-def test_points_in_boxes_cpu_and_crop_match_compiled_reference(oracle, hip):
-    """roiaware_pool3d.cpp's points_in_boxes_cpu compiled from the reference (oracle/_ref) against the device mask, incl. points on
-    the MARGIN shell and the z faces; crop_boxes against masks built from that matrix."""
+def test_points_in_boxes_cpu_and_crop_match_compiled_reference(golden, hip):
+    """roiaware_pool3d.cpp's points_in_boxes_cpu, compiled from the reference in the build container and recorded in
+    tests/golden/points_in_boxes.npz (the binary itself does not travel), against the device mask, incl. points on the MARGIN
+    shell and the z faces; crop_boxes against masks built from that matrix."""
     import torch
-    from oracle.binding import load_reference_points_in_boxes
     from cpd_amd import prefilter
-    ref = load_reference_points_in_boxes()
-    rng = np.random.default_rng(11)
-    k, n = 37, 20000
-    boxes = np.concatenate([rng.uniform(-40, 40, (k, 2)), rng.uniform(-1, 1, (k, 1)), rng.uniform(0.5, 6, (k, 3)), rng.uniform(-3.2, 3.2, (k, 1))], 1).astype(np.float32)
-    pts = np.concatenate([rng.uniform(-45, 45, (n, 2)), rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)
-    for i in range(k):                                                  # points on / next to every face, incl. the 1e-2 margin shell
-        b = boxes[i]
-        c, s = np.cos(b[6]), np.sin(b[6])
-        for j, (fx, fy, fz) in enumerate([(0.5, 0, 0), (0.5 + 0.01 / b[3], 0, 0), (0, 0.5 + 0.0099 / b[4], 0), (0, 0, 0.5), (0, 0, 0.50001), (0.499, 0.499, -0.5)]):
-            lx, ly, lz = fx * b[3], fy * b[4], fz * b[5]
-            pts[i * 6 + j] = [lx * c - ly * s + b[0], lx * s + ly * c + b[1], lz + b[2]]
-    want = ref(boxes, pts) if ref is not None else oracle.points_in_boxes_mask(boxes, pts)
+    g = golden("points_in_boxes")
+    boxes, pts, want, discard = g["boxes"], g["points"], g["mask"], g["discard"]
+    k, n = boxes.shape[0], pts.shape[0]
     got = prefilter.points_in_boxes_cpu(torch.from_numpy(pts).cuda(), torch.from_numpy(boxes).cuda()).cpu().numpy()
     np.testing.assert_array_equal(got, want)
-    full = np.concatenate([pts, rng.uniform(0, 1, (n, 2)).astype(np.float32)], 1)
-    discard = rng.integers(0, 2, k).astype(bool)
+    full = np.concatenate([pts, g["extra"]], 1)
     a, b_ = prefilter.crop_boxes(torch.from_numpy(full).cuda(), torch.from_numpy(boxes).cuda(), discard)
     np.testing.assert_array_equal(a.cpu().numpy(), full[want.sum(0) == 0])
     np.testing.assert_array_equal(b_.cpu().numpy(), full[want[discard].sum(0) == 0])
     e0, e1 = prefilter.crop_boxes(torch.from_numpy(full).cuda(), torch.zeros((0, 7)).cuda(), np.zeros(0, bool))   # no boxes: everything stays
     assert e0.shape[0] == n and e1.shape[0] == n
+
+
+def test_oracle_points_in_boxes_mask_matches_reference_fixture(oracle, golden):
+    """the oracle's restatement against the recorded output of the compiled reference (runs anywhere; the live comparison below
+    needs oracle/_ref, i.e. the build container)"""
+    g = golden("points_in_boxes")
+    np.testing.assert_array_equal(oracle.points_in_boxes_mask(g["boxes"], g["points"]), g["mask"])
 
 
 def test_oracle_points_in_boxes_mask_matches_compiled_reference(oracle):
