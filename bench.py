@@ -15,10 +15,17 @@ HBM when the timed region starts; each step ends with the one D2H of its final b
 labels into host memory (inside the timed region; --device-results leaves them in HBM).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : dominant kernel (gather_conv_kernel<ms,nt,vec>, fp32 MFMA bound) measured live with
-                 HIP events on the launch stream in a second pass right after the timed region
-  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host
-                 cores on one full frame (rank 0, N=1 only)
+  roofline     : the dominant conv kernel (today window_conv_f16_kernel<128>: split-fp16 on the fp16 MFMA pipe, priced against
+                 2500 / 3 TFLOP/s) measured live with HIP events on the launch stream in a second pass right after the timed
+                 region; `traffic` from the round's committed rocprofv3 --pmc passes of this same command
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host cores: median of three
+                 full frames on all hardware threads, and one frame on ONE thread (rank 0, N = 1 only)
+and, at N = 1 unless --no-extras, measured in the same process right after the timed region (each its own engine, same clouds):
+  value_fp32_mfma      frames/s of the same step with conv_math = "f32" (fp32-input MFMA everywhere: the reference's arithmetic)
+  value_batch4         frames/s at the reference's eval batch (4 frames per step, voxel_rcnn_cproto_center.yaml:188)
+  latency_1frame_ms    one frame per step
+  module_api           frames/s of the same 48 frames through the drop-in modules (cpd_amd.models.CenterPoint, batch_dict API)
+  train_step           config 3 on this GPU: ms per step / frames/s of CenterPointTrainer (forward + backward + Adam)
 """
 import argparse
 import json
@@ -81,6 +88,9 @@ def parse():
                          "one RCCL gradient all-reduce + Adam, --frames (default 1) frames per GPU per step")
     ap.add_argument("--device-results", action="store_true", help="leave the final boxes on the device (default: the one D2H "
                     "of each step's boxes / scores / labels into host memory is inside the timed region, SURVEY 8d)")
+    ap.add_argument("--api", choices=["engine", "modules"], default="engine",
+                    help="engine = the fused CenterPointEngine (headline); modules = the drop-in module path: device voxelizer -> "
+                         "batch_dict -> cpd_amd.models.CenterPoint (eval), spconv.install(conv_math=--conv-math)")
     ap.add_argument("--launch-check", action="store_true", help="only launch the --gpus ranks, rendezvous, run the timing "
                     "collectives (barrier, max over ranks) and print the n_gpus line: no GPU work (the CPU test of the N > 1 "
                     "launcher, backend from CPD_DIST_BACKEND)")
@@ -117,7 +127,7 @@ class ConvProfiler:
 
         def wrapped(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
             kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False), kw.get("bf16x3", False), nbr,
-                                         math=kw.get("math"))
+                                         math=kw.get("math"), scaled=kw.get("in_absmax") is not None)
             pairs = prof._pairs(nbr, n_out, c_in, c_out)
             flops = 2.0 * pairs * c_in * c_out
             # algorithmic HBM bytes of the layer: every feature row once in and once out, the weights, the
@@ -240,16 +250,106 @@ class HbmStageProfiler:
         return out
 
 
+def pmc_summary_file():
+    """the newest committed PMC summary (profiles/rNN_pmc_summary.json, written by tools/pmc_bench.sh from this command)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+    return files[-1] if files else None
+
+
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_summary.json: 2 x FETCH_SIZE + WRITE_SIZE, per MI355X_MICROARCH.md), or None.
-    bench.py cannot run the counters itself; the number is from the same command's PMC run."""
+    """HBM-side bytes per launch of `kernel` from the round's committed rocprofv3 PMC passes of this command
+    (2 x FETCH_SIZE + WRITE_SIZE, per MI355X_MICROARCH.md), or None. bench.py cannot run the counters itself."""
     try:
-        with open(os.path.join(REPO, "profiles", "r02_pmc_summary.json")) as f:
+        with open(pmc_summary_file()) as f:
             k = json.load(f)["kernels"].get(kernel)
         return k["hbm_bytes_per_launch_corrected"] if k else None
     except Exception:
         return None
+
+
+def time_steps(step, steps, warmup):
+    """warmup + timed steps of step(i) on the current stream -> seconds per step"""
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def module_api_runner(cfg, sd, dev, clouds, conv_math):
+    """The drop-in module path on the same frames: the device voxelizer fills the reference's batch_dict keys
+    (voxel_features -- MeanVFE fused --, voxel_coords, batch_size), cpd_amd.models.CenterPoint (reference class names, batch_dict
+    contract, state_dict names) runs in eval mode under no_grad, results are copied to the host like the engine's."""
+    from cpd_amd import models
+    from cpd_amd import spconv as sp
+    sp.install(conv_math=conv_math)
+    net = models.CenterPoint(point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size).to(dev).eval()
+    net.load_state_dict(sd)
+    vox = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features, cfg.max_points_per_voxel, cfg.max_voxels,
+                        device=torch.device(dev))
+
+    def run(frames):
+        with torch.no_grad():
+            _, coords, _, feats, nvox = vox.batch(frames)
+            n = int(nvox[len(frames)])
+            bd = {"voxel_features": feats[:n], "voxel_coords": coords[:n], "batch_size": len(frames)}
+            preds, _ = net(bd)
+            return [{k: v.cpu() for k, v in p.items()} for p in preds]
+
+    return run
+
+
+def extras(args, cfg, sd, dev, clouds, value):
+    """The extra figures of the default N = 1 line, each measured here with its own engine on the same clouds."""
+    out = {}
+    B = args.frames
+
+    def engine_rate(c, frames, steps, warmup):
+        eng = CenterPointEngine(c, sd, device=dev, host_results=not args.device_results)
+        sec = time_steps(lambda i: eng.forward([clouds[(i * frames + j) % POOL] for j in range(frames)]), steps, warmup)
+        del eng
+        return frames / sec, sec
+
+    if cfg.conv_math != "f32":
+        c32 = ModelConfig(conv_math="f32", row_order=cfg.row_order, row_order_chunk=cfg.row_order_chunk)
+        v, sec = engine_rate(c32, B, 5, 2)
+        out["value_fp32_mfma"] = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 5,
+                                  "note": "same step with conv_math='f32': fp32-input MFMA (v_mfma_f32_16x16x4_f32) in every layer"}
+    v, sec = engine_rate(cfg, 4, 40, 8)
+    out["value_batch4"] = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 40,
+                           "note": "4 frames per step: the reference's eval batch per GPU (voxel_rcnn_cproto_center.yaml:188)"}
+    v, sec = engine_rate(cfg, 1, 60, 10)
+    out["latency_1frame_ms"] = 1e3 * sec
+    run = module_api_runner(cfg, sd, dev, clouds, cfg.conv_math)
+    sec = time_steps(lambda i: run([clouds[(i * B + j) % POOL] for j in range(B)]), 6, 2)
+    out["module_api"] = {"value": B / sec, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 6, "ratio_to_engine": B / sec / value,
+                         "note": "device voxelizer -> batch_dict -> cpd_amd.models.CenterPoint (eval, no_grad; canonical row order, "
+                                 "first-appearance voxel order as at the B1 boundary), results copied to the host"}
+    return out
+
+
+def train_step_extra(args, cfg, sd, dev, steps=12, warmup=4):
+    """Config 3 inside the default run: CenterPointTrainer.step on one frame per step (voxelize, training-mode forward, CenterHead
+    targets + loss, backward, all-reduce no-op at N = 1, Adam, weight repack)."""
+    from cpd_amd.synthetic import gt_boxes
+    from cpd_amd.train_engine import CenterPointTrainer
+    seeds = dist_utils.frame_seeds(0, POOL)
+    clouds = [torch.from_numpy(waymo_cloud(s, n_points=args.points)).cuda() for s in seeds]
+    gts = [torch.from_numpy(gt_boxes(s)).cuda() for s in seeds]
+    tr = CenterPointTrainer(cfg, sd, device=dev, total_steps=steps + warmup, world_size=1)
+    last = [None]
+
+    def step(i):
+        last[0] = tr.step([clouds[i % POOL]], torch.stack([gts[i % POOL]]))
+
+    sec = time_steps(step, steps, warmup)
+    return {"ms_per_step": 1e3 * sec, "frames_per_s": 1.0 / sec, "steps": steps, "frames_per_step": 1,
+            "arithmetic": {"forward": tr.store.math, "gradients": tr.store.grad_math if tr.store.math != "f32" else "f32"},
+            "batch_norm": "training mode (batch statistics)", "final_loss": float(last[0][0])}
 
 
 def cpu_model():
@@ -261,24 +361,42 @@ def cpu_model():
         return "unknown"
 
 
-def cpu_baseline(cfg, sd, points_np):
-    """The oracle's un-fused restatement of the reference graph on the host CPU, one full frame."""
+def cpu_baseline(cfg, sd, clouds_np, full_frames=3, one_thread=True):
+    """The oracle's un-fused restatement of the reference graph on the host CPU: `full_frames` full 160k-point frames on all
+    hardware threads (value = 1 / median), then ONE frame on one thread (OpenMP team size set through libgomp; the voxelizer,
+    rulebook builds and NMS scan are serial either way, as in the reference)."""
+    import ctypes
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import ref_pipeline
     from oracle import Oracle
     o = Oracle()
     cores = os.cpu_count() or 1
-    if os.environ.get("OMP_NUM_THREADS", "").isdigit():      # `OMP_NUM_THREADS=1 python bench.py` gives the 1-thread figure
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():      # `OMP_NUM_THREADS=k python bench.py` bounds the team
         cores = min(cores, max(1, int(os.environ["OMP_NUM_THREADS"])))
     # one untimed voxelizer call so that, as in the reference's generator object, the dense lookup
     # volume already exists (it is allocated once per worker, data_processor.py:133-144)
-    o.voxelize(points_np[:1000], cfg.voxel_size, cfg.point_cloud_range, cfg.max_points_per_voxel, cfg.max_voxels)
-    t0 = time.perf_counter()
-    ref_pipeline.forward(o, cfg, sd, [points_np])
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
-            "sample": "1 full 160k-point frame through the whole path (oracle/cpd_oracle.c, OpenMP on %d threads), "
-                      "%.1f s" % (cores, dt)}
+    o.voxelize(clouds_np[0][:1000], cfg.voxel_size, cfg.point_cloud_range, cfg.max_points_per_voxel, cfg.max_voxels)
+    times = []
+    for i in range(max(1, full_frames)):
+        t0 = time.perf_counter()
+        ref_pipeline.forward(o, cfg, sd, [clouds_np[i % len(clouds_np)]])
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    out = {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+           "sample": "%d full 160k-point frames through the whole path (oracle/cpd_oracle.c, OpenMP on %d threads): %s s, median %.1f s"
+                     % (len(times), cores, "/".join("%.1f" % t for t in times), med)}
+    if one_thread and cores > 1:
+        try:
+            gomp = ctypes.CDLL("libgomp.so.1")
+            gomp.omp_set_num_threads(1)
+            t0 = time.perf_counter()
+            ref_pipeline.forward(o, cfg, sd, [clouds_np[0]])
+            dt1 = time.perf_counter() - t0
+            gomp.omp_set_num_threads(cores)
+            out["one_thread"] = {"value": 1.0 / dt1, "unit": "frames/s", "cores": 1, "sample": "1 full frame, %.1f s" % dt1}
+        except OSError:
+            out["one_thread"] = None
+    return out
 
 
 def train_main(args, cfg, sd, dev, rank, world, distributed):
@@ -381,9 +499,10 @@ def main():
     if args.mode == "train":
         return train_main(args, cfg, sd, dev, rank, world, distributed)
     S = max(1, args.streams)
-    engines = [CenterPointEngine(cfg, sd, device=dev, host_results=not args.device_results) for _ in range(S)]
+    if args.api == "modules":
+        S = 1
+    engines = [CenterPointEngine(cfg, sd, device=dev, host_results=not args.device_results) for _ in range(S)] if args.api == "engine" else []
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    eng = engines[0]
     clouds_np = [waymo_cloud(sd_, n_points=args.points) for sd_ in dist_utils.frame_seeds(rank, POOL)]
     clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
     B = args.frames
@@ -391,7 +510,11 @@ def main():
 
     host_clouds = [torch.from_numpy(c).pin_memory() for c in clouds_np] if args.host_input else None
 
+    module_run = None
+
     def step(i, w=0):
+        if module_run is not None:
+            return module_run([clouds[(i * B + j) % POOL] for j in range(B)])
         if host_clouds is not None:      # boundary hands over host buffers: H2D inside the step
             return engines[w].forward([host_clouds[(i * B + j) % POOL].cuda(non_blocking=True) for j in range(B)])
         return engines[w].forward([clouds[(i * B + j) % POOL] for j in range(B)])
@@ -420,6 +543,8 @@ def main():
             t.join()
 
     barrier = dist_utils.barrier
+    if args.api == "modules":
+        module_run = module_api_runner(cfg, sd, dev, clouds, cfg.conv_math)
 
     run_steps(args.warmup)
     barrier()
@@ -434,8 +559,13 @@ def main():
         "metric": "frames/sec voxelize->sparse3D->BEV->NMS, 160k-pt Waymo cloud",
         "value": world * args.steps * B / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (inputs in pinned host memory, H2D timed)" if args.host_input else ""),
+        "vs_baseline": None,
+        "dtype": {"f16x2": "f32 (split-fp16 x2 on the fp16 MFMA pipe: 3 products, fp32 accumulate)",
+                  "bf16x3": "f32 (split-bf16 x3 on the bf16 MFMA pipe: 6 products, fp32 accumulate)", "f32": "f32"}[cfg.conv_math],
+        "data": "synthetic" + (" (inputs in pinned host memory, H2D timed)" if args.host_input else ""),
         "results": "left on the device" if args.device_results else "copied to host memory inside the timed region",
+        "api": "fused engine (cpd_amd.engine.CenterPointEngine)" if args.api == "engine" else
+               "drop-in modules (cpd_amd.models.CenterPoint through batch_dict, eval-mode fusion)",
         "config": {"workload": "configs[1]: Waymo-shape %d-point cloud, CPD VoxelResBackBone8x + HeightCompression + "
                                "BaseBEVBackbone + CenterHead + rotated NMS, forward-only" % args.points,
                    "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
@@ -451,7 +581,7 @@ def main():
                                  "f32": "fp32 MFMA everywhere"}[cfg.conv_math]},
     }
 
-    if not args.no_roofline:
+    if not args.no_roofline and args.api == "engine":
         # Second pass, same configuration (same streams / batch), with every cpd_gather_conv launch
         # bracketed by HIP events on its own launch stream.
         n_prof = max(S, min(args.steps, 6))
@@ -482,7 +612,7 @@ def main():
                               "the 1400 W socket cap, and this kernel runs at 1.9-2.1 GHz for the same reason (DESIGN.md 4.1)",
             "traffic": pmc_traffic(key),
             "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 --pmc passes of this "
-                            "command, profiles/r02_pmc_summary.json; bench.py cannot collect counters itself)",
+                            "command, %s; bench.py cannot collect counters itself)" % (os.path.relpath(pmc_summary_file() or "none", REPO)),
             "launches_per_frame": launches / (n_prof * B), "avg_launch_us": 1e3 * ms / launches,
             "algorithmic_gflop_per_launch": flops / launches / 1e9,
             "note": "per-launch figures measured with %d concurrent stream(s): a launch shares the chip with the other "
@@ -496,7 +626,7 @@ def main():
                                  for k, v in sorted(agg.items())},
         }
 
-    if not args.no_roofline:
+    if not args.no_roofline and args.api == "engine":
         with HbmStageProfiler() as hp:
             run_steps(max(S, 2))
             out["hbm_stages"] = hp.summary(max(S, 2) * B)
@@ -512,8 +642,15 @@ def main():
         out["hbm_stages"]["note"] = ("algorithmic bytes (SURVEY 8d) / HIP-event time of each call (one call = all its launches), "
                                      "single stream; peak = 8 TB/s nominal HBM3E")
 
+    if world == 1 and not args.no_extras and args.api == "engine" and S == 1 and not args.host_input:
+        engines.clear()
+        torch.cuda.empty_cache()
+        out.update(extras(args, cfg, sd, dev, clouds, out["value"]))
+        torch.cuda.empty_cache()
+        out["train_step"] = train_step_extra(args, cfg, sd, dev)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, sd, clouds_np[0])
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, clouds_np)
 
     if rank == 0:
         print(json.dumps(out))

@@ -266,16 +266,20 @@ class AnchorHeadSingle(torch.nn.Module):
     mask, the 1x1 conv_cls / conv_box / conv_dir_cls (cpd_gather_conv through cpd_amd.models.Conv2d; state_dict
     names as in the reference), masked anchors, generate_predicted_boxes (cpd_anchor_decode)."""
 
-    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, **kwargs):
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range,
+                 predict_boxes_when_training=True, **kwargs):
         super().__init__()
         from .models import Conv2d
         self.model_cfg, self.num_class, self.class_names = model_cfg, num_class, list(class_names)
+        self.predict_boxes_when_training = bool(predict_boxes_when_training)   # ctor arg as in the reference (l.195-196), default True
         self.range = [float(v) for v in point_cloud_range]
         self.voxel_size = (self.range[3] - self.range[0]) / float(grid_size[0])
         agc = model_cfg["ANCHOR_GENERATOR_CONFIG"]
         fms = [[int(grid_size[0]) // c["feature_map_stride"], int(grid_size[1]) // c["feature_map_stride"]] for c in agc]
         self._gen = (AnchorGenerator(self.range, agc), fms)
         self.anchors_root = None                                     # built on the first forward (device known then)
+        self.anchors = None                                          # the occupancy-masked anchors of the last forward
+        self.forward_ret_dict = {}
         per_loc = sum(len(c["anchor_rotations"]) * len(c["anchor_sizes"]) * len(c["anchor_bottom_heights"]) for c in agc)
         self.num_anchors_per_location = per_loc
         self.conv_cls = Conv2d(input_channels, per_loc * num_class, kernel_size=1)
@@ -302,31 +306,65 @@ class AnchorHeadSingle(torch.nn.Module):
         mask[rows, cols] = 1
         return mask.bool()
 
-    def get_loss(self, forward_ret_dict, anchors=None):
+    @property
+    def target_assigner(self):
+        """AnchorHeadTemplate.get_target_assigner (anchor_head_template.py:62-81), built on first use."""
+        if getattr(self, "_assigner", None) is None:
+            self._assigner = get_target_assigner(self.model_cfg["TARGET_ASSIGNER_CONFIG"], self.model_cfg["ANCHOR_GENERATOR_CONFIG"],
+                                                 self.class_names)
+        return self._assigner
+
+    def assign_targets(self, gt_boxes):
+        """AnchorHeadTemplate.assign_targets (anchor_head_template.py:116-127): the assigner on the anchors of THIS forward (the
+        occupancy-masked ones) and gt_boxes (B, M, 8)."""
+        return self.target_assigner.assign_targets(self.anchors, gt_boxes)
+
+    def _train_targets(self, data_dict):
+        """anchor_head_single.py:176-181 / 335-340: in training mode the targets of this batch join forward_ret_dict and the
+        per-anchor IoUs go to data_dict['gt_ious'] (the axis-aligned assigner provides them; part_wraper.py:137 reads them)."""
+        targets = self.assign_targets(data_dict["gt_boxes"])
+        self.forward_ret_dict.update(targets)
+        if "gt_ious" in targets:
+            data_dict["gt_ious"] = targets["gt_ious"]
+
+    def get_loss(self, forward_ret_dict=None, anchors=None):
         """AnchorHeadTemplate.get_loss (anchor_head_template.py:321-334) for a forward_ret_dict with the reference's keys
-        (cls_preds, box_preds, dir_cls_preds, box_cls_labels, box_reg_targets). Fused loss + gradient kernel; returns
+        (cls_preds, box_preds, dir_cls_preds, box_cls_labels, box_reg_targets); defaults: the dict and the (masked) anchors of
+        the last forward -- the predictions are laid out on those. Fused loss + gradient kernel; returns
         (losses[4] = rpn_loss, cls, loc, dir on the device, (d_cls_preds, d_box_preds, d_dir_cls_preds))."""
         lw = self.model_cfg["LOSS_CONFIG"]["LOSS_WEIGHTS"]
-        f = forward_ret_dict
-        return anchor_head_loss(anchors if anchors is not None else self.anchors_root, f["cls_preds"], f["box_preds"],
+        f = forward_ret_dict if forward_ret_dict is not None else self.forward_ret_dict
+        if anchors is None:
+            anchors = self.anchors if self.anchors is not None else self.anchors_root
+        return anchor_head_loss(anchors, f["cls_preds"], f["box_preds"],
                                 f.get("dir_cls_preds"), f["box_cls_labels"], f["box_reg_targets"], self.num_class,
                                 lw["cls_weight"], lw["loc_weight"], lw.get("dir_weight", 0.2), lw["code_weights"],
                                 self.model_cfg.get("DIR_OFFSET", 0.78539), self.num_dir_bins)
 
-    @torch.no_grad()
+    def _predict(self, data_dict, cls_preds, box_preds, dir_preds):
+        """generate_predicted_boxes on detached predictions (eval, or training with predict_boxes_when_training: l.183-190)."""
+        with torch.no_grad():
+            cls, boxes = generate_predicted_boxes(self.anchors, data_dict["batch_size"], cls_preds.detach(), box_preds.detach(),
+                                                  dir_preds.detach() if dir_preds is not None else None,
+                                                  self.model_cfg.get("DIR_OFFSET", 0.78539), self.model_cfg.get("DIR_LIMIT_OFFSET", 0.0),
+                                                  self.num_dir_bins)
+        data_dict.update(batch_cls_preds=cls, batch_box_preds=boxes, cls_preds_normalized=False)
+
     def forward(self, data_dict):
         x = data_dict["st_features_2d"]
         if self.anchors_root is None:
             self.anchors_root = self._gen[0].generate_anchors(self._gen[1], device=x.device)[0]
         mask = self.get_anchor_mask(data_dict["points"], x.shape)
-        anchors = [a[:, mask, ...] for a in self.anchors_root]
+        self.anchors = [a[:, mask, ...] for a in self.anchors_root]
         pick = lambda t: t.permute(0, 2, 3, 1).contiguous()[:, mask, :]
-        cls_preds, box_preds = pick(self.conv_cls(x)), pick(self.conv_box(x))
-        dir_preds = pick(self.conv_dir_cls(x)) if self.conv_dir_cls is not None else None
-        cls, boxes = generate_predicted_boxes(anchors, data_dict["batch_size"], cls_preds, box_preds, dir_preds,
-                                              self.model_cfg.get("DIR_OFFSET", 0.78539), self.model_cfg.get("DIR_LIMIT_OFFSET", 0.0),
-                                              self.num_dir_bins)
-        data_dict.update(batch_cls_preds=cls, batch_box_preds=boxes, cls_preds_normalized=False)
+        with torch.set_grad_enabled(self.training and torch.is_grad_enabled()):
+            cls_preds, box_preds = pick(self.conv_cls(x)), pick(self.conv_box(x))
+            dir_preds = pick(self.conv_dir_cls(x)) if self.conv_dir_cls is not None else None
+        self.forward_ret_dict.update(cls_preds=cls_preds, box_preds=box_preds, dir_cls_preds=dir_preds)
+        if self.training:
+            self._train_targets(data_dict)
+        if not self.training or self.predict_boxes_when_training:
+            self._predict(data_dict, cls_preds, box_preds, dir_preds)
         return data_dict
 
 
@@ -357,10 +395,13 @@ class AnchorHeadSingleV2(AnchorHeadSingle):
 
     SHARD_C = 64
 
-    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, conv_math="f16x2", **kwargs):
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, conv_math="f16x2",
+                 predict_boxes_when_training=True, **kwargs):
         torch.nn.Module.__init__(self)
         from .models import Conv2d
         self.model_cfg, self.num_class, self.class_names = model_cfg, num_class, list(class_names)
+        self.predict_boxes_when_training = bool(predict_boxes_when_training)   # reference ctor arg (anchor_head_single.py:32-33)
+        self.anchors = None
         self.range = [float(v) for v in point_cloud_range]
         self.voxel_size = (self.range[3] - self.range[0]) / float(grid_size[0])
         agc = model_cfg["ANCHOR_GENERATOR_CONFIG"]
@@ -464,11 +505,8 @@ class AnchorHeadSingleV2(AnchorHeadSingle):
                 cls_preds, box_preds = pick(cls_r), pick(box_r)
                 dir_preds = pick(dir_r) if dir_r is not None else None
         self.forward_ret_dict.update(cls_preds=cls_preds, box_preds=box_preds, dir_cls_preds=dir_preds)
-        if not self.training or self.model_cfg.get("PREDICT_BOXES_WHEN_TRAINING", False):
-            with torch.no_grad():
-                cls, boxes = generate_predicted_boxes(self.anchors, data_dict["batch_size"], cls_preds.detach(), box_preds.detach(),
-                                                      dir_preds.detach() if dir_preds is not None else None,
-                                                      self.model_cfg.get("DIR_OFFSET", 0.78539), self.model_cfg.get("DIR_LIMIT_OFFSET", 0.0),
-                                                      self.num_dir_bins)
-            data_dict.update(batch_cls_preds=cls, batch_box_preds=boxes, cls_preds_normalized=False)
+        if self.training:                                  # anchor_head_single.py:176-181: targets on the MASKED anchors
+            self._train_targets(data_dict)
+        if not self.training or self.predict_boxes_when_training:
+            self._predict(data_dict, cls_preds, box_preds, dir_preds)
         return data_dict

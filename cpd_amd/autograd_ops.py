@@ -51,7 +51,8 @@ class GatherConv(torch.autograd.Function):
             ops.gather_conv(inp, c_in, packed, None, 1, spec.n_out, c_out, None, b.repeat(u2) if b is not None else None,
                             out=out, out_row_map=spec.up_map, out_col_group=c_bn, dense=spec.dense, math=spec.math)
         else:
-            out = ops.gather_conv(inp, c_in, packed, spec.nbr, kv, spec.n_out, c_out, None, b, dense=spec.dense, math=spec.math)
+            out = ops.gather_conv(inp, c_in, packed, spec.nbr, kv, spec.n_out, c_out, None, b, dense=spec.dense, math=spec.math,
+                                  guard=True)           # f16x2: inputs of the module-by-module path come from torch ops -- measured
         ctx.save_for_backward(inp, w)
         ctx.spec = spec
         ctx.has_bias = bias is not None
@@ -115,5 +116,12 @@ class Densify(torch.autograd.Function):
 
 
 def gather_conv(inp, w_kio, bias, spec):
-    """Differentiable when any of (inp, w_kio, bias) requires grad and grad mode is on; otherwise the plain launch."""
-    return GatherConv.apply(inp, w_kio, bias, spec)
+    """Differentiable when any of (inp, w_kio, bias) requires grad and grad mode is on; otherwise the plain launch on the
+    module's cached packed image -- no autograd node, no copy of the permuted weight."""
+    needs = torch.is_grad_enabled() and (inp.requires_grad or w_kio.requires_grad or (bias is not None and bias.requires_grad))
+    if needs or spec.packed is None or spec.mode == "up":
+        return GatherConv.apply(inp, w_kio, bias, spec)
+    kv, c_in, c_out = w_kio.shape
+    b = bias.detach().contiguous().float() if bias is not None else None
+    return ops.gather_conv(inp.contiguous().float(), c_in, spec.packed, spec.nbr, kv, spec.n_out, c_out, None, b, dense=spec.dense,
+                           math=spec.math, guard=True)

@@ -50,6 +50,8 @@ struct GcParams {
     const void *wb;           // split image of the weights (bf16x3 or f16x2, after the fp32 image) or NULL
     const uint32_t *in_absmax; // f16x2 only, or NULL: device word holding the bits of max |in| -- the kernel scales `in` by the power of two
                               // that puts it at [2^14, 2^15) before the split and undoes it in the epilogue (gradients: fp16's range)
+    uint32_t *out_absmax;     // or NULL: absmax block (CPD_ABSMAX_SLOTS words, one per 128-byte line) raised to the bits of max |out| by the
+                              // epilogue -- the `in_absmax` of the layers that read `out` (the range guard of the f16x2 inference path)
     const float *dsc;         // f16x2 only: per output column, the power of two that undoes the weights' pre-scale (or NULL)
     const int32_t *nbr;
     const uint32_t *tapmask;  // per 16-row sub-tile: bit t = some row has a neighbour at tap t (or NULL)
@@ -129,6 +131,7 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
         grp[nt] = p.col_group ? col / p.col_group : 0;
         cloc[nt] = col - grp[nt] * p.col_group;
     }
+    uint32_t vmax = 0;                // bits of the largest |v| this lane stores (non-negative floats order like their bits; NaN on top)
 #pragma unroll
     for (int s = 0; s < MS; ++s) {
 #pragma unroll
@@ -147,6 +150,8 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
                 v = v * sc[nt] + sh[nt];
                 if (p.residual) v += p.residual[(size_t)row * p.res_ld + col];
                 if (p.relu) v = v > 0.f ? v : 0.f;
+                const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
+                vmax = vb > vmax ? vb : vmax;
                 if (p.col_group) {
                     if (grp[nt] != grp_have) {                 // one map entry per (row, group): a column tile rarely spans two
                         grp_have = grp[nt];
@@ -157,6 +162,19 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
                     p.out[orow * p.out_ld + col] = v;
                 }
             }
+        }
+    }
+    if (p.out_absmax) {
+        // one (rarely issued) atomic per wave: the slot is read past the L1 first and raised only when this wave holds a larger
+        // value -- after the first workgroups almost nobody does. Slots sit on CPD_ABSMAX_SLOTS different 128-byte lines.
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)vmax, o);
+            vmax = t > vmax ? t : vmax;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+            if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
         }
     }
 }
@@ -955,7 +973,15 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
     // instead of masking EXEC -- the stage loop of the 32-column kernel spent 156 scalar instructions per 12 MFMAs, most of them
     // EXEC bookkeeping around conditions the compiler could not prove wave-uniform
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
+    const int r = lane & 15, g = lane >> 4;          // MFMA fragment coordinates: row of the sub-tile, k-group
+    // GATHER coordinates (round 3): a quad of lanes fetches 64 CONTIGUOUS bytes of ONE row (lane -> row lane >> 2, 16-byte piece
+    // lane & 3 of each 64-byte half), and a 4 x 16 lane transpose (ds_bpermute) turns the two registers into the fragment of
+    // lane (r, g) = channels {4g..4g+3, 16+4g..16+4g+3} of the 32-channel block. Fragment-shaped loads (a quad = 4 different rows)
+    // cost the vector L1 one tag lookup PER LANE: 64 per instruction at one per clock -- profiles/r03_rowwave_pmc.json has these
+    // kernels at 0.64-0.84 L1 accesses per clock per CU, tools/gather_probe.hip prices the shapes: 14.9 B/clk/CU fragment-shaped,
+    // 22 quad-shaped, 20.4 with the transpose. The weights' k order follows through their LDS image (stage_commit).
+    const int qr = lane >> 2, qj = lane & 3;
+    const int tsrc = (4 * r + g) << 2;               // ds_bpermute source of fragment lane (r, g): quad lane g of row r
     const int item = xcd_remap(blockIdx.x, gridDim.x);
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
     const int row0 = rb * WG_ROWS + wave * (16 * MS), col0 = cb * BN;
@@ -991,7 +1017,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
     bool row_ok[MS];
 #pragma unroll
     for (int s = 0; s < MS; ++s) {
-        const int row = row0 + 16 * s + r;
+        const int row = row0 + 16 * s + qr;          // the row this lane GATHERS for
         row_ok[s] = row < p.n_out;
         rowc[s] = row_ok[s] ? row : p.n_out - 1;
     }
@@ -1040,8 +1066,8 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                     const int id = row_ok[s] ? idx[s] : -1;
                     az[s] = id < 0;
                     if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; continue; }
-                    araw[s][0] = load_a<true>(p, id, kk * 32 + g * 8);
-                    araw[s][1] = load_a<true>(p, id, kk * 32 + g * 8 + 4);
+                    araw[s][0] = load_a<true>(p, id, kk * 32 + qj * 4);
+                    araw[s][1] = load_a<true>(p, id, kk * 32 + 16 + qj * 4);
                 }
             }
         };
@@ -1061,21 +1087,36 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
         auto stage_commit = [&](uint32_t on) {      // B -> LDS, A -> split fragments
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
-                if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+                if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) {
+                    // k order of the LDS weight image = the gathered fragments': the packed slot (piece image q, k-group go, column n)
+                    // holds channels 8 go .. 8 go + 7; its half hf (channels 4 (2 go + hf) ..) goes to k-group (2 go + hf) & 3, position go >> 1
+                    const int id = j * 256 + tid;
+                    const int pgo = id / BN, n = id - pgo * BN, go = pgo & 3;
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 lo = {__float_as_uint(rbv[j][0]), __float_as_uint(rbv[j][1])}, hi = {__float_as_uint(rbv[j][2]), __float_as_uint(rbv[j][3])};
+                    char *img = sb + (pgo >> 2) * B_IMG + (go >> 1) * 8;
+                    *reinterpret_cast<u32x2 *>(img + ((((2 * go) & 3) * BN + n) << 4)) = lo;
+                    *reinterpret_cast<u32x2 *>(img + ((((2 * go + 1) & 3) * BN + n) << 4)) = hi;
+                }
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if ((on >> s) & 1u) {
+                    // rows without a neighbour become zeros in GATHER coordinates, then the lane transpose
+                    araw[s][0] = zero_if(araw[s][0], az[s]);
+                    araw[s][1] = zero_if(araw[s][1], az[s]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        araw[s][0][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(araw[s][0][k])));
+                        araw[s][1][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(araw[s][1][k])));
+                    }
                     if (CPD_GC_ABLATE & 4096) {      // timing only: the gathered bits taken as they are (what pre-split storage would allow)
 #pragma unroll
-                        for (int q = 0; q < NP; ++q) {
-                            const f32x4 v = az[s] ? f32x4{0.f, 0.f, 0.f, 0.f} : araw[s][q & 1];
-                            a[s][q] = __builtin_bit_cast(typename S::frag, v);
-                        }
+                        for (int q = 0; q < NP; ++q) a[s][q] = __builtin_bit_cast(typename S::frag, araw[s][q & 1]);
                         continue;
                     }
                     typename S::half lo[NP], hi[NP];
-                    S::split(SC ? zero_if(araw[s][0], az[s]) * in_s : zero_if(araw[s][0], az[s]), lo);
-                    S::split(SC ? zero_if(araw[s][1], az[s]) * in_s : zero_if(araw[s][1], az[s]), hi);
+                    S::split(SC ? araw[s][0] * in_s : araw[s][0], lo);
+                    S::split(SC ? araw[s][1] * in_s : araw[s][1], hi);
 #pragma unroll
                     for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
                 }
@@ -1684,7 +1725,8 @@ extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, i
 static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
                             const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
                             const float *residual, int res_ld, int relu, float *out, int out_ld,
-                            const int32_t *out_row_map, int out_col_group, int flags, const uint32_t *in_absmax, cpd_stream_t stream) {
+                            const int32_t *out_row_map, int out_col_group, int flags, const uint32_t *in_absmax, uint32_t *out_absmax,
+                            cpd_stream_t stream) {
     if (n_out == 0 && n_in >= 0 && c_in > 0 && c_out > 0 && kv > 0) return CPD_OK;   // an empty site set is a valid (empty) result
     if (!in || !packed_w || !out || n_in < 0 || n_out < 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || in_ld < c_in ||
         (residual && res_ld < c_out) || (!nbr && kv != 1) || (tapmask && kv > 32) || out_col_group < 0 || (out_col_group > 0 && !out_row_map) ||
@@ -1692,7 +1734,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
     GcParams p;
-    p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.in_absmax = in_absmax; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.in_absmax = in_absmax; p.out_absmax = out_absmax; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
@@ -1842,7 +1884,7 @@ extern "C" int cpd_conv3x3_rows_tile(int frames, int h, int w, int c_in, int c_o
 }
 static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
                              const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
-                             int out_ld, int flags, const uint32_t *in_absmax, cpd_stream_t stream) {
+                             int out_ld, int flags, const uint32_t *in_absmax, uint32_t *out_absmax, cpd_stream_t stream) {
     if (!in || !packed_w || !out || frames <= 0 || h <= 0 || w <= 0 || c_in <= 0 || c_out <= 0 || in_ld < c_in || out_ld < c_out ||
         (residual && res_ld < c_out))
         return CPD_ERR_ARG;
@@ -1852,7 +1894,7 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
     memset(&p, 0, sizeof(p));
     const int n_out = frames * h * w;
     const int math = split_math(flags, cpd_tuning());
-    p.in = in; p.w = packed_w; p.in_absmax = in_absmax;
+    p.in = in; p.w = packed_w; p.in_absmax = in_absmax; p.out_absmax = out_absmax;
     if (math == 2) { p.wb = packed_f16_ptr(packed_w, 9, c_in, c_out); p.dsc = packed_dsc_ptr(packed_w, 9, c_in, c_out); }
     else p.wb = packed_bf16_ptr(packed_w, 9, c_in, c_out);
     p.scale = scale; p.shift = shift; p.residual = residual; p.out = out;
@@ -1901,7 +1943,7 @@ extern "C" int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, c
                                const float *residual, int res_ld, int relu, float *out, int out_ld,
                                const int32_t *out_row_map, int out_col_group, int flags, cpd_stream_t stream) {
     return gather_conv_impl(in, in_ld, n_in, c_in, packed_w, nbr, tapmask, kv, n_out, c_out, scale, shift, residual, res_ld, relu, out,
-                            out_ld, out_row_map, out_col_group, flags, nullptr, stream);
+                            out_ld, out_row_map, out_col_group, flags, nullptr, nullptr, stream);
 }
 extern "C" int cpd_gather_conv_scaled(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
                                       const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
@@ -1909,17 +1951,55 @@ extern "C" int cpd_gather_conv_scaled(const float *in, int in_ld, int n_in, int 
                                       const int32_t *out_row_map, int out_col_group, int flags, const uint32_t *in_absmax,
                                       cpd_stream_t stream) {
     return gather_conv_impl(in, in_ld, n_in, c_in, packed_w, nbr, tapmask, kv, n_out, c_out, scale, shift, residual, res_ld, relu, out,
-                            out_ld, out_row_map, out_col_group, flags, in_absmax, stream);
+                            out_ld, out_row_map, out_col_group, flags, in_absmax, nullptr, stream);
+}
+extern "C" int cpd_gather_conv_ranged(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
+                                      const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
+                                      const float *residual, int res_ld, int relu, float *out, int out_ld,
+                                      const int32_t *out_row_map, int out_col_group, int flags, const uint32_t *in_absmax,
+                                      uint32_t *out_absmax, cpd_stream_t stream) {
+    return gather_conv_impl(in, in_ld, n_in, c_in, packed_w, nbr, tapmask, kv, n_out, c_out, scale, shift, residual, res_ld, relu, out,
+                            out_ld, out_row_map, out_col_group, flags, in_absmax, out_absmax, stream);
 }
 extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
                                 const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
                                 int out_ld, int flags, cpd_stream_t stream) {
     return conv3x3_rows_impl(in, in_ld, frames, h, w, c_in, packed_w, c_out, scale, shift, residual, res_ld, relu, out, out_ld, flags,
-                             nullptr, stream);
+                             nullptr, nullptr, stream);
 }
 extern "C" int cpd_conv3x3_rows_scaled(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
                                        const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
                                        int out_ld, int flags, const uint32_t *in_absmax, cpd_stream_t stream) {
     return conv3x3_rows_impl(in, in_ld, frames, h, w, c_in, packed_w, c_out, scale, shift, residual, res_ld, relu, out, out_ld, flags,
-                             in_absmax, stream);
+                             in_absmax, nullptr, stream);
+}
+extern "C" int cpd_conv3x3_rows_ranged(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
+                                       const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,
+                                       int out_ld, int flags, const uint32_t *in_absmax, uint32_t *out_absmax, cpd_stream_t stream) {
+    return conv3x3_rows_impl(in, in_ld, frames, h, w, c_in, packed_w, c_out, scale, shift, residual, res_ld, relu, out, out_ld, flags,
+                             in_absmax, out_absmax, stream);
+}
+// bits of max |x| over n rows x c columns (row pitch ld) raised into an absmax block: the range of a tensor no kernel of this
+// library produced (the first split layer of a chain fed from outside)
+__global__ void __launch_bounds__(256) absmax_rows_kernel(const float *__restrict__ x, int ld, long long n, int c, uint32_t *__restrict__ block) {
+    uint32_t m = 0;
+    const long long total = n * c;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c;
+        const uint32_t b = __float_as_uint(x[r * ld + (i - r * c)]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(block + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE, m);
+}
+extern "C" int cpd_absmax_rows(const float *x, int ld, long long n, int c, uint32_t *absmax_block, cpd_stream_t stream) {
+    if (!x || !absmax_block || n < 0 || c <= 0 || ld < c) return CPD_ERR_ARG;
+    if (n == 0) return CPD_OK;
+    const long long blocks = cpd_div_up(n * c, 256 * 8);
+    absmax_rows_kernel<<<(unsigned)(blocks > 2048 ? 2048 : blocks), 256, 0, cpd_s(stream)>>>(x, ld, n, c, absmax_block);
+    return cpd_check_launch();
 }

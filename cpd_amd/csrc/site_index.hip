@@ -250,6 +250,18 @@ __global__ void __launch_bounds__(256) densify_nhwc_kernel(const float *__restri
     reinterpret_cast<float4 *>(out)[(pix * g.d + q.y) * c4 + k] = v;
 }
 
+// channels-last pixels with the REFERENCE's channel order c*D + z (what view(N, C*D, H, W) of spconv's dense() gives): lanes run over
+// the channels of a site, so a wave writes D-strided floats of one pixel
+__global__ void __launch_bounds__(256) densify_nhwc_cd_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                              int n, int c, Grid g, float *__restrict__ out) {
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int i = (int)(tid / c), k = (int)(tid % c);
+    if (i >= n) return;
+    int4 q = reinterpret_cast<const int4 *>(idx)[i];
+    size_t pix = ((size_t)q.x * g.h + q.z) * g.w + q.w;
+    out[(pix * c + k) * g.d + q.y] = feat[(size_t)i * c + k];
+}
+
 __global__ void __launch_bounds__(256) densify_nchw_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
                                                            int n, int c, Grid g, float *__restrict__ out) {
     // lanes run over sites (canonical order => consecutive x), channels looped through LDS-free
@@ -363,7 +375,7 @@ extern "C" int cpd_order_rows_by_taps(const int32_t *indices, int n, int batch, 
         return CPD_ERR_ARG;
     for (int d = 0; d < 3; ++d)
         if (ksize[d] <= 0 || !(ksize[d] & 1)) return CPD_ERR_ARG;
-    if (ksize[0] * ksize[1] * ksize[2] > 32) return CPD_ERR_UNSUPPORTED;
+    if (ksize[0] * ksize[1] * ksize[2] > 32 || ksize[2] > 32) return CPD_ERR_UNSUPPORTED;
     if (chunk_rows != 1024 && chunk_rows != 4096 && chunk_rows != 8192 && chunk_rows != 16384) return CPD_ERR_UNSUPPORTED;
     if (workspace_bytes < (size_t)(n > 0 ? n : 1) * 4) return CPD_ERR_WORKSPACE;
     if (n == 0) return CPD_OK;
@@ -407,6 +419,7 @@ extern "C" int cpd_conv_out_shape(const int32_t in_shape[3], const int32_t ksize
 static int rulebook_launch(const int32_t *out_idx, int n_out, int batch, const int32_t in_shape[3], const int32_t k[3],
                            const int32_t st[3], const int32_t pd[3], const void *index, int32_t *nbr, uint32_t *tapmask,
                            hipStream_t s) {
+    if (k[2] > 32) return CPD_ERR_UNSUPPORTED;       // a row's kw taps must fit two bitmap words (rulebook_kernel's per-row word cache)
     // the index was carved with some capacity; pointers before perm do not depend on it
     IndexView v = index_carve(const_cast<void *>(index), batch, in_shape, 1);
     Grid g{batch, in_shape[0], in_shape[1], in_shape[2]};
@@ -487,6 +500,18 @@ extern "C" int cpd_densify_nhwc(const float *feat, const int32_t *indices, int n
     CPD_HIP_TRY(hipMemsetAsync(out, 0, total * sizeof(float), s));
     long long threads = (long long)n * (c / 4);
     if (threads > 0) densify_nhwc_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(feat, indices, n, c / 4, g, out);
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_densify_nhwc_cd(const float *feat, const int32_t *indices, int n, int c, int batch,
+                                   const int32_t shape_zyx[3], float *out, cpd_stream_t stream) {
+    if (!valid_shape(batch, shape_zyx) || n < 0 || c <= 0 || !out || (n > 0 && (!feat || !indices))) return CPD_ERR_ARG;
+    hipStream_t s = cpd_s(stream);
+    Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
+    size_t total = (size_t)batch * shape_zyx[0] * shape_zyx[1] * shape_zyx[2] * c;
+    CPD_HIP_TRY(hipMemsetAsync(out, 0, total * sizeof(float), s));
+    long long threads = (long long)n * c;
+    if (threads > 0) densify_nhwc_cd_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(feat, indices, n, c, g, out);
     return cpd_check_launch();
 }
 

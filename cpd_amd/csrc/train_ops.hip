@@ -12,6 +12,7 @@
 // The input gradient itself is cpd_gather_conv again, on transposed (and, for SubM / stride-1
 // convs, tap-flipped) weights with the same or the transposed rulebook.
 #include "common.h"
+#include "site_index_layout.h"
 
 #ifndef CPD_WG_ABLATE
 #define CPD_WG_ABLATE 0      // diagnostic builds of the split weight-gradient kernel (wrong results, timing only): 1 no row loads, 2 no MFMAs, 4 no split / LDS image writes
@@ -749,9 +750,12 @@ __device__ __forceinline__ int32_t lookup_canonical(const uint64_t *bitmap, cons
 __global__ void __launch_bounds__(256)
 rulebook_transpose_kernel(const int32_t *__restrict__ in_idx, int n_in, GridT go, int kd, int kh, int kw, int sd, int sh, int sw,
                           int pd, int ph, int pw, const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
-                          int32_t *__restrict__ nbr_t) {
+                          const int32_t *__restrict__ perm_own, const int32_t *__restrict__ flags, int32_t *__restrict__ nbr_t) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_in) return;
+    // the output level's rows may have been re-ordered after its index was built (cpd_index_set_order, tap-pattern order): the
+    // index then names the rank -> row map to go through, exactly as rulebook_kernel does
+    const int32_t *perm = index_order(flags, perm_own);
     const int4 q = reinterpret_cast<const int4 *>(in_idx)[i];
     int t = 0;
     for (int tz = 0; tz < kd; ++tz)
@@ -763,6 +767,7 @@ rulebook_transpose_kernel(const int32_t *__restrict__ in_idx, int n_in, GridT go
                     const int oz = nz / sd, oy = ny / sh, ox = nx / sw;
                     if (oz < go.d && oy < go.h && ox < go.w)
                         rr = lookup_canonical(bitmap, base, (((long long)q.x * go.d + oz) * go.h + oy) * go.w + ox);
+                    if (rr >= 0 && perm) rr = perm[rr];
                 }
                 nbr_t[(size_t)t * n_in + i] = rr;
             }
@@ -1392,16 +1397,16 @@ extern "C" int cpd_rulebook_conv_transpose(const int32_t *in_indices, int n_in, 
     if (!in_indices || !out_index || !nbr_t || n_in <= 0 || batch <= 0) return CPD_ERR_ARG;
     int rc = cpd_conv_out_shape(in_shape, ksize, stride, pad, os);
     if (rc) return rc;
-    // the output index is canonical (built by cpd_conv_outset): header 256 B, bitmap, base
-    const long long cells = (long long)batch * os[0] * os[1] * os[2];
-    const long long words = (cells + 63) / 64;
-    const char *b = (const char *)out_index;
-    const uint64_t *bitmap = (const uint64_t *)(b + 256);
-    const uint32_t *base = (const uint32_t *)(b + 256 + cpd_align((size_t)words * 8));
+    if (ksize[2] > 32) return CPD_ERR_UNSUPPORTED;
+    // the output index (cpd_conv_outset / cpd_index_build): flags | bitmap | base | spine | own rank -> row map; which map applies
+    // (none, its own, a caller-owned one) is read from the flags on the device
+    IndexView v = index_carve(const_cast<void *>(out_index), batch, os, 1);
+    const uint64_t *bitmap = v.bitmap;
+    const uint32_t *base = v.base;
     GridT go{batch, os[0], os[1], os[2]};
     rulebook_transpose_kernel<<<cpd_div_up(n_in, 256), 256, 0, cpd_s(st)>>>(in_indices, n_in, go, ksize[0], ksize[1], ksize[2],
                                                                            stride[0], stride[1], stride[2], pad[0], pad[1],
-                                                                           pad[2], bitmap, base, nbr_t);
+                                                                           pad[2], bitmap, base, v.perm, v.flags, nbr_t);
     return cpd_check_launch();
 }
 

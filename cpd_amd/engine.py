@@ -54,6 +54,10 @@ class ModelConfig:
     # rows of level 0 inside the engine: "canonical" = ascending (frame, z, y, x), straight from the occupancy bitmap's ranks
     # (no first-appearance scan, canonical level-0 index, coherent lookups for the rulebooks built on it); "appearance" = the
     # voxelizer's boundary order (Point2VoxelCPU3d). Same voxels and features either way.
+    # f16x2 only: every conv epilogue records the bits of max |output| and the next layer pre-scales its input by a power of
+    # two taken from it (exact; the `*_f16s_*` kernels), so that an activation of ANY fp32 magnitude gives the fp32 answer where
+    # unguarded split-fp16 arithmetic overflows to inf / NaN at 65504. False = the unscaled kernels.
+    range_guard: bool = True
     voxel_row_order: str = "canonical"
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
     row_order: str = "taps"
@@ -301,10 +305,36 @@ class CenterPointEngine:
         return shape[0]
 
     # ------------------------------------------------------------------ forward pieces
-    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False):
-        return ops.gather_conv(x, layer.c_in, layer.w, nbr, layer.kv, n_out, layer.c_out, layer.scale, layer.shift,
-                               residual, layer.relu, out=out, out_row_map=out_row_map, out_col_group=out_col_group,
-                               dense=dense, math=self.cfg.conv_math)
+    # Range bookkeeping of the f16x2 path: `self._rb` = block of the tensor the NEXT conv reads (None: unknown / not guarded).
+    # Every _conv call reads it as in_absmax and replaces it by a fresh block its epilogue fills (`keep_rb`: write into the current
+    # output block instead -- the second half of a concat buffer).
+    def _range_reset(self):
+        self._rb = None
+        self._rb_next = 0
+        if self.cfg.conv_math == "f16x2" and self.cfg.range_guard:
+            if getattr(self, "_rb_pool", None) is None:
+                self._rb_pool = ops.absmax_blocks(96, self.device)
+            else:
+                self._rb_pool.zero_()
+        else:
+            self._rb_pool = None
+
+    def _range_new(self):
+        if self._rb_pool is None:
+            return None
+        b = self._rb_pool[self._rb_next]
+        self._rb_next += 1
+        return b
+
+    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False, in_rb="cur",
+              out_rb="new"):
+        rb_in = self._rb if in_rb == "cur" else in_rb
+        rb_out = self._range_new() if out_rb == "new" else out_rb
+        y = ops.gather_conv(x, layer.c_in, layer.w, nbr, layer.kv, n_out, layer.c_out, layer.scale, layer.shift,
+                            residual, layer.relu, out=out, out_row_map=out_row_map, out_col_group=out_col_group,
+                            dense=dense, math=self.cfg.conv_math, in_absmax=rb_in, out_absmax=rb_out)
+        self._rb = rb_out
+        return y
 
     def _blocks(self, blocks, x, nbr):
         n = x.shape[0]
@@ -322,6 +352,7 @@ class CenterPointEngine:
         if index is None:
             index = ops.SiteIndex.build(coords, batch, shape)
         nbr = ops.rulebook_subm(coords, index)               # 'subm1' and 'res1' are the same L0 table
+        self._range_reset()                                  # (the 5-channel input layer runs on the fp32 pipe: no block for `feats`)
         x = self._conv(L["conv_input"], feats, nbr, coords.shape[0])
         x = self._blocks(L["conv1"], x, nbr)
         levels = {"x_conv1": (x, coords, shape)}
@@ -346,6 +377,7 @@ class CenterPointEngine:
         out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
         nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
         x = self._conv(L["conv_out"], x, nbr_dn, out_idx.shape[0])
+        self._rb_stage = "backbone"                            # the densified map inherits this output's range block
         return levels, (x, out_idx, out_shape)
 
     def _bev_tables(self, batch, h, w):
@@ -374,6 +406,10 @@ class CenterPointEngine:
         (center_head.py:323-330) on channels-last rows [batch*h*w, C]."""
         cfg = self.cfg
         T = self._bev_tables(batch, h, w)
+        if getattr(self, "_rb_stage", None) != "backbone":     # called on its own (tests, tools): the input's range is unknown
+            self._range_reset()
+        self._rb_stage = None
+        cat_rb = self._range_new()                             # ONE block for the concat buffer: both deblocks raise it
         n_full = batch * h * w
         c_cat = sum(cfg.bev_num_upsample_filters)
         cat = torch.empty((n_full, c_cat), dtype=torch.float32, device=self.device)
@@ -395,13 +431,16 @@ class CenterPointEngine:
                 x = self._conv(cv, x, nbr_same, n_lvl, dense=True)
             cur_h, cur_w = ho, wo
             dst = cat[:, col:col + c_up]
+            x_rb = self._rb                                    # the next level goes on from x, not from the deblock's output
             if u == 1:
-                self._conv(de, x, None, n_lvl, out=dst, dense=True)
+                self._conv(de, x, None, n_lvl, out=dst, dense=True, out_rb=cat_rb)
             elif u == 2 and (ho * 2, wo * 2) == (h, w):
-                self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up, dense=True)
+                self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up, dense=True, out_rb=cat_rb)
             else:
                 raise NotImplementedError("upsample stride outside the shipped configs")
+            self._rb = x_rb
             col += c_up
+        self._rb = cat_rb
         s = self._conv(self.shared, cat, T["s1"][0], n_full, dense=True)
         h1 = self._conv(self.head1, s, T["s1"][0], n_full, dense=True)
         out = torch.empty((n_full, self.head_ld), dtype=torch.float32, device=self.device)
@@ -464,19 +503,20 @@ class CenterPointEngine:
             # (workspace) per group, rows concatenated with the frame index offset; the level-0 index is built over the whole list
             g = self.cfg.voxelizer_group
             groups = [points_list[i:i + g] for i in range(0, batch, g)]
+            if len(groups[-1]) == 1:                        # e.g. batch = g + 1: the batched call wants >= 2 frames -- borrow one
+                groups[-1].insert(0, groups[-2].pop())
             while len(self._group_voxelizers) < len(groups):
                 self._group_voxelizers.append(ops.Voxelizer(self.cfg.voxel_size, self.cfg.point_cloud_range, self.cfg.num_point_features,
                                                             self.cfg.max_points_per_voxel, self.cfg.max_voxels, device=self.device))
-            outs = [vz.batch(grp) if len(grp) > 1 else None for vz, grp in zip(self._group_voxelizers, groups)]
-            if any(o is None for o in outs):
-                raise NotImplementedError("batch size %d leaves a group of one frame (voxelizer_group %d)" % (batch, g))
+            outs = [vz.batch(grp) for vz, grp in zip(self._group_voxelizers, groups)]
             totals = torch.stack([o[4][len(grp)] for o, grp in zip(outs, groups)]).tolist()       # the one read-back
             feats = torch.cat([o[3][:m] for o, m in zip(outs, totals)])
-            parts = []
-            for k, (o, m) in enumerate(zip(outs, totals)):
+            parts, first = [], 0
+            for o, m, grp in zip(outs, totals, groups):
                 c = o[1][:m].clone()
-                c[:, 0] += k * g
+                c[:, 0] += first                            # frame index within the whole batch
                 parts.append(c)
+                first += len(grp)
             coords = torch.cat(parts)
         else:
             while len(self._voxelizers) < batch:           # one workspace per in-flight frame of the batch

@@ -23,6 +23,7 @@ import torch.nn as nn
 from . import autograd_ops, iou3d_nms_utils, ops, train_ops
 from . import spconv as _spconv_pkg
 from .spconv import pytorch as spconv
+from .spconv.pytorch.conv import default_conv_math, fold_batchnorm as _fold_batchnorm, fusable_eval as _fusable_eval
 
 
 class AttrDict(dict):
@@ -94,6 +95,12 @@ class SparseBasicBlock(spconv.SparseModule):
         self.downsample, self.stride = downsample, stride
 
     def forward(self, x):
+        if self.downsample is None and _fusable_eval(self) and self.bn1.track_running_stats:
+            # eval, no autograd: two launches -- conv1 with bn1 + ReLU in its epilogue, conv2 with bn2 + identity + ReLU
+            s1, t1 = _fold_batchnorm(self.bn1, self.conv1.bias)
+            s2, t2 = _fold_batchnorm(self.bn2, self.conv2.bias)
+            out = self.conv1(x, scale=s1, shift=t1, relu=True)
+            return self.conv2(out, scale=s2, shift=t2, residual=x.features.contiguous().float(), relu=True)
         identity = x
         out = self.conv1(x)
         out = replace_feature(out, self.relu(self.bn1(out.features)))
@@ -187,6 +194,12 @@ class HeightCompression(nn.Module):
 
     def forward(self, batch_dict):
         sp = batch_dict["encoded_spconv_tensor"]
+        if _fusable_eval(self) and sp.features.is_cuda:
+            # same (N, C*D, H, W) tensor, channel = c*D + z, in channels_last memory: the BEV convs read it without a transpose pass
+            rows = ops.densify_nhwc_cd(sp.features.float(), sp.indices, sp.batch_size, sp.spatial_shape)
+            batch_dict["spatial_features"] = _tag(rows.permute(0, 3, 1, 2), getattr(sp.features, "_cpd_rb", None))
+            batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]
+            return batch_dict
         dense = sp.dense()
         n, c, d, h, w = dense.shape
         batch_dict["spatial_features"] = dense.view(n, c * d, h, w)
@@ -204,23 +217,71 @@ def _nchw(rows, b, h, w):
     return rows.view(b, h, w, rows.shape[1]).permute(0, 3, 1, 2)   # NCHW view, channels_last strides
 
 
+def _range_in_out(x, c_in, math, out_rb=None):
+    """f16x2 range guard of the fused module path: (block of the input map -- the attribute its producer left, else measured --,
+    block this launch fills: the caller's `out_rb` or a fresh one); (None, None) for the other arithmetics."""
+    if math != "f16x2":
+        return None, None
+    rb_in = None
+    if c_in % 32 == 0:
+        rb_in = getattr(x, "_cpd_rb", None)
+        if rb_in is None:
+            rb_in = ops.absmax_rows(_rows(x.float()), c_in)
+    return rb_in, (out_rb if out_rb is not None else ops.absmax_blocks(1, x.device)[0])
+
+
+def _tag(t, rb):
+    if rb is not None:
+        t._cpd_rb = rb
+    return t
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d parameters (state_dict compatible), forward on cpd_gather_conv with a dense pixel
     rulebook. k x k, one stride, zero padding."""
     _tables = {}
 
+    @property
+    def math(self):
+        """this layer's arithmetic: its own `conv_math` attribute, else the package default (spconv.install(conv_math=...))"""
+        m = getattr(self, "conv_math", None)
+        return m if m is not None else default_conv_math()
+
+    def _table(self, b, h, w, p, device):
+        k, s = self.kernel_size[0], self.stride[0]
+        key = (b, h, w, k, s, p, device)
+        if key not in Conv2d._tables:
+            Conv2d._tables[key] = ops.rulebook_conv2d(b, h, w, k, k, s, p, device)
+        return key, Conv2d._tables[key]
+
+    def _packed(self):
+        k = self.kernel_size[0]
+        ver = (self.weight._version, self.weight.data_ptr())
+        if getattr(self, "_pk_ver", None) != ver:
+            self._pk = ops.pack_weight(self.weight.detach().permute(2, 3, 1, 0).reshape(k * k, self.in_channels, self.out_channels).contiguous())
+            self._pk_ver = ver
+        return self._pk
+
+    def forward_fused(self, x, scale=None, shift=None, relu=False, extra_pad=0, out=None, out_rb=None):
+        """Inference launch with the epilogue fused: zero padding of a preceding ZeroPad2d folded into the pixel table
+        (extra_pad), folded BatchNorm2d (scale, shift; shift already carries the bias) and ReLU in the conv kernel. `x`:
+        (B, C, H, W) in any memory format (channels_last = no copy); `out`: optional [B*Ho*Wo, >= Cout] row view to write."""
+        b, c, h, w = x.shape
+        k = self.kernel_size[0]
+        _, (nbr, ho, wo) = self._table(b, h, w, self.padding[0] + extra_pad, x.device)
+        if shift is None and self.bias is not None:
+            shift = self.bias.detach().float()
+        rb_in, rb_out = _range_in_out(x, c, self.math, out_rb)
+        rows = ops.gather_conv(_rows(x.float()), c, self._packed(), nbr, k * k, b * ho * wo, self.out_channels, scale, shift, None, relu,
+                               out=out, dense=True, math=self.math, in_absmax=rb_in, out_absmax=rb_out)
+        return _tag(_nchw(rows[:, :self.out_channels] if out is not None else rows, b, ho, wo), rb_out)
+
     def forward(self, x):
         assert x.is_cuda, "cpd_amd.models.Conv2d runs on the GPU only"
         b, c, h, w = x.shape
         k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
-        key = (b, h, w, k, s, p, x.device)
-        if key not in Conv2d._tables:
-            Conv2d._tables[key] = ops.rulebook_conv2d(b, h, w, k, k, s, p, x.device)
-        nbr, ho, wo = Conv2d._tables[key]
-        ver = (self.weight._version, self.weight.data_ptr())
-        if getattr(self, "_pk_ver", None) != ver:
-            self._pk = ops.pack_weight(self.weight.detach().permute(2, 3, 1, 0).reshape(k * k, c, self.out_channels).contiguous())
-            self._pk_ver = ver
+        key, (nbr, ho, wo) = self._table(b, h, w, p, x.device)
+        self._packed()
 
         def adjoint():          # transposed pixel table of a strided / unpadded conv (input gradient)
             tkey = key + ("t",)
@@ -229,7 +290,7 @@ class Conv2d(nn.Conv2d):
             return Conv2d._tables[tkey]
 
         same = s == 1 and 2 * p == k - 1
-        spec = autograd_ops.ConvSpec(nbr, k * k, b * ho * wo, dense=True, math=getattr(self, "conv_math", "f32"),
+        spec = autograd_ops.ConvSpec(nbr, k * k, b * ho * wo, dense=True, math=self.math,
                                      mode="same" if same else "strided", adjoint=adjoint, packed=self._pk)
         w_kio = self.weight.permute(2, 3, 1, 0).reshape(k * k, c, self.out_channels)
         out = autograd_ops.gather_conv(_rows(x.float()), w_kio, self.bias, spec)
@@ -239,33 +300,101 @@ class Conv2d(nn.Conv2d):
 class ConvTranspose2d(nn.ConvTranspose2d):
     """kernel == stride, no padding (base_bev_backbone.py:52-56): one 1x1 GEMM over the k*k taps."""
     _maps = {}
+    math = Conv2d.math
+
+    def _packed(self):
+        u = self.kernel_size[0]
+        ver = (self.weight._version, self.weight.data_ptr())
+        if getattr(self, "_pk_ver", None) != ver:
+            self._pk = ops.pack_weight(self.weight.detach().permute(0, 2, 3, 1).reshape(1, self.in_channels, u * u * self.out_channels).contiguous())
+            self._pk_ver = ver
+        return self._pk
+
+    @staticmethod
+    def _up_map(b, h, w, u, device):
+        key = (b, h, w, u, device)
+        if key not in ConvTranspose2d._maps:
+            H, W = h * u, w * u
+            bi = torch.arange(b, device=device).view(-1, 1, 1)
+            yy = torch.arange(h, device=device).view(1, -1, 1)
+            xx = torch.arange(w, device=device).view(1, 1, -1)
+            maps = [((bi * H + u * yy + a) * W + u * xx + bb).reshape(-1) for a in range(u) for bb in range(u)]
+            ConvTranspose2d._maps[key] = torch.stack(maps).to(torch.int32).contiguous()
+        return ConvTranspose2d._maps[key]
+
+    def forward_fused(self, x, scale=None, shift=None, relu=False, extra_pad=0, out=None, out_rb=None):
+        """Inference launch: the u*u taps as column groups of one 1x1 GEMM scattered to the upsampled rows, folded BatchNorm2d
+        + ReLU in the epilogue; `out`: optional [B*H*W, >= Cout] row view (e.g. a column block of the concat buffer)."""
+        assert extra_pad == 0
+        b, c, h, w = x.shape
+        u = self.kernel_size[0]
+        assert self.stride[0] == u and self.padding[0] == 0
+        H, W, co = h * u, w * u, self.out_channels
+        if shift is None and self.bias is not None:
+            shift = self.bias.detach().float()
+        if out is None:
+            out = torch.empty((b * H * W, co), dtype=torch.float32, device=x.device)
+        rep = (lambda t: t.repeat(u * u) if t is not None and u > 1 else t)
+        rb_in, rb_out = _range_in_out(x, c, self.math, out_rb)
+        if u == 1:
+            ops.gather_conv(_rows(x.float()), c, self._packed(), None, 1, b * h * w, co, scale, shift, None, relu, out=out, dense=True,
+                            math=self.math, in_absmax=rb_in, out_absmax=rb_out)
+        else:
+            ops.gather_conv(_rows(x.float()), c, self._packed(), None, 1, b * h * w, u * u * co, rep(scale), rep(shift), None, relu,
+                            out=out, out_row_map=self._up_map(b, h, w, u, x.device), out_col_group=co, dense=True, math=self.math,
+                            in_absmax=rb_in, out_absmax=rb_out)
+        return _tag(_nchw(out[:, :co], b, H, W), rb_out)
 
     def forward(self, x):
         b, c, h, w = x.shape
         u = self.kernel_size[0]
         assert self.stride[0] == u and self.padding[0] == 0
-        ver = (self.weight._version, self.weight.data_ptr())
-        if getattr(self, "_pk_ver", None) != ver:
-            self._pk = ops.pack_weight(self.weight.detach().permute(0, 2, 3, 1).reshape(1, c, u * u * self.out_channels).contiguous())
-            self._pk_ver = ver
+        self._packed()
         H, W = h * u, w * u
         w_kio = self.weight.permute(0, 2, 3, 1).reshape(1, c, u * u * self.out_channels)
-        math = getattr(self, "conv_math", "f32")
+        math = self.math
         if u == 1:
             spec = autograd_ops.ConvSpec(None, 1, b * h * w, dense=True, math=math, mode="same", packed=self._pk)
             out = autograd_ops.gather_conv(_rows(x.float()), w_kio, self.bias, spec)
         else:
-            key = (b, h, w, u, x.device)
-            if key not in ConvTranspose2d._maps:
-                bi = torch.arange(b, device=x.device).view(-1, 1, 1)
-                yy = torch.arange(h, device=x.device).view(1, -1, 1)
-                xx = torch.arange(w, device=x.device).view(1, 1, -1)
-                maps = [((bi * H + u * yy + a) * W + u * xx + bb).reshape(-1) for a in range(u) for bb in range(u)]
-                ConvTranspose2d._maps[key] = torch.stack(maps).to(torch.int32).contiguous()
-            spec = autograd_ops.ConvSpec(None, 1, b * h * w, dense=True, math=math, mode="up", up_map=ConvTranspose2d._maps[key],
+            spec = autograd_ops.ConvSpec(None, 1, b * h * w, dense=True, math=math, mode="up", up_map=self._up_map(b, h, w, u, x.device),
                                          up=u, n_up=b * H * W, packed=self._pk)
             out = autograd_ops.gather_conv(_rows(x.float()), w_kio, self.bias, spec)
         return _nchw(out, b, H, W)
+
+
+class DenseSequential(nn.Sequential):
+    """nn.Sequential (same children, same state_dict names) whose eval / no-autograd forward fuses what the reference writes as
+    separate modules: ZeroPad2d(p) -> Conv2d becomes the conv's own padding, Conv2d | ConvTranspose2d -> BatchNorm2d [-> ReLU]
+    one launch with the folded statistics and the ReLU in the conv epilogue (base_bev_backbone.py:31-59, center_head.py:21-27,
+    73-80). Maps stay channels-last in memory between layers. In training mode, or under autograd, it is nn.Sequential."""
+
+    def forward(self, x, out=None, out_rb=None):
+        mods = list(self)
+        if not _fusable_eval(*mods):
+            return super().forward(x)
+        i, pad = 0, 0
+        while i < len(mods):
+            m = mods[i]
+            i += 1
+            if isinstance(m, nn.ZeroPad2d) and i < len(mods) and isinstance(mods[i], Conv2d) and len(set(m.padding)) == 1:
+                pad = int(m.padding[0])
+                continue
+            if isinstance(m, (Conv2d, ConvTranspose2d)):
+                scale = shift = None
+                relu = False
+                if i < len(mods) and isinstance(mods[i], nn.BatchNorm2d) and mods[i].track_running_stats:
+                    scale, shift = _fold_batchnorm(mods[i], m.bias)
+                    i += 1
+                    if i < len(mods) and isinstance(mods[i], nn.ReLU):
+                        relu = True
+                        i += 1
+                last = i == len(mods)
+                x = m.forward_fused(x, scale, shift, relu, extra_pad=pad, out=out if last else None, out_rb=out_rb if last else None)
+                pad = 0
+                continue
+            x = m(x)
+        return x
 
 
 class BaseBEVBackbone(nn.Module):
@@ -282,14 +411,31 @@ class BaseBEVBackbone(nn.Module):
             for _ in range(layer_nums[idx]):
                 layers.extend([Conv2d(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
                                nn.BatchNorm2d(num_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()])
-            self.blocks.append(nn.Sequential(*layers))
-            self.deblocks.append(nn.Sequential(
+            self.blocks.append(DenseSequential(*layers))
+            self.deblocks.append(DenseSequential(
                 ConvTranspose2d(num_filters[idx], num_up[idx], up_strides[idx], stride=up_strides[idx], bias=False),
                 nn.BatchNorm2d(num_up[idx], eps=1e-3, momentum=0.01), nn.ReLU()))
         self.num_bev_features_post = sum(num_up)
 
     def forward(self, data_dict):
         x = data_dict["spatial_features"]
+        if len(self.blocks) > 1 and _fusable_eval(self):
+            # eval, no autograd: every deblock writes its column block of ONE channels-last concat buffer (no torch.cat pass)
+            cat, col = None, 0
+            cat_rb = ops.absmax_blocks(1, x.device)[0] if self.deblocks[0][0].math == "f16x2" else None    # one block for the concat
+            for i in range(len(self.blocks)):
+                x = self.blocks[i](x)
+                de = self.deblocks[i]
+                c_up = de[0].out_channels
+                if cat is None:
+                    b, _, h, w = x.shape
+                    u = de[0].kernel_size[0]
+                    H, W = h * u, w * u
+                    cat = torch.empty((b * H * W, self.num_bev_features_post), dtype=torch.float32, device=x.device)
+                de(x, out=cat[:, col:col + c_up], out_rb=cat_rb)
+                col += c_up
+            data_dict["st_features_2d"] = _tag(_nchw(cat, b, H, W), cat_rb)
+            return data_dict
         ups = []
         for i in range(len(self.blocks)):
             x = self.blocks[i](x)
@@ -307,10 +453,10 @@ class SeparateHead(nn.Module):
             out_c, num_conv = sep_head_dict[cur_name]["out_channels"], sep_head_dict[cur_name]["num_conv"]
             fc = []
             for _ in range(num_conv - 1):
-                fc.append(nn.Sequential(Conv2d(input_channels, input_channels, kernel_size=3, stride=1, padding=1, bias=use_bias),
-                                        nn.BatchNorm2d(input_channels), nn.ReLU()))
+                fc.append(DenseSequential(Conv2d(input_channels, input_channels, kernel_size=3, stride=1, padding=1, bias=use_bias),
+                                          nn.BatchNorm2d(input_channels), nn.ReLU()))
             fc.append(Conv2d(input_channels, out_c, kernel_size=3, stride=1, padding=1, bias=True))
-            fc = nn.Sequential(*fc)
+            fc = DenseSequential(*fc)
             if "hm" in cur_name:
                 fc[-1].bias.data.fill_(init_bias)
             else:
@@ -321,8 +467,71 @@ class SeparateHead(nn.Module):
                             nn.init.constant_(m.bias, 0)
             self.__setattr__(cur_name, fc)
 
+    def _fused_images(self, dev):
+        """All branches' first convs side by side (C -> n_heads * C, BatchNorm folded) and their output convs as one
+        block-diagonal conv (n_heads * C -> sum of the heads' channels): two launches for the whole SeparateHead, as in the
+        engine. Rebuilt when a parameter or a BatchNorm statistic changes."""
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = tuple((t._version, t.data_ptr()) for t in tensors)
+        cached = getattr(self, "_fused", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        names = list(self.sep_head_dict)
+        w1, s1, t1, slices = [], [], [], {}
+        c = self.__getattr__(names[0])[0][0].in_channels
+        n_out = sum(self.__getattr__(n)[1].out_channels for n in names)
+        w2 = torch.zeros(9, c * len(names), n_out)
+        b2 = torch.zeros(n_out)
+        col = 0
+        with torch.no_grad():
+            for hi, name in enumerate(names):
+                fc = self.__getattr__(name)
+                conv, bn, last = fc[0][0], fc[0][1], fc[1]
+                w1.append(conv.weight.detach().float().cpu().permute(2, 3, 1, 0).reshape(9, c, c))
+                sc, sh = _fold_batchnorm(bn, conv.bias)
+                s1.append(sc.cpu()); t1.append(sh.cpu())
+                co = last.out_channels
+                w2[:, hi * c:(hi + 1) * c, col:col + co] = last.weight.detach().float().cpu().permute(2, 3, 1, 0).reshape(9, c, co)
+                b2[col:col + co] = last.bias.detach().float().cpu()
+                slices[name] = (col, co)
+                col += co
+            img = dict(w1=ops.pack_weight(torch.cat(w1, dim=2).to(dev).contiguous()), s1=torch.cat(s1).to(dev), t1=torch.cat(t1).to(dev),
+                       w2=ops.pack_weight(w2.to(dev).contiguous()), b2=b2.to(dev), c=c, c1=c * len(names), n_out=n_out, slices=slices,
+                       ld=16 * ((n_out + 15) // 16))
+        self._fused = (key, img)
+        return img
+
+    def _fusable(self):
+        if not _fusable_eval(self):
+            return False
+        for name in self.sep_head_dict:
+            fc = self.__getattr__(name)
+            if len(fc) != 2 or not isinstance(fc[0], DenseSequential) or not fc[0][1].track_running_stats:
+                return False
+        return True
+
     def forward(self, x):
+        if self._fusable():
+            b, c, h, w = x.shape
+            img = self._fused_images(x.device)
+            nbr, _, _ = ops.rulebook_conv2d_cached(b, h, w, x.device)
+            n = b * h * w
+            math = self.__getattr__(next(iter(self.sep_head_dict)))[1].math
+            rb_in, rb_h1 = _range_in_out(x, c, math)
+            h1 = ops.gather_conv(_rows(x.float()), c, img["w1"], nbr, 9, n, img["c1"], img["s1"], img["t1"], None, True, dense=True, math=math,
+                                 in_absmax=rb_in, out_absmax=rb_h1)
+            rows = torch.empty((n, img["ld"]), dtype=torch.float32, device=x.device)
+            ops.gather_conv(h1, img["c1"], img["w2"], nbr, 9, n, img["n_out"], None, img["b2"], None, False, out=rows, dense=True, math=math,
+                            in_absmax=rb_h1)
+            maps = HeadMaps((name, _nchw(rows[:, c0:c0 + co], b, h, w)) for name, (c0, co) in img["slices"].items())
+            maps.rows, maps.slices, maps.ld = rows, img["slices"], img["ld"]
+            return maps
         return {name: self.__getattr__(name)(x) for name in self.sep_head_dict}
+
+
+class HeadMaps(dict):
+    """The maps of one SeparateHead as NCHW views of ONE channels-last row block (`rows` [B*H*W, ld], `slices` name -> (first
+    column, channels)): what the fused eval forward returns, and what lets decode + NMS run batched on the block."""
 
 
 class CenterHead(nn.Module):
@@ -339,7 +548,7 @@ class CenterHead(nn.Module):
             self.class_id_mapping_each_head.append(torch.tensor([class_names.index(x) for x in cur if x in class_names]))
         use_bias = model_cfg.get("USE_BIAS_BEFORE_NORM", False)
         sc = model_cfg.SHARED_CONV_CHANNEL
-        self.shared_conv = nn.Sequential(Conv2d(input_channels, sc, 3, stride=1, padding=1, bias=use_bias), nn.BatchNorm2d(sc), nn.ReLU())
+        self.shared_conv = DenseSequential(Conv2d(input_channels, sc, 3, stride=1, padding=1, bias=use_bias), nn.BatchNorm2d(sc), nn.ReLU())
         self.heads_list = nn.ModuleList()
         for cur in self.class_names_each_head:
             head_dict = {k: dict(v) for k, v in model_cfg.SEPARATE_HEAD_CFG.HEAD_DICT.items()}
@@ -351,6 +560,9 @@ class CenterHead(nn.Module):
     def generate_predicted_boxes(self, batch_size, pred_dicts):
         """center_head.py:252-303 with decode + NMS on the device (cpd_center_decode, cpd_nms_rotated)."""
         pp = self.model_cfg.POST_PROCESSING
+        if len(pred_dicts) == 1 and isinstance(pred_dicts[0], HeadMaps) and pp.NMS_CONFIG.NMS_TYPE == "nms_gpu" \
+                and pp.MAX_OBJ_PER_SAMPLE <= pp.NMS_CONFIG.NMS_PRE_MAXSIZE:
+            return self._predicted_boxes_batched(batch_size, pred_dicts[0])
         ret = [{"pred_boxes": [], "pred_scores": [], "pred_labels": []} for _ in range(batch_size)]
         for idx, pd in enumerate(pred_dicts):
             hm = pd["hm"]
@@ -375,6 +587,25 @@ class CenterHead(nn.Module):
             ret[b]["pred_scores"] = torch.cat(ret[b]["pred_scores"], dim=0)
             ret[b]["pred_labels"] = torch.cat(ret[b]["pred_labels"], dim=0) + 1
         return ret
+
+    def _predicted_boxes_batched(self, batch_size, maps):
+        """The same decode + class-agnostic NMS for ALL samples in five launches on the head's row block, one host read (the
+        per-sample counts): scores leave the decode sorted, so nms_gpu's topk(NMS_PRE_MAXSIZE) + sort are identities while
+        MAX_OBJ_PER_SAMPLE <= NMS_PRE_MAXSIZE (checked by the caller)."""
+        pp = self.model_cfg.POST_PROCESSING
+        rows, sl, ld = maps.rows, maps.slices, maps.ld
+        nc, h, w = maps["hm"].shape[1:]
+        boxes, scores, labels, counts = ops.center_decode(
+            rows[:, sl["hm"][0]:], rows[:, sl["center"][0]:], rows[:, sl["center_z"][0]:], rows[:, sl["dim"][0]:], rows[:, sl["rot"][0]:],
+            ld, 1, nc, h, w, pp.MAX_OBJ_PER_SAMPLE, float(self.feature_map_stride), list(self.voxel_size)[:2],
+            list(self.point_cloud_range)[:2], list(pp.POST_CENTER_LIMIT_RANGE), pp.SCORE_THRESH, sync=False, batch=batch_size,
+            sample_stride=h * w * ld)
+        mapping = self.class_id_mapping_each_head[0]
+        assert mapping.tolist() == list(range(len(mapping))), "the batched path keeps head-local class ids (one head over all classes)"
+        keep, num_keep = ops.nms_batch(boxes, counts, pp.NMS_CONFIG.NMS_THRESH)
+        ob, os_, ol, on = ops.select_boxes(boxes, scores, labels, keep, num_keep, pp.NMS_CONFIG.NMS_POST_MAXSIZE, label_offset=1)
+        ns = on.tolist()
+        return [{"pred_boxes": ob[b, :ns[b]], "pred_scores": os_[b, :ns[b]], "pred_labels": ol[b, :ns[b]]} for b in range(batch_size)]
 
     def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
         """center_head.py:159-219 for every head, vectorised on the device (cpd_amd.center_loss;

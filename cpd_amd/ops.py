@@ -248,14 +248,20 @@ def _gc_flags(dense, bf16x3, math):
 
 
 def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=None, residual=None, relu=False,
-                out=None, out_row_map=None, out_col_group=0, dense=False, bf16x3=False, math=None, in_absmax=None):
+                out=None, out_row_map=None, out_col_group=0, dense=False, bf16x3=False, math=None, in_absmax=None, out_absmax=None,
+                guard=False):
     """out[j,:c_out] = act((sum_t in[nbr[t][j]] . W[t]) * scale + shift + residual[j]).
     `inp` / `out` / `residual` are 2-D row tensors whose row stride may exceed the channel count.
     `math`: "f32" | "bf16x3" | "f16x2" (overrides the older `bf16x3` switch).
-    `in_absmax`: the absmax block of `inp` (int32 device tensor, train_ops.bn_backward fills it; train_ops.absmax_block): the
-    split-fp16 kernels then pre-scale `inp` into fp16's range by a power of two -- how gradients take that path."""
+    `in_absmax`: the absmax block of `inp` (int32 device tensor: absmax_blocks / absmax_rows here, train_ops.bn_backward for
+    gradients): the split-fp16 kernels then pre-scale `inp` into fp16's range by a power of two (exact) -- the range guard of
+    the f16x2 inference path, and how gradients take that path. `out_absmax`: a block this launch raises to max |out| (zeroed by
+    the caller; the next layer's `in_absmax`). `guard=True`: f16x2 with no `in_absmax` given measures the input first
+    (one extra pass over `inp`) instead of trusting it to stay below 65504."""
     _need_cuda(inp, "inp")
     assert inp.dim() == 2 and inp.stride(1) == 1
+    if guard and in_absmax is None and (math == "f16x2") and c_in % 32 == 0:
+        in_absmax = absmax_rows(inp, c_in)
     if out is None:
         out = torch.empty((n_out, c_out), dtype=torch.float32, device=inp.device)
     assert out.dim() == 2 and out.stride(1) == 1
@@ -266,21 +272,54 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     flags = _gc_flags(dense, bf16x3, math)
     image = getattr(nbr, "image", None)             # 3x3 / stride 1 / pad 1 pixel table: the rulebook-free window kernel
     if image is not None and out_row_map is None and kv == 9 and n_out == image[0] * image[1] * image[2] and inp.shape[0] == n_out:
-        rc = lib().cpd_conv3x3_rows_scaled(
+        rc = lib().cpd_conv3x3_rows_ranged(
             ctypes.c_void_p(inp.data_ptr()), inp.stride(0), image[0], image[1], image[2], c_in, ptr(packed_w), c_out,
             ptr(scale), ptr(shift), ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld,
-            int(bool(relu)), ctypes.c_void_p(out.data_ptr()), out.stride(0), flags, ptr(in_absmax), stream())
+            int(bool(relu)), ctypes.c_void_p(out.data_ptr()), out.stride(0), flags, ptr(in_absmax), ptr(out_absmax), stream())
         if rc != -4:                                # CPD_ERR_UNSUPPORTED: shape / alignment / size -> the table path below
             check(rc, "cpd_conv3x3_rows")
             return out
-    check(lib().cpd_gather_conv_scaled(
+    check(lib().cpd_gather_conv_ranged(
         ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w),
         ptr(nbr), ptr(getattr(nbr, "tapmask", None)), kv, n_out, c_out, ptr(scale), ptr(shift),
         ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
         ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), flags,
-        ptr(in_absmax), stream()),
+        ptr(in_absmax), ptr(out_absmax), stream()),
         "cpd_gather_conv")
     return out
+
+
+ABSMAX_WORDS = 16 * 32       # CPD_ABSMAX_WORDS of include/cpd_hip.h: 16 words, one per 128-byte line
+
+
+def absmax_blocks(n, device):
+    """n zeroed absmax blocks [n, ABSMAX_WORDS] int32: row i is the block of one activation tensor (bits of its max |value|)."""
+    return torch.zeros((n, ABSMAX_WORDS), dtype=torch.int32, device=device)
+
+
+def absmax_rows(x, c=None, block=None):
+    """The absmax block of a row tensor no kernel of this library produced (cpd_absmax_rows: one pass over x[:, :c])."""
+    _need_cuda(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    if block is None:
+        block = torch.zeros((ABSMAX_WORDS,), dtype=torch.int32, device=x.device)
+    check(lib().cpd_absmax_rows(ctypes.c_void_p(x.data_ptr()), x.stride(0), x.shape[0], int(c if c is not None else x.shape[1]), ptr(block),
+                                stream()), "cpd_absmax_rows")
+    return block
+
+
+def range_block(t, c=None):
+    """The absmax block travelling with tensor `t` as attribute `_cpd_rb` (set by the layer that produced it), else measured now."""
+    b = getattr(t, "_cpd_rb", None)
+    if b is not None:
+        return b
+    t2 = t if t.dim() == 2 else t.reshape(-1, t.shape[-1])
+    return absmax_rows(t2.contiguous().float(), c)
+
+
+def absmax_value(block):
+    """max |value| recorded in a block, as a Python float (a host read: tests and diagnostics)."""
+    return float(block.view(-1)[::32][:16].max().view(torch.float32) if block.dtype == torch.int32 else block.max())
 
 
 def densify_nchw(feat, indices, batch, shape_zyx):
@@ -301,6 +340,27 @@ def densify_nhwc(feat, indices, batch, shape_zyx, out=None):
     check(lib().cpd_densify_nhwc(ptr(feat), ptr(indices.contiguous()), n, c, batch, iarr(shape_zyx), ptr(out),
                                  stream()), "cpd_densify_nhwc")
     return out
+
+
+def densify_nhwc_cd(feat, indices, batch, shape_zyx):
+    """(B, H, W, C*D) with channel = c*D + z: the reference's (B, C*D, H, W) map in channels_last memory."""
+    feat = feat.contiguous()
+    n, c = feat.shape
+    out = torch.empty((batch, shape_zyx[1], shape_zyx[2], c * shape_zyx[0]), dtype=torch.float32, device=feat.device)
+    check(lib().cpd_densify_nhwc_cd(ptr(feat), ptr(indices.contiguous()), n, c, batch, iarr(shape_zyx), ptr(out), stream()),
+          "cpd_densify_nhwc_cd")
+    return out
+
+
+_PIXEL_TABLES = {}
+
+
+def rulebook_conv2d_cached(batch, h, w, device, k=3, stride=1, pad=1):
+    """The pixel table of a k x k conv over (batch, h, w) maps, built once per shape and device."""
+    key = (batch, h, w, k, stride, pad, str(device))
+    if key not in _PIXEL_TABLES:
+        _PIXEL_TABLES[key] = rulebook_conv2d(batch, h, w, k, k, stride, pad, device)
+    return _PIXEL_TABLES[key]
 
 
 def rulebook_conv2d(batch, h, w, kh, kw, stride, pad, device):
@@ -415,8 +475,14 @@ def boxes_iou_bev_cpu(a, b):
     return out
 
 
-def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None):
-    """Name of the kernel instantiation gather_conv will run for this problem (`nbr`: the table it would be given)."""
+def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None, scaled=False):
+    """Name of the kernel instantiation gather_conv will run for this problem (`nbr`: the table it would be given; `scaled`: an
+    `in_absmax` block comes with the input -- the split-fp16 kernels then run as their pre-scaling `f16s` instantiations)."""
+    name = _gather_conv_tile(n_out, c_in, c_out, in_ld, dense, bf16x3, nbr, math)
+    return name.replace("_f16_kernel", "_f16s_kernel") if scaled else name
+
+
+def _gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None):
     image = getattr(nbr, "image", None)
     flags = _gc_flags(dense, bf16x3, math)
     if image is not None and n_out == image[0] * image[1] * image[2] and in_ld % 4 == 0 and lib().cpd_conv3x3_rows_supported(

@@ -13,11 +13,15 @@ from .pytorch import (SparseConv3d, SparseConvTensor, SparseInverseConv3d, Spars
 __version__ = "2.1.22+cpd_amd"
 
 
-def install():
-    """Make `import spconv`, `import spconv.pytorch`, `from spconv.pytorch.utils import PointToVoxel`,
+def install(conv_math=None):
+    """conv_math: package default for modules built without their own (`"f32"` | `"f16x2"` | `"bf16x3"`,
+    cpd_amd.spconv.pytorch.conv.set_default_conv_math; also CPD_CONV_MATH).
+    Make `import spconv`, `import spconv.pytorch`, `from spconv.pytorch.utils import PointToVoxel`,
     `from spconv.utils import Point2VoxelCPU3d` and `import cumm.tensorview as tv` resolve to this
     package (only if the real spconv is absent)."""
     me = sys.modules[__name__]
+    if conv_math is not None:
+        pytorch.conv.set_default_conv_math(conv_math)
     for name, mod in {"spconv": me, "spconv.pytorch": pytorch, "spconv.pytorch.conv": pytorch.conv,
                       "spconv.pytorch.utils": pytorch.utils, "spconv.utils": utils}.items():
         sys.modules.setdefault(name, mod)

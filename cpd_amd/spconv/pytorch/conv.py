@@ -3,6 +3,7 @@ kernel on the adjoint weights / rulebook, the weight gradient cpd_conv_wgrad), s
 (tools/train_utils/train_utils.py:41) trains through these modules. Weight layout is spconv-2.x (Cout, kD, kH, kW, Cin), so
 reference checkpoints load (detector3d_template.py:388-419)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -14,6 +15,48 @@ from .modules import SparseModule
 
 def _triple(v):
     return [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
+
+
+# Arithmetic of the layers with c_in % 32 == 0 when a module is built without an explicit `conv_math=`: "f32" (fp32 MFMA, the
+# reference's arithmetic bit for bit as an fma chain), "f16x2" or "bf16x3" (fp32-level results on the 16-bit matrix pipe,
+# include/cpd_hip.h). Set by `cpd_amd.spconv.install(conv_math=...)`, `set_default_conv_math()` or CPD_CONV_MATH in the
+# environment; a module reads it at CALL time unless it was given its own.
+_DEFAULT_CONV_MATH = [os.environ.get("CPD_CONV_MATH", "f32")]
+
+
+def set_default_conv_math(math):
+    assert math in ops.CONV_MATH, math
+    _DEFAULT_CONV_MATH[0] = math
+
+
+def default_conv_math():
+    return _DEFAULT_CONV_MATH[0]
+
+
+def fold_batchnorm(bn, conv_bias=None):
+    """Eval-mode BatchNorm (+ the preceding conv's bias) as the conv epilogue's per-channel (scale, shift), cached on the
+    BatchNorm module until one of its tensors (or the bias) changes."""
+    tensors = [bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv_bias] if conv_bias is not None else [])
+    key = tuple((t._version, t.data_ptr()) for t in tensors if t is not None)
+    cached = getattr(bn, "_cpd_fold", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    with torch.no_grad():
+        var = bn.running_var.double()
+        w = bn.weight.double() if bn.weight is not None else torch.ones_like(var)
+        b = bn.bias.double() if bn.bias is not None else torch.zeros_like(var)
+        scale = w / torch.sqrt(var + bn.eps)
+        shift = b - bn.running_mean.double() * scale
+        if conv_bias is not None:
+            shift = shift + conv_bias.double() * scale
+        scale, shift = scale.float().contiguous(), shift.float().contiguous()
+    bn._cpd_fold = (key, scale, shift)
+    return scale, shift
+
+
+def fusable_eval(*mods):
+    """The fused eval path applies when nothing is being trained: every module in eval mode and no autograd graph wanted."""
+    return not torch.is_grad_enabled() and all(not m.training for m in mods)
 
 
 class SparseConvolution(SparseModule):
@@ -32,7 +75,16 @@ class SparseConvolution(SparseModule):
         self.reset_parameters()
         self._packed = None
         self._packed_version = None
-        self.conv_math = kwargs.get("conv_math", "f32")     # "f32" | "bf16x3" | "f16x2" (ops.CONV_MATH), layers with c_in % 32 == 0
+        self._conv_math = kwargs.get("conv_math")           # None: the package default at call time (set_default_conv_math)
+
+    @property
+    def conv_math(self):
+        return self._conv_math if self._conv_math is not None else _DEFAULT_CONV_MATH[0]
+
+    @conv_math.setter
+    def conv_math(self, m):
+        assert m is None or m in ops.CONV_MATH, m
+        self._conv_math = m
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -50,7 +102,10 @@ class SparseConvolution(SparseModule):
             self._packed_version = key
         return self._packed
 
-    def forward(self, x: SparseConvTensor):
+    def forward(self, x: SparseConvTensor, scale=None, shift=None, residual=None, relu=False):
+        """scale / shift / residual / relu: an eval-mode epilogue fused into the launch (SparseSequential and SparseBasicBlock
+        pass the folded BatchNorm1d, the block's identity and the ReLU here when nothing is being trained); without them this
+        is the plain convolution (+ bias) of the reference module."""
         assert isinstance(x, SparseConvTensor)
         if self.inverse:
             raise NotImplementedError("SparseInverseConv3d is declared by the reference (spconv_backbone.py:24) "
@@ -84,8 +139,21 @@ class SparseConvolution(SparseModule):
 
         spec = autograd_ops.ConvSpec(nbr, kv, out_indices.shape[0], dense=False, math=self.conv_math,
                                      mode="same" if self.subm else "strided", adjoint=adjoint, packed=self._packed_weight())
-        w_kio = self.weight.reshape(self.out_channels, kv, self.in_channels).permute(1, 2, 0)
-        out_feats = autograd_ops.gather_conv(feats, w_kio, self.bias, spec)
+        if scale is not None or shift is not None or residual is not None or relu:
+            assert not torch.is_grad_enabled(), "the fused epilogue is an inference path"
+            if shift is None and self.bias is not None:
+                shift = self.bias.detach().float()
+            # f16x2: the range block travels with the feature tensor (attribute _cpd_rb); a tensor without one is measured first
+            guard = self.conv_math == "f16x2"
+            rb_in = ops.range_block(x.features, self.in_channels) if guard and self.in_channels % 32 == 0 else None
+            rb_out = ops.absmax_blocks(1, feats.device)[0] if guard else None
+            out_feats = ops.gather_conv(feats, self.in_channels, spec.packed, nbr, kv, spec.n_out, self.out_channels, scale, shift,
+                                        residual, relu, dense=False, math=self.conv_math, in_absmax=rb_in, out_absmax=rb_out)
+            if rb_out is not None:
+                out_feats._cpd_rb = rb_out
+        else:
+            w_kio = self.weight.reshape(self.out_channels, kv, self.in_channels).permute(1, 2, 0)
+            out_feats = autograd_ops.gather_conv(feats, w_kio, self.bias, spec)
         out = SparseConvTensor(out_feats, out_indices, cached["out_shape"], x.batch_size, x.grid, x.benchmark)
         out.indice_dict = x.indice_dict
         out._site_index = cached["out_index"]
@@ -98,7 +166,7 @@ class SubMConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  indice_key=None, **kwargs):
         super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, subm=True,
-                         indice_key=indice_key)
+                         indice_key=indice_key, **kwargs)
 
 
 class SparseConv3d(SparseConvolution):
@@ -107,9 +175,9 @@ class SparseConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  indice_key=None, **kwargs):
         super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
-                         indice_key=indice_key)
+                         indice_key=indice_key, **kwargs)
 
 
 class SparseInverseConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, **kwargs):
-        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key, **kwargs)

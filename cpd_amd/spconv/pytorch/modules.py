@@ -31,8 +31,24 @@ class SparseSequential(SparseModule):
         return len(self._modules)
 
     def forward(self, x):
+        from .conv import SparseConvolution, fold_batchnorm, fusable_eval
         from .core import SparseConvTensor
-        for m in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            i += 1
+            # eval mode, no autograd: conv -> BatchNorm1d [-> ReLU] is ONE launch, the folded statistics and the ReLU in the conv
+            # epilogue (post_act_block / conv_input / conv_out of the backbone, spconv_backbone.py:13-35,414-455)
+            if isinstance(m, SparseConvolution) and not m.inverse and i < len(mods) and isinstance(mods[i], nn.BatchNorm1d) \
+                    and isinstance(x, SparseConvTensor) and fusable_eval(m, mods[i]) and mods[i].track_running_stats:
+                bn = mods[i]
+                i += 1
+                relu = i < len(mods) and isinstance(mods[i], nn.ReLU)
+                i += int(relu)
+                scale, shift = fold_batchnorm(bn, m.bias)
+                x = m(x, scale=scale, shift=shift, relu=relu)
+                continue
             if is_spconv_module(m):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):

@@ -218,11 +218,15 @@ int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, int flags, i
 /* SparseConvTensor.dense() + view(N, C*D, H, W) (height_compression.py:136-138).
  *   nchw: out (B, C*D, H, W), channel = c*D + z   -- the reference layout
  *   nhwc: out (B, H, W, D*C), channel = z*C + c   -- channels-last, feeds cpd_gather_conv
- * Both zero-fill `out` themselves.                                                           */
+ *   nhwc_cd: out (B, H, W, C*D), channel = c*D + z -- channels-last memory with the reference's channel order: the (N, C*D, H, W)
+ *            tensor of height_compression.py:136-138 in torch's channels_last format (what the module path hands to Conv2d)
+ * All zero-fill `out` themselves.                                                            */
 int cpd_densify_nchw(const float *feat, const int32_t *indices, int n, int c, int batch,
                      const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
 int cpd_densify_nhwc(const float *feat, const int32_t *indices, int n, int c, int batch,
                      const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
+int cpd_densify_nhwc_cd(const float *feat, const int32_t *indices, int n, int c, int batch,
+                        const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
 /* Dense-pixel rulebooks for the BEV convs: nbr[kh*kw][ho*wo*batch] for a (kh x kw, stride, pad)
  * Conv2d over a (batch, h, w) channels-last map. */
 int cpd_rulebook_conv2d(int batch, int h, int w, int kh, int kw, int stride, int pad,
@@ -367,6 +371,23 @@ int cpd_conv3x3_rows_scaled(const float *in, int in_ld, int frames, int h, int w
                             const float *packed_w, int c_out, const float *scale, const float *shift,
                             const float *residual, int res_ld, int relu, float *out, int out_ld, int flags,
                             const uint32_t *in_absmax, cpd_stream_t stream);
+/* The range guard of the f16x2 INFERENCE path (fp16's narrow exponent is the one way split-fp16 arithmetic differs from the
+ * reference's fp32 convolutions, spconv_backbone.py:108-136 / base_bev_backbone.py:31-59): every launch may leave the bits of
+ * max |out| behind in an absmax block (out_absmax; zero the block before the first launch that writes it -- several launches
+ * may raise the same block, e.g. the two halves of a concat buffer), and takes its input's block as in_absmax exactly like the
+ * _scaled calls above: the split-fp16 kernels then pre-scale the input by a power of two and undo it in the epilogue (exact),
+ * so an activation of any fp32 magnitude gives the fp32 answer instead of inf / NaN. in_absmax = NULL: input used as is;
+ * out_absmax = NULL: nothing recorded. cpd_absmax_rows raises a block to the range of a tensor that came from elsewhere. */
+int cpd_gather_conv_ranged(const float *in, int in_ld, int n_in, int c_in, const float *packed_w,
+                           const int32_t *nbr, const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale,
+                           const float *shift, const float *residual, int res_ld, int relu, float *out,
+                           int out_ld, const int32_t *out_row_map, int out_col_group, int flags,
+                           const uint32_t *in_absmax, uint32_t *out_absmax, cpd_stream_t stream);
+int cpd_conv3x3_rows_ranged(const float *in, int in_ld, int frames, int h, int w, int c_in,
+                            const float *packed_w, int c_out, const float *scale, const float *shift,
+                            const float *residual, int res_ld, int relu, float *out, int out_ld, int flags,
+                            const uint32_t *in_absmax, uint32_t *out_absmax, cpd_stream_t stream);
+int cpd_absmax_rows(const float *x, int ld, long long n, int c, uint32_t *absmax_block, cpd_stream_t stream);
 /* All packed images of a model in three launches (a train step rewrites every one of them after the optimiser step; one
  * cpd_pack_weight / cpd_pack_weight_adjoint call is four launches). A job names one packed buffer (sized by
  * cpd_packed_weight_floats for the conv the image is FOR) and the [kv][c_in][c_out] tensor it is built from: adjoint = 0

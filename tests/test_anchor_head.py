@@ -119,7 +119,7 @@ def test_anchor_head_single_v2_forward_matches_reference_module(golden, hip, mat
                  feature_map_stride=8, matched_threshold=0.5, unmatched_threshold=0.35)
             for n, s in (("Vehicle", [4.7, 2.1, 1.7]), ("Pedestrian", [0.91, 0.86, 1.73]), ("Cyclist", [1.78, 0.84, 1.78]))]
     mcfg = dict(ANCHOR_GENERATOR_CONFIG=cfgs, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
-                PREDICT_BOXES_WHEN_TRAINING=True)
+                TARGET_ASSIGNER_CONFIG=dict(NAME="AxisAlignedTargetAssigner", NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False))
     head = ah.AnchorHeadSingleV2(mcfg, 32, 3, CLASSES, np.array([416, 416, 40]), g["pcr"].tolist(), conv_math=math)
     sd = {k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("v2.")}
     res = head.load_state_dict(sd, strict=True)                      # same parameter / buffer names as the reference class
@@ -128,6 +128,8 @@ def test_anchor_head_single_v2_forward_matches_reference_module(golden, hip, mat
     if mode == "train":
         head.training = True                                         # forward takes the module path; BatchNorms stay in eval
     dd = {"points": torch.from_numpy(g["points"]).cuda(), "st_features_2d": torch.from_numpy(g["feat"]).cuda(), "batch_size": 2}
+    if mode == "train":                                              # training mode assigns targets (anchor_head_single.py:176-181)
+        dd["gt_boxes"] = torch.tensor([[[3.0, -2.0, 0.0, 4.5, 2.0, 1.6, 0.3, 1.0], [-6.0, 5.0, 0.1, 0.9, 0.8, 1.7, 1.2, 2.0]]] * 2).cuda()
     mask = head.get_anchor_mask(dd["points"], dd["st_features_2d"].shape)
     np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])
     out = head(dd)
@@ -138,8 +140,72 @@ def test_anchor_head_single_v2_forward_matches_reference_module(golden, hip, mat
     np.testing.assert_allclose(out["batch_cls_preds"].cpu().numpy(), g["batch_cls_preds"], atol=1e-4, rtol=0)
     np.testing.assert_allclose(out["batch_box_preds"].cpu().numpy(), g["batch_box_preds"], atol=5e-4, rtol=1e-4)
     if mode == "train":                                              # the module path is differentiable end to end
+        n_anchor = g["batch_box_preds"].shape[1]
+        assert f["box_cls_labels"].shape == (2, n_anchor) and f["box_reg_targets"].shape == (2, n_anchor, 7)
+        assert out["gt_ious"].shape == (2, n_anchor)
         (f["cls_preds"].sum() + f["box_preds"].sum()).backward()
         assert all(p.grad is not None for n, p in head.named_parameters() if not n.startswith("conv_dir_cls"))
+
+
+@pytest.mark.gpu
+def test_v2_head_and_proto_head_train_one_step_end_to_end(golden, hip):
+    """with the shipped voxel_rcnn configs a training step runs AnchorHeadSingleV2 (targets on the occupancy-masked
+    anchors, boxes predicted because predict_boxes_when_training defaults to True as in the reference ctor) and hands
+    batch_box_preds / batch_cls_preds to VoxelRCNNProtoHead.proposal_layer. One such step, end to end: V2's fused get_loss on
+    its own forward_ret_dict (default = masked anchors) equals the autograd restatement (loss and gradients), its gradients reach
+    the V2 parameters, and the second stage trains on V2's proposals."""
+    import types
+    import torch
+    from cpd_amd import anchor_head as ah
+    from cpd_amd.roi_head_train import VoxelRCNNProtoHead
+    from test_gpu_roi_train import _cfg
+    g2, gp = golden("anchor_head_single_v2"), golden("proto_head")
+    cfgs = [dict(class_name=n, anchor_sizes=[s], anchor_rotations=[0, 1.57], anchor_bottom_heights=[0], align_center=False,
+                 feature_map_stride=8, matched_threshold=0.5, unmatched_threshold=0.35)
+            for n, s in (("Vehicle", [4.7, 2.1, 1.7]), ("Pedestrian", [0.91, 0.86, 1.73]), ("Cyclist", [1.78, 0.84, 1.78]))]
+    mcfg = dict(ANCHOR_GENERATOR_CONFIG=cfgs, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
+                TARGET_ASSIGNER_CONFIG=dict(NAME="AxisAlignedTargetAssigner", NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False),
+                LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, code_weights=[1.0] * 7)))
+    head = ah.AnchorHeadSingleV2(mcfg, 32, 3, CLASSES, np.array([416, 416, 40]), g2["pcr"].tolist(), conv_math="f32")
+    head.load_state_dict({k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g2.items() if k.startswith("v2.")})
+    head = head.cuda().train()                                      # REAL training mode: batch-statistics BatchNorm
+    gt = torch.from_numpy(gp["gt"]).cuda()
+    dd = {"points": torch.from_numpy(g2["points"]).cuda(), "st_features_2d": torch.from_numpy(g2["feat"]).cuda().requires_grad_(True),
+          "batch_size": 2, "gt_boxes": gt}
+    dd = head(dd)
+    f = head.forward_ret_dict
+    assert "batch_box_preds" in dd and "gt_ious" in dd and "box_cls_labels" in f and "box_reg_targets" in f
+    assert int((f["box_cls_labels"] > 0).sum()) > 0                  # the scene has matched anchors
+    losses, grads = head.get_loss()                                  # defaults: own forward_ret_dict, masked anchors
+    det = {k: (v.detach().requires_grad_(True) if k.endswith("preds") and v is not None else v) for k, v in f.items()}
+    want, _ = ah.anchor_head_loss_torch(head.anchors, det["cls_preds"], det["box_preds"], det["dir_cls_preds"], f["box_cls_labels"],
+                                        f["box_reg_targets"], 3, 1.0, 2.0, 0.2, [1.0] * 7)
+    want.backward()
+    assert abs(float(losses[0]) - float(want)) <= 1e-4 * max(1.0, abs(float(want)))
+    for got, key in zip(grads, ("cls_preds", "box_preds", "dir_cls_preds")):
+        ref = det[key].grad
+        assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    torch.autograd.backward([f["cls_preds"], f["box_preds"], f["dir_cls_preds"]], list(grads))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in head.parameters())
+    assert dd["st_features_2d"].grad is not None
+    # second stage on V2's proposals
+    roi = VoxelRCNNProtoHead(input_channels={"x_conv3": 8, "x_conv4": 12}, model_cfg=_cfg(), point_cloud_range=gp["pcr"].tolist(),
+                             voxel_size=[0.1, 0.1, 0.15], num_class=1).cuda().train()
+    lv, lv_mm = {}, {}
+    for name, shp in (("x_conv3", [11, 104, 104]), ("x_conv4", [5, 52, 52])):
+        idx = torch.from_numpy(gp[name + "_idx"]).cuda()
+        for d, key in ((lv, "_feat"), (lv_mm, "_feat_mm")):
+            d[name] = types.SimpleNamespace(indices=idx, features=torch.from_numpy(gp[name + key]).cuda().requires_grad_(True),
+                                            spatial_shape=shp, batch_size=2)
+    dd.update(css_score=torch.from_numpy(gp["css"]).cuda(), multi_scale_3d_features=lv, multi_scale_3d_features_mm=lv_mm,
+              multi_scale_3d_strides={"x_conv3": 4, "x_conv4": 8})
+    np.random.seed(1); torch.manual_seed(1)
+    roi(dd)
+    loss, tb = roi.get_loss()
+    assert torch.isfinite(loss)
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in roi.parameters() if p.grad is not None)
+    assert sum(p.grad is not None for p in roi.parameters()) >= 30
 
 
 def test_anchor_loss_restatement_matches_reference_get_loss(golden):

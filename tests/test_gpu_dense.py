@@ -309,6 +309,27 @@ def test_split_bf16_conv_is_fp32_accurate(hip, math, cin, cout, k, stride):
         xb[rows[0]] = 7e4
         bad = ops.gather_conv(xb, cin, pw, nbr, kv, n_out, cout, dense=True, math=math)
         assert not torch.isfinite(bad).all()
+        # ... and GUARDED: with the input's absmax block the kernel pre-scales by a power of two and the same
+        # input gives the fp32 answer -- measured here (guard=True), or left behind by the producing layer's epilogue (below)
+        want = ops.gather_conv(xb, cin, pw, nbr, kv, n_out, cout, dense=True, math="f32")
+        good = ops.gather_conv(xb, cin, pw, nbr, kv, n_out, cout, dense=True, math=math, guard=True)
+        assert torch.isfinite(good).all()
+        rowmax = want.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+        assert float(((good - want).abs() / rowmax).max()) <= 1e-4
+        # producer -> consumer: layer 1 (weights x 3e4: outputs ~1e5..1e6) records max |out|, layer 2 reads it
+        blocks = ops.absmax_blocks(2, "cuda")
+        big = ops.pack_weight(w * 3e4)
+        y1 = ops.gather_conv(x, cin, big, nbr, kv, n_out, cout, None, None, None, True, dense=True, math=math, guard=True, out_absmax=blocks[0])
+        assert ops.absmax_value(blocks[0]) == float(y1.abs().max()) and ops.absmax_value(blocks[0]) > 65504
+        if cout % 32 == 0 and k == 3 and stride == 1:
+            w2 = torch.randn(kv, cout, 64, device="cuda") * (2.0 / (kv * cout)) ** 0.5
+            pw2 = ops.pack_weight(w2)
+            y2 = ops.gather_conv(y1, cout, pw2, nbr, kv, n_out, 64, dense=True, math=math, in_absmax=blocks[0], out_absmax=blocks[1])
+            y2_ref = ops.gather_conv(y1, cout, pw2, nbr, kv, n_out, 64, dense=True, math="f32")
+            assert torch.isfinite(y2).all()
+            assert float((y2 - y2_ref).abs().max()) <= 1e-4 * float(y2_ref.abs().max())
+            assert ops.absmax_value(blocks[1]) == float(y2.abs().max())
+            assert not torch.isfinite(ops.gather_conv(y1, cout, pw2, nbr, kv, n_out, 64, dense=True, math=math)).all()     # unguarded: loud
 
 
 @pytest.mark.parametrize("cin,cout,batch,h,w", [(128, 128, 3, 188, 188), (256, 256, 5, 94, 94), (64, 320, 2, 188, 188),

@@ -162,6 +162,19 @@ def test_strided_sparse_conv_gradients(oracle, hip):
     tt, jj = np.nonzero(nbr_np >= 0)
     want_t[tt, nbr_np[tt, jj]] = jj
     np.testing.assert_array_equal(nbr_t, want_t)
+    # ... and over an output level whose rows were re-ordered after its index was built (tap-pattern order, cpd_index_set_order):
+    # the transposed table names the NEW rows, like the forward table built over the re-ordered site list
+    new_idx, n2o, o2n = ops.order_rows_by_taps(out_idx, out_index, chunk_rows=1024)
+    out_index.set_order(o2n)
+    nbr_p = ops.rulebook_conv(new_idx, index, k, s, p).cpu().numpy()
+    np.testing.assert_array_equal(nbr_p, nbr_np[:, n2o.cpu().numpy()])
+    nbr_tp = T.rulebook_conv_transpose(d_idx, batch, shape, k, s, p, out_index).cpu().numpy()
+    want_tp = np.full((27, n_in), -1, np.int32)
+    tt, jj = np.nonzero(nbr_p >= 0)
+    want_tp[tt, nbr_p[tt, jj]] = jj
+    np.testing.assert_array_equal(nbr_tp, want_tp)
+    assert not np.array_equal(nbr_tp, nbr_t)
+    out_index.set_order(None)
     x = rng.normal(size=(n_in, cin)).astype(np.float32)
     w = (rng.normal(size=(27, cin, cout)) * 0.05).astype(np.float32)
     dy = rng.normal(size=(n_out, cout)).astype(np.float32)
