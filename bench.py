@@ -578,7 +578,11 @@ def main():
                                  "f16x2": "layers with >= 32 input channels: split-fp16 x2 (fp32 operands written as 2 fp16 terms, 3 fp16 MFMA "
                                           "products per fp32 multiply-add, fp32 accumulation, fp32-level error); 5/16-channel sparse layers: "
                                           "fp32 MFMA",
-                                 "f32": "fp32 MFMA everywhere"}[cfg.conv_math]},
+                                 "f32": "fp32 MFMA everywhere"}[cfg.conv_math],
+                   "range_guard": ("f16x2 range guard on: every conv epilogue records max |out|, the verdict rides with the step's count "
+                                   "read-back, a step with an activation >= 2^15 is re-run with power-of-two pre-scaling (exact); re-runs "
+                                   "in this run: %d" % sum(getattr(e, "range_reruns", 0) for e in engines))
+                   if cfg.conv_math == "f16x2" and cfg.range_guard and engines else "n/a"},
     }
 
     if not args.no_roofline and args.api == "engine":

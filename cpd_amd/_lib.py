@@ -27,6 +27,9 @@ _FP = ctypes.POINTER(ctypes.c_float)
 
 # name -> (restype, argtypes): one row per declaration in include/cpd_hip.h
 SIGNATURES = {
+    "cpd_launch_log_enable": (None, [_I]),
+    "cpd_launch_log_note": (None, [ctypes.c_char_p]),
+    "cpd_launch_log_dump": (_SZ, [ctypes.c_char_p, _SZ]),
     "cpd_version": (ctypes.c_char_p, []),
     "cpd_last_hip_error": (_I, []),
     "cpd_voxel_grid_size": (_I, [_FP, _FP, _I3]),

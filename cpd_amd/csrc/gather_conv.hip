@@ -59,6 +59,7 @@ struct GcParams {
     float *out;
     const int32_t *out_row_map;
     int in_ld, c_in, kc;  // kc = 16-channel chunks
+    int n_in_rows;        // rows of `in` (bounds of the row-wave kernels' buffer loads)
     int kv, n_out, c_out, ntot, np;  // np = padded columns (16*ntot)
     int res_ld, relu, out_ld, col_group;
     int n_rb, n_cb, items, n_sub;
@@ -193,11 +194,20 @@ struct StepRegs {
     unsigned act;  // sub-tiles with at least one neighbour at this step's tap
 };
 
-template <int MS, int NT, unsigned MASK>
-__device__ __forceinline__ void step_mma(StepRegs<MS, NT> &R, f32x4 (&acc)[MS][NT]) {
+// QUAD: the A pieces were gathered quad-shaped (lane -> row lane >> 2, piece lane & 3: a quad reads the 64 contiguous bytes of
+// one row's 16-channel chunk -- one L1 access instead of four, see the row-wave kernel) and become fragments (lane -> row
+// lane & 15, piece lane >> 4) through a 4 x 16 lane transpose here; `tsrc` = byte address of the source lane for ds_bpermute.
+template <int MS, int NT, unsigned MASK, bool QUAD = false>
+__device__ __forceinline__ void step_mma(StepRegs<MS, NT> &R, f32x4 (&acc)[MS][NT], int tsrc = 0) {
 #pragma unroll
     for (int s = 0; s < MS; ++s)
-        if (MASK & (1u << s)) R.a[s] = zero_if(R.a[s], R.idx[s] < 0);
+        if (MASK & (1u << s)) {
+            R.a[s] = zero_if(R.a[s], R.idx[s] < 0);
+            if (QUAD) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) R.a[s][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(R.a[s][k])));
+            }
+        }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -216,6 +226,9 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
     if (item >= p.items) return;
     const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
     const int r = lane & 15, g = lane >> 4;
+    // gather coordinates of the 16-byte-piece (VEC) path: quad-shaped, transposed into fragments in step_mma
+    const int lr = VEC ? (lane >> 2) : r, lp = VEC ? (lane & 3) : g;
+    const int tsrc = (4 * r + g) << 2;
     const int row0 = rb * (16 * MS);
     const int col0 = cb * NT * 16;
 
@@ -288,9 +301,9 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
             R.act = act_of(t_ld);
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
-                R.idx[s] = s_idx[wave][t_ld][16 * s + r];
+                R.idx[s] = s_idx[wave][t_ld][16 * s + lr];
                 if (CPD_GC_ABLATE & 2) R.a[s] = f32x4{(float)g, 1.f, (float)kc_cur, 2.f};
-                else R.a[s] = load_a<VEC>(p, R.idx[s], kc_cur * 16 + 4 * g);
+                else R.a[s] = load_a<VEC>(p, R.idx[s], kc_cur * 16 + 4 * lp);
             }
             const float *wk = wl + ((size_t)t_ld * p.kc + kc_cur) * w_chunk;
 #pragma unroll
@@ -314,13 +327,13 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
         };
         auto mma = [&](StepRegs<MS, NT> &R) {
             if constexpr (MS == 1) {
-                step_mma<MS, NT, 1u>(R, acc);
+                step_mma<MS, NT, 1u, VEC>(R, acc, tsrc);
             } else if constexpr (MS == 2) {
-                if (R.act == 3u) step_mma<MS, NT, 3u>(R, acc);
-                else if (R.act == 1u) step_mma<MS, NT, 1u>(R, acc);
-                else step_mma<MS, NT, 2u>(R, acc);
+                if (R.act == 3u) step_mma<MS, NT, 3u, VEC>(R, acc, tsrc);
+                else if (R.act == 1u) step_mma<MS, NT, 1u, VEC>(R, acc, tsrc);
+                else step_mma<MS, NT, 2u, VEC>(R, acc, tsrc);
             } else {
-                step_mma<MS, NT, (1u << MS) - 1u>(R, acc);
+                step_mma<MS, NT, (1u << MS) - 1u, VEC>(R, acc, tsrc);
             }
         };
 
@@ -1058,6 +1071,14 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
 
         f32x4 araw[MS][2];
         bool az[MS];
+        // Rows are fetched through a BUFFER resource over the input tensor (raw buffer, byte offsets): a load beyond num_records
+        // returns zeros, so a row without a neighbour (idx < 0, taken as unsigned and clamped to n_in) needs no select afterwards, and
+        // the address is one 32-bit multiply instead of 64-bit arithmetic per load (-20 vector instructions per stage). The launcher
+        // sends tensors of 4 GB and more to the workgroup kernels.
+        const size_t in_bytes = ((size_t)p.n_in_rows * p.in_ld) * sizeof(float);
+        constexpr bool use_buf = true;
+        const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, (int)(uint32_t)in_bytes, 0x00020000);
+        const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
         f32x4u rbv[BJ];
         auto load_rows = [&](uint32_t on, int kk, const int (&idx)[MS]) {
 #pragma unroll
@@ -1065,7 +1086,15 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                 if ((on >> s) & 1u) {
                     const int id = row_ok[s] ? idx[s] : -1;
                     az[s] = id < 0;
-                    if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; continue; }
+                    if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; az[s] = false; continue; }
+                    if (use_buf) {
+                        const uint32_t rowu = (uint32_t)id < (uint32_t)p.n_in_rows ? (uint32_t)id : (uint32_t)p.n_in_rows;   // -1 -> n_in: out of range
+                        const uint32_t off = rowu * row_bytes + (uint32_t)qj * 16u;
+                        araw[s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, kk * 128, 0));
+                        araw[s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, kk * 128 + 64, 0));
+                        az[s] = false;
+                        continue;
+                    }
                     araw[s][0] = load_a<true>(p, id, kk * 32 + qj * 4);
                     araw[s][1] = load_a<true>(p, id, kk * 32 + 16 + qj * 4);
                 }
@@ -1102,8 +1131,10 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             for (int s = 0; s < MS; ++s) {
                 if ((on >> s) & 1u) {
                     // rows without a neighbour become zeros in GATHER coordinates, then the lane transpose
-                    araw[s][0] = zero_if(araw[s][0], az[s]);
-                    araw[s][1] = zero_if(araw[s][1], az[s]);
+                    if (!use_buf) {
+                        araw[s][0] = zero_if(araw[s][0], az[s]);
+                        araw[s][1] = zero_if(araw[s][1], az[s]);
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         araw[s][0][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(araw[s][0][k])));
@@ -1736,11 +1767,12 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     GcParams p;
     p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.in_absmax = in_absmax; p.out_absmax = out_absmax; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
-    p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16;
+    p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16; p.n_in_rows = n_in;
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
-    if (pl.use_wg == 3 && kv > 32) pl = plan(n_out, c_in, c_out, in_ld, in, flags | CPD_GC_DENSE);   // the row-wave kernel keeps its taps in 32-bit sets
+    if (pl.use_wg == 3 && (kv > 32 || (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
+        pl = plan(n_out, c_in, c_out, in_ld, in, flags | CPD_GC_DENSE);   // the row-wave kernel keeps its taps in 32-bit sets and reads its rows through a 4 GB buffer resource
     p.taps_inner = 1;       // measured (tools/order_probe.py): -6...-8 % on the 32- and 128-channel SubM layers, neutral at 64
     if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_TAPS_INNER")) p.taps_inner = atoi(e);
     static const bool trace = getenv("CPD_GC_TRACE") != nullptr;    // one line per launch: which kernel a layer got
@@ -1756,6 +1788,15 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     }
     const dim3 grid(p.items), block(256);
     hipStream_t hs = cpd_s(stream);
+    {   // launch log (cpd_launch_log_*): the instantiation this call runs
+        char nm[96];
+        const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? "f16" : "bf16");
+        if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
+        else if (pl.use_wg == 2) snprintf(nm, sizeof nm, "tile_conv_%s_kernel<%d,%d>", sc, pl.a, pl.b);
+        else if (pl.use_wg == 1) snprintf(nm, sizeof nm, "tile_conv_kernel<%d,%d>", pl.a, pl.b);
+        else snprintf(nm, sizeof nm, "gather_conv_kernel<%d,%d,%s>", pl.a, pl.b, pl.vec ? "true" : "false");
+        cpd_launch_log_note(nm);
+    }
 #define CPD_LAUNCH(K, LDS) hipLaunchKernelGGL((K), grid, block, (LDS), hs, p)
     if (pl.use_wg == 3 && pl.math == 2 && in_absmax) {
         if (pl.a == 64) {
@@ -1905,6 +1946,11 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
     const int bm = window_bm(frames, h, w, c_out, bn, flags);
     p.n_rb = (n_out + bm - 1) / bm; p.n_cb = (c_out + bn - 1) / bn; p.items = p.n_rb * p.n_cb;
     p.img_h = h; p.img_w = w;
+    {
+        char nm[96];
+        snprintf(nm, sizeof nm, "window_conv_%s_kernel<%d,%d>", math == 2 ? (in_absmax ? "f16s" : "f16") : "bf16", bn, bm);
+        cpd_launch_log_note(nm);
+    }
     const size_t lds = (math == 2 ? 2 : 3) * ((size_t)(128 + 16) * 64 + (size_t)bn * 64);
     if (math == 2 && bm == 256 && in_absmax) {
         const size_t ldsa = 2 * (size_t)(256 + 16) * 64;

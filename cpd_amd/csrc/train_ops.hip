@@ -1343,6 +1343,11 @@ static int conv_wgrad_impl(const float *in, int in_ld, int c_in, const float *dy
         if (ws_bytes < (size_t)p.n_chunks * elems * sizeof(float)) return CPD_ERR_WORKSPACE;
         if (p.n_chunks >= 65536 || kv >= 65536) return CPD_ERR_UNSUPPORTED;
         const dim3 grid(p.ci_tiles * p.co_tiles, kv, p.n_chunks);
+        {
+            char nm[64];
+            snprintf(nm, sizeof nm, "wgrad_%s_kernel<%d,%d>", (flags & 4) ? "f16" : "bf16", tm, tn);
+            cpd_launch_log_note(nm);
+        }
         if (flags & 4) {
             if (tm == 128) launch_wgrad_f16<128>(tn, grid, cpd_s(st), p);
             else if (tm == 64) launch_wgrad_f16<64>(tn, grid, cpd_s(st), p);
@@ -1365,6 +1370,7 @@ static int conv_wgrad_impl(const float *in, int in_ld, int c_in, const float *dy
         wgrad_tile_plan(n_out, c_in, c_out, kv, &p, &tm, &tn);
         if (p.n_chunks >= 65536 || kv >= 65536) return CPD_ERR_UNSUPPORTED;
         const dim3 grid(p.ci_tiles * p.co_tiles, kv, p.n_chunks);
+        { char nm[64]; snprintf(nm, sizeof nm, "wgrad_tile_kernel<%d,%d>", tm, tn); cpd_launch_log_note(nm); }
         if (tm == 128 && tn == 128) wgrad_tile_kernel<128, 128><<<grid, 256, 0, cpd_s(st)>>>(p);
         else if (tm == 128) wgrad_tile_kernel<128, 64><<<grid, 256, 0, cpd_s(st)>>>(p);
         else if (tn == 128) wgrad_tile_kernel<64, 128><<<grid, 256, 0, cpd_s(st)>>>(p);
@@ -1372,6 +1378,7 @@ static int conv_wgrad_impl(const float *in, int in_ld, int c_in, const float *dy
     } else {
         wg_kernel_t k = pick_wg(va, vb);
         if (!k) return CPD_ERR_UNSUPPORTED;
+        { char nm[64]; snprintf(nm, sizeof nm, "wgrad_kernel<%d,%d>", va, vb); cpd_launch_log_note(nm); }
         const long long blocks = (long long)p.n_chunks * kv * p.ci_tiles * p.co_tiles;
         if (blocks >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), 0, cpd_s(st), p);

@@ -18,12 +18,42 @@
 //   6 gather    : coalesced copy of the kept points into voxels[M,P,C], count, mean
 // HBM traffic is ~ the points read 3x (12 B/pt keys + rows) + outputs; see DESIGN.md.
 #include "common.h"
+#include <string.h>
 #include "site_index_layout.h"
 
 thread_local int g_cpd_last_hip_error = 0;
 
 extern "C" const char *cpd_version(void) { return "cpd_hip 0.1 (gfx950)"; }
 extern "C" int cpd_last_hip_error(void) { return g_cpd_last_hip_error; }
+
+// ---- launch log (diagnostics: which kernel instantiation served a call; tests assert the names, nothing else reads it) ----
+#include <map>
+#include <mutex>
+#include <string>
+static std::mutex g_log_mutex;
+static std::map<std::string, int> g_log;
+static bool g_log_on = false;
+extern "C" void cpd_launch_log_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_log_mutex);
+    g_log_on = on != 0;
+    g_log.clear();
+}
+extern "C" void cpd_launch_log_note(const char *kernel) {
+    if (!g_log_on || !kernel) return;
+    std::lock_guard<std::mutex> lk(g_log_mutex);
+    ++g_log[kernel];
+}
+extern "C" size_t cpd_launch_log_dump(char *buf, size_t cap) {      // "name count\n" lines; returns the bytes needed (incl. the NUL)
+    std::lock_guard<std::mutex> lk(g_log_mutex);
+    std::string out;
+    for (const auto &kv : g_log) out += kv.first + " " + std::to_string(kv.second) + "\n";
+    if (buf && cap) {
+        const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return out.size() + 1;
+}
 
 extern "C" int cpd_voxel_grid_size(const float vsize_xyz[3], const float range_xyz[6], int32_t grid_zyx[3]) {
     if (!vsize_xyz || !range_xyz || !grid_zyx) return CPD_ERR_ARG;

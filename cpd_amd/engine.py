@@ -305,9 +305,13 @@ class CenterPointEngine:
         return shape[0]
 
     # ------------------------------------------------------------------ forward pieces
-    # Range bookkeeping of the f16x2 path: `self._rb` = block of the tensor the NEXT conv reads (None: unknown / not guarded).
-    # Every _conv call reads it as in_absmax and replaces it by a fresh block its epilogue fills (`keep_rb`: write into the current
-    # output block instead -- the second half of a concat buffer).
+    # Range guard of the f16x2 path. Every conv epilogue raises an absmax block to max |out| (a wave
+    # reduction + a rarely issued atomic: free). OPTIMISTIC pass: the layers run their unscaled kernels and only RECORD; the largest
+    # recorded value rides along with the step's final count read-back, and if any activation reached 2^15 the step is run again
+    # in the GUARDED mode, where each layer takes its input's block as `in_absmax` (the `*_f16s_*` kernels pre-scale by a power of
+    # two: exact at any magnitude). Always guarded costs the dense kernels ~3 % (the extra multiply in their staging); a re-run
+    # costs a step, once, for inputs the unguarded arithmetic would have turned into inf / NaN (or, behind a ReLU, into zeros).
+    # `self._rb` = block of the tensor the NEXT conv reads; a _conv call consumes it and replaces it by the block its epilogue fills.
     def _range_reset(self):
         self._rb = None
         self._rb_next = 0
@@ -326,9 +330,14 @@ class CenterPointEngine:
         self._rb_next += 1
         return b
 
-    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False, in_rb="cur",
-              out_rb="new"):
-        rb_in = self._rb if in_rb == "cur" else in_rb
+    def _range_exceeded_flag(self):
+        """device int32 [1]: 1 when some recorded activation is >= 2^15 (or NaN / inf); None when nothing is recorded"""
+        if self._rb_pool is None or getattr(self, "_rb_scaled", False):
+            return None
+        return (self._rb_pool.max() >= 0x47000000).to(torch.int32).view(1)        # bits of 32768.0f; NaN / inf bits are larger
+
+    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False, out_rb="new"):
+        rb_in = self._rb if getattr(self, "_rb_scaled", False) else None
         rb_out = self._range_new() if out_rb == "new" else out_rb
         y = ops.gather_conv(x, layer.c_in, layer.w, nbr, layer.kv, n_out, layer.c_out, layer.scale, layer.shift,
                             residual, layer.relu, out=out, out_row_map=out_row_map, out_col_group=out_col_group,
@@ -465,14 +474,17 @@ class CenterPointEngine:
         assert cfg.max_obj_per_sample <= cfg.nms_pre_maxsize
         keep, num_keep = ops.nms_batch(boxes, counts, cfg.nms_thresh)
         ob, os_, ol, on = ops.select_boxes(boxes, scores, labels, keep, num_keep, cfg.nms_post_maxsize, label_offset=1)
+        flag = self._range_exceeded_flag()        # the range guard's verdict travels with the counts: no extra synchronisation
+        ns = (torch.cat([on, flag]) if flag is not None else on).tolist()      # the one host read-back of the stage
+        self._range_exceeded = bool(ns[batch]) if flag is not None else False
+        ns = ns[:batch]
+        if self._range_exceeded:
+            return None                           # forward() runs the step again, guarded
         if self.host_results:
             # blocking copies: the first waits for the frame's last kernel, the rest are ~20 us each. (Asynchronous copies
             # into pinned memory queued on the compute stream were measured 5-8 ms per step SLOWER on MI355X / ROCm 7.2 --
             # tools/d2h_probe.py -- whatever the wait that followed them: event, stream or a later blocking read.)
-            ns = on.tolist()
             ob, os_, ol = ob.cpu(), os_.cpu(), ol.cpu()
-        else:
-            ns = on.tolist()                      # the one host read-back of the stage
         return [{"pred_boxes": ob[b, :ns[b]], "pred_scores": os_[b, :ns[b]], "pred_labels": ol[b, :ns[b]]}
                 for b in range(batch)]
 
@@ -528,11 +540,20 @@ class CenterPointEngine:
             ms = torch.cat([o[4] for o in outs]).tolist() if batch > 1 else [int(outs[0][4].item())]   # one read-back
             feats = torch.cat([o[3][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][3][:ms[0]]
             coords = torch.cat([o[1][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][1][:ms[0]]
-        levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0)
-        d, h, w = out_shape
-        dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
-        cat, head = self.bev_and_head(dense, batch, h, w)
-        results = self.decode_and_nms(head, batch, h, w)
+        self._rb_scaled = False
+        self.range_reruns = getattr(self, "range_reruns", 0)
+        while True:
+            levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0)
+            d, h, w = out_shape
+            dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
+            cat, head = self.bev_and_head(dense, batch, h, w)
+            results = self.decode_and_nms(head, batch, h, w)
+            if results is not None:
+                break
+            # an activation left fp16's safe range: the same step with every layer pre-scaling its input (exact), see _range_reset
+            self._rb_scaled = True
+            self.range_reruns += 1
+        self._rb_scaled = False
         if return_intermediates:
             return results, dict(voxel_features=feats, voxel_coords=coords, levels=levels,
                                  encoded=(x, out_idx, out_shape), spatial_features_nhwc=dense, bev_cat=cat,

@@ -289,6 +289,25 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     return out
 
 
+class launch_log:
+    """with ops.launch_log() as log: ...; log.counts -> {kernel instantiation: launches} of the conv / weight-gradient calls made
+    inside (cpd_launch_log_*; diagnostics for tests and tools)."""
+
+    def __enter__(self):
+        lib().cpd_launch_log_enable(1)
+        self.counts = {}
+        return self
+
+    def __exit__(self, *exc):
+        n = lib().cpd_launch_log_dump(None, 0)
+        buf = ctypes.create_string_buffer(int(n))
+        lib().cpd_launch_log_dump(buf, n)
+        lib().cpd_launch_log_enable(0)
+        for ln in buf.value.decode().splitlines():
+            name, cnt = ln.rsplit(" ", 1)
+            self.counts[name] = int(cnt)
+
+
 ABSMAX_WORDS = 16 * 32       # CPD_ABSMAX_WORDS of include/cpd_hip.h: 16 words, one per 128-byte line
 
 

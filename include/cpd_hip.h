@@ -34,6 +34,12 @@ typedef void *cpd_stream_t; /* hipStream_t; NULL = the default stream, as the re
 #define CPD_ERR_UNSUPPORTED (-4) /* size outside the supported envelope (e.g. >2^31 cells)    */
 
 const char *cpd_version(void);
+/* Diagnostics: with the log enabled every conv / weight-gradient call notes the kernel instantiation it launched
+ * ("rowwave_conv_f16s_kernel<64,2>", "wgrad_f16_kernel<128,128>", ...). dump writes "name count" lines and returns the bytes
+ * needed; enable(…) also clears the log. Host only; tests use it to assert which kernels a full-size step runs.            */
+void cpd_launch_log_enable(int on);
+void cpd_launch_log_note(const char *kernel);
+size_t cpd_launch_log_dump(char *buf, size_t cap);
 int cpd_last_hip_error(void); /* hipError_t of the last CPD_ERR_LAUNCH on this thread */
 
 /* ===== B1. Voxelizer (+ fused MeanVFE) =====================================================
