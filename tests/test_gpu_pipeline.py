@@ -252,7 +252,7 @@ def test_f16x2_range_guard_gives_the_fp32_answer_beyond_fp16_range(hip):
         assert torch.equal(got["levels"][lvl][1], ref["levels"][lvl][1]) or got["levels"][lvl][1].shape == ref["levels"][lvl][1].shape
     close(got["encoded"][0], ref["encoded"][0], "stride-8 sparse output")
     close(got["bev_cat"], ref["bev_cat"], "BEV concat map")
-    close(got["head_rows"], ref["head_rows"], "head maps")
+    close(got["head_rows"][:, :11], ref["head_rows"][:, :11], "head maps")         # (columns 11..15 of the 16-wide block are padding)
     from cpd_amd import ops
     n2 = ref["levels"]["x_conv2"][0].shape[0]
     assert ops.gather_conv_tile(n2, 32, 32, 32, math="f16x2", scaled=True).startswith("rowwave_conv_f16s_kernel")   # the guarded kernels ran
