@@ -201,7 +201,7 @@ def test_tapmask_skipping_is_exact(oracle, hip, cin, cout, n):
 
 
 @pytest.mark.parametrize("cin,cout,n,want", [(128, 128, 80000, "<128,2>"), (128, 128, 24000, "<128,1>"), (64, 64, 30000, "<64,1>"),
-                                             (32, 32, 30000, "<32,1>"), (32, 32, 80000, "<32,2>"), (64, 128, 12000, "<64,1>")])
+                                             (32, 32, 30000, "<32,1>"), (32, 32, 80000, "<32,2>"), (64, 128, 12000, "<64,1>"), (64, 64, 80000, "<64,2>")])
 @pytest.mark.parametrize("math", ["bf16x3", "f16x2"])
 def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, math, cin, cout, n, want):
     """The sparse split kernel (both split arithmetics) in each of its shapes -- 128-row workgroups, the 64-row ones small layers get, and the
@@ -218,7 +218,10 @@ def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, math, cin, cout, 
     d_idx = dev(idx)
     nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
     name = ops.gather_conv_tile(rows, cin, cout, cin, dense=False, math=math)
-    assert name == "rowwave_conv_%s_kernel" % ("f16" if math == "f16x2" else "bf16") + want, (name, rows)
+    family = "rowwave_conv_%s_kernel" % ("f16" if math == "f16x2" else "bf16")
+    if math == "f16x2" and want == "<64,2>":
+        family = "rowwave_deep_f16_kernel"          # round 3: the 64-column f16x2 tiles take the deep-prefetch form (gathers two stages ahead)
+    assert name == family + want, (name, rows)
     w_kio = torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda()
     got = ops.gather_conv(dev(feat), cin, ops.pack_weight(w_kio), nbr, 27, rows, cout, dev(scale), dev(shift), dev(res), True,
                           math=math).cpu().numpy()
