@@ -486,3 +486,23 @@ def test_engine_internal_row_orders_do_not_change_the_result(hip):
             assert torch.equal(a["pred_labels"], b["pred_labels"])
             assert torch.allclose(a["pred_scores"], b["pred_scores"], atol=1e-5)
             assert torch.allclose(a["pred_boxes"], b["pred_boxes"], atol=1e-4)
+
+
+def test_batch_of_65_frames_does_not_leave_a_group_of_one(hip):
+    """more frames than one batched-voxelizer call takes (64) go in groups; 65 used to leave a group of ONE frame, which
+    the batched call refuses -- the last group now borrows a frame. Frames 0, 63 and 64 of a 65-frame batch of small clouds give
+    the detections they give in a batch of their own."""
+    cfg = small_cfg()
+    eng = CenterPointEngine(cfg, init_state_dict(cfg, seed=3), device="cuda")
+    clouds = []
+    for i in range(65):
+        p = waymo_cloud(i % 5, n_points=3000 + 17 * i)
+        p[:, :2] *= 0.3
+        clouds.append(torch.from_numpy(p).cuda())
+    res = eng.forward(clouds)
+    assert len(res) == 65
+    for i in (0, 63, 64):
+        one = eng.forward([clouds[i], clouds[(i + 1) % 65]])[0]
+        assert res[i]["pred_boxes"].shape == one["pred_boxes"].shape
+        np.testing.assert_array_equal(res[i]["pred_labels"].cpu().numpy(), one["pred_labels"].cpu().numpy())
+        np.testing.assert_allclose(res[i]["pred_scores"].cpu().numpy(), one["pred_scores"].cpu().numpy(), atol=2e-5)

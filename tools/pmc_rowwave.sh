@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=$PWD
 tag="$1"; shift
 out=$R/gpurun_out/pmc_rw_$tag; [ -n "$PASSES" ] || rm -rf $out; mkdir -p $out
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras $*"
+CMD="python $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline --no-extras $*"
 cd /tmp
 # every pass under its own timeout: a counter set the hardware cannot schedule makes rocprofv3 abort and then HANG (round 3: 25 min lost)
 pass() { n=$1; shift; if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $n "; then return; fi
