@@ -181,7 +181,7 @@ def test_v2_head_and_proto_head_train_one_step_end_to_end(golden, hip):
     want, _ = ah.anchor_head_loss_torch(head.anchors, det["cls_preds"], det["box_preds"], det["dir_cls_preds"], f["box_cls_labels"],
                                         f["box_reg_targets"], 3, 1.0, 2.0, 0.2, [1.0] * 7)
     want.backward()
-    assert abs(float(losses[0]) - float(want)) <= 1e-4 * max(1.0, abs(float(want)))
+    assert abs(float(losses[0]) - float(want.detach())) <= 1e-4 * max(1.0, abs(float(want.detach())))
     for got, key in zip(grads, ("cls_preds", "box_preds", "dir_cls_preds")):
         ref = det[key].grad
         assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
