@@ -343,11 +343,12 @@ def extras(args, cfg, sd, dev, clouds, value):
         out["value_fp32_mfma"] = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 5,
                                   "note": "same step with conv_math='f32': fp32-input MFMA (v_mfma_f32_16x16x4_f32) in every layer"}
     v, sec = engine_rate(cfg, 4, 40, 8)
-    v2, sec2 = engine_rate(cfg, 4, 60, 8, n_streams=3)
+    v2, sec2 = engine_rate(cfg, 4, 60, 8, n_streams=2)
     out["value_batch4"] = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 40,
-                           "three_batches_in_flight": {"value": v2, "ms_per_step_amortised": 1e3 * sec2, "steps": 60},
+                           "two_batches_in_flight": {"value": v2, "ms_per_step_amortised": 1e3 * sec2, "steps": 60},
                            "note": "4 frames per step: the reference's eval batch per GPU (voxel_rcnn_cproto_center.yaml:188); `value` = one "
-                                   "stream (a step's latency = ms_per_step), three_batches_in_flight = three 4-frame batches on three HIP streams"}
+                                   "stream (a step's latency = ms_per_step), two_batches_in_flight = two 4-frame batches on two HIP streams "
+                                   "(three are slower: the host side of a 4-frame step is 3.6 ms of Python and the workers share the GIL)"}
     v, sec = engine_rate(cfg, 1, 60, 10)
     out["latency_1frame_ms"] = 1e3 * sec
     run = module_api_runner(cfg, sd, dev, clouds, cfg.conv_math)
