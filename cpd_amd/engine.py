@@ -44,8 +44,8 @@ class ModelConfig:
     nms_pre_maxsize: int = 4096
     nms_post_maxsize: int = 500
     # arithmetic of the convolutions with >= 32 input channels (include/cpd_hip.h): "f16x2" = fp32 operands written as two fp16
-    # terms, three partial products accumulated in fp32 on the 16-bit matrix pipe (fp32-level error; activations must stay
-    # below 65504 in magnitude -- an overflow shows as inf / NaN, CPD_GC_F16X2); "bf16x3" = three bf16 terms, six partial
+    # terms, three partial products accumulated in fp32 on the 16-bit matrix pipe (fp32-level error; fp16's range is guarded per
+    # layer, `range_guard` below: any activation magnitude gives the fp32 answer, CPD_GC_F16X2); "bf16x3" = three bf16 terms, six partial
     # products (exact split over the whole fp32 range, CPD_GC_BF16X3); "f32" = fp32-input MFMA everywhere (bitwise an fmaf chain)
     conv_math: str = "f16x2"
     # internal row order of the strided levels: "taps" = every chunk of `row_order_chunk` canonical rows sorted by neighbour

@@ -193,9 +193,10 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
                           workgroup kernel over the tap-skipping wave kernel) */
 /* allow the split-fp16 matrix path instead: fp32 operands written as h + l, two fp16 terms (2 x 11 bits + sign: x to
  * 2^-24 relative, or 2^-25 absolute below 0.5), 3 partial products (hh, hl, lh) accumulated in fp32 -- fp32-level error at
- * half the matrix work of CPD_GC_BF16X3. fp16's range is the contract: |activation| < 65504 (an overflow gives inf / NaN
- * in the output, never a silently wrong number); weights of any magnitude (pre-scaled per output column by a power of two
- * at pack time, undone exactly in the epilogue). Takes precedence over CPD_GC_BF16X3 when both are set. */
+ * half the matrix work of CPD_GC_BF16X3. fp16's range: an input of magnitude >= 65504 gives inf / NaN (0 behind a ReLU
+ * epilogue) UNLESS the call comes with its input's absmax block (cpd_gather_conv_ranged / cpd_conv3x3_rows_ranged below: the
+ * input is then pre-scaled by a power of two, exact at any magnitude); weights of any magnitude (pre-scaled per output column
+ * by a power of two at pack time, undone exactly in the epilogue). Takes precedence over CPD_GC_BF16X3 when both are set. */
 #define CPD_GC_F16X2 4
 
 /* 3x3 / stride 1 / pad 1 convolution (+ folded BN / bias, residual, ReLU: same epilogue as
