@@ -972,7 +972,7 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
 // MS = row sub-tiles per wave: 2 (128-row workgroups) or 1 (64-row workgroups, for layers too small to give every CU a
 // 128-row workgroup: twice the workgroups, each staging the same weights for half the rows).
 template <class S, int BN, int MS, bool SC = false>
-__device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb) {
+__device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb, int *const sidx) {
     float in_s = 1.f, in_inv = 1.f;
     if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
     constexpr int NP = S::NP;
@@ -1047,10 +1047,25 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             for (int s = 0; s < MS; ++s) b |= ((my_mask[s] >> t) & 1u) << s;
             return b;
         };
-        auto load_idx = [&](int t, int (&idx)[MS]) {
+        // The rulebook columns of the wave's rows go to LDS once, for every tap one of its sub-tiles has (round 3). Fetched stage by
+        // stage into registers they were copied from one register set to the next at the loop's end, and the compiler's wait for
+        // that copy -- s_waitcnt vmcnt(0) -- landed at the TOP of the loop, right after the stage's gathers and weight loads had
+        // been issued: every stage waited for all its loads before its MFMAs (the ISA of round 2's kernel shows it).
+        int *const my_idx = sidx + wave * (32 * 16 * MS);
+        {
+            uint32_t my_any = 0;
 #pragma unroll
-            for (int s = 0; s < MS; ++s) idx[s] = p.nbr ? p.nbr[(size_t)t * p.n_out + rowc[s]] : rowc[s];
-        };
+            for (int s = 0; s < MS; ++s) my_any |= my_mask[s];
+            const int wrow0 = row0;
+            for (int e = lane; e < p.kv * 16 * MS; e += 64) {
+                const int t = e / (16 * MS), rr = e - t * (16 * MS);
+                if (!((my_any >> t) & 1u)) continue;
+                const int row = wrow0 + rr;
+                int v = -1;
+                if (row < p.n_out) v = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
+                my_idx[t * 16 * MS + rr] = v;
+            }
+        }
 
         // Stage order: (tap outer, 32-channel block inner), or -- p.taps_inner, the default -- (block outer, tap inner): the
         // taps of one channel block re-gather neighbouring rows' same 128-byte segments back to back (-6...-8 % on the 32- and
@@ -1080,11 +1095,11 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
         const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, (int)(uint32_t)in_bytes, 0x00020000);
         const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
         f32x4u rbv[BJ];
-        auto load_rows = [&](uint32_t on, int kk, const int (&idx)[MS]) {
+        auto load_rows = [&](uint32_t on, int kk, int t) {
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 if ((on >> s) & 1u) {
-                    const int id = row_ok[s] ? idx[s] : -1;
+                    const int id = my_idx[t * 16 * MS + 16 * s + qr];       // (-1 for rows past the end: out of range below)
                     az[s] = id < 0;
                     if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; az[s] = false; continue; }
                     if (use_buf) {
@@ -1181,18 +1196,14 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
         uint32_t on1 = ok1 ? sub_bits(t1) : 0u;
         bool ok2 = ok1 && advance(rem, k2);
         int t2 = ok2 ? __builtin_ctz(rem) : 0;
-        int idx_a[MS], idx_b[MS];                  // rulebook columns, fetched one stage before the gathers they address
-        load_idx(tc, idx_a);
-        load_rows(onc, kc, idx_a);
+        load_rows(onc, kc, tc);
         load_weights(tc, kc);
-        if (ok1) load_idx(t1, idx_b);              // idx_b: column of the next stage to be gathered
         stage_commit(onc);
         __syncthreads();
         while (true) {
             if (ok1) {
                 load_weights(t1, k1);
-                load_rows(on1, k1, idx_b);
-                if (ok2) load_idx(t2, idx_a);
+                load_rows(on1, k1, t1);
             }
             stage_mma(onc);
             if (!ok1) break;
@@ -1206,217 +1217,6 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                 ok2 = advance(rem, k2);
                 t2 = ok2 ? __builtin_ctz(rem) : 0;
             }
-#pragma unroll
-            for (int s = 0; s < MS; ++s) idx_b[s] = idx_a[s];
-        }
-    }
-    epilogue<MS, NT>(p, acc, row0, col0, r, g, in_inv);
-}
-
-// Round 3, second form of the row-wave kernel ("deep"): the same tiles, fragments and epilogue, but
-//   * the rows of a stage are gathered TWO stages ahead into one of two register sets (the current form issues them one
-//     stage ahead: once the gathers stopped queueing at the vector L1 -- quad-shaped loads -- what a wave waited for was one
-//     full memory round trip per stage, covered only by the other waves of its SIMD);
-//   * every vector-memory instruction of the loop is UNCONDITIONAL and in a fixed order (weights of stage s+1, then the
-//     2 MS row loads of stage s+2): a sub-tile without the tap, or a stage past the end, loads out of range (no memory access,
-//     zeros), so the wait before a stage's commit is a counted vmcnt(2 MS) instead of vmcnt(0);
-//   * the rulebook columns of the wave's rows go to LDS once, for all taps the workgroup has (one pass of coalesced loads, like
-//     the fp32 wave kernel), so the loop has no rulebook loads and no address arithmetic for them.
-template <class S, int BN, int MS, bool SC = false>
-__device__ __forceinline__ void rowwave_deep_body(const GcParams &p, char *const sb, int *const sidx) {
-    float in_s = 1.f, in_inv = 1.f;
-    if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
-    constexpr int NP = S::NP;
-    constexpr int NT = BN / 16;
-    constexpr int WG_ROWS = 64 * MS, WG_SUBS = 4 * MS;
-    constexpr int B_SLOTS = NP * 4 * BN;
-    constexpr int BJ = (B_SLOTS + 255) / 256;
-    constexpr int B_IMG = BN * 64;
-    constexpr int WR = 16 * MS;                  // rows of a wave
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int qr = lane >> 2, qj = lane & 3;
-    const int tsrc = (4 * r + g) << 2;
-    const int item = xcd_remap(blockIdx.x, gridDim.x);
-    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
-    const int row0 = rb * WG_ROWS + wave * WR, col0 = cb * BN;
-
-    uint32_t wg_mask = p.kv >= 32 ? 0xffffffffu : ((1u << p.kv) - 1u), my_mask[MS];
-#pragma unroll
-    for (int s = 0; s < MS; ++s) my_mask[s] = wg_mask;
-    if (p.tapmask) {
-        wg_mask = 0;
-#pragma unroll
-        for (int i = 0; i < WG_SUBS; ++i) {
-            const int sub = rb * WG_SUBS + i;
-            const uint32_t m = sub < p.n_sub ? p.tapmask[sub] : 0u;
-            wg_mask |= m;
-#pragma unroll
-            for (int s = 0; s < MS; ++s)
-                if (i == MS * wave + s) my_mask[s] = m;
-        }
-#pragma unroll
-        for (int s = 0; s < MS; ++s) my_mask[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_mask[s]);
-        wg_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_mask);
-    }
-    uint32_t my_any = 0;
-#pragma unroll
-    for (int s = 0; s < MS; ++s) my_any |= my_mask[s];
-
-    f32x4 acc[MS][NT];
-#pragma unroll
-    for (int s = 0; s < MS; ++s)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int sk = p.c_in >> 5;
-    const size_t b_stage = (size_t)NP * 4 * p.np * 16;
-    if (wg_mask) {
-        // rulebook columns of this wave's rows, every tap one of its sub-tiles has: sidx[wave][tap][row of the wave]
-        int *const my_idx = sidx + wave * (32 * WR);
-        for (int e = lane; e < p.kv * WR; e += 64) {
-            const int t = e / WR, rr = e - t * WR;
-            if (!((my_any >> t) & 1u)) continue;
-            const int row = row0 + rr;
-            int v = -1;
-            if (row < p.n_out) v = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
-            my_idx[t * WR + rr] = v;
-        }
-        auto sub_bits = [&](int t) -> uint32_t {
-            uint32_t b = 0;
-#pragma unroll
-            for (int s = 0; s < MS; ++s) b |= ((my_mask[s] >> t) & 1u) << s;
-            return b;
-        };
-        const bool inner = p.taps_inner != 0;
-        auto advance = [&](uint32_t &rem, int &kk) -> bool {
-            if (inner) {
-                rem &= rem - 1u;
-                if (!rem) { rem = wg_mask; ++kk; }
-                return kk < sk;
-            }
-            if (++kk == sk) { kk = 0; rem &= rem - 1u; }
-            return rem != 0u;
-        };
-        const size_t in_bytes = ((size_t)p.n_in_rows * p.in_ld) * sizeof(float);
-        const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, (int)(uint32_t)in_bytes, 0x00020000);
-        const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
-        const uint32_t oob = (uint32_t)p.n_in_rows * row_bytes;          // first byte past the tensor: loads from here on return zeros
-
-        f32x4 ra[MS][2], rbx[MS][2];                   // the two row register sets
-        f32x4u rbv[BJ];
-        // rows of stage (t, kk), sub-tiles `on`, into R -- always 2 MS loads
-        auto load_rows = [&](f32x4 (&R)[MS][2], uint32_t on, int t, int kk) {
-#pragma unroll
-            for (int s = 0; s < MS; ++s) {
-                const int id = my_idx[t * WR + 16 * s + qr];
-                uint32_t off = oob;
-                if (((on >> s) & 1u) && (uint32_t)id < (uint32_t)p.n_in_rows) off = (uint32_t)id * row_bytes + (uint32_t)qj * 16u;
-                if (CPD_GC_ABLATE & 2) { R[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; R[s][1] = R[s][0]; continue; }
-                R[s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, kk * 128, 0));
-                R[s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, kk * 128 + 64, 0));
-            }
-        };
-        auto load_weights = [&](int t, int kk) {
-            const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const int id = j * 256 + tid;
-                const int pg = id / BN, n = id - pg * BN;
-                if (B_SLOTS % 256 == 0 || id < B_SLOTS) {
-                    if (CPD_GC_ABLATE & 1) rbv[j] = f32x4u{(float)t, 1.f, (float)kk, (float)n};
-                    else rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
-                }
-            }
-        };
-        typename S::frag a[MS][NP];
-        auto stage_commit = [&](f32x4 (&R)[MS][2], uint32_t on) {
-#pragma unroll
-            for (int j = 0; j < BJ; ++j)
-                if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) {
-                    const int id = j * 256 + tid;
-                    const int pgo = id / BN, n = id - pgo * BN, go = pgo & 3;
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 lo = {__float_as_uint(rbv[j][0]), __float_as_uint(rbv[j][1])}, hi = {__float_as_uint(rbv[j][2]), __float_as_uint(rbv[j][3])};
-                    char *img = sb + (pgo >> 2) * B_IMG + (go >> 1) * 8;
-                    *reinterpret_cast<u32x2 *>(img + ((((2 * go) & 3) * BN + n) << 4)) = lo;
-                    *reinterpret_cast<u32x2 *>(img + ((((2 * go + 1) & 3) * BN + n) << 4)) = hi;
-                }
-#pragma unroll
-            for (int s = 0; s < MS; ++s) {
-                if ((on >> s) & 1u) {
-                    f32x4 v0 = R[s][0], v1 = R[s][1];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v0[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(v0[k])));
-                        v1[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(v1[k])));
-                    }
-                    typename S::half lo[NP], hi[NP];
-                    S::split(SC ? v0 * in_s : v0, lo);
-                    S::split(SC ? v1 * in_s : v1, hi);
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) a[s][q] = join_halves<S>(lo[q], hi[q]);
-                }
-            }
-        };
-        auto stage_mma = [&](uint32_t on) {
-            if (on) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const char *src = sb + ((g * BN + 16 * nt + r) << 4);
-                    typename S::frag b[NP];
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
-#pragma unroll
-                    for (int s = 0; s < MS; ++s) {
-                        if (CPD_GC_ABLATE & 4) {
-                            if ((on >> s) & 1u) asm volatile("" :: "v"(a[s][0]), "v"(a[s][1]), "v"(b[0]), "v"(b[1]));
-                        } else if ((on >> s) & 1u) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
-                    }
-                }
-            }
-        };
-
-        // cursors: c = computing, 1 / 2 = the stages after it. A stage past the end keeps the last valid (tap, block) with no
-        // active sub-tile: its loads go out of range, its commit and MFMAs do nothing.
-        uint32_t rem = wg_mask;
-        int kq = 0;
-        int tc = __builtin_ctz(rem), kc = 0;
-        uint32_t onc = sub_bits(tc);
-        bool ok1 = advance(rem, kq);
-        int t1 = ok1 ? __builtin_ctz(rem) : tc, k1 = ok1 ? kq : kc;
-        uint32_t on1 = ok1 ? sub_bits(t1) : 0u;
-        bool ok2 = ok1 && advance(rem, kq);
-        int t2 = ok2 ? __builtin_ctz(rem) : t1, k2 = ok2 ? kq : k1;
-        uint32_t on2 = ok2 ? sub_bits(t2) : 0u;
-
-        load_weights(tc, kc);
-        load_rows(ra, onc, tc, kc);
-        load_rows(rbx, on1, t1, k1);
-        stage_commit(ra, onc);
-        __syncthreads();
-        // one iteration: RA is free (its stage was committed), RB holds the rows of stage 1 (in flight)
-        auto iteration = [&](f32x4 (&RA)[MS][2], f32x4 (&RB)[MS][2]) -> bool {
-            load_weights(t1, k1);                       // (stage 1 past the end: a harmless reload of the last stage's weights)
-            load_rows(RA, on2, t2, k2);                 // two stages ahead
-            stage_mma(onc);
-            if (!ok1) return false;
-            if (!(CPD_GC_ABLATE & 8)) __syncthreads();
-            stage_commit(RB, on1);                      // needs the weights (oldest of this iteration) and RB (older): vmcnt(2 MS)
-            if (!(CPD_GC_ABLATE & 8)) __syncthreads();
-            tc = t1; kc = k1; onc = on1;
-            t1 = t2; k1 = k2; on1 = on2; ok1 = ok2;
-            if (ok2) {
-                ok2 = advance(rem, kq);
-                if (ok2) { t2 = __builtin_ctz(rem); k2 = kq; on2 = sub_bits(t2); }
-                else on2 = 0u;
-            }
-            return true;
-        };
-        while (true) {
-            if (!iteration(ra, rbx)) break;
-            if (!iteration(rbx, ra)) break;
         }
     }
     epilogue<MS, NT>(p, acc, row0, col0, r, g, in_inv);
@@ -1427,27 +1227,22 @@ template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, BN == 128 && MS == 2 ? 3 : 8)))
 rowwave_conv_bf16_kernel(GcParams p) {
     __shared__ __attribute__((aligned(16))) char sb[SplitBf16x3::NP * BN * 64];     // one weight stage: pieces x 4 k-groups x BN x 16 B
-    rowwave_conv_split_body<SplitBf16x3, BN, MS>(p, sb);
+    __shared__ int sidx[4 * 32 * 16 * MS];                                         // rulebook columns of the waves' rows
+    rowwave_conv_split_body<SplitBf16x3, BN, MS>(p, sb, sidx);
 }
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
 rowwave_conv_f16_kernel(GcParams p) {
     __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
-    rowwave_conv_split_body<SplitF16x2, BN, MS>(p, sb);
-}
-// the deep-prefetch form (rowwave_deep_body): weights stage + the waves' rulebook columns in LDS
-template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
-rowwave_deep_f16_kernel(GcParams p) {
-    __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
     __shared__ int sidx[4 * 32 * 16 * MS];
-    rowwave_deep_body<SplitF16x2, BN, MS>(p, sb, sidx);
+    rowwave_conv_split_body<SplitF16x2, BN, MS>(p, sb, sidx);
 }
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
 rowwave_conv_f16s_kernel(GcParams p) {            // pre-scaled input (see tile_conv_f16s_kernel)
     __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
-    rowwave_conv_split_body<SplitF16x2, BN, MS, true>(p, sb);
+    __shared__ int sidx[4 * 32 * 16 * MS];
+    rowwave_conv_split_body<SplitF16x2, BN, MS, true>(p, sb, sidx);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -1961,22 +1756,11 @@ extern "C" int cpd_pack_batch_run(const void *table, int n_jobs, const int32_t g
     return cpd_check_launch();
 }
 
-// Which unscaled split-fp16 row-wave launches take the deep-prefetch form (rowwave_deep_body): measured (48 frames, same box A/B,
-// profiles/README.md): 64-column tiles 0.1386 -> 0.127 ms per frame (-8 %: same 4 waves per SIMD, the gathers two stages ahead);
-// 128-column tiles unchanged; 32-column tiles +4 % (88 registers: 5 waves per SIMD instead of 6). CPD_GC_ROWWAVE_DEEP = 0 / 1
-// forces none / all (read once).
-static bool rowwave_deep(const GcPlan &pl, bool scaled) {
-    static const int knob = [] { const char *e = getenv("CPD_GC_ROWWAVE_DEEP"); return e ? atoi(e) : -1; }();
-    if (pl.use_wg != 3 || pl.math != 2 || scaled || pl.a != 128) return false;
-    return knob < 0 ? pl.b == 64 : knob != 0;
-}
-
 extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, int flags, int *wg, int *a, int *b,
                                     int *vec) {
     if (n_out <= 0 || c_in <= 0 || c_out <= 0 || !wg || !a || !b || !vec) return CPD_ERR_ARG;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, nullptr, flags);
     *wg = pl.use_wg + ((pl.use_wg >= 2 && pl.math == 2) ? 10 : 0);      // 12 / 13: the f16x2 instantiations of 2 / 3
-    if (rowwave_deep(pl, false)) *wg = 23;                               // ... 23: the deep-prefetch form of 13 (unscaled input)
     *a = pl.a; *b = pl.b; *vec = pl.vec;
     return CPD_OK;
 }
@@ -2019,8 +1803,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     {   // launch log (cpd_launch_log_*): the instantiation this call runs
         char nm[96];
         const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? "f16" : "bf16");
-        if (rowwave_deep(pl, in_absmax != nullptr)) snprintf(nm, sizeof nm, "rowwave_deep_f16_kernel<%d,%d>", pl.b, pl.a / 64);
-        else if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
+        if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
         else if (pl.use_wg == 2) snprintf(nm, sizeof nm, "tile_conv_%s_kernel<%d,%d>", sc, pl.a, pl.b);
         else if (pl.use_wg == 1) snprintf(nm, sizeof nm, "tile_conv_kernel<%d,%d>", pl.a, pl.b);
         else snprintf(nm, sizeof nm, "gather_conv_kernel<%d,%d,%s>", pl.a, pl.b, pl.vec ? "true" : "false");
@@ -2035,12 +1818,6 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16s_kernel<32, 2>), 0);
         else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16s_kernel<64, 2>), 0);
         else CPD_LAUNCH((rowwave_conv_f16s_kernel<128, 2>), 0);
-        return cpd_check_launch();
-    }
-    if (rowwave_deep(pl, in_absmax != nullptr)) {
-        if (pl.b == 32) CPD_LAUNCH((rowwave_deep_f16_kernel<32, 2>), 0);
-        else if (pl.b == 64) CPD_LAUNCH((rowwave_deep_f16_kernel<64, 2>), 0);
-        else CPD_LAUNCH((rowwave_deep_f16_kernel<128, 2>), 0);
         return cpd_check_launch();
     }
     if (pl.use_wg == 3 && pl.math == 2) {

@@ -498,9 +498,7 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=N
     """Name of the kernel instantiation gather_conv will run for this problem (`nbr`: the table it would be given; `scaled`: an
     `in_absmax` block comes with the input -- the split-fp16 kernels then run as their pre-scaling `f16s` instantiations)."""
     name = _gather_conv_tile(n_out, c_in, c_out, in_ld, dense, bf16x3, nbr, math)
-    if scaled:                                  # the pre-scaling instantiations have no deep-prefetch form
-        name = name.replace("rowwave_deep_f16_kernel", "rowwave_conv_f16_kernel").replace("_f16_kernel", "_f16s_kernel")
-    return name
+    return name.replace("_f16_kernel", "_f16s_kernel") if scaled else name
 
 
 def _gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None):
@@ -516,8 +514,6 @@ def _gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=
     check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), flags,
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
           "cpd_gather_conv_tile")
-    if wg.value == 23:
-        return "rowwave_deep_f16_kernel<%d,%d>" % (b.value, a.value // 64)            # the deep-prefetch form (unscaled f16x2 input)
     if wg.value in (3, 13):
         return "rowwave_conv_%s_kernel<%d,%d>" % ("f16" if wg.value == 13 else "bf16", b.value, a.value // 64)   # <column tile, row sub-tiles per wave>
     if wg.value in (2, 12):

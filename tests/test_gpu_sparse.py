@@ -218,10 +218,7 @@ def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, math, cin, cout, 
     d_idx = dev(idx)
     nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
     name = ops.gather_conv_tile(rows, cin, cout, cin, dense=False, math=math)
-    family = "rowwave_conv_%s_kernel" % ("f16" if math == "f16x2" else "bf16")
-    if math == "f16x2" and want == "<64,2>":
-        family = "rowwave_deep_f16_kernel"          # round 3: the 64-column f16x2 tiles take the deep-prefetch form (gathers two stages ahead)
-    assert name == family + want, (name, rows)
+    assert name == "rowwave_conv_%s_kernel" % ("f16" if math == "f16x2" else "bf16") + want, (name, rows)
     w_kio = torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda()
     got = ops.gather_conv(dev(feat), cin, ops.pack_weight(w_kio), nbr, 27, rows, cout, dev(scale), dev(shift), dev(res), True,
                           math=math).cpu().numpy()

@@ -303,7 +303,7 @@ def test_full_size_config3_step_is_locally_exact_on_the_benchmarked_kernels(hip)
     assert report[0][0] <= 1e-4, report[:5]
     # the instantiations of the measured train step (one frame, full widths): weight gradients, input-gradient and forward convs
     for name in ("wgrad_f16_kernel<128,128>", "wgrad_f16_kernel<64,64>", "wgrad_f16_kernel<32,32>", "tile_conv_f16s_kernel<64,128>",
-                 "tile_conv_f16_kernel<64,128>", "rowwave_conv_f16s_kernel<64,2>", "rowwave_deep_f16_kernel<64,2>",
+                 "tile_conv_f16_kernel<64,128>", "rowwave_conv_f16s_kernel<64,2>", "rowwave_conv_f16_kernel<64,2>",
                  "rowwave_conv_f16s_kernel<32,2>", "rowwave_conv_f16_kernel<32,2>", "rowwave_conv_f16s_kernel<128,1>",
                  "rowwave_conv_f16_kernel<128,1>"):
         assert log.counts.get(name, 0) > 0, (name, sorted(log.counts))

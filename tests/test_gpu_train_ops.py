@@ -380,7 +380,7 @@ def test_scaled_split_fp16_gradient_convs(oracle, hip, monkeypatch, mag):
     # input gradient = gather_conv on the adjoint weights, same rulebook
     pw_adj = T.pack_weight_adjoint(d_w, flip_taps=True)
     name = ops.gather_conv_tile(n, cout, cin, cout, dense=False, math="f16x2")
-    assert name.startswith(("rowwave_conv_f16_kernel", "rowwave_deep_f16_kernel")), name
+    assert name.startswith("rowwave_conv_f16_kernel"), name
     dx16 = ops.gather_conv(d_dz, cout, pw_adj, nbr, 27, n, cin, math="f16x2", in_absmax=am).double().cpu().numpy()
     dx3 = ops.gather_conv(d_dz, cout, pw_adj, nbr, 27, n, cin, math="bf16x3").double().cpu().numpy()
     idx_t = np.where(nbr_h < 0, n, nbr_h)

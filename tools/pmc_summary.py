@@ -13,7 +13,7 @@ root, out = sys.argv[1], sys.argv[2]
 
 
 def short(name):
-    m = re.search(r"((?:gather|tile|rowwave|window)_(?:conv|deep)\w*kernel)<([^>]*)>", name)
+    m = re.search(r"((?:gather|tile|rowwave|window)_conv\w*kernel)<([^>]*)>", name)
     if not m:
         return None
     args = [a.strip() for a in m.group(2).split(",")]
