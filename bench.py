@@ -304,8 +304,10 @@ def module_api_runner(cfg, sd, dev, clouds, conv_math):
     return run
 
 
-def extras(args, cfg, sd, dev, clouds, value):
-    """The extra figures of the default N = 1 line, each measured here with its own engine on the same clouds."""
+def extras(args, cfg, sd, dev, clouds, value, streams=()):
+    """The extra figures of the default N = 1 line, each measured here with its own engine on the same clouds. `streams`: the HIP
+    streams of the main run, re-used for the two-batches-in-flight figure (HIP deals streams to a few hardware queues in creation
+    order; a fresh pair made after the main run's can land on ONE queue and serialise: 640 instead of 897 frames/s, round 3)."""
     out = {}
     B = args.frames
 
@@ -316,7 +318,7 @@ def extras(args, cfg, sd, dev, clouds, value):
         if n_streams == 1:
             sec = time_steps(lambda i: engs[0].forward([clouds[(i * frames + j) % POOL] for j in range(frames)]), steps, warmup)
             return frames / sec, sec
-        strs = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        strs = list(streams[:n_streams]) + [torch.cuda.Stream(device=dev) for _ in range(n_streams - len(streams))]
 
         def run(n):
             def worker(w):
@@ -676,7 +678,7 @@ def main():
     if world == 1 and not args.no_extras and args.api == "engine" and not args.host_input:
         engines.clear()
         torch.cuda.empty_cache()
-        out.update(extras(args, cfg, sd, dev, clouds, out["value"]))
+        out.update(extras(args, cfg, sd, dev, clouds, out["value"], streams))
         torch.cuda.empty_cache()
         out["train_step"] = train_step_extra(args, cfg, sd, dev)
 
