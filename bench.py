@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--row-order", choices=["taps", "canonical"], default="taps",
                     help="internal row order of the strided sparse levels (ModelConfig.row_order)")
     ap.add_argument("--row-order-chunk", type=int, default=4096)
+    ap.add_argument("--pair-rows", type=int, choices=[0, 1], default=1, help="fp16-pair rows between the f16x2 sparse layers (ModelConfig.pair_rows)")
     ap.add_argument("--conv-math", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
                     help="arithmetic of the layers with >= 32 input channels: split-fp16 x2 (3 products) or split-bf16 x3 (6 products) "
                          "on the 16-bit matrix pipe (both fp32-level error), or fp32 MFMA")
@@ -128,7 +129,7 @@ class ConvProfiler:
 
         def wrapped(inp, c_in, packed_w, nbr, kv, n_out, c_out, *a, **kw):
             kname = ops.gather_conv_tile(n_out, c_in, c_out, inp.stride(0), kw.get("dense", False), kw.get("bf16x3", False), nbr,
-                                         math=kw.get("math"), scaled=kw.get("in_absmax") is not None)
+                                         math=kw.get("math"), scaled=kw.get("in_absmax") is not None, in_pairs=kw.get("in_pairs", False))
             pairs = prof._pairs(nbr, n_out, c_in, c_out)
             flops = 2.0 * pairs * c_in * c_out
             # algorithmic HBM bytes of the layer: every feature row once in and once out, the weights, the
@@ -522,7 +523,7 @@ def main():
     # "nccl" is RCCL on ROCm; CPD_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests
     distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"), torch.device("cuda", local))
 
-    cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk)
+    cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk, pair_rows=bool(args.pair_rows))
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local
     if args.mode == "train":

@@ -65,6 +65,10 @@ struct GcParams {
     int n_rb, n_cb, items, n_sub;
     int img_h, img_w;         // window kernel only: the rows are frames x img_h x img_w pixels
     int taps_inner;           // row-wave kernel: stage order (32-channel block outer, tap inner)
+    // fp16-pair rows (CPD_GC_*_PAIRS): a row keeps its 4 * C bytes, but every 32-channel block holds the fp16 HIGH terms of its
+    // channels (64 B) followed by the fp16 LOW terms (64 B) -- the split x = h + l of SplitF16x2, made ONCE by the epilogue that
+    // produced the row instead of by every gather of it (27 taps x ...); the row-wave kernel then takes gathered bits as fragments
+    int in_pairs, out_pairs, res_pairs;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -118,7 +122,8 @@ __device__ __forceinline__ void in_pow2_scale(const uint32_t *absmax, float &s, 
     }
 }
 
-template <int MS, int NT>
+// PAIRS: the instantiation honours p.out_pairs / p.res_pairs (the sparse kernels; elsewhere the flags are refused by the launcher)
+template <int MS, int NT, bool PAIRS = false>
 __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT], int row0, int col0, int r, int g, float acc_scale = 1.f) {
     float sc[NT], sh[NT];
     int grp[NT], cloc[NT];            // column-group scatter (ConvTranspose as one GEMM): group and column inside it, per column tile
@@ -149,7 +154,14 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
                 if (col >= p.c_out) continue;
                 float v = acc[s][nt][i];
                 v = v * sc[nt] + sh[nt];
-                if (p.residual) v += p.residual[(size_t)row * p.res_ld + col];
+                if (p.residual) {
+                    if (PAIRS && p.res_pairs) {       // h + l is exact in fp32
+                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)row * p.res_ld) + ((col >> 5) << 7) + ((col & 31) << 1);
+                        v += (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 64);
+                    } else {
+                        v += p.residual[(size_t)row * p.res_ld + col];
+                    }
+                }
                 if (p.relu) v = v > 0.f ? v : 0.f;
                 const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
                 vmax = vb > vmax ? vb : vmax;
@@ -159,6 +171,17 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
                         drow = (size_t)p.out_row_map[(size_t)grp_have * p.n_out + row];
                     }
                     p.out[drow * p.out_ld + cloc[nt]] = v;
+                } else if (PAIRS && p.out_pairs) {
+                    // fp16-pair row: lanes r, r ^ 1 (columns col, col ^ 1; same row) trade their (h, l): the even lane stores the two
+                    // high terms, the odd lane the two low terms -- one 4-byte store per lane, as for an fp32 row
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    const uint32_t mine = (uint32_t)__builtin_bit_cast(unsigned short, h) | ((uint32_t)__builtin_bit_cast(unsigned short, l) << 16);
+                    const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                    const bool odd = (r & 1) != 0;
+                    const uint32_t word = odd ? ((theirs >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (theirs << 16));
+                    char *op = reinterpret_cast<char *>(p.out + orow * p.out_ld) + ((col >> 5) << 7) + (odd ? 64 : 0) + ((col & 30) << 1);
+                    *reinterpret_cast<uint32_t *>(op) = word;
                 } else {
                     p.out[orow * p.out_ld + col] = v;
                 }
@@ -349,7 +372,7 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
             if (t_cur < 0) break;
         }
     }
-    epilogue<MS, NT>(p, acc, row0, col0, r, g);
+    epilogue<MS, NT, true>(p, acc, row0, col0, r, g);
 }
 
 // ================================ workgroup kernel ===========================================
@@ -971,7 +994,7 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
 // MS = row sub-tiles per wave: 2 (128-row workgroups) or 1 (64-row workgroups, for layers too small to give every CU a
 // 128-row workgroup: twice the workgroups, each staging the same weights for half the rows).
-template <class S, int BN, int MS, bool SC = false>
+template <class S, int BN, int MS, bool SC = false, bool PS = false>
 __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb, int *const sidx) {
     float in_s = 1.f, in_inv = 1.f;
     if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
@@ -1135,6 +1158,10 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                     // k order of the LDS weight image = the gathered fragments': the packed slot (piece image q, k-group go, column n)
                     // holds channels 8 go .. 8 go + 7; its half hf (channels 4 (2 go + hf) ..) goes to k-group (2 go + hf) & 3, position go >> 1
                     const int id = j * 256 + tid;
+                    if (PS) {               // fp16-pair input: the fragments come in the natural k order, and so does the image
+                        *reinterpret_cast<f32x4u *>(sb + (id << 4)) = rbv[j];
+                        continue;
+                    }
                     const int pgo = id / BN, n = id - pgo * BN, go = pgo & 3;
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                     const u32x2 lo = {__float_as_uint(rbv[j][0]), __float_as_uint(rbv[j][1])}, hi = {__float_as_uint(rbv[j][2]), __float_as_uint(rbv[j][3])};
@@ -1155,7 +1182,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                         araw[s][0][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(araw[s][0][k])));
                         araw[s][1][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(araw[s][1][k])));
                     }
-                    if (CPD_GC_ABLATE & 4096) {      // timing only: the gathered bits taken as they are (what pre-split storage would allow)
+                    if (PS || (CPD_GC_ABLATE & 4096)) {     // fp16-pair rows: piece 0 = the high terms of channels 8g .. 8g + 7, piece 1 = the low terms
 #pragma unroll
                         for (int q = 0; q < NP; ++q) a[s][q] = __builtin_bit_cast(typename S::frag, araw[s][q & 1]);
                         continue;
@@ -1219,7 +1246,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             }
         }
     }
-    epilogue<MS, NT>(p, acc, row0, col0, r, g, in_inv);
+    epilogue<MS, NT, true>(p, acc, row0, col0, r, g, in_inv);
 }
 
 // (bf16x3, BN = 128, MS = 2 sits at the 3-waves-per-SIMD budget)
@@ -1243,6 +1270,14 @@ rowwave_conv_f16s_kernel(GcParams p) {            // pre-scaled input (see tile_
     __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
     __shared__ int sidx[4 * 32 * 16 * MS];
     rowwave_conv_split_body<SplitF16x2, BN, MS, true>(p, sb, sidx);
+}
+
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcParams::in_pairs): no split in the stage loop
+    __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
+    __shared__ int sidx[4 * 32 * 16 * MS];
+    rowwave_conv_split_body<SplitF16x2, BN, MS, false, true>(p, sb, sidx);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -1501,7 +1536,7 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
                 return pl;
             }
         }
-        if ((small_rows ? row_tiles64 : row_tiles) * (c_out / 32) >= rw_floor) {
+        if ((small_rows ? row_tiles64 : row_tiles) * (c_out / 32) >= rw_floor || (flags & CPD_GC_IN_PAIRS)) {   // (fp16-pair rows: only this kernel reads them)
             pl.use_wg = 3; pl.a = small_rows ? 64 : 128; pl.b = 32;
             return pl;
         }
@@ -1776,7 +1811,14 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         out_ld < (out_col_group > 0 ? (out_col_group < c_out ? out_col_group : c_out) : c_out))
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
+    // fp16-pair rows: whole 32-channel blocks, f16x2 arithmetic, no pre-scaling (a guarded re-run works on fp32 rows)
+    if ((flags & CPD_GC_IN_PAIRS) && (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || c_in % 32 || c_out % 32 || in_ld % 4 || in_absmax || kv > 32 ||
+                                      (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
+        return CPD_ERR_UNSUPPORTED;
+    if ((flags & CPD_GC_OUT_PAIRS) && (c_out % 32 || out_col_group > 0)) return CPD_ERR_UNSUPPORTED;
+    if ((flags & CPD_GC_RES_PAIRS) && (!residual || c_out % 32)) return CPD_ERR_ARG;
     GcParams p;
+    p.in_pairs = (flags & CPD_GC_IN_PAIRS) != 0; p.out_pairs = (flags & CPD_GC_OUT_PAIRS) != 0; p.res_pairs = (flags & CPD_GC_RES_PAIRS) != 0;
     p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.in_absmax = in_absmax; p.out_absmax = out_absmax; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16; p.n_in_rows = n_in;
@@ -1785,6 +1827,8 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
     if (pl.use_wg == 3 && (kv > 32 || (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
         pl = plan(n_out, c_in, c_out, in_ld, in, flags | CPD_GC_DENSE);   // the row-wave kernel keeps its taps in 32-bit sets and reads its rows through a 4 GB buffer resource
+    if (p.in_pairs && (pl.use_wg != 3 || pl.math != 2)) return CPD_ERR_UNSUPPORTED;
+    if ((p.out_pairs || p.res_pairs) && pl.use_wg != 3 && pl.use_wg != 0) return CPD_ERR_UNSUPPORTED;   // (the sparse kernels' epilogues)
     p.taps_inner = 1;       // measured (tools/order_probe.py): -6...-8 % on the 32- and 128-channel SubM layers, neutral at 64
     if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_TAPS_INNER")) p.taps_inner = atoi(e);
     static const bool trace = getenv("CPD_GC_TRACE") != nullptr;    // one line per launch: which kernel a layer got
@@ -1802,7 +1846,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     hipStream_t hs = cpd_s(stream);
     {   // launch log (cpd_launch_log_*): the instantiation this call runs
         char nm[96];
-        const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? "f16" : "bf16");
+        const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? (p.in_pairs ? "f16p" : "f16") : "bf16");
         if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
         else if (pl.use_wg == 2) snprintf(nm, sizeof nm, "tile_conv_%s_kernel<%d,%d>", sc, pl.a, pl.b);
         else if (pl.use_wg == 1) snprintf(nm, sizeof nm, "tile_conv_kernel<%d,%d>", pl.a, pl.b);
@@ -1818,6 +1862,16 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16s_kernel<32, 2>), 0);
         else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16s_kernel<64, 2>), 0);
         else CPD_LAUNCH((rowwave_conv_f16s_kernel<128, 2>), 0);
+        return cpd_check_launch();
+    }
+    if (pl.use_wg == 3 && pl.math == 2 && p.in_pairs) {
+        if (pl.a == 64) {
+            if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16p_kernel<32, 1>), 0);
+            else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16p_kernel<64, 1>), 0);
+            else CPD_LAUNCH((rowwave_conv_f16p_kernel<128, 1>), 0);
+        } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16p_kernel<32, 2>), 0);
+        else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16p_kernel<64, 2>), 0);
+        else CPD_LAUNCH((rowwave_conv_f16p_kernel<128, 2>), 0);
         return cpd_check_launch();
     }
     if (pl.use_wg == 3 && pl.math == 2) {

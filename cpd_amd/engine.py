@@ -59,6 +59,10 @@ class ModelConfig:
     # unguarded split-fp16 arithmetic overflows to inf / NaN at 65504. False = the unscaled kernels.
     range_guard: bool = True
     voxel_row_order: str = "canonical"
+    # storage of the activations BETWEEN the f16x2 sparse layers of levels 2-4 (engine-internal; every exported tensor is fp32):
+    # True = fp16-pair rows (CPD_GC_*_PAIRS: the epilogue that produces a row writes its split x = h + l, the up to 27 gathers of
+    # the row take the bits as MFMA fragments -- same products, no split in the stage loop); a range-guard re-run uses fp32 rows
+    pair_rows: bool = True
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
     row_order: str = "taps"
     row_order_chunk: int = 4096
@@ -336,26 +340,31 @@ class CenterPointEngine:
             return None
         return (self._rb_pool.max() >= 0x47000000).to(torch.int32).view(1)        # bits of 32768.0f; NaN / inf bits are larger
 
-    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False, out_rb="new"):
+    def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False, out_rb="new",
+              in_pairs=False, out_pairs=False, res_pairs=False):
         rb_in = self._rb if getattr(self, "_rb_scaled", False) else None
         rb_out = self._range_new() if out_rb == "new" else out_rb
         y = ops.gather_conv(x, layer.c_in, layer.w, nbr, layer.kv, n_out, layer.c_out, layer.scale, layer.shift,
                             residual, layer.relu, out=out, out_row_map=out_row_map, out_col_group=out_col_group,
-                            dense=dense, math=self.cfg.conv_math, in_absmax=rb_in, out_absmax=rb_out)
+                            dense=dense, math=self.cfg.conv_math, in_absmax=rb_in, out_absmax=rb_out,
+                            in_pairs=in_pairs, out_pairs=out_pairs, res_pairs=res_pairs)
         self._rb = rb_out
         return y
 
-    def _blocks(self, blocks, x, nbr):
+    def _blocks(self, blocks, x, nbr, pairs=False):
         n = x.shape[0]
         for c1, c2 in blocks:                      # SparseBasicBlock, spconv_backbone.py:120-136
-            y = self._conv(c1, x, nbr, n)
-            x = self._conv(c2, y, nbr, n, residual=x)
+            y = self._conv(c1, x, nbr, n, in_pairs=pairs, out_pairs=pairs)
+            x = self._conv(c2, y, nbr, n, residual=x, in_pairs=pairs, out_pairs=pairs, res_pairs=pairs)
         return x
 
-    def backbone3d(self, feats, coords, batch, index=None):
+    def backbone3d(self, feats, coords, batch, index=None, pair_rows=False, export_levels=True):
         """VoxelResBackBone8x.forward (spconv_backbone.py:502-558). Returns per-level
         {name: (features, indices, spatial_shape)} and the stride-8 output. `index`: the level-0 site index when the
-        voxelizer already built it (cpd_voxelize_batch_index)."""
+        voxelizer already built it (cpd_voxelize_batch_index). `pair_rows`: levels 2-4 keep their activations as fp16-pair rows
+        between layers (ModelConfig.pair_rows; f16x2 only); the returned level features are fp32 either way when
+        `export_levels` (decoded copies), else whatever the layers left."""
+        pairs = bool(pair_rows) and self.cfg.conv_math == "f16x2"
         L = self.sparse
         shape = self.cfg.sparse_shape
         if index is None:
@@ -366,6 +375,7 @@ class CenterPointEngine:
         x = self._blocks(L["conv1"], x, nbr)
         levels = {"x_conv1": (x, coords, shape)}
         coords_c = coords                  # the list the next level's output set is marked from: canonical order wherever one exists
+        pairs_in = False                   # level 1 (16 channels) runs on the fp32 pipe: fp32 rows
         for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
             k, s, pd = _DOWN[stage]
             out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
@@ -377,15 +387,18 @@ class CenterPointEngine:
                 out_idx, _, old_to_new = ops.order_rows_by_taps(out_c, out_index, chunk_rows=self.cfg.row_order_chunk)
                 out_index.set_order(old_to_new)
             nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
-            x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0])
+            # (pair rows are read through the row-wave kernel's 4 GB buffer resource: a level that large stays fp32)
+            pairs_out = pairs and out_idx.shape[0] * L[stage + ".down"].c_out * 4 < 0xfffff000
+            x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in, out_pairs=pairs_out)
             nbr = ops.rulebook_subm(out_idx, out_index)
-            x = self._blocks(L[stage], x, nbr)
+            x = self._blocks(L[stage], x, nbr, pairs=pairs_out)
+            pairs_in = pairs_out
             coords, coords_c, index, shape = out_idx, out_c, out_index, out_shape
-            levels["x_conv%d" % i] = (x, coords, shape)
+            levels["x_conv%d" % i] = (ops.pairs_to_rows(x) if pairs_in and export_levels else x, coords, shape)
         k, s, pd = _DOWN["conv_out"]
         out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
         nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
-        x = self._conv(L["conv_out"], x, nbr_dn, out_idx.shape[0])
+        x = self._conv(L["conv_out"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in)
         self._rb_stage = "backbone"                            # the densified map inherits this output's range block
         return levels, (x, out_idx, out_shape)
 
@@ -543,7 +556,8 @@ class CenterPointEngine:
         self._rb_scaled = False
         self.range_reruns = getattr(self, "range_reruns", 0)
         while True:
-            levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0)
+            levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0, export_levels=return_intermediates,
+                                                              pair_rows=self.cfg.pair_rows and not self._rb_scaled)
             d, h, w = out_shape
             dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
             cat, head = self.bev_and_head(dense, batch, h, w)

@@ -249,7 +249,7 @@ def _gc_flags(dense, bf16x3, math):
 
 def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=None, residual=None, relu=False,
                 out=None, out_row_map=None, out_col_group=0, dense=False, bf16x3=False, math=None, in_absmax=None, out_absmax=None,
-                guard=False):
+                guard=False, in_pairs=False, out_pairs=False, res_pairs=False):
     """out[j,:c_out] = act((sum_t in[nbr[t][j]] . W[t]) * scale + shift + residual[j]).
     `inp` / `out` / `residual` are 2-D row tensors whose row stride may exceed the channel count.
     `math`: "f32" | "bf16x3" | "f16x2" (overrides the older `bf16x3` switch).
@@ -257,7 +257,10 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     gradients): the split-fp16 kernels then pre-scale `inp` into fp16's range by a power of two (exact) -- the range guard of
     the f16x2 inference path, and how gradients take that path. `out_absmax`: a block this launch raises to max |out| (zeroed by
     the caller; the next layer's `in_absmax`). `guard=True`: f16x2 with no `in_absmax` given measures the input first
-    (one extra pass over `inp`) instead of trusting it to stay below 65504."""
+    (one extra pass over `inp`) instead of trusting it to stay below 65504.
+    `in_pairs` / `out_pairs` / `res_pairs`: the rows of `inp` / `out` / `residual` are fp16-PAIR rows (CPD_GC_*_PAIRS of
+    include/cpd_hip.h: per 32-channel block the fp16 high terms, then the fp16 low terms -- rows_to_pairs / pairs_to_rows here):
+    storage between the engine's f16x2 sparse layers, sparse (non-`dense`) f16x2 calls only."""
     _need_cuda(inp, "inp")
     assert inp.dim() == 2 and inp.stride(1) == 1
     if guard and in_absmax is None and (math == "f16x2") and c_in % 32 == 0:
@@ -269,9 +272,9 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     if residual is not None:
         assert residual.dim() == 2 and residual.stride(1) == 1
         res_ld = residual.stride(0)
-    flags = _gc_flags(dense, bf16x3, math)
+    flags = _gc_flags(dense, bf16x3, math) | (16 if in_pairs else 0) | (32 if out_pairs else 0) | (64 if res_pairs else 0)
     image = getattr(nbr, "image", None)             # 3x3 / stride 1 / pad 1 pixel table: the rulebook-free window kernel
-    if image is not None and out_row_map is None and kv == 9 and n_out == image[0] * image[1] * image[2] and inp.shape[0] == n_out:
+    if image is not None and not (flags & 0x70) and out_row_map is None and kv == 9 and n_out == image[0] * image[1] * image[2] and inp.shape[0] == n_out:
         rc = lib().cpd_conv3x3_rows_ranged(
             ctypes.c_void_p(inp.data_ptr()), inp.stride(0), image[0], image[1], image[2], c_in, ptr(packed_w), c_out,
             ptr(scale), ptr(shift), ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld,
@@ -287,6 +290,26 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
         ptr(in_absmax), ptr(out_absmax), stream()),
         "cpd_gather_conv")
     return out
+
+
+def rows_to_pairs(x):
+    """fp32 rows [n, C] (C % 32 == 0) -> the same bytes as fp16-pair rows (a float32 tensor of the same shape holding, per 32-channel
+    block, 32 fp16 high terms then 32 fp16 low terms of x = h + l; CPD_GC_*_PAIRS). torch ops: tests and tools, not the hot path."""
+    n, c = x.shape
+    assert c % 32 == 0 and x.dtype == torch.float32
+    h = x.to(torch.float16)
+    l = (x - h.float()).to(torch.float16)
+    pairs = torch.stack([h.view(n, c // 32, 32), l.view(n, c // 32, 32)], dim=2)       # [n, blocks, 2, 32] fp16
+    return pairs.contiguous().view(n, c * 2).view(torch.float32)
+
+
+def pairs_to_rows(x, c=None):
+    """fp16-pair rows -> fp32 rows (h + l, exact in fp32)."""
+    n = x.shape[0]
+    c = x.shape[1] if c is None else c
+    assert c % 32 == 0 and x.dtype == torch.float32
+    halves = x[:, :c].contiguous().view(torch.float16).view(n, c // 32, 2, 32).float()
+    return (halves[:, :, 0] + halves[:, :, 1]).reshape(n, c)
 
 
 class launch_log:
@@ -494,16 +517,16 @@ def boxes_iou_bev_cpu(a, b):
     return out
 
 
-def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None, scaled=False):
+def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None, scaled=False, in_pairs=False):
     """Name of the kernel instantiation gather_conv will run for this problem (`nbr`: the table it would be given; `scaled`: an
     `in_absmax` block comes with the input -- the split-fp16 kernels then run as their pre-scaling `f16s` instantiations)."""
-    name = _gather_conv_tile(n_out, c_in, c_out, in_ld, dense, bf16x3, nbr, math)
+    name = _gather_conv_tile(n_out, c_in, c_out, in_ld, dense, bf16x3, nbr, math, in_pairs)
     return name.replace("_f16_kernel", "_f16s_kernel") if scaled else name
 
 
-def _gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None):
+def _gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None, in_pairs=False):
     image = getattr(nbr, "image", None)
-    flags = _gc_flags(dense, bf16x3, math)
+    flags = _gc_flags(dense, bf16x3, math) | (16 if in_pairs else 0)
     if image is not None and n_out == image[0] * image[1] * image[2] and in_ld % 4 == 0 and lib().cpd_conv3x3_rows_supported(
             image[0], image[1], image[2], int(c_in), int(c_out), flags):
         bm, bn = ctypes.c_int(0), ctypes.c_int(0)
@@ -515,7 +538,7 @@ def _gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
           "cpd_gather_conv_tile")
     if wg.value in (3, 13):
-        return "rowwave_conv_%s_kernel<%d,%d>" % ("f16" if wg.value == 13 else "bf16", b.value, a.value // 64)   # <column tile, row sub-tiles per wave>
+        return "rowwave_conv_%s_kernel<%d,%d>" % (("f16p" if flags & 16 else "f16") if wg.value == 13 else "bf16", b.value, a.value // 64)   # <column tile, row sub-tiles per wave>
     if wg.value in (2, 12):
         return "tile_conv_%s_kernel<%d,%d>" % ("f16" if wg.value == 12 else "bf16", a.value, b.value)
     if wg.value:

@@ -198,6 +198,19 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
  * input is then pre-scaled by a power of two, exact at any magnitude); weights of any magnitude (pre-scaled per output column
  * by a power of two at pack time, undone exactly in the epilogue). Takes precedence over CPD_GC_BF16X3 when both are set. */
 #define CPD_GC_F16X2 4
+/* fp16-pair rows (engine-internal storage between f16x2 sparse layers; the boundary tensors stay fp32): a row keeps its 4 * C
+ * bytes, but every 32-channel block holds the fp16 HIGH terms of its channels (64 B, natural order) followed by the fp16 LOW terms
+ * (64 B) -- exactly the split x = h + l the f16x2 kernels make of a gathered fp32 row, made ONCE by the epilogue that produced
+ * the row instead of by each of the <= 27 gathers of it. The partial products are those of fp32 rows (the accumulation order inside
+ * a 32-channel block differs: fp32 rounding); a residual read back from pairs is h + l (x to 2^-24 relative). Same range as CPD_GC_F16X2 without an absmax block: |x| < 65504
+ * (the engine's range guard re-runs such a step on fp32 rows with pre-scaling).
+ *   CPD_GC_IN_PAIRS   `in` rows are pairs: needs CPD_GC_F16X2, c_in % 32 == 0, c_out % 32 == 0, kv <= 32, < 4 GB of input, no
+ *                     in_absmax, not CPD_GC_DENSE (the row-wave kernel is the one that reads them) -- else CPD_ERR_UNSUPPORTED
+ *   CPD_GC_OUT_PAIRS  `out` rows are written as pairs (any kernel's epilogue; c_out % 32 == 0, no out_col_group)
+ *   CPD_GC_RES_PAIRS  `residual` rows are pairs (c_out % 32 == 0) */
+#define CPD_GC_IN_PAIRS 16
+#define CPD_GC_OUT_PAIRS 32
+#define CPD_GC_RES_PAIRS 64
 
 /* 3x3 / stride 1 / pad 1 convolution (+ folded BN / bias, residual, ReLU: same epilogue as
  * cpd_gather_conv) over channels-last pixel rows in[frames*h*w][c_in] WITHOUT a rulebook -- the

@@ -488,6 +488,39 @@ def test_engine_internal_row_orders_do_not_change_the_result(hip):
             assert torch.allclose(a["pred_boxes"], b["pred_boxes"], atol=1e-4)
 
 
+def test_fp16_pair_rows_between_sparse_layers_do_not_change_the_result(hip):
+    """ModelConfig.pair_rows: levels 2-4 keep their activations as fp16-pair rows between the f16x2 layers (the split made once by
+    the producing epilogue). Same partial products as fp32 rows: every exported level (decoded), the BEV map and the detections
+    agree with the fp32-row engine; the launch log shows the pair kernels carrying levels 2-4 and none of them when it is off."""
+    from cpd_amd import ops
+    cfgs = [ModelConfig(pair_rows=p) for p in (True, False)]
+    sd = init_state_dict(cfgs[0], seed=0)
+    clouds = [torch.from_numpy(waymo_cloud(k, n_points=60000)).cuda() for k in range(3)]
+    outs, logs = [], []
+    for c in cfgs:
+        eng = CenterPointEngine(c, sd)
+        with ops.launch_log() as log:
+            outs.append(eng.forward(clouds, return_intermediates=True))
+        logs.append(log.counts)
+        assert eng.range_reruns == 0
+    pair_launches = sum(v for k, v in logs[0].items() if "f16p" in k)
+    assert pair_launches == 15, logs[0]            # 4 + 5 + 5 + conv_out: the layers that read levels 2-4 (conv2.down reads 16 fp32 channels)
+    assert not any("f16p" in k for k in logs[1]), logs[1]
+    assert not any(k.startswith("rowwave_conv_f16_kernel") for k in logs[0]), logs[0]
+    (ra, ia), (rb, ib) = outs
+    for name in ("x_conv2", "x_conv3", "x_conv4"):
+        fa, ca, _ = ia["levels"][name]
+        fb, cb, _ = ib["levels"][name]
+        assert torch.equal(ca, cb)
+        assert float((fa - fb).abs().max()) <= 1e-4 * max(1.0, float(fb.abs().max())), name
+    assert float((ia["spatial_features_nhwc"] - ib["spatial_features_nhwc"]).abs().max()) <= 1e-4 * max(1.0, float(ib["spatial_features_nhwc"].abs().max()))
+    for a, b in zip(ra, rb):
+        assert a["pred_boxes"].shape == b["pred_boxes"].shape
+        assert torch.equal(a["pred_labels"], b["pred_labels"])
+        assert torch.allclose(a["pred_scores"], b["pred_scores"], atol=1e-5)
+        assert torch.allclose(a["pred_boxes"], b["pred_boxes"], atol=1e-4)
+
+
 def test_batch_of_65_frames_does_not_leave_a_group_of_one(hip):
     """more frames than one batched-voxelizer call takes (64) go in groups; 65 used to leave a group of ONE frame, which
     the batched call refuses -- the last group now borrows a frame. Frames 0, 63 and 64 of a 65-frame batch of small clouds give

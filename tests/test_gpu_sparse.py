@@ -228,6 +228,60 @@ def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, math, cin, cout, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,n,want", [(128, 128, 80000, "<128,2>"), (128, 128, 24000, "<128,1>"), (64, 64, 30000, "<64,1>"), (32, 32, 30000, "<32,1>"),
+                                             (32, 32, 80000, "<32,2>"), (64, 128, 12000, "<64,1>"), (64, 64, 80000, "<64,2>"), (64, 128, 600, "<32,1>"),
+                                             (16, 32, 20000, None)])
+def test_fp16_pair_rows_give_the_fp32_rows_result(oracle, hip, cin, cout, n, want):
+    """CPD_GC_IN/OUT/RES_PAIRS: activations stored as fp16-pair rows (the f16x2 split made once, by the producing epilogue). The
+    row-wave kernel on pair input, with a pair residual and pair output, in each of its shapes -- and the fp32 wave kernel writing
+    pairs (the 16 -> 32 layer that feeds level 2) -- against the oracle (1e-4) and against the same call on fp32 rows (the same
+    partial products; the pair kernel sums a 32-channel block in natural channel order, the fp32-row kernel in its gather order:
+    fp32 rounding of the accumulation, 2e-5 here)."""
+    import torch
+    from cpd_amd import ops
+    rng = np.random.default_rng(n + cin)
+    batch, shape = 2, [11, 96, 96]
+    idx = np.unique(np.concatenate([random_sites(rng, batch, [11, 40, 40], n // 2), random_sites(rng, batch, shape, n // 2)]), axis=0).astype(np.int32)
+    rows = idx.shape[0]
+    feat = rng.normal(size=(rows, cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    scale = (rng.random(cout) + 0.5).astype(np.float32); shift = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(rows, cout)).astype(np.float32)
+    d_idx = dev(idx)
+    nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
+    w_kio = torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda()
+    packed = ops.pack_weight(w_kio)
+    in_pairs = cin % 32 == 0
+    if in_pairs:
+        name = ops.gather_conv_tile(rows, cin, cout, cin, dense=False, math="f16x2", in_pairs=True)
+        assert name == "rowwave_conv_f16p_kernel" + want, (name, rows)
+    x, r = dev(feat), dev(res)
+    xp, rp = (ops.rows_to_pairs(x) if in_pairs else x), ops.rows_to_pairs(r)
+    np.testing.assert_array_equal(ops.pairs_to_rows(rp).cpu().numpy(), (r.half().float() + (r - r.half().float()).half().float()).cpu().numpy())
+    with ops.launch_log() as log:
+        got_p = ops.gather_conv(xp, cin, packed, nbr, 27, rows, cout, dev(scale), dev(shift), rp, True, math="f16x2",
+                                in_pairs=in_pairs, out_pairs=True, res_pairs=True)
+    if in_pairs:
+        assert log.counts == {"rowwave_conv_f16p_kernel" + want: 1}, log.counts
+    got = ops.pairs_to_rows(got_p).cpu().numpy()
+    ref = oracle.sparse_conv(feat, w, None, nbr.cpu().numpy())
+    ref = np.maximum(ref * scale + shift + res, 0)
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
+    plain = ops.gather_conv(x, cin, packed, nbr, 27, rows, cout, dev(scale), dev(shift), r, True, math="f16x2")
+    np.testing.assert_allclose(got, plain.cpu().numpy(), atol=5e-5, rtol=0)
+    if in_pairs:
+        # pair input with fp32 output and no residual
+        a = ops.gather_conv(xp, cin, packed, nbr, 27, rows, cout, dev(scale), dev(shift), None, True, math="f16x2", in_pairs=True)
+        b = ops.gather_conv(x, cin, packed, nbr, 27, rows, cout, dev(scale), dev(shift), None, True, math="f16x2")
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=5e-5, rtol=0)
+        # what the flags refuse: pair input into the dense path / with an absmax block / without f16x2
+        from cpd_amd._lib import CpdHipError
+        for kw in (dict(dense=True, math="f16x2"), dict(math="bf16x3"), dict(math="f16x2", in_absmax=ops.absmax_rows(x))):
+            with pytest.raises(CpdHipError):
+                ops.gather_conv(xp, cin, packed, nbr, 27, rows, cout, in_pairs=True, **kw)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("chunk", [1024, 4096, 8192, 16384])
 def test_tap_pattern_row_order(oracle, hip, chunk):
     """ops.order_rows_by_taps: a permutation that stays inside chunks of `chunk` canonical rows, sorts every chunk by the rows'

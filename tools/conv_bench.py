@@ -40,6 +40,18 @@ def run(label, x, cin, w, nbr, kv, n_out, cout, dense, pairs, **kw):
         err = float((out - ref).abs().max())
         us = timeit(lambda: ops.gather_conv(x, cin, pw, nbr, kv, n_out, cout, dense=dense, math=m, out=out, **kw))
         print("%-26s %-7s %-34s %8.1f us %7.1f TF  maxdiff_vs_f32 %.2e" % (label, m, name, us, 2.0 * pairs * cin * cout / us / 1e6, err), flush=True)
+        if m == "f16x2" and not dense and cin % 32 == 0 and cout % 32 == 0 and os.environ.get("PAIRS", "1") != "0":
+            # the same layer on fp16-pair rows (CPD_GC_*_PAIRS): input / output / both (+ the residual)
+            xp = ops.rows_to_pairs(x)
+            kwp = dict(kw)
+            if kw.get("residual") is not None:
+                kwp["residual"] = ops.rows_to_pairs(kw["residual"])
+            for tag, args in (("pairs in", dict(in_pairs=True, **kw)), ("pairs out", dict(out_pairs=True, **kw)),
+                              ("pairs in+out+res", dict(in_pairs=True, out_pairs=True, res_pairs=kw.get("residual") is not None, **kwp))):
+                o2 = ops.gather_conv(xp if args.get("in_pairs") else x, cin, pw, nbr, kv, n_out, cout, dense=dense, math=m, **args)
+                e2 = float(((ops.pairs_to_rows(o2) if args.get("out_pairs") else o2) - ref).abs().max())
+                us2 = timeit(lambda: ops.gather_conv(xp if args.get("in_pairs") else x, cin, pw, nbr, kv, n_out, cout, dense=dense, math=m, out=o2, **args))
+                print("%-26s %-7s %-34s %8.1f us %7.1f TF  maxdiff_vs_f32 %.2e" % (label, m, "  " + tag, us2, 2.0 * pairs * cin * cout / us2 / 1e6, e2), flush=True)
 
 
 if which in ("dense", "all"):
