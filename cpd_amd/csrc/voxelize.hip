@@ -258,6 +258,13 @@ struct FrameOffsets {
         }
         return lo;
     }
+    // the same for lane `lane` of a wave whose lanes hold consecutive points: the wave's first and last point are looked up on the
+    // scalar unit; only a wave that straddles a frame boundary searches per lane
+    __device__ __forceinline__ int frame_of_lane(int i, int lane) const {
+        const int i0 = __builtin_amdgcn_readfirstlane(i - lane);
+        const int f0 = frame_of(i0), f1 = frame_of(i0 + 63);
+        return f0 == f1 ? f0 : frame_of(i);
+    }
 };
 
 // Batched form: pkey holds the point's cell INSIDE its frame (< cells, 31 bits); the bitmap position frame * cells + cell is
@@ -279,7 +286,7 @@ __global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__rest
     }
     long long key = -1;
     const int32_t local = ok ? (cz[0] * geo.g[1] + cz[1]) * geo.g[2] + cz[2] : -1;
-    if (ok) key = (long long)fo.frame_of(i) * cells + local;
+    if (ok) key = (long long)fo.frame_of_lane(i, threadIdx.x & 63) * cells + local;
     // consecutive returns of a beam often share a voxel: the lane after an equal key leaves the bit to its neighbour
     const long long prev = __shfl_up(key, 1);
     if (ok && ((threadIdx.x & 63) == 0 || prev != key)) atomicOr((unsigned long long *)&bitmap[key >> 6], 1ull << (key & 63));
@@ -440,7 +447,7 @@ __global__ void __launch_bounds__(256) vox_count_kernel(int n, long long cells, 
     if (i < n) {
         const int32_t local = pkey[i];
         if (local >= 0) {
-            const long long key = (long long)fo.frame_of(i) * cells + local;
+            const long long key = (long long)fo.frame_of_lane(i, lane) * cells + local;
             const uint64_t w = bitmap[key >> 6];
             r = (int32_t)(base[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1ull)));
         }
@@ -490,6 +497,44 @@ __global__ void __launch_bounds__(256) vox_build_kernel(const float *__restrict_
     const int cnt = counts[v];
     const int32_t *seg = order + offsets[v];
     const int kept = cnt < P ? cnt : P;
+    if (cnt <= 8 && P <= 8) {
+        // the common case in registers: the segment's (<= 8) entries in one round of independent loads, the selection on the
+        // vector ALU, then the kept points' values in a second round -- two memory round trips instead of one per candidate
+        int32_t e[8], sel[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = j < cnt ? seg[j] : 0x7fffffff;
+        int32_t last = -1;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            sel[p] = 0x7fffffff;
+            if (p < kept) {                 // (skipped by the whole wave once none of its voxels keeps that many: most keep 1-3)
+                int32_t best = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) best = (e[j] > last && e[j] < best) ? e[j] : best;
+                sel[p] = best;
+                last = best;
+            }
+        }
+        float val[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) val[p] = p < kept ? pts[(size_t)sel[p] * c + ch] : 0.f;
+        if (ch == 0 && kept > 0) {
+            const int32_t key = pkey[sel[0]];                      // the cell inside the frame
+            int32_t *o = coords + (size_t)v * 4;
+            o[0] = fo.frame_of(sel[0]); o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {       // sum order p = 0..P-1, zeros included (mean_vfe.py:41)
+            if (p < P) {
+                if (voxels) voxels[((size_t)v * P + p) * c + ch] = val[p];
+                s += val[p];
+            }
+        }
+        if (mean) mean[(size_t)v * c + ch] = __fdiv_rn(s, (float)(kept < 1 ? 1 : kept));
+        if (ch == 0) num_points[v] = kept;
+        return;
+    }
     int32_t last = -1;
     float s = 0.f;
     for (int p = 0; p < P; ++p) {      // sum order p = 0..P-1, zeros included (mean_vfe.py:41)
