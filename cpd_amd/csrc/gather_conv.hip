@@ -1962,10 +1962,25 @@ static int window_bn(int frames, int h, int w, int c_in, int c_out, int flags) {
     if (rows >= (1ll << 31)) return 0;
     // 16-column tile: the final head convs (c_out <= 16, e.g. 320 -> 11), which are bound by re-reading their wide input
     // once per tap -- the window stages it once per dy
-    const int bn = c_out <= 16 ? 16 : (c_out % 128 == 0 ? 128 : 64);
+    int bn = c_out <= 16 ? 16 : (c_out % 128 == 0 ? 128 : 64);
+    if (const char *e = cpd_knob(tn, "CPD_GC_WINDOW_BN")) { if (atoi(e) == 64 && bn == 128) bn = 64; }      // tuning only
     long long min_wgs = 600;                    // below that the rulebook path's 64-row tiles fill the chip better
     if (const char *e = cpd_knob(tn, "CPD_GC_BF16_MIN")) min_wgs = atoll(e);
-    if (((rows + 127) / 128) * ((c_out + bn - 1) / bn) < min_wgs) return 0;
+    const long long row_tiles = (rows + 127) / 128;
+    int small = 1;                              // 0: round 2's single threshold
+    if (const char *e = cpd_knob(tn, "CPD_GC_WINDOW_SMALL")) small = atoi(e);
+    if (small && !cpd_knob(tn, "CPD_GC_BF16_MIN")) {
+        // one- and four-frame batches (round 3, tools/conv_bench.py dense at FRAMES = 1 / 4): a 128-column tile from 500 workgroups
+        // (4 x 94 x 94 x 256 channels: 141 vs 161 us on the rulebook path), else 64-column tiles from 250 (188 x 188 x 128 -> 128: 55
+        // vs 61 us; 94 x 94 x 256: 76 vs 79), the 16-column head tile from 250 (320 -> 11: 70 vs 86); a layer whose ONLY tiling is
+        // 64 columns (512 -> 64) keeps the old bound (140 vs 135 us at 277 workgroups)
+        if (bn == 128) {
+            if (row_tiles * (c_out / 128) >= 500) return 128;
+            return row_tiles * (c_out / 64) >= 250 ? 64 : 0;
+        }
+        if (bn == 16) return row_tiles >= 250 ? 16 : 0;
+    }
+    if (row_tiles * ((c_out + bn - 1) / bn) < min_wgs) return 0;
     return bn;
 }
 // rows per workgroup of the window kernel: 256 when the layer has a single column tile (c_out = 64 or <= 16), f16x2 arithmetic

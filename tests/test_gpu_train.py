@@ -305,5 +305,7 @@ def test_full_size_config3_step_is_locally_exact_on_the_benchmarked_kernels(hip)
     for name in ("wgrad_f16_kernel<128,128>", "wgrad_f16_kernel<64,64>", "wgrad_f16_kernel<32,32>", "tile_conv_f16s_kernel<64,128>",
                  "tile_conv_f16_kernel<64,128>", "rowwave_conv_f16s_kernel<64,2>", "rowwave_conv_f16_kernel<64,2>",
                  "rowwave_conv_f16s_kernel<32,2>", "rowwave_conv_f16_kernel<32,2>", "rowwave_conv_f16s_kernel<128,1>",
-                 "rowwave_conv_f16_kernel<128,1>"):
+                 "rowwave_conv_f16_kernel<128,1>",
+                 # the one-frame 3 x 3 BEV / head layers on 64-column window tiles (round 3's small-batch tile rule)
+                 "window_conv_f16_kernel<64,128>", "window_conv_f16s_kernel<64,128>", "window_conv_f16_kernel<16,128>"):
         assert log.counts.get(name, 0) > 0, (name, sorted(log.counts))
