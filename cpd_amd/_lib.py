@@ -59,6 +59,8 @@ SIGNATURES = {
     "cpd_conv3x3_rows_scaled": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     "cpd_conv3x3_rows_ranged": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP, _VP]),
     "cpd_gather_conv_ranged": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _I, _VP, _VP, _VP]),
+    "cpd_gather_conv_ws": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_gather_conv_split_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "cpd_absmax_rows": (_I, [_VP, _I, ctypes.c_longlong, _I, _VP, _VP]),
     "cpd_densify_nchw": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_densify_nhwc": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),

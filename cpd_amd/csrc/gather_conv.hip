@@ -69,6 +69,10 @@ struct GcParams {
     // channels (64 B) followed by the fp16 LOW terms (64 B) -- the split x = h + l of SplitF16x2, made ONCE by the epilogue that
     // produced the row instead of by every gather of it (27 taps x ...); the row-wave kernel then takes gathered bits as fragments
     int in_pairs, out_pairs, res_pairs;
+    // tap split of the row-wave kernels (small launches): blockIdx.y = z takes every split-th active tap of its row tile and
+    // writes its RAW accumulators to part[z][n_out][c_out]; split_finish_kernel sums the parts in order and runs the epilogue
+    int split;
+    float *part;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -1043,6 +1047,19 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
         wg_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_mask);
     }
 
+    if (p.split > 1) {                               // this workgroup's share of the tile's taps: every split-th active one
+        const int z = blockIdx.y;
+        uint32_t keep = 0, left = wg_mask;
+        for (int ord = 0; left; ++ord) {
+            const uint32_t bit = left & (0u - left);
+            left ^= bit;
+            if (ord % p.split == z) keep |= bit;
+        }
+        wg_mask = keep;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) my_mask[s] &= keep;
+    }
+
     f32x4 acc[MS][NT];
 #pragma unroll
     for (int s = 0; s < MS; ++s)
@@ -1246,7 +1263,78 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             }
         }
     }
+    if (p.split > 1) {                               // raw partial sums; scale / shift / residual / ReLU happen in split_finish_kernel
+        float *part = p.part + (size_t)blockIdx.y * p.n_out * p.c_out;
+#pragma unroll
+        for (int s = 0; s < MS; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 16 * s + 4 * g + i;
+                if (row >= p.n_out) continue;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) part[(size_t)row * p.c_out + col0 + nt * 16 + r] = acc[s][nt][i];
+            }
+        return;
+    }
     epilogue<MS, NT, true>(p, acc, row0, col0, r, g, in_inv);
+}
+
+// The second half of a tap-split launch: thread = (row, two adjacent columns); parts summed in z order (deterministic), then the
+// shared epilogue's arithmetic in its order -- (sum * (scale * dsc * in_inv)) + shift, + residual, ReLU, absmax, fp32 or pair rows.
+__global__ void __launch_bounds__(256) split_finish_kernel(GcParams p) {
+    float in_s = 1.f, in_inv = 1.f;
+    in_pow2_scale(p.in_absmax, in_s, in_inv);
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = p.c_out >> 1;
+    const int row = (int)(tid / half), col = 2 * (int)(tid % half);
+    uint32_t vmax = 0;
+    if (row < p.n_out) {
+        float v[2] = {0.f, 0.f};
+        for (int z = 0; z < p.split; ++z) {
+            const float2 t = *reinterpret_cast<const float2 *>(p.part + ((size_t)z * p.n_out + row) * p.c_out + col);
+            v[0] += t.x; v[1] += t.y;
+        }
+        const size_t orow = p.out_row_map ? (size_t)p.out_row_map[row] : (size_t)row;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = col + k;
+            float sc = p.scale ? p.scale[c] : 1.f;
+            if (p.dsc) sc *= p.dsc[c];
+            sc *= in_inv;
+            v[k] = v[k] * sc + (p.shift ? p.shift[c] : 0.f);
+            if (p.residual) {
+                if (p.res_pairs) {
+                    const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)row * p.res_ld) + ((c >> 5) << 7) + ((c & 31) << 1);
+                    v[k] += (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 64);
+                } else {
+                    v[k] += p.residual[(size_t)row * p.res_ld + c];
+                }
+            }
+            if (p.relu) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            const uint32_t vb = __float_as_uint(v[k]) & 0x7fffffffu;
+            vmax = vb > vmax ? vb : vmax;
+        }
+        if (p.out_pairs) {
+            const _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1];
+            const _Float16 l0 = (_Float16)(v[0] - (float)h0), l1 = (_Float16)(v[1] - (float)h1);
+            char *op = reinterpret_cast<char *>(p.out + orow * p.out_ld) + ((col >> 5) << 7) + ((col & 31) << 1);
+            *reinterpret_cast<uint32_t *>(op) = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+            *reinterpret_cast<uint32_t *>(op + 64) = (uint32_t)__builtin_bit_cast(unsigned short, l0) | ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
+        } else {
+            *reinterpret_cast<float2 *>(p.out + orow * p.out_ld + col) = float2{v[0], v[1]};
+        }
+    }
+    if (p.out_absmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)vmax, o);
+            vmax = t > vmax ? t : vmax;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+            if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
+        }
+    }
 }
 
 // (bf16x3, BN = 128, MS = 2 sits at the 3-waves-per-SIMD budget)
@@ -1800,11 +1888,39 @@ extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, i
     return CPD_OK;
 }
 
+// Tap split of a SMALL row-wave launch (one frame, the train step): a workgroup walks its row tile's (tap, 32-channel block) stages
+// one after the other -- 108 of them at 128 channels, ~0.9 us each when a CU holds one or two workgroups -- so a layer with fewer
+// workgroups than ~2 per CU takes its stage count times a memory round trip whatever its size. With a workspace the taps of a tile
+// are dealt to `split` workgroups (blockIdx.y), each writes raw partial sums, and split_finish_kernel adds them in a fixed order
+// and runs the epilogue. -> number of parts (1 = no split).
+static int rowwave_split(const GcPlan &pl, int n_out, int c_in, int c_out, int kv) {
+    if (pl.use_wg != 3) return 1;
+    const bool tn = cpd_tuning();
+    if (const char *e = cpd_knob(tn, "CPD_GC_SPLIT")) { const int v = atoi(e); return v < 1 ? 1 : (v > 8 ? 8 : v); }
+    const long long wgs = (long long)((n_out + pl.a - 1) / pl.a) * (c_out / pl.b);
+    const int stages = kv * (c_in / 32);
+    int min_stages = 16;                             // (16 vs 100, same box: one frame 3.23 vs 3.27 ms, train step 9.85 vs 10.2 ms)
+    if (const char *e = cpd_knob(tn, "CPD_GC_SPLIT_STAGES")) min_stages = atoi(e);
+    if (wgs >= 600 || stages < min_stages || kv < 4) return 1;
+    long long s = 1200 / (wgs > 0 ? wgs : 1);
+    if (s > kv / 4) s = kv / 4;                      // at least ~4 taps per part
+    return s < 2 ? 1 : (s > 4 ? 4 : (int)s);
+}
+
+static int rowwave_finish(const GcParams &p, hipStream_t hs) {      // after a row-wave launch: the second half of a tap split
+    if (p.split > 1) {
+        cpd_launch_log_note("split_finish_kernel");
+        const long long threads = (long long)p.n_out * (p.c_out / 2);
+        hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)cpd_div_up(threads, 256)), dim3(256), 0, hs, p);
+    }
+    return cpd_check_launch();
+}
+
 static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
                             const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
                             const float *residual, int res_ld, int relu, float *out, int out_ld,
                             const int32_t *out_row_map, int out_col_group, int flags, const uint32_t *in_absmax, uint32_t *out_absmax,
-                            cpd_stream_t stream) {
+                            cpd_stream_t stream, float *part = nullptr, size_t part_bytes = 0) {
     if (n_out == 0 && n_in >= 0 && c_in > 0 && c_out > 0 && kv > 0) return CPD_OK;   // an empty site set is a valid (empty) result
     if (!in || !packed_w || !out || n_in < 0 || n_out < 0 || c_in <= 0 || c_out <= 0 || kv <= 0 || in_ld < c_in ||
         (residual && res_ld < c_out) || (!nbr && kv != 1) || (tapmask && kv > 32) || out_col_group < 0 || (out_col_group > 0 && !out_row_map) ||
@@ -1819,6 +1935,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     if ((flags & CPD_GC_RES_PAIRS) && (!residual || c_out % 32)) return CPD_ERR_ARG;
     GcParams p;
     p.in_pairs = (flags & CPD_GC_IN_PAIRS) != 0; p.out_pairs = (flags & CPD_GC_OUT_PAIRS) != 0; p.res_pairs = (flags & CPD_GC_RES_PAIRS) != 0;
+    p.split = 1; p.part = nullptr;
     p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.in_absmax = in_absmax; p.out_absmax = out_absmax; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16; p.n_in_rows = n_in;
@@ -1842,8 +1959,12 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         p.n_cb = c_out / pl.b;
         p.items = p.n_rb * p.n_cb;
     }
-    const dim3 grid(p.items), block(256);
     hipStream_t hs = cpd_s(stream);
+    if (part && pl.use_wg == 3 && !out_col_group && c_out % 2 == 0 && out_ld % 2 == 0 && ((uintptr_t)out & 7) == 0) {
+        const int sp = rowwave_split(pl, n_out, c_in, c_out, kv);
+        if (sp > 1 && part_bytes >= (size_t)sp * n_out * c_out * sizeof(float)) { p.split = sp; p.part = part; }
+    }
+    const dim3 grid(p.items, p.split), block(256);
     {   // launch log (cpd_launch_log_*): the instantiation this call runs
         char nm[96];
         const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? (p.in_pairs ? "f16p" : "f16") : "bf16");
@@ -1862,7 +1983,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16s_kernel<32, 2>), 0);
         else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16s_kernel<64, 2>), 0);
         else CPD_LAUNCH((rowwave_conv_f16s_kernel<128, 2>), 0);
-        return cpd_check_launch();
+        return rowwave_finish(p, hs);
     }
     if (pl.use_wg == 3 && pl.math == 2 && p.in_pairs) {
         if (pl.a == 64) {
@@ -1872,7 +1993,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16p_kernel<32, 2>), 0);
         else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16p_kernel<64, 2>), 0);
         else CPD_LAUNCH((rowwave_conv_f16p_kernel<128, 2>), 0);
-        return cpd_check_launch();
+        return rowwave_finish(p, hs);
     }
     if (pl.use_wg == 3 && pl.math == 2) {
         if (pl.a == 64) {
@@ -1882,7 +2003,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16_kernel<32, 2>), 0);
         else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16_kernel<64, 2>), 0);
         else CPD_LAUNCH((rowwave_conv_f16_kernel<128, 2>), 0);
-        return cpd_check_launch();
+        return rowwave_finish(p, hs);
     }
     if (pl.use_wg == 3) {
         if (pl.a == 64) {
@@ -1892,7 +2013,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_bf16_kernel<32, 2>), 0);
         else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_bf16_kernel<64, 2>), 0);
         else CPD_LAUNCH((rowwave_conv_bf16_kernel<128, 2>), 0);
-        return cpd_check_launch();
+        return rowwave_finish(p, hs);
     }
     if (pl.use_wg == 2 && pl.math == 2) {
         const size_t lds = 2 * (size_t)(pl.a + pl.b) * 64;
@@ -2087,6 +2208,21 @@ extern "C" int cpd_gather_conv_ranged(const float *in, int in_ld, int n_in, int 
                                       uint32_t *out_absmax, cpd_stream_t stream) {
     return gather_conv_impl(in, in_ld, n_in, c_in, packed_w, nbr, tapmask, kv, n_out, c_out, scale, shift, residual, res_ld, relu, out,
                             out_ld, out_row_map, out_col_group, flags, in_absmax, out_absmax, stream);
+}
+extern "C" size_t cpd_gather_conv_split_bytes(int n_out, int c_in, int c_out, int in_ld, int kv, int flags) {
+    if (n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0) return 0;
+    const GcPlan pl = plan(n_out, c_in, c_out, in_ld, nullptr, flags);
+    if (pl.use_wg != 3 || kv > 32) return 0;
+    const int sp = rowwave_split(pl, n_out, c_in, c_out, kv);
+    return sp > 1 ? (size_t)sp * n_out * c_out * sizeof(float) : 0;
+}
+extern "C" int cpd_gather_conv_ws(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const int32_t *nbr,
+                                  const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale, const float *shift,
+                                  const float *residual, int res_ld, int relu, float *out, int out_ld,
+                                  const int32_t *out_row_map, int out_col_group, int flags, const uint32_t *in_absmax,
+                                  uint32_t *out_absmax, void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
+    return gather_conv_impl(in, in_ld, n_in, c_in, packed_w, nbr, tapmask, kv, n_out, c_out, scale, shift, residual, res_ld, relu, out,
+                            out_ld, out_row_map, out_col_group, flags, in_absmax, out_absmax, stream, (float *)workspace, workspace_bytes);
 }
 extern "C" int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c_in, const float *packed_w, int c_out,
                                 const float *scale, const float *shift, const float *residual, int res_ld, int relu, float *out,

@@ -282,12 +282,18 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
         if rc != -4:                                # CPD_ERR_UNSUPPORTED: shape / alignment / size -> the table path below
             check(rc, "cpd_conv3x3_rows")
             return out
-    check(lib().cpd_gather_conv_ranged(
+    ws, ws_bytes = None, 0
+    if not dense and (flags & 6) and c_in % 32 == 0:
+        # a small sparse launch deals its taps to several workgroups through a workspace (cpd_gather_conv_ws)
+        ws_bytes = int(lib().cpd_gather_conv_split_bytes(int(n_out), int(c_in), int(c_out), int(inp.stride(0)), int(kv), flags))
+        if ws_bytes:
+            ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=inp.device)
+    check(lib().cpd_gather_conv_ws(
         ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w),
         ptr(nbr), ptr(getattr(nbr, "tapmask", None)), kv, n_out, c_out, ptr(scale), ptr(shift),
         ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
         ctypes.c_void_p(out.data_ptr()), out.stride(0), ptr(out_row_map), int(out_col_group), flags,
-        ptr(in_absmax), ptr(out_absmax), stream()),
+        ptr(in_absmax), ptr(out_absmax), ptr(ws), ws_bytes, stream()),
         "cpd_gather_conv")
     return out
 

@@ -403,6 +403,17 @@ int cpd_gather_conv_ranged(const float *in, int in_ld, int n_in, int c_in, const
                            const float *shift, const float *residual, int res_ld, int relu, float *out,
                            int out_ld, const int32_t *out_row_map, int out_col_group, int flags,
                            const uint32_t *in_absmax, uint32_t *out_absmax, cpd_stream_t stream);
+/* The same with a workspace: small sparse launches (one frame, the train step: fewer row-wave workgroups than ~2 per CU) deal the
+ * taps of a row tile to several workgroups that write partial sums into the workspace; a second launch adds them in a fixed order
+ * and runs the epilogue (results equal the unsplit launch up to fp32 summation order). cpd_gather_conv_split_bytes: the workspace
+ * this problem wants (0: it runs unsplit, and cpd_gather_conv_ws with any workspace is cpd_gather_conv_ranged). HOST only. */
+size_t cpd_gather_conv_split_bytes(int n_out, int c_in, int c_out, int in_ld, int kv, int flags);
+int cpd_gather_conv_ws(const float *in, int in_ld, int n_in, int c_in, const float *packed_w,
+                       const int32_t *nbr, const uint32_t *tapmask, int kv, int n_out, int c_out, const float *scale,
+                       const float *shift, const float *residual, int res_ld, int relu, float *out,
+                       int out_ld, const int32_t *out_row_map, int out_col_group, int flags,
+                       const uint32_t *in_absmax, uint32_t *out_absmax, void *workspace, size_t workspace_bytes,
+                       cpd_stream_t stream);
 int cpd_conv3x3_rows_ranged(const float *in, int in_ld, int frames, int h, int w, int c_in,
                             const float *packed_w, int c_out, const float *scale, const float *shift,
                             const float *residual, int res_ld, int relu, float *out, int out_ld, int flags,

@@ -282,6 +282,65 @@ def test_fp16_pair_rows_give_the_fp32_rows_result(oracle, hip, cin, cout, n, wan
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,n,math,pairs,parts", [(128, 128, 20000, "f16x2", False, None), (128, 128, 20000, "f16x2", True, None),
+                                                         (64, 64, 30000, "f16x2", True, 3), (32, 64, 9000, "f16x2", False, 2),
+                                                         (64, 128, 12000, "bf16x3", False, None), (128, 128, 5000, "f16x2", False, 8)])
+def test_tap_split_of_small_sparse_launches(oracle, hip, monkeypatch, cin, cout, n, math, pairs, parts):
+    """cpd_gather_conv_ws: a sparse launch with fewer row-wave workgroups than ~2 per CU (one frame, the train step) deals the taps
+    of a row tile to several workgroups (partial sums in a workspace) and finishes in a second launch -- parts added in a fixed
+    order, then the shared epilogue's arithmetic. Chosen automatically (parts = None) or forced; fp32 and fp16-pair rows, residual,
+    BN, ReLU, the absmax guard (pre-scaled input), an output row map; equal to the unsplit launch to fp32 summation order and to
+    the oracle to 1e-4; the same bits on every run."""
+    import torch
+    from cpd_amd import ops
+    monkeypatch.setenv("CPD_TUNE", "1")
+    rng = np.random.default_rng(n + cin)
+    batch, shape = 2, [11, 96, 96]
+    idx = np.unique(np.concatenate([random_sites(rng, batch, [11, 40, 40], n // 2), random_sites(rng, batch, shape, n // 2)]), axis=0).astype(np.int32)
+    rows = idx.shape[0]
+    feat = rng.normal(size=(rows, cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    scale = (rng.random(cout) + 0.5).astype(np.float32); shift = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(rows, cout)).astype(np.float32)
+    d_idx = dev(idx)
+    nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
+    packed = ops.pack_weight(torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda())
+    x, r = dev(feat), dev(res)
+    perm = torch.randperm(rows, device="cuda").to(torch.int32)
+    kw = dict(in_pairs=True, out_pairs=True, res_pairs=True) if pairs else {}
+    xin, rin = (ops.rows_to_pairs(x), ops.rows_to_pairs(r)) if pairs else (x, r)
+    ref = np.maximum(oracle.sparse_conv(feat, w, None, nbr.cpu().numpy()) * scale + shift + res, 0)
+
+    def run(split, **more):
+        if split is None:
+            monkeypatch.delenv("CPD_GC_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("CPD_GC_SPLIT", str(split))
+        with ops.launch_log() as log:
+            y = ops.gather_conv(xin, cin, packed, nbr, 27, rows, cout, dev(scale), dev(shift), rin, True, math=math, **kw, **more)
+        return (ops.pairs_to_rows(y) if pairs else y), log.counts
+
+    whole, log1 = run(1)
+    assert "split_finish_kernel" not in log1, log1
+    got, log = run(parts)
+    assert log.get("split_finish_kernel", 0) == 1 and len(log) == 2, log
+    np.testing.assert_allclose(got.cpu().numpy(), ref, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(got.cpu().numpy(), whole.cpu().numpy(), atol=2e-5, rtol=0)
+    again, _ = run(parts)
+    assert torch.equal(got, again)                                   # parts are summed in a fixed order
+    if math == "f16x2" and not pairs:
+        # the guarded form (pre-scaled input) and an output row map go through the same second launch
+        block = ops.absmax_rows(x)
+        out_block = ops.absmax_blocks(1, x.device)[0]
+        g, lg = run(parts, in_absmax=block, out_absmax=out_block, out_row_map=perm)
+        assert any(k.startswith("rowwave_conv_f16s_kernel") for k in lg) and "split_finish_kernel" in lg, lg
+        back = torch.empty_like(g)
+        back[:] = g[perm.long()]
+        np.testing.assert_allclose(back.cpu().numpy(), ref, atol=1e-4, rtol=0)
+        assert ops.absmax_value(out_block) == float(g.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("chunk", [1024, 4096, 8192, 16384])
 def test_tap_pattern_row_order(oracle, hip, chunk):
     """ops.order_rows_by_taps: a permutation that stays inside chunks of `chunk` canonical rows, sorts every chunk by the rows'
