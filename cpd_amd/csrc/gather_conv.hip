@@ -608,9 +608,12 @@ __device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
     const int n_stage = p.kv * sk;
     const size_t b_stage = (size_t)NP * 4 * p.np * 16;   // bytes of one (tap, k32) block of the split image
 
+    // stage split (small launches, see rowwave_split): workgroup z = blockIdx.y walks its contiguous share of the stage sequence
+    const int st_begin = p.split > 1 ? (int)((long long)blockIdx.y * n_stage / p.split) : 0;
+    const int st_end = p.split > 1 ? (int)((long long)(blockIdx.y + 1) * n_stage / p.split) : n_stage;
     int idx_cur[AJ];
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr ? p.nbr[a_rowc[j]] : a_rowc[j];
+    for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr ? p.nbr[(size_t)(st_begin % p.kv) * p.n_out + a_rowc[j]] : a_rowc[j];
 
     f32x4 ra[AJ];
     bool rz[AJ];                    // "no neighbour": applied when the piece is split, so that nothing
@@ -661,19 +664,19 @@ __device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) idx_cur[j] = p.nbr[(size_t)t * p.n_out + a_rowc[j]];
     };
-    stage_load(0);
-    if (n_stage > 1) idx_load(1);
-    if (LATE_B) stage_load_b(0);
+    stage_load(st_begin);
+    if (st_begin + 1 < st_end) idx_load(st_begin + 1);
+    if (LATE_B) stage_load_b(st_begin);
     stage_store(0);
     __syncthreads();
-    for (int st = 0; st < n_stage; ++st) {
+    for (int st = st_begin; st < st_end; ++st) {
         const int nx = st + 1;
-        if (nx < n_stage) {
+        if (nx < st_end) {
             stage_load(nx);
-            if (nx + 1 < n_stage) idx_load(nx + 1);
+            if (nx + 1 < st_end) idx_load(nx + 1);
         }
         {
-            const char *sa = smem + (DB ? (st & 1) : 0) * STAGE;
+            const char *sa = smem + (DB ? ((st - st_begin) & 1) : 0) * STAGE;
             const char *sb = sa + NP * A_IMG;
 #pragma unroll
             for (int s0 = 0; s0 < MS; s0 += SH) {
@@ -699,9 +702,22 @@ __device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
             }
         }
         if (!DB) __syncthreads();          // single buffer: everyone is done reading before it is overwritten
-        if (LATE_B && nx < n_stage) stage_load_b(nx);
-        if (nx < n_stage) stage_store(nx & 1);
+        if (LATE_B && nx < st_end) stage_load_b(nx);
+        if (nx < st_end) stage_store((nx - st_begin) & 1);
         __syncthreads();
+    }
+    if (p.split > 1) {                     // raw partial sums: split_finish_kernel adds the parts and runs the epilogue
+        float *part = p.part + (size_t)blockIdx.y * p.n_out * p.c_out;
+#pragma unroll
+        for (int s = 0; s < MS; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + wr * (BM / 2) + 16 * s + 4 * g + i;
+                if (row >= p.n_out) continue;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) part[(size_t)row * p.c_out + col0 + wc * (BN / 2) + nt * 16 + r] = acc[s][nt][i];
+            }
+        return;
     }
     epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g, in_inv);
 }
@@ -1279,49 +1295,51 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
     epilogue<MS, NT, true>(p, acc, row0, col0, r, g, in_inv);
 }
 
-// The second half of a tap-split launch: thread = (row, two adjacent columns); parts summed in z order (deterministic), then the
+// The second half of a tap-split launch: thread = (row, four adjacent columns); parts summed in z order (deterministic), then the
 // shared epilogue's arithmetic in its order -- (sum * (scale * dsc * in_inv)) + shift, + residual, ReLU, absmax, fp32 or pair rows.
 __global__ void __launch_bounds__(256) split_finish_kernel(GcParams p) {
     float in_s = 1.f, in_inv = 1.f;
     in_pow2_scale(p.in_absmax, in_s, in_inv);
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int half = p.c_out >> 1;
-    const int row = (int)(tid / half), col = 2 * (int)(tid % half);
+    const int quarter = p.c_out >> 2;                 // thread = (row, four adjacent columns): 16-byte accesses throughout
+    const int row = (int)(tid / quarter), col = 4 * (int)(tid % quarter);
     uint32_t vmax = 0;
     if (row < p.n_out) {
-        float v[2] = {0.f, 0.f};
-        for (int z = 0; z < p.split; ++z) {
-            const float2 t = *reinterpret_cast<const float2 *>(p.part + ((size_t)z * p.n_out + row) * p.c_out + col);
-            v[0] += t.x; v[1] += t.y;
-        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.split; ++z) v += *reinterpret_cast<const f32x4 *>(p.part + ((size_t)z * p.n_out + row) * p.c_out + col);
         const size_t orow = p.out_row_map ? (size_t)p.out_row_map[row] : (size_t)row;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = col + k;
-            float sc = p.scale ? p.scale[c] : 1.f;
-            if (p.dsc) sc *= p.dsc[c];
-            sc *= in_inv;
-            v[k] = v[k] * sc + (p.shift ? p.shift[c] : 0.f);
-            if (p.residual) {
-                if (p.res_pairs) {
-                    const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)row * p.res_ld) + ((c >> 5) << 7) + ((c & 31) << 1);
-                    v[k] += (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 64);
-                } else {
-                    v[k] += p.residual[(size_t)row * p.res_ld + c];
-                }
+        f32x4 sc = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+        if (p.dsc) sc *= *reinterpret_cast<const f32x4 *>(p.dsc + col);
+        sc *= in_inv;
+        const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int pair_off = ((col >> 5) << 7) + ((col & 31) << 1);      // byte offset of the four high terms inside a pair row
+        f32x4 res = {0.f, 0.f, 0.f, 0.f};
+        if (p.residual) {
+            if (p.res_pairs) {
+                const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)row * p.res_ld) + pair_off;
+                const f16x4 h = *reinterpret_cast<const f16x4 *>(rp), l = *reinterpret_cast<const f16x4 *>(rp + 64);
+                res = __builtin_convertvector(h, f32x4) + __builtin_convertvector(l, f32x4);
+            } else {
+                res = *reinterpret_cast<const f32x4 *>(p.residual + (size_t)row * p.res_ld + col);
             }
-            if (p.relu) v[k] = v[k] > 0.f ? v[k] : 0.f;
-            const uint32_t vb = __float_as_uint(v[k]) & 0x7fffffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = v[k] * sc[k] + sh[k];
+            if (p.residual) t += res[k];
+            if (p.relu) t = t > 0.f ? t : 0.f;
+            v[k] = t;
+            const uint32_t vb = __float_as_uint(t) & 0x7fffffffu;
             vmax = vb > vmax ? vb : vmax;
         }
         if (p.out_pairs) {
-            const _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1];
-            const _Float16 l0 = (_Float16)(v[0] - (float)h0), l1 = (_Float16)(v[1] - (float)h1);
-            char *op = reinterpret_cast<char *>(p.out + orow * p.out_ld) + ((col >> 5) << 7) + ((col & 31) << 1);
-            *reinterpret_cast<uint32_t *>(op) = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
-            *reinterpret_cast<uint32_t *>(op + 64) = (uint32_t)__builtin_bit_cast(unsigned short, l0) | ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
+            const f16x4 h = __builtin_convertvector(v, f16x4);
+            const f16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+            char *op = reinterpret_cast<char *>(p.out + orow * p.out_ld) + pair_off;
+            *reinterpret_cast<f16x4 *>(op) = h;
+            *reinterpret_cast<f16x4 *>(op + 64) = l;
         } else {
-            *reinterpret_cast<float2 *>(p.out + orow * p.out_ld + col) = float2{v[0], v[1]};
+            *reinterpret_cast<f32x4 *>(p.out + orow * p.out_ld + col) = v;
         }
     }
     if (p.out_absmax) {
@@ -1894,8 +1912,18 @@ extern "C" int cpd_gather_conv_tile(int n_out, int c_in, int c_out, int in_ld, i
 // are dealt to `split` workgroups (blockIdx.y), each writes raw partial sums, and split_finish_kernel adds them in a fixed order
 // and runs the epilogue. -> number of parts (1 = no split).
 static int rowwave_split(const GcPlan &pl, int n_out, int c_in, int c_out, int kv) {
-    if (pl.use_wg != 3) return 1;
+    if (pl.use_wg != 3 && pl.use_wg != 2) return 1;
     const bool tn = cpd_tuning();
+    if (pl.use_wg == 2) {                            // the workgroup (tile) kernel: contiguous shares of its kv * c_in / 32 stages
+        int on = 1;
+        if (const char *e = cpd_knob(tn, "CPD_GC_SPLIT_TILE")) on = atoi(e);
+        const long long wgs = (long long)((n_out + pl.a - 1) / pl.a) * (c_out / pl.b);
+        const int stages = kv * (c_in / 32);
+        if (!on || wgs >= 600 || stages < 32) return 1;
+        long long s = on > 1 ? on : 1200 / (wgs > 0 ? wgs : 1);
+        if (s > stages / 16) s = stages / 16;        // at least 16 stages per part
+        return s < 2 ? 1 : (s > 4 ? 4 : (int)s);
+    }
     if (const char *e = cpd_knob(tn, "CPD_GC_SPLIT")) { const int v = atoi(e); return v < 1 ? 1 : (v > 8 ? 8 : v); }
     const long long wgs = (long long)((n_out + pl.a - 1) / pl.a) * (c_out / pl.b);
     const int stages = kv * (c_in / 32);
@@ -1910,7 +1938,7 @@ static int rowwave_split(const GcPlan &pl, int n_out, int c_in, int c_out, int k
 static int rowwave_finish(const GcParams &p, hipStream_t hs) {      // after a row-wave launch: the second half of a tap split
     if (p.split > 1) {
         cpd_launch_log_note("split_finish_kernel");
-        const long long threads = (long long)p.n_out * (p.c_out / 2);
+        const long long threads = (long long)p.n_out * (p.c_out / 4);
         hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)cpd_div_up(threads, 256)), dim3(256), 0, hs, p);
     }
     return cpd_check_launch();
@@ -1960,7 +1988,9 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         p.items = p.n_rb * p.n_cb;
     }
     hipStream_t hs = cpd_s(stream);
-    if (part && pl.use_wg == 3 && !out_col_group && c_out % 2 == 0 && out_ld % 2 == 0 && ((uintptr_t)out & 7) == 0) {
+    if (part && (pl.use_wg == 3 || pl.use_wg == 2) && !out_col_group && c_out % 4 == 0 && out_ld % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
+        (!residual || (flags & CPD_GC_RES_PAIRS) || (res_ld % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+        (!scale || ((uintptr_t)scale & 15) == 0) && (!shift || ((uintptr_t)shift & 15) == 0)) {
         const int sp = rowwave_split(pl, n_out, c_in, c_out, kv);
         if (sp > 1 && part_bytes >= (size_t)sp * n_out * c_out * sizeof(float)) { p.split = sp; p.part = part; }
     }
@@ -2022,13 +2052,13 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
             else if (pl.a == 64) CPD_LAUNCH((tile_conv_f16s_kernel<64, 64>), lds);
             else if (pl.b == 64) CPD_LAUNCH((tile_conv_f16s_kernel<128, 64>), lds);
             else CPD_LAUNCH((tile_conv_f16s_kernel<128, 128>), lds);
-            return cpd_check_launch();
+            return rowwave_finish(p, hs);
         }
         if (pl.a == 64 && pl.b == 128) CPD_LAUNCH((tile_conv_f16_kernel<64, 128>), lds);
         else if (pl.a == 64) CPD_LAUNCH((tile_conv_f16_kernel<64, 64>), lds);
         else if (pl.b == 64) CPD_LAUNCH((tile_conv_f16_kernel<128, 64>), lds);
         else CPD_LAUNCH((tile_conv_f16_kernel<128, 128>), lds);
-        return cpd_check_launch();
+        return rowwave_finish(p, hs);
     }
     if (pl.use_wg == 2) {
         int db = 0;
@@ -2038,7 +2068,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
             const size_t lds64 = 3 * (size_t)(64 + pl.b) * 64;
             if (pl.b == 128) CPD_LAUNCH((tile_conv_bf16_kernel<64, 128, false>), lds64);
             else CPD_LAUNCH((tile_conv_bf16_kernel<64, 64, false>), lds64);
-            return cpd_check_launch();
+            return rowwave_finish(p, hs);
         }
         const size_t lds = (db ? 2 : 1) * 3 * (size_t)(pl.a + pl.b) * 64;
         static bool attr_set = false;
@@ -2050,7 +2080,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         if (pl.b == 64) CPD_LAUNCH((tile_conv_bf16_kernel<128, 64, false>), lds);
         else if (db) CPD_LAUNCH((tile_conv_bf16_kernel<128, 128, true>), lds);
         else CPD_LAUNCH((tile_conv_bf16_kernel<128, 128, false>), lds);
-        return cpd_check_launch();
+        return rowwave_finish(p, hs);
     }
 #undef CPD_LAUNCH
     if (pl.use_wg) {
@@ -2212,7 +2242,7 @@ extern "C" int cpd_gather_conv_ranged(const float *in, int in_ld, int n_in, int 
 extern "C" size_t cpd_gather_conv_split_bytes(int n_out, int c_in, int c_out, int in_ld, int kv, int flags) {
     if (n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0) return 0;
     const GcPlan pl = plan(n_out, c_in, c_out, in_ld, nullptr, flags);
-    if (pl.use_wg != 3 || kv > 32) return 0;
+    if ((pl.use_wg != 3 || kv > 32) && pl.use_wg != 2) return 0;
     const int sp = rowwave_split(pl, n_out, c_in, c_out, kv);
     return sp > 1 ? (size_t)sp * n_out * c_out * sizeof(float) : 0;
 }

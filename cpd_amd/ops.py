@@ -283,8 +283,8 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
             check(rc, "cpd_conv3x3_rows")
             return out
     ws, ws_bytes = None, 0
-    if not dense and (flags & 6) and c_in % 32 == 0:
-        # a small sparse launch deals its taps to several workgroups through a workspace (cpd_gather_conv_ws)
+    if (flags & 6) and c_in % 32 == 0 and not out_col_group:
+        # a small launch (one frame, the train step) deals its taps / stages to several workgroups through a workspace (cpd_gather_conv_ws)
         ws_bytes = int(lib().cpd_gather_conv_split_bytes(int(n_out), int(c_in), int(c_out), int(inp.stride(0)), int(kv), flags))
         if ws_bytes:
             ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=inp.device)

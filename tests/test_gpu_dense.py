@@ -370,3 +370,43 @@ def test_window_conv_matches_the_table_path(hip, cin, cout, batch, h, w):
     ops.gather_conv(xin[:, 32:], cin, pw, nbr, 9, n, cout, dense=True, bf16x3=True, out=buf[:, 64:])
     want2 = ops.gather_conv(xin[:, 32:], cin, pw, plain, 9, n, cout, dense=True, bf16x3=True)
     assert torch.allclose(buf[:, 64:], want2, rtol=1e-5, atol=2e-5 if cout % 64 == 0 else 1e-4) and not buf[:, :64].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,hw,k,stride,math", [(512, 64, 188, 3, 1, "f16x2"), (128, 256, 188, 3, 2, "f16x2"), (256, 256, 94, 3, 1, "bf16x3")])
+def test_stage_split_of_small_dense_launches(hip, monkeypatch, cin, cout, hw, k, stride, math):
+    """cpd_gather_conv_ws on the workgroup (tile) kernel: a one-frame dense layer with few workgroups and many (tap, 32-channel)
+    stages (512 -> 64: 553 workgroups x 144 stages) gives contiguous shares of its stages to 2-4 workgroups per tile; the second
+    launch adds the parts in order and runs the epilogue (BN, residual, ReLU, absmax). Equal to the unsplit launch to fp32 summation
+    order, to the fp32 kernel to 1e-4 of the output's scale, and bit-identical from run to run."""
+    monkeypatch.setenv("CPD_TUNE", "1")
+    monkeypatch.setenv("CPD_GC_WINDOW", "0")               # the rulebook path (strided layers take it anyway)
+    torch.manual_seed(cin + cout)
+    nbr, ho, wo = ops.rulebook_conv2d(1, hw, hw, k, k, stride, 1, "cuda")
+    n_in, n_out, kv = hw * hw, ho * wo, k * k
+    x = torch.randn(n_in, cin, device="cuda")
+    w = torch.randn(kv, cin, cout, device="cuda") * (2.0 / (kv * cin)) ** 0.5
+    pw = ops.pack_weight(w)
+    sc = torch.rand(cout, device="cuda") + 0.5
+    sh = torch.randn(cout, device="cuda")
+    res = torch.randn(n_out, cout, device="cuda")
+
+    def run(split):
+        monkeypatch.setenv("CPD_GC_SPLIT_TILE", str(split))
+        blk = ops.absmax_blocks(1, x.device)[0]
+        with ops.launch_log() as log:
+            y = ops.gather_conv(x, cin, pw, nbr, kv, n_out, cout, sc, sh, res, True, dense=True, math=math, out_absmax=blk)
+        return y, log.counts, ops.absmax_value(blk)
+
+    whole, log0, m0 = run(0)
+    assert "split_finish_kernel" not in log0 and any(k_.startswith("tile_conv_") for k_ in log0), log0
+    got, log1, m1 = run(1)
+    assert log1.get("split_finish_kernel", 0) == 1 and any(k_.startswith("tile_conv_") for k_ in log1), log1
+    exact = ops.gather_conv(x, cin, pw, nbr, kv, n_out, cout, sc, sh, res, True, dense=True, math="f32")
+    tol = 1e-4 * float(exact.abs().max())
+    assert float((got - exact).abs().max()) <= tol
+    assert float((got - whole).abs().max()) <= 0.2 * tol
+    assert m1 == float(got.abs().max()) and m0 == float(whole.abs().max())
+    again, _, _ = run(1)
+    assert torch.equal(got, again)
+

@@ -262,7 +262,8 @@ def test_fp16_pair_rows_give_the_fp32_rows_result(oracle, hip, cin, cout, n, wan
         got_p = ops.gather_conv(xp, cin, packed, nbr, 27, rows, cout, dev(scale), dev(shift), rp, True, math="f16x2",
                                 in_pairs=in_pairs, out_pairs=True, res_pairs=True)
     if in_pairs:
-        assert log.counts == {"rowwave_conv_f16p_kernel" + want: 1}, log.counts
+        convs = {k: v for k, v in log.counts.items() if k != "split_finish_kernel"}      # (small launches split their taps: two launches)
+        assert convs == {"rowwave_conv_f16p_kernel" + want: 1}, log.counts
     got = ops.pairs_to_rows(got_p).cpu().numpy()
     ref = oracle.sparse_conv(feat, w, None, nbr.cpu().numpy())
     ref = np.maximum(ref * scale + shift + res, 0)
