@@ -1014,8 +1014,16 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
 // staged at all; a wave skips the loads and MFMAs of a sub-tile without a neighbour at the tap.
 // MS = row sub-tiles per wave: 2 (128-row workgroups) or 1 (64-row workgroups, for layers too small to give every CU a
 // 128-row workgroup: twice the workgroups, each staging the same weights for half the rows).
-template <class S, int BN, int MS, bool SC = false, bool PS = false>
-__device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb, int *const sidx) {
+// Taps a row-wave launch can have: a wave's rulebook columns live in LDS (CPD_RW_TAPS x 16 MS words per wave; 28 rather than 32 keeps
+// the 32-column kernel at 7 workgroups per CU next to its two weight buffers); larger kernels go to the workgroup kernels.
+#define CPD_RW_TAPS 28
+#ifndef CPD_RW_WB
+#define CPD_RW_WB 2          // weight buffers of the f16x2 row-wave kernels (diagnostic builds: 1 = round 2's single buffer, two barriers)
+#endif
+// WB = weight buffers in LDS: with two, a stage's block is committed to the buffer the previous stage is NOT reading, and the barrier
+// before the commit ("every wave is done with this stage's weights") goes: one barrier per stage instead of two
+template <class S, int BN, int MS, bool SC = false, bool PS = false, int WB = 1>
+__device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb0, int *const sidx) {
     float in_s = 1.f, in_inv = 1.f;
     if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
     constexpr int NP = S::NP;
@@ -1107,7 +1115,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
         // stage into registers they were copied from one register set to the next at the loop's end, and the compiler's wait for
         // that copy -- s_waitcnt vmcnt(0) -- landed at the TOP of the loop, right after the stage's gathers and weight loads had
         // been issued: every stage waited for all its loads before its MFMAs (the ISA of round 2's kernel shows it).
-        int *const my_idx = sidx + wave * (32 * 16 * MS);
+        int *const my_idx = sidx + wave * (CPD_RW_TAPS * 16 * MS);
         {
             uint32_t my_any = 0;
 #pragma unroll
@@ -1184,7 +1192,8 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             }
         };
         typename S::frag a[MS][NP];
-        auto stage_commit = [&](uint32_t on) {      // B -> LDS, A -> split fragments
+        auto stage_commit = [&](uint32_t on, int slot) {      // B -> LDS buffer `slot`, A -> split fragments
+            char *const sb = sb0 + (WB > 1 ? slot * (NP * B_IMG) : 0);
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
                 if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) {
@@ -1228,7 +1237,8 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                 }
             }
         };
-        auto stage_mma = [&](uint32_t on) {
+        auto stage_mma = [&](uint32_t on, int slot) {
+            const char *const sb = sb0 + (WB > 1 ? slot * (NP * B_IMG) : 0);
             if (on) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -1258,18 +1268,20 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
         int t2 = ok2 ? __builtin_ctz(rem) : 0;
         load_rows(onc, kc, tc);
         load_weights(tc, kc);
-        stage_commit(onc);
+        stage_commit(onc, 0);
         __syncthreads();
+        int par = 0;
         while (true) {
             if (ok1) {
                 load_weights(t1, k1);
                 load_rows(on1, k1, t1);
             }
-            stage_mma(onc);
+            stage_mma(onc, par);
             if (!ok1) break;
-            if (!(CPD_GC_ABLATE & 8)) __syncthreads();                        // every wave is done with this stage's weights
-            stage_commit(on1);
+            if (WB == 1 && !(CPD_GC_ABLATE & 8)) __syncthreads();             // every wave is done with this stage's weights
+            stage_commit(on1, par ^ 1);
             if (!(CPD_GC_ABLATE & 8)) __syncthreads();
+            par ^= 1;
             tc = t1; kc = k1; onc = on1;
             t1 = t2; k1 = k2; ok1 = ok2;
             on1 = ok1 ? sub_bits(t1) : 0u;
@@ -1360,30 +1372,30 @@ template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, BN == 128 && MS == 2 ? 3 : 8)))
 rowwave_conv_bf16_kernel(GcParams p) {
     __shared__ __attribute__((aligned(16))) char sb[SplitBf16x3::NP * BN * 64];     // one weight stage: pieces x 4 k-groups x BN x 16 B
-    __shared__ int sidx[4 * 32 * 16 * MS];                                         // rulebook columns of the waves' rows
+    __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];                                         // rulebook columns of the waves' rows
     rowwave_conv_split_body<SplitBf16x3, BN, MS>(p, sb, sidx);
 }
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
 rowwave_conv_f16_kernel(GcParams p) {
-    __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
-    __shared__ int sidx[4 * 32 * 16 * MS];
-    rowwave_conv_split_body<SplitF16x2, BN, MS>(p, sb, sidx);
+    __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];   // weight buffers
+    __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
+    rowwave_conv_split_body<SplitF16x2, BN, MS, false, false, CPD_RW_WB>(p, sb, sidx);
 }
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
 rowwave_conv_f16s_kernel(GcParams p) {            // pre-scaled input (see tile_conv_f16s_kernel)
-    __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
-    __shared__ int sidx[4 * 32 * 16 * MS];
-    rowwave_conv_split_body<SplitF16x2, BN, MS, true>(p, sb, sidx);
+    __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];   // weight buffers
+    __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
+    rowwave_conv_split_body<SplitF16x2, BN, MS, true, false, CPD_RW_WB>(p, sb, sidx);
 }
 
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
 rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcParams::in_pairs): no split in the stage loop
-    __shared__ __attribute__((aligned(16))) char sb[SplitF16x2::NP * BN * 64];
-    __shared__ int sidx[4 * 32 * 16 * MS];
-    rowwave_conv_split_body<SplitF16x2, BN, MS, false, true>(p, sb, sidx);
+    __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];   // weight buffers
+    __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
+    rowwave_conv_split_body<SplitF16x2, BN, MS, false, true, CPD_RW_WB>(p, sb, sidx);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -1956,7 +1968,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
     // fp16-pair rows: whole 32-channel blocks, f16x2 arithmetic, no pre-scaling (a guarded re-run works on fp32 rows)
-    if ((flags & CPD_GC_IN_PAIRS) && (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || c_in % 32 || c_out % 32 || in_ld % 4 || in_absmax || kv > 32 ||
+    if ((flags & CPD_GC_IN_PAIRS) && (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || c_in % 32 || c_out % 32 || in_ld % 4 || in_absmax || kv > CPD_RW_TAPS ||
                                       (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
         return CPD_ERR_UNSUPPORTED;
     if ((flags & CPD_GC_OUT_PAIRS) && (c_out % 32 || out_col_group > 0)) return CPD_ERR_UNSUPPORTED;
@@ -1970,7 +1982,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = (c_out + 15) / 16; p.np = p.ntot * 16;
     p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group;
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
-    if (pl.use_wg == 3 && (kv > 32 || (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
+    if (pl.use_wg == 3 && (kv > CPD_RW_TAPS || (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
         pl = plan(n_out, c_in, c_out, in_ld, in, flags | CPD_GC_DENSE);   // the row-wave kernel keeps its taps in 32-bit sets and reads its rows through a 4 GB buffer resource
     if (p.in_pairs && (pl.use_wg != 3 || pl.math != 2)) return CPD_ERR_UNSUPPORTED;
     if ((p.out_pairs || p.res_pairs) && pl.use_wg != 3 && pl.use_wg != 0) return CPD_ERR_UNSUPPORTED;   // (the sparse kernels' epilogues)
@@ -2242,7 +2254,7 @@ extern "C" int cpd_gather_conv_ranged(const float *in, int in_ld, int n_in, int 
 extern "C" size_t cpd_gather_conv_split_bytes(int n_out, int c_in, int c_out, int in_ld, int kv, int flags) {
     if (n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0) return 0;
     const GcPlan pl = plan(n_out, c_in, c_out, in_ld, nullptr, flags);
-    if ((pl.use_wg != 3 || kv > 32) && pl.use_wg != 2) return 0;
+    if ((pl.use_wg != 3 || kv > CPD_RW_TAPS) && pl.use_wg != 2) return 0;
     const int sp = rowwave_split(pl, n_out, c_in, c_out, kv);
     return sp > 1 ? (size_t)sp * n_out * c_out * sizeof(float) : 0;
 }

@@ -204,7 +204,7 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
  * the row instead of by each of the <= 27 gathers of it. The partial products are those of fp32 rows (the accumulation order inside
  * a 32-channel block differs: fp32 rounding); a residual read back from pairs is h + l (x to 2^-24 relative). Same range as CPD_GC_F16X2 without an absmax block: |x| < 65504
  * (the engine's range guard re-runs such a step on fp32 rows with pre-scaling).
- *   CPD_GC_IN_PAIRS   `in` rows are pairs: needs CPD_GC_F16X2, c_in % 32 == 0, c_out % 32 == 0, kv <= 32, < 4 GB of input, no
+ *   CPD_GC_IN_PAIRS   `in` rows are pairs: needs CPD_GC_F16X2, c_in % 32 == 0, c_out % 32 == 0, kv <= 28, < 4 GB of input, no
  *                     in_absmax, not CPD_GC_DENSE (the row-wave kernel is the one that reads them) -- else CPD_ERR_UNSUPPORTED
  *   CPD_GC_OUT_PAIRS  `out` rows are written as pairs (any kernel's epilogue; c_out % 32 == 0, no out_col_group)
  *   CPD_GC_RES_PAIRS  `residual` rows are pairs (c_out % 32 == 0) */
