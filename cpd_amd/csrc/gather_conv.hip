@@ -1017,6 +1017,17 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
 // Taps a row-wave launch can have: a wave's rulebook columns live in LDS (CPD_RW_TAPS x 16 MS words per wave; 28 rather than 32 keeps
 // the 32-column kernel at 7 workgroups per CU next to its two weight buffers); larger kernels go to the workgroup kernels.
 #define CPD_RW_TAPS 28
+// CPD_RW_BOTH (128-column tiles): a stage with ANY active sub-tile loads, transposes and multiplies BOTH of the wave's sub-tiles (the
+// rows of an inactive one have no neighbours: their loads are out of range, the fragments zeros) -- one scalar test per stage step
+// instead of one per sub-tile: 101 -> 67 scalar instructions per stage; 1.6 of a wave's 16 stages have one active sub-tile only
+// (tap-pattern rows). Same box, three pairs: <128,2> 0.1616 -> 0.1531 ms/frame; <32,2> unchanged (0.0913 / 0.0909: left as it was);
+// <64,2> 0.1179 -> 0.1266 (95 -> 102 registers: 5 -> 4 waves per SIMD) -- so the 128-column tiles only
+#ifndef CPD_RW_BOTH
+#define CPD_RW_BOTH 1
+#endif
+#ifndef CPD_RW_BOTH_MIN
+#define CPD_RW_BOTH_MIN 128      // narrowest column tile that does it (64: 0.1171 -> 0.1162, bench equal: not worth a second variant)
+#endif
 #ifndef CPD_RW_WB
 #define CPD_RW_WB 2          // weight buffers of the f16x2 row-wave kernels (diagnostic builds: 1 = round 2's single buffer, two barriers)
 #endif
@@ -1029,6 +1040,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
     constexpr int NP = S::NP;
     constexpr int NT = BN / 16;
     constexpr int WG_ROWS = 64 * MS, WG_SUBS = 4 * MS;
+    constexpr bool BOTH = CPD_RW_BOTH && MS == 2 && BN >= CPD_RW_BOTH_MIN;
     constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one stage
     constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
@@ -1162,7 +1174,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
         auto load_rows = [&](uint32_t on, int kk, int t) {
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
-                if ((on >> s) & 1u) {
+                if (BOTH ? on != 0u : ((on >> s) & 1u) != 0u) {
                     const int id = my_idx[t * 16 * MS + 16 * s + qr];       // (-1 for rows past the end: out of range below)
                     az[s] = id < 0;
                     if (CPD_GC_ABLATE & 2) { araw[s][0] = f32x4{(float)id, 1.f, (float)kk, 2.f}; araw[s][1] = araw[s][0]; az[s] = false; continue; }
@@ -1179,15 +1191,16 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                 }
             }
         };
+        const uint32_t b_stage32 = (uint32_t)b_stage;              // (a packed image is far below 4 GB: 32-bit stage offsets)
         auto load_weights = [&](int t, int kk) {
-            const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+            const char *wt = reinterpret_cast<const char *>(p.wb) + (uint32_t)(t * sk + kk) * b_stage32;
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
                 const int id = j * 256 + tid;
                 const int pg = id / BN, n = id - pg * BN;
                 if (B_SLOTS % 256 == 0 || id < B_SLOTS) {
                     if (CPD_GC_ABLATE & 1) rbv[j] = f32x4u{(float)t, 1.f, (float)kk, (float)n};
-                    else rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+                    else rbv[j] = *reinterpret_cast<const f32x4u *>(wt + (uint32_t)(pg * p.np + col0 + n) * 16u);
                 }
             }
         };
@@ -1213,7 +1226,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                 }
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
-                if ((on >> s) & 1u) {
+                if (BOTH ? on != 0u : ((on >> s) & 1u) != 0u) {
                     // rows without a neighbour become zeros in GATHER coordinates, then the lane transpose
                     if (!use_buf) {
                         araw[s][0] = zero_if(araw[s][0], az[s]);
@@ -1250,7 +1263,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                     for (int s = 0; s < MS; ++s) {
                         if (CPD_GC_ABLATE & 4) {               // no MFMAs: keep the operands live
                             if ((on >> s) & 1u) asm volatile("" :: "v"(a[s][0]), "v"(a[s][1]), "v"(b[0]), "v"(b[1]));
-                        } else if ((on >> s) & 1u) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
+                        } else if (BOTH || ((on >> s) & 1u)) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
                     }
                 }
             }
@@ -1376,14 +1389,14 @@ rowwave_conv_bf16_kernel(GcParams p) {
     rowwave_conv_split_body<SplitBf16x3, BN, MS>(p, sb, sidx);
 }
 template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : (BN == 64 && MS == 2 ? 5 : 4), 8)))
 rowwave_conv_f16_kernel(GcParams p) {
     __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];   // weight buffers
     __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
     rowwave_conv_split_body<SplitF16x2, BN, MS, false, false, CPD_RW_WB>(p, sb, sidx);
 }
 template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : (BN == 64 && MS == 2 ? 5 : 4), 8)))
 rowwave_conv_f16s_kernel(GcParams p) {            // pre-scaled input (see tile_conv_f16s_kernel)
     __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];   // weight buffers
     __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
@@ -1391,7 +1404,7 @@ rowwave_conv_f16s_kernel(GcParams p) {            // pre-scaled input (see tile_
 }
 
 template <int BN, int MS = 2>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : 4, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : (BN == 64 && MS == 2 ? 5 : 4), 8)))
 rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcParams::in_pairs): no split in the stage loop
     __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];   // weight buffers
     __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
