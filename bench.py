@@ -79,7 +79,8 @@ def parse():
     ap.add_argument("--row-order", choices=["taps", "canonical"], default="taps",
                     help="internal row order of the strided sparse levels (ModelConfig.row_order)")
     ap.add_argument("--row-order-chunk", type=int, default=4096)
-    ap.add_argument("--pair-rows", type=int, choices=[0, 1], default=1, help="fp16-pair rows between the f16x2 sparse layers (ModelConfig.pair_rows)")
+    ap.add_argument("--pair-rows", type=int, choices=[0, 1, 2], default=2, help="fp16-pair rows between the f16x2 sparse layers "
+                    "(ModelConfig.pair_rows): 1 = levels 2-4, 2 = level 1 as well (pair_rows_level1)")
     ap.add_argument("--conv-math", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
                     help="arithmetic of the layers with >= 32 input channels: split-fp16 x2 (3 products) or split-bf16 x3 (6 products) "
                          "on the 16-bit matrix pipe (both fp32-level error), or fp32 MFMA")
@@ -523,7 +524,8 @@ def main():
     # "nccl" is RCCL on ROCm; CPD_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests
     distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"), torch.device("cuda", local))
 
-    cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk, pair_rows=bool(args.pair_rows))
+    cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk, pair_rows=bool(args.pair_rows),
+                      pair_rows_level1=args.pair_rows == 2)
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local
     if args.mode == "train":

@@ -159,7 +159,10 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
                 float v = acc[s][nt][i];
                 v = v * sc[nt] + sh[nt];
                 if (p.residual) {
-                    if (PAIRS && p.res_pairs) {       // h + l is exact in fp32
+                    if (PAIRS && p.res_pairs == 2) {  // 16-channel pair rows: k-group (col >> 2) = [hi 4 | lo 4]
+                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)row * p.res_ld) + ((col >> 2) << 4) + ((col & 3) << 1);
+                        v += (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 8);
+                    } else if (PAIRS && p.res_pairs) {       // h + l is exact in fp32
                         const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)row * p.res_ld) + ((col >> 5) << 7) + ((col & 31) << 1);
                         v += (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 64);
                     } else {
@@ -184,7 +187,9 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
                     const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
                     const bool odd = (r & 1) != 0;
                     const uint32_t word = odd ? ((theirs >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (theirs << 16));
-                    char *op = reinterpret_cast<char *>(p.out + orow * p.out_ld) + ((col >> 5) << 7) + (odd ? 64 : 0) + ((col & 30) << 1);
+                    char *op = reinterpret_cast<char *>(p.out + orow * p.out_ld);
+                    if (p.out_pairs == 2) op += ((col >> 2) << 4) + (odd ? 8 : 0) + ((col & 2) << 1);          // 16-channel pair rows
+                    else op += ((col >> 5) << 7) + (odd ? 64 : 0) + ((col & 30) << 1);
                     *reinterpret_cast<uint32_t *>(op) = word;
                 } else {
                     p.out[orow * p.out_ld + col] = v;
@@ -224,7 +229,11 @@ struct StepRegs {
 // QUAD: the A pieces were gathered quad-shaped (lane -> row lane >> 2, piece lane & 3: a quad reads the 64 contiguous bytes of
 // one row's 16-channel chunk -- one L1 access instead of four, see the row-wave kernel) and become fragments (lane -> row
 // lane & 15, piece lane >> 4) through a 4 x 16 lane transpose here; `tsrc` = byte address of the source lane for ds_bpermute.
-template <int MS, int NT, unsigned MASK, bool QUAD = false>
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+// H16 (16-channel fp16-pair rows, K = 16 MFMA): a gathered 16-byte piece is [hi 4 | lo 4] of channels 4g..4g+3 of its row, a weight
+// piece the same of one column: three products (hi*hi, hi*lo, lo*hi) per (sub-tile, column tile), 48 matrix cycles instead of the
+// 128 of four fp32 MFMAs -- and no split: the producing epilogue made it
+template <int MS, int NT, unsigned MASK, bool QUAD = false, bool H16 = false>
 __device__ __forceinline__ void step_mma(StepRegs<MS, NT> &R, f32x4 (&acc)[MS][NT], int tsrc = 0) {
 #pragma unroll
     for (int s = 0; s < MS; ++s)
@@ -235,6 +244,24 @@ __device__ __forceinline__ void step_mma(StepRegs<MS, NT> &R, f32x4 (&acc)[MS][N
                 for (int k = 0; k < 4; ++k) R.a[s][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(R.a[s][k])));
             }
         }
+    if (H16) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const h16x4 bh = __builtin_bit_cast(h16x4, f32x2{R.b[nt][0], R.b[nt][1]}), bl = __builtin_bit_cast(h16x4, f32x2{R.b[nt][2], R.b[nt][3]});
+#pragma unroll
+            for (int s = 0; s < MS; ++s)
+                if (MASK & (1u << s)) {
+                    const h16x4 ah = __builtin_bit_cast(h16x4, f32x2{R.a[s][0], R.a[s][1]}), al = __builtin_bit_cast(h16x4, f32x2{R.a[s][2], R.a[s][3]});
+                    f32x4 c = acc[s][nt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+                    acc[s][nt] = c;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -245,7 +272,7 @@ __device__ __forceinline__ void step_mma(StepRegs<MS, NT> &R, f32x4 (&acc)[MS][N
                     acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.a[s][q], R.b[nt][q], acc[s][nt], 0, 0, 0);
 }
 
-template <int MS, int NT, bool VEC>
+template <int MS, int NT, bool VEC, bool H16 = false>
 __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: item, row0, col0 and the weight / mask addresses stay scalar
@@ -318,8 +345,8 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
 
     int t_cur = any ? __builtin_ctz(any) : -1;
     if (t_cur >= 0) {
-        const size_t w_chunk = (size_t)4 * p.np * 4;  // floats per 16-channel chunk of P
-        const float *wl = p.w + ((size_t)g * p.np + col0 + r) * 4;
+        const size_t w_chunk = (size_t)4 * p.np * 4;  // floats per 16-channel chunk of P (H16: per tap of Ph16 -- the same 16 bytes per (g, n))
+        const float *wl = (H16 ? reinterpret_cast<const float *>(p.wb) : p.w) + ((size_t)g * p.np + col0 + r) * 4;
         int kc_cur = 0;
         int t_ld = t_cur;  // tap the load cursor points at (stays valid after the last step)
 
@@ -354,13 +381,13 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
         };
         auto mma = [&](StepRegs<MS, NT> &R) {
             if constexpr (MS == 1) {
-                step_mma<MS, NT, 1u, VEC>(R, acc, tsrc);
+                step_mma<MS, NT, 1u, VEC, H16>(R, acc, tsrc);
             } else if constexpr (MS == 2) {
-                if (R.act == 3u) step_mma<MS, NT, 3u, VEC>(R, acc, tsrc);
-                else if (R.act == 1u) step_mma<MS, NT, 1u, VEC>(R, acc, tsrc);
-                else step_mma<MS, NT, 2u, VEC>(R, acc, tsrc);
+                if (R.act == 3u) step_mma<MS, NT, 3u, VEC, H16>(R, acc, tsrc);
+                else if (R.act == 1u) step_mma<MS, NT, 1u, VEC, H16>(R, acc, tsrc);
+                else step_mma<MS, NT, 2u, VEC, H16>(R, acc, tsrc);
             } else {
-                step_mma<MS, NT, (1u << MS) - 1u, VEC>(R, acc, tsrc);
+                step_mma<MS, NT, (1u << MS) - 1u, VEC, H16>(R, acc, tsrc);
             }
         };
 
@@ -1506,6 +1533,26 @@ __global__ void __launch_bounds__(256) pack_weight_f16_kernel(const float *__res
 }
 
 
+// Ph16[t][g][n][hi 4 | lo 4] of W[t][4g + q][n] * 2^e[n] (c_in = 16)
+__global__ void __launch_bounds__(256) pack_weight_h16_kernel(const float *__restrict__ w, int kv, int c_out, int np,
+                                                              const float *__restrict__ dsc, _Float16 *__restrict__ ph) {
+    const size_t total = (size_t)kv * 4 * np * 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i & 3);
+    size_t rest = i >> 2;
+    const int n = (int)(rest % np); rest /= np;
+    const int g = (int)(rest & 3);
+    const int t = (int)(rest >> 2);
+    float v = 0.f;
+    if (n < c_out) v = w[((size_t)t * 16 + 4 * g + q) * c_out + n] / dsc[n];       // * 2^e, exact
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    const size_t slot = (((size_t)t * 4 + g) * np + n) * 8;
+    ph[slot + q] = h;
+    ph[slot + 4 + q] = l;
+}
+
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restrict__ w, int kv, int c_in, int c_out, int kc,
                                                           int np, float *__restrict__ packed) {
     // packed[(((t*KC + kc)*4 + g)*NP + n)*4 + q] = W[t][kc*16 + 4*g + q][n]   (zero padded)
@@ -1564,6 +1611,13 @@ static gc_kernel_t pick_nt(int nt, bool vec) {
         case 5: return pick_vec<MS, 5>(vec);
         case 8: return pick_vec<MS, 8>(vec);
     }
+    return nullptr;
+}
+static gc_kernel_t pick_h16(int ms, int nt) {           // 16-channel fp16-pair input: c_out = 16 or 32
+    if (ms == 1 && nt == 1) return gather_conv_kernel<1, 1, true, true>;
+    if (ms == 2 && nt == 1) return gather_conv_kernel<2, 1, true, true>;
+    if (ms == 1 && nt == 2) return gather_conv_kernel<1, 2, true, true>;
+    if (ms == 2 && nt == 2) return gather_conv_kernel<2, 2, true, true>;
     return nullptr;
 }
 static gc_kernel_t pick(int ms, int nt, bool vec) {
@@ -1721,9 +1775,24 @@ static size_t packed_f16_floats(int kv, int c_in, int c_out) {
     if (c_in % 32) return 0;
     return packed_f16_image_floats(kv, c_in, c_out) + (size_t)(((c_out + 15) / 16) * 16);
 }
+// 16-channel layers (level 1 of the backbone): a split-fp16 image for the K = 16 MFMA, Ph16[t][g][n][hi 4 | lo 4] (16 B per
+// (tap, k-group, column): the four high terms of channels 4g..4g+3, then the four low terms), followed by its np descale floats.
+// Forward images only (cpd_pack_weight); it sits at the END of the buffer, so the other images' offsets do not move.
+static size_t packed_h16_image_floats(int kv, int c_in, int c_out) {
+    if (c_in != 16) return 0;
+    return (size_t)kv * 4 * (((c_out + 15) / 16) * 16) * 4;
+}
+static size_t packed_h16_floats(int kv, int c_in, int c_out) {
+    if (c_in != 16) return 0;
+    return packed_h16_image_floats(kv, c_in, c_out) + (size_t)(((c_out + 15) / 16) * 16);
+}
 extern "C" size_t cpd_packed_weight_floats(int kv, int c_in, int c_out) {
     if (kv <= 0 || c_in <= 0 || c_out <= 0) return 0;
-    return packed_f32_floats(kv, c_in, c_out) + packed_bf16_floats(kv, c_in, c_out) + packed_f16_floats(kv, c_in, c_out);
+    return packed_f32_floats(kv, c_in, c_out) + packed_bf16_floats(kv, c_in, c_out) + packed_f16_floats(kv, c_in, c_out) +
+           packed_h16_floats(kv, c_in, c_out);
+}
+static const float *packed_h16_ptr(const float *packed, int kv, int c_in, int c_out) {
+    return packed + packed_f32_floats(kv, c_in, c_out) + packed_bf16_floats(kv, c_in, c_out) + packed_f16_floats(kv, c_in, c_out);
 }
 // where the images of one packed buffer start
 static const float *packed_bf16_ptr(const float *packed, int kv, int c_in, int c_out) { return packed + packed_f32_floats(kv, c_in, c_out); }
@@ -1751,6 +1820,13 @@ extern "C" int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, 
     size_t total = packed_f32_floats(kv, c_in, c_out);
     pack_weight_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, kc, np, packed);
     pack_bf16_image(w_kio, kv, c_in, c_out, 0, 0, packed, cpd_s(stream));
+    if (packed_h16_floats(kv, c_in, c_out)) {
+        float *img = const_cast<float *>(packed_h16_ptr(packed, kv, c_in, c_out));
+        float *dsc = img + packed_h16_image_floats(kv, c_in, c_out);
+        weight_col_scale_kernel<<<np, 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, 0, dsc);
+        const size_t n16 = (size_t)kv * 4 * np * 4;
+        pack_weight_h16_kernel<<<cpd_div_up((long long)n16, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_out, np, dsc, reinterpret_cast<_Float16 *>(img));
+    }
     return cpd_check_launch();
 }
 
@@ -1981,13 +2057,19 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
     // fp16-pair rows: whole 32-channel blocks, f16x2 arithmetic, no pre-scaling (a guarded re-run works on fp32 rows)
-    if ((flags & CPD_GC_IN_PAIRS) && (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || c_in % 32 || c_out % 32 || in_ld % 4 || in_absmax || kv > CPD_RW_TAPS ||
-                                      (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
+    const bool in16 = (flags & CPD_GC_IN_PAIRS) && c_in == 16;      // 16-channel pair rows: the wave kernel's K = 16 form
+    if (in16 && (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || (c_out != 16 && c_out != 32) || in_ld % 4 || (((uintptr_t)in) & 15) || in_absmax))
         return CPD_ERR_UNSUPPORTED;
-    if ((flags & CPD_GC_OUT_PAIRS) && (c_out % 32 || out_col_group > 0)) return CPD_ERR_UNSUPPORTED;
-    if ((flags & CPD_GC_RES_PAIRS) && (!residual || c_out % 32)) return CPD_ERR_ARG;
+    if ((flags & CPD_GC_IN_PAIRS) && !in16 &&
+        (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || c_in % 32 || c_out % 32 || in_ld % 4 || in_absmax || kv > CPD_RW_TAPS ||
+         (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
+        return CPD_ERR_UNSUPPORTED;
+    if ((flags & CPD_GC_OUT_PAIRS) && ((c_out % 32 && c_out != 16) || out_col_group > 0)) return CPD_ERR_UNSUPPORTED;
+    if ((flags & CPD_GC_RES_PAIRS) && (!residual || (c_out % 32 && c_out != 16))) return CPD_ERR_ARG;
     GcParams p;
-    p.in_pairs = (flags & CPD_GC_IN_PAIRS) != 0; p.out_pairs = (flags & CPD_GC_OUT_PAIRS) != 0; p.res_pairs = (flags & CPD_GC_RES_PAIRS) != 0;
+    p.in_pairs = (flags & CPD_GC_IN_PAIRS) != 0;
+    p.out_pairs = (flags & CPD_GC_OUT_PAIRS) ? (c_out == 16 ? 2 : 1) : 0;       // (2: the 16-channel row format)
+    p.res_pairs = (flags & CPD_GC_RES_PAIRS) ? (c_out == 16 ? 2 : 1) : 0;
     p.split = 1; p.part = nullptr;
     p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.in_absmax = in_absmax; p.out_absmax = out_absmax; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
@@ -1997,7 +2079,8 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
     if (pl.use_wg == 3 && (kv > CPD_RW_TAPS || (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
         pl = plan(n_out, c_in, c_out, in_ld, in, flags | CPD_GC_DENSE);   // the row-wave kernel keeps its taps in 32-bit sets and reads its rows through a 4 GB buffer resource
-    if (p.in_pairs && (pl.use_wg != 3 || pl.math != 2)) return CPD_ERR_UNSUPPORTED;
+    if (in16 && pl.use_wg != 0) return CPD_ERR_UNSUPPORTED;
+    if (p.in_pairs && !in16 && (pl.use_wg != 3 || pl.math != 2)) return CPD_ERR_UNSUPPORTED;
     if ((p.out_pairs || p.res_pairs) && pl.use_wg != 3 && pl.use_wg != 0) return CPD_ERR_UNSUPPORTED;   // (the sparse kernels' epilogues)
     p.taps_inner = 1;       // measured (tools/order_probe.py): -6...-8 % on the 32- and 128-channel SubM layers, neutral at 64
     if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_TAPS_INNER")) p.taps_inner = atoi(e);
@@ -2026,6 +2109,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
         else if (pl.use_wg == 2) snprintf(nm, sizeof nm, "tile_conv_%s_kernel<%d,%d>", sc, pl.a, pl.b);
         else if (pl.use_wg == 1) snprintf(nm, sizeof nm, "tile_conv_kernel<%d,%d>", pl.a, pl.b);
+        else if (in16) snprintf(nm, sizeof nm, "gather_conv_h16_kernel<%d,%d>", pl.a, pl.b);
         else snprintf(nm, sizeof nm, "gather_conv_kernel<%d,%d,%s>", pl.a, pl.b, pl.vec ? "true" : "false");
         cpd_launch_log_note(nm);
     }
@@ -2118,8 +2202,12 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         hipLaunchKernelGGL(k, dim3(p.items), dim3(256), lds, cpd_s(stream), p);
         return cpd_check_launch();
     }
-    gc_kernel_t k = pick(pl.a, pl.b, pl.vec != 0);
+    gc_kernel_t k = in16 ? pick_h16(pl.a, pl.b) : pick(pl.a, pl.b, pl.vec != 0);
     if (!k) return CPD_ERR_UNSUPPORTED;
+    if (in16) {
+        p.wb = packed_h16_ptr(packed_w, kv, c_in, c_out);
+        p.dsc = reinterpret_cast<const float *>(p.wb) + packed_h16_image_floats(kv, c_in, c_out);
+    }
     p.n_rb = (n_out + 16 * pl.a - 1) / (16 * pl.a);
     p.n_cb = p.ntot / pl.b;
     p.items = p.n_rb * p.n_cb;

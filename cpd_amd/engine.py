@@ -63,6 +63,7 @@ class ModelConfig:
     # True = fp16-pair rows (CPD_GC_*_PAIRS: the epilogue that produces a row writes its split x = h + l, the up to 27 gathers of
     # the row take the bits as MFMA fragments -- same products, no split in the stage loop); a range-guard re-run uses fp32 rows
     pair_rows: bool = True
+    pair_rows_level1: bool = True          # ... and level 1 (16 channels: K = 16 MFMA form of the wave kernel) as well
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
     row_order: str = "taps"
     row_order_chunk: int = 4096
@@ -371,11 +372,14 @@ class CenterPointEngine:
             index = ops.SiteIndex.build(coords, batch, shape)
         nbr = ops.rulebook_subm(coords, index)               # 'subm1' and 'res1' are the same L0 table
         self._range_reset()                                  # (the 5-channel input layer runs on the fp32 pipe: no block for `feats`)
-        x = self._conv(L["conv_input"], feats, nbr, coords.shape[0])
-        x = self._blocks(L["conv1"], x, nbr)
-        levels = {"x_conv1": (x, coords, shape)}
+        # level 1 (16 channels): with pair rows its layers run the K = 16 split-fp16 MFMA on 16-channel pair rows (three products of
+        # 16 matrix cycles instead of four fp32 MFMAs of 32); the 5-channel input layer stays on the fp32 pipe and writes the first pairs
+        pairs16 = pairs and self.cfg.pair_rows_level1
+        x = self._conv(L["conv_input"], feats, nbr, coords.shape[0], out_pairs=pairs16)
+        x = self._blocks(L["conv1"], x, nbr, pairs=pairs16)
+        levels = {"x_conv1": (ops.pairs_to_rows(x) if pairs16 and export_levels else x, coords, shape)}
         coords_c = coords                  # the list the next level's output set is marked from: canonical order wherever one exists
-        pairs_in = False                   # level 1 (16 channels) runs on the fp32 pipe: fp32 rows
+        pairs_in = pairs16                 # (what conv2.down reads)
         for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
             k, s, pd = _DOWN[stage]
             out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)

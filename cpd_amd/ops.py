@@ -302,10 +302,11 @@ def rows_to_pairs(x):
     """fp32 rows [n, C] (C % 32 == 0) -> the same bytes as fp16-pair rows (a float32 tensor of the same shape holding, per 32-channel
     block, 32 fp16 high terms then 32 fp16 low terms of x = h + l; CPD_GC_*_PAIRS). torch ops: tests and tools, not the hot path."""
     n, c = x.shape
-    assert c % 32 == 0 and x.dtype == torch.float32
+    blk = 4 if c == 16 else 32          # 16-channel rows: per k-group of 4 channels [hi 4 | lo 4] (the K = 16 MFMA's pieces)
+    assert c % blk == 0 and (c == 16 or c % 32 == 0) and x.dtype == torch.float32
     h = x.to(torch.float16)
     l = (x - h.float()).to(torch.float16)
-    pairs = torch.stack([h.view(n, c // 32, 32), l.view(n, c // 32, 32)], dim=2)       # [n, blocks, 2, 32] fp16
+    pairs = torch.stack([h.view(n, c // blk, blk), l.view(n, c // blk, blk)], dim=2)   # [n, blocks, 2, blk] fp16
     return pairs.contiguous().view(n, c * 2).view(torch.float32)
 
 
@@ -313,8 +314,9 @@ def pairs_to_rows(x, c=None):
     """fp16-pair rows -> fp32 rows (h + l, exact in fp32)."""
     n = x.shape[0]
     c = x.shape[1] if c is None else c
-    assert c % 32 == 0 and x.dtype == torch.float32
-    halves = x[:, :c].contiguous().view(torch.float16).view(n, c // 32, 2, 32).float()
+    blk = 4 if c == 16 else 32
+    assert (c == 16 or c % 32 == 0) and x.dtype == torch.float32
+    halves = x[:, :c].contiguous().view(torch.float16).view(n, c // blk, 2, blk).float()
     return (halves[:, :, 0] + halves[:, :, 1]).reshape(n, c)
 
 

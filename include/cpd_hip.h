@@ -206,8 +206,10 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
  * (the engine's range guard re-runs such a step on fp32 rows with pre-scaling).
  *   CPD_GC_IN_PAIRS   `in` rows are pairs: needs CPD_GC_F16X2, c_in % 32 == 0, c_out % 32 == 0, kv <= 28, < 4 GB of input, no
  *                     in_absmax, not CPD_GC_DENSE (the row-wave kernel is the one that reads them) -- else CPD_ERR_UNSUPPORTED
- *   CPD_GC_OUT_PAIRS  `out` rows are written as pairs (any kernel's epilogue; c_out % 32 == 0, no out_col_group)
- *   CPD_GC_RES_PAIRS  `residual` rows are pairs (c_out % 32 == 0) */
+ *                     -- or c_in == 16 (c_out 16 or 32; the wave kernel's K = 16 MFMA form): 16-channel pair rows hold, per group of
+ *                     four channels, the four high terms (8 B) then the four low terms (8 B)
+ *   CPD_GC_OUT_PAIRS  `out` rows are written as pairs (the sparse kernels' epilogues; c_out % 32 == 0 or c_out == 16, no out_col_group)
+ *   CPD_GC_RES_PAIRS  `residual` rows are pairs (c_out % 32 == 0 or c_out == 16) */
 #define CPD_GC_IN_PAIRS 16
 #define CPD_GC_OUT_PAIRS 32
 #define CPD_GC_RES_PAIRS 64

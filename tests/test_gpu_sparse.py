@@ -230,7 +230,7 @@ def test_rowwave_split_bf16_variants_match_oracle(oracle, hip, math, cin, cout, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,n,want", [(128, 128, 80000, "<128,2>"), (128, 128, 24000, "<128,1>"), (64, 64, 30000, "<64,1>"), (32, 32, 30000, "<32,1>"),
                                              (32, 32, 80000, "<32,2>"), (64, 128, 12000, "<64,1>"), (64, 64, 80000, "<64,2>"), (64, 128, 600, "<32,1>"),
-                                             (16, 32, 20000, None)])
+                                             (16, 32, 20000, "h16"), (16, 16, 30000, "h16"), (16, 16, 900, "h16"), (5, 16, 20000, None)])
 def test_fp16_pair_rows_give_the_fp32_rows_result(oracle, hip, cin, cout, n, want):
     """CPD_GC_IN/OUT/RES_PAIRS: activations stored as fp16-pair rows (the f16x2 split made once, by the producing epilogue). The
     row-wave kernel on pair input, with a pair residual and pair output, in each of its shapes -- and the fp32 wave kernel writing
@@ -251,8 +251,8 @@ def test_fp16_pair_rows_give_the_fp32_rows_result(oracle, hip, cin, cout, n, wan
     nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
     w_kio = torch.from_numpy(w).reshape(cout, -1, cin).permute(1, 2, 0).contiguous().cuda()
     packed = ops.pack_weight(w_kio)
-    in_pairs = cin % 32 == 0
-    if in_pairs:
+    in_pairs = cin % 32 == 0 or cin == 16          # (16 channels: the wave kernel's K = 16 form on 16-channel pair rows)
+    if in_pairs and cin != 16:
         name = ops.gather_conv_tile(rows, cin, cout, cin, dense=False, math="f16x2", in_pairs=True)
         assert name == "rowwave_conv_f16p_kernel" + want, (name, rows)
     x, r = dev(feat), dev(res)
@@ -261,7 +261,9 @@ def test_fp16_pair_rows_give_the_fp32_rows_result(oracle, hip, cin, cout, n, wan
     with ops.launch_log() as log:
         got_p = ops.gather_conv(xp, cin, packed, nbr, 27, rows, cout, dev(scale), dev(shift), rp, True, math="f16x2",
                                 in_pairs=in_pairs, out_pairs=True, res_pairs=True)
-    if in_pairs:
+    if cin == 16:
+        assert len(log.counts) == 1 and next(iter(log.counts)).startswith("gather_conv_h16_kernel<"), log.counts
+    elif in_pairs:
         convs = {k: v for k, v in log.counts.items() if k != "split_finish_kernel"}      # (small launches split their taps: two launches)
         assert convs == {"rowwave_conv_f16p_kernel" + want: 1}, log.counts
     got = ops.pairs_to_rows(got_p).cpu().numpy()
@@ -277,7 +279,7 @@ def test_fp16_pair_rows_give_the_fp32_rows_result(oracle, hip, cin, cout, n, wan
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=5e-5, rtol=0)
         # what the flags refuse: pair input into the dense path / with an absmax block / without f16x2
         from cpd_amd._lib import CpdHipError
-        for kw in (dict(dense=True, math="f16x2"), dict(math="bf16x3"), dict(math="f16x2", in_absmax=ops.absmax_rows(x))):
+        for kw in (dict(dense=True, math="f16x2"), dict(math="bf16x3"), dict(math="f16x2", in_absmax=ops.absmax_rows(x) if cin != 16 else ops.absmax_blocks(1, x.device)[0])):
             with pytest.raises(CpdHipError):
                 ops.gather_conv(xp, cin, packed, nbr, 27, rows, cout, in_pairs=True, **kw)
 
