@@ -1533,8 +1533,9 @@ __global__ void __launch_bounds__(256) pack_weight_f16_kernel(const float *__res
 }
 
 
-// Ph16[t][g][n][hi 4 | lo 4] of W[t][4g + q][n] * 2^e[n] (c_in = 16)
-__global__ void __launch_bounds__(256) pack_weight_h16_kernel(const float *__restrict__ w, int kv, int c_out, int np,
+// Ph16[t][g][n][hi 4 | lo 4] of W[t][4g + q][n] * 2^e[n] (c_in = 16; (c_in, c_out) are those of the conv the image is FOR, the
+// source is [kv][c_in][c_out], or [kv][c_out][c_in] when `adjoint`, tap-flipped when `flip`: as pack_weight_f16_kernel)
+__global__ void __launch_bounds__(256) pack_weight_h16_kernel(const float *__restrict__ w, int kv, int c_out, int np, int adjoint, int flip,
                                                               const float *__restrict__ dsc, _Float16 *__restrict__ ph) {
     const size_t total = (size_t)kv * 4 * np * 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1544,8 +1545,9 @@ __global__ void __launch_bounds__(256) pack_weight_h16_kernel(const float *__res
     const int n = (int)(rest % np); rest /= np;
     const int g = (int)(rest & 3);
     const int t = (int)(rest >> 2);
+    const int ch = 4 * g + q, ts = flip ? kv - 1 - t : t;
     float v = 0.f;
-    if (n < c_out) v = w[((size_t)t * 16 + 4 * g + q) * c_out + n] / dsc[n];       // * 2^e, exact
+    if (n < c_out) v = (adjoint ? w[((size_t)ts * c_out + n) * 16 + ch] : w[((size_t)ts * 16 + ch) * c_out + n]) / dsc[n];       // * 2^e, exact
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
     const size_t slot = (((size_t)t * 4 + g) * np + n) * 8;
@@ -1814,19 +1816,23 @@ static void pack_bf16_image(const float *w, int kv, int c_in, int c_out, int adj
         w, kv, c_in, c_out, np, adjoint, flip, dsc, reinterpret_cast<_Float16 *>(const_cast<float *>(packed_f16_ptr(packed, kv, c_in, c_out))));
 }
 
+static void pack_h16_image(const float *w, int kv, int c_in, int c_out, int adjoint, int flip, float *packed, hipStream_t s) {
+    if (!packed_h16_floats(kv, c_in, c_out)) return;           // (c_in, c_out): of the conv the image is for
+    const int np = ((c_out + 15) / 16) * 16;
+    float *img = const_cast<float *>(packed_h16_ptr(packed, kv, c_in, c_out));
+    float *dsc = img + packed_h16_image_floats(kv, c_in, c_out);
+    weight_col_scale_kernel<<<np, 256, 0, s>>>(w, kv, c_in, c_out, adjoint, dsc);
+    const size_t n16 = (size_t)kv * 4 * np * 4;
+    pack_weight_h16_kernel<<<cpd_div_up((long long)n16, 256), 256, 0, s>>>(w, kv, c_out, np, adjoint, flip, dsc, reinterpret_cast<_Float16 *>(img));
+}
+
 extern "C" int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *packed, cpd_stream_t stream) {
     if (!w_kio || !packed || kv <= 0 || c_in <= 0 || c_out <= 0) return CPD_ERR_ARG;
     int kc = (c_in + 15) / 16, np = ((c_out + 15) / 16) * 16;
     size_t total = packed_f32_floats(kv, c_in, c_out);
     pack_weight_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, kc, np, packed);
     pack_bf16_image(w_kio, kv, c_in, c_out, 0, 0, packed, cpd_s(stream));
-    if (packed_h16_floats(kv, c_in, c_out)) {
-        float *img = const_cast<float *>(packed_h16_ptr(packed, kv, c_in, c_out));
-        float *dsc = img + packed_h16_image_floats(kv, c_in, c_out);
-        weight_col_scale_kernel<<<np, 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, 0, dsc);
-        const size_t n16 = (size_t)kv * 4 * np * 4;
-        pack_weight_h16_kernel<<<cpd_div_up((long long)n16, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_out, np, dsc, reinterpret_cast<_Float16 *>(img));
-    }
+    pack_h16_image(w_kio, kv, c_in, c_out, 0, 0, packed, cpd_s(stream));
     return cpd_check_launch();
 }
 
@@ -1838,6 +1844,7 @@ extern "C" int cpd_pack_weight_adjoint(const float *w_kio, int kv, int c_in, int
     pack_weight_adjoint_kernel<<<cpd_div_up((long long)total, 256), 256, 0, cpd_s(stream)>>>(w_kio, kv, c_in, c_out, flip_taps,
                                                                                             kc_o, np_o, packed);
     pack_bf16_image(w_kio, kv, c_out, c_in, 1, flip_taps, packed, cpd_s(stream));
+    pack_h16_image(w_kio, kv, c_out, c_in, 1, flip_taps, packed, cpd_s(stream));
     return cpd_check_launch();
 }
 
@@ -1851,8 +1858,10 @@ struct PackJobDev {
     int kv, c_in, c_out, adjoint, flip;     // c_in / c_out of the SOURCE tensor
     int ci, co, kc, np;                     // of the conv the image is for; kc = 16-channel chunks, np = padded columns
     int split;                              // has the split images (ci % 32 == 0)
+    int h16;                                // has the K = 16 split-fp16 image (forward image of a 16-channel layer)
     unsigned b_f32, b_scale, b_split;       // first block of the job in the fp32-image / column-scale / split-image grids
     size_t off_bf16, off_f16, off_dsc;      // float offsets of the images inside `packed`
+    size_t off_h16, off_dsc16;
 };
 template <unsigned PackJobDev::*FIRST>
 __device__ __forceinline__ int pack_job_of(const PackJobDev *jobs, int n_jobs, unsigned block) {
@@ -1886,7 +1895,7 @@ __global__ void __launch_bounds__(256) pack_batch_f32_kernel(const PackJobDev *_
 __global__ void __launch_bounds__(256) pack_batch_scale_kernel(const PackJobDev *__restrict__ jobs, int n_jobs) {
     const PackJobDev j = jobs[pack_job_of<&PackJobDev::b_scale>(jobs, n_jobs, blockIdx.x)];
     const int n = (int)(blockIdx.x - j.b_scale);
-    if (!j.split || n >= j.np) return;
+    if ((!j.split && !j.h16) || n >= j.np) return;
     float m = 0.f;
     if (n < j.co) {
         const int per = j.kv * j.ci;
@@ -1912,12 +1921,32 @@ __global__ void __launch_bounds__(256) pack_batch_scale_kernel(const PackJobDev 
             e = 14 - ex;
             e = e > 110 ? 110 : (e < -110 ? -110 : e);
         }
-        j.packed[j.off_dsc + n] = ldexpf(1.f, -e);
+        j.packed[(j.h16 ? j.off_dsc16 : j.off_dsc) + n] = ldexpf(1.f, -e);
     }
 }
 // images: bit 0 = the split-bf16 image, bit 1 = the split-fp16 image (needs the column scales of the launch before)
 __global__ void __launch_bounds__(256) pack_batch_split_kernel(const PackJobDev *__restrict__ jobs, int n_jobs, int images) {
     const PackJobDev j = jobs[pack_job_of<&PackJobDev::b_split>(jobs, n_jobs, blockIdx.x)];
+    if (j.h16) {                            // Ph16[t][g][n][hi 4 | lo 4], as pack_weight_h16_kernel
+        const size_t total16 = (size_t)j.kv * 4 * j.np * 4;
+        const size_t e = (size_t)(blockIdx.x - j.b_split) * 256 + threadIdx.x;
+        if (!(images & 2) || e >= total16) return;
+        const int q = (int)(e & 3);
+        size_t rest = e >> 2;
+        const int n = (int)(rest % j.np); rest /= j.np;
+        const int g = (int)(rest & 3);
+        const int t = (int)(rest >> 2);
+        const int ch = 4 * g + q, ts = j.flip ? j.kv - 1 - t : t;
+        float v = 0.f;
+        if (n < j.co) v = (j.adjoint ? j.w[((size_t)ts * j.c_in + n) * j.c_out + ch] : j.w[((size_t)ts * j.c_in + ch) * j.c_out + n]) / j.packed[j.off_dsc16 + n];
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        _Float16 *ph = reinterpret_cast<_Float16 *>(j.packed + j.off_h16);
+        const size_t slot = (((size_t)t * 4 + g) * j.np + n) * 8;
+        ph[slot + q] = h;
+        ph[slot + 4 + q] = l;
+        return;
+    }
     if (!j.split) return;
     const int k32 = j.ci >> 5;
     const size_t total = (size_t)j.kv * k32 * 4 * j.np * 8;
@@ -1975,11 +2004,17 @@ extern "C" int cpd_pack_batch_prepare(const cpd_pack_job *jobs, int n_jobs, void
         d.off_bf16 = packed_f32_floats(d.kv, d.ci, d.co);
         d.off_f16 = d.off_bf16 + packed_bf16_floats(d.kv, d.ci, d.co);
         d.off_dsc = d.off_f16 + packed_f16_image_floats(d.kv, d.ci, d.co);
+        d.h16 = packed_h16_floats(d.kv, d.ci, d.co) != 0;
+        d.off_h16 = d.off_f16 + packed_f16_floats(d.kv, d.ci, d.co);
+        d.off_dsc16 = d.off_h16 + packed_h16_image_floats(d.kv, d.ci, d.co);
         d.b_f32 = (unsigned)b0; d.b_scale = (unsigned)b1; d.b_split = (unsigned)b2;
         b0 += (unsigned long long)cpd_div_up((long long)packed_f32_floats(d.kv, d.ci, d.co), 256);
         if (d.split) {
             b1 += (unsigned long long)d.np;
             b2 += (unsigned long long)cpd_div_up((long long)d.kv * (d.ci / 32) * 4 * d.np * 8, 256);
+        } else if (d.h16) {
+            b1 += (unsigned long long)d.np;
+            b2 += (unsigned long long)cpd_div_up((long long)d.kv * 4 * d.np * 4, 256);
         }
         if (b0 >= (1ull << 31) || b2 >= (1ull << 31)) return CPD_ERR_UNSUPPORTED;
     }

@@ -551,4 +551,6 @@ def _gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=
         return "tile_conv_%s_kernel<%d,%d>" % ("f16" if wg.value == 12 else "bf16", a.value, b.value)
     if wg.value:
         return "tile_conv_kernel<%d,%d>" % (a.value, b.value)
+    if in_pairs and c_in == 16:
+        return "gather_conv_h16_kernel<%d,%d>" % (a.value, b.value)                   # 16-channel pair rows: the K = 16 MFMA form
     return "gather_conv_kernel<%d,%d,%s>" % (a.value, b.value, "true" if vec.value else "false")
