@@ -158,7 +158,11 @@ int cpd_rulebook_conv(const int32_t *out_indices, int n_out, int batch, const in
                       const void *in_index, int32_t *nbr, uint32_t *tapmask, cpd_stream_t stream);
 
 /* Weights for cpd_gather_conv: pack a dense [kv][c_in][c_out] f32 tensor (device) into the
- * MFMA-fragment order the kernel streams (zero padded to multiples of 16).                   */
+ * MFMA-fragment order the kernel streams (zero padded to multiples of 16). One buffer holds every image the conv may run on: the
+ * fp32 image; for c_in % 32 == 0 the split-bf16 and split-fp16 images (the latter pre-scaled per output column by a power of two,
+ * followed by the descale factors); for c_in == 16 the K = 16 split-fp16 image Ph16[t][g][n][hi 4 | lo 4] + its descale factors
+ * (round 3: 16-channel pair rows, CPD_GC_IN_PAIRS). cpd_packed_weight_floats sizes the buffer; every packer (this one, the adjoint
+ * one, the batched one) writes every image the buffer has, bit for bit alike.                                                   */
 size_t cpd_packed_weight_floats(int kv, int c_in, int c_out);
 int cpd_pack_weight(const float *w_kio, int kv, int c_in, int c_out, float *packed,
                     cpd_stream_t stream);
