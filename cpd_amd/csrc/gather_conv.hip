@@ -2114,6 +2114,12 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     GcPlan pl = plan(n_out, c_in, c_out, in_ld, in, flags);
     if (pl.use_wg == 3 && (kv > CPD_RW_TAPS || (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
         pl = plan(n_out, c_in, c_out, in_ld, in, flags | CPD_GC_DENSE);   // the row-wave kernel keeps its taps in 32-bit sets and reads its rows through a 4 GB buffer resource
+    if (pl.use_wg == 0 && kv > 32) {
+        // the wave kernel keeps a tile's taps in 32-bit sets and their rulebook columns in a 32-tap LDS table: a larger kernel goes to
+        // the workgroup kernels when its channel counts allow, and is refused -- loudly -- when they do not
+        pl = plan(n_out, c_in, c_out, in_ld, in, flags | CPD_GC_DENSE);
+        if (pl.use_wg == 0) return CPD_ERR_UNSUPPORTED;
+    }
     if (in16 && pl.use_wg != 0) return CPD_ERR_UNSUPPORTED;
     if (p.in_pairs && !in16 && (pl.use_wg != 3 || pl.math != 2)) return CPD_ERR_UNSUPPORTED;
     if ((p.out_pairs || p.res_pairs) && pl.use_wg != 3 && pl.use_wg != 0) return CPD_ERR_UNSUPPORTED;   // (the sparse kernels' epilogues)

@@ -379,3 +379,34 @@ def test_tap_pattern_row_order(oracle, hip, chunk):
     np.testing.assert_array_equal(nbr_p.tapmask.cpu().numpy().astype(np.int64) & ((1 << 27) - 1), tm)
     index.set_order(None)                                                               # canonical again
     np.testing.assert_array_equal(ops.rulebook_subm(idx, index).cpu().numpy(), nbr_c)
+
+
+@pytest.mark.gpu
+def test_kernels_with_more_than_32_taps_fail_loudly_or_run_exactly(oracle, hip):
+    """The wave kernel keeps a tile's taps in 32-bit sets: a 45-tap kernel (3 x 3 x 5) on 16 channels has no kernel that can take it
+    and is REFUSED (it used to run the first 32 taps); on 64 channels with split arithmetic it goes to the workgroup kernel and matches the oracle."""
+    import torch
+    from cpd_amd import ops
+    from cpd_amd._lib import CpdHipError
+    rng = np.random.default_rng(5)
+    batch, shape, ks = 2, [11, 96, 96], [3, 3, 5]
+    idx = random_sites(rng, batch, shape, 60000).astype(np.int32)
+    d_idx = dev(idx)
+    index = ops.SiteIndex.build(d_idx, batch, shape)
+    nbr = ops.rulebook_subm(d_idx, index, ksize=ks)
+    kv, rows = 45, idx.shape[0]
+    assert nbr.shape[0] == kv
+    for c, ok in ((16, False), (64, True)):
+        feat = rng.normal(size=(rows, c)).astype(np.float32)
+        w = (rng.normal(size=(c, 3, 3, 5, c)) * np.sqrt(2.0 / (kv * c))).astype(np.float32)
+        packed = ops.pack_weight(torch.from_numpy(w).reshape(c, -1, c).permute(1, 2, 0).contiguous().cuda())
+        table = nbr.clone()                    # (no tap masks: they are 32-bit)
+        if not ok:
+            with pytest.raises(CpdHipError):
+                ops.gather_conv(dev(feat), c, packed, table, kv, rows, c)
+            continue
+        with ops.launch_log() as log:
+            got = ops.gather_conv(dev(feat), c, packed, table, kv, rows, c, math="f16x2").cpu().numpy()
+        assert all(k.startswith(("tile_conv_f16_kernel", "split_finish")) for k in log.counts), log.counts
+        np.testing.assert_allclose(got, oracle.sparse_conv(feat, w, None, nbr.cpu().numpy()), atol=1e-4, rtol=0)
+
