@@ -351,13 +351,22 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
         int t_ld = t_cur;  // tap the load cursor points at (stays valid after the last step)
 
         StepRegs<MS, NT> R0, R1;
+        // H16: rows through a buffer resource (the launcher checks < 4 GB): a row without a neighbour is out of range and comes back as
+        // zeros -- no select afterwards, 32-bit offsets
+        const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0,
+                                                                                 (int)(uint32_t)((size_t)p.n_in_rows * p.in_ld * sizeof(float)), 0x00020000);
+        const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
         auto load = [&](StepRegs<MS, NT> &R) {
             R.act = act_of(t_ld);
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
                 R.idx[s] = s_idx[wave][t_ld][16 * s + lr];
                 if (CPD_GC_ABLATE & 2) R.a[s] = f32x4{(float)g, 1.f, (float)kc_cur, 2.f};
-                else R.a[s] = load_a<VEC>(p, R.idx[s], kc_cur * 16 + 4 * lp);
+                else if (H16) {
+                    const uint32_t rowu = (uint32_t)R.idx[s] < (uint32_t)p.n_in_rows ? (uint32_t)R.idx[s] : (uint32_t)p.n_in_rows;
+                    R.a[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, rowu * row_bytes + (uint32_t)lp * 16u, 0, 0));
+                    R.idx[s] = 0;                              // (nothing to zero afterwards)
+                } else R.a[s] = load_a<VEC>(p, R.idx[s], kc_cur * 16 + 4 * lp);
             }
             const float *wk = wl + ((size_t)t_ld * p.kc + kc_cur) * w_chunk;
 #pragma unroll
@@ -2093,7 +2102,8 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     if (n_out == 0) return CPD_OK;
     // fp16-pair rows: whole 32-channel blocks, f16x2 arithmetic, no pre-scaling (a guarded re-run works on fp32 rows)
     const bool in16 = (flags & CPD_GC_IN_PAIRS) && c_in == 16;      // 16-channel pair rows: the wave kernel's K = 16 form
-    if (in16 && (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || (c_out != 16 && c_out != 32) || in_ld % 4 || (((uintptr_t)in) & 15) || in_absmax))
+    if (in16 && (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || (c_out != 16 && c_out != 32) || in_ld % 4 || (((uintptr_t)in) & 15) || in_absmax ||
+                 (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
         return CPD_ERR_UNSUPPORTED;
     if ((flags & CPD_GC_IN_PAIRS) && !in16 &&
         (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || c_in % 32 || c_out % 32 || in_ld % 4 || in_absmax || kv > CPD_RW_TAPS ||
