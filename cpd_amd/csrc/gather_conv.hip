@@ -273,7 +273,7 @@ __device__ __forceinline__ void step_mma(StepRegs<MS, NT> &R, f32x4 (&acc)[MS][N
 }
 
 template <int MS, int NT, bool VEC, bool H16 = false>
-__global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H16 && MS * NT == 4 ? 4 : 1, 8))) gather_conv_kernel(GcParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: item, row0, col0 and the weight / mask addresses stay scalar
     const int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
@@ -391,6 +391,11 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GcParams p) {
         auto mma = [&](StepRegs<MS, NT> &R) {
             if constexpr (MS == 1) {
                 step_mma<MS, NT, 1u, VEC, H16>(R, acc, tsrc);
+            } else if constexpr (MS == 2 && H16 && NT == 2) {       // (the 16 -> 32 layer: -13 %; the 16 -> 16 layers +3 % this way: left alone)
+                // both sub-tiles of every active step: the rows of an inactive one are out of range (zeros), and ONE form of the
+                // step, with the occupancy bound that makes the compiler keep the accumulators in ordinary registers (no AGPR copies),
+                // is 46 registers less: 5 -> 7 waves per SIMD
+                step_mma<MS, NT, 3u, VEC, H16>(R, acc, tsrc);
             } else if constexpr (MS == 2) {
                 if (R.act == 3u) step_mma<MS, NT, 3u, VEC, H16>(R, acc, tsrc);
                 else if (R.act == 1u) step_mma<MS, NT, 1u, VEC, H16>(R, acc, tsrc);
