@@ -58,7 +58,26 @@ def kernel_peak(kname):
         return PEAK_BF16_MFMA_TFLOPS / F16X2_PRODUCTS, "fp16 dense MFMA peak 2500 TFLOP/s / 3 partial products (split-fp16, fp32-level result)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32-input MFMA peak"
 
-POOL = 8                        # distinct synthetic frames per rank (seeds rank*8 .. rank*8+7: SURVEY 8d), cycled
+POOL = 48                       # distinct synthetic frames per rank (seeds rank*48 .. rank*48+47: SURVEY 8d): every frame of the
+                                # default 48-frame step is a different cloud (round 3 cycled 8 clouds six times)
+
+
+def make_clouds(seeds, n_points):
+    """the rank's synthetic clouds (numpy, host), generated on a few threads (numpy releases the GIL in its kernels)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        return list(ex.map(lambda s_: waymo_cloud(s_, n_points=n_points), seeds))
+
+
+def kernel_source_hash():
+    """BLAKE2 over the kernel sources (cpd_amd/csrc/*.hip, *.h, sorted): stamps which code a committed PMC pass measured"""
+    import glob
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for f in sorted(glob.glob(os.path.join(REPO, "cpd_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "cpd_amd", "csrc", "*.h"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
 
 
 def parse():
@@ -94,6 +113,8 @@ def parse():
     ap.add_argument("--api", choices=["engine", "modules"], default="engine",
                     help="engine = the fused CenterPointEngine (headline); modules = the drop-in module path: device voxelizer -> "
                          "batch_dict -> cpd_amd.models.CenterPoint (eval), spconv.install(conv_math=--conv-math)")
+    ap.add_argument("--no-digest-check", action="store_true", help="do not re-run steps on one stream to compare their results_digest "
+                    "with the timed (multi-stream) steps'")
     ap.add_argument("--launch-check", action="store_true", help="only launch the --gpus ranks, rendezvous, run the timing "
                     "collectives (barrier, max over ranks) and print the n_gpus line: no GPU work (the CPU test of the N > 1 "
                     "launcher, backend from CPD_DIST_BACKEND)")
@@ -271,6 +292,20 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_stamp():
+    """which code the committed PMC passes measured: the git sha and kernel-source hash tools/pmc_bench.sh recorded in the summary,
+    and whether the kernel sources of THIS run hash the same"""
+    try:
+        with open(pmc_summary_file()) as f:
+            d = json.load(f)
+        here = kernel_source_hash()
+        return {"file": os.path.relpath(pmc_summary_file(), REPO), "git_sha": d.get("git_sha"),
+                "kernel_source_hash": d.get("kernel_source_hash"), "this_run_kernel_source_hash": here,
+                "same_kernel_sources": (d.get("kernel_source_hash") == here) if d.get("kernel_source_hash") else None}
+    except Exception:
+        return None
+
+
 def time_steps(step, steps, warmup):
     """warmup + timed steps of step(i) on the current stream -> seconds per step"""
     for i in range(warmup):
@@ -313,12 +348,19 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
     out = {}
     B = args.frames
 
-    def engine_rate(c, frames, steps, warmup, n_streams=1):
-        """frames/s and seconds per step of `steps` steps of `frames` frames, dealt to n_streams workers (engine + HIP stream each)"""
+    def engine_rate(c, frames, steps, warmup, n_streams=1, host=None):
+        """frames/s and seconds per step of `steps` steps of `frames` frames, dealt to n_streams workers (engine + HIP stream each).
+        `host`: pinned host copies of the clouds -- the H2D copies then run inside the step, on the worker's stream"""
         import threading
         engs = [CenterPointEngine(c, sd, device=dev, host_results=not args.device_results) for _ in range(n_streams)]
+
+        def batch_of(i):
+            if host is not None:
+                return [host[(i * frames + j) % POOL].cuda(non_blocking=True) for j in range(frames)]
+            return [clouds[(i * frames + j) % POOL] for j in range(frames)]
+
         if n_streams == 1:
-            sec = time_steps(lambda i: engs[0].forward([clouds[(i * frames + j) % POOL] for j in range(frames)]), steps, warmup)
+            sec = time_steps(lambda i: engs[0].forward(batch_of(i)), steps, warmup)
             return frames / sec, sec
         strs = list(streams[:n_streams]) + [torch.cuda.Stream(device=dev) for _ in range(n_streams - len(streams))]
 
@@ -327,7 +369,7 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
                 torch.cuda.set_device(torch.device(dev))
                 with torch.cuda.stream(strs[w]):
                     for i in range(w, n, n_streams):
-                        engs[w].forward([clouds[(i * frames + j) % POOL] for j in range(frames)])
+                        engs[w].forward(batch_of(i))
                     strs[w].synchronize()
             ts = [threading.Thread(target=worker, args=(w,)) for w in range(n_streams)]
             [t.start() for t in ts]
@@ -341,6 +383,14 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
         sec = (time.perf_counter() - t0) / steps
         return frames / sec, sec
 
+    # the boundary handing over HOST buffers: same step, same two streams, the clouds start in pinned host memory and their H2D
+    # copies (3.2 MB per frame) are inside the timed region. Never the headline value (inputs resident in HBM is the contract).
+    host = [c.cpu().pin_memory() for c in clouds]
+    v, sec = engine_rate(cfg, B, 8, 2, n_streams=max(1, args.streams), host=host)
+    out["value_host_input"] = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 8, "ratio_to_value": v / value,
+                               "h2d_MB_per_step": sum(int(c.numel()) * 4 for c in host[:B]) / 1e6 if B <= POOL else None,
+                               "note": "PCIe-inclusive: clouds in pinned host memory, H2D inside the step (%d stream(s))" % max(1, args.streams)}
+    del host
     if cfg.conv_math != "f32":
         c32 = ModelConfig(conv_math="f32", row_order=cfg.row_order, row_order_chunk=cfg.row_order_chunk)
         v, sec = engine_rate(c32, B, 5, 2)
@@ -363,13 +413,13 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
     return out
 
 
-def train_step_extra(args, cfg, sd, dev, steps=12, warmup=4):
+def train_step_extra(args, cfg, sd, dev, steps=12, warmup=4, clouds=None):
     """Config 3 inside the default run: CenterPointTrainer.step on one frame per step (voxelize, training-mode forward, CenterHead
     targets + loss, backward, all-reduce no-op at N = 1, Adam, weight repack)."""
     from cpd_amd.synthetic import gt_boxes
     from cpd_amd.train_engine import CenterPointTrainer
     seeds = dist_utils.frame_seeds(0, POOL)
-    clouds = [torch.from_numpy(waymo_cloud(s, n_points=args.points)).cuda() for s in seeds]
+    clouds = [torch.from_numpy(c).cuda() for c in make_clouds(seeds, args.points)] if clouds is None else clouds
     gts = [torch.from_numpy(gt_boxes(s)).cuda() for s in seeds]
     tr = CenterPointTrainer(cfg, sd, device=dev, total_steps=steps + warmup, world_size=1)
     last = [None]
@@ -436,15 +486,16 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
     from cpd_amd.synthetic import gt_boxes
     from cpd_amd.train_engine import CenterPointTrainer
     B = args.frames
-    seeds = dist_utils.frame_seeds(rank, POOL)
-    clouds = [torch.from_numpy(waymo_cloud(s, n_points=args.points)).cuda() for s in seeds]
-    gts = [torch.from_numpy(gt_boxes(s)).cuda() for s in seeds]
     total = args.steps + args.warmup
+    seeds = dist_utils.frame_seeds(rank, POOL)[:max(1, min(POOL, (total + 16) * B))]      # no more clouds than the run will touch
+    clouds = [torch.from_numpy(c).cuda() for c in make_clouds(seeds, args.points)]
+    gts = [torch.from_numpy(gt_boxes(s)).cuda() for s in seeds]
+    POOL_T = len(seeds)
     tr = CenterPointTrainer(cfg, sd, device=dev, total_steps=max(total, 2), world_size=world)
     prof = ConvProfiler() if not args.no_roofline else None
 
     def step(i):
-        idx = [(i * B + j) % POOL for j in range(B)]
+        idx = [(i * B + j) % POOL_T for j in range(B)]
         return tr.step([clouds[k] for k in idx], torch.stack([gts[k] for k in idx]))
 
     for i in range(args.warmup):
@@ -456,7 +507,32 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
         loss, _ = step(args.warmup + i)
     torch.cuda.synchronize()
     dist_utils.barrier()
-    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device="cuda" if distributed else "cpu")
+    local_elapsed = time.perf_counter() - t0
+    elapsed = dist_utils.max_over_ranks(local_elapsed, device="cuda" if distributed else "cpu")
+    per_rank = dist_utils.gather_floats(local_elapsed, device="cuda" if distributed else "cpu")
+    comm = None
+    if distributed:
+        # the step's one collective, timed: (a) in place, HIP events around it in three more steps (includes waiting for the slowest
+        # rank's backward); (b) alone, ten back-to-back all-reduces of the same flat buffer (ring / direct bandwidth over xGMI)
+        tr.allreduce_events = []
+        for i in range(3):
+            step(total + 10 + i)
+        torch.cuda.synchronize()
+        in_step = [e0.elapsed_time(e1) for e0, e1 in tr.allreduce_events]
+        tr.allreduce_events = None
+        buf = torch.zeros_like(tr.store.grad)
+        for _ in range(2):
+            torch.distributed.all_reduce(buf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            torch.distributed.all_reduce(buf)
+        torch.cuda.synchronize()
+        alone = (time.perf_counter() - t1) / 10
+        nbytes = buf.numel() * 4
+        comm = {"allreduce_in_step_ms": in_step, "allreduce_alone_ms": 1e3 * alone, "bytes": nbytes,
+                "bus_GBps": 2.0 * (world - 1) / world * nbytes / alone / 1e9,
+                "note": "one all-reduce of the flat fp32 gradient buffer per step, after the whole backward (not overlapped)"}
     out = {
         "metric": "train frames/sec (fwd+bwd+Adam), 160k-pt Waymo cloud", "value": world * B * args.steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -474,6 +550,16 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
                                           "their max |value| (exact; DESIGN.md 5a). Layers below 32 channels: fp32 MFMA."},
                    "final_loss": float(loss)},
     }
+    if world > 1:
+        dd = "cuda" if distributed else "cpu"
+        # data-parallel invariants, checked across ranks: disjoint frame shards, identical parameters after the last step
+        out["per_rank"] = {"elapsed_s": per_rank, "frames_per_s": [args.steps * B / t for t in per_rank],
+                           "first_frame_seed": [int(v) for v in dist_utils.gather_floats(seeds[0], device=dd)],
+                           "param_checksum": dist_utils.gather_floats(float(tr.store.flat.double().abs().sum()), device=dd),
+                           "param_first_words": dist_utils.gather_floats(float(tr.store.flat[:4096].double().sum()), device=dd)}
+        pc = out["per_rank"]["param_checksum"]
+        out["per_rank"]["parameters_identical_across_ranks"] = all(v == pc[0] for v in pc)
+        out["collective"] = comm
     if prof is not None:
         with prof:
             for i in range(2):
@@ -535,7 +621,7 @@ def main():
         S = 1
     engines = [CenterPointEngine(cfg, sd, device=dev, host_results=not args.device_results) for _ in range(S)] if args.api == "engine" else []
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    clouds_np = [waymo_cloud(sd_, n_points=args.points) for sd_ in dist_utils.frame_seeds(rank, POOL)]
+    clouds_np = make_clouds(dist_utils.frame_seeds(rank, POOL), args.points)
     clouds = [torch.from_numpy(c).cuda() for c in clouds_np]
     B = args.frames
     torch.cuda.synchronize()
@@ -551,13 +637,16 @@ def main():
             return engines[w].forward([host_clouds[(i * B + j) % POOL].cuda(non_blocking=True) for j in range(B)])
         return engines[w].forward([clouds[(i * B + j) % POOL] for j in range(B)])
 
-    def run_steps(n, S=S):
+    def run_steps(n, S=S, keep=None):
         """n steps, dealt round-robin to S worker threads; each worker owns a HIP stream, an engine
         workspace and its frames' host-side count reads, so latency-bound phases of one frame
-        (voxelizer, rulebooks, decode, NMS, count syncs) overlap the MFMA phases of the others."""
+        (voxelizer, rulebooks, decode, NMS, count syncs) overlap the MFMA phases of the others.
+        `keep`: dict step index -> that step's results (references only; digested after the timed region)."""
         if S == 1:
             for i in range(n):
-                step(i)
+                r = step(i)
+                if keep is not None:
+                    keep[i] = r
             return
         import threading
 
@@ -565,7 +654,9 @@ def main():
             torch.cuda.set_device(local)
             with torch.cuda.stream(streams[w]):
                 for i in range(w, n, S):
-                    step(i, w)
+                    r = step(i, w)
+                    if keep is not None:
+                        keep[i] = r
                 streams[w].synchronize()
 
         ts = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
@@ -581,11 +672,21 @@ def main():
     run_steps(args.warmup)
     barrier()
     torch.cuda.synchronize()
+    timed_results = {}
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps, keep=timed_results)
     torch.cuda.synchronize()
     barrier()
-    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device="cuda" if distributed else "cpu")
+    local_elapsed = time.perf_counter() - t0
+    elapsed = dist_utils.max_over_ranks(local_elapsed, device="cuda" if distributed else "cpu")
+    per_rank = dist_utils.gather_floats(local_elapsed, device="cuda" if distributed else "cpu")
+    # what the timed steps returned, digested AFTER the clock stopped: per-frame box counts + a hash over every kept box / score /
+    # label of every frame (cpd_amd/digest.py). Step i of any run of this configuration sees the same frames, so the single-stream
+    # pass below must reproduce these digests bit for bit -- the check that two batches in flight on two HIP streams computed what
+    # one stream computes.
+    from cpd_amd.digest import step_digest
+    timed_digests = {i: step_digest(r) for i, r in sorted(timed_results.items())}
+    timed_results.clear()
 
     out = {
         "metric": "frames/sec voxelize->sparse3D->BEV->NMS, 160k-pt Waymo cloud",
@@ -608,25 +709,34 @@ def main():
                    "conv_math": {"bf16x3": "layers with >= 32 input channels: split-bf16 x3 (fp32 operands split exactly into 3 bf16 terms, "
                                            "6 bf16 MFMA products per fp32 multiply-add, fp32-level error); 5/16-channel sparse layers: fp32 MFMA",
                                  "f16x2": "layers with >= 32 input channels: split-fp16 x2 (fp32 operands written as 2 fp16 terms, 3 fp16 MFMA "
-                                          "products per fp32 multiply-add, fp32 accumulation, fp32-level error); 5/16-channel sparse layers: "
-                                          "fp32 MFMA",
+                                          "products per fp32 multiply-add, fp32 accumulation, fp32-level error); the 5-channel input layer: fp32 "
+                                          "MFMA; the 16-channel level-1 layers: " +
+                                          ("the same split-fp16 arithmetic on the K = 16 MFMA (v_mfma_f32_16x16x16_f16, gather_conv_h16_kernel), "
+                                           "reading fp16-pair rows" if (cfg.pair_rows and cfg.pair_rows_level1) else "fp32 MFMA"),
                                  "f32": "fp32 MFMA everywhere"}[cfg.conv_math],
+                   "pair_rows": bool(cfg.pair_rows) and cfg.conv_math == "f16x2", "pair_rows_level1": bool(cfg.pair_rows and cfg.pair_rows_level1) and cfg.conv_math == "f16x2",
+                   "activation_storage": ("between the sparse layers of levels %s: fp16-pair rows (each fp32 activation stored as its two fp16 "
+                                          "terms h + l, 4 bytes per channel, split made once by the producing epilogue); exported levels, the "
+                                          "BEV map and every dense activation: fp32" % ("1-4" if cfg.pair_rows_level1 else "2-4"))
+                   if (cfg.pair_rows and cfg.conv_math == "f16x2") else "fp32 everywhere",
+                   "distinct_clouds_per_rank": POOL,
                    "range_guard": ("f16x2 range guard on: every conv epilogue records max |out|, the verdict rides with the step's count "
                                    "read-back, a step with an activation >= 2^15 is re-run with power-of-two pre-scaling (exact); re-runs "
                                    "in this run: %d" % sum(getattr(e, "range_reruns", 0) for e in engines))
                    if cfg.conv_math == "f16x2" and cfg.range_guard and engines else "n/a"},
     }
 
+    single_results = {}
     if not args.no_roofline and args.api == "engine":
         # Second pass, same configuration (same streams / batch), with every cpd_gather_conv launch
         # bracketed by HIP events on its own launch stream.
         n_prof = min(args.steps, 6)
         with ConvProfiler() as prof:
-            run_steps(POOL // max(1, B) + 1, 1)           # settle the allocator with the profiler's own temporaries in play
+            run_steps(min(POOL // max(1, B) + 1, 4), 1)   # settle the allocator with the profiler's own temporaries in play
             torch.cuda.synchronize()
             prof.records.clear()
             prof.bytes_total = 0.0
-            run_steps(n_prof, 1)                          # ONE stream: every launch owns the chip while it is timed
+            run_steps(n_prof, 1, keep=single_results)     # ONE stream: every launch owns the chip while it is timed
             agg, conv_ms = prof.summary()
             if args.layers and rank == 0:
                 per = len(prof.records) // n_prof
@@ -647,6 +757,7 @@ def main():
                               "loop of nothing but f16 MFMAs on register operands sustains 0.65 (random data) to 0.74 (half zeros) of it under "
                               "the 1400 W socket cap, and this kernel runs at 1.9-2.1 GHz for the same reason (DESIGN.md 4.1)",
             "traffic": pmc_traffic(key),
+            "traffic_source": pmc_stamp(),
             "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 --pmc passes of this "
                             "command, %s; bench.py cannot collect counters itself)" % (os.path.relpath(pmc_summary_file() or "none", REPO)),
             "launches_per_frame": launches / (n_prof * B), "avg_launch_us": 1e3 * ms / launches,
@@ -678,12 +789,37 @@ def main():
         out["hbm_stages"]["note"] = ("algorithmic bytes (SURVEY 8d) / HIP-event time of each call (one call = all its launches), "
                                      "single stream; peak = 8 TB/s nominal HBM3E")
 
+    # results_digest: the timed steps (S batches in flight) against the same steps on ONE stream
+    if not single_results and not args.no_digest_check:
+        run_steps(min(2, args.steps), 1, keep=single_results)
+        torch.cuda.synchronize()
+    single_digests = {i: step_digest(r) for i, r in sorted(single_results.items())}
+    single_results.clear()
+    common = sorted(set(single_digests) & set(timed_digests))
+    mismatch = [i for i in common if single_digests[i] != timed_digests[i]]
+    d0 = timed_digests[min(timed_digests)] if timed_digests else ([], [], None)
+    out["results_digest"] = {
+        "timed_steps": [timed_digests[i][2] for i in sorted(timed_digests)],
+        "boxes_per_frame_step0": d0[0], "boxes_step0": sum(d0[0]),
+        "single_stream_steps": [single_digests[i][2] for i in sorted(single_digests)],
+        "steps_compared": len(common), "equal_to_single_stream_pass": (not mismatch) if common else None,
+        "all_timed_steps_equal": (len({timed_digests[i][2] for i in timed_digests}) == 1) if (timed_digests and POOL % B == 0 and B == POOL) else None,
+        "note": "per step: BLAKE2 over every frame's kept boxes / scores / labels (cpd_amd/digest.py). The timed region ran %d batch(es) "
+                "in flight on %d HIP stream(s) / worker thread(s); the single-stream pass re-ran the same steps on one stream after "
+                "the clock stopped. Equal digests = bit-identical detections." % (S, S)}
+    if mismatch and not args.no_digest_check:
+        print(json.dumps(out["results_digest"]), file=sys.stderr)
+        raise SystemExit("bench.py: results of timed step(s) %s differ from the single-stream pass (results_digest)" % mismatch)
+    if world > 1:
+        out["per_rank"] = {"elapsed_s": per_rank, "frames_per_s": [args.steps * B / t for t in per_rank],
+                           "note": "each rank's own clock around its %d timed steps (value uses the slowest)" % args.steps}
+
     if world == 1 and not args.no_extras and args.api == "engine" and not args.host_input:
         engines.clear()
         torch.cuda.empty_cache()
         out.update(extras(args, cfg, sd, dev, clouds, out["value"], streams))
         torch.cuda.empty_cache()
-        out["train_step"] = train_step_extra(args, cfg, sd, dev)
+        out["train_step"] = train_step_extra(args, cfg, sd, dev, clouds=clouds)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, clouds_np)

@@ -65,6 +65,16 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_floats(value, device="cpu"):
+    """every rank's `value`, in rank order, on every rank ([value] without a process group)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def aggregate_throughput(units_per_rank, elapsed_local, device="cpu"):
     """Whole-job units/s: all ranks' units over the slowest rank's time."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1

@@ -322,7 +322,10 @@ class CenterPointEngine:
         self._rb_next = 0
         if self.cfg.conv_math == "f16x2" and self.cfg.range_guard:
             if getattr(self, "_rb_pool", None) is None:
-                self._rb_pool = ops.absmax_blocks(96, self.device)
+                # one block per conv launch of a step: 20 sparse layers + conv_out, the BEV levels' convs, the concat buffer,
+                # shared conv + the two head launches (+ slack for callers that run the stages on their own)
+                n = 21 + sum(k + 1 for k in self.cfg.bev_layer_nums) + 1 + 3 + 16
+                self._rb_pool = ops.absmax_blocks(n, self.device)
             else:
                 self._rb_pool.zero_()
         else:
@@ -331,15 +334,24 @@ class CenterPointEngine:
     def _range_new(self):
         if self._rb_pool is None:
             return None
+        if self._rb_next >= self._rb_pool.shape[0]:
+            raise RuntimeError("range guard: this model launches more convolutions per step than the %d absmax blocks the engine "
+                               "sized from its config (engine._range_reset)" % self._rb_pool.shape[0])
         b = self._rb_pool[self._rb_next]
         self._rb_next += 1
         return b
 
+    RANGE_STICKY_STEPS = 16       # guarded steps that follow a re-run before the engine tries the unguarded kernels again
+
     def _range_exceeded_flag(self):
-        """device int32 [1]: 1 when some recorded activation is >= 2^15 (or NaN / inf); None when nothing is recorded"""
-        if self._rb_pool is None or getattr(self, "_rb_scaled", False):
+        """device int32 [1] riding with the step's count read-back; None when nothing is recorded. Optimistic step: 1 when some
+        recorded activation is >= 2^15 (or NaN / inf) -> the step is re-run guarded. Guarded step: 1 while some activation is
+        still >= 2^14 -> the engine stays guarded (hysteresis: it returns to the unguarded kernels only after
+        RANGE_STICKY_STEPS consecutive steps well inside fp16's range)."""
+        if self._rb_pool is None:
             return None
-        return (self._rb_pool.max() >= 0x47000000).to(torch.int32).view(1)        # bits of 32768.0f; NaN / inf bits are larger
+        thr = 0x46800000 if getattr(self, "_rb_scaled", False) else 0x47000000   # bits of 16384.0f / 32768.0f; NaN / inf bits are larger
+        return (self._rb_pool.max() >= thr).to(torch.int32).view(1)
 
     def _conv(self, layer, x, nbr, n_out, residual=None, out=None, out_row_map=None, out_col_group=0, dense=False, out_rb="new",
               in_pairs=False, out_pairs=False, res_pairs=False):
@@ -493,7 +505,11 @@ class CenterPointEngine:
         ob, os_, ol, on = ops.select_boxes(boxes, scores, labels, keep, num_keep, cfg.nms_post_maxsize, label_offset=1)
         flag = self._range_exceeded_flag()        # the range guard's verdict travels with the counts: no extra synchronisation
         ns = (torch.cat([on, flag]) if flag is not None else on).tolist()      # the one host read-back of the stage
-        self._range_exceeded = bool(ns[batch]) if flag is not None else False
+        high = bool(ns[batch]) if flag is not None else False
+        if getattr(self, "_rb_scaled", False):
+            self._range_exceeded, self._range_high = False, high     # guarded already: exact whatever the range; `high` keeps it guarded
+        else:
+            self._range_exceeded = high
         ns = ns[:batch]
         if self._range_exceeded:
             return None                           # forward() runs the step again, guarded
@@ -557,8 +573,14 @@ class CenterPointEngine:
             ms = torch.cat([o[4] for o in outs]).tolist() if batch > 1 else [int(outs[0][4].item())]   # one read-back
             feats = torch.cat([o[3][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][3][:ms[0]]
             coords = torch.cat([o[1][:m] for o, m in zip(outs, ms)]) if batch > 1 else outs[0][1][:ms[0]]
-        self._rb_scaled = False
+        # A step whose activations left fp16's safe range is re-run guarded (exact), and the engine then STAYS guarded for the next
+        # RANGE_STICKY_STEPS steps (each of which extends the stay while its activations are still >= 2^14): a checkpoint or scene
+        # that habitually exceeds the range pays the guarded kernels' ~3 % instead of a second pass per step.
         self.range_reruns = getattr(self, "range_reruns", 0)
+        self.range_guarded_steps = getattr(self, "range_guarded_steps", 0)
+        self._guard_left = getattr(self, "_guard_left", 0)
+        self._rb_scaled = self._guard_left > 0
+        self._range_high = False
         while True:
             levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0, export_levels=return_intermediates,
                                                               pair_rows=self.cfg.pair_rows and not self._rb_scaled)
@@ -569,8 +591,16 @@ class CenterPointEngine:
             if results is not None:
                 break
             # an activation left fp16's safe range: the same step with every layer pre-scaling its input (exact), see _range_reset
+            if self.range_reruns == 0:
+                import warnings
+                warnings.warn("cpd_amd: an activation reached 2^15 -- step re-run with the range-guarded f16x2 kernels; the engine "
+                              "stays guarded for the next %d steps" % self.RANGE_STICKY_STEPS)
             self._rb_scaled = True
             self.range_reruns += 1
+            self._guard_left = self.RANGE_STICKY_STEPS + 1
+        if self._rb_scaled:
+            self.range_guarded_steps += 1
+            self._guard_left = self.RANGE_STICKY_STEPS if self._range_high else self._guard_left - 1
         self._rb_scaled = False
         if return_intermediates:
             return results, dict(voxel_features=feats, voxel_coords=coords, levels=levels,

@@ -197,7 +197,7 @@ class HeightCompression(nn.Module):
         if _fusable_eval(self) and sp.features.is_cuda:
             # same (N, C*D, H, W) tensor, channel = c*D + z, in channels_last memory: the BEV convs read it without a transpose pass
             rows = ops.densify_nhwc_cd(sp.features.float(), sp.indices, sp.batch_size, sp.spatial_shape)
-            batch_dict["spatial_features"] = _tag(rows.permute(0, 3, 1, 2), getattr(sp.features, "_cpd_rb", None))
+            batch_dict["spatial_features"] = _tag(rows.permute(0, 3, 1, 2), ops.tagged_range(sp.features))
             batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]
             return batch_dict
         dense = sp.dense()
@@ -224,16 +224,14 @@ def _range_in_out(x, c_in, math, out_rb=None):
         return None, None
     rb_in = None
     if c_in % 32 == 0:
-        rb_in = getattr(x, "_cpd_rb", None)
+        rb_in = ops.tagged_range(x)
         if rb_in is None:
             rb_in = ops.absmax_rows(_rows(x.float()), c_in)
     return rb_in, (out_rb if out_rb is not None else ops.absmax_blocks(1, x.device)[0])
 
 
 def _tag(t, rb):
-    if rb is not None:
-        t._cpd_rb = rb
-    return t
+    return ops.tag_range(t, rb)
 
 
 class Conv2d(nn.Conv2d):
@@ -269,8 +267,7 @@ class Conv2d(nn.Conv2d):
         b, c, h, w = x.shape
         k = self.kernel_size[0]
         _, (nbr, ho, wo) = self._table(b, h, w, self.padding[0] + extra_pad, x.device)
-        if shift is None and self.bias is not None:
-            shift = self.bias.detach().float()
+        shift = ops.epilogue_shift(scale, shift, self.bias)
         rb_in, rb_out = _range_in_out(x, c, self.math, out_rb)
         rows = ops.gather_conv(_rows(x.float()), c, self._packed(), nbr, k * k, b * ho * wo, self.out_channels, scale, shift, None, relu,
                                out=out, dense=True, math=self.math, in_absmax=rb_in, out_absmax=rb_out)
@@ -330,8 +327,7 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         u = self.kernel_size[0]
         assert self.stride[0] == u and self.padding[0] == 0
         H, W, co = h * u, w * u, self.out_channels
-        if shift is None and self.bias is not None:
-            shift = self.bias.detach().float()
+        shift = ops.epilogue_shift(scale, shift, self.bias)
         if out is None:
             out = torch.empty((b * H * W, co), dtype=torch.float32, device=x.device)
         rep = (lambda t: t.repeat(u * u) if t is not None and u > 1 else t)
@@ -372,7 +368,11 @@ class DenseSequential(nn.Sequential):
     def forward(self, x, out=None, out_rb=None):
         mods = list(self)
         if not _fusable_eval(*mods):
-            return super().forward(x)
+            y = super().forward(x)
+            if out is not None:                       # the caller's buffer is written on EVERY path
+                out[:, :y.shape[1]].copy_(_rows(y.float()))
+            return y
+        wrote = False
         i, pad = 0, 0
         while i < len(mods):
             m = mods[i]
@@ -391,9 +391,12 @@ class DenseSequential(nn.Sequential):
                         i += 1
                 last = i == len(mods)
                 x = m.forward_fused(x, scale, shift, relu, extra_pad=pad, out=out if last else None, out_rb=out_rb if last else None)
+                wrote = wrote or last
                 pad = 0
                 continue
             x = m(x)
+        if out is not None and not wrote:             # the sequence did not end in a fused conv: copy what it produced
+            out[:, :x.shape[1]].copy_(_rows(x.float()))
         return x
 
 

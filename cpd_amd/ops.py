@@ -358,9 +358,35 @@ def absmax_rows(x, c=None, block=None):
     return block
 
 
+def tag_range(t, block):
+    """Attach the absmax block a kernel filled for tensor `t` (attribute `_cpd_rb`) together with the tensor's version counter: an
+    in-place operation on `t` (or on a view sharing its storage) afterwards bumps the counter and retires the tag."""
+    if block is not None:
+        t._cpd_rb = (block, t._version)
+    return t
+
+
+def tagged_range(t):
+    """the block attached by tag_range, or None when there is none or `t` was written in place since (stale maximum: ADVICE r3)"""
+    tag = getattr(t, "_cpd_rb", None)
+    if tag is None:
+        return None
+    block, ver = tag
+    return block if ver == t._version else None
+
+
+def epilogue_shift(scale, shift, bias):
+    """The conv epilogue computes acc * scale + shift. A caller that gives no shift but whose conv has a bias means
+    (acc + bias) * scale: shift = bias * scale (bias alone when there is no scale)."""
+    if shift is not None or bias is None:
+        return shift
+    b = bias.detach().float()
+    return b * scale if scale is not None else b
+
+
 def range_block(t, c=None):
-    """The absmax block travelling with tensor `t` as attribute `_cpd_rb` (set by the layer that produced it), else measured now."""
-    b = getattr(t, "_cpd_rb", None)
+    """The absmax block travelling with tensor `t` (tag_range, set by the layer that produced it) when still valid, else measured now."""
+    b = tagged_range(t)
     if b is not None:
         return b
     t2 = t if t.dim() == 2 else t.reshape(-1, t.shape[-1])

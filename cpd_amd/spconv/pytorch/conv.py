@@ -55,8 +55,19 @@ def fold_batchnorm(bn, conv_bias=None):
 
 
 def fusable_eval(*mods):
-    """The fused eval path applies when nothing is being trained: every module in eval mode and no autograd graph wanted."""
-    return not torch.is_grad_enabled() and all(not m.training for m in mods)
+    """The fused eval path applies when nothing is being trained: no autograd graph wanted and every module OF THE WHOLE TREE under
+    each of `mods` in eval mode, every BatchNorm among them with running statistics to fold. (A container in eval() whose BatchNorm
+    was switched back to .train(), or a BatchNorm built with track_running_stats=False, normalises with batch statistics: the
+    fused launch would silently use running ones -- such a tree takes the plain module-by-module path. ADVICE r3.)"""
+    if torch.is_grad_enabled():
+        return False
+    for m in mods:
+        for s in m.modules():
+            if s.training:
+                return False
+            if isinstance(s, nn.modules.batchnorm._BatchNorm) and (not s.track_running_stats or s.running_mean is None):
+                return False
+    return True
 
 
 class SparseConvolution(SparseModule):
@@ -141,16 +152,15 @@ class SparseConvolution(SparseModule):
                                      mode="same" if self.subm else "strided", adjoint=adjoint, packed=self._packed_weight())
         if scale is not None or shift is not None or residual is not None or relu:
             assert not torch.is_grad_enabled(), "the fused epilogue is an inference path"
-            if shift is None and self.bias is not None:
-                shift = self.bias.detach().float()
-            # f16x2: the range block travels with the feature tensor (attribute _cpd_rb); a tensor without one is measured first
+            shift = ops.epilogue_shift(scale, shift, self.bias)
+            # f16x2: the range block travels with the feature tensor (ops.tag_range); a tensor without one -- or modified in place
+            # since it was tagged -- is measured first
             guard = self.conv_math == "f16x2"
             rb_in = ops.range_block(x.features, self.in_channels) if guard and self.in_channels % 32 == 0 else None
             rb_out = ops.absmax_blocks(1, feats.device)[0] if guard else None
             out_feats = ops.gather_conv(feats, self.in_channels, spec.packed, nbr, kv, spec.n_out, self.out_channels, scale, shift,
                                         residual, relu, dense=False, math=self.conv_math, in_absmax=rb_in, out_absmax=rb_out)
-            if rb_out is not None:
-                out_feats._cpd_rb = rb_out
+            ops.tag_range(out_feats, rb_out)
         else:
             w_kio = self.weight.reshape(self.out_channels, kv, self.in_channels).permute(1, 2, 0)
             out_feats = autograd_ops.gather_conv(feats, w_kio, self.bias, spec)

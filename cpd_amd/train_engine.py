@@ -590,7 +590,14 @@ class CenterPointTrainer:
 
     def optimizer_step(self):
         st = self.store
+        ev = getattr(self, "allreduce_events", None)         # bench.py --mode train: HIP events around the collective
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         scale = dist_utils.reduce_gradients(st.grad, self.world, self.pg)   # the one collective (no-op without a process group)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         clip = None
         if self.grad_clip:                                           # clip_grad_norm_, train_utils.py:43 -- factor stays on the device
             norm = st.grad.norm() * scale

@@ -547,3 +547,59 @@ def test_batch_of_65_frames_does_not_leave_a_group_of_one(hip):
         assert res[i]["pred_boxes"].shape == one["pred_boxes"].shape
         np.testing.assert_array_equal(res[i]["pred_labels"].cpu().numpy(), one["pred_labels"].cpu().numpy())
         np.testing.assert_allclose(res[i]["pred_scores"].cpu().numpy(), one["pred_scores"].cpu().numpy(), atol=2e-5)
+
+
+def test_range_guard_stays_guarded_after_a_rerun(hip):
+    """a model that habitually exceeds fp16's range must not pay a second pass on every step: after ONE re-run the engine
+    stays on the guarded kernels (RANGE_STICKY_STEPS, extended while activations stay >= 2^14) -- same results, no more re-runs --
+    and a model inside the range never enters the guarded mode."""
+    cfg = small_cfg()
+    sd = init_state_dict(cfg, seed=9)
+    hot = dict(sd)
+    hot["backbone_3d.conv_input.1.weight"] = sd["backbone_3d.conv_input.1.weight"] * 3e4
+    hot["backbone_3d.conv_input.1.bias"] = sd["backbone_3d.conv_input.1.bias"] * 3e4
+    clouds = []
+    for s_ in (4, 5):
+        p = waymo_cloud(s_, n_points=40000)
+        p[:, :2] *= 0.3
+        clouds.append(torch.from_numpy(p).cuda())
+    eng = CenterPointEngine(cfg, hot)
+    with pytest.warns(UserWarning, match="range-guarded"):
+        _, first = eng.forward(clouds, return_intermediates=True)
+    assert (eng.range_reruns, eng.range_guarded_steps) == (1, 1)
+    for k in range(3):
+        _, again = eng.forward(clouds, return_intermediates=True)
+        assert (eng.range_reruns, eng.range_guarded_steps) == (1, 2 + k)        # guarded from the start: no second pass
+        assert torch.equal(again["head_rows"][:, :11], first["head_rows"][:, :11])
+    assert eng._guard_left == eng.RANGE_STICKY_STEPS                            # still hot: the stay is extended every step
+    cool = CenterPointEngine(cfg, sd)
+    cool.forward(clouds)
+    assert (cool.range_reruns, cool.range_guarded_steps, cool._guard_left) == (0, 0, 0)
+
+
+def test_eval_container_with_a_training_batchnorm_takes_the_plain_path(hip):
+    """BaseBEVBackbone in eval() with one deblock's BatchNorm switched back to .train() used to write nothing
+    into its concat buffer for that deblock (uninitialised memory in st_features_2d). The fused path now requires the whole tree
+    in eval mode; the result equals the module-by-module forward (batch statistics in that BatchNorm)."""
+    from cpd_amd import models
+    torch.manual_seed(0)
+    mcfg = models.waymo_centerpoint_cfg().BACKBONE_2D
+    mcfg.NUM_FILTERS, mcfg.NUM_UPSAMPLE_FILTERS, mcfg.LAYER_NUMS = [32, 64], [64, 64], [1, 1]
+    net = models.BaseBEVBackbone(mcfg, input_channels=64).cuda().eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.75, 1.25)
+    x = torch.randn(2, 64, 24, 24, device="cuda")
+    with torch.no_grad():
+        fused = net({"spatial_features": x})["st_features_2d"].clone()
+    net.deblocks[1][1].train()                               # container stays in eval; this BatchNorm now uses batch statistics
+    snap = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        got = net({"spatial_features": x})["st_features_2d"].clone()
+    net.load_state_dict(snap)                                # (the training BatchNorm updated its running statistics)
+    want = net({"spatial_features": x})["st_features_2d"].detach()      # autograd on: every module runs as the plain reference module
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, want, atol=2e-4, rtol=1e-4)
+    assert float((got[:, 64:] - fused[:, 64:]).abs().max()) > 1e-3     # and it differs from the running-statistics answer
+    torch.testing.assert_close(got[:, :64], fused[:, :64], atol=2e-4, rtol=1e-4)

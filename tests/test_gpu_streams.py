@@ -1,0 +1,89 @@
+"""The BENCHMARKED execution mode against the single-stream one and the oracle.
+
+bench.py's headline runs two CenterPointEngines on two HIP streams in two Python threads, 48 distinct frames per step. Every other
+parity test runs one engine on one stream. Here: the same two 48-frame batches (a) one after the other on one stream, (b) in
+flight together, three rounds, each engine on its own stream and thread -- every frame of every round must come back bit-identical
+(boxes, scores, labels) to (a); and one frame of the batch is checked against the CPU oracle's un-fused reference graph, so that the
+thing both modes agree on is the reference's answer. A race in shared state (the pixel-table cache, the launch log, allocator reuse
+across streams, a workspace shared between engines) would show up as a digest mismatch."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from cpd_amd.digest import frame_digest, step_digest
+from cpd_amd.engine import CenterPointEngine, ModelConfig, init_state_dict
+from cpd_amd.synthetic import waymo_cloud
+
+import ref_pipeline
+
+pytestmark = pytest.mark.gpu
+
+FRAMES = 48
+
+
+def _clouds(n):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        return list(ex.map(waymo_cloud, range(n)))
+
+
+def test_two_engines_two_streams_48_frames_equal_single_stream_and_oracle(oracle, hip):
+    cfg = ModelConfig()
+    sd = init_state_dict(cfg, seed=0)
+    host = _clouds(FRAMES)
+    dev = [torch.from_numpy(c).cuda() for c in host]
+    batch_a = dev                                            # frame k of batch A = cloud k
+    batch_b = dev[FRAMES // 2:] + dev[:FRAMES // 2]          # batch B = the same clouds rotated by half: other row offsets everywhere
+
+    # (a) one engine, the default stream, one batch after the other
+    single = CenterPointEngine(cfg, sd, host_results=True)
+    ref_a = single.forward(batch_a)
+    ref_b = single.forward(batch_b)
+    da, db = step_digest(ref_a), step_digest(ref_b)
+    assert sum(da[0]) > 0, "no detections at all: the comparison would be vacuous"
+    # the same cloud gives the same detections wherever it sits in the batch (summation order per output row does not depend on
+    # the row's position; asserted bitwise because the bench's digest relies on it)
+    for k in range(FRAMES):
+        assert da[1][k] == db[1][(k + FRAMES // 2) % FRAMES], "frame %d depends on its position in the batch" % k
+
+    # (b) two engines, two HIP streams, two threads, three rounds in flight together
+    engines = [CenterPointEngine(cfg, sd, host_results=True) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    got = [[], []]
+    errors = []
+
+    def worker(w):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(streams[w]):
+                for _ in range(3):
+                    got[w].append(engines[w].forward(batch_a if w == 0 else batch_b))
+                streams[w].synchronize()
+        except Exception as e:                               # surfaced below: a thread's exception is otherwise lost
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for w, want in ((0, da), (1, db)):
+        for rnd, res in enumerate(got[w]):
+            d = step_digest(res)
+            assert d[0] == want[0], "worker %d round %d: box counts differ from the single-stream run" % (w, rnd)
+            bad = [k for k in range(FRAMES) if d[1][k] != want[1][k]]
+            assert not bad, "worker %d round %d: frames %s differ bitwise from the single-stream run" % (w, rnd, bad)
+
+    # (c) one of those frames against the oracle (the un-fused reference graph on the CPU), as test_full_size_config2_matches_oracle does
+    fi = 5
+    ref, _ = ref_pipeline.forward(oracle, cfg, sd, [host[fi]])
+    g, want = got[0][2][fi], ref[0]
+    a, b = g["pred_boxes"].numpy(), want["pred_boxes"]
+    assert a.shape == b.shape
+    np.testing.assert_allclose(g["pred_scores"].numpy(), want["pred_scores"], atol=1e-5)
+    j = np.abs(a[:, None, :] - b[None, :, :]).max(-1).argmin(1)          # boxes whose scores tie to ~1e-6 may swap ranks
+    assert sorted(j.tolist()) == list(range(len(b)))
+    np.testing.assert_allclose(a, b[j], atol=1e-3, rtol=1e-4)
+    np.testing.assert_array_equal(g["pred_labels"].numpy(), want["pred_labels"][j])
+    assert frame_digest(g) == da[1][fi]

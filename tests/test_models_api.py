@@ -91,3 +91,43 @@ def test_mm_branch_layers_follow_the_reference_names():
     assert tuple(bb.state_dict()["conv4_2.0.0.weight"].shape) == (128, 3, 3, 3, 64)
     plain = models.VoxelResBackBone8x(models.waymo_centerpoint_cfg().BACKBONE_3D, input_channels=5, grid_size=[1504, 1504, 40])
     assert not any("_2." in k for k in plain.state_dict())
+
+
+def test_fused_eval_needs_the_whole_tree_in_eval_mode():
+    """a container in eval() whose BatchNorm was switched back to .train() (or has no running statistics) must not take
+    the fused path -- it would fold running statistics the module is not using."""
+    from cpd_amd.spconv.pytorch.conv import fusable_eval
+    seq = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1), torch.nn.BatchNorm2d(4), torch.nn.ReLU()).eval()
+    with torch.no_grad():
+        assert fusable_eval(seq)
+        seq[1].train()
+        assert not seq.training and not fusable_eval(seq)          # container still in eval, its BatchNorm is not
+        seq[1].eval()
+        assert fusable_eval(seq)
+        nostats = torch.nn.Sequential(torch.nn.BatchNorm2d(4, track_running_stats=False)).eval()
+        assert not fusable_eval(nostats)
+    assert not fusable_eval(seq)                                   # autograd on: never fused
+
+
+def test_range_tag_is_retired_by_an_in_place_write():
+    """the f16x2 range block rides on the tensor as an attribute; an in-place op afterwards makes it stale."""
+    from cpd_amd import ops
+    t = torch.ones(8, 32)
+    blk = torch.zeros(ops.ABSMAX_WORDS, dtype=torch.int32)
+    ops.tag_range(t, blk)
+    assert ops.tagged_range(t) is blk
+    v = t.view(4, 64)                       # a view shares the version counter
+    v.mul_(1e6)
+    assert ops.tagged_range(t) is None      # stale: the consumer measures the tensor again
+    assert ops.tagged_range(torch.ones(2, 2)) is None
+
+
+def test_epilogue_shift_with_scale_but_no_shift_keeps_the_bias_inside_the_scale():
+    """acc * scale + shift with shift omitted must mean (acc + bias) * scale."""
+    from cpd_amd import ops
+    bias, scale = torch.tensor([1.0, -2.0]), torch.tensor([3.0, 0.5])
+    assert torch.equal(ops.epilogue_shift(scale, None, bias), bias * scale)
+    assert torch.equal(ops.epilogue_shift(None, None, bias), bias)
+    given = torch.tensor([7.0, 7.0])
+    assert ops.epilogue_shift(scale, given, bias) is given
+    assert ops.epilogue_shift(scale, None, None) is None

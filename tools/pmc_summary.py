@@ -39,7 +39,18 @@ for k, c in sorted(vals.items()):
     if "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
         e["mfma_busy_frac_of_simd_cycles"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (avg["GRBM_GUI_ACTIVE"] / 8.0), 3)
     res[k] = e
-json.dump({"source": "rocprofv3 --pmc passes of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline` "
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    src_hash = bench.kernel_source_hash()
+except Exception:
+    src_hash = None
+json.dump({"git_sha": os.environ.get("CPD_GIT_SHA"), "kernel_source_hash": src_hash,
+           "stamp_note": "git_sha = HEAD of the tree the passes ran on (CPD_GIT_SHA, set by the gpurun command line: the GPU box has no "
+                         ".git); kernel_source_hash = bench.kernel_source_hash() over cpd_amd/csrc/*.hip|*.h of that tree -- bench.py "
+                         "prints both next to roofline.traffic and says whether its own kernel sources hash the same",
+           "source": "rocprofv3 --pmc passes of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline` "
                      "(FETCH_SIZE, WRITE_SIZE and SQ_VALU_MFMA_BUSY_CYCLES/GRBM_GUI_ACTIVE in three separate passes, "
                      "--kernel-trace only; tools/pmc_bench.sh). FETCH_SIZE is doubled (gfx950 reports 1/2 of wide coalesced "
                      "reads, MI355X_MICROARCH.md); WRITE_SIZE is uncalibrated. mfma busy = SQ_VALU_MFMA_BUSY_CYCLES / "
