@@ -95,7 +95,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements the default N = 1 run appends to its line "
                     "(fp32-MFMA value, batch-4 and 1-frame figures, the config-3 train step)")
     ap.add_argument("--layers", action="store_true", help="print a per-launch table of the conv kernels (stderr)")
-    ap.add_argument("--row-order", choices=["taps", "canonical"], default="taps",
+    ap.add_argument("--row-order", choices=["bricks", "taps", "canonical"], default="bricks",
                     help="internal row order of the strided sparse levels (ModelConfig.row_order)")
     ap.add_argument("--row-order-chunk", type=int, default=4096)
     ap.add_argument("--pair-rows", type=int, choices=[0, 1, 2], default=2, help="fp16-pair rows between the f16x2 sparse layers "
@@ -704,8 +704,10 @@ def main():
                    "frames_per_step_per_gpu": B, "streams_per_gpu": S, "voxel_size": cfg.voxel_size, "sparse_shape": cfg.sparse_shape,
                    "parallelism": "frame-sharded replicas x%d, no data-path collective" % world,
                    "weights": "random-init (seed 0), eval-mode BN folded",
-                   "sparse_row_order": ("strided levels in tap-pattern order (chunks of %d canonical rows sorted by neighbour pattern)" % cfg.row_order_chunk
-                                        if cfg.row_order == "taps" else "canonical (b, z, y, x)"),
+                   "sparse_row_order": {"taps": "strided levels in tap-pattern order (chunks of %d canonical rows sorted by neighbour pattern)" % cfg.row_order_chunk,
+                                        "bricks": "strided levels in %d x %d (y, x) brick order per z-plane, 128-row tiles sorted by neighbour pattern; their "
+                                                  "sub-manifold rulebooks carry a row plan (staged row-wave kernel)" % tuple(cfg.row_order_brick),
+                                        "canonical": "canonical (b, z, y, x)"}[cfg.row_order],
                    "conv_math": {"bf16x3": "layers with >= 32 input channels: split-bf16 x3 (fp32 operands split exactly into 3 bf16 terms, "
                                            "6 bf16 MFMA products per fp32 multiply-add, fp32-level error); 5/16-channel sparse layers: fp32 MFMA",
                                  "f16x2": "layers with >= 32 input channels: split-fp16 x2 (fp32 operands written as 2 fp16 terms, 3 fp16 MFMA "

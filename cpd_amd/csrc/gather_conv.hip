@@ -73,6 +73,11 @@ struct GcParams {
     // writes its RAW accumulators to part[z][n_out][c_out]; split_finish_kernel sums the parts in order and runs the epilogue
     int split;
     float *part;
+    // row plan of a sub-manifold rulebook (cpd_rulebook_plan; the staged row-wave kernel): per 128-row tile and dz group of 9 taps
+    // the sorted list of DISTINCT input rows the group touches and, per (tap, row), the 16-bit position in that list
+    const uint16_t *plan_slots;   // [tiles][27][128], 0xffff = no neighbour
+    const int32_t *plan_ulist;    // [tiles][3][CPD_PLAN_LIST]
+    const int32_t *plan_count;    // [tiles][4]: list lengths of the three groups
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -1452,6 +1457,164 @@ rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcPar
     rowwave_conv_split_body<SplitF16x2, BN, MS, false, true, CPD_RW_WB>(p, sb, sidx);
 }
 
+
+// ================================ staged row-wave kernel (round 4) ================================
+// The row-wave kernels above gather every (row, tap) pair's 128-byte channel block through the vector L1: ~13 gathers per row and
+// channel block on the sub-manifold levels, of which (profiles/r03_rowwave_pmc.json) the texture-data return path is 0.96 / 0.92 /
+// 0.78 busy -- the kernels run at the L1's gather rate (tools/gather_probe.hip: ~20 B/clk/CU for this shape), neither roof near.
+// But a tile of 128 output rows touches few DISTINCT input rows when its rows are neighbours in space: 2.9 per output row in 8 x 8
+// (y, x) brick order against 13.5 pairs (tools/unique_probe2.py). This kernel stages those distinct rows ONCE in LDS -- per dz group
+// of nine taps: the three z-planes of a 3 x 3 x 3 stencil share no input row, and one plane's list (<= 205 rows on the Waymo-shape
+// levels) fits a 224-row window -- as whole 128-byte lines (8 lanes per row: the cheapest gather shape), and forms the MFMA
+// fragments of all nine taps with ds_read_b128 at 256 B/clk/CU: a (row, tap) pair costs an LDS read instead of an L1 gather.
+// What it needs beyond the rulebook: the ROW PLAN (cpd_rulebook_plan: per tile and group the sorted list of distinct input rows,
+// per (tap, row) the position in it). Weights go through LDS per (tap, 32-channel block) exactly as above; tap masks skip
+// (16-row sub-tile, tap) pairs without a neighbour as above. A group whose list is longer than the window (never on the measured
+// levels; possible in principle up to 9 x 128) is walked in several window passes: rows outside the pass read the window's zero row.
+// Input: fp16-pair rows (CPD_GC_IN_PAIRS), c_in % 32 == 0; one column tile (BN = c_out = 32 / 64 / 128); kv = 27.
+#define CPD_PLAN_LIST 1152           // list stride per (tile, group): 9 taps x 128 rows can never give more distinct rows
+#define CPD_RP_WIN 224               // window slots; slot CPD_RP_WIN is the zero row
+#define CPD_RP_P16 225               // plane stride in 16-byte slots: odd, so that the 8 lanes that stage one row (8 planes, same slot) write 8 different
+                                     // bank groups; == 1 (mod 16), so that a fragment read of consecutive slots has one 2-way conflict in 16 lanes
+template <int BN>
+__device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const sb0, char *const swin, uint16_t *const sslot) {
+    typedef SplitF16x2 S;
+    constexpr int NP = 2, NT = BN / 16, MS = 2;
+    constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one stage
+    constexpr int BJ = (B_SLOTS + 255) / 256;
+    constexpr int B_IMG = BN * 64;
+    constexpr int PLANE = CPD_RP_P16 * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = tile * 128 + wave * 32;
+
+    uint32_t wg_mask = (1u << 27) - 1u, my_mask[MS] = {wg_mask, wg_mask};
+    if (p.tapmask) {
+        wg_mask = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sub = tile * 8 + i;
+            const uint32_t m = sub < p.n_sub ? p.tapmask[sub] : 0u;
+            wg_mask |= m;
+#pragma unroll
+            for (int s = 0; s < MS; ++s)
+                if (i == MS * wave + s) my_mask[s] = m;
+        }
+#pragma unroll
+        for (int s = 0; s < MS; ++s) my_mask[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_mask[s]);
+        wg_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_mask);
+    }
+
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the zero row of the window (slot CPD_RP_WIN of every plane): written once, never overwritten
+    if (tid < 8) *reinterpret_cast<f32x4u *>(swin + tid * PLANE + CPD_RP_WIN * 16) = f32x4u{0.f, 0.f, 0.f, 0.f};
+
+    const int sk = p.c_in >> 5;
+    const uint32_t b_stage32 = (uint32_t)((size_t)NP * 4 * p.np * 16);
+    const char *const in_bytes = reinterpret_cast<const char *>(p.in);
+    const size_t row_bytes = (size_t)p.in_ld * 4u;
+    f32x4u rbv[BJ];
+    auto load_weights = [&](int t, int kk) {
+        const char *wt = reinterpret_cast<const char *>(p.wb) + (uint32_t)(t * sk + kk) * b_stage32;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int id = j * 256 + tid;
+            const int pg = id / BN, n = id - pg * BN;
+            if (B_SLOTS % 256 == 0 || id < B_SLOTS) rbv[j] = *reinterpret_cast<const f32x4u *>(wt + (uint32_t)(pg * p.np + n) * 16u);
+        }
+    };
+    auto commit_weights = [&](int slot) {
+        char *const sb = sb0 + slot * (NP * B_IMG);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+    };
+
+    for (int grp = 0; grp < 3; ++grp) {
+        const uint32_t gmask = (wg_mask >> (9 * grp)) & 0x1ffu;            // this group's taps some sub-tile of the workgroup has
+        if (!gmask) continue;
+        const int n_list = p.plan_count[tile * 4 + grp];
+        const int32_t *const ulist = p.plan_ulist + ((size_t)tile * 3 + grp) * CPD_PLAN_LIST;
+        __syncthreads();                                                   // the previous group's taps are done with sslot
+        if (tid < 144)                                                     // 9 taps x 128 rows x 2 bytes = 144 16-byte pieces
+            *reinterpret_cast<f32x4u *>(reinterpret_cast<char *>(sslot) + tid * 16) =
+                *reinterpret_cast<const f32x4u *>(reinterpret_cast<const char *>(p.plan_slots + ((size_t)tile * 27 + 9 * grp) * 128) + tid * 16);
+        uint32_t sub_on[MS];
+#pragma unroll
+        for (int s = 0; s < MS; ++s) sub_on[s] = (my_mask[s] >> (9 * grp)) & 0x1ffu;
+        for (int base = 0; base < (n_list > 0 ? n_list : 1); base += CPD_RP_WIN) {
+            const int n_stage = n_list - base < CPD_RP_WIN ? n_list - base : CPD_RP_WIN;
+            for (int kk = 0; kk < sk; ++kk) {
+                // ---- stage the window: thread -> (slot, 16-byte piece); 8 consecutive lanes fetch one row's 128-byte channel block
+                int t_first = __builtin_ctz(gmask);
+                load_weights(9 * grp + t_first, kk);
+                __syncthreads();                                           // every wave is done with the previous window and weight buffers
+                for (int e = tid; e < n_stage * 8; e += 256) {
+                    const int slot = e >> 3, pc = e & 7;
+                    const int id = ulist[base + slot];
+                    const f32x4u v = *reinterpret_cast<const f32x4u *>(in_bytes + (size_t)id * row_bytes + kk * 128 + pc * 16);
+                    *reinterpret_cast<f32x4u *>(swin + pc * PLANE + slot * 16) = v;
+                }
+                commit_weights(0);
+                __syncthreads();
+                // ---- the group's taps
+                uint32_t rem = gmask;
+                int par = 0;
+                while (true) {
+                    const int tl = __builtin_ctz(rem);                     // tap within the group
+                    rem &= rem - 1u;
+                    if (rem) load_weights(9 * grp + __builtin_ctz(rem), kk);
+                    const uint32_t on = ((sub_on[0] >> tl) & 1u) | (((sub_on[1] >> tl) & 1u) << 1);
+                    if (on) {
+                        typename S::frag a[MS][NP];
+#pragma unroll
+                        for (int s = 0; s < MS; ++s) {
+                            if ((on >> s) & 1u) {
+                                const uint32_t sl = sslot[tl * 128 + wave * 32 + 16 * s + r];
+                                uint32_t w = sl - (uint32_t)base;          // 0xffff (no neighbour) and rows of other passes land beyond the window:
+                                w = w < (uint32_t)n_stage ? w : (uint32_t)CPD_RP_WIN;   // the zero row
+                                const char *src = swin + g * PLANE + w * 16;
+                                a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
+                                a[s][1] = *reinterpret_cast<const typename S::frag *>(src + 4 * PLANE);
+                            }
+                        }
+                        const char *const sb = sb0 + par * (NP * B_IMG);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const char *src = sb + ((g * BN + 16 * nt + r) << 4);
+                            typename S::frag b[NP];
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+#pragma unroll
+                            for (int s = 0; s < MS; ++s)
+                                if ((on >> s) & 1u) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
+                        }
+                    }
+                    if (!rem) break;
+                    commit_weights(par ^ 1);
+                    __syncthreads();
+                    par ^= 1;
+                }
+            }
+        }
+    }
+    epilogue<MS, NT, true>(p, acc, row0, 0, r, g, 1.f);
+}
+
+template <int BN>
+__global__ void __launch_bounds__(256) rowplan_conv_f16p_kernel(GcParams p) {
+    __shared__ __attribute__((aligned(16))) char sb[2 * SplitF16x2::NP * BN * 64];          // two weight buffers
+    __shared__ __attribute__((aligned(16))) char swin[8 * CPD_RP_P16 * 16];                  // 8 planes (hi / lo x 4 k-groups) x 225 slots
+    __shared__ __attribute__((aligned(16))) uint16_t sslot[9 * 128];                         // the group's positions
+    rowplan_conv_body<BN>(p, sb, swin, sslot);
+}
+
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
 // W[t_src][ci][co] (optionally the adjoint: tap-flipped and/or transposed source).
 __global__ void __launch_bounds__(256) pack_weight_bf16_kernel(const float *__restrict__ w, int kv, int c_in, int c_out, int np,
@@ -2121,6 +2284,7 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     p.out_pairs = (flags & CPD_GC_OUT_PAIRS) ? (c_out == 16 ? 2 : 1) : 0;       // (2: the 16-channel row format)
     p.res_pairs = (flags & CPD_GC_RES_PAIRS) ? (c_out == 16 ? 2 : 1) : 0;
     p.split = 1; p.part = nullptr;
+    p.plan_slots = nullptr; p.plan_ulist = nullptr; p.plan_count = nullptr;
     p.in = in; p.w = packed_w; p.wb = nullptr; p.dsc = nullptr; p.in_absmax = in_absmax; p.out_absmax = out_absmax; p.nbr = nbr; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16; p.scale = scale; p.shift = shift; p.residual = residual;
     p.out = out; p.out_row_map = out_row_map;
     p.in_ld = in_ld; p.c_in = c_in; p.kc = (c_in + 15) / 16; p.n_in_rows = n_in;
@@ -2407,6 +2571,51 @@ extern "C" int cpd_gather_conv_ranged(const float *in, int in_ld, int n_in, int 
                                       uint32_t *out_absmax, cpd_stream_t stream) {
     return gather_conv_impl(in, in_ld, n_in, c_in, packed_w, nbr, tapmask, kv, n_out, c_out, scale, shift, residual, res_ld, relu, out,
                             out_ld, out_row_map, out_col_group, flags, in_absmax, out_absmax, stream);
+}
+// The staged row-wave kernel (rowplan_conv_f16p_kernel): a sub-manifold 3 x 3 x 3 layer on fp16-pair rows whose rulebook comes with a
+// row plan. Problems it does not take return CPD_ERR_UNSUPPORTED (the caller then runs cpd_gather_conv_ws: same result).
+extern "C" int cpd_gather_conv_planned_supported(int n_in, int n_out, int c_in, int c_out, int in_ld, int kv, int flags) {
+    const bool tn = cpd_tuning();
+    if (const char *e = cpd_knob(tn, "CPD_GC_PLANNED")) { if (!atoi(e)) return 0; }
+    long long min_tiles = 512;                 // below two workgroups per CU the row-wave kernel's tap split fills the chip better
+    if (const char *e = cpd_knob(tn, "CPD_GC_PLANNED_MIN")) min_tiles = atoll(e);
+    return kv == 27 && (flags & CPD_GC_F16X2) && (flags & CPD_GC_IN_PAIRS) && !(flags & CPD_GC_DENSE) && c_in % 32 == 0 &&
+           (c_out == 32 || c_out == 64 || c_out == 128) && in_ld % 4 == 0 && n_in > 0 && (n_out + 127) / 128 >= min_tiles;
+}
+extern "C" int cpd_gather_conv_planned(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const uint32_t *tapmask,
+                                       const uint16_t *plan_slots, const int32_t *plan_ulist, const int32_t *plan_count, int kv,
+                                       int n_out, int c_out, const float *scale, const float *shift, const float *residual, int res_ld,
+                                       int relu, float *out, int out_ld, int flags, uint32_t *out_absmax, cpd_stream_t stream) {
+    if (!in || !packed_w || !out || !plan_slots || !plan_ulist || !plan_count || n_in <= 0 || n_out < 0 || in_ld < c_in || out_ld < c_out ||
+        (residual && res_ld < c_out))
+        return CPD_ERR_ARG;
+    if (n_out == 0) return CPD_OK;
+    if (!cpd_gather_conv_planned_supported(n_in, n_out, c_in, c_out, in_ld, kv, flags) || (((uintptr_t)in) & 15)) return CPD_ERR_UNSUPPORTED;
+    if ((flags & CPD_GC_RES_PAIRS) && !residual) return CPD_ERR_ARG;
+    GcParams p;
+    memset(&p, 0, sizeof p);
+    p.in_pairs = 1;
+    p.out_pairs = (flags & CPD_GC_OUT_PAIRS) ? 1 : 0;
+    p.res_pairs = (flags & CPD_GC_RES_PAIRS) ? 1 : 0;
+    p.split = 1;
+    p.in = in; p.w = packed_w; p.out_absmax = out_absmax; p.tapmask = tapmask; p.n_sub = (n_out + 15) / 16;
+    p.scale = scale; p.shift = shift; p.residual = residual; p.out = out;
+    p.in_ld = in_ld; p.c_in = c_in; p.kc = c_in / 16; p.n_in_rows = n_in;
+    p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = c_out / 16; p.np = c_out;
+    p.res_ld = res_ld; p.relu = relu; p.out_ld = out_ld;
+    p.wb = packed_f16_ptr(packed_w, kv, c_in, c_out);
+    p.dsc = packed_dsc_ptr(packed_w, kv, c_in, c_out);
+    p.plan_slots = plan_slots; p.plan_ulist = plan_ulist; p.plan_count = plan_count;
+    p.n_rb = (n_out + 127) / 128; p.n_cb = 1; p.items = p.n_rb;
+    char nm[64];
+    snprintf(nm, sizeof nm, "rowplan_conv_f16p_kernel<%d>", c_out);
+    cpd_launch_log_note(nm);
+    const dim3 grid(p.items), block(256);
+    hipStream_t hs = cpd_s(stream);
+    if (c_out == 32) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<32>), grid, block, 0, hs, p);
+    else if (c_out == 64) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<64>), grid, block, 0, hs, p);
+    else hipLaunchKernelGGL((rowplan_conv_f16p_kernel<128>), grid, block, 0, hs, p);
+    return cpd_check_launch();
 }
 extern "C" size_t cpd_gather_conv_split_bytes(int n_out, int c_in, int c_out, int in_ld, int kv, int flags) {
     if (n_out <= 0 || c_in <= 0 || c_out <= 0 || kv <= 0) return 0;

@@ -65,7 +65,12 @@ class ModelConfig:
     pair_rows: bool = True
     pair_rows_level1: bool = True          # ... and level 1 (16 channels: K = 16 MFMA form of the wave kernel) as well
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
-    row_order: str = "taps"
+    # "bricks" (round 4): rows of the strided levels in 8 x 8 (y, x) brick order of their z-plane, pattern-sorted inside every 128-row
+    # tile (ops.order_rows_bricks), and their sub-manifold rulebooks PLANNED (ops.rulebook_plan): the SparseBasicBlock convs of
+    # levels 2-4 then run the staged row-wave kernel, which fetches a tile's distinct input rows once into LDS instead of gathering
+    # every (row, tap) pair through the vector L1 (cpd_gather_conv_planned; needs pair_rows). "taps" = round 3's order.
+    row_order: str = "bricks"
+    row_order_brick: tuple = (8, 8)
     row_order_chunk: int = 4096
     row_order_min_rows: int = 65536        # below this a level does not fill the chip either way
 
@@ -396,7 +401,11 @@ class CenterPointEngine:
             k, s, pd = _DOWN[stage]
             out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
             out_c = out_idx
-            if self.cfg.row_order == "taps" and out_idx.shape[0] >= self.cfg.row_order_min_rows:
+            bricks = self.cfg.row_order == "bricks" and out_idx.shape[0] >= self.cfg.row_order_min_rows
+            if bricks:
+                out_idx, _, old_to_new = ops.order_rows_bricks(out_c, out_index, brick=self.cfg.row_order_brick)
+                out_index.set_order(old_to_new)
+            elif self.cfg.row_order == "taps" and out_idx.shape[0] >= self.cfg.row_order_min_rows:
                 # rows of the level sorted, chunk by chunk, by their neighbour pattern (ops.order_rows_by_taps): the level's
                 # site list in the new order + the rank -> row map installed in its index re-order everything that follows
                 # (both rulebooks, the features, the exported level) without any kernel knowing
@@ -407,6 +416,8 @@ class CenterPointEngine:
             pairs_out = pairs and out_idx.shape[0] * L[stage + ".down"].c_out * 4 < 0xfffff000
             x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in, out_pairs=pairs_out)
             nbr = ops.rulebook_subm(out_idx, out_index)
+            if bricks and pairs_out:
+                ops.rulebook_plan(nbr)                         # the level's four SubM convs: the staged row-wave kernel
             x = self._blocks(L[stage], x, nbr, pairs=pairs_out)
             pairs_in = pairs_out
             coords, coords_c, index, shape = out_idx, out_c, out_index, out_shape

@@ -172,6 +172,36 @@ def order_rows_by_taps(indices, index, ksize=(3, 3, 3), chunk_rows=4096):
     return out, new_to_old, old_to_new
 
 
+def order_rows_bricks(indices, index, brick=(8, 8)):
+    """For a level's CANONICAL site list [n, 4] and its canonical SiteIndex: (indices in brick order, new_to_old, old_to_new) --
+    rows sorted by (b, z, y / brick[0], x / brick[1], y, x), then by neighbour pattern inside every 128-row tile
+    (cpd_order_rows_bricks): the row order the staged row-wave kernel (gather_conv with a planned rulebook) wants."""
+    indices = indices.contiguous()
+    n = indices.shape[0]
+    dev = indices.device
+    new_to_old = torch.empty((n,), dtype=torch.int32, device=dev)
+    old_to_new = torch.empty((n,), dtype=torch.int32, device=dev)
+    out = torch.empty_like(indices)
+    a = lambda b: (b + 255) // 256 * 256
+    ws = torch.empty((2 * a(4 * max(n, 1)) + a(16 * max(n, 1)),), dtype=torch.uint8, device=dev)
+    check(lib().cpd_order_rows_bricks(ptr(indices), n, index.batch, iarr(index.shape), ptr(index.buf), int(brick[0]), int(brick[1]),
+                                      ptr(new_to_old), ptr(old_to_new), ptr(out), ptr(ws), ws.numel(), stream()), "cpd_order_rows_bricks")
+    return out, new_to_old, old_to_new
+
+
+def rulebook_plan(nbr):
+    """Attach the row plan of a 27-tap sub-manifold rulebook (cpd_rulebook_plan) to the table: gather_conv then runs the staged
+    row-wave kernel on it where that kernel applies. Returns nbr."""
+    kv, n = nbr.shape
+    dev = nbr.device
+    slots = torch.empty((lib().cpd_rulebook_plan_bytes(n, 0) // 2,), dtype=torch.int16, device=dev)
+    ulist = torch.empty((lib().cpd_rulebook_plan_bytes(n, 1) // 4,), dtype=torch.int32, device=dev)
+    count = torch.empty((lib().cpd_rulebook_plan_bytes(n, 2) // 4,), dtype=torch.int32, device=dev)
+    check(lib().cpd_rulebook_plan(ptr(nbr), kv, n, ptr(slots), ptr(ulist), ptr(count), stream()), "cpd_rulebook_plan")
+    nbr.plan = (slots, ulist, count)
+    return nbr
+
+
 def _new_tapmask(n, kv, device):
     if kv > 32 or n == 0:
         return None
@@ -282,6 +312,15 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
         if rc != -4:                                # CPD_ERR_UNSUPPORTED: shape / alignment / size -> the table path below
             check(rc, "cpd_conv3x3_rows")
             return out
+    plan = getattr(nbr, "plan", None)               # a planned sub-manifold rulebook: the staged row-wave kernel, where it applies
+    if plan is not None and in_absmax is None and out_row_map is None and not out_col_group and lib().cpd_gather_conv_planned_supported(
+            int(inp.shape[0]), int(n_out), int(c_in), int(c_out), int(inp.stride(0)), int(kv), flags):
+        check(lib().cpd_gather_conv_planned(
+            ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w), ptr(getattr(nbr, "tapmask", None)),
+            ptr(plan[0]), ptr(plan[1]), ptr(plan[2]), kv, n_out, c_out, ptr(scale), ptr(shift),
+            ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
+            ctypes.c_void_p(out.data_ptr()), out.stride(0), flags, ptr(out_absmax), stream()), "cpd_gather_conv_planned")
+        return out
     ws, ws_bytes = None, 0
     if (flags & 6) and c_in % 32 == 0 and not out_col_group:
         # a small launch (one frame, the train step) deals its taps / stages to several workgroups through a workspace (cpd_gather_conv_ws)
@@ -554,6 +593,10 @@ def boxes_iou_bev_cpu(a, b):
 def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=None, math=None, scaled=False, in_pairs=False):
     """Name of the kernel instantiation gather_conv will run for this problem (`nbr`: the table it would be given; `scaled`: an
     `in_absmax` block comes with the input -- the split-fp16 kernels then run as their pre-scaling `f16s` instantiations)."""
+    if nbr is not None and getattr(nbr, "plan", None) is not None and not scaled and lib().cpd_gather_conv_planned_supported(
+            int(nbr.shape[1]), int(n_out), int(c_in), int(c_out), int(in_ld), int(nbr.shape[0]),
+            _gc_flags(dense, bf16x3, math) | (16 if in_pairs else 0)):
+        return "rowplan_conv_f16p_kernel<%d>" % c_out
     name = _gather_conv_tile(n_out, c_in, c_out, in_ld, dense, bf16x3, nbr, math, in_pairs)
     return name.replace("_f16_kernel", "_f16s_kernel") if scaled else name
 

@@ -133,12 +133,31 @@ int cpd_order_rows_by_taps(const int32_t *indices, int n, int batch, const int32
                            int32_t *old_to_new, int32_t *indices_out, void *workspace, size_t workspace_bytes,
                            cpd_stream_t stream);
 int cpd_index_set_order(void *index, const int32_t *rank_to_row, cpd_stream_t stream);
+/* Brick order of a level (round 4; any row order is a valid SparseConvTensor, spconv_backbone.py:502-558 never reads one): rows
+ * sorted by (b, z, y / brick_y, x / brick_x, y, x) -- brick_y x brick_x bricks of one z-plane, computed WITHOUT a sort from rank
+ * queries on the level's canonical site index -- and then, inside every tile of 128 consecutive rows of that order, by their 27-bit
+ * sub-manifold neighbour pattern (what cpd_order_rows_by_taps does per chunk). A tile of 128 output rows then touches ~2.9 distinct
+ * input rows per row instead of 4.5 (canonical) or 8.8 (4096-row pattern chunks): what cpd_gather_conv_planned stages in LDS.
+ * `indices` [n][4]: the CANONICAL list of the level, `index`: its canonical index. Outputs as cpd_order_rows_by_taps.
+ * workspace: 2 * align256(4 n) + align256(16 n) bytes. */
+int cpd_order_rows_bricks(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3], const void *index,
+                          int brick_y, int brick_x, int32_t *new_to_old, int32_t *old_to_new, int32_t *indices_out,
+                          void *workspace, size_t workspace_bytes, cpd_stream_t stream);
 /* SubMConv3d rulebook: output set == input set, same order; tap t reads coord + t - k/2.
  * tapmask (optional, u32 [ceil(n/16)], kernel volume <= 32): bit t of word s is set iff some row
  * of the 16-row group s has a neighbour at tap t -- lets cpd_gather_conv skip empty
  * (row group, tap) pairs without touching nbr. */
 int cpd_rulebook_subm(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3],
                       const int32_t ksize[3], const void *index, int32_t *nbr, uint32_t *tapmask,
+                      cpd_stream_t stream);
+/* Row plan of a 3 x 3 x 3 sub-manifold rulebook nbr[27][n_out] (round 4): per tile of 128 consecutive output rows and per dz group of
+ * nine taps (tap = (dz * 3 + dy) * 3 + dx; the three groups read three different z-planes and share no input row)
+ *   ulist [tiles][3][1152] i32   the distinct input rows the group touches, ascending, `count` of them;
+ *   slots [tiles][27][128] u16   per (tap, row of the tile): position of nbr[tap][row] in its group's list, 0xffff = no neighbour;
+ *   count [tiles][4]       i32   the three list lengths and their sum.
+ * cpd_rulebook_plan_bytes(n_out, which): bytes of slots (0), ulist (1), count (2). Any row order is planned correctly. */
+size_t cpd_rulebook_plan_bytes(int n_out, int which);
+int cpd_rulebook_plan(const int32_t *nbr, int kv, int n_out, uint16_t *slots, int32_t *ulist, int32_t *count,
                       cpd_stream_t stream);
 /* out_shape = (in + 2*pad - k)/stride + 1. HOST only. */
 int cpd_conv_out_shape(const int32_t in_shape[3], const int32_t ksize[3], const int32_t stride[3],
@@ -235,6 +254,19 @@ int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c
                      const float *packed_w, int c_out, const float *scale, const float *shift,
                      const float *residual, int res_ld, int relu, float *out, int out_ld, int flags,
                      cpd_stream_t stream);
+/* cpd_gather_conv for a 3 x 3 x 3 SubMConv3d layer (spconv_backbone.py:108-115: the SparseBasicBlock convs) whose rulebook comes with
+ * a row plan (cpd_rulebook_plan): the STAGED row-wave kernel. Per tile of 128 output rows and dz group it copies the group's distinct
+ * input rows (128-byte channel blocks, whole cache lines) into an LDS window once and forms the MFMA fragments of all nine taps from
+ * LDS -- a (row, tap) pair costs a ds_read instead of a gather through the vector L1 (which is what bounded the row-wave kernels:
+ * profiles/r03_rowwave_pmc.json). Same arithmetic as cpd_gather_conv with CPD_GC_F16X2 | CPD_GC_IN_PAIRS (identical partial products,
+ * accumulated in the same tap order). Takes: kv = 27, c_in % 32 == 0, c_out = 32 / 64 / 128, fp16-pair input rows, >= 512 tiles
+ * (cpd_gather_conv_planned_supported tells; otherwise CPD_ERR_UNSUPPORTED and the caller uses cpd_gather_conv_ws: same result).
+ * flags: CPD_GC_F16X2 | CPD_GC_IN_PAIRS [| CPD_GC_OUT_PAIRS | CPD_GC_RES_PAIRS]. */
+int cpd_gather_conv_planned_supported(int n_in, int n_out, int c_in, int c_out, int in_ld, int kv, int flags);
+int cpd_gather_conv_planned(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const uint32_t *tapmask,
+                            const uint16_t *plan_slots, const int32_t *plan_ulist, const int32_t *plan_count, int kv,
+                            int n_out, int c_out, const float *scale, const float *shift, const float *residual, int res_ld,
+                            int relu, float *out, int out_ld, int flags, uint32_t *out_absmax, cpd_stream_t stream);
 /* Introspection for benchmarks/profilers: which kernel instantiation cpd_gather_conv runs for
  * this problem: wg=1 -> tile_conv_kernel<a,b> (a x b workgroup tile), wg=0 ->
  * gather_conv_kernel<a,b,vec> ((16a) x (16b) wave tile; vec = 16-byte A pieces). HOST only.  */
