@@ -149,6 +149,37 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
     uint32_t vmax = 0;                // bits of the largest |v| this lane stores (non-negative floats order like their bits; NaN on top)
 #pragma unroll
     for (int s = 0; s < MS; ++s) {
+        // Residual first, for the whole sub-tile: the loads of all 4 * NT elements are issued back to back and their round trips overlap.
+        // (Loaded inside the element loop below, each load sat between the previous element's store and its own use: the compiler
+        // cannot move a load above a store through a pointer it cannot tell apart, so an epilogue was 4 * MS * NT SERIAL global round
+        // trips -- 16 ... 64 per workgroup; tools/rowplan_bench.py with the epilogue ablated: 354 of 821 us on the 32-channel level.)
+        // (column tiles in chunks of NC: 4 * NC live values -- all of a sub-tile at once costs the 128-column kernels their registers)
+        constexpr int NC = NT > 4 ? 4 : NT;
+#pragma unroll
+        for (int c0 = 0; c0 < NT; c0 += NC) {
+        float resv[4][NC];
+        if (p.residual) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 16 * s + 4 * g + i;
+                const int rowc = row < p.n_out ? row : p.n_out - 1;
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc) {
+                    const int nt = c0 + nc;
+                    int col = col0 + nt * 16 + r;
+                    col = col < p.c_out ? col : p.c_out - 1;
+                    if (PAIRS && p.res_pairs == 2) {  // 16-channel pair rows: k-group (col >> 2) = [hi 4 | lo 4]
+                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + ((col >> 2) << 4) + ((col & 3) << 1);
+                        resv[i][nc] = (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 8);
+                    } else if (PAIRS && p.res_pairs) {       // h + l is exact in fp32
+                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + ((col >> 5) << 7) + ((col & 31) << 1);
+                        resv[i][nc] = (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 64);
+                    } else {
+                        resv[i][nc] = p.residual[(size_t)rowc * p.res_ld + col];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + 16 * s + 4 * g + i;
@@ -158,22 +189,13 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
             int grp_have = -1;
             size_t drow = 0;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int nc = 0; nc < NC; ++nc) {
+                const int nt = c0 + nc;
                 const int col = col0 + nt * 16 + r;
                 if (col >= p.c_out) continue;
                 float v = acc[s][nt][i];
                 v = v * sc[nt] + sh[nt];
-                if (p.residual) {
-                    if (PAIRS && p.res_pairs == 2) {  // 16-channel pair rows: k-group (col >> 2) = [hi 4 | lo 4]
-                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)row * p.res_ld) + ((col >> 2) << 4) + ((col & 3) << 1);
-                        v += (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 8);
-                    } else if (PAIRS && p.res_pairs) {       // h + l is exact in fp32
-                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)row * p.res_ld) + ((col >> 5) << 7) + ((col & 31) << 1);
-                        v += (float)*reinterpret_cast<const _Float16 *>(rp) + (float)*reinterpret_cast<const _Float16 *>(rp + 64);
-                    } else {
-                        v += p.residual[(size_t)row * p.res_ld + col];
-                    }
-                }
+                if (p.residual) v += resv[i][nc];
                 if (p.relu) v = v > 0.f ? v : 0.f;
                 const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
                 vmax = vb > vmax ? vb : vmax;
@@ -200,6 +222,7 @@ __device__ __forceinline__ void epilogue(const GcParams &p, f32x4 (&acc)[MS][NT]
                     p.out[orow * p.out_ld + col] = v;
                 }
             }
+        }
         }
     }
     if (p.out_absmax) {
@@ -1476,18 +1499,31 @@ rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcPar
 #define CPD_RP_WIN 224               // window slots; slot CPD_RP_WIN is the zero row
 #define CPD_RP_P16 225               // plane stride in 16-byte slots: odd, so that the 8 lanes that stage one row (8 planes, same slot) write 8 different
                                      // bank groups; == 1 (mod 16), so that a fragment read of consecutive slots has one 2-way conflict in 16 lanes
-template <int BN>
-__device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const sb0, char *const swin, uint16_t *const sslot) {
+// Pipeline (one LDS copy of everything, the NEXT stage's data in registers): a STAGE is (dz group, window pass, 32-channel block,
+// tap batch) -- a batch = TB taps whose weights are staged together (all nine of a group at 32 columns, the three dx taps of one dy at
+// 64 / 128: 36 / 24 / 48 KB). Per stage: barrier; registers -> LDS (weights; the window and the slot table when they change); barrier;
+// the global loads of the stage after it are issued (weights, window rows: whole lines, all in flight together); then the stage's
+// taps run from LDS with no barrier in between -- slot read, two fragment reads, B fragments, MFMAs -- so the loads fly under a
+// whole batch of MFMAs, and a tap costs no global round trip. (The first version staged one tap's weights per barrier interval,
+// as the row-wave kernels do: at 3-4 workgroups per CU the L2 latency of every 4 KB weight block was exposed: 0.128 vs 0.093
+// ms/frame on the 32-channel level.)
+template <int BN, int TB>
+__device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const smem) {
     typedef SplitF16x2 S;
     constexpr int NP = 2, NT = BN / 16, MS = 2;
-    constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one stage
-    constexpr int BJ = (B_SLOTS + 255) / 256;
-    constexpr int B_IMG = BN * 64;
+    constexpr int NB = 9 / TB;                 // stages (tap batches) per window; TB = taps per weight stage
+    char *const sw = smem;                                                  // one stage's weights
+    char *const swin = smem + TB * NP * BN * 64;                            // the window: 8 planes x 225 slots
+    uint16_t *const sslot = reinterpret_cast<uint16_t *>(swin + 8 * CPD_RP_P16 * 16);
+    constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one tap (a multiple of 256)
+    constexpr int B_IMG = BN * 64;             // bytes of one piece image of a tap
+    constexpr int WJ = TB * B_SLOTS / 256;     // weight pieces per thread and stage: 9 / 6 / 12
+    constexpr int JT = B_SLOTS / 256;          // ... per tap: 1 / 2 / 4
     constexpr int PLANE = CPD_RP_P16 * 16;
+    constexpr int SJ = (CPD_RP_WIN * 8 + 255) / 256;                       // window pieces per thread: 7
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int row0 = tile * 128 + wave * 32;
 
     uint32_t wg_mask = (1u << 27) - 1u, my_mask[MS] = {wg_mask, wg_mask};
     if (p.tapmask) {
@@ -1505,6 +1541,9 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
         for (int s = 0; s < MS; ++s) my_mask[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_mask[s]);
         wg_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_mask);
     }
+    int n_list[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) n_list[q] = __builtin_amdgcn_readfirstlane(p.plan_count[tile * 4 + q]);
 
     f32x4 acc[MS][NT];
 #pragma unroll
@@ -1516,103 +1555,253 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
     if (tid < 8) *reinterpret_cast<f32x4u *>(swin + tid * PLANE + CPD_RP_WIN * 16) = f32x4u{0.f, 0.f, 0.f, 0.f};
 
     const int sk = p.c_in >> 5;
-    const uint32_t b_stage32 = (uint32_t)((size_t)NP * 4 * p.np * 16);
-    const char *const in_bytes = reinterpret_cast<const char *>(p.in);
-    const size_t row_bytes = (size_t)p.in_ld * 4u;
-    f32x4u rbv[BJ];
-    auto load_weights = [&](int t, int kk) {
-        const char *wt = reinterpret_cast<const char *>(p.wb) + (uint32_t)(t * sk + kk) * b_stage32;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int id = j * 256 + tid;
-            const int pg = id / BN, n = id - pg * BN;
-            if (B_SLOTS % 256 == 0 || id < B_SLOTS) rbv[j] = *reinterpret_cast<const f32x4u *>(wt + (uint32_t)(pg * p.np + n) * 16u);
+    const uint32_t b_stage32 = (uint32_t)((size_t)NP * 4 * p.np * 16);     // bytes of one (tap, channel block) of the packed image
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0,
+                                                                              (int)(uint32_t)(((size_t)p.n_in_rows * p.in_ld) * sizeof(float)), 0x00020000);
+    const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
+    const int pc = tid & 7, slot0 = tid >> 3;                               // window piece of this thread: plane pc, slots slot0 + 32 j
+
+    // ---- the stage sequence (scalar state; every workgroup-uniform)
+    struct Stage { int grp, base, kk, bt; };
+    auto batch_mask = [&](int grp, int bt) -> uint32_t { return (wg_mask >> (9 * grp + TB * bt)) & ((1u << TB) - 1u); };
+    // -> the stage after `st`; new_win: it needs another window (its group / pass / channel block differs). false at the end
+    auto advance = [&](Stage &st, bool &new_win) -> bool {
+        new_win = false;
+        while (true) {
+            if (++st.bt < NB) {
+                if (batch_mask(st.grp, st.bt)) return true;
+                continue;
+            }
+            st.bt = -1;
+            new_win = true;
+            if (++st.kk < sk) continue;
+            st.kk = 0;
+            st.base += CPD_RP_WIN;
+            if (st.base < n_list[st.grp]) continue;
+            st.base = 0;
+            do { ++st.grp; } while (st.grp < 3 && !((wg_mask >> (9 * st.grp)) & 0x1ffu));
+            if (st.grp >= 3) return false;
         }
     };
-    auto commit_weights = [&](int slot) {
-        char *const sb = sb0 + slot * (NP * B_IMG);
+
+    // ---- registers of the stage in flight
+    f32x4u wreg[WJ];                 // weights of the next stage
+    f32x4u rows[SJ];                 // window rows of the next stage (when it opens a window)
+    f32x4u sreg;                     // slot table piece (threads 0 .. 143) when the group changes
+    auto issue_weights = [&](const Stage &st) {
+        const uint32_t bm = batch_mask(st.grp, st.bt);
+        const int t0 = 9 * st.grp + TB * st.bt;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+        for (int tt = 0; tt < TB; ++tt) {
+            if (!((bm >> tt) & 1u)) continue;
+            const char *wt = reinterpret_cast<const char *>(p.wb) + (uint32_t)((t0 + tt) * sk + st.kk) * b_stage32;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                if (CPD_GC_ABLATE & 65536) wreg[tt * JT + j] = f32x4u{(float)tt, 1.f, (float)j, 2.f};       // diagnostic builds: no weight loads
+                else wreg[tt * JT + j] = *reinterpret_cast<const f32x4u *>(wt + (uint32_t)(j * 256 + tid) * 16u);
+            }
+        }
+    };
+    auto write_weights = [&](const Stage &st) {
+        const uint32_t bm = batch_mask(st.grp, st.bt);
+#pragma unroll
+        for (int tt = 0; tt < TB; ++tt) {
+            if (!((bm >> tt) & 1u)) continue;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) *reinterpret_cast<f32x4u *>(sw + tt * (NP * B_IMG) + ((j * 256 + tid) << 4)) = wreg[tt * JT + j];
+        }
+    };
+    auto issue_window = [&](const Stage &st, bool new_grp) {
+        const int32_t *const ulist = p.plan_ulist + ((size_t)tile * 3 + st.grp) * CPD_PLAN_LIST + st.base;
+        const int n_stage = n_list[st.grp] - st.base < CPD_RP_WIN ? n_list[st.grp] - st.base : CPD_RP_WIN;
+        uint32_t roff[SJ];
+#pragma unroll
+        for (int j = 0; j < SJ; ++j) {
+            const int slot = slot0 + 32 * j;
+            const int id = slot < n_stage ? ulist[slot] : p.n_in_rows;      // beyond the list: out of range = zeros, no memory access
+            roff[j] = (uint32_t)id * row_bytes + (uint32_t)pc * 16u;
+        }
+#pragma unroll
+        for (int j = 0; j < SJ; ++j) {
+            if (CPD_GC_ABLATE & 131072) rows[j] = f32x4u{(float)roff[j], 1.f, 0.f, 2.f};                      // diagnostic builds: no row loads
+            else rows[j] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, roff[j], st.kk * 128, 0));
+        }
+        if (new_grp && tid < 144)                                           // 9 taps x 128 rows x 2 bytes = 144 16-byte pieces
+            sreg = *reinterpret_cast<const f32x4u *>(reinterpret_cast<const char *>(p.plan_slots + ((size_t)tile * 27 + 9 * st.grp) * 128) + tid * 16);
+    };
+    auto write_window = [&](bool new_grp) {
+#pragma unroll
+        for (int j = 0; j < SJ; ++j) *reinterpret_cast<f32x4u *>(swin + pc * PLANE + (slot0 + 32 * j) * 16) = rows[j];
+        if (new_grp && tid < 144) *reinterpret_cast<f32x4u *>(reinterpret_cast<char *>(sslot) + tid * 16) = sreg;
     };
 
-    for (int grp = 0; grp < 3; ++grp) {
-        const uint32_t gmask = (wg_mask >> (9 * grp)) & 0x1ffu;            // this group's taps some sub-tile of the workgroup has
-        if (!gmask) continue;
-        const int n_list = p.plan_count[tile * 4 + grp];
-        const int32_t *const ulist = p.plan_ulist + ((size_t)tile * 3 + grp) * CPD_PLAN_LIST;
-        __syncthreads();                                                   // the previous group's taps are done with sslot
-        if (tid < 144)                                                     // 9 taps x 128 rows x 2 bytes = 144 16-byte pieces
-            *reinterpret_cast<f32x4u *>(reinterpret_cast<char *>(sslot) + tid * 16) =
-                *reinterpret_cast<const f32x4u *>(reinterpret_cast<const char *>(p.plan_slots + ((size_t)tile * 27 + 9 * grp) * 128) + tid * 16);
-        uint32_t sub_on[MS];
+    // the epilogue's units: a thread owns (row, 8 adjacent channels) pieces of the tile; their residual pieces are fetched while the
+    // LAST stage computes (the registers of "the next stage's data" are free then)
+    constexpr int UNITS = 128 * (BN / 8) / 256;      // units per thread: 2 / 4 / 8
+    constexpr int UR = 256 / (BN / 8);
+    const int cg = tid % (BN / 8);                   // this thread's 8-channel group: the same for all its units
+    const int urow0 = tid / (BN / 8);                // ... in rows urow0 + k * UR of the tile
+    constexpr int UC = UNITS > 4 ? 4 : UNITS;        // units whose residual pieces are in registers at a time (128 columns: two halves,
+    constexpr bool EARLY = UNITS <= 4;               // fetched in the epilogue itself: 64 more live registers cost that kernel a wave per SIMD)
+    f16x8 rh[UC], rl[UC];
+    bool res_issued = false;
+    auto issue_residual = [&](int k0 = 0) {
 #pragma unroll
-        for (int s = 0; s < MS; ++s) sub_on[s] = (my_mask[s] >> (9 * grp)) & 0x1ffu;
-        for (int base = 0; base < (n_list > 0 ? n_list : 1); base += CPD_RP_WIN) {
-            const int n_stage = n_list - base < CPD_RP_WIN ? n_list - base : CPD_RP_WIN;
-            for (int kk = 0; kk < sk; ++kk) {
-                // ---- stage the window: thread -> (slot, 16-byte piece); 8 consecutive lanes fetch one row's 128-byte channel block
-                int t_first = __builtin_ctz(gmask);
-                load_weights(9 * grp + t_first, kk);
-                __syncthreads();                                           // every wave is done with the previous window and weight buffers
-                for (int e = tid; e < n_stage * 8; e += 256) {
-                    const int slot = e >> 3, pc = e & 7;
-                    const int id = ulist[base + slot];
-                    const f32x4u v = *reinterpret_cast<const f32x4u *>(in_bytes + (size_t)id * row_bytes + kk * 128 + pc * 16);
-                    *reinterpret_cast<f32x4u *>(swin + pc * PLANE + slot * 16) = v;
-                }
-                commit_weights(0);
-                __syncthreads();
-                // ---- the group's taps
-                uint32_t rem = gmask;
-                int par = 0;
-                while (true) {
-                    const int tl = __builtin_ctz(rem);                     // tap within the group
-                    rem &= rem - 1u;
-                    if (rem) load_weights(9 * grp + __builtin_ctz(rem), kk);
-                    const uint32_t on = ((sub_on[0] >> tl) & 1u) | (((sub_on[1] >> tl) & 1u) << 1);
-                    if (on) {
-                        typename S::frag a[MS][NP];
+        for (int kc = 0; kc < UC; ++kc) {
+            const int k = k0 + kc;
+            const int row = tile * 128 + urow0 + k * UR;
+            const int rowc = row < p.n_out ? row : p.n_out - 1;
+            const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + ((cg >> 2) << 7) + ((cg & 3) << 4);
+            rh[kc] = *reinterpret_cast<const f16x8 *>(rp);
+            rl[kc] = *reinterpret_cast<const f16x8 *>(rp + 64);
+        }
+        res_issued = true;
+    };
+
+    Stage cur = {0, 0, 0, -1};
+    while (cur.grp < 3 && !((wg_mask >> (9 * cur.grp)) & 0x1ffu)) ++cur.grp;
+    bool have = cur.grp < 3, cur_win = true, cur_grp = true;
+    if (have) {
+        bool nw;
+        have = advance(cur, nw);            // the first batch of the first group with a tap (bt: -1 -> first live batch)
+    }
+    if (have) {
+        issue_window(cur, true);
+        issue_weights(cur);
+    }
+    while (have) {
+        Stage nxt = cur;
+        bool nxt_win = false;
+        const bool more = advance(nxt, nxt_win);
+        const bool nxt_grp = more && nxt.grp != cur.grp;
+        __syncthreads();                                                   // every wave is done with the previous stage's LDS
+        write_weights(cur);
+        if (cur_win) write_window(cur_grp);
+        __syncthreads();
+        if (more) {                                                        // the next stage's loads fly under this stage's MFMAs
+            if (nxt_win) issue_window(nxt, nxt_grp);
+            issue_weights(nxt);
+        } else if (EARLY && p.residual) {
+            issue_residual();                                              // ... and under the last stage's, the epilogue's residual pieces
+        }
+        // ---- this stage's taps, from LDS
+        {
+            const int n_stage = n_list[cur.grp] - cur.base < CPD_RP_WIN ? n_list[cur.grp] - cur.base : CPD_RP_WIN;
+            uint32_t rem = batch_mask(cur.grp, cur.bt);
+            const int tl0 = TB * cur.bt;                                   // first tap of the batch within the group
+            const uint32_t so0 = (my_mask[0] >> (9 * cur.grp + tl0)), so1 = (my_mask[1] >> (9 * cur.grp + tl0));
+            if (CPD_GC_ABLATE & 262144) rem = 0;                          // diagnostic builds: no fragment reads, no MFMAs
+            while (rem) {
+                const int tt = __builtin_ctz(rem);
+                rem &= rem - 1u;
+                const uint32_t on = ((so0 >> tt) & 1u) | (((so1 >> tt) & 1u) << 1);
+                if (!on) continue;
+                typename S::frag a[MS][NP];
 #pragma unroll
-                        for (int s = 0; s < MS; ++s) {
-                            if ((on >> s) & 1u) {
-                                const uint32_t sl = sslot[tl * 128 + wave * 32 + 16 * s + r];
-                                uint32_t w = sl - (uint32_t)base;          // 0xffff (no neighbour) and rows of other passes land beyond the window:
-                                w = w < (uint32_t)n_stage ? w : (uint32_t)CPD_RP_WIN;   // the zero row
-                                const char *src = swin + g * PLANE + w * 16;
-                                a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
-                                a[s][1] = *reinterpret_cast<const typename S::frag *>(src + 4 * PLANE);
-                            }
-                        }
-                        const char *const sb = sb0 + par * (NP * B_IMG);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const char *src = sb + ((g * BN + 16 * nt + r) << 4);
-                            typename S::frag b[NP];
-#pragma unroll
-                            for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
-#pragma unroll
-                            for (int s = 0; s < MS; ++s)
-                                if ((on >> s) & 1u) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
-                        }
+                for (int s = 0; s < MS; ++s) {
+                    if ((on >> s) & 1u) {
+                        const uint32_t sl = sslot[(tl0 + tt) * 128 + wave * 32 + 16 * s + r];
+                        uint32_t w = sl - (uint32_t)cur.base;              // 0xffff (no neighbour) and rows of other passes land beyond the window:
+                        w = w < (uint32_t)n_stage ? w : (uint32_t)CPD_RP_WIN;   // the zero row
+                        const char *src = swin + g * PLANE + w * 16;
+                        a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
+                        a[s][1] = *reinterpret_cast<const typename S::frag *>(src + 4 * PLANE);
                     }
-                    if (!rem) break;
-                    commit_weights(par ^ 1);
-                    __syncthreads();
-                    par ^= 1;
+                }
+                const char *const sb = sw + tt * (NP * B_IMG);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const char *src = sb + ((g * BN + 16 * nt + r) << 4);
+                    typename S::frag b[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+#pragma unroll
+                    for (int s = 0; s < MS; ++s)
+                        if ((on >> s) & 1u) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
                 }
             }
         }
+        cur = nxt; cur_win = nxt_win; cur_grp = nxt_grp; have = more;
     }
-    epilogue<MS, NT, true>(p, acc, row0, 0, r, g, 1.f);
+    if (CPD_GC_ABLATE & 524288) { if (acc[0][0][0] == 123.f) p.out[0] = 1.f; return; }         // diagnostic builds: no epilogue
+    // ---- epilogue through LDS: the tile's 128 output rows are CONSECUTIVE rows of `out` (and of the residual): a linear block of
+    // 128 * 4 BN bytes. The accumulators go to LDS in row-major order; a thread then owns (row, 8 adjacent channels) units: 32
+    // contiguous bytes of accumulators, one 16-byte piece of the residual row's high terms and one of its low terms, two 16-byte
+    // stores -- whole cache lines in, whole cache lines out. (The fragment-shaped epilogue of the other kernels reads / writes
+    // 2- and 4-byte elements, 8 x 32-byte segments per instruction: 354 of 821 us at two workgroups per CU, tools/rowplan_bench.py.)
+    constexpr int LD = BN + 4;                       // floats per tile row in LDS (+4: the transposed writes of the four k-groups hit different banks)
+    float *const stile = reinterpret_cast<float *>(smem);
+    if (p.residual && !res_issued) issue_residual();     // (128 columns; or no stage ran: a tile without any neighbour)
+    float sc[8], sh[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int col = 8 * cg + q;
+        sc[q] = p.scale ? p.scale[col] : 1.f;
+        if (p.dsc) sc[q] *= p.dsc[col];
+        sh[q] = p.shift ? p.shift[col] : 0.f;
+    }
+    __syncthreads();                                 // every wave is done with the last stage's LDS
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stile[(wave * 32 + 16 * s + 4 * g + i) * LD + 16 * nt + r] = acc[s][nt][i];
+    __syncthreads();
+    uint32_t vmax = 0;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+        if (UNITS > UC && k == UC && p.residual) issue_residual(UC);       // second half of the residual pieces
+        const int lrow = urow0 + k * UR;
+        const int row = tile * 128 + lrow;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * cg);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * cg + 4);
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float v = (q < 4 ? v0[q] : v1[q - 4]) * sc[q] + sh[q];
+            if (p.residual) v += (float)rh[k % UC][q] + (float)rl[k % UC][q];   // h + l is exact in fp32
+            if (p.relu) v = v > 0.f ? v : 0.f;
+            t[q] = v;
+            const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
+            vmax = (row < p.n_out && vb > vmax) ? vb : vmax;
+        }
+        if (row < p.n_out) {
+            f16x8 h, l;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                h[q] = (_Float16)t[q];
+                l[q] = (_Float16)(t[q] - (float)h[q]);
+            }
+            char *op = reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld) + ((cg >> 2) << 7) + ((cg & 3) << 4);
+            *reinterpret_cast<f16x8 *>(op) = h;
+            *reinterpret_cast<f16x8 *>(op + 64) = l;
+        }
+    }
+    if (p.out_absmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t2 = (uint32_t)__shfl_xor((int)vmax, o);
+            vmax = t2 > vmax ? t2 : vmax;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+            if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
+        }
+    }
 }
 
-template <int BN>
+// LDS: [one stage's weights | window | slot table]; the epilogue's 128 x (BN + 4) float tile aliases the first two
+template <int BN, int TB>
+struct RowplanLds {
+    static constexpr int kStage = TB * SplitF16x2::NP * BN * 64 + 8 * CPD_RP_P16 * 16 + 9 * 128 * 2;
+    static constexpr int kTile = 128 * (BN + 4) * 4;
+    static constexpr int kBytes = kStage > kTile ? kStage : kTile;
+};
+template <int BN, int TB>
 __global__ void __launch_bounds__(256) rowplan_conv_f16p_kernel(GcParams p) {
-    __shared__ __attribute__((aligned(16))) char sb[2 * SplitF16x2::NP * BN * 64];          // two weight buffers
-    __shared__ __attribute__((aligned(16))) char swin[8 * CPD_RP_P16 * 16];                  // 8 planes (hi / lo x 4 k-groups) x 225 slots
-    __shared__ __attribute__((aligned(16))) uint16_t sslot[9 * 128];                         // the group's positions
-    rowplan_conv_body<BN>(p, sb, swin, sslot);
+    __shared__ __attribute__((aligned(16))) char smem[RowplanLds<BN, TB>::kBytes];
+    rowplan_conv_body<BN, TB>(p, smem);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -2579,8 +2768,9 @@ extern "C" int cpd_gather_conv_planned_supported(int n_in, int n_out, int c_in, 
     if (const char *e = cpd_knob(tn, "CPD_GC_PLANNED")) { if (!atoi(e)) return 0; }
     long long min_tiles = 512;                 // below two workgroups per CU the row-wave kernel's tap split fills the chip better
     if (const char *e = cpd_knob(tn, "CPD_GC_PLANNED_MIN")) min_tiles = atoll(e);
-    return kv == 27 && (flags & CPD_GC_F16X2) && (flags & CPD_GC_IN_PAIRS) && !(flags & CPD_GC_DENSE) && c_in % 32 == 0 &&
-           (c_out == 32 || c_out == 64 || c_out == 128) && in_ld % 4 == 0 && n_in > 0 && (n_out + 127) / 128 >= min_tiles;
+    return kv == 27 && (flags & CPD_GC_F16X2) && (flags & CPD_GC_IN_PAIRS) && (flags & CPD_GC_OUT_PAIRS) && !(flags & CPD_GC_DENSE) && c_in % 32 == 0 &&
+           (c_out == 32 || c_out == 64 || c_out == 128) && in_ld % 4 == 0 && n_in > 0 && (n_out + 127) / 128 >= min_tiles &&
+           (size_t)n_in * in_ld * sizeof(float) < 0xfffff000ull;          // (rows are read through a 4 GB buffer resource)
 }
 extern "C" int cpd_gather_conv_planned(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const uint32_t *tapmask,
                                        const uint16_t *plan_slots, const int32_t *plan_ulist, const int32_t *plan_count, int kv,
@@ -2592,6 +2782,8 @@ extern "C" int cpd_gather_conv_planned(const float *in, int in_ld, int n_in, int
     if (n_out == 0) return CPD_OK;
     if (!cpd_gather_conv_planned_supported(n_in, n_out, c_in, c_out, in_ld, kv, flags) || (((uintptr_t)in) & 15)) return CPD_ERR_UNSUPPORTED;
     if ((flags & CPD_GC_RES_PAIRS) && !residual) return CPD_ERR_ARG;
+    if (residual && !(flags & CPD_GC_RES_PAIRS)) return CPD_ERR_UNSUPPORTED;          // (the kernel's epilogue reads pair rows)
+    if ((((uintptr_t)out) & 15) || out_ld % 4 || (residual && ((((uintptr_t)residual) & 15) || res_ld % 4))) return CPD_ERR_UNSUPPORTED;
     GcParams p;
     memset(&p, 0, sizeof p);
     p.in_pairs = 1;
@@ -2612,9 +2804,12 @@ extern "C" int cpd_gather_conv_planned(const float *in, int in_ld, int n_in, int
     cpd_launch_log_note(nm);
     const dim3 grid(p.items), block(256);
     hipStream_t hs = cpd_s(stream);
-    if (c_out == 32) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<32>), grid, block, 0, hs, p);
-    else if (c_out == 64) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<64>), grid, block, 0, hs, p);
-    else hipLaunchKernelGGL((rowplan_conv_f16p_kernel<128>), grid, block, 0, hs, p);
+    int tb32 = 3;             // 32 columns: the three dx taps of one dy per weight stage (12 KB, 3 workgroups per CU: 443 us) or all nine (36 KB, 2: 559 us)
+    if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_PLANNED_TB32")) tb32 = atoi(e);
+    if (c_out == 32 && tb32 == 3) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<32, 3>), grid, block, 0, hs, p);
+    else if (c_out == 32) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<32, 9>), grid, block, 0, hs, p);
+    else if (c_out == 64) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<64, 3>), grid, block, 0, hs, p);
+    else hipLaunchKernelGGL((rowplan_conv_f16p_kernel<128, 3>), grid, block, 0, hs, p);
     return cpd_check_launch();
 }
 extern "C" size_t cpd_gather_conv_split_bytes(int n_out, int c_in, int c_out, int in_ld, int kv, int flags) {

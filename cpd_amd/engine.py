@@ -65,12 +65,15 @@ class ModelConfig:
     pair_rows: bool = True
     pair_rows_level1: bool = True          # ... and level 1 (16 channels: K = 16 MFMA form of the wave kernel) as well
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
-    # "bricks" (round 4): rows of the strided levels in 8 x 8 (y, x) brick order of their z-plane, pattern-sorted inside every 128-row
-    # tile (ops.order_rows_bricks), and their sub-manifold rulebooks PLANNED (ops.rulebook_plan): the SparseBasicBlock convs of
-    # levels 2-4 then run the staged row-wave kernel, which fetches a tile's distinct input rows once into LDS instead of gathering
-    # every (row, tap) pair through the vector L1 (cpd_gather_conv_planned; needs pair_rows). "taps" = round 3's order.
-    row_order: str = "bricks"
+    # "bricks" (round 4, measured, NOT the default): rows of the strided levels in 8 x 8 (y, x) brick order of their z-plane,
+    # pattern-sorted inside every 128-row tile (ops.order_rows_bricks); with plan_rulebooks their sub-manifold rulebooks are PLANNED
+    # (ops.rulebook_plan) and the SparseBasicBlock convs of levels 2-4 run the staged row-wave kernel, which fetches a tile's distinct
+    # input rows once into LDS instead of gathering every (row, tap) pair through the vector L1 (cpd_gather_conv_planned; needs
+    # pair_rows). Same box, 48 frames: taps 1057, bricks 1045 (rulebooks -9 us/frame, row-wave kernels +5 %: coarser tap skipping),
+    # bricks + plan 956 (the staged kernel moves half the bytes through the L1 but holds 8-12 waves per CU, not 25).
+    row_order: str = "taps"
     row_order_brick: tuple = (8, 8)
+    plan_rulebooks: bool = False           # "bricks" only: plan the sub-manifold rulebooks -> the staged row-wave kernel
     row_order_chunk: int = 4096
     row_order_min_rows: int = 65536        # below this a level does not fill the chip either way
 
@@ -416,7 +419,7 @@ class CenterPointEngine:
             pairs_out = pairs and out_idx.shape[0] * L[stage + ".down"].c_out * 4 < 0xfffff000
             x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in, out_pairs=pairs_out)
             nbr = ops.rulebook_subm(out_idx, out_index)
-            if bricks and pairs_out:
+            if bricks and pairs_out and self.cfg.plan_rulebooks:
                 ops.rulebook_plan(nbr)                         # the level's four SubM convs: the staged row-wave kernel
             x = self._blocks(L[stage], x, nbr, pairs=pairs_out)
             pairs_in = pairs_out

@@ -595,7 +595,7 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=N
     `in_absmax` block comes with the input -- the split-fp16 kernels then run as their pre-scaling `f16s` instantiations)."""
     if nbr is not None and getattr(nbr, "plan", None) is not None and not scaled and lib().cpd_gather_conv_planned_supported(
             int(nbr.shape[1]), int(n_out), int(c_in), int(c_out), int(in_ld), int(nbr.shape[0]),
-            _gc_flags(dense, bf16x3, math) | (16 if in_pairs else 0)):
+            _gc_flags(dense, bf16x3, math) | (16 if in_pairs else 0) | 32):      # (the staged kernel writes pair rows)
         return "rowplan_conv_f16p_kernel<%d>" % c_out
     name = _gather_conv_tile(n_out, c_in, c_out, in_ld, dense, bf16x3, nbr, math, in_pairs)
     return name.replace("_f16_kernel", "_f16s_kernel") if scaled else name

@@ -3,6 +3,7 @@
 # (row-wave split kernel: 1 no weight loads, 2 no row gathers, 4 no MFMAs, 8 no barriers; window kernel: 16 no border masks,
 # 64 no weight stages, 128 no window loads/splits/stores, 256 fragment LDS reads in the first stage only, 512 no MFMAs, 1024 no epilogue;
 # both: 2048 two of the three split-fp16 products; row-wave: 4096 no split (gathered bits used as fragments); sums combine),
+# staged row-wave kernel (rowplan): 65536 no weight loads, 131072 no row loads, 262144 no fragment reads / MFMAs, 524288 no epilogue;
 # rest of the library unchanged.
 set -e
 cd "$(dirname "$0")/../cpd_amd/csrc"
@@ -13,6 +14,6 @@ for n in "$@"; do
 done
 wait
 for n in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probe/libcpd_abl$n.so voxelize.o site_index.o /tmp/gc_abl$n.o decode.o iou3d_nms.o train_ops.o roi_pool.o atss.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probe/libcpd_abl$n.so voxelize.o site_index.o row_plan.o /tmp/gc_abl$n.o decode.o iou3d_nms.o train_ops.o roi_pool.o atss.o
 done
 ls -la ../../tools/probe/*.so
