@@ -386,6 +386,8 @@ class CenterPointEngine:
         between layers (ModelConfig.pair_rows; f16x2 only); the returned level features are fp32 either way when
         `export_levels` (decoded copies), else whatever the layers left."""
         pairs = bool(pair_rows) and self.cfg.conv_math == "f16x2"
+        want = (lambda name: name in export_levels) if isinstance(export_levels, (tuple, list, set)) else (lambda name: bool(export_levels))
+        self.level_indexes = {}                               # name -> SiteIndex of the level (in the level's row order)
         L = self.sparse
         shape = self.cfg.sparse_shape
         if index is None:
@@ -397,7 +399,8 @@ class CenterPointEngine:
         pairs16 = pairs and self.cfg.pair_rows_level1
         x = self._conv(L["conv_input"], feats, nbr, coords.shape[0], out_pairs=pairs16)
         x = self._blocks(L["conv1"], x, nbr, pairs=pairs16)
-        levels = {"x_conv1": (ops.pairs_to_rows(x) if pairs16 and export_levels else x, coords, shape)}
+        levels = {"x_conv1": (ops.pairs_to_rows(x) if pairs16 and want("x_conv1") else x, coords, shape)}
+        self.level_indexes["x_conv1"] = index
         coords_c = coords                  # the list the next level's output set is marked from: canonical order wherever one exists
         pairs_in = pairs16                 # (what conv2.down reads)
         for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
@@ -424,7 +427,8 @@ class CenterPointEngine:
             x = self._blocks(L[stage], x, nbr, pairs=pairs_out)
             pairs_in = pairs_out
             coords, coords_c, index, shape = out_idx, out_c, out_index, out_shape
-            levels["x_conv%d" % i] = (ops.pairs_to_rows(x) if pairs_in and export_levels else x, coords, shape)
+            levels["x_conv%d" % i] = (ops.pairs_to_rows(x) if pairs_in and want("x_conv%d" % i) else x, coords, shape)
+            self.level_indexes["x_conv%d" % i] = index
         k, s, pd = _DOWN["conv_out"]
         out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
         nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
@@ -499,7 +503,7 @@ class CenterPointEngine:
         self._conv(self.head2, h1, T["s1"][0], n_full, out=out)
         return cat, out
 
-    def decode_and_nms(self, head_rows, batch, h, w):
+    def decode_and_nms(self, head_rows, batch, h, w, raw=False):
         """generate_predicted_boxes (center_head.py:252-303) + class_agnostic_nms
         (model_nms_utils.py:115-134) for all samples of the batch: five launches, nothing read back
         until the final per-sample counts."""
@@ -527,6 +531,8 @@ class CenterPointEngine:
         ns = ns[:batch]
         if self._range_exceeded:
             return None                           # forward() runs the step again, guarded
+        if raw:                                   # the padded device block + per-frame counts (the two-stage engine's proposals)
+            return ob, os_, ol, ns
         if self.host_results:
             # blocking copies: the first waits for the frame's last kernel, the rest are ~20 us each. (Asynchronous copies
             # into pinned memory queued on the compute stream were measured 5-8 ms per step SLOWER on MI355X / ROCm 7.2 --
@@ -537,8 +543,11 @@ class CenterPointEngine:
 
     # ------------------------------------------------------------------ whole frame(s)
     @torch.no_grad()
-    def forward(self, points_list, return_intermediates=False):
-        """points_list: list of [N_i, C] device tensors (one per frame of the batch)."""
+    def forward(self, points_list, return_intermediates=False, proposals=None):
+        """points_list: list of [N_i, C] device tensors (one per frame of the batch).
+        proposals = a collection of level names: the first stage of a two-stage detector -- returns
+        (boxes [B, cap, 7], scores, labels i64 (1-based), per-frame counts (host list), levels) with the named levels' features
+        exported as fp32 rows and their site indexes in self.level_indexes; nothing but the counts leaves the device."""
         if isinstance(points_list, torch.Tensor):
             points_list = [points_list]
         batch = len(points_list)
@@ -596,12 +605,13 @@ class CenterPointEngine:
         self._rb_scaled = self._guard_left > 0
         self._range_high = False
         while True:
-            levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0, export_levels=return_intermediates,
+            levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0,
+                                                              export_levels=proposals if proposals is not None else return_intermediates,
                                                               pair_rows=self.cfg.pair_rows and not self._rb_scaled)
             d, h, w = out_shape
             dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
             cat, head = self.bev_and_head(dense, batch, h, w)
-            results = self.decode_and_nms(head, batch, h, w)
+            results = self.decode_and_nms(head, batch, h, w, raw=proposals is not None)
             if results is not None:
                 break
             # an activation left fp16's safe range: the same step with every layer pre-scaling its input (exact), see _range_reset
@@ -616,6 +626,8 @@ class CenterPointEngine:
             self.range_guarded_steps += 1
             self._guard_left = self.RANGE_STICKY_STEPS if self._range_high else self._guard_left - 1
         self._rb_scaled = False
+        if proposals is not None:
+            return results + (levels,)
         if return_intermediates:
             return results, dict(voxel_features=feats, voxel_coords=coords, levels=levels,
                                  encoded=(x, out_idx, out_shape), spatial_features_nhwc=dense, bev_cat=cat,

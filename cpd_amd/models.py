@@ -185,6 +185,100 @@ class VoxelResBackBone8x(nn.Module):
         return batch_dict
 
 
+class VoxelBackBone8x(nn.Module):
+    """The non-residual backbone of the reference's registry (spconv_backbone.py:138-395, backbones_3d/__init__.py:3-8): conv_input,
+    one SubM block at stride 1, then per stride (2, 4, 8) a strided SparseConv3d + two SubM blocks, conv_out (3, 1, 1) / (2, 1, 1);
+    same parameter names (`conv2.0.0.weight` ...), so its checkpoints load.
+
+    forward follows the reference in both modes. Training: every stage (`transform_param` given: stage i reads `voxel_features<i>` /
+    `voxel_coords<i>`) goes through the backbone on its own. Eval: the stages are laid side by side along X -- stage i's voxels
+    shifted by i * sparse_shape[2] on a grid four times as wide -- so that ONE pass through the sparse convolutions serves all of
+    them (l.333-359), and `decompose_tensor` (l.241-261) cuts x_conv3 / x_conv4 / out back into per-stage tensors: columns strictly
+    between i * W/4 and (i + 1) * W/4 of the level's width W (the reference's open interval: column i * W/4 itself is dropped),
+    shifted back; x_conv1 / x_conv2 are None in eval mode, as there."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, num_frames=1, **kwargs):
+        super().__init__()
+        self.model_cfg, self.num_frames = model_cfg, num_frames
+        nf = model_cfg.NUM_FILTERS
+        self.out_features = model_cfg.OUT_FEATURES
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = [int(v) for v in (np.asarray(grid_size)[::-1] + [1, 0, 0])]
+        block = post_act_block
+
+        def encoder(sfx):
+            conv_input = spconv.SparseSequential(
+                spconv.SubMConv3d(input_channels, nf[0], 3, padding=1, bias=False, indice_key="subm1" + sfx), norm_fn(nf[0]), nn.ReLU())
+            conv1 = spconv.SparseSequential(block(nf[0], nf[0], 3, norm_fn=norm_fn, padding=1, indice_key="subm1" + sfx))
+            stages = []
+            for lvl, pad in ((1, 1), (2, 1), (3, (0, 1, 1))):
+                key = "%d%s" % (lvl + 1, sfx)
+                stages.append(spconv.SparseSequential(
+                    block(nf[lvl - 1], nf[lvl], 3, norm_fn=norm_fn, stride=2, padding=pad, indice_key="spconv" + key, conv_type="spconv"),
+                    block(nf[lvl], nf[lvl], 3, norm_fn=norm_fn, padding=1, indice_key="subm" + key),
+                    block(nf[lvl], nf[lvl], 3, norm_fn=norm_fn, padding=1, indice_key="subm" + key)))
+            return [conv_input, conv1] + stages
+
+        self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4 = encoder("")
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(nf[3], self.out_features, (3, 1, 1), stride=(2, 1, 1), padding=model_cfg.get("last_pad", 0), bias=False,
+                                indice_key="spconv_down2"), norm_fn(self.out_features), nn.ReLU())
+        if model_cfg.get("MM", False):           # declared like the reference (l.194-227); its forward never runs them either
+            self.conv_input_2, self.conv1_2, self.conv2_2, self.conv3_2, self.conv4_2 = encoder("_2")
+        self.num_point_features = self.out_features
+        if model_cfg.get("RETURN_NUM_FEATURES_AS_DICT", False):
+            self.num_point_features = {"x_conv1": nf[0], "x_conv2": nf[1], "x_conv3": nf[2], "x_conv4": nf[3]}
+
+    def _encode(self, feats, coords, shape, batch_size):
+        x = self.conv_input(spconv.SparseConvTensor(features=feats, indices=coords.int(), spatial_shape=shape, batch_size=batch_size))
+        x1 = self.conv1(x)
+        x2 = self.conv2(x1)
+        x3 = self.conv3(x2)
+        x4 = self.conv4(x3)
+        return x1, x2, x3, x4, self.conv_out(x4)
+
+    @staticmethod
+    def decompose_tensor(tensor, i, batch_size):
+        """stage i's share of a side-by-side tensor (reference l.241-261)"""
+        quarter = tensor.spatial_shape[2] // 4
+        xs = tensor.indices[:, 3]
+        keep = (xs > i * quarter) & (xs < (i + 1) * quarter)
+        idx = tensor.indices[keep].clone()
+        idx[:, 3] -= i * quarter
+        return spconv.SparseConvTensor(features=tensor.features[keep], indices=idx.int(),
+                                       spatial_shape=[tensor.spatial_shape[0], tensor.spatial_shape[1], quarter], batch_size=batch_size)
+
+    def forward(self, batch_dict):
+        stages = batch_dict["transform_param"].shape[1] if "transform_param" in batch_dict else 1
+        batch_size = batch_dict["batch_size"]
+        sid = lambda i: "" if i == 0 else str(i)
+        strides = {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}
+        if self.training:
+            for i in range(stages):
+                x1, x2, x3, x4, out = self._encode(batch_dict["voxel_features" + sid(i)], batch_dict["voxel_coords" + sid(i)],
+                                                   self.sparse_shape, batch_size)
+                batch_dict.update({"encoded_spconv_tensor" + sid(i): out, "encoded_spconv_tensor_stride" + sid(i): 8,
+                                   "multi_scale_3d_features" + sid(i): {"x_conv1": x1, "x_conv2": x2, "x_conv3": x3, "x_conv4": x4},
+                                   "multi_scale_3d_strides" + sid(i): dict(strides)})
+            return batch_dict
+        feats, coords = [], []
+        for i in range(stages):
+            feats.append(batch_dict["voxel_features" + sid(i)])
+            c = batch_dict["voxel_coords" + sid(i)].clone()
+            c[:, 3] += i * self.sparse_shape[2]
+            coords.append(c)
+        wide = [self.sparse_shape[0], self.sparse_shape[1], self.sparse_shape[2] * 4]
+        _, _, x3, x4, out = self._encode(torch.cat(feats, 0), torch.cat(coords), wide, batch_size)
+        for i in range(stages):
+            batch_dict.update({"encoded_spconv_tensor" + sid(i): self.decompose_tensor(out, i, batch_size),
+                               "encoded_spconv_tensor_stride" + sid(i): 8,
+                               "multi_scale_3d_features" + sid(i): {"x_conv1": None, "x_conv2": None,
+                                                                    "x_conv3": self.decompose_tensor(x3, i, batch_size),
+                                                                    "x_conv4": self.decompose_tensor(x4, i, batch_size)},
+                               "multi_scale_3d_strides" + sid(i): dict(strides)})
+        return batch_dict
+
+
 # ------------------------------------------------------------------------------------- BEV
 class HeightCompression(nn.Module):
     def __init__(self, model_cfg, **kwargs):
@@ -714,7 +808,8 @@ class _Registry(dict):
         raise KeyError(name)
 
 
-__all__ = _Registry({"MeanVFE": MeanVFE, "VoxelResBackBone8x": VoxelResBackBone8x, "HeightCompression": HeightCompression,
+__all__ = _Registry({"MeanVFE": MeanVFE, "VoxelResBackBone8x": VoxelResBackBone8x, "VoxelBackBone8x": VoxelBackBone8x,
+                     "HeightCompression": HeightCompression,
                      "BaseBEVBackbone": BaseBEVBackbone, "CenterHead": CenterHead})
 
 
@@ -801,3 +896,105 @@ class CenterPoint(nn.Module):
         from .engine import CenterPointEngine
         sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
         return CenterPointEngine(self.to_engine_config(), sd, device=device)
+
+
+def waymo_voxel_rcnn_cfg():
+    """MODEL section of voxel_rcnn_cproto_center.yaml:13-183: the two-stage detector the shipped CPD config selects (`NAME: VoxelRCNN`):
+    the CenterPoint first stage + ROI_HEAD (VoxelRCNNProtoHead, class-agnostic) + POST_PROCESSING (class-agnostic NMS 0.3)."""
+    cfg = waymo_centerpoint_cfg()
+    cfg.NAME = "VoxelRCNN"
+    cfg.BACKBONE_3D.MM = True
+    pool = dict(FEATURES_SOURCE=["x_conv3", "x_conv4"], PRE_MLP=True, GRID_SIZE=6,
+                POOL_LAYERS={"x_conv3": dict(MLPS=[[32, 32], [32, 32]], QUERY_RANGES=[[2, 2, 2], [4, 4, 4]], POOL_RADIUS=[0.4, 0.8],
+                                             NSAMPLE=[16, 16], POOL_METHOD="max_pool"),
+                             "x_conv4": dict(MLPS=[[32, 32], [32, 32]], QUERY_RANGES=[[2, 2, 2], [4, 4, 4]], POOL_RADIUS=[0.8, 1.6],
+                                             NSAMPLE=[16, 16], POOL_METHOD="max_pool")})
+    import copy
+    cfg.ROI_HEAD = AttrDict(
+        NAME="VoxelRCNNProtoHead", CLASS_AGNOSTIC=True, SHARED_FC=[256, 256], CLS_FC=[256, 256], REG_FC=[256, 256], DP_RATIO=0.3,
+        NMS_CONFIG=dict(TRAIN=dict(NMS_TYPE="nms_gpu", MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=4000, NMS_POST_MAXSIZE=500, NMS_THRESH=0.8),
+                        TEST=dict(NMS_TYPE="nms_gpu", MULTI_CLASSES_NMS=False, USE_FAST_NMS=True, SCORE_THRESH=0.0, NMS_PRE_MAXSIZE=4000,
+                                  NMS_POST_MAXSIZE=200, NMS_THRESH=0.8)),
+        ROI_GRID_POOL=pool, ROI_GRID_POOL_PROTO=copy.deepcopy(pool),
+        TARGET_CONFIG=dict(BOX_CODER="ResidualCoder", ROI_PER_IMAGE=130, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True, CLS_SCORE_TYPE="roi_iou",
+                           CLS_FG_THRESH=0.6, CLS_BG_THRESH=0.02, CLS_BG_THRESH_LO=0.01, HARD_BG_RATIO=0.1, REG_FG_THRESH=0.3),
+        LOSS_CONFIG=dict(CLS_LOSS="BinaryCrossEntropy", REG_LOSS="smooth-l1", CORNER_LOSS_REGULARIZATION=True, GRID_3D_IOU_LOSS=False,
+                         LOSS_WEIGHTS=dict(rcnn_proto_weight=1.0, rcnn_cls_weight=1.0, rcnn_reg_weight=1.0, rcnn_corner_weight=1.0,
+                                           rcnn_iou3d_weight=1.0, code_weights=[1.0] * 7)))
+    cfg.POST_PROCESSING = AttrDict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], SCORE_THRESH=0.01, OUTPUT_RAW_SCORE=False, EVAL_METRIC="waymo",
+                                   NMS_CONFIG=dict(MULTI_CLASSES_NMS=False, NMS_TYPE="nms_gpu", NMS_THRESH=0.3, NMS_PRE_MAXSIZE=4096,
+                                                   NMS_POST_MAXSIZE=50075))
+    return cfg
+
+
+def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
+    """model_nms_utils.class_agnostic_nms (cpd/models/model_utils/model_nms_utils.py:113-134) on the B3 operators."""
+    src = box_scores
+    if score_thresh is not None:
+        mask = box_scores >= score_thresh
+        box_scores, box_preds = box_scores[mask], box_preds[mask]
+    selected = box_scores.new_zeros((0,), dtype=torch.long)
+    if box_scores.shape[0] > 0:
+        top, order = torch.topk(box_scores, k=min(nms_config["NMS_PRE_MAXSIZE"], box_scores.shape[0]))
+        fn = getattr(iou3d_nms_utils, nms_config["NMS_TYPE"])
+        keep, _ = fn(box_preds[order][:, 0:7], top, nms_config["NMS_THRESH"])
+        selected = order[keep[:nms_config["NMS_POST_MAXSIZE"]]]
+    if score_thresh is not None:
+        selected = mask.nonzero().view(-1)[selected]
+    return selected, src[selected]
+
+
+class VoxelRCNN(CenterPoint):
+    """The two-stage detector (cpd/models/detectors/voxel_rcnn.py:3-43 over Detector3DTemplate's module_topology with `roi_head`,
+    detector3d_template.py:22-25,170-190): CenterPoint's modules with the dense head predicting boxes in every mode (its NMS output is
+    the second stage's `rois`, center_head.py:340-350), the RoI head of ROI_HEAD.NAME, and `post_processing`
+    (detector3d_template.py:222-343: sigmoid, the RoI labels, class-agnostic NMS at POST_PROCESSING.NMS_CONFIG). Training returns
+    ({'loss': loss_rpn + loss_rcnn}, tb_dict, disp_dict); eval (pred_dicts, recall_dicts, batch_dict) as the reference does.
+    State-dict prefixes: vfe. backbone_3d. backbone_2d. dense_head. roi_head."""
+
+    def __init__(self, model_cfg=None, num_class=3, **kw):
+        cfg = model_cfg or waymo_voxel_rcnn_cfg()
+        super().__init__(cfg, num_class=num_class, **kw)
+        self.dense_head.predict_boxes_when_training = True
+        rc = cfg.ROI_HEAD
+        self.roi_head = __all__[rc.NAME](input_channels=self.backbone_3d.num_point_features, model_cfg=rc,
+                                         point_cloud_range=self.point_cloud_range, voxel_size=self.voxel_size,
+                                         num_class=1 if rc.get("CLASS_AGNOSTIC", False) else num_class)
+        self.module_list = self.module_list + [self.roi_head]
+
+    def post_processing(self, batch_dict):
+        pp = self.model_cfg.POST_PROCESSING
+        if pp.NMS_CONFIG["MULTI_CLASSES_NMS"] or pp.get("WBF", False):
+            raise NotImplementedError("MULTI_CLASSES_NMS / WBF post-processing is not selected by the shipped CPD configs")
+        pred_dicts = []
+        for b in range(batch_dict["batch_size"]):
+            boxes = batch_dict["batch_box_preds"][b]
+            src = batch_dict["batch_cls_preds"][b]
+            assert src.shape[1] in (1, self.num_class)
+            cls = src if batch_dict["cls_preds_normalized"] else torch.sigmoid(src)
+            cls, labels = torch.max(cls, dim=-1)
+            if batch_dict.get("has_class_labels", False):
+                labels = batch_dict["roi_labels" if "roi_labels" in batch_dict else "batch_pred_labels"][b]
+            else:
+                labels = labels + 1
+            sel, scores = class_agnostic_nms(cls, boxes, pp.NMS_CONFIG, pp.SCORE_THRESH)
+            if pp.OUTPUT_RAW_SCORE:
+                scores = torch.max(src, dim=-1)[0][sel]
+            pred_dicts.append({"pred_boxes": boxes[sel], "pred_scores": scores, "pred_labels": labels[sel]})
+        return pred_dicts, {}
+
+    def forward(self, batch_dict):
+        for m in self.module_list:
+            batch_dict = m(batch_dict)
+        if self.training:
+            loss_rpn, tb_dict = self.dense_head.get_loss()
+            loss_rcnn, tb_dict = self.roi_head.get_loss(tb_dict)
+            return {"loss": loss_rpn + loss_rcnn}, tb_dict, {}
+        pred_dicts, recall = self.post_processing(batch_dict)
+        return pred_dicts, recall, batch_dict
+
+    def to_engine(self, device="cuda", **kw):
+        """The fused two-stage inference engine (cpd_amd/two_stage.py) on this model's weights."""
+        from .two_stage import VoxelRCNNEngine
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+        return VoxelRCNNEngine(self.to_engine_config(), self.model_cfg.ROI_HEAD, self.model_cfg.POST_PROCESSING, sd, device=device, **kw)

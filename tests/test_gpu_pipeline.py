@@ -603,3 +603,85 @@ def test_eval_container_with_a_training_batchnorm_takes_the_plain_path(hip):
     torch.testing.assert_close(got, want, atol=2e-4, rtol=1e-4)
     assert float((got[:, 64:] - fused[:, 64:]).abs().max()) > 1e-3     # and it differs from the running-statistics answer
     torch.testing.assert_close(got[:, :64], fused[:, :64], atol=2e-4, rtol=1e-4)
+
+
+def test_voxel_backbone8x_eval_side_by_side_stages_match_oracle(oracle, hip):
+    """VoxelBackBone8x in eval mode (spconv_backbone.py:333-393): two stages laid side by side along X on a 4x wide grid, one pass,
+    then decompose_tensor per stage -- against the same graph walked on the CPU oracle (folded eval BatchNorm), including the
+    reference's open-interval column mask; and in training mode every stage on its own (batch-statistics BatchNorm)."""
+    from cpd_amd import models
+    cfg = models.waymo_centerpoint_cfg().BACKBONE_3D
+    torch.manual_seed(5)
+    bb = models.VoxelBackBone8x(cfg, input_channels=5, grid_size=[160, 160, 40]).cuda().eval()
+    with torch.no_grad():
+        for mod in bb.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.uniform_(0.6, 1.4); mod.bias.normal_(0, 0.2)
+                mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.7, 1.3)
+    rng = np.random.default_rng(8)
+    stages = []
+    for s_ in range(2):
+        zyx = np.unique(np.concatenate([rng.integers([0, 0, 0], [41, 160, 160], size=(7000, 3)),
+                                        rng.integers([5, 40, 40], [20, 100, 100], size=(5000, 3))]), axis=0)
+        rng.shuffle(zyx)
+        b = rng.integers(0, 2, (zyx.shape[0], 1))
+        stages.append((np.concatenate([b, zyx], 1).astype(np.int32), rng.normal(size=(zyx.shape[0], 5)).astype(np.float32)))
+    batch = {"batch_size": 2, "transform_param": torch.zeros(2, 2, 8)}
+    for i, (c, f) in enumerate(stages):
+        sid = "" if i == 0 else str(i)
+        batch["voxel_features" + sid] = torch.from_numpy(f).cuda()
+        batch["voxel_coords" + sid] = torch.from_numpy(c).float().cuda()
+    with torch.no_grad():
+        out = bb(dict(batch))
+    assert out["multi_scale_3d_features"]["x_conv1"] is None and out["multi_scale_3d_features1"]["x_conv2"] is None
+    sd = {k: v.detach().cpu().numpy() for k, v in bb.state_dict().items()}
+
+    def bn(x, name):
+        sc = sd[name + ".weight"] / np.sqrt(sd[name + ".running_var"] + 1e-3)
+        return np.maximum(x * sc + (sd[name + ".bias"] - sd[name + ".running_mean"] * sc), 0).astype(np.float32)
+
+    conv = lambda name, x, nbr: oracle.sparse_conv(x, sd[name + ".weight"], None, nbr)
+    coords = np.concatenate([np.concatenate([c[:, :3], c[:, 3:] + i * 160], 1) for i, (c, _) in enumerate(stages)]).astype(np.int32)
+    feats = np.concatenate([f for _, f in stages])
+    shape = [41, 160, 640]
+    nbr = oracle.subm_rulebook(coords, 2, shape, [3, 3, 3])
+    x = bn(conv("conv_input.0", feats, nbr), "conv_input.1")
+    x = bn(conv("conv1.0.0", x, nbr), "conv1.0.1")
+    cur, levels = coords, {}
+    for lvl, (stage, k, s, pd) in enumerate([("conv2", [3, 3, 3], [2, 2, 2], [1, 1, 1]), ("conv3", [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                                             ("conv4", [3, 3, 3], [2, 2, 2], [0, 1, 1])], start=2):
+        out_idx = oracle.conv_outset(cur, 2, shape, k, s, pd)
+        x = bn(conv(stage + ".0.0", x, oracle.conv_rulebook(cur, out_idx, 2, shape, k, s, pd)), stage + ".0.1")
+        shape, cur = oracle.conv_out_shape(shape, k, s, pd), out_idx
+        sub = oracle.subm_rulebook(cur, 2, shape, [3, 3, 3])
+        x = bn(conv(stage + ".1.0", x, sub), stage + ".1.1")
+        x = bn(conv(stage + ".2.0", x, sub), stage + ".2.1")
+        levels["x_conv%d" % lvl] = (x, cur, list(shape))
+    k, s, pd = [3, 1, 1], [2, 1, 1], [0, 0, 0]
+    out_idx = oracle.conv_outset(cur, 2, shape, k, s, pd)
+    xo = bn(conv("conv_out.0", x, oracle.conv_rulebook(cur, out_idx, 2, shape, k, s, pd)), "conv_out.1")
+    levels["out"] = (xo, out_idx, oracle.conv_out_shape(shape, k, s, pd))
+
+    def check(t, name, i):
+        f0, i0, sh = levels[name]
+        q = sh[2] // 4
+        keep = (i0[:, 3] > i * q) & (i0[:, 3] < (i + 1) * q)              # the reference's open interval (column i * q is dropped)
+        want_i = i0[keep].copy(); want_i[:, 3] -= i * q
+        assert list(t.spatial_shape) == [sh[0], sh[1], q]
+        gi, gf = t.indices.cpu().numpy(), t.features.cpu().numpy()
+        o1, o2 = canon(gi), canon(want_i)
+        np.testing.assert_array_equal(gi[o1], want_i[o2], err_msg="%s stage %d" % (name, i))
+        np.testing.assert_allclose(gf[o1], f0[keep][o2], atol=1e-4, rtol=0, err_msg="%s stage %d" % (name, i))
+
+    for i in range(2):
+        sid = "" if i == 0 else str(i)
+        check(out["multi_scale_3d_features" + sid]["x_conv3"], "x_conv3", i)
+        check(out["multi_scale_3d_features" + sid]["x_conv4"], "x_conv4", i)
+        check(out["encoded_spconv_tensor" + sid], "out", i)
+        assert out["encoded_spconv_tensor_stride" + sid] == 8
+    # training mode: each stage separately, all four levels exported
+    bb.train()
+    with torch.no_grad():
+        tr = bb(dict(batch))
+    assert tr["multi_scale_3d_features1"]["x_conv1"].features.shape[0] == stages[1][0].shape[0]
+    assert list(tr["encoded_spconv_tensor1"].spatial_shape) == [2, 20, 20]

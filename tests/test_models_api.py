@@ -131,3 +131,19 @@ def test_epilogue_shift_with_scale_but_no_shift_keeps_the_bias_inside_the_scale(
     given = torch.tensor([7.0, 7.0])
     assert ops.epilogue_shift(scale, given, bias) is given
     assert ops.epilogue_shift(scale, None, None) is None
+
+
+def test_voxel_backbone8x_is_registered_with_the_reference_parameter_names():
+    """spconv_backbone.py:138-232 / backbones_3d/__init__.py:3-8: the non-residual backbone, same module tree (so its checkpoints load)."""
+    cfg = models.waymo_centerpoint_cfg().BACKBONE_3D
+    bb = models.__all__["VoxelBackBone8x"](cfg, input_channels=5, grid_size=[1504, 1504, 40], num_frames=1)
+    sd = bb.state_dict()
+    convs = sorted(k for k in sd if sd[k].dim() == 5)
+    assert convs == sorted(["conv_input.0.weight", "conv1.0.0.weight", "conv_out.0.weight"] +
+                           ["conv%d.%d.0.weight" % (s, i) for s in (2, 3, 4) for i in (0, 1, 2)])
+    assert tuple(sd["conv2.0.0.weight"].shape) == (32, 3, 3, 3, 16) and tuple(sd["conv_out.0.weight"].shape) == (128, 3, 1, 1, 128)
+    assert not any(k.endswith(".bias") and sd[k].dim() == 1 and ".0.bias" in k for k in sd)      # post_act_block convs carry no bias
+    assert bb.sparse_shape == [41, 1504, 1504] and bb.num_point_features == {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 128}
+    cfg.MM = True
+    mm = models.VoxelBackBone8x(cfg, input_channels=5, grid_size=[400, 400, 40])
+    assert "conv4_2.2.0.weight" in mm.state_dict() and "conv_input_2.0.weight" in mm.state_dict()
