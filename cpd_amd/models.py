@@ -935,7 +935,11 @@ def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
         box_scores, box_preds = box_scores[mask], box_preds[mask]
     selected = box_scores.new_zeros((0,), dtype=torch.long)
     if box_scores.shape[0] > 0:
-        top, order = torch.topk(box_scores, k=min(nms_config["NMS_PRE_MAXSIZE"], box_scores.shape[0]))
+        # (the reference's torch.topk leaves the order of EQUAL scores to the implementation; here, and in the fused engine, ties go
+        # to the lower index -- a stable descending sort -- so that both paths keep the same boxes among tied, overlapping ones)
+        ranked, order = torch.sort(box_scores, descending=True, stable=True)
+        k = min(nms_config["NMS_PRE_MAXSIZE"], box_scores.shape[0])
+        top, order = ranked[:k], order[:k]
         fn = getattr(iou3d_nms_utils, nms_config["NMS_TYPE"])
         keep, _ = fn(box_preds[order][:, 0:7], top, nms_config["NMS_THRESH"])
         selected = order[keep[:nms_config["NMS_POST_MAXSIZE"]]]

@@ -81,7 +81,7 @@ class VoxelRCNNEngine:
         pp, nms = self.post_cfg, self.post_cfg["NMS_CONFIG"]
         scores = torch.sigmoid(cls).max(dim=-1)[0]                       # (B, R); class-agnostic head: one column
         ok = scores >= pp["SCORE_THRESH"]
-        ranked, order = torch.sort(torch.where(ok, scores, torch.full_like(scores, -1.0)), dim=1, descending=True)
+        ranked, order = torch.sort(torch.where(ok, scores, torch.full_like(scores, -1.0)), dim=1, descending=True, stable=True)   # ties: lower index first
         n_ok = ok.sum(dim=1).clamp(max=int(nms["NMS_PRE_MAXSIZE"])).to(torch.int32)
         sboxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 7)).contiguous()
         slabels = torch.gather(roi_labels, 1, order).to(torch.int32).contiguous()
