@@ -444,7 +444,7 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
     return out
 
 
-def train_step_extra(args, cfg, sd, dev, steps=12, warmup=4, clouds=None):
+def train_step_extra(args, cfg, sd, dev, steps=12, warmup=4, clouds=None, frames=1):
     """Config 3 inside the default run: CenterPointTrainer.step on one frame per step (voxelize, training-mode forward, CenterHead
     targets + loss, backward, all-reduce no-op at N = 1, Adam, weight repack)."""
     from cpd_amd.synthetic import gt_boxes
@@ -456,10 +456,11 @@ def train_step_extra(args, cfg, sd, dev, steps=12, warmup=4, clouds=None):
     last = [None]
 
     def step(i):
-        last[0] = tr.step([clouds[i % POOL]], torch.stack([gts[i % POOL]]))
+        idx = [(i * frames + j) % POOL for j in range(frames)]
+        last[0] = tr.step([clouds[k] for k in idx], torch.stack([gts[k] for k in idx]))
 
     sec = time_steps(step, steps, warmup)
-    return {"ms_per_step": 1e3 * sec, "frames_per_s": 1.0 / sec, "steps": steps, "frames_per_step": 1,
+    return {"ms_per_step": 1e3 * sec, "frames_per_s": frames / sec, "steps": steps, "frames_per_step": frames,
             "arithmetic": {"forward": tr.store.math, "gradients": tr.store.grad_math if tr.store.math != "f32" else "f32"},
             "batch_norm": "training mode (batch statistics)", "final_loss": float(last[0][0])}
 
@@ -853,6 +854,9 @@ def main():
         out.update(extras(args, cfg, sd, dev, clouds, out["value"], streams))
         torch.cuda.empty_cache()
         out["train_step"] = train_step_extra(args, cfg, sd, dev, clouds=clouds)
+        torch.cuda.empty_cache()
+        # config 3 prescribes one frame per GPU; one frame does not fill the chip -- the same step at 8 frames per GPU for comparison
+        out["train_step_8frames"] = train_step_extra(args, cfg, sd, dev, steps=6, warmup=2, clouds=clouds, frames=8)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, clouds_np)
