@@ -159,6 +159,106 @@ rulebook_kernel(const int32_t *__restrict__ out_idx, int n_out, Grid gin, int kd
 
 #pragma clang diagnostic pop
 
+// ---- rulebook of a CHUNK-ORDERED level (round 4) ---------------------------------------------------------------------------------
+// rulebook_kernel above walks the output rows in THEIR order, one row per lane. For a level in tap-pattern order the rows of a wave are
+// not neighbours in space: its nine (z, y) bitmap-word / prefix fetches and its 27 rank -> row fetches go to 64 different cache
+// lines per instruction -- one L1 tag lookup per lane, ~2900 per 64 rows: the kernel runs at the L1's lookup rate (a tap-ordered
+// level cost 2.2x a canonical one, profiles/README.md). But a chunk-ordered level (cpd_order_rows_by_taps) permutes rows only INSIDE
+// chunks of `chunk` canonical rows. So: one workgroup per chunk walks the chunk's rows in CANONICAL order -- lanes are x-neighbours,
+// their words, prefixes and neighbour ranks coincide or are adjacent: a few lines per instruction --, drops each row's three dx taps
+// of one (dz, dy) into an LDS stage at the row's NEW position (old_to_new - chunk start), and the stage goes out as whole lines:
+// nbr[t][chunk start ...]. Nine such passes; the tap masks come from the staged values (16 new rows = 16 consecutive lanes).
+// Same table, bit for bit. 3 x 3 x 3 kernels, any stride / padding.
+#define CPD_RBC_CHUNK 4096
+__global__ void __launch_bounds__(1024)
+rulebook_chunk_kernel(const int32_t *__restrict__ out_canon, const int32_t *__restrict__ out_o2n, int n_out, Grid gin, int sd, int sh, int sw,
+                      int pd, int ph, int pw, const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
+                      const int32_t *__restrict__ perm_in, const int32_t *__restrict__ flags, int32_t *__restrict__ nbr,
+                      uint32_t *__restrict__ tapmask) {
+    __shared__ int32_t stage[3][CPD_RBC_CHUNK];
+    constexpr int RPT = CPD_RBC_CHUNK / 1024;                       // rows per thread
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * CPD_RBC_CHUNK;
+    const int32_t *perm = index_order(flags, perm_in);
+    int4 q[RPT];
+    int dst[RPT];                                                   // new position inside the chunk (-1: no such row)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int j = c0 + k * 1024 + tid;                          // canonical row
+        dst[k] = -1;
+        q[k] = make_int4(0, 0, 0, 0);
+        if (j < n_out) {
+            q[k] = reinterpret_cast<const int4 *>(out_canon)[j];
+            dst[k] = (out_o2n ? out_o2n[j] : j) - c0;
+        }
+    }
+    uint32_t pattern[RPT];                                          // per NEW row c0 + k * 1024 + tid: which taps exist
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) pattern[k] = 0;
+    for (int tzy = 0; tzy < 9; ++tzy) {
+        const int tz = tzy / 3, ty = tzy - 3 * tz;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            if (dst[k] < 0) continue;
+            const int z = q[k].y * sd - pd + tz, y = q[k].z * sh - ph + ty;
+            const int x0 = q[k].w * sw - pw;
+            int32_t r3[3] = {-1, -1, -1};
+            if ((unsigned)z < (unsigned)gin.d && (unsigned)y < (unsigned)gin.h && (unsigned)q[k].x < (unsigned)gin.b) {
+                const long long rowkey = gin.key(q[k].x, z, y, 0);
+                const int xlo = x0 < 0 ? 0 : x0, xhi = x0 + 2 < gin.w ? x0 + 2 : gin.w - 1;
+                if (xlo <= xhi) {
+                    const long long wia = (rowkey + xlo) >> 6, wib = (rowkey + xhi) >> 6;
+                    const uint64_t wa = bitmap[wia];
+                    const uint32_t ba = base[wia];
+                    uint64_t wb = wa;
+                    uint32_t bb = ba;
+                    if (wib != wia) { wb = bitmap[wib]; bb = base[wib]; }
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        const int x = x0 + tx;
+                        if ((unsigned)x >= (unsigned)gin.w) continue;
+                        const long long kk = rowkey + x;
+                        const bool first = (kk >> 6) == wia;
+                        const uint64_t w = first ? wa : wb;
+                        const uint64_t bit = 1ull << (kk & 63);
+                        if (w & bit) {
+                            int32_t r = (int32_t)((first ? ba : bb) + __popcll(w & (bit - 1ull)));
+                            if (perm) r = perm[r];
+                            r3[tx] = r;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) stage[tx][dst[k]] = r3[tx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = k * 1024 + tid, row = c0 + i;
+            if (row < n_out) {
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const int32_t v = stage[tx][i];
+                    nbr[(size_t)(3 * tzy + tx) * n_out + row] = v;
+                    if (v >= 0) pattern[k] |= 1u << (3 * tzy + tx);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tapmask) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {                             // 16 consecutive new rows = 16 consecutive lanes: OR over each 16-lane group
+            uint32_t m = pattern[k];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m |= (uint32_t)__shfl_xor((int)m, o, 16);
+            const int row = c0 + k * 1024 + tid;
+            if ((tid & 15) == 0 && row < n_out) tapmask[row >> 4] = m;
+        }
+    }
+}
+
 // Output sites of a regular (strided) sparse conv: every input site marks the output cells whose receptive field holds it.
 // One thread per input site; for each (z', y') output row it reaches, the x' cells it reaches form a mask inside ONE 64-cell
 // bitmap word (two at a word boundary: the second part goes out on its own). Neighbouring sites of a row -- consecutive lanes
@@ -526,6 +626,27 @@ extern "C" int cpd_rulebook_conv(const int32_t *out_indices, int n_out, int batc
     int rc = cpd_conv_out_shape(in_shape, ksize, stride, pad, os);
     if (rc) return rc;
     return rulebook_launch(out_indices, n_out, batch, in_shape, ksize, stride, pad, in_index, nbr, tapmask, cpd_s(stream));
+}
+
+
+// The same tables as cpd_rulebook_subm / cpd_rulebook_conv for a CHUNK-ORDERED output level: `out_canonical` [n_out][4] is the level's
+// canonical site list and `out_old_to_new` [n_out] its order (canonical row -> row; rows move only inside chunks of 4096 canonical
+// rows: cpd_order_rows_by_taps with chunk_rows = 4096; NULL = canonical). Rows of nbr / tapmask are in the NEW order, bit for bit what
+// the plain builders give over the re-ordered list -- built by walking each chunk in canonical order (coalesced index reads) and
+// re-ordering it in LDS (rulebook_chunk_kernel). 3 x 3 x 3 kernels only (else CPD_ERR_UNSUPPORTED).
+extern "C" int cpd_rulebook_chunk_ordered(const int32_t *out_canonical, const int32_t *out_old_to_new, int n_out, int batch,
+                                          const int32_t in_shape[3], const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3],
+                                          const void *in_index, int chunk_rows, int32_t *nbr, uint32_t *tapmask, cpd_stream_t stream) {
+    if (!valid_shape(batch, in_shape) || n_out < 0 || !in_index || !ksize || !stride || !pad || (n_out > 0 && (!out_canonical || !nbr)))
+        return CPD_ERR_ARG;
+    if (ksize[0] != 3 || ksize[1] != 3 || ksize[2] != 3 || chunk_rows != CPD_RBC_CHUNK) return CPD_ERR_UNSUPPORTED;
+    if (n_out == 0) return CPD_OK;
+    IndexView v = index_carve(const_cast<void *>(in_index), batch, in_shape, 1);
+    Grid g{batch, in_shape[0], in_shape[1], in_shape[2]};
+    rulebook_chunk_kernel<<<cpd_div_up(n_out, CPD_RBC_CHUNK), 1024, 0, cpd_s(stream)>>>(out_canonical, out_old_to_new, n_out, g, stride[0], stride[1],
+                                                                                         stride[2], pad[0], pad[1], pad[2], v.bitmap, v.base, v.perm,
+                                                                                         v.flags, nbr, tapmask);
+    return cpd_check_launch();
 }
 
 extern "C" int cpd_conv_outset(const int32_t *in_indices, int n_in, int batch, const int32_t in_shape[3],

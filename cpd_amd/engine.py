@@ -73,6 +73,7 @@ class ModelConfig:
     # bricks + plan 956 (the staged kernel moves half the bytes through the L1 but holds 8-12 waves per CU, not 25).
     row_order: str = "taps"
     row_order_brick: tuple = (8, 8)
+    chunked_rulebooks: bool = True         # "taps": rulebooks of the re-ordered levels built chunk-wise in canonical order (ops.rulebook_*(canonical=))
     plan_rulebooks: bool = False           # "bricks" only: plan the sub-manifold rulebooks -> the staged row-wave kernel
     row_order_chunk: int = 4096
     row_order_min_rows: int = 65536        # below this a level does not fill the chip either way
@@ -411,17 +412,22 @@ class CenterPointEngine:
             if bricks:
                 out_idx, _, old_to_new = ops.order_rows_bricks(out_c, out_index, brick=self.cfg.row_order_brick)
                 out_index.set_order(old_to_new)
+            canon = None                      # (canonical list, order, chunk) of a chunk-ordered level: its tables are built chunk-wise
+            if bricks:
+                pass
             elif self.cfg.row_order == "taps" and out_idx.shape[0] >= self.cfg.row_order_min_rows:
                 # rows of the level sorted, chunk by chunk, by their neighbour pattern (ops.order_rows_by_taps): the level's
                 # site list in the new order + the rank -> row map installed in its index re-order everything that follows
                 # (both rulebooks, the features, the exported level) without any kernel knowing
                 out_idx, _, old_to_new = ops.order_rows_by_taps(out_c, out_index, chunk_rows=self.cfg.row_order_chunk)
                 out_index.set_order(old_to_new)
-            nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
+                if self.cfg.chunked_rulebooks:
+                    canon = (out_c, old_to_new, self.cfg.row_order_chunk)
+            nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd, canonical=canon)
             # (pair rows are read through the row-wave kernel's 4 GB buffer resource: a level that large stays fp32)
             pairs_out = pairs and out_idx.shape[0] * L[stage + ".down"].c_out * 4 < 0xfffff000
             x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in, out_pairs=pairs_out)
-            nbr = ops.rulebook_subm(out_idx, out_index)
+            nbr = ops.rulebook_subm(out_idx, out_index, canonical=canon)
             if bricks and pairs_out and self.cfg.plan_rulebooks:
                 ops.rulebook_plan(nbr)                         # the level's four SubM convs: the staged row-wave kernel
             x = self._blocks(L[stage], x, nbr, pairs=pairs_out)

@@ -208,7 +208,24 @@ def _new_tapmask(n, kv, device):
     return torch.empty(((n + 15) // 16,), dtype=torch.int32, device=device)
 
 
-def rulebook_subm(indices, index, ksize=(3, 3, 3)):
+def _rulebook_chunked(canonical, in_index, ksize, stride, pad, n):
+    """the table of a chunk-ordered level, built chunk by chunk in canonical order (cpd_rulebook_chunk_ordered); `canonical` =
+    (canonical site list, old_to_new or None, chunk_rows)"""
+    out_c, o2n, chunk = canonical
+    dev = out_c.device
+    nbr = torch.empty((27, n), dtype=torch.int32, device=dev)
+    tapmask = _new_tapmask(n, 27, dev)
+    check(lib().cpd_rulebook_chunk_ordered(ptr(out_c.contiguous()), ptr(o2n), n, in_index.batch, iarr(in_index.shape), iarr(ksize), iarr(stride),
+                                           iarr(pad), ptr(in_index.buf), int(chunk), ptr(nbr), ptr(tapmask), stream()), "cpd_rulebook_chunk_ordered")
+    nbr.tapmask = tapmask
+    return nbr
+
+
+def rulebook_subm(indices, index, ksize=(3, 3, 3), canonical=None):
+    """`canonical` = (canonical site list, old_to_new, chunk_rows) of a level whose `indices` are chunk-ordered (order_rows_by_taps,
+    chunk_rows = 4096): same table, built by the chunk-wise kernel (3 x 3 x 3 only)."""
+    if canonical is not None and tuple(ksize) == (3, 3, 3) and canonical[2] == 4096:
+        return _rulebook_chunked(canonical, index, ksize, (1, 1, 1), (1, 1, 1), indices.shape[0])
     indices = indices.contiguous()
     n = indices.shape[0]
     kv = int(ksize[0] * ksize[1] * ksize[2])
@@ -243,7 +260,9 @@ def conv_outset(in_indices, batch, in_shape, ksize, stride, pad):
     return out_indices, out_index, out_shape
 
 
-def rulebook_conv(out_indices, in_index, ksize, stride, pad):
+def rulebook_conv(out_indices, in_index, ksize, stride, pad, canonical=None):
+    if canonical is not None and tuple(ksize) == (3, 3, 3) and canonical[2] == 4096:
+        return _rulebook_chunked(canonical, in_index, ksize, stride, pad, out_indices.shape[0])
     out_indices = out_indices.contiguous()
     n_out = out_indices.shape[0]
     kv = int(ksize[0] * ksize[1] * ksize[2])

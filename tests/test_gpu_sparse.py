@@ -410,3 +410,36 @@ def test_kernels_with_more_than_32_taps_fail_loudly_or_run_exactly(oracle, hip):
         assert all(k.startswith(("tile_conv_f16_kernel", "split_finish")) for k in log.counts), log.counts
         np.testing.assert_allclose(got, oracle.sparse_conv(feat, w, None, nbr.cpu().numpy()), atol=1e-4, rtol=0)
 
+
+
+@pytest.mark.gpu
+def test_chunk_ordered_rulebooks_equal_the_plain_builders(hip):
+    """cpd_rulebook_chunk_ordered (round 4): the SubM and the strided tables of a tap-ordered level, built chunk by chunk in canonical
+    order and re-ordered in LDS, are bit for bit the tables (and tap masks) cpd_rulebook_subm / cpd_rulebook_conv build over the
+    re-ordered list -- on a level with several chunks, a ragged last chunk, and an input level that is itself re-ordered."""
+    import torch
+    from cpd_amd import ops
+    rng = np.random.default_rng(77)
+    shape, B = [21, 120, 130], 2
+    cells = np.unique(np.stack([rng.integers(0, B, 60000), rng.integers(0, shape[0], 60000), rng.integers(0, shape[1], 60000),
+                                rng.integers(0, shape[2], 60000)], 1), axis=0).astype(np.int32)
+    idx = torch.from_numpy(cells).cuda()
+    index = ops.SiteIndex.build(idx, B, shape)
+    new_idx, _, o2n = ops.order_rows_by_taps(idx, index, chunk_rows=4096)
+    index.set_order(o2n)
+    plain = ops.rulebook_subm(new_idx, index)
+    chunked = ops.rulebook_subm(new_idx, index, canonical=(idx, o2n, 4096))
+    assert new_idx.shape[0] % 4096 != 0 and new_idx.shape[0] > 3 * 4096
+    assert torch.equal(plain, chunked) and torch.equal(plain.tapmask, chunked.tapmask)
+    # strided level on top of the re-ordered one
+    k, s, pd = [3, 3, 3], [2, 2, 2], [1, 1, 1]
+    out_c, out_index, out_shape = ops.conv_outset(idx, B, shape, k, s, pd)
+    out_new, _, out_o2n = ops.order_rows_by_taps(out_c, out_index, chunk_rows=4096)
+    plain_dn = ops.rulebook_conv(out_new, index, k, s, pd)
+    chunked_dn = ops.rulebook_conv(out_new, index, k, s, pd, canonical=(out_c, out_o2n, 4096))
+    assert torch.equal(plain_dn, chunked_dn) and torch.equal(plain_dn.tapmask, chunked_dn.tapmask)
+    # canonical output order (no map) over the re-ordered input, both paddings of the backbone
+    for pad in ([1, 1, 1], [0, 1, 1]):
+        a = ops.rulebook_conv(out_c, index, k, s, pad)
+        b = ops.rulebook_conv(out_c, index, k, s, pad, canonical=(out_c, None, 4096))
+        assert torch.equal(a, b) and torch.equal(a.tapmask, b.tapmask)
