@@ -18,8 +18,6 @@
 // go through perm[rank]; canonical lists use rank directly.
 #include "common.h"
 
-#include <rocprim/block/block_radix_sort.hpp>
-
 #include "site_index_layout.h"
 
 namespace {
@@ -432,30 +430,106 @@ extern "C" int cpd_index_build(const int32_t *indices, int n, int batch, const i
 // of every CHUNK of consecutive canonical rows by their kv-bit neighbour pattern makes the groups nearly uniform (executed /
 // useful 1.33-1.55 -> 1.06-1.12 on the Waymo-shape levels) while a chunk's rows stay within the same few thousand rows, so the
 // gathers keep their cache locality.
-// One workgroup per chunk: a stable LSD radix sort (rocPRIM's block primitive: digit ranking with packed LDS counters) of the 27-bit
+// One workgroup per chunk: a stable LSD radix sort (BlockSort27 below) of the 27-bit
 // patterns with the local row as payload -- equal patterns keep their canonical order, the result is deterministic. (A bitonic
 // network does log^2 work: 1800 lane-operations per row at 8192 rows, 100+ us on the one CU a chunk lives on; the radix passes
 // need ~ 250.)
+// Block-wide STABLE sort of T * E (27-bit key, payload) pairs, hand-written (round 4; rocPRIM's block_radix_sort did this until
+// round 3 -- the one vendor primitive of the hot path). LSD radix, four passes of 7 bits. Items live in registers in "wave-striped"
+// order: wave w owns positions [w * 64 E, (w + 1) * 64 E), slot e of lane l is position (w * E + e) * 64 + l -- so walking the slots
+// of a wave in order IS walking its positions in order. One pass: per slot the lanes of a wave with the same digit find each other
+// with seven ballots (peer mask), a lane's rank among them is a popcount, the wave's running count per digit sits in LDS
+// (hist[digit][wave]: only this wave touches its column -- no atomics); an exclusive scan over (digit major, wave minor) turns the
+// counts into bases; position = base + count before this slot + rank among peers: equal digits keep their order. Keys and payloads
+// go through one LDS buffer (scatter, barrier, read back in wave-striped order).
+template <int T, int E>
+struct BlockSort27 {
+    static constexpr int W = T / 64, N = T * E;
+    struct Storage {
+        uint32_t key[N], val[N];
+        uint32_t hist[128 * W + 1];
+        uint32_t scan_tmp[17];
+    };
+    __device__ static void sort(uint32_t (&key)[E], uint32_t (&val)[E], Storage &sm) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int shift = 0; shift < 27; shift += 7) {
+            for (int i = tid; i < 128 * W; i += T) sm.hist[i] = 0;
+            __syncthreads();
+            uint32_t rank[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t d = (key[e] >> shift) & 127u;
+                unsigned long long peers = ~0ull;
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    const unsigned long long m = __ballot((d >> b) & 1u);
+                    peers &= ((d >> b) & 1u) ? m : ~m;
+                }
+                const uint32_t before = sm.hist[d * W + wave];                  // this wave's earlier slots with digit d
+                rank[e] = before + (uint32_t)__popcll(peers & lt);
+                __builtin_amdgcn_wave_barrier();
+                if ((peers & lt) == 0ull) sm.hist[d * W + wave] = before + (uint32_t)__popcll(peers);     // the peers' lowest lane
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+            // exclusive scan of hist[128 * W] (digit major, wave minor): T threads, (128 W) / T entries each
+            constexpr int PER = (128 * W + T - 1) / T;
+            uint32_t loc[PER], sum = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = tid * PER + k;
+                loc[k] = i < 128 * W ? sm.hist[i] : 0u;
+                sum += loc[k];
+            }
+            uint32_t tot;
+            uint32_t ex = block_excl_scan(sum, sm.scan_tmp, &tot);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = tid * PER + k;
+                if (i < 128 * W) sm.hist[i] = ex;
+                ex += loc[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t d = (key[e] >> shift) & 127u;
+                const uint32_t pos = sm.hist[d * W + wave] + rank[e];
+                sm.key[pos] = key[e];
+                sm.val[pos] = val[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = (wave * E + e) * 64 + lane;
+                key[e] = sm.key[i];
+                val[e] = sm.val[i];
+            }
+            __syncthreads();
+        }
+    }
+};
+
 // `pre_n2o` (optional): the list being sorted is itself a re-ordering of the canonical list (cpd_order_rows_bricks): position ->
 // canonical row; new_to_old / old_to_new are then written against the canonical rows.
 template <int T, int E>
 __global__ void __launch_bounds__(T) order_rows_kernel(const uint32_t *__restrict__ pattern, const int32_t *__restrict__ coords, int n,
                                                        int32_t *__restrict__ new_to_old, int32_t *__restrict__ old_to_new,
                                                        int32_t *__restrict__ coords_out, const int32_t *__restrict__ pre_n2o = nullptr) {
-    using sort_t = rocprim::block_radix_sort<unsigned int, T, E, unsigned int>;
-    __shared__ typename sort_t::storage_type storage;
-    const int c0 = blockIdx.x * (T * E), tid = threadIdx.x;
-    unsigned int key[E], val[E];
+    using sort_t = BlockSort27<T, E>;
+    __shared__ typename sort_t::Storage storage;
+    const int c0 = blockIdx.x * (T * E), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t key[E], val[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int i = tid * E + e, row = c0 + i;
+        const int i = (wave * E + e) * 64 + lane, row = c0 + i;          // wave-striped: position i of the chunk
         key[e] = row < n ? (pattern[row] & 0x7ffffffu) : 0x7ffffffu;      // padding rows: largest key, and last among equals
         val[e] = (unsigned)i;
     }
-    sort_t().sort(key, val, storage, 0, 27);
+    sort_t::sort(key, val, storage);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int row = c0 + tid * E + e;
+        const int row = c0 + (wave * E + e) * 64 + lane;
         if (row < n) {
             const int old = c0 + (int)val[e];
             const int canon = pre_n2o ? pre_n2o[old] : old;
@@ -465,7 +539,6 @@ __global__ void __launch_bounds__(T) order_rows_kernel(const uint32_t *__restric
         }
     }
 }
-
 
 // ---- brick order (round 4) ---------------------------------------------------------------------------------------------------
 // The staged row-wave kernel fetches a tile's DISTINCT input rows once; how many there are depends on how close in space the tile's

@@ -4,7 +4,7 @@ usage: pmc_rowwave_summary.py <pass dir> <out.json> [name filter regex]"""
 import collections, csv, glob, json, re, sys
 
 root, outp = sys.argv[1], sys.argv[2]
-filt = re.compile(sys.argv[3] if len(sys.argv) > 3 else r"(rowwave|window|tile|gather)_conv")
+filt = re.compile(sys.argv[3] if len(sys.argv) > 3 else r"(rowwave|rowplan|window|tile|gather)_conv")
 
 
 def short(n):
