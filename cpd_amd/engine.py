@@ -73,6 +73,9 @@ class ModelConfig:
     # bricks + plan 956 (the staged kernel moves half the bytes through the L1 but holds 8-12 waves per CU, not 25).
     row_order: str = "taps"
     row_order_brick: tuple = (8, 8)
+    # "taps": level 0 (the voxel list) in tap-pattern order as well, when the voxelizer delivered canonical rows. Measured, same box, two
+    # pairs: level-1 convs 51.8 -> 46.7 us/frame, rulebooks + the sort + the feature gather +6 us: 1046 vs 1049.5 frames/s -> off
+    row_order_level0: bool = False
     chunked_rulebooks: bool = True         # "taps": rulebooks of the re-ordered levels built chunk-wise in canonical order (ops.rulebook_*(canonical=))
     plan_rulebooks: bool = False           # "bricks" only: plan the sub-manifold rulebooks -> the staged row-wave kernel
     row_order_chunk: int = 4096
@@ -380,7 +383,7 @@ class CenterPointEngine:
             x = self._conv(c2, y, nbr, n, residual=x, in_pairs=pairs, out_pairs=pairs, res_pairs=pairs)
         return x
 
-    def backbone3d(self, feats, coords, batch, index=None, pair_rows=False, export_levels=True):
+    def backbone3d(self, feats, coords, batch, index=None, pair_rows=False, export_levels=True, canonical0=False):
         """VoxelResBackBone8x.forward (spconv_backbone.py:502-558). Returns per-level
         {name: (features, indices, spatial_shape)} and the stride-8 output. `index`: the level-0 site index when the
         voxelizer already built it (cpd_voxelize_batch_index). `pair_rows`: levels 2-4 keep their activations as fp16-pair rows
@@ -393,7 +396,17 @@ class CenterPointEngine:
         shape = self.cfg.sparse_shape
         if index is None:
             index = ops.SiteIndex.build(coords, batch, shape)
-        nbr = ops.rulebook_subm(coords, index)               # 'subm1' and 'res1' are the same L0 table
+        coords_c0, canon0 = coords, None
+        if canonical0 and self.cfg.row_order == "taps" and self.cfg.row_order_level0 and coords.shape[0] >= self.cfg.row_order_min_rows:
+            # level 0 in tap-pattern order too (round 4): its rows have 4.3 of 27 neighbours on average, and a canonical 16-row group
+            # executes 2.2x the (group, tap) pairs its rows need -- 1.3x after the sort (tools/unique_probe.py). `canonical0`: the
+            # voxelizer delivered canonical rows and a canonical index (rank = row), which is what the sort and the map need.
+            coords, n2o, o2n = ops.order_rows_by_taps(coords_c0, index, chunk_rows=self.cfg.row_order_chunk)
+            index.set_order(o2n)
+            feats = feats.index_select(0, n2o.long())
+            if self.cfg.chunked_rulebooks:
+                canon0 = (coords_c0, o2n, self.cfg.row_order_chunk)
+        nbr = ops.rulebook_subm(coords, index, canonical=canon0)               # 'subm1' and 'res1' are the same L0 table
         self._range_reset()                                  # (the 5-channel input layer runs on the fp32 pipe: no block for `feats`)
         # level 1 (16 channels): with pair rows its layers run the K = 16 split-fp16 MFMA on 16-channel pair rows (three products of
         # 16 matrix cycles instead of four fp32 MFMAs of 32); the 5-channel input layer stays on the fp32 pipe and writes the first pairs
@@ -402,7 +415,7 @@ class CenterPointEngine:
         x = self._blocks(L["conv1"], x, nbr, pairs=pairs16)
         levels = {"x_conv1": (ops.pairs_to_rows(x) if pairs16 and want("x_conv1") else x, coords, shape)}
         self.level_indexes["x_conv1"] = index
-        coords_c = coords                  # the list the next level's output set is marked from: canonical order wherever one exists
+        coords_c = coords_c0               # the list the next level's output set is marked from: canonical order wherever one exists
         pairs_in = pairs16                 # (what conv2.down reads)
         for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
             k, s, pd = _DOWN[stage]
@@ -558,6 +571,7 @@ class CenterPointEngine:
             points_list = [points_list]
         batch = len(points_list)
         index0 = None
+        canonical0 = False
         z_extra = self.cfg.sparse_shape[0] - self.cfg.grid_zyx[0]
         if batch > 1 and self.voxelizer.batch_supported(batch, z_extra):
             # one set of voxelizer launches for the whole batch; rows come out frame after frame; the voxelizer's occupancy
@@ -572,6 +586,7 @@ class CenterPointEngine:
                 counts = nvox.tolist()
             total = counts[batch]
             feats, coords = feats[:total], coords[:total]
+            canonical0 = canonical and max(counts[:batch]) <= self.cfg.max_voxels
         elif batch > 1 and self.voxelizer.batch_supported(self.cfg.voxelizer_group, z_extra):
             # more frames than one batched-voxelizer call takes: groups of `voxelizer_group` frames, one voxelizer
             # (workspace) per group, rows concatenated with the frame index offset; the level-0 index is built over the whole list
@@ -611,7 +626,7 @@ class CenterPointEngine:
         self._rb_scaled = self._guard_left > 0
         self._range_high = False
         while True:
-            levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0,
+            levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0, canonical0=canonical0,
                                                               export_levels=proposals if proposals is not None else return_intermediates,
                                                               pair_rows=self.cfg.pair_rows and not self._rb_scaled)
             d, h, w = out_shape
