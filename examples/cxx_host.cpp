@@ -2,7 +2,10 @@
 //   points (binary f32 file) -> cpd_voxelize (+ fused MeanVFE) -> cpd_index_build -> cpd_rulebook_subm
 //   -> cpd_pack_weight -> cpd_gather_conv (SubMConv3d 5 -> 16, weights from a binary f32 file)
 // and prints the voxel count and two checksums that tests/test_gpu_cxx_host.py compares with the Python
-// host path on the same inputs. Build: hipcc examples/cxx_host.cpp -Iinclude -Lcpd_amd/csrc -lcpd_hip.
+// host path on the same inputs. Round 4: the launch chain BETWEEN the count read-backs (index build -> rulebook -> conv; every entry
+// point takes a stream, allocates nothing and never synchronises: include/cpd_hip.h) is also captured into a hipGraph and replayed --
+// same bits out, and the per-replay time printed next to the direct launches' (fourth to sixth output tokens).
+// Build: hipcc examples/cxx_host.cpp -Iinclude -Lcpd_amd/csrc -lcpd_hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -79,6 +82,47 @@ int main(int argc, char **argv) {
     double s_mean = 0, s_out = 0;
     for (float v : mean) s_mean += v;
     for (float v : out) s_out += v;
-    printf("%d %.9e %.9e\n", m, s_mean, s_out);
-    return 0;
+
+    // ---- the same chain as a hipGraph: capture once, replay
+    hipStream_t st;
+    CHECK_HIP(hipStreamCreate(&st));
+    auto chain = [&](hipStream_t q) -> int {
+        CHECK_CPD(cpd_index_build(d_coords, m, 1, shape, d_index, index_bytes, q));
+        CHECK_CPD(cpd_rulebook_subm(d_coords, m, 1, shape, k3, d_index, d_nbr, d_mask, q));
+        CHECK_CPD(cpd_gather_conv(d_mean, C, m, C, d_pw, d_nbr, d_mask, KV, m, COUT, nullptr, nullptr, nullptr, 0, 1, d_out, COUT, nullptr, 0, 0, q));
+        return 0;
+    };
+    CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)m * COUT * 4, st));
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    if (int rc = chain(st)) return rc;
+    CHECK_HIP(hipStreamEndCapture(st, &graph));
+    CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    CHECK_HIP(hipGraphLaunch(exec, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    std::vector<float> out_g((size_t)m * COUT);
+    CHECK_HIP(hipMemcpy(out_g.data(), d_out, out_g.size() * 4, hipMemcpyDeviceToHost));
+    double s_graph = 0;
+    bool same = true;
+    for (size_t i = 0; i < out_g.size(); ++i) { s_graph += out_g[i]; same = same && out_g[i] == out[i]; }
+    hipEvent_t e0, e1;
+    CHECK_HIP(hipEventCreate(&e0));
+    CHECK_HIP(hipEventCreate(&e1));
+    const int reps = 50;
+    float ms_graph = 0, ms_direct = 0;
+    CHECK_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) CHECK_HIP(hipGraphLaunch(exec, st));
+    CHECK_HIP(hipEventRecord(e1, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    CHECK_HIP(hipEventElapsedTime(&ms_graph, e0, e1));
+    CHECK_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i)
+        if (int rc = chain(st)) return rc;
+    CHECK_HIP(hipEventRecord(e1, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    CHECK_HIP(hipEventElapsedTime(&ms_direct, e0, e1));
+    printf("%d %.9e %.9e %s %.1f %.1f\n", m, s_mean, s_out, same ? "graph_bitwise_equal" : "graph_DIFFERS", 1e3 * ms_graph / reps, 1e3 * ms_direct / reps);
+    (void)s_graph;
+    return same ? 0 : 4;
 }

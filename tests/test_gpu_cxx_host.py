@@ -24,7 +24,10 @@ def test_cxx_host_matches_python_host(hip, tmp_path):
     w.tofile(tmp_path / "weights.f32")
     out = subprocess.run([exe, str(tmp_path / "points.f32"), str(tmp_path / "weights.f32")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    m, s_mean, s_out = out.stdout.split()
+    m, s_mean, s_out, graph, us_graph, us_direct = out.stdout.split()
+    # the chain between the read-backs (index build -> rulebook -> conv), captured into a hipGraph and replayed: same bits
+    assert graph == "graph_bitwise_equal" and float(us_graph) > 0 and float(us_direct) > 0
+    print("cxx host: %s us per graph replay, %s us per direct chain" % (us_graph, us_direct))
     vox = ops.Voxelizer(WAYMO["voxel_size"], WAYMO["point_cloud_range"], 5, 5, 1000000)
     _, coords, _, mean, n = vox(torch.from_numpy(pts).cuda(), batch_idx=0, coord_cols=4, want_voxels=False, want_mean=True, sync=True)
     assert int(m) == n

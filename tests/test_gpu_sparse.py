@@ -419,6 +419,7 @@ def test_chunk_ordered_rulebooks_equal_the_plain_builders(hip):
     re-ordered list -- on a level with several chunks, a ragged last chunk, and an input level that is itself re-ordered."""
     import torch
     from cpd_amd import ops
+    ops.CHUNKED_MIN_ROWS, keep_min = 0, ops.CHUNKED_MIN_ROWS          # (the level here is far below the size the engine switches at)
     rng = np.random.default_rng(77)
     shape, B = [21, 120, 130], 2
     cells = np.unique(np.stack([rng.integers(0, B, 60000), rng.integers(0, shape[0], 60000), rng.integers(0, shape[1], 60000),
@@ -443,3 +444,4 @@ def test_chunk_ordered_rulebooks_equal_the_plain_builders(hip):
         a = ops.rulebook_conv(out_c, index, k, s, pad)
         b = ops.rulebook_conv(out_c, index, k, s, pad, canonical=(out_c, None, 4096))
         assert torch.equal(a, b) and torch.equal(a.tapmask, b.tapmask)
+    ops.CHUNKED_MIN_ROWS = keep_min
