@@ -99,6 +99,7 @@ def parse():
                     help="internal row order of the strided sparse levels (ModelConfig.row_order)")
     ap.add_argument("--row-order-chunk", type=int, default=4096)
     ap.add_argument("--order-level0", type=int, choices=[0, 1], default=0, help="ModelConfig.row_order_level0")
+    ap.add_argument("--plan-tile", type=int, choices=[128, 256], default=256, help="ModelConfig.plan_tile_rows")
     ap.add_argument("--plan", type=int, choices=[0, 1], default=0, help="--row-order bricks: plan the sub-manifold rulebooks of levels 2-4 "
                     "(ModelConfig.plan_rulebooks: the staged row-wave kernel)")
     ap.add_argument("--pair-rows", type=int, choices=[0, 1, 2], default=2, help="fp16-pair rows between the f16x2 sparse layers "
@@ -643,7 +644,7 @@ def main():
     # "nccl" is RCCL on ROCm; CPD_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests
     distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"), torch.device("cuda", local))
 
-    cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk, plan_rulebooks=bool(args.plan), row_order_level0=bool(args.order_level0), pair_rows=bool(args.pair_rows),
+    cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk, plan_rulebooks=bool(args.plan), plan_tile_rows=args.plan_tile, row_order_level0=bool(args.order_level0), pair_rows=bool(args.pair_rows),
                       pair_rows_level1=args.pair_rows == 2)
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local

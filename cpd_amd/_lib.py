@@ -43,12 +43,12 @@ SIGNATURES = {
     "cpd_index_build": (_I, [_VP, _I, _I, _I3, _VP, _SZ, _VP]),
     "cpd_order_rows_by_taps": (_I, [_VP, _I, _I, _I3, _I3, _VP, _I, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_index_set_order": (_I, [_VP, _VP, _VP]),
-    "cpd_order_rows_bricks": (_I, [_VP, _I, _I, _I3, _VP, _I, _I, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_order_rows_bricks": (_I, [_VP, _I, _I, _I3, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_rulebook_chunk_ordered": (_I, [_VP, _VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _I, _VP, _VP, _VP]),
-    "cpd_rulebook_plan_bytes": (_SZ, [_I, _I]),
-    "cpd_rulebook_plan": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP]),
+    "cpd_rulebook_plan_bytes": (_SZ, [_I, _I, _I]),
+    "cpd_rulebook_plan": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "cpd_gather_conv_planned_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
-    "cpd_gather_conv_planned": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
+    "cpd_gather_conv_planned": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     "cpd_rulebook_subm": (_I, [_VP, _I, _I, _I3, _I3, _VP, _VP, _VP, _VP]),
     "cpd_conv_out_shape": (_I, [_I3, _I3, _I3, _I3, _I3]),
     "cpd_conv_outset": (_I, [_VP, _I, _I, _I3, _I3, _I3, _I3, _VP, _SZ, _VP, _VP]),

@@ -1507,20 +1507,28 @@ rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcPar
 // whole batch of MFMAs, and a tap costs no global round trip. (The first version staged one tap's weights per barrier interval,
 // as the row-wave kernels do: at 3-4 workgroups per CU the L2 latency of every 4 KB weight block was exposed: 0.128 vs 0.093
 // ms/frame on the 32-channel level.)
-template <int BN, int TB>
+// ROWS = output rows per workgroup: 128 (4 waves) or 256 (8 waves: a stage's weights serve twice the rows -- the weight blocks every
+// tile re-fetches are the part of the L1 traffic that staging the rows does not touch -- and a CU holds 16 waves instead of 8-12;
+// the window grows to 384 slots: 366 distinct rows per dz group at most on the measured levels in 8 x 8 brick order).
+template <int ROWS> struct RpGeom;
+template <> struct RpGeom<128> { static constexpr int WIN = 224, P16 = 225; };   // P16: plane stride in 16-byte slots, odd and == 1 (mod 16)
+template <> struct RpGeom<256> { static constexpr int WIN = 384, P16 = 385; };
+template <int BN, int TB, int ROWS>
 __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const smem) {
+    constexpr int NTHR = 2 * ROWS, WIN = RpGeom<ROWS>::WIN, P16 = RpGeom<ROWS>::P16;
     typedef SplitF16x2 S;
     constexpr int NP = 2, NT = BN / 16, MS = 2;
     constexpr int NB = 9 / TB;                 // stages (tap batches) per window; TB = taps per weight stage
     char *const sw = smem;                                                  // one stage's weights
-    char *const swin = smem + TB * NP * BN * 64;                            // the window: 8 planes x 225 slots
-    uint16_t *const sslot = reinterpret_cast<uint16_t *>(swin + 8 * CPD_RP_P16 * 16);
+    char *const swin = smem + TB * NP * BN * 64;                            // the window: 8 planes x P16 slots
+    uint16_t *const sslot = reinterpret_cast<uint16_t *>(swin + 8 * P16 * 16);
     constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one tap (a multiple of 256)
     constexpr int B_IMG = BN * 64;             // bytes of one piece image of a tap
-    constexpr int WJ = TB * B_SLOTS / 256;     // weight pieces per thread and stage: 9 / 6 / 12
-    constexpr int JT = B_SLOTS / 256;          // ... per tap: 1 / 2 / 4
-    constexpr int PLANE = CPD_RP_P16 * 16;
-    constexpr int SJ = (CPD_RP_WIN * 8 + 255) / 256;                       // window pieces per thread: 7
+    constexpr int W_PIECES = TB * B_SLOTS;     // 16-byte pieces of one stage's weights
+    constexpr int WJ = (W_PIECES + NTHR - 1) / NTHR;                       // ... per thread
+    constexpr int PLANE = P16 * 16;
+    constexpr int SJ = (WIN * 8 + NTHR - 1) / NTHR;                        // window pieces per thread: 7 / 6
+    constexpr int SSTEP = NTHR / 8;                                        // slots between a thread's pieces
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -1529,8 +1537,8 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
     if (p.tapmask) {
         wg_mask = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int sub = tile * 8 + i;
+        for (int i = 0; i < ROWS / 16; ++i) {
+            const int sub = tile * (ROWS / 16) + i;
             const uint32_t m = sub < p.n_sub ? p.tapmask[sub] : 0u;
             wg_mask |= m;
 #pragma unroll
@@ -1552,14 +1560,14 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
         for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // the zero row of the window (slot CPD_RP_WIN of every plane): written once, never overwritten
-    if (tid < 8) *reinterpret_cast<f32x4u *>(swin + tid * PLANE + CPD_RP_WIN * 16) = f32x4u{0.f, 0.f, 0.f, 0.f};
+    if (tid < 8) *reinterpret_cast<f32x4u *>(swin + tid * PLANE + WIN * 16) = f32x4u{0.f, 0.f, 0.f, 0.f};
 
     const int sk = p.c_in >> 5;
     const uint32_t b_stage32 = (uint32_t)((size_t)NP * 4 * p.np * 16);     // bytes of one (tap, channel block) of the packed image
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0,
                                                                               (int)(uint32_t)(((size_t)p.n_in_rows * p.in_ld) * sizeof(float)), 0x00020000);
     const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
-    const int pc = tid & 7, slot0 = tid >> 3;                               // window piece of this thread: plane pc, slots slot0 + 32 j
+    const int pc = tid & 7, slot0 = tid >> 3;                               // window piece of this thread: plane pc, slots slot0 + SSTEP j
 
     // ---- the stage sequence (scalar state; every workgroup-uniform)
     struct Stage { int grp, base, kk, bt; };
@@ -1576,7 +1584,7 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
             new_win = true;
             if (++st.kk < sk) continue;
             st.kk = 0;
-            st.base += CPD_RP_WIN;
+            st.base += WIN;
             if (st.base < n_list[st.grp]) continue;
             st.base = 0;
             do { ++st.grp; } while (st.grp < 3 && !((wg_mask >> (9 * st.grp)) & 0x1ffu));
@@ -1592,32 +1600,32 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
         const uint32_t bm = batch_mask(st.grp, st.bt);
         const int t0 = 9 * st.grp + TB * st.bt;
 #pragma unroll
-        for (int tt = 0; tt < TB; ++tt) {
-            if (!((bm >> tt) & 1u)) continue;
+        for (int j = 0; j < WJ; ++j) {
+            const int i = j * NTHR + tid;                                   // piece of the stage image: tap i / B_SLOTS, piece i % B_SLOTS of it
+            const int tt = i / B_SLOTS, within = i - tt * B_SLOTS;
+            if ((W_PIECES % NTHR != 0 && i >= W_PIECES) || !((bm >> tt) & 1u)) continue;
             const char *wt = reinterpret_cast<const char *>(p.wb) + (uint32_t)((t0 + tt) * sk + st.kk) * b_stage32;
-#pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                if (CPD_GC_ABLATE & 65536) wreg[tt * JT + j] = f32x4u{(float)tt, 1.f, (float)j, 2.f};       // diagnostic builds: no weight loads
-                else wreg[tt * JT + j] = *reinterpret_cast<const f32x4u *>(wt + (uint32_t)(j * 256 + tid) * 16u);
-            }
+            if (CPD_GC_ABLATE & 65536) wreg[j] = f32x4u{(float)tt, 1.f, (float)j, 2.f};       // diagnostic builds: no weight loads
+            else wreg[j] = *reinterpret_cast<const f32x4u *>(wt + (uint32_t)within * 16u);
         }
     };
     auto write_weights = [&](const Stage &st) {
         const uint32_t bm = batch_mask(st.grp, st.bt);
 #pragma unroll
-        for (int tt = 0; tt < TB; ++tt) {
-            if (!((bm >> tt) & 1u)) continue;
-#pragma unroll
-            for (int j = 0; j < JT; ++j) *reinterpret_cast<f32x4u *>(sw + tt * (NP * B_IMG) + ((j * 256 + tid) << 4)) = wreg[tt * JT + j];
+        for (int j = 0; j < WJ; ++j) {
+            const int i = j * NTHR + tid;
+            const int tt = i / B_SLOTS;
+            if ((W_PIECES % NTHR != 0 && i >= W_PIECES) || !((bm >> tt) & 1u)) continue;
+            *reinterpret_cast<f32x4u *>(sw + (i << 4)) = wreg[j];           // (tap tt's image starts at tt * NP * B_IMG = tt * B_SLOTS * 16)
         }
     };
     auto issue_window = [&](const Stage &st, bool new_grp) {
-        const int32_t *const ulist = p.plan_ulist + ((size_t)tile * 3 + st.grp) * CPD_PLAN_LIST + st.base;
-        const int n_stage = n_list[st.grp] - st.base < CPD_RP_WIN ? n_list[st.grp] - st.base : CPD_RP_WIN;
+        const int32_t *const ulist = p.plan_ulist + ((size_t)tile * 3 + st.grp) * (9 * ROWS) + st.base;
+        const int n_stage = n_list[st.grp] - st.base < WIN ? n_list[st.grp] - st.base : WIN;
         uint32_t roff[SJ];
 #pragma unroll
         for (int j = 0; j < SJ; ++j) {
-            const int slot = slot0 + 32 * j;
+            const int slot = slot0 + SSTEP * j;
             const int id = slot < n_stage ? ulist[slot] : p.n_in_rows;      // beyond the list: out of range = zeros, no memory access
             roff[j] = (uint32_t)id * row_bytes + (uint32_t)pc * 16u;
         }
@@ -1626,30 +1634,33 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
             if (CPD_GC_ABLATE & 131072) rows[j] = f32x4u{(float)roff[j], 1.f, 0.f, 2.f};                      // diagnostic builds: no row loads
             else rows[j] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, roff[j], st.kk * 128, 0));
         }
-        if (new_grp && tid < 144)                                           // 9 taps x 128 rows x 2 bytes = 144 16-byte pieces
-            sreg = *reinterpret_cast<const f32x4u *>(reinterpret_cast<const char *>(p.plan_slots + ((size_t)tile * 27 + 9 * st.grp) * 128) + tid * 16);
+        if (new_grp && tid < 9 * ROWS / 8)                                  // 9 taps x ROWS rows x 2 bytes, in 16-byte pieces
+            sreg = *reinterpret_cast<const f32x4u *>(reinterpret_cast<const char *>(p.plan_slots + ((size_t)tile * 27 + 9 * st.grp) * ROWS) + tid * 16);
     };
     auto write_window = [&](bool new_grp) {
 #pragma unroll
-        for (int j = 0; j < SJ; ++j) *reinterpret_cast<f32x4u *>(swin + pc * PLANE + (slot0 + 32 * j) * 16) = rows[j];
-        if (new_grp && tid < 144) *reinterpret_cast<f32x4u *>(reinterpret_cast<char *>(sslot) + tid * 16) = sreg;
+        for (int j = 0; j < SJ; ++j)
+            if (WIN % SSTEP == 0 || slot0 + SSTEP * j < WIN) *reinterpret_cast<f32x4u *>(swin + pc * PLANE + (slot0 + SSTEP * j) * 16) = rows[j];
+        if (new_grp && tid < 9 * ROWS / 8) *reinterpret_cast<f32x4u *>(reinterpret_cast<char *>(sslot) + tid * 16) = sreg;
     };
 
     // the epilogue's units: a thread owns (row, 8 adjacent channels) pieces of the tile; their residual pieces are fetched while the
     // LAST stage computes (the registers of "the next stage's data" are free then)
-    constexpr int UNITS = 128 * (BN / 8) / 256;      // units per thread: 2 / 4 / 8
-    constexpr int UR = 256 / (BN / 8);
+    constexpr int EPI_ROWS = (ROWS == 256 && BN == 128) ? 128 : ROWS;      // rows per epilogue pass (the LDS tile of 256 x 132 floats does not fit)
+    constexpr int UNITS = EPI_ROWS * (BN / 8) / NTHR;  // units per thread and pass
+    constexpr int UR = NTHR / (BN / 8);
     const int cg = tid % (BN / 8);                   // this thread's 8-channel group: the same for all its units
     const int urow0 = tid / (BN / 8);                // ... in rows urow0 + k * UR of the tile
     constexpr int UC = UNITS > 4 ? 4 : UNITS;        // units whose residual pieces are in registers at a time (128 columns: two halves,
-    constexpr bool EARLY = UNITS <= 4;               // fetched in the epilogue itself: 64 more live registers cost that kernel a wave per SIMD)
+    constexpr bool EARLY = UNITS <= 4 && ROWS == 128;  // fetched in the epilogue itself: 64 more live registers cost that kernel a wave per SIMD;
+                                                     // the 8-wave form has 128 registers per lane and 16 waves per CU to hide the fetch behind)
     f16x8 rh[UC], rl[UC];
     bool res_issued = false;
-    auto issue_residual = [&](int k0 = 0) {
+    auto issue_residual = [&](int k0 = 0, int pass = 0) {
 #pragma unroll
         for (int kc = 0; kc < UC; ++kc) {
             const int k = k0 + kc;
-            const int row = tile * 128 + urow0 + k * UR;
+            const int row = tile * ROWS + pass * EPI_ROWS + urow0 + k * UR;
             const int rowc = row < p.n_out ? row : p.n_out - 1;
             const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + ((cg >> 2) << 7) + ((cg & 3) << 4);
             rh[kc] = *reinterpret_cast<const f16x8 *>(rp);
@@ -1686,7 +1697,7 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
         }
         // ---- this stage's taps, from LDS
         {
-            const int n_stage = n_list[cur.grp] - cur.base < CPD_RP_WIN ? n_list[cur.grp] - cur.base : CPD_RP_WIN;
+            const int n_stage = n_list[cur.grp] - cur.base < WIN ? n_list[cur.grp] - cur.base : WIN;
             uint32_t rem = batch_mask(cur.grp, cur.bt);
             const int tl0 = TB * cur.bt;                                   // first tap of the batch within the group
             const uint32_t so0 = (my_mask[0] >> (9 * cur.grp + tl0)), so1 = (my_mask[1] >> (9 * cur.grp + tl0));
@@ -1700,9 +1711,9 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
 #pragma unroll
                 for (int s = 0; s < MS; ++s) {
                     if ((on >> s) & 1u) {
-                        const uint32_t sl = sslot[(tl0 + tt) * 128 + wave * 32 + 16 * s + r];
+                        const uint32_t sl = sslot[(tl0 + tt) * ROWS + wave * 32 + 16 * s + r];
                         uint32_t w = sl - (uint32_t)cur.base;              // 0xffff (no neighbour) and rows of other passes land beyond the window:
-                        w = w < (uint32_t)n_stage ? w : (uint32_t)CPD_RP_WIN;   // the zero row
+                        w = w < (uint32_t)n_stage ? w : (uint32_t)WIN;         // the zero row
                         const char *src = swin + g * PLANE + w * 16;
                         a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
                         a[s][1] = *reinterpret_cast<const typename S::frag *>(src + 4 * PLANE);
@@ -1731,7 +1742,6 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
     // 2- and 4-byte elements, 8 x 32-byte segments per instruction: 354 of 821 us at two workgroups per CU, tools/rowplan_bench.py.)
     constexpr int LD = BN + 4;                       // floats per tile row in LDS (+4: the transposed writes of the four k-groups hit different banks)
     float *const stile = reinterpret_cast<float *>(smem);
-    if (p.residual && !res_issued) issue_residual();     // (128 columns; or no stage ran: a tile without any neighbour)
     float sc[8], sh[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -1740,42 +1750,48 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
         if (p.dsc) sc[q] *= p.dsc[col];
         sh[q] = p.shift ? p.shift[col] : 0.f;
     }
-    __syncthreads();                                 // every wave is done with the last stage's LDS
-#pragma unroll
-    for (int s = 0; s < MS; ++s)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) stile[(wave * 32 + 16 * s + 4 * g + i) * LD + 16 * nt + r] = acc[s][nt][i];
-    __syncthreads();
     uint32_t vmax = 0;
 #pragma unroll
-    for (int k = 0; k < UNITS; ++k) {
-        if (UNITS > UC && k == UC && p.residual) issue_residual(UC);       // second half of the residual pieces
-        const int lrow = urow0 + k * UR;
-        const int row = tile * 128 + lrow;
-        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * cg);
-        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * cg + 4);
-        float t[8];
+    for (int pass = 0; pass < ROWS / EPI_ROWS; ++pass) {
+        if (p.residual && !(pass == 0 && res_issued)) issue_residual(0, pass);
+        __syncthreads();                             // every wave is done with the last stage's LDS (or the previous pass's tile)
+        if (ROWS == EPI_ROWS || (wave * 32) / EPI_ROWS == pass) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float v = (q < 4 ? v0[q] : v1[q - 4]) * sc[q] + sh[q];
-            if (p.residual) v += (float)rh[k % UC][q] + (float)rl[k % UC][q];   // h + l is exact in fp32
-            if (p.relu) v = v > 0.f ? v : 0.f;
-            t[q] = v;
-            const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
-            vmax = (row < p.n_out && vb > vmax) ? vb : vmax;
+            for (int s = 0; s < MS; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) stile[((wave * 32) % EPI_ROWS + 16 * s + 4 * g + i) * LD + 16 * nt + r] = acc[s][nt][i];
         }
-        if (row < p.n_out) {
-            f16x8 h, l;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < UNITS; ++k) {
+            if (UNITS > UC && k == UC && p.residual) issue_residual(UC, pass);   // second half of the residual pieces
+            const int lrow = urow0 + k * UR;
+            const int row = tile * ROWS + pass * EPI_ROWS + lrow;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * cg);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * cg + 4);
+            float t[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                h[q] = (_Float16)t[q];
-                l[q] = (_Float16)(t[q] - (float)h[q]);
+                float v = (q < 4 ? v0[q] : v1[q - 4]) * sc[q] + sh[q];
+                if (p.residual) v += (float)rh[k % UC][q] + (float)rl[k % UC][q];   // h + l is exact in fp32
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                t[q] = v;
+                const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
+                vmax = (row < p.n_out && vb > vmax) ? vb : vmax;
             }
-            char *op = reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld) + ((cg >> 2) << 7) + ((cg & 3) << 4);
-            *reinterpret_cast<f16x8 *>(op) = h;
-            *reinterpret_cast<f16x8 *>(op + 64) = l;
+            if (row < p.n_out) {
+                f16x8 h, l;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    h[q] = (_Float16)t[q];
+                    l[q] = (_Float16)(t[q] - (float)h[q]);
+                }
+                char *op = reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld) + ((cg >> 2) << 7) + ((cg & 3) << 4);
+                *reinterpret_cast<f16x8 *>(op) = h;
+                *reinterpret_cast<f16x8 *>(op + 64) = l;
+            }
         }
     }
     if (p.out_absmax) {
@@ -1791,17 +1807,17 @@ __device__ __forceinline__ void rowplan_conv_body(const GcParams &p, char *const
     }
 }
 
-// LDS: [one stage's weights | window | slot table]; the epilogue's 128 x (BN + 4) float tile aliases the first two
-template <int BN, int TB>
+// LDS: [one stage's weights | window | slot table]; the epilogue's EPI_ROWS x (BN + 4) float tile aliases the first two
+template <int BN, int TB, int ROWS>
 struct RowplanLds {
-    static constexpr int kStage = TB * SplitF16x2::NP * BN * 64 + 8 * CPD_RP_P16 * 16 + 9 * 128 * 2;
-    static constexpr int kTile = 128 * (BN + 4) * 4;
+    static constexpr int kStage = TB * SplitF16x2::NP * BN * 64 + 8 * RpGeom<ROWS>::P16 * 16 + 9 * ROWS * 2;
+    static constexpr int kTile = ((ROWS == 256 && BN == 128) ? 128 : ROWS) * (BN + 4) * 4;
     static constexpr int kBytes = kStage > kTile ? kStage : kTile;
 };
-template <int BN, int TB>
-__global__ void __launch_bounds__(256) rowplan_conv_f16p_kernel(GcParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[RowplanLds<BN, TB>::kBytes];
-    rowplan_conv_body<BN, TB>(p, smem);
+template <int BN, int TB, int ROWS = 128>
+__global__ void __launch_bounds__(2 * ROWS) rowplan_conv_f16p_kernel(GcParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[RowplanLds<BN, TB, ROWS>::kBytes];
+    rowplan_conv_body<BN, TB, ROWS>(p, smem);
 }
 
 // Split-bf16 image of the weights: Pb[t][k32][piece][g][n][8], piece = h, m, l of
@@ -2773,13 +2789,14 @@ extern "C" int cpd_gather_conv_planned_supported(int n_in, int n_out, int c_in, 
            (size_t)n_in * in_ld * sizeof(float) < 0xfffff000ull;          // (rows are read through a 4 GB buffer resource)
 }
 extern "C" int cpd_gather_conv_planned(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const uint32_t *tapmask,
-                                       const uint16_t *plan_slots, const int32_t *plan_ulist, const int32_t *plan_count, int kv,
+                                       const uint16_t *plan_slots, const int32_t *plan_ulist, const int32_t *plan_count, int tile_rows, int kv,
                                        int n_out, int c_out, const float *scale, const float *shift, const float *residual, int res_ld,
                                        int relu, float *out, int out_ld, int flags, uint32_t *out_absmax, cpd_stream_t stream) {
     if (!in || !packed_w || !out || !plan_slots || !plan_ulist || !plan_count || n_in <= 0 || n_out < 0 || in_ld < c_in || out_ld < c_out ||
         (residual && res_ld < c_out))
         return CPD_ERR_ARG;
     if (n_out == 0) return CPD_OK;
+    if (tile_rows != 128 && tile_rows != 256) return CPD_ERR_ARG;
     if (!cpd_gather_conv_planned_supported(n_in, n_out, c_in, c_out, in_ld, kv, flags) || (((uintptr_t)in) & 15)) return CPD_ERR_UNSUPPORTED;
     if ((flags & CPD_GC_RES_PAIRS) && !residual) return CPD_ERR_ARG;
     if (residual && !(flags & CPD_GC_RES_PAIRS)) return CPD_ERR_UNSUPPORTED;          // (the kernel's epilogue reads pair rows)
@@ -2800,13 +2817,18 @@ extern "C" int cpd_gather_conv_planned(const float *in, int in_ld, int n_in, int
     p.plan_slots = plan_slots; p.plan_ulist = plan_ulist; p.plan_count = plan_count;
     p.n_rb = (n_out + 127) / 128; p.n_cb = 1; p.items = p.n_rb;
     char nm[64];
-    snprintf(nm, sizeof nm, "rowplan_conv_f16p_kernel<%d>", c_out);
+    snprintf(nm, sizeof nm, tile_rows == 256 ? "rowplan_conv_f16p_kernel<%d,256>" : "rowplan_conv_f16p_kernel<%d>", c_out);
     cpd_launch_log_note(nm);
     const dim3 grid(p.items), block(256);
     hipStream_t hs = cpd_s(stream);
     int tb32 = 3;             // 32 columns: the three dx taps of one dy per weight stage (12 KB, 3 workgroups per CU: 443 us) or all nine (36 KB, 2: 559 us)
     if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_PLANNED_TB32")) tb32 = atoi(e);
-    if (c_out == 32 && tb32 == 3) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<32, 3>), grid, block, 0, hs, p);
+    if (tile_rows == 256) {
+        const dim3 grid2((n_out + 255) / 256), block2(512);
+        if (c_out == 32) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<32, 3, 256>), grid2, block2, 0, hs, p);
+        else if (c_out == 64) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<64, 3, 256>), grid2, block2, 0, hs, p);
+        else hipLaunchKernelGGL((rowplan_conv_f16p_kernel<128, 1, 256>), grid2, block2, 0, hs, p);
+    } else if (c_out == 32 && tb32 == 3) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<32, 3>), grid, block, 0, hs, p);
     else if (c_out == 32) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<32, 9>), grid, block, 0, hs, p);
     else if (c_out == 64) hipLaunchKernelGGL((rowplan_conv_f16p_kernel<64, 3>), grid, block, 0, hs, p);
     else hipLaunchKernelGGL((rowplan_conv_f16p_kernel<128, 3>), grid, block, 0, hs, p);

@@ -619,8 +619,9 @@ extern "C" int cpd_order_rows_by_taps(const int32_t *indices, int n, int batch, 
 
 
 extern "C" int cpd_order_rows_bricks(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3], const void *index,
-                                     int brick_y, int brick_x, int32_t *new_to_old, int32_t *old_to_new, int32_t *indices_out,
+                                     int brick_y, int brick_x, int tile_rows, int32_t *new_to_old, int32_t *old_to_new, int32_t *indices_out,
                                      void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
+    if (tile_rows != 128 && tile_rows != 256) return CPD_ERR_UNSUPPORTED;
     if (!valid_shape(batch, shape_zyx) || n < 0 || !index || brick_y <= 0 || brick_x <= 0 ||
         (n > 0 && (!indices || !new_to_old || !old_to_new || !indices_out || !workspace)))
         return CPD_ERR_ARG;
@@ -640,7 +641,8 @@ extern "C" int cpd_order_rows_bricks(const int32_t *indices, int n, int batch, c
     // does per 4096-row chunk): the kernels' 16-row tap skipping gets nearly uniform groups, the tile keeps its footprint
     rulebook_kernel<true><<<cpd_div_up(n, 256), 256, 0, s>>>(coords_b, n, g, 3, 3, 3, 1, 1, 1, 1, 1, 1, v.bitmap, v.base, v.perm, v.flags,
                                                              nullptr, nullptr, pattern);
-    order_rows_kernel<64, 2><<<cpd_div_up(n, 128), 64, 0, s>>>(pattern, coords_b, n, new_to_old, old_to_new, indices_out, pos_to_row);
+    if (tile_rows == 128) order_rows_kernel<64, 2><<<cpd_div_up(n, 128), 64, 0, s>>>(pattern, coords_b, n, new_to_old, old_to_new, indices_out, pos_to_row);
+    else order_rows_kernel<64, 4><<<cpd_div_up(n, 256), 64, 0, s>>>(pattern, coords_b, n, new_to_old, old_to_new, indices_out, pos_to_row);
     return cpd_check_launch();
 }
 

@@ -77,6 +77,8 @@ class ModelConfig:
     # pairs: level-1 convs 51.8 -> 46.7 us/frame, rulebooks + the sort + the feature gather +6 us: 1046 vs 1049.5 frames/s -> off
     row_order_level0: bool = False
     chunked_rulebooks: bool = True         # "taps": rulebooks of the re-ordered levels built chunk-wise in canonical order (ops.rulebook_*(canonical=))
+    plan_channels: tuple = (32, 64)        # levels (by channel count) whose SubM convs take the staged kernel when plan_rulebooks
+    plan_tile_rows: int = 256              # rows per workgroup of the staged kernel / per pattern-sorted tile of the brick order (128 | 256)
     plan_rulebooks: bool = False           # "bricks" only: plan the sub-manifold rulebooks -> the staged row-wave kernel
     row_order_chunk: int = 4096
     row_order_min_rows: int = 65536        # below this a level does not fill the chip either way
@@ -421,14 +423,17 @@ class CenterPointEngine:
             k, s, pd = _DOWN[stage]
             out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
             out_c = out_idx
-            bricks = self.cfg.row_order == "bricks" and out_idx.shape[0] >= self.cfg.row_order_min_rows
+            # "bricks" per level: only where the staged kernel is used (plan_channels: the widths it wins at); other levels keep "taps"
+            c_lvl = L[stage + ".down"].c_out
+            use_plan = self.cfg.plan_rulebooks and pairs and c_lvl in self.cfg.plan_channels
+            bricks = self.cfg.row_order == "bricks" and out_idx.shape[0] >= self.cfg.row_order_min_rows and (use_plan or not self.cfg.plan_rulebooks)
             if bricks:
-                out_idx, _, old_to_new = ops.order_rows_bricks(out_c, out_index, brick=self.cfg.row_order_brick)
+                out_idx, _, old_to_new = ops.order_rows_bricks(out_c, out_index, brick=self.cfg.row_order_brick, tile_rows=self.cfg.plan_tile_rows)
                 out_index.set_order(old_to_new)
             canon = None                      # (canonical list, order, chunk) of a chunk-ordered level: its tables are built chunk-wise
             if bricks:
                 pass
-            elif self.cfg.row_order == "taps" and out_idx.shape[0] >= self.cfg.row_order_min_rows:
+            elif self.cfg.row_order in ("taps", "bricks") and out_idx.shape[0] >= self.cfg.row_order_min_rows:
                 # rows of the level sorted, chunk by chunk, by their neighbour pattern (ops.order_rows_by_taps): the level's
                 # site list in the new order + the rank -> row map installed in its index re-order everything that follows
                 # (both rulebooks, the features, the exported level) without any kernel knowing
@@ -441,8 +446,8 @@ class CenterPointEngine:
             pairs_out = pairs and out_idx.shape[0] * L[stage + ".down"].c_out * 4 < 0xfffff000
             x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in, out_pairs=pairs_out)
             nbr = ops.rulebook_subm(out_idx, out_index, canonical=canon)
-            if bricks and pairs_out and self.cfg.plan_rulebooks:
-                ops.rulebook_plan(nbr)                         # the level's four SubM convs: the staged row-wave kernel
+            if bricks and pairs_out and use_plan:
+                ops.rulebook_plan(nbr, self.cfg.plan_tile_rows)  # the level's four SubM convs: the staged row-wave kernel
             x = self._blocks(L[stage], x, nbr, pairs=pairs_out)
             pairs_in = pairs_out
             coords, coords_c, index, shape = out_idx, out_c, out_index, out_shape

@@ -172,7 +172,7 @@ def order_rows_by_taps(indices, index, ksize=(3, 3, 3), chunk_rows=4096):
     return out, new_to_old, old_to_new
 
 
-def order_rows_bricks(indices, index, brick=(8, 8)):
+def order_rows_bricks(indices, index, brick=(8, 8), tile_rows=128):
     """For a level's CANONICAL site list [n, 4] and its canonical SiteIndex: (indices in brick order, new_to_old, old_to_new) --
     rows sorted by (b, z, y / brick[0], x / brick[1], y, x), then by neighbour pattern inside every 128-row tile
     (cpd_order_rows_bricks): the row order the staged row-wave kernel (gather_conv with a planned rulebook) wants."""
@@ -184,21 +184,22 @@ def order_rows_bricks(indices, index, brick=(8, 8)):
     out = torch.empty_like(indices)
     a = lambda b: (b + 255) // 256 * 256
     ws = torch.empty((2 * a(4 * max(n, 1)) + a(16 * max(n, 1)),), dtype=torch.uint8, device=dev)
-    check(lib().cpd_order_rows_bricks(ptr(indices), n, index.batch, iarr(index.shape), ptr(index.buf), int(brick[0]), int(brick[1]),
+    check(lib().cpd_order_rows_bricks(ptr(indices), n, index.batch, iarr(index.shape), ptr(index.buf), int(brick[0]), int(brick[1]), int(tile_rows),
                                       ptr(new_to_old), ptr(old_to_new), ptr(out), ptr(ws), ws.numel(), stream()), "cpd_order_rows_bricks")
     return out, new_to_old, old_to_new
 
 
-def rulebook_plan(nbr):
-    """Attach the row plan of a 27-tap sub-manifold rulebook (cpd_rulebook_plan) to the table: gather_conv then runs the staged
-    row-wave kernel on it where that kernel applies. Returns nbr."""
+def rulebook_plan(nbr, tile_rows=128):
+    """Attach the row plan of a 27-tap sub-manifold rulebook (cpd_rulebook_plan; tiles of 128 or 256 rows) to the table: gather_conv
+    then runs the staged row-wave kernel on it where that kernel applies. Returns nbr."""
     kv, n = nbr.shape
     dev = nbr.device
-    slots = torch.empty((lib().cpd_rulebook_plan_bytes(n, 0) // 2,), dtype=torch.int16, device=dev)
-    ulist = torch.empty((lib().cpd_rulebook_plan_bytes(n, 1) // 4,), dtype=torch.int32, device=dev)
-    count = torch.empty((lib().cpd_rulebook_plan_bytes(n, 2) // 4,), dtype=torch.int32, device=dev)
-    check(lib().cpd_rulebook_plan(ptr(nbr), kv, n, ptr(slots), ptr(ulist), ptr(count), stream()), "cpd_rulebook_plan")
-    nbr.plan = (slots, ulist, count)
+    t = int(tile_rows)
+    slots = torch.empty((lib().cpd_rulebook_plan_bytes(n, t, 0) // 2,), dtype=torch.int16, device=dev)
+    ulist = torch.empty((lib().cpd_rulebook_plan_bytes(n, t, 1) // 4,), dtype=torch.int32, device=dev)
+    count = torch.empty((lib().cpd_rulebook_plan_bytes(n, t, 2) // 4,), dtype=torch.int32, device=dev)
+    check(lib().cpd_rulebook_plan(ptr(nbr), kv, n, t, ptr(slots), ptr(ulist), ptr(count), stream()), "cpd_rulebook_plan")
+    nbr.plan = (slots, ulist, count, t)
     return nbr
 
 
@@ -341,7 +342,7 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
             int(inp.shape[0]), int(n_out), int(c_in), int(c_out), int(inp.stride(0)), int(kv), flags):
         check(lib().cpd_gather_conv_planned(
             ctypes.c_void_p(inp.data_ptr()), inp.stride(0), inp.shape[0], c_in, ptr(packed_w), ptr(getattr(nbr, "tapmask", None)),
-            ptr(plan[0]), ptr(plan[1]), ptr(plan[2]), kv, n_out, c_out, ptr(scale), ptr(shift),
+            ptr(plan[0]), ptr(plan[1]), ptr(plan[2]), plan[3], kv, n_out, c_out, ptr(scale), ptr(shift),
             ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld, int(bool(relu)),
             ctypes.c_void_p(out.data_ptr()), out.stride(0), flags, ptr(out_absmax), stream()), "cpd_gather_conv_planned")
         return out
@@ -620,7 +621,7 @@ def gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=N
     if nbr is not None and getattr(nbr, "plan", None) is not None and not scaled and lib().cpd_gather_conv_planned_supported(
             int(nbr.shape[1]), int(n_out), int(c_in), int(c_out), int(in_ld), int(nbr.shape[0]),
             _gc_flags(dense, bf16x3, math) | (16 if in_pairs else 0) | 32):      # (the staged kernel writes pair rows)
-        return "rowplan_conv_f16p_kernel<%d>" % c_out
+        return "rowplan_conv_f16p_kernel<%d%s>" % (c_out, ",256" if nbr.plan[3] == 256 else "")
     name = _gather_conv_tile(n_out, c_in, c_out, in_ld, dense, bf16x3, nbr, math, in_pairs)
     return name.replace("_f16_kernel", "_f16s_kernel") if scaled else name
 

@@ -135,13 +135,13 @@ int cpd_order_rows_by_taps(const int32_t *indices, int n, int batch, const int32
 int cpd_index_set_order(void *index, const int32_t *rank_to_row, cpd_stream_t stream);
 /* Brick order of a level (round 4; any row order is a valid SparseConvTensor, spconv_backbone.py:502-558 never reads one): rows
  * sorted by (b, z, y / brick_y, x / brick_x, y, x) -- brick_y x brick_x bricks of one z-plane, computed WITHOUT a sort from rank
- * queries on the level's canonical site index -- and then, inside every tile of 128 consecutive rows of that order, by their 27-bit
+ * queries on the level's canonical site index -- and then, inside every tile of `tile_rows` (128 or 256) consecutive rows of that order, by their 27-bit
  * sub-manifold neighbour pattern (what cpd_order_rows_by_taps does per chunk). A tile of 128 output rows then touches ~2.9 distinct
  * input rows per row instead of 4.5 (canonical) or 8.8 (4096-row pattern chunks): what cpd_gather_conv_planned stages in LDS.
  * `indices` [n][4]: the CANONICAL list of the level, `index`: its canonical index. Outputs as cpd_order_rows_by_taps.
  * workspace: 2 * align256(4 n) + align256(16 n) bytes. */
 int cpd_order_rows_bricks(const int32_t *indices, int n, int batch, const int32_t shape_zyx[3], const void *index,
-                          int brick_y, int brick_x, int32_t *new_to_old, int32_t *old_to_new, int32_t *indices_out,
+                          int brick_y, int brick_x, int tile_rows, int32_t *new_to_old, int32_t *old_to_new, int32_t *indices_out,
                           void *workspace, size_t workspace_bytes, cpd_stream_t stream);
 /* SubMConv3d rulebook: output set == input set, same order; tap t reads coord + t - k/2.
  * tapmask (optional, u32 [ceil(n/16)], kernel volume <= 32): bit t of word s is set iff some row
@@ -152,12 +152,13 @@ int cpd_rulebook_subm(const int32_t *indices, int n, int batch, const int32_t sh
                       cpd_stream_t stream);
 /* Row plan of a 3 x 3 x 3 sub-manifold rulebook nbr[27][n_out] (round 4): per tile of 128 consecutive output rows and per dz group of
  * nine taps (tap = (dz * 3 + dy) * 3 + dx; the three groups read three different z-planes and share no input row)
- *   ulist [tiles][3][1152] i32   the distinct input rows the group touches, ascending, `count` of them;
- *   slots [tiles][27][128] u16   per (tap, row of the tile): position of nbr[tap][row] in its group's list, 0xffff = no neighbour;
+ * (tile_rows = 128 or 256: the rows of one workgroup of cpd_gather_conv_planned)
+ *   ulist [tiles][3][9 * tile_rows] i32   the distinct input rows the group touches (any order), `count` of them;
+ *   slots [tiles][27][tile_rows] u16   per (tap, row of the tile): position of nbr[tap][row] in its group's list, 0xffff = no neighbour;
  *   count [tiles][4]       i32   the three list lengths and their sum.
  * cpd_rulebook_plan_bytes(n_out, which): bytes of slots (0), ulist (1), count (2). Any row order is planned correctly. */
-size_t cpd_rulebook_plan_bytes(int n_out, int which);
-int cpd_rulebook_plan(const int32_t *nbr, int kv, int n_out, uint16_t *slots, int32_t *ulist, int32_t *count,
+size_t cpd_rulebook_plan_bytes(int n_out, int tile_rows, int which);
+int cpd_rulebook_plan(const int32_t *nbr, int kv, int n_out, int tile_rows, uint16_t *slots, int32_t *ulist, int32_t *count,
                       cpd_stream_t stream);
 /* cpd_rulebook_subm / cpd_rulebook_conv for a CHUNK-ORDERED output level (cpd_order_rows_by_taps, chunk_rows = 4096): out_canonical
  * [n_out][4] = the level's canonical site list, out_old_to_new [n_out] = its order (NULL = canonical). Gives, bit for bit, the table and
@@ -272,7 +273,7 @@ int cpd_conv3x3_rows(const float *in, int in_ld, int frames, int h, int w, int c
  * flags: CPD_GC_F16X2 | CPD_GC_IN_PAIRS [| CPD_GC_OUT_PAIRS | CPD_GC_RES_PAIRS]. */
 int cpd_gather_conv_planned_supported(int n_in, int n_out, int c_in, int c_out, int in_ld, int kv, int flags);
 int cpd_gather_conv_planned(const float *in, int in_ld, int n_in, int c_in, const float *packed_w, const uint32_t *tapmask,
-                            const uint16_t *plan_slots, const int32_t *plan_ulist, const int32_t *plan_count, int kv,
+                            const uint16_t *plan_slots, const int32_t *plan_ulist, const int32_t *plan_count, int tile_rows, int kv,
                             int n_out, int c_out, const float *scale, const float *shift, const float *residual, int res_ld,
                             int relu, float *out, int out_ld, int flags, uint32_t *out_absmax, cpd_stream_t stream);
 /* Introspection for benchmarks/profilers: which kernel instantiation cpd_gather_conv runs for

@@ -36,10 +36,11 @@ def _brick_key(idx, shape, by=8, bx=8):
     return np.lexsort((idx[:, 3], idx[:, 2], idx[:, 3] // bx, idx[:, 2] // by, idx[:, 1], idx[:, 0]))
 
 
-def test_brick_order_is_the_brick_sort_with_pattern_sorted_tiles(oracle, hip):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_brick_order_is_the_brick_sort_with_pattern_sorted_tiles(oracle, hip, tile):
     coords, index, shape = _level(2, 2)
     n = coords.shape[0]
-    out, n2o, o2n = ops.order_rows_bricks(coords, index)
+    out, n2o, o2n = ops.order_rows_bricks(coords, index, tile_rows=tile)
     c, out, n2o, o2n = coords.cpu().numpy(), out.cpu().numpy(), n2o.cpu().numpy(), o2n.cpu().numpy()
     np.testing.assert_array_equal(np.sort(n2o), np.arange(n))                 # a permutation
     np.testing.assert_array_equal(o2n[n2o], np.arange(n))                     # and its inverse
@@ -49,53 +50,55 @@ def test_brick_order_is_the_brick_sort_with_pattern_sorted_tiles(oracle, hip):
     pat = np.zeros(n, np.int64)
     for t in range(27):
         pat |= (nbr[t] >= 0).astype(np.int64) << t
-    for t0 in range(0, n, 128):
-        rows = n2o[t0:t0 + 128]
-        tile = want[t0:t0 + 128]
-        # the tile holds exactly the rows of brick positions t0 .. t0 + 127, stably sorted by neighbour pattern
-        expect = tile[np.argsort(pat[tile], kind="stable")]
+    for t0 in range(0, n, tile):
+        rows = n2o[t0:t0 + tile]
+        mine = want[t0:t0 + tile]
+        # the tile holds exactly the rows of brick positions t0 .. t0 + tile - 1, stably sorted by neighbour pattern
+        expect = mine[np.argsort(pat[mine], kind="stable")]
         np.testing.assert_array_equal(rows, expect)
 
 
-def test_row_plan_lists_the_distinct_inputs_of_every_tile_and_group(hip):
+@pytest.mark.parametrize("T", [128, 256])
+def test_row_plan_lists_the_distinct_inputs_of_every_tile_and_group(hip, T):
     coords, index, shape = _level(1, 1)
-    out, _, o2n = ops.order_rows_bricks(coords, index)
+    out, _, o2n = ops.order_rows_bricks(coords, index, tile_rows=T)
     index.set_order(o2n)
     nbr = ops.rulebook_subm(out, index)
-    ops.rulebook_plan(nbr)
+    ops.rulebook_plan(nbr, T)
     n = out.shape[0]
-    tiles = (n + 127) // 128
+    tiles = (n + T - 1) // T
     tab = nbr.cpu().numpy()
-    slots = nbr.plan[0].cpu().numpy().view(np.uint16).reshape(tiles, 27, 128)
-    ulist = nbr.plan[1].cpu().numpy().reshape(tiles, 3, 1152)
+    slots = nbr.plan[0].cpu().numpy().view(np.uint16).reshape(tiles, 27, T)
+    ulist = nbr.plan[1].cpu().numpy().reshape(tiles, 3, 9 * T)
     count = nbr.plan[2].cpu().numpy().reshape(tiles, 4)
-    pad = np.full((27, tiles * 128), -1, np.int32)
+    pad = np.full((27, tiles * T), -1, np.int32)
     pad[:, :n] = tab
     longest = 0
     for t in range(tiles):
         for g in range(3):
-            blk = pad[9 * g:9 * g + 9, t * 128:(t + 1) * 128]
+            blk = pad[9 * g:9 * g + 9, t * T:(t + 1) * T]
             u = np.unique(blk[blk >= 0])
             assert count[t, g] == u.size
-            np.testing.assert_array_equal(ulist[t, g, :u.size], u)
+            np.testing.assert_array_equal(np.sort(ulist[t, g, :u.size]), u)           # each distinct row once (list order is arrival order)
             sl = slots[t, 9 * g:9 * g + 9]
             assert ((sl == 0xffff) == (blk < 0)).all()
             np.testing.assert_array_equal(ulist[t, g][sl[blk >= 0]], blk[blk >= 0])
             longest = max(longest, u.size)
         assert count[t, 3] == count[t, :3].sum()
-    assert longest <= 224, longest                        # brick order keeps every group inside the kernel's one-pass window
+    assert longest <= {128: 224, 256: 384}[T], longest    # brick order keeps every group inside the kernel's one-pass window
 
 
+@pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("c", [32, 64, 128])
 @pytest.mark.parametrize("order", ["bricks", "canonical"])
-def test_planned_conv_matches_oracle_and_the_rowwave_kernel(oracle, hip, c, order):
+def test_planned_conv_matches_oracle_and_the_rowwave_kernel(oracle, hip, c, order, tile):
     """SubM c -> c on fp16-pair rows, with the BatchNorm / residual / ReLU epilogue the SparseBasicBlocks use, pair output: the staged
     kernel (asserted through the launch log) vs the oracle on the same fp32 values (<= 1e-4) and vs the row-wave kernel on the same
     table (identical partial products; for c = 32 the same accumulation order: bit-identical). `canonical`: the plan makes no
     assumption on the row order -- lists are longer there (a group can exceed the window: the multi-pass path)."""
     coords, index, shape = _level(2, {32: 1, 64: 2, 128: 2}[c])
     if order == "bricks":
-        idx, _, o2n = ops.order_rows_bricks(coords, index)
+        idx, _, o2n = ops.order_rows_bricks(coords, index, tile_rows=tile)
         index.set_order(o2n)
     else:
         idx = coords
@@ -115,12 +118,12 @@ def test_planned_conv_matches_oracle_and_the_rowwave_kernel(oracle, hip, c, orde
     os.environ["CPD_TUNE"], os.environ["CPD_GC_PLANNED_MIN"] = "1", "1"       # (the 128-channel level of two frames is below 512 tiles)
     try:
         base = ops.gather_conv(xp, c, pw, nbr, 27, n, c, scale, shift, rp, True, math="f16x2", in_pairs=True, out_pairs=True, res_pairs=True)
-        ops.rulebook_plan(nbr)
+        ops.rulebook_plan(nbr, tile)
         with ops.launch_log() as log:
             got = ops.gather_conv(xp, c, pw, nbr, 27, n, c, scale, shift, rp, True, math="f16x2", in_pairs=True, out_pairs=True, res_pairs=True)
     finally:
         del os.environ["CPD_TUNE"], os.environ["CPD_GC_PLANNED_MIN"]
-    assert log.counts == {"rowplan_conv_f16p_kernel<%d>" % c: 1}, log.counts
+    assert log.counts == {"rowplan_conv_f16p_kernel<%d%s>" % (c, ",256" if tile == 256 else ""): 1}, log.counts
     got, base = ops.pairs_to_rows(got), ops.pairs_to_rows(base)
     # c = 32 in brick order (one window pass per group): the row-wave kernel's products in its accumulation order -- what is left is
     # the epilogue's scale / shift / residual arithmetic, contracted differently by the compiler in the two kernels (1 ulp)

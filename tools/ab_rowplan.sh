@@ -3,7 +3,8 @@
 mkdir -p gpurun_out
 for o in "$@"; do
   extra=""; ro=$o
-  if [ "$o" = "bricks+plan" ]; then ro=bricks; extra="--plan 1"; fi
+  if [ "$o" = "bricks+plan" ]; then ro=bricks; extra="--plan 1 --plan-tile 256"; fi
+  if [ "$o" = "bricks+plan128" ]; then ro=bricks; extra="--plan 1 --plan-tile 128"; fi
   timeout 300 python bench.py --no-extras --no-cpu-baseline --row-order $ro $extra > gpurun_out/ab_$o.json 2> gpurun_out/ab_$o.err || tail -5 gpurun_out/ab_$o.err
   python - <<PY
 import json

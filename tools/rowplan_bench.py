@@ -10,6 +10,7 @@ from cpd_amd.synthetic import WAYMO, waymo_cloud
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(os.environ.get("FRAMES", "16"))
+TILE = int(os.environ.get("TILE", "256"))
 DOWN = [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1])]
 
 
@@ -47,12 +48,12 @@ for lvl, (k, s, p) in enumerate(DOWN):
         if order == "taps":
             idx, _, o2n = ops.order_rows_by_taps(coords, index)
         else:
-            idx, _, o2n = ops.order_rows_bricks(coords, index)
+            idx, _, o2n = ops.order_rows_bricks(coords, index, tile_rows=TILE)
         index.set_order(o2n)
         nbr = ops.rulebook_subm(idx, index)
         pairs = int((nbr >= 0).sum())
         if order == "bricks+plan":
-            us_plan = timeit(lambda: ops.rulebook_plan(nbr))
+            us_plan = timeit(lambda: ops.rulebook_plan(nbr, TILE))
         name = ops.gather_conv_tile(n, c, c, c, nbr=nbr, math="f16x2", in_pairs=True)
         us = timeit(lambda: ops.gather_conv(xp, c, w, nbr, 27, n, c, scale, shift, res, True, out=out, math="f16x2", in_pairs=True, out_pairs=True, res_pairs=True))
         line += "  %s %s %.0f us (%.0f TF)" % (order, name.replace("_conv_f16p_kernel", ""), us, 2.0 * pairs * c * c / us / 1e6)
