@@ -345,9 +345,20 @@ class VoxelRCNNHead(nn.Module):
         self._fc = {k: pack(getattr(self, k)) for k in ("shared_fc_layers", "cls_layers", "reg_layers")}
 
     @staticmethod
-    def _run(layers, x):
-        for w, cin, cout, s, t, relu in layers:
-            x = ops.gather_conv(x, cin, w, None, 1, x.shape[0], cout, s, t, None, relu)
+    def _run(layers, x, math=None, in_block=None):
+        """the stack as 1 x 1 GEMM launches. math = "f16x2": the split-fp16 tile kernels, range-guarded the whole way -- every layer
+        takes the absmax block its producer filled (`in_block` for the first; measured when None) and fills the next one."""
+        if math != "f16x2":
+            for w, cin, cout, s, t, relu in layers:
+                x = ops.gather_conv(x, cin, w, None, 1, x.shape[0], cout, s, t, None, relu)
+            return x
+        blocks = ops.absmax_blocks(len(layers), x.device)
+        rb = in_block if in_block is not None else ops.absmax_rows(x)
+        for i, (w, cin, cout, s, t, relu) in enumerate(layers):
+            ok = cin % 32 == 0 and cout % 64 == 0            # (the 256 -> 1 / 256 -> 7 output layers stay on the fp32 pipe)
+            x = ops.gather_conv(x, cin, w, None, 1, x.shape[0], cout, s, t, None, relu, dense=True, math="f16x2" if ok else "f32",
+                                in_absmax=rb if ok else None, out_absmax=blocks[i])
+            rb = blocks[i]
         return x
 
     @torch.no_grad()

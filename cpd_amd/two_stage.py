@@ -73,9 +73,11 @@ class VoxelRCNNEngine:
                                         indexes={name: self.rpn.level_indexes[name] for name in self.sources})
         x = pooled.reshape(pooled.shape[0], -1).contiguous()
         fc = self.head._fc
-        shared = self.head._run(fc["shared_fc_layers"], x)
-        rcnn_cls = self.head._run(fc["cls_layers"], shared)
-        rcnn_reg = self.head._run(fc["reg_layers"], shared)
+        m = self.cfg.conv_math if self.cfg.conv_math == "f16x2" else None     # FC stacks on the split-fp16 tile kernels, range-guarded
+        shared = self.head._run(fc["shared_fc_layers"], x, math=m)
+        rb = ops.absmax_rows(shared) if m else None
+        rcnn_cls = self.head._run(fc["cls_layers"], shared, math=m, in_block=rb)
+        rcnn_reg = self.head._run(fc["reg_layers"], shared, math=m, in_block=rb)
         cls, boxes = self.head.generate_predicted_boxes(batch, rois, rcnn_cls, rcnn_reg)
         # ---- post_processing, all frames at once
         pp, nms = self.post_cfg, self.post_cfg["NMS_CONFIG"]
