@@ -53,7 +53,15 @@ def test_proto_head_training_step_matches_reference(golden, hip):
           "multi_scale_3d_features_mm": lv_mm, "multi_scale_3d_strides": {"x_conv3": 4, "x_conv4": 8}}
     np.random.seed(int(g["seed"]))
     torch.manual_seed(int(g["seed"]))
-    head(bd)
+    from cpd_amd import ops
+    from cpd_amd.autograd_ops import HipConv1d, HipLinear
+    with ops.launch_log() as fwd_log:
+        head(bd)
+    # round 4: the FC stacks and the pooling MLPs' 1 x 1 convs are C-ABI launches in TRAINING too (no rocBLAS GEMM on the path):
+    # every Linear layer of the six stacks and the 16 Conv1d layers (2 branches x 2 levels x 2 scales x in / out), one launch each
+    n_fc = sum(isinstance(m, HipLinear) for m in head.modules())
+    n_c1 = sum(isinstance(m, HipConv1d) for m in head.modules())
+    assert n_fc >= 12 and n_c1 == 16 and sum(fwd_log.counts.values()) >= n_fc + n_c1, (n_fc, n_c1, fwd_log.counts)
     t0, t1 = head.forward_ret_dict["targets_dict0"], head.forward_ret_dict["targets_dict1"]
     # sampling and targets
     np.testing.assert_allclose(t0["rois"].cpu().numpy(), g["t_rois"], rtol=0, atol=1e-6)
