@@ -1102,16 +1102,19 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
 #endif
 // WB = weight buffers in LDS: with two, a stage's block is committed to the buffer the previous stage is NOT reading, and the barrier
 // before the commit ("every wave is done with this stage's weights") goes: one barrier per stage instead of two
-template <class S, int BN, int MS, bool SC = false, bool PS = false, int WB = 1>
+// WV = waves per workgroup: 4, or (round 4, fp16-pair rows) 8 -- 256-row workgroups: the (tap, channel block) weight images every
+// workgroup re-fetches through the vector L1 serve twice the rows (at 128 columns they are HALF of a 128-row workgroup's L1 traffic)
+template <class S, int BN, int MS, bool SC = false, bool PS = false, int WB = 1, int WV = 4>
 __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb0, int *const sidx) {
     float in_s = 1.f, in_inv = 1.f;
     if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
     constexpr int NP = S::NP;
     constexpr int NT = BN / 16;
-    constexpr int WG_ROWS = 64 * MS, WG_SUBS = 4 * MS;
+    constexpr int THREADS = 64 * WV;
+    constexpr int WG_ROWS = 16 * WV * MS, WG_SUBS = WV * MS;
     constexpr bool BOTH = CPD_RW_BOTH && MS == 2 && BN >= CPD_RW_BOTH_MIN;
     constexpr int B_SLOTS = NP * 4 * BN;       // 16-byte B pieces of one stage
-    constexpr int BJ = (B_SLOTS + 255) / 256;  // ... staged per thread
+    constexpr int BJ = (B_SLOTS + THREADS - 1) / THREADS;  // ... staged per thread
     constexpr int B_IMG = BN * 64;             // bytes of one piece image: 4 k-groups x BN x 16
 
     // the wave id in a SCALAR register: everything derived from it (this wave's tap masks, its row range) then branches on SCC
@@ -1265,9 +1268,9 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             const char *wt = reinterpret_cast<const char *>(p.wb) + (uint32_t)(t * sk + kk) * b_stage32;
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
-                const int id = j * 256 + tid;
+                const int id = j * THREADS + tid;
                 const int pg = id / BN, n = id - pg * BN;
-                if (B_SLOTS % 256 == 0 || id < B_SLOTS) {
+                if (B_SLOTS % THREADS == 0 || id < B_SLOTS) {
                     if (CPD_GC_ABLATE & 1) rbv[j] = f32x4u{(float)t, 1.f, (float)kk, (float)n};
                     else rbv[j] = *reinterpret_cast<const f32x4u *>(wt + (uint32_t)(pg * p.np + col0 + n) * 16u);
                 }
@@ -1278,10 +1281,10 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             char *const sb = sb0 + (WB > 1 ? slot * (NP * B_IMG) : 0);
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
-                if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) {
+                if (B_SLOTS % THREADS == 0 || j * THREADS + tid < B_SLOTS) {
                     // k order of the LDS weight image = the gathered fragments': the packed slot (piece image q, k-group go, column n)
                     // holds channels 8 go .. 8 go + 7; its half hf (channels 4 (2 go + hf) ..) goes to k-group (2 go + hf) & 3, position go >> 1
-                    const int id = j * 256 + tid;
+                    const int id = j * THREADS + tid;
                     if (PS) {               // fp16-pair input: the fragments come in the natural k order, and so does the image
                         *reinterpret_cast<f32x4u *>(sb + (id << 4)) = rbv[j];
                         continue;
@@ -1478,6 +1481,22 @@ rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcPar
     __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];   // weight buffers
     __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
     rowwave_conv_split_body<SplitF16x2, BN, MS, false, true, CPD_RW_WB>(p, sb, sidx);
+}
+#ifndef CPD_RW8_DEFAULT
+#define CPD_RW8_DEFAULT 0            // column-tile widths (sum of 32 / 64 / 128) that take the wide-workgroup variant by default
+#endif
+// ... on wide workgroups: WV = 8 waves / 256 rows (32 and 64 columns) or 6 waves / 192 rows (128 columns: 150 registers = 3 waves per
+// SIMD = two 6-wave workgroups per CU; at 8 waves a CU would need 4 per SIMD = 128 registers, which spills 253)
+#define CPD_RW_WIDE_WV(BN) ((BN) == 128 ? 6 : 8)
+#ifndef CPD_RW8_OCC
+#define CPD_RW8_OCC(BN) ((BN) == 128 ? 3 : ((BN) == 64 ? 4 : 6))     // waves per SIMD the wide variants are compiled for
+#endif
+template <int BN, int WV = CPD_RW_WIDE_WV(BN)>
+__global__ void __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(CPD_RW8_OCC(BN), CPD_RW8_OCC(BN))))
+rowwave_conv_f16pw_kernel(GcParams p) {
+    __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];
+    __shared__ int sidx[WV * CPD_RW_TAPS * 16 * 2];
+    rowwave_conv_split_body<SplitF16x2, BN, 2, false, true, CPD_RW_WB, WV>(p, sb, sidx);
 }
 
 
@@ -2090,6 +2109,16 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
         const long long row_tiles = (n_out + 127) / 128;
         if (row_tiles * (c_out / bn) >= rw_min) {
             pl.use_wg = 3; pl.a = 128; pl.b = bn;
+            if (pl.math == 2 && (flags & CPD_GC_IN_PAIRS)) {
+                // fp16-pair rows: wide workgroups (256 rows / 8 waves; 192 / 6 at 128 columns) for the column tiles in CPD_GC_RW8 (a sum of
+                // widths) once the layer has >= CPD_GC_RW8_MIN of them
+                int widths = CPD_RW8_DEFAULT;
+                long long min_wgs = 1024;
+                if (const char *e = cpd_knob(tn, "CPD_GC_RW8")) widths = atoi(e);
+                if (const char *e = cpd_knob(tn, "CPD_GC_RW8_MIN")) min_wgs = atoll(e);
+                const int wide = 32 * CPD_RW_WIDE_WV(bn);
+                if ((widths & bn) && (long long)((n_out + wide - 1) / wide) * (c_out / bn) >= min_wgs) pl.a = wide;
+            }
             return pl;
         }
         int small_rows = 1;                     // 64-row workgroups before narrower column tiles
@@ -2527,11 +2556,12 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         const int sp = rowwave_split(pl, n_out, c_in, c_out, kv);
         if (sp > 1 && part_bytes >= (size_t)sp * n_out * c_out * sizeof(float)) { p.split = sp; p.part = part; }
     }
-    const dim3 grid(p.items, p.split), block(256);
+    const dim3 grid(p.items, p.split), block(pl.use_wg == 3 && pl.a > 128 ? pl.a * 2 : 256);
     {   // launch log (cpd_launch_log_*): the instantiation this call runs
         char nm[96];
         const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? (p.in_pairs ? "f16p" : "f16") : "bf16");
-        if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
+        if (pl.use_wg == 3 && pl.a > 128) snprintf(nm, sizeof nm, "rowwave_conv_f16pw_kernel<%d,%d>", pl.b, pl.a / 32);
+        else if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
         else if (pl.use_wg == 2) snprintf(nm, sizeof nm, "tile_conv_%s_kernel<%d,%d>", sc, pl.a, pl.b);
         else if (pl.use_wg == 1) snprintf(nm, sizeof nm, "tile_conv_kernel<%d,%d>", pl.a, pl.b);
         else if (in16) snprintf(nm, sizeof nm, "gather_conv_h16_kernel<%d,%d>", pl.a, pl.b);
@@ -2550,7 +2580,11 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         return rowwave_finish(p, hs);
     }
     if (pl.use_wg == 3 && pl.math == 2 && p.in_pairs) {
-        if (pl.a == 64) {
+        if (pl.a > 128) {
+            if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16pw_kernel<32>), 0);
+            else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16pw_kernel<64>), 0);
+            else CPD_LAUNCH((rowwave_conv_f16pw_kernel<128>), 0);
+        } else if (pl.a == 64) {
             if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16p_kernel<32, 1>), 0);
             else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16p_kernel<64, 1>), 0);
             else CPD_LAUNCH((rowwave_conv_f16p_kernel<128, 1>), 0);

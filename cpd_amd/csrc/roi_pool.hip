@@ -106,6 +106,101 @@ __global__ void __launch_bounds__(256) voxel_query_kernel(QueryParams p, Lookup 
     }
 }
 
+// The same query for the bitmap index, ROW-WISE (round 4): the x-run [cx - xr, cx + xr] of one (dz, dy) window row is <= 32 consecutive
+// bits of the occupancy bitmap -- one or two 64-bit words -- so a lane tests a whole ROW of the window per step instead of one cell:
+// 81 rows instead of 729 cells at range 4, 289 instead of 4913 at range 8, and no rank lookup / coordinate load for an empty row (most
+// of them: a grid point in free space walked the entire window before). The set bits of 16 rows, in (dz, dy) row order and dx order
+// inside a row, are the candidates in the reference's scan order; a prefix sum of the rows' popcounts deals them to the group's 16
+// lanes -- "first nsample hits" (voxel_query_gpu.cu:41-77) exactly.
+__global__ void __launch_bounds__(256) voxel_query_rows_kernel(QueryParams p, IndexLookup lookup) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const int pt = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp;
+    const bool live = pt < p.m;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    int b = 0, cz = 0, cy = 0, cx = 0;
+    if (live) {
+        nx = p.new_xyz[3 * (size_t)pt]; ny = p.new_xyz[3 * (size_t)pt + 1]; nz = p.new_xyz[3 * (size_t)pt + 2];
+        const int4 c = reinterpret_cast<const int4 *>(p.new_coords)[pt];
+        b = c.x; cz = c.y; cy = c.z; cx = c.w;
+    }
+    const int wy = 2 * p.yr + 1;
+    const int nrow = (2 * p.zr + 1) * wy;
+    const int x0 = cx - p.xr < 0 ? 0 : cx - p.xr, x1 = cx + p.xr >= p.r3 ? p.r3 - 1 : cx + p.xr;
+    const int nbits = x1 - x0 + 1;                                   // <= 32 (the launcher checks 2 xr + 1 <= 32); <= 0: nothing in range
+    const int32_t *const perm = index_order(lookup.flags, lookup.perm);
+    int cnt = 0, first = -1;
+    for (int r0 = 0; r0 < nrow; r0 += 16) {
+        const bool group_active = live && cnt < p.nsample;
+        if (!__any(group_active)) break;
+        uint32_t mask = 0;
+        long long key0 = 0;
+        const int rr = r0 + sub;
+        if (group_active && rr < nrow && nbits > 0) {
+            const int qz = rr / wy;
+            const int z = cz + qz - p.zr, y = cy + (rr - qz * wy) - p.yr;
+            if (z >= 0 && z < p.r1 && y >= 0 && y < p.r2) {
+                key0 = (((long long)b * p.r1 + z) * p.r2 + y) * p.r3 + x0;
+                const long long w0 = key0 >> 6;
+                const int off = (int)(key0 & 63);
+                uint64_t bits = lookup.bitmap[w0] >> off;
+                if (off + nbits > 64) bits |= lookup.bitmap[w0 + 1] << (64 - off);
+                mask = (uint32_t)bits & (nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u));
+            }
+        }
+        // the set bits of the group's 16 rows = its candidates in scan order; they are dealt to the 16 lanes sixteen at a time (a row
+        // with one site and a row with nine cost the same: what is serial is ceil(candidates / 16), not the number of non-empty rows)
+        int incl = __popc(mask);
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int up = __shfl_up(incl, d, 16);
+            if (sub >= d) incl += up;
+        }
+        const int excl = incl - __popc(mask);
+        const int total = __shfl(incl, 16 * grp + 15, 64);
+        for (int j0 = 0; __any(group_active && j0 < total && cnt < p.nsample); j0 += 16) {
+            const int j = j0 + sub;
+            const bool mine = group_active && j < total && cnt < p.nsample;
+            int rl = 0;                                       // the row (lane of the group) candidate j lies in: # rows whose inclusive prefix <= j
+#pragma unroll
+            for (int l = 0; l < 15; ++l) rl += __shfl(incl, 16 * grp + l, 64) <= j ? 1 : 0;
+            const int src = 16 * grp + rl;
+            uint32_t m = (uint32_t)__shfl((int)mask, src, 64);
+            int k = j - __shfl(excl, src, 64);
+            const long long rkey = ((long long)__shfl((int)(key0 >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)key0, src, 64);
+            int nb = -1;
+            if (mine) {
+                int pos = 0;                                  // position of the k-th set bit of m
+#pragma unroll
+                for (int sft = 16; sft; sft >>= 1) {
+                    const int c = __popc(m & ((1u << sft) - 1u));
+                    if (k >= c) { k -= c; m >>= sft; pos += sft; }
+                }
+                const int32_t cand = site_lookup(lookup.bitmap, lookup.base, perm, rkey + pos);
+                const float xp = p.xyz[3 * (size_t)cand], yp = p.xyz[3 * (size_t)cand + 1], zp = p.xyz[3 * (size_t)cand + 2];
+                const float d2 = (xp - nx) * (xp - nx) + (yp - ny) * (yp - ny) + (zp - nz) * (zp - nz);
+                if (!(d2 > p.radius2)) nb = cand;
+            }
+            const unsigned long long hb = __ballot(nb >= 0);
+            const unsigned hits = (unsigned)((hb >> (16 * grp)) & 0xffffull);
+            const int f = __shfl(nb, 16 * grp + (hits ? __ffs(hits) - 1 : 0), 64);
+            if (hits) {                                       // (group-uniform; lanes past `total` of a group with hits just count)
+                const int pos = cnt + __popc(hits & ((1u << sub) - 1u));
+                if (nb >= 0 && pos < p.nsample) p.idx[(size_t)pt * p.nsample + pos] = nb;
+                if (first < 0) first = f;
+                cnt += __popc(hits);
+            }
+        }
+    }
+    if (live) {
+        if (cnt > p.nsample) cnt = p.nsample;
+        if (cnt == 0) {
+            if (sub == 0) p.idx[(size_t)pt * p.nsample] = -1;
+        } else {
+            for (int l = cnt + sub; l < p.nsample; l += 16) p.idx[(size_t)pt * p.nsample + l] = first;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) group_points_kernel(int nb, int m, int c, int nsample, const float *__restrict__ feat,
                                                            const int32_t *__restrict__ feat_cnt, const int32_t *__restrict__ idx,
                                                            const int32_t *__restrict__ idx_cnt, float *__restrict__ out) {
@@ -680,7 +775,12 @@ extern "C" int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, i
     (void)use_perm;
     IndexView v = index_carve(const_cast<void *>(index), batch, shape, n_sites);
     QueryParams p{m, r1, r2, r3, nsample, radius * radius, z_range, y_range, x_range, new_xyz, xyz, new_coords, idx};
-    voxel_query_kernel<IndexLookup><<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags});
+    static const bool cellwise = getenv("CPD_QUERY_CELLWISE") != nullptr;       // diagnostic: round 3's cell-by-cell scan
+    cpd_launch_log_note(2 * x_range + 1 <= 32 && !cellwise ? "voxel_query_rows_kernel" : "voxel_query_kernel<IndexLookup>");
+    if (2 * x_range + 1 <= 32 && !cellwise)
+        voxel_query_rows_kernel<<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags});
+    else
+        voxel_query_kernel<IndexLookup><<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags});
     return cpd_check_launch();
 }
 

@@ -639,6 +639,8 @@ def _gather_conv_tile(n_out, c_in, c_out, in_ld, dense=False, bf16x3=False, nbr=
     check(lib().cpd_gather_conv_tile(int(n_out), int(c_in), int(c_out), int(in_ld), flags,
                                      ctypes.byref(wg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(vec)),
           "cpd_gather_conv_tile")
+    if wg.value == 13 and a.value > 128:
+        return "rowwave_conv_f16pw_kernel<%d,%d>" % (b.value, a.value // 32)            # wide workgroups: <column tile, waves>
     if wg.value in (3, 13):
         return "rowwave_conv_%s_kernel<%d,%d>" % (("f16p" if flags & 16 else "f16") if wg.value == 13 else "bf16", b.value, a.value // 64)   # <column tile, row sub-tiles per wave>
     if wg.value in (2, 12):

@@ -17,7 +17,9 @@ def _scene(rng, batch, shape, n_vox, n_query):
     return cells, np.ascontiguousarray(xyz), np.ascontiguousarray(q), np.ascontiguousarray(qxyz)
 
 
-@pytest.mark.parametrize("max_range,radius,nsample", [([1, 1, 1], 0.7, 4), ([2, 2, 2], 1.1, 16), ([1, 4, 4], 1.5, 16)])
+@pytest.mark.parametrize("max_range,radius,nsample", [([1, 1, 1], 0.7, 4), ([2, 2, 2], 1.1, 16), ([1, 4, 4], 1.5, 16),
+                                                      ([4, 4, 4], 1.6, 16), ([8, 8, 8], 3.2, 16), ([8, 8, 8], 0.5, 16),   # the shipped yaml's ranges
+                                                      ([1, 2, 15], 2.5, 16), ([1, 1, 16], 2.5, 16)])    # 31-cell rows; 33: the cell-wise kernel
 def test_voxel_query_dense_and_indexed_match_oracle(oracle, hip, max_range, radius, nsample):
     from cpd_amd import ops, roi_pool
     rng = np.random.default_rng(sum(max_range) + nsample)
@@ -34,7 +36,10 @@ def test_voxel_query_dense_and_indexed_match_oracle(oracle, hip, max_range, radi
     np.testing.assert_array_equal(empty.cpu().numpy(), empty_want)
     np.testing.assert_array_equal(idx.cpu().numpy(), want)
     index = ops.SiteIndex.build(d_cells, batch, shape)           # cells are in canonical order: rank == row
-    idx2, empty2 = roi_pool.voxel_query(max_range, radius, nsample, d_xyz, d_qxyz, d_q, index=index)
+    with ops.launch_log() as log:
+        idx2, empty2 = roi_pool.voxel_query(max_range, radius, nsample, d_xyz, d_qxyz, d_q, index=index)
+    # the bitmap index is scanned a window ROW (<= 32 bits of the bitmap) at a time; wider rows take the cell-by-cell kernel
+    assert log.counts == {"voxel_query_rows_kernel" if 2 * max_range[2] + 1 <= 32 else "voxel_query_kernel<IndexLookup>": 1}, log.counts
     np.testing.assert_array_equal(idx2.cpu().numpy(), want)
     # arbitrary row order goes through the index permutation
     perm = rng.permutation(cells.shape[0])
