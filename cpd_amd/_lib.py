@@ -104,6 +104,7 @@ SIGNATURES = {
     "cpd_voxel2pinds": (_I, [_VP, _I, _I, _I3, _VP, _VP]),
     "cpd_voxel_query": (_I, [_I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_voxel_query_index": (_I, [_I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "cpd_voxel_query_index_grid": (_I, [_I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "cpd_group_points": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_group_points_grad": (_I, [_I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_voxel_pool_max": (_I, [_I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),

@@ -201,6 +201,106 @@ __global__ void __launch_bounds__(256) voxel_query_rows_kernel(QueryParams p, In
     }
 }
 
+// ... and for a VOXEL level, whose point coordinates are by construction its cells' centres (get_voxel_centers, common_utils.py:66-82:
+// (index + 0.5) * cell + origin, three fp32 operations per axis): the kernel evaluates the reference's distance test from the cell
+// coordinates -- same operations, same order, this file is compiled without contraction -- instead of loading xyz[candidate], so a
+// candidate costs no memory access until it is a HIT (rank -> row). Rounding is monotonic: d2 = fl(fl(a + b) + c) >= fl(b + c) for a >= 0,
+// so a window row whose (dy, dz) part alone exceeds radius^2 is skipped before its bitmap words are fetched; and only the rows the ball can
+// reach at all are dealt to the lanes (<= 6 of 25 at range 2 / radius = one cell, <= 15 of 81 at range 4 / radius = two cells -- the shipped
+// yaml's pairs: ONE 16-row step instead of two / six). A lane writes the hits of its own row at the positions a prefix sum gives.
+struct CellGeom { float sx, sy, sz, ox, oy, oz; };
+// -> [lo, hi]: the cells c of [c0 - range, c0 + range] n [0, n) whose centre (c + 0.5) * s + o can lie within `radius` of q: a SUPERSET
+// (1e-3 cells of slack, far above the fp32 error of this expression for any grid CPD has; the exact test runs on every row / cell kept)
+__device__ __forceinline__ void cells_within(float q, float radius, float s, float o, int c0, int range, int n, int &lo, int &hi) {
+    const float inv = 1.0f / s;
+    const float a = (q - radius - o) * inv - 0.5f - 1e-3f, b = (q + radius - o) * inv - 0.5f + 1e-3f;
+    lo = c0 - range < 0 ? 0 : c0 - range;
+    hi = c0 + range >= n ? n - 1 : c0 + range;
+    if (a > (float)lo) lo = (int)ceilf(a);          // (a, b beyond the int range only for coordinates no grid has; the comparisons guard them)
+    if (b < (float)hi) hi = (int)floorf(b);
+}
+__global__ void __launch_bounds__(256) voxel_query_grid_kernel(QueryParams p, IndexLookup lookup, CellGeom cg, float radius) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const int pt = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp;
+    const bool live = pt < p.m;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    int b = 0, cz = 0, cy = 0, cx = 0;
+    if (live) {
+        nx = p.new_xyz[3 * (size_t)pt]; ny = p.new_xyz[3 * (size_t)pt + 1]; nz = p.new_xyz[3 * (size_t)pt + 2];
+        const int4 c = reinterpret_cast<const int4 *>(p.new_coords)[pt];
+        b = c.x; cz = c.y; cy = c.z; cx = c.w;
+    }
+    // the part of the window the ball can reach: rows [zlo, zhi] x [ylo, yhi] in (z, y) order -- the reference's scan order restricted to
+    // them --, cells [xlo, xhi] of each (<= 2 xr + 1 <= 32 bits of the bitmap)
+    int zlo, zhi, ylo, yhi, xlo, xhi;
+    cells_within(nz, radius, cg.sz, cg.oz, cz, p.zr, p.r1, zlo, zhi);
+    cells_within(ny, radius, cg.sy, cg.oy, cy, p.yr, p.r2, ylo, yhi);
+    cells_within(nx, radius, cg.sx, cg.ox, cx, p.xr, p.r3, xlo, xhi);
+    const int wy = yhi - ylo + 1, nbits = xhi - xlo + 1;
+    const int nrow = (live && wy > 0 && nbits > 0 && zhi >= zlo) ? (zhi - zlo + 1) * wy : 0;
+    const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
+    const int32_t *const perm = index_order(lookup.flags, lookup.perm);
+    int cnt = 0, first = -1;
+    for (int r0 = 0; __any(r0 < nrow && cnt < p.nsample); r0 += 16) {
+        const bool group_active = r0 < nrow && cnt < p.nsample;
+        uint32_t mask = 0;                                          // this lane's row: the cells within the radius
+        long long key0 = 0;
+        const int rr = r0 + sub;
+        if (group_active && rr < nrow) {
+            const int qz = (int)(((float)rr + 0.5f) * inv_wy);      // rr / wy (exact: both far below 2^20)
+            const int z = zlo + qz, y = ylo + (rr - qz * wy);
+            const float yp = ((float)y + 0.5f) * cg.sy + cg.oy, zp = ((float)z + 0.5f) * cg.sz + cg.oz;
+            const float b2 = (yp - ny) * (yp - ny), c2 = (zp - nz) * (zp - nz);
+            if (!(b2 + c2 > p.radius2)) {
+                key0 = (((long long)b * p.r1 + z) * p.r2 + y) * p.r3 + xlo;
+                const long long w0 = key0 >> 6;
+                const int off = (int)(key0 & 63);
+                uint64_t bits = lookup.bitmap[w0] >> off;
+                if (off + nbits > 64) bits |= lookup.bitmap[w0 + 1] << (64 - off);
+                uint32_t occ = (uint32_t)bits & (nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u));
+                while (occ) {                                       // the reference's test on every occupied cell of the row
+                    const int pos = __ffs(occ) - 1;
+                    occ &= occ - 1u;
+                    const float xp = ((float)(xlo + pos) + 0.5f) * cg.sx + cg.ox;
+                    const float d2 = (xp - nx) * (xp - nx) + b2 + c2;
+                    if (!(d2 > p.radius2)) mask |= 1u << pos;
+                }
+            }
+        }
+        int incl = __popc(mask);                                    // hits before this row, in scan order
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int up = __shfl_up(incl, d, 16);
+            if (sub >= d) incl += up;
+        }
+        const int total = __shfl(incl, 16 * grp + 15, 64);
+        int at = cnt + incl - __popc(mask), fc = -1;
+        while (mask && at < p.nsample) {                            // a lane writes its own row's hits: rank -> row id
+            const int pos = __ffs(mask) - 1;
+            mask &= mask - 1u;
+            const int32_t cand = site_lookup(lookup.bitmap, lookup.base, perm, key0 + pos);
+            p.idx[(size_t)pt * p.nsample + at] = cand;
+            if (fc < 0) fc = cand;
+            ++at;
+        }
+        const unsigned long long hb = __ballot(fc >= 0);
+        const unsigned rows = (unsigned)((hb >> (16 * grp)) & 0xffffull);
+        const int f = __shfl(fc, 16 * grp + (rows ? __ffs(rows) - 1 : 0), 64);
+        if (group_active) {
+            if (first < 0 && rows) first = f;
+            cnt += total;
+        }
+    }
+    if (live) {
+        if (cnt > p.nsample) cnt = p.nsample;
+        if (cnt == 0) {
+            if (sub == 0) p.idx[(size_t)pt * p.nsample] = -1;
+        } else {
+            for (int l = cnt + sub; l < p.nsample; l += 16) p.idx[(size_t)pt * p.nsample + l] = first;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) group_points_kernel(int nb, int m, int c, int nsample, const float *__restrict__ feat,
                                                            const int32_t *__restrict__ feat_cnt, const int32_t *__restrict__ idx,
                                                            const int32_t *__restrict__ idx_cnt, float *__restrict__ out) {
@@ -781,6 +881,24 @@ extern "C" int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, i
         voxel_query_rows_kernel<<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags});
     else
         voxel_query_kernel<IndexLookup><<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags});
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_voxel_query_index_grid(int m, int batch, int r1, int r2, int r3, int nsample, float radius, int z_range,
+                                          int y_range, int x_range, const float *new_xyz, const int32_t *new_coords,
+                                          const void *index, int n_sites, const float cell_xyz[3], const float origin_xyz[3],
+                                          int32_t *idx, cpd_stream_t st) {
+    if (!query_args_ok(m, r1, r2, r3, nsample, radius, z_range, y_range, x_range, new_xyz, new_xyz, new_coords, index, idx) ||
+        batch <= 0 || !cell_xyz || !origin_xyz || !(cell_xyz[0] > 0.f) || !(cell_xyz[1] > 0.f) || !(cell_xyz[2] > 0.f))
+        return CPD_ERR_ARG;
+    if (2 * x_range + 1 > 32) return CPD_ERR_UNSUPPORTED;          // (a window row is one 32-bit mask; the xyz form takes any range)
+    if (m == 0) return CPD_OK;
+    const int32_t shape[3] = {r1, r2, r3};
+    IndexView v = index_carve(const_cast<void *>(index), batch, shape, n_sites);
+    QueryParams p{m, r1, r2, r3, nsample, radius * radius, z_range, y_range, x_range, new_xyz, nullptr, new_coords, idx};
+    cpd_launch_log_note("voxel_query_grid_kernel");
+    voxel_query_grid_kernel<<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags},
+                                                                      CellGeom{cell_xyz[0], cell_xyz[1], cell_xyz[2], origin_xyz[0], origin_xyz[1], origin_xyz[2]}, radius);
     return cpd_check_launch();
 }
 

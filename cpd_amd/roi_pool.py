@@ -28,6 +28,28 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def cell_geometry(voxel_size, downsample_times, point_cloud_range):
+    """(cell_xyz, origin_xyz) as two ctypes float[3]: the fp32 constants get_voxel_centers (common_utils.py:66-82) multiplies and adds
+    with -- float32(voxel_size) * stride, float32(point_cloud_range[0:3]) -- for the queries that evaluate voxel centres from cell
+    coordinates (`cpd_voxel_query_index_grid`)."""
+    vs = (torch.tensor([float(v) for v in voxel_size]).float() * downsample_times).tolist()
+    org = torch.tensor([float(v) for v in point_cloud_range[0:3]]).float().tolist()
+    return (ctypes.c_float * 3)(*vs), (ctypes.c_float * 3)(*org)
+
+
+def _query_index(index, nsample, radius, ranges, new_xyz, xyz, new_coords, idx, grid=None):
+    """the bitmap-index query: from cell geometry (`grid` = cell_geometry(...), window rows of <= 32 cells) or from the xyz rows"""
+    zr, yr, xr = [int(v) for v in ranges]
+    z, y, x = index.shape
+    m = new_coords.shape[0]
+    if grid is not None and 2 * xr + 1 <= 32:
+        check(lib().cpd_voxel_query_index_grid(m, index.batch, z, y, x, int(nsample), float(radius), zr, yr, xr, ptr(new_xyz), ptr(new_coords),
+                                               ptr(index.buf), xyz.shape[0], grid[0], grid[1], ptr(idx), stream()), "cpd_voxel_query_index_grid")
+    else:
+        check(lib().cpd_voxel_query_index(m, index.batch, z, y, x, int(nsample), float(radius), zr, yr, xr, ptr(new_xyz), ptr(xyz),
+                                          ptr(new_coords), ptr(index.buf), 0, xyz.shape[0], ptr(idx), stream()), "cpd_voxel_query_index")
+
+
 def generate_voxel2pinds(indices, batch_size, spatial_shape):
     """indices [n,4] i32 (b,z,y,x) -> int32 (B,Z,Y,X) volume of row ids, -1 = empty."""
     indices = indices.contiguous()
@@ -37,20 +59,18 @@ def generate_voxel2pinds(indices, batch_size, spatial_shape):
     return out
 
 
-def voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices=None, index=None):
+def voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices=None, index=None, grid=None):
     """VoxelQuery.forward: (idx [M, nsample] i32 with empty balls zeroed, empty_ball_mask [M] bool).
     new_coords [M,4] = (b,z,y,x). Pass `point_indices` (dense volume) like the reference, or `index`
     (an ops.SiteIndex of the sparse tensor; whether its ranks are row ids or go through its permutation is recorded in the
-    index buffer itself and read on the device)."""
+    index buffer itself and read on the device). `grid` = cell_geometry(...) with an index: xyz ARE the cells' centres
+    (get_voxel_centers), and the kernel computes them instead of loading them."""
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and new_coords.is_contiguous()
     m = new_coords.shape[0]
     idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
     zr, yr, xr = [int(v) for v in max_range]
     if index is not None:
-        z, y, x = index.shape
-        check(lib().cpd_voxel_query_index(m, index.batch, z, y, x, int(nsample), float(radius), zr, yr, xr, ptr(new_xyz), ptr(xyz),
-                                          ptr(new_coords), ptr(index.buf), 0,
-                                          xyz.shape[0], ptr(idx), stream()), "cpd_voxel_query_index")
+        _query_index(index, nsample, radius, max_range, new_xyz, xyz, new_coords, idx, grid)
     else:
         assert point_indices.is_contiguous() and point_indices.dtype == torch.int32
         b, z, y, x = point_indices.shape
@@ -181,14 +201,16 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         return torch.cat(outs, dim=1)
 
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices=None,
-                index=None):
+                index=None, grid=None):
+        """`index` / `grid` (beyond the reference's arguments): the level's ops.SiteIndex instead of the dense volume, and its
+        cell_geometry(...) when xyz = get_voxel_centers of that level (eval: the query then computes the centres)."""
         if self.training:
             self._packed = None
             return self._forward_train(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index)
         with torch.no_grad():
-            return self._forward_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index)
+            return self._forward_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid)
 
-    def _forward_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index):
+    def _forward_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid=None):
         if self._packed is None:
             self._pack()
         new_coords = new_coords[:, [0, 3, 2, 1]].contiguous()                 # (b,x,y,z) -> (b,z,y,x), l.84
@@ -199,11 +221,7 @@ class NeighborVoxelSAModuleMSG(nn.Module):
             idx = torch.zeros((m, self.nsamples[k]), dtype=torch.int32, device=xyz.device)
             zr, yr, xr = self.query_ranges[k]
             if index is not None:
-                z, y, x = index.shape
-                check(lib().cpd_voxel_query_index(m, index.batch, z, y, x, self.nsamples[k], float(self.radii[k]), zr, yr, xr,
-                                                  ptr(new_xyz), ptr(xyz), ptr(new_coords), ptr(index.buf),
-                                                  0, n, ptr(idx), stream()),
-                      "cpd_voxel_query_index")
+                _query_index(index, self.nsamples[k], self.radii[k], (zr, yr, xr), new_xyz, xyz, new_coords, idx, grid)
             else:
                 b, z, y, x = voxel2point_indices.shape
                 check(lib().cpd_voxel_query(m, z, y, x, self.nsamples[k], float(self.radii[k]), zr, yr, xr, ptr(new_xyz), ptr(xyz),
@@ -255,7 +273,8 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
         index = indexes.get(name) if indexes else None
         v2p = None if index is not None else generate_voxel2pinds(coords, batch_size, shape)
         out = layer(xyz=xyz, xyz_batch_cnt=cnt, new_xyz=grid_xyz.contiguous().view(-1, 3), new_xyz_batch_cnt=new_cnt,
-                    new_coords=cur, features=feats.contiguous(), voxel2point_indices=v2p, index=index)
+                    new_coords=cur, features=feats.contiguous(), voxel2point_indices=v2p, index=index,
+                    grid=cell_geometry(voxel_size, stride, point_cloud_range) if index is not None else None)
         pooled.append(out.view(-1, grid_size ** 3, out.shape[-1]))
     return torch.cat(pooled, dim=-1)
 

@@ -557,6 +557,15 @@ int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, int nsample,
                           int z_range, int y_range, int x_range, const float *new_xyz, const float *xyz,
                           const int32_t *new_coords, const void *index, int use_perm, int n_sites,
                           int32_t *idx, cpd_stream_t stream);
+/* The same query for a VOXEL level, where the reference passes xyz = get_voxel_centers(indices) (common_utils.py:66-82;
+ * voxel_rcnn_head.py:236-241): a site's coordinates are (cell + 0.5) * cell_xyz + origin_xyz per axis in fp32, so the kernel evaluates
+ * the distance test from the cell coordinates (same operations, same order: identical decisions) and reads nothing per candidate
+ * until it is a hit. cell_xyz = fp32(voxel_size) * stride, origin_xyz = point_cloud_range[0:3] (host arrays, x y z).
+ * 2 * x_range + 1 <= 32, else CPD_ERR_UNSUPPORTED (use cpd_voxel_query_index). */
+int cpd_voxel_query_index_grid(int m, int batch, int r1, int r2, int r3, int nsample, float radius,
+                               int z_range, int y_range, int x_range, const float *new_xyz,
+                               const int32_t *new_coords, const void *index, int n_sites,
+                               const float cell_xyz[3], const float origin_xyz[3], int32_t *idx, cpd_stream_t stream);
 /* group_points_wrapper (group_points_gpu.cu:69-99): out[pt][c][s] = features[start(batch of pt) +
  * idx[pt][s]][c]; *_batch_cnt are device int32[b]. out [m, c, nsample]. */
 int cpd_group_points(int b, int m, int c, int nsample, const float *features,

@@ -51,6 +51,52 @@ def test_voxel_query_dense_and_indexed_match_oracle(oracle, hip, max_range, radi
     np.testing.assert_array_equal(idx3.cpu().numpy(), want_p)
 
 
+@pytest.mark.parametrize("max_range,radius,nsample", [([2, 2, 2], 0.4, 16), ([4, 4, 4], 0.8, 16), ([2, 2, 2], 0.8, 16), ([4, 4, 4], 1.6, 16),
+                                                      ([8, 8, 8], 1.6, 16), ([1, 2, 15], 2.5, 8), ([3, 3, 3], 0.0, 4)])
+def test_voxel_query_from_cell_geometry_matches_oracle(oracle, hip, max_range, radius, nsample):
+    """cpd_voxel_query_index_grid: xyz = get_voxel_centers(level) is not loaded but evaluated from the cell coordinates (the
+    reference's three fp32 operations per axis), rows of the window beyond the radius are skipped -- same neighbours, same order as
+    the oracle's cell-by-cell scan over the xyz rows (voxel_query_gpu.cu:41-77). Query points: random, on the grid's rim, and exactly
+    ON cell centres (distances that equal the radius exactly: the test is `not >`)."""
+    from cpd_amd import ops, roi_pool
+    rng = np.random.default_rng(sum(max_range) + nsample + int(10 * radius))
+    batch, shape, stride = 2, [9, 40, 70], 4
+    voxel_size, pc_range = [0.1, 0.1, 0.15], [-3.0, -2.0, -1.0, 25.0, 14.0, 4.4]
+    cells = np.unique(np.stack([rng.integers(0, batch, 20000)] + [rng.integers(0, s, 20000) for s in shape], 1), axis=0).astype(np.int32)
+    d_cells = torch.from_numpy(cells).cuda()
+    d_xyz = roi_pool.get_voxel_centers(d_cells[:, 1:4], stride, voxel_size, pc_range).contiguous()
+    xyz = d_xyz.cpu().numpy()
+    n_query = 6001
+    q = np.stack([rng.integers(0, batch, n_query)] + [rng.integers(0, s, n_query) for s in shape], 1).astype(np.int32)
+    q = q[np.argsort(q[:, 0], kind="stable")]
+    cell = (np.float32(voxel_size) * np.float32(stride)).astype(np.float32)
+    qxyz = ((q[:, [3, 2, 1]] + rng.uniform(0, 1, (n_query, 3))) * cell + np.float32(pc_range[:3])).astype(np.float32)
+    on_centre = rng.random(n_query) < 0.3
+    qxyz[on_centre] = ((q[on_centre][:, [3, 2, 1]].astype(np.float32) + np.float32(0.5)) * cell + np.float32(pc_range[:3])).astype(np.float32)
+    qxyz, q = np.ascontiguousarray(qxyz), np.ascontiguousarray(q)
+    v2p = oracle.voxel2pinds(cells, batch, shape)
+    want = oracle.voxel_query(max_range, radius, nsample, xyz, qxyz, q, v2p)
+    empty_want = want[:, 0] == -1
+    want[empty_want] = 0
+    assert empty_want.sum() < n_query or radius == 0.0
+    index = ops.SiteIndex.build(d_cells, batch, shape)
+    grid = roi_pool.cell_geometry(voxel_size, stride, pc_range)
+    with ops.launch_log() as log:
+        idx, empty = roi_pool.voxel_query(max_range, radius, nsample, d_xyz, torch.from_numpy(qxyz).cuda(), torch.from_numpy(q).cuda(),
+                                          index=index, grid=grid)
+    assert log.counts == {"voxel_query_grid_kernel": 1}, log.counts
+    np.testing.assert_array_equal(empty.cpu().numpy(), empty_want)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    # rows in arbitrary order: the hits go through the index's rank -> row map
+    perm = rng.permutation(cells.shape[0])
+    index_p = ops.SiteIndex.build(torch.from_numpy(cells[perm]).cuda(), batch, shape)
+    idx_p, _ = roi_pool.voxel_query(max_range, radius, nsample, d_xyz[torch.from_numpy(perm).cuda()].contiguous(), torch.from_numpy(qxyz).cuda(),
+                                    torch.from_numpy(q).cuda(), index=index_p, grid=grid)
+    want_p = oracle.voxel_query(max_range, radius, nsample, xyz[perm], qxyz, q, oracle.voxel2pinds(cells[perm], batch, shape))
+    want_p[want_p[:, 0] == -1] = 0
+    np.testing.assert_array_equal(idx_p.cpu().numpy(), want_p)
+
+
 def test_group_points_matches_oracle(oracle, hip):
     from cpd_amd import roi_pool
     rng = np.random.default_rng(5)
