@@ -2152,6 +2152,13 @@ static GcPlan plan(int n_out, int c_in, int c_out, int in_ld, const void *in, in
             pl.use_wg = 2; pl.a = 64; pl.b = bn;
             return pl;
         }
+        // K-heavy GEMMs with few rows (the RoI head's 27648 -> 256 shared FC on a few thousand RoIs: 864 stages): the stage split
+        // (rowwave_split, up to 8 parts) makes the workgroups the row tiles cannot -- on the wave kernel this layer ran at 62 TFLOP/s
+        const long long parts = c_in / 32 / 16 > 8 ? 8 : c_in / 32 / 16;
+        if (c_in >= 2048 && (long long)((n_out + 127) / 128) * (c_out / bn) * parts >= min64) {
+            pl.use_wg = 2; pl.a = 128; pl.b = bn;
+            return pl;
+        }
     }
     int force_wg = -1;
     if (const char *e = cpd_knob(tn, "CPD_GC_WG")) force_wg = atoi(e);
@@ -2469,7 +2476,8 @@ static int rowwave_split(const GcPlan &pl, int n_out, int c_in, int c_out, int k
         if (!on || wgs >= 600 || stages < 32) return 1;
         long long s = on > 1 ? on : 1200 / (wgs > 0 ? wgs : 1);
         if (s > stages / 16) s = stages / 16;        // at least 16 stages per part
-        return s < 2 ? 1 : (s > 4 ? 4 : (int)s);
+        const int cap = stages >= 256 ? 8 : 4;
+        return s < 2 ? 1 : (s > cap ? cap : (int)s);
     }
     if (const char *e = cpd_knob(tn, "CPD_GC_SPLIT")) { const int v = atoi(e); return v < 1 ? 1 : (v > 8 ? 8 : v); }
     const long long wgs = (long long)((n_out + pl.a - 1) / pl.a) * (c_out / pl.b);

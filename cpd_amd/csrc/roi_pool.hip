@@ -367,6 +367,72 @@ __global__ void __launch_bounds__(256) voxel_pool_max_kernel(int m, int c, int n
 }
 
 // ---- dataloader pre-filter --------------------------------------------------------
+// ... followed by the module's output MLP (mlps_out: 1 x 1 conv + eval BatchNorm + ReLU, voxel_pool_modules.py:118-121) in the same
+// kernel: out[m][co] = relu(sum_ch pooled[m][ch] * w_out[ch][co] + t_out[co]) with the BatchNorm scale folded into w_out; the pooled
+// [M, C] tensor never reaches memory (C = 16 / 32 / 64, C2 <= 2 C).
+template <int C, int NCOL>
+__global__ void __launch_bounds__(256) voxel_pool_max_mlp_kernel(int m, int nsample, const float *__restrict__ fin, int fin_ld,
+                                                                 const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                 const int32_t *__restrict__ idx, const float *__restrict__ wpos,
+                                                                 const float *__restrict__ bpos, const float *__restrict__ wout,
+                                                                 const float *__restrict__ tout, int c2, int relu,
+                                                                 float *__restrict__ out, int out_ld) {
+    // thread = (point slot, channel); a block walks CPD_POOL_ITERS x (256 / C) consecutive points. The pooled channels of the block's
+    // points go through LDS (a broadcast read per four channels); the thread's column(s) of w_out stay in registers over the walk.
+    constexpr int PPB = 256 / C, ITERS = 8;                          // NCOL columns of w_out per thread: c2 <= NCOL * C (the launcher's choice)
+    __shared__ __attribute__((aligned(16))) float pooled[PPB][C];
+    const int slot = threadIdx.x / C, ch = threadIdx.x - slot * C;
+    float wcol[NCOL][C], tcol[NCOL];
+#pragma unroll
+    for (int q = 0; q < NCOL; ++q) {
+        const int co = ch + q * C;
+        tcol[q] = co < c2 ? tout[co] : 0.f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) wcol[q][k] = co < c2 ? wout[k * c2 + co] : 0.f;
+    }
+    const float w0 = wpos[ch], w1 = wpos[C + ch], w2 = wpos[2 * C + ch], b0 = bpos[ch];
+    for (int it = 0; it < ITERS; ++it) {
+        const int pt = (blockIdx.x * ITERS + it) * PPB + slot;
+        if (blockIdx.x * ITERS * PPB + it * PPB >= m) break;         // (block-uniform)
+        const bool live = pt < m;
+        float best = 0.f;
+        if (live) {
+            const int32_t *id = idx + (size_t)pt * nsample;
+            if (id[0] < 0) {
+                best = b0 > 0.f ? b0 : 0.f;
+            } else {
+                const float nx = new_xyz[3 * (size_t)pt], ny = new_xyz[3 * (size_t)pt + 1], nz = new_xyz[3 * (size_t)pt + 2];
+                for (int s = 0; s < nsample; ++s) {
+                    const int32_t j = id[s];
+                    const float dx = xyz[3 * (size_t)j] - nx, dy = xyz[3 * (size_t)j + 1] - ny, dz = xyz[3 * (size_t)j + 2] - nz;
+                    const float pos = ((dx * w0 + dy * w1) + dz * w2) + b0;
+                    const float v = fin[(size_t)j * fin_ld + ch] + pos;
+                    best = v > best ? v : best;
+                }
+            }
+        }
+        __syncthreads();                                             // the previous iteration's readers are done
+        pooled[slot][ch] = best;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NCOL; ++q) {
+            const int co = ch + q * C;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < C; k += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(&pooled[slot][k]);
+                acc += v.x * wcol[q][k];
+                acc += v.y * wcol[q][k + 1];
+                acc += v.z * wcol[q][k + 2];
+                acc += v.w * wcol[q][k + 3];
+            }
+            acc += tcol[q];
+            if (relu) acc = acc > 0.f ? acc : 0.f;
+            if (live && co < c2) out[(size_t)pt * out_ld + co] = acc;
+        }
+    }
+}
+
 struct RangeFlagFn {      // mask_points_by_range (common_utils.py:60-63): x, y inside the closed range
     const float *pts;
     int c;
@@ -881,6 +947,25 @@ extern "C" int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, i
         voxel_query_rows_kernel<<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags});
     else
         voxel_query_kernel<IndexLookup><<<cpd_div_up(m, 16), 256, 0, cpd_s(st)>>>(p, IndexLookup{v.bitmap, v.base, v.perm, v.flags});
+    return cpd_check_launch();
+}
+
+extern "C" int cpd_voxel_pool_max_mlp(int m, int c, int nsample, const float *features_in, int features_ld, const float *xyz,
+                                      const float *new_xyz, const int32_t *idx, const float *w_pos, const float *b_pos,
+                                      const float *w_out, const float *t_out, int c_out, int relu, float *out, int out_ld,
+                                      cpd_stream_t st) {
+    if (m < 0 || c <= 0 || nsample <= 0 || c_out <= 0 || features_ld < c || out_ld < c_out || !w_pos || !b_pos || !w_out || !t_out ||
+        (m > 0 && (!features_in || !xyz || !new_xyz || !idx || !out)))
+        return CPD_ERR_ARG;
+    if ((c != 16 && c != 32 && c != 64) || c_out > 2 * c) return CPD_ERR_UNSUPPORTED;   // (the thread keeps <= 2 columns of w_out in registers; other shapes: cpd_voxel_pool_max + a GEMM)
+    if (m == 0) return CPD_OK;
+    const dim3 grid((unsigned)cpd_div_up((long long)m, 8 * (256 / c)));     // ITERS x points per pass
+    cpd_launch_log_note("voxel_pool_max_mlp_kernel");
+#define CPD_POOL_MLP(C, N) voxel_pool_max_mlp_kernel<C, N><<<grid, 256, 0, cpd_s(st)>>>(m, nsample, features_in, features_ld, xyz, new_xyz, idx, w_pos, \
+                                                                                         b_pos, w_out, t_out, c_out, relu, out, out_ld)
+    if (c_out <= c) { if (c == 16) CPD_POOL_MLP(16, 1); else if (c == 32) CPD_POOL_MLP(32, 1); else CPD_POOL_MLP(64, 1); }
+    else { if (c == 16) CPD_POOL_MLP(16, 2); else if (c == 32) CPD_POOL_MLP(32, 2); else CPD_POOL_MLP(64, 2); }
+#undef CPD_POOL_MLP
     return cpd_check_launch();
 }
 

@@ -181,6 +181,7 @@ class NeighborVoxelSAModuleMSG(nn.Module):
             w_out = self.mlps_out[k][0].weight.detach()[:, :, 0].t().contiguous()[None]        # [1, C1, C2]
             pk.append(dict(w_in=ops.pack_weight(w_in), s_in=s_in.contiguous(), t_in=t_in.contiguous(), w_pos=w_pos,
                            b_pos=t_p.contiguous(), w_out=ops.pack_weight(w_out), s_out=s_o.contiguous(), t_out=t_o.contiguous(),
+                           w_out_folded=(w_out[0] * s_o[None, :]).contiguous(),                      # [C1, C2]: the fused pooling kernel's form
                            c0=w_in.shape[1], c1=w_in.shape[2], c2=w_out.shape[2]))
         self._packed = pk
 
@@ -201,21 +202,26 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         return torch.cat(outs, dim=1)
 
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices=None,
-                index=None, grid=None):
-        """`index` / `grid` (beyond the reference's arguments): the level's ops.SiteIndex instead of the dense volume, and its
-        cell_geometry(...) when xyz = get_voxel_centers of that level (eval: the query then computes the centres)."""
+                index=None, grid=None, out=None):
+        """`index` / `grid` / `out` (beyond the reference's arguments): the level's ops.SiteIndex instead of the dense volume, its
+        cell_geometry(...) when xyz = get_voxel_centers of that level (eval: the query then computes the centres), and (eval) the
+        [M, sum C2] block to write -- may be a column slice of wider rows."""
         if self.training:
             self._packed = None
             return self._forward_train(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index)
         with torch.no_grad():
-            return self._forward_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid)
+            return self._forward_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid, out)
 
-    def _forward_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid=None):
+    def _forward_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid=None, out=None):
         if self._packed is None:
             self._pack()
         new_coords = new_coords[:, [0, 3, 2, 1]].contiguous()                 # (b,x,y,z) -> (b,z,y,x), l.84
         n, m = features.shape[0], new_xyz.shape[0]
-        outs = []
+        width = sum(pk["c2"] for pk in self._packed)
+        if out is None:
+            out = torch.empty((m, width), dtype=torch.float32, device=xyz.device)
+        assert out.shape == (m, width) and out.stride(1) == 1
+        col = 0
         for k, pk in enumerate(self._packed):
             fin = ops.gather_conv(features, pk["c0"], pk["w_in"], None, 1, n, pk["c1"], pk["s_in"], pk["t_in"], None, False)
             idx = torch.zeros((m, self.nsamples[k]), dtype=torch.int32, device=xyz.device)
@@ -226,9 +232,16 @@ class NeighborVoxelSAModuleMSG(nn.Module):
                 b, z, y, x = voxel2point_indices.shape
                 check(lib().cpd_voxel_query(m, z, y, x, self.nsamples[k], float(self.radii[k]), zr, yr, xr, ptr(new_xyz), ptr(xyz),
                                             ptr(new_coords), ptr(voxel2point_indices), ptr(idx), stream()), "cpd_voxel_query")
-            pooled = voxel_pool_max(fin, xyz, new_xyz, idx, pk["w_pos"], pk["b_pos"])
-            outs.append(ops.gather_conv(pooled, pk["c1"], pk["w_out"], None, 1, m, pk["c2"], pk["s_out"], pk["t_out"], None, True))
-        return torch.cat(outs, dim=1)
+            if pk["c1"] in (16, 32, 64) and pk["c2"] <= 2 * pk["c1"]:        # pooling + output MLP in one kernel, written straight into the scales' shared rows
+                o = out[:, col:col + pk["c2"]]
+                check(lib().cpd_voxel_pool_max_mlp(m, pk["c1"], self.nsamples[k], _p(fin), fin.stride(0), ptr(xyz), ptr(new_xyz), ptr(idx),
+                                                   ptr(pk["w_pos"]), ptr(pk["b_pos"]), ptr(pk["w_out_folded"]), ptr(pk["t_out"]), pk["c2"], 1,
+                                                   _p(o), out.stride(0), stream()), "cpd_voxel_pool_max_mlp")
+            else:
+                pooled = voxel_pool_max(fin, xyz, new_xyz, idx, pk["w_pos"], pk["b_pos"])
+                out[:, col:col + pk["c2"]] = ops.gather_conv(pooled, pk["c1"], pk["w_out"], None, 1, m, pk["c2"], pk["s_out"], pk["t_out"], None, True)
+            col += pk["c2"]
+        return out
 
 
 def get_voxel_centers(voxel_coords_zyx, downsample_times, voxel_size, point_cloud_range):
@@ -264,6 +277,11 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
     bidx = torch.arange(batch_size, device=rois.device, dtype=gc.dtype).view(-1, 1, 1).expand(-1, gc.shape[1], 1)
     new_cnt = torch.full((batch_size,), gc.shape[1], dtype=torch.int32, device=rois.device)
     pooled = []
+    # eval: the levels' blocks are written side by side into one [M, sum C] tensor by the pooling kernels themselves (no torch.cat)
+    fused = not torch.is_grad_enabled() and all(not layer.training for layer in pool_layers.values())
+    widths = [sum(int(seq[0].out_channels) for seq in layer.mlps_out) for layer in pool_layers.values()] if fused else []
+    whole = torch.empty((gc.shape[0] * gc.shape[1], sum(widths)), dtype=torch.float32, device=rois.device) if fused else None
+    col = 0
     for name, layer in pool_layers.items():
         feats, coords, shape = levels[name]
         stride = strides[name]
@@ -274,8 +292,13 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
         v2p = None if index is not None else generate_voxel2pinds(coords, batch_size, shape)
         out = layer(xyz=xyz, xyz_batch_cnt=cnt, new_xyz=grid_xyz.contiguous().view(-1, 3), new_xyz_batch_cnt=new_cnt,
                     new_coords=cur, features=feats.contiguous(), voxel2point_indices=v2p, index=index,
-                    grid=cell_geometry(voxel_size, stride, point_cloud_range) if index is not None else None)
-        pooled.append(out.view(-1, grid_size ** 3, out.shape[-1]))
+                    grid=cell_geometry(voxel_size, stride, point_cloud_range) if index is not None else None,
+                    **(dict(out=whole[:, col:col + widths[len(pooled)]]) if fused else {}))
+        if fused:
+            col += widths[len(pooled)]
+        pooled.append(out if fused else out.view(-1, grid_size ** 3, out.shape[-1]))
+    if fused:
+        return whole.view(-1, grid_size ** 3, whole.shape[-1])
     return torch.cat(pooled, dim=-1)
 
 

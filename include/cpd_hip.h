@@ -585,6 +585,15 @@ int cpd_group_points_grad(int b, int m, int c, int nsample, int n, const float *
 int cpd_voxel_pool_max(int m, int c, int nsample, const float *features_in, int features_ld,
                        const float *xyz, const float *new_xyz, const int32_t *idx, const float *w_pos,
                        const float *b_pos, float *out, int out_ld, cpd_stream_t stream);
+/* ... followed in the same kernel by the module's output MLP (mlps_out, voxel_pool_modules.py:118-121: 1 x 1 conv, eval BatchNorm,
+ * ReLU): out[m][co] = act(sum_ch pooled[m][ch] * w_out[ch][co] + t_out[co]), w_out [c, c_out] with the BatchNorm scale folded in,
+ * t_out [c_out] its shift; the pooled [m, c] tensor is never stored. out may be a column block of a wider row (out_ld): the
+ * scales of a level are written side by side, as the reference's torch.cat lays them out. c = 16, 32 or 64 and c_out <= 2 c,
+ * else CPD_ERR_UNSUPPORTED. */
+int cpd_voxel_pool_max_mlp(int m, int c, int nsample, const float *features_in, int features_ld,
+                           const float *xyz, const float *new_xyz, const int32_t *idx, const float *w_pos,
+                           const float *b_pos, const float *w_out, const float *t_out, int c_out, int relu,
+                           float *out, int out_ld, cpd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dataloader pre-filter on the device.
