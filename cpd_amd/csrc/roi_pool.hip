@@ -402,7 +402,8 @@ __global__ void __launch_bounds__(256) voxel_pool_max_mlp_kernel(int m, int nsam
                 best = b0 > 0.f ? b0 : 0.f;
             } else {
                 const float nx = new_xyz[3 * (size_t)pt], ny = new_xyz[3 * (size_t)pt + 1], nz = new_xyz[3 * (size_t)pt + 2];
-                for (int s = 0; s < nsample; ++s) {
+#pragma unroll 8
+                for (int s = 0; s < nsample; ++s) {                 // (unrolled: the samples' loads in flight together)
                     const int32_t j = id[s];
                     const float dx = xyz[3 * (size_t)j] - nx, dy = xyz[3 * (size_t)j + 1] - ny, dz = xyz[3 * (size_t)j + 2] - nz;
                     const float pos = ((dx * w0 + dy * w1) + dz * w2) + b0;
