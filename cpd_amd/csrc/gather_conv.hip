@@ -2707,7 +2707,9 @@ static int window_bn(int frames, int h, int w, int c_in, int c_out, int flags) {
         // 64 columns (512 -> 64) keeps the old bound (140 vs 135 us at 277 workgroups)
         if (bn == 128) {
             if (row_tiles * (c_out / 128) >= 500) return 128;
-            return row_tiles * (c_out / 64) >= 250 ? 64 : 0;
+            long long min64w = 300;
+            if (const char *e = cpd_knob(tn, "CPD_GC_WINDOW_MIN64")) min64w = atoll(e);
+            return row_tiles * (c_out / 64) >= min64w ? 64 : 0;     // (round 4: 94 x 94 x 256 -> 256 at ONE frame, 280 tiles: 78.6 here vs 60.7 us on the rulebook path's 64-row tiles)
         }
         if (bn == 16) return row_tiles >= 250 ? 16 : 0;
     }

@@ -1,7 +1,3 @@
-R=$PWD
-cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/ts_prof
-FRAMES=16 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ts_prof -- python $R/tools/two_stage_bench.py > $R/gpurun_out/ts_bench.txt 2>&1
-cd $R
-cp $(ls gpurun_out/ts_prof/*/*kernel_stats.csv | head -1) gpurun_out/ts_kernel_stats.csv
-cp $(ls gpurun_out/ts_prof/*/*kernel_trace.csv | head -1) gpurun_out/ts_kernel_trace.csv
+for rep in 1 2; do for v in 250 300; do
+CPD_TUNE=1 CPD_GC_WINDOW_MIN64=$v python bench.py --frames 1 --streams 1 --steps 300 --warmup 30 --no-extras --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('min64w=$v', d['ms_per_step'])"
+done; done
