@@ -72,6 +72,7 @@ struct GcParams {
     // tap split of the row-wave kernels (small launches): blockIdx.y = z takes every split-th active tap of its row tile and
     // writes its RAW accumulators to part[z][n_out][c_out]; split_finish_kernel sums the parts in order and runs the epilogue
     int split;
+    int epi_lds;              // window kernels: the output tile goes through LDS and leaves as whole 16-byte row pieces (set by the launcher when the tile shape allows)
     float *part;
     // row plan of a sub-manifold rulebook (cpd_rulebook_plan; the staged row-wave kernel): per 128-row tile and dz group of 9 taps
     // the sorted list of DISTINCT input rows the group touches and, per (tap, row), the 16-bit position in that list
@@ -1054,7 +1055,76 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
         if (t == 123.456f) p.out[tid] = t;
         return;
     }
-    epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g, in_inv);
+    if constexpr (BN >= 64) {
+        // Epilogue through LDS (round 4; the 64- and 128-column tiles: c_out is a multiple of the tile there): the tile's rows are
+        // consecutive rows of `out`, so after a transpose in LDS a thread owns (row, four adjacent columns): one 16-byte store (and
+        // residual load), 16 lanes = 256 contiguous bytes of a row -- instead of the fragment-shaped 4-byte accesses (a lane = one column
+        // of four rows) of the shared epilogue. 64 rows per pass: the waves of wave-row `pass` write acc * scale + shift in fragment
+        // coordinates, then everybody adds the residual, applies the ReLU and stores. p.epi_lds = 0: `out` / `residual` are not
+        // 16-byte addressable -- same walk, element accesses.
+        constexpr int LD = BN + 4, WN = BN / WC;
+        constexpr int C4 = BN / 4, RPI = 256 / C4, UNITS = 64 / RPI;        // 16-byte units per row; rows covered per instruction; units per thread and pass
+        static_assert(WM == 64, "a pass is one wave row");
+        float *const stile = reinterpret_cast<float *>(smem);
+        float sc[NT], sh[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = col0 + wc * WN + nt * 16 + r;
+            sc[nt] = p.scale ? p.scale[col] : 1.f;
+            if (p.dsc) sc[nt] *= p.dsc[col];
+            sc[nt] *= in_inv;
+            sh[nt] = p.shift ? p.shift[col] : 0.f;
+        }
+        uint32_t vmax = 0;
+        const int c4 = tid % C4, urow = tid / C4;
+#pragma unroll 1
+        for (int pass = 0; pass < WR; ++pass) {
+            __syncthreads();                         // every wave is done with the last stage's LDS (or the previous pass's tile)
+            if (wr == pass) {
+#pragma unroll
+                for (int s = 0; s < MS; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) stile[(16 * s + 4 * g + i) * LD + wc * WN + 16 * nt + r] = acc[s][nt][i] * sc[nt] + sh[nt];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < UNITS; ++k) {
+                const int lrow = urow + k * RPI;
+                const int row = row0 + pass * 64 + lrow;
+                if (row >= p.n_out) continue;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 4 * c4);
+                float *const op = p.out + (size_t)row * p.out_ld + col0 + 4 * c4;
+                if (p.residual) {
+                    const float *rp = p.residual + (size_t)row * p.res_ld + col0 + 4 * c4;
+                    if (p.epi_lds) v += *reinterpret_cast<const f32x4 *>(rp);
+                    else v += f32x4{rp[0], rp[1], rp[2], rp[3]};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (p.relu) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                    const uint32_t vb = __float_as_uint(v[q]) & 0x7fffffffu;
+                    vmax = vb > vmax ? vb : vmax;
+                }
+                if (p.epi_lds) *reinterpret_cast<f32x4 *>(op) = v;
+                else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
+            }
+        }
+        if (p.out_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t = (uint32_t)__shfl_xor((int)vmax, o);
+                vmax = t > vmax ? t : vmax;
+            }
+            if (lane == 0) {
+                uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+                if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
+            }
+        }
+    } else {
+        epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g, in_inv);
+    }
 }
 
 template <int BN>
@@ -2760,6 +2830,11 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
     const int bm = window_bm(frames, h, w, c_out, bn, flags);
     p.n_rb = (n_out + bm - 1) / bm; p.n_cb = (c_out + bn - 1) / bn; p.items = p.n_rb * p.n_cb;
     p.img_h = h; p.img_w = w;
+    {
+        // the 64- / 128-column tiles' LDS epilogue: 16-byte row pieces when `out` (and `residual`) allow them
+        p.epi_lds = out_ld % 4 == 0 && (((uintptr_t)out) & 15) == 0 && (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0));
+        if (bn >= 64 && c_out % bn) return CPD_ERR_UNSUPPORTED;       // (window_bn never picks such a tile)
+    }
     {
         char nm[96];
         snprintf(nm, sizeof nm, "window_conv_%s_kernel<%d,%d>", math == 2 ? (in_absmax ? "f16s" : "f16") : "bf16", bn, bm);

@@ -1,3 +1,2 @@
-for rep in 1 2; do for v in 250 300; do
-CPD_TUNE=1 CPD_GC_WINDOW_MIN64=$v python bench.py --frames 1 --streams 1 --steps 300 --warmup 30 --no-extras --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('min64w=$v', d['ms_per_step'])"
-done; done
+for f in 16 48; do for lib in tools/probe/libcpd_old.so cpd_amd/csrc/libcpd_hip.so; do echo "FRAMES=$f $lib"; CPD_HIP_LIB=$PWD/$lib FRAMES=$f python tools/conv_bench.py dense f16x2 20 2>&1 | grep -v amdgpu.ids | tail -9; done; done
+python -m pytest tests/test_gpu_dense.py -x -q 2>&1 | tail -3
