@@ -1174,7 +1174,9 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
 // before the commit ("every wave is done with this stage's weights") goes: one barrier per stage instead of two
 // WV = waves per workgroup: 4, or (round 4, fp16-pair rows) 8 -- 256-row workgroups: the (tap, channel block) weight images every
 // workgroup re-fetches through the vector L1 serve twice the rows (at 128 columns they are HALF of a 128-row workgroup's L1 traffic)
-template <class S, int BN, int MS, bool SC = false, bool PS = false, int WB = 1, int WV = 4>
+// EPI (fp16-pair kernels): the instantiation's epilogue goes through LDS (see the end of the body) -- a second kernel rather than a
+// branch: with both epilogues in one kernel the 64-column instantiation spilled an accumulator inside its stage loop
+template <class S, int BN, int MS, bool SC = false, bool PS = false, int WB = 1, int WV = 4, bool EPI = false>
 __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb0, int *const sidx) {
     float in_s = 1.f, in_inv = 1.f;
     if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
@@ -1459,7 +1461,95 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             }
         return;
     }
-    epilogue<MS, NT, true>(p, acc, row0, col0, r, g, in_inv);
+    if constexpr (!EPI) {
+        epilogue<MS, NT, true>(p, acc, row0, col0, r, g, in_inv);
+    } else {
+        // Epilogue through LDS (round 4; fp16-pair rows in and out): a wave's rows are consecutive rows of `out` and of the residual. Its
+        // accumulators go to a wave-private LDS tile in row-major order; a lane then owns (row, 8 adjacent channels) units: 32 contiguous
+        // bytes of accumulators, one 16-byte piece of the residual row's high terms and one of its low terms, two 16-byte stores -- against
+        // the shared epilogue's 2-byte residual loads and 4-byte stores in fragment coordinates (a lane = one column of four rows).
+        // The tile aliases the weight buffers and the rulebook columns (nobody needs them any more): EPI_R rows per wave and pass.
+        constexpr int EPI_R = (BN == 32 && MS == 2 && WV == 4) ? 32 : 16;
+        constexpr int LD = BN + 4, UPR = BN / 8, RPI = 64 / UPR, UNITS = EPI_R / RPI;   // floats per tile row; units per row; rows per instruction; units per lane and pass
+        float *const stile = reinterpret_cast<float *>(sb0) + wave * (EPI_R * LD);
+        int ln = lane, rc = r;
+        asm volatile("" : "+v"(ln), "+v"(rc));       // nothing of the epilogue is computed (or loaded) above this point: the stage loop of the
+                                                     // 64-column kernel sits at its register budget (95 of 96) and spilled an accumulator otherwise
+        const int cg = ln % UPR, urow = ln / UPR;
+        float sc[NT], sh[NT];                        // scale / shift in fragment coordinates, as the accumulators leave the registers
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = col0 + 16 * nt + rc;
+            sc[nt] = p.scale ? p.scale[col] : 1.f;
+            if (p.dsc) sc[nt] *= p.dsc[col];
+            sc[nt] *= in_inv;
+            sh[nt] = p.shift ? p.shift[col] : 0.f;
+        }
+        uint32_t vmax = 0;
+        const int pair_off = (((col0 >> 3) + cg) >> 2 << 7) + ((((col0 >> 3) + cg) & 3) << 4);     // byte offset of the unit's high terms in a pair row
+#pragma unroll
+        for (int pass = 0; pass < 16 * MS / EPI_R; ++pass) {
+            __syncthreads();                         // every wave is done with the last stage's LDS (or, wave by wave, the previous pass's tile)
+#pragma unroll
+            for (int s = 0; s < EPI_R / 16; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) stile[(16 * s + 4 * g + i) * LD + 16 * nt + r] = acc[pass * (EPI_R / 16) + s][nt][i] * sc[nt] + sh[nt];
+            __syncthreads();
+            constexpr int UC = UNITS > 2 ? 2 : UNITS;        // units whose residual pieces are in flight together
+            f16x8 rh[UC], rl[UC];
+#pragma unroll
+            for (int k = 0; k < UNITS; ++k) {
+                if (p.residual && k % UC == 0) {
+#pragma unroll
+                    for (int kc = 0; kc < UC; ++kc) {
+                        const int row = row0 + pass * EPI_R + urow + (k + kc) * RPI;
+                        const int rowc = row < p.n_out ? row : p.n_out - 1;
+                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + pair_off;
+                        rh[kc] = *reinterpret_cast<const f16x8 *>(rp);
+                        rl[kc] = *reinterpret_cast<const f16x8 *>(rp + 64);
+                    }
+                }
+                const int lrow = urow + k * RPI;
+                const int row = row0 + pass * EPI_R + lrow;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * cg);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * cg + 4);
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = q < 4 ? v0[q] : v1[q - 4];
+                    if (p.residual) v += (float)rh[k % UC][q] + (float)rl[k % UC][q];   // h + l is exact in fp32
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    t[q] = v;
+                    const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
+                    vmax = (row < p.n_out && vb > vmax) ? vb : vmax;
+                }
+                if (row < p.n_out) {
+                    f16x8 h, l;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        h[q] = (_Float16)t[q];
+                        l[q] = (_Float16)(t[q] - (float)h[q]);
+                    }
+                    char *op = reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld) + pair_off;
+                    *reinterpret_cast<f16x8 *>(op) = h;
+                    *reinterpret_cast<f16x8 *>(op + 64) = l;
+                }
+            }
+        }
+        if (p.out_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t = (uint32_t)__shfl_xor((int)vmax, o);
+                vmax = t > vmax ? t : vmax;
+            }
+            if (lane == 0) {
+                uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+                if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
+            }
+        }
+    }
 }
 
 // The second half of a tap-split launch: thread = (row, four adjacent columns); parts summed in z order (deterministic), then the
@@ -1551,6 +1641,14 @@ rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcPar
     __shared__ __attribute__((aligned(16))) char sb[CPD_RW_WB * SplitF16x2::NP * BN * 64];   // weight buffers
     __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
     rowwave_conv_split_body<SplitF16x2, BN, MS, false, true, CPD_RW_WB>(p, sb, sidx);
+}
+template <int BN, int MS = 2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : (BN == 64 && MS == 2 ? 5 : 4), 8)))
+rowwave_conv_f16pe_kernel(GcParams p) {           // ... pair rows out too, in place: the epilogue through LDS (GcParams::epi_lds)
+    constexpr int SB = CPD_RW_WB * SplitF16x2::NP * BN * 64;                    // weight buffers, then the rulebook columns: ONE array, the
+    __shared__ __attribute__((aligned(16))) char sm[SB + 4 * CPD_RW_TAPS * 16 * MS * 4];    // epilogue's tile aliases both
+    static_assert(sizeof(sm) >= 4 * ((BN == 32 && MS == 2) ? 32 : 16) * (BN + 4) * 4, "epilogue tile");
+    rowwave_conv_split_body<SplitF16x2, BN, MS, false, true, CPD_RW_WB, 4, true>(p, sm, reinterpret_cast<int *>(sm + SB));
 }
 #ifndef CPD_RW8_DEFAULT
 #define CPD_RW8_DEFAULT 0            // column-tile widths (sum of 32 / 64 / 128) that take the wide-workgroup variant by default
@@ -2634,10 +2732,17 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         const int sp = rowwave_split(pl, n_out, c_in, c_out, kv);
         if (sp > 1 && part_bytes >= (size_t)sp * n_out * c_out * sizeof(float)) { p.split = sp; p.part = part; }
     }
+    {   // the pair-row row-wave kernels' LDS epilogue (rowwave_conv_split_body): pair rows out, a pair-row residual or none, rows in place
+        int epi = 1;                                 // tuning: 0 = the shared fragment-shaped epilogue
+        if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_RW_EPI")) epi = atoi(e);
+        p.epi_lds = epi && pl.use_wg == 3 && pl.a <= 128 && pl.math == 2 && p.in_pairs && p.out_pairs == 1 && (!residual || p.res_pairs == 1) && !out_row_map &&
+                    !out_col_group && p.split == 1 && out_ld % 4 == 0 && (((uintptr_t)out) & 15) == 0 &&
+                    (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0));
+    }
     const dim3 grid(p.items, p.split), block(pl.use_wg == 3 && pl.a > 128 ? pl.a * 2 : 256);
     {   // launch log (cpd_launch_log_*): the instantiation this call runs
         char nm[96];
-        const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? (p.in_pairs ? "f16p" : "f16") : "bf16");
+        const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? (p.in_pairs ? (p.epi_lds ? "f16pe" : "f16p") : "f16") : "bf16");
         if (pl.use_wg == 3 && pl.a > 128) snprintf(nm, sizeof nm, "rowwave_conv_f16pw_kernel<%d,%d>", pl.b, pl.a / 32);
         else if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
         else if (pl.use_wg == 2) snprintf(nm, sizeof nm, "tile_conv_%s_kernel<%d,%d>", sc, pl.a, pl.b);
@@ -2655,6 +2760,16 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16s_kernel<32, 2>), 0);
         else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16s_kernel<64, 2>), 0);
         else CPD_LAUNCH((rowwave_conv_f16s_kernel<128, 2>), 0);
+        return rowwave_finish(p, hs);
+    }
+    if (pl.use_wg == 3 && pl.math == 2 && p.in_pairs && p.epi_lds) {
+        if (pl.a == 64) {
+            if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16pe_kernel<32, 1>), 0);
+            else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16pe_kernel<64, 1>), 0);
+            else CPD_LAUNCH((rowwave_conv_f16pe_kernel<128, 1>), 0);
+        } else if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16pe_kernel<32, 2>), 0);
+        else if (pl.b == 64) CPD_LAUNCH((rowwave_conv_f16pe_kernel<64, 2>), 0);
+        else CPD_LAUNCH((rowwave_conv_f16pe_kernel<128, 2>), 0);
         return rowwave_finish(p, hs);
     }
     if (pl.use_wg == 3 && pl.math == 2 && p.in_pairs) {

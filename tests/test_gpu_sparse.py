@@ -265,7 +265,8 @@ def test_fp16_pair_rows_give_the_fp32_rows_result(oracle, hip, cin, cout, n, wan
         assert len(log.counts) == 1 and next(iter(log.counts)).startswith("gather_conv_h16_kernel<"), log.counts
     elif in_pairs:
         convs = {k: v for k, v in log.counts.items() if k != "split_finish_kernel"}      # (small launches split their taps: two launches)
-        assert convs == {"rowwave_conv_f16p_kernel" + want: 1}, log.counts
+        # (f16pe: the same body with its epilogue through LDS -- pair rows out, in place, no tap split: GcParams::epi_lds)
+        assert convs in ({"rowwave_conv_f16p_kernel" + want: 1}, {"rowwave_conv_f16pe_kernel" + want: 1}), log.counts
     got = ops.pairs_to_rows(got_p).cpu().numpy()
     ref = oracle.sparse_conv(feat, w, None, nbr.cpu().numpy())
     ref = np.maximum(ref * scale + shift + res, 0)
@@ -445,3 +446,37 @@ def test_chunk_ordered_rulebooks_equal_the_plain_builders(hip):
         b = ops.rulebook_conv(out_c, index, k, s, pad, canonical=(out_c, None, 4096))
         assert torch.equal(a, b) and torch.equal(a.tapmask, b.tapmask)
     ops.CHUNKED_MIN_ROWS = keep_min
+
+
+@pytest.mark.parametrize("c", [32, 64, 128])
+def test_rowwave_lds_epilogue_equals_the_shared_epilogue(hip, c, monkeypatch):
+    """Round 4: `rowwave_conv_f16pe_kernel` -- the pair-row row-wave kernel with its epilogue through LDS (transposed tile, 16-byte
+    residual pieces in, 16-byte pair pieces out) -- against `rowwave_conv_f16p_kernel` (fragment-shaped epilogue) on the same launch:
+    same accumulators, the same scale / shift / residual / ReLU arithmetic (<= 1 ulp apart where the compiler contracts differently),
+    with and without the residual, on a row count that is not a multiple of the tile. Both against the oracle elsewhere in this file."""
+    import torch
+    from cpd_amd import ops
+    rng = np.random.default_rng(c)
+    batch, shape = 2, [9, 128, 128]
+    idx = random_sites(rng, batch, shape, 90001)          # >= 600 row tiles: no tap split (a split launch finishes in split_finish_kernel)
+    d_idx = dev(idx)
+    rows = idx.shape[0]
+    nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
+    g = torch.Generator().manual_seed(c)
+    xp = ops.rows_to_pairs((torch.randn(rows, c, generator=g) * 2).cuda())
+    rp = ops.rows_to_pairs(torch.randn(rows, c, generator=g).cuda())
+    packed = ops.pack_weight((torch.randn(27, c, c, generator=g) * (2.0 / (27 * c)) ** 0.5).cuda())
+    scale, shift = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.1).cuda()
+    monkeypatch.setenv("CPD_TUNE", "1")
+    for res, relu in ((rp, True), (None, False)):
+        outs = {}
+        for epi in ("0", "1"):
+            monkeypatch.setenv("CPD_GC_RW_EPI", epi)
+            rb = ops.absmax_blocks(1, xp.device)[0]
+            with ops.launch_log() as log:
+                outs[epi] = ops.gather_conv(xp, c, packed, nbr, 27, rows, c, scale, shift, res, relu, math="f16x2", in_pairs=True, out_pairs=True,
+                                            res_pairs=res is not None, out_absmax=rb)
+            assert list(log.counts) == ["rowwave_conv_f16p%s_kernel<%d,2>" % ("e" if epi == "1" else "", c)], log.counts
+            outs[epi] = (ops.pairs_to_rows(outs[epi]), int(rb.max()))
+        np.testing.assert_allclose(outs["1"][0].cpu().numpy(), outs["0"][0].cpu().numpy(), atol=4e-6, rtol=0)
+        assert abs(outs["1"][1] - outs["0"][1]) <= 2          # the range guard's absmax word (float bits): the same maximum
