@@ -1212,19 +1212,15 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
 #pragma unroll
     for (int s = 0; s < MS; ++s) my_mask[s] = wg_mask;
     if (p.tapmask) {
+        // one vector load of the workgroup's WG_SUBS words (lane i = sub-tile i), then lane reads: as a loop of scalar loads with a
+        // bound check each, the compiler waited for every word before asking for the next
+        const int sub = rb * WG_SUBS + (lane < WG_SUBS ? lane : 0);
+        const uint32_t mine = (lane < WG_SUBS && sub < p.n_sub) ? p.tapmask[sub] : 0u;
         wg_mask = 0;
 #pragma unroll
-        for (int i = 0; i < WG_SUBS; ++i) {
-            const int sub = rb * WG_SUBS + i;
-            const uint32_t m = sub < p.n_sub ? p.tapmask[sub] : 0u;
-            wg_mask |= m;
+        for (int i = 0; i < WG_SUBS; ++i) wg_mask |= (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
 #pragma unroll
-            for (int s = 0; s < MS; ++s)
-                if (i == MS * wave + s) my_mask[s] = m;
-        }
-#pragma unroll
-        for (int s = 0; s < MS; ++s) my_mask[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_mask[s]);
-        wg_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)wg_mask);
+        for (int s = 0; s < MS; ++s) my_mask[s] = (uint32_t)__builtin_amdgcn_readlane((int)mine, MS * wave + s);
     }
 
     if (p.split > 1) {                               // this workgroup's share of the tile's taps: every split-th active one
@@ -1277,13 +1273,21 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
 #pragma unroll
             for (int s = 0; s < MS; ++s) my_any |= my_mask[s];
             const int wrow0 = row0;
-            for (int e = lane; e < p.kv * 16 * MS; e += 64) {
-                const int t = e / (16 * MS), rr = e - t * (16 * MS);
-                if (!((my_any >> t) & 1u)) continue;
-                const int row = wrow0 + rr;
-                int v = -1;
-                if (row < p.n_out) v = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
-                my_idx[t * 16 * MS + rr] = v;
+            // all the columns' loads first, then the LDS writes (round 4): as a fetch-and-store loop this was 14 SERIAL global round
+            // trips per wave -- load, s_waitcnt vmcnt(0), ds_write, next -- before the first stage could start
+            constexpr int U = (CPD_RW_TAPS * 16 * MS + 63) / 64;
+            const int n_el = p.kv * 16 * MS;
+            int v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = u * 64 + lane, t = e / (16 * MS), row = wrow0 + (e & (16 * MS - 1));
+                v[u] = -1;
+                if (e < n_el && ((my_any >> t) & 1u) && row < p.n_out) v[u] = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = u * 64 + lane;
+                if (e < n_el && ((my_any >> (e / (16 * MS))) & 1u)) my_idx[e] = v[u];
             }
         }
 
