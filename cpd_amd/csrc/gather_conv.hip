@@ -35,6 +35,8 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic builds only (tools/probe): bit 0 drops the B loads, bit 1 the A gathers, so the MFMA
 // loop can be timed without its memory traffic. The shipped library is built with 0.
@@ -360,14 +362,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H16 &&
     // inside it unconditional and counted on vmcnt alone.
     __shared__ int s_idx[4][32][16 * MS];
     {
-        const int total = p.kv * 16 * MS;
-        for (int e = lane; e < total; e += 64) {
-            const int t = e / (16 * MS), rr = e - t * (16 * MS);
-            if (t < 32 && !((any >> t) & 1u)) continue;      // a tap no sub-tile has: its column is never read
-            const int row = row0 + rr;
-            int v = -1;
-            if (row < p.n_out) v = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
-            s_idx[wave][t][rr] = v;
+        // (round 4: UB columns' loads in flight together, then their LDS writes -- element by element this was one global round trip per
+        // 64 entries, 14 in a row for a 27-tap kernel, before the first step: a third of a level-1 wave's life)
+        const int total = (p.kv < 32 ? p.kv : 32) * 16 * MS;
+        constexpr int UB = 8;
+        int *const flat = &s_idx[wave][0][0];
+        for (int e0 = 0; e0 < total; e0 += 64 * UB) {
+            int v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int e = e0 + u * 64 + lane, t = e / (16 * MS), row = row0 + (e & (16 * MS - 1));
+                v[u] = -1;
+                if (e < total && ((any >> t) & 1u) && row < p.n_out) v[u] = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;   // a tap no sub-tile has: never read
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int e = e0 + u * 64 + lane;
+                if (e < total && ((any >> (e / (16 * MS))) & 1u)) flat[e] = v[u];
+            }
         }
     }
     (void)rowc; (void)rowok;
@@ -444,6 +456,96 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H16 &&
             load(R0);
             mma(R1);
             if (t_cur < 0) break;
+        }
+    }
+    if constexpr (H16 && NT <= 2 && 16 * (16 * NT + 4) <= 32 * 16 * MS) {
+        if (p.epi_lds) {
+            // Epilogue through LDS (round 4; the level-1 layers: 16-channel pair rows in, 16- or 32-channel pair rows out, in place):
+            // sub-tile by sub-tile the accumulators go to a wave-private tile (this wave's rulebook columns: not needed any more) in
+            // row-major order; a lane then owns one 16-byte piece of a row -- [hi 4 | lo 4] of a k-group (16 columns) or the hi / lo
+            // halves of 8 channels (32 columns) -- and of the residual row: whole pieces instead of 2-byte loads and 4-byte stores in
+            // fragment coordinates. The waves of a workgroup are independent items: wave-local ordering only (DS operations of a wave
+            // execute in order).
+            constexpr int LD = 16 * NT + 4;
+            float *const stile = reinterpret_cast<float *>(&s_idx[wave][0][0]);
+            float sc[NT], sh[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = col0 + 16 * nt + r;
+                sc[nt] = p.scale ? p.scale[col] : 1.f;
+                if (p.dsc) sc[nt] *= p.dsc[col];
+                sh[nt] = p.shift ? p.shift[col] : 0.f;
+            }
+            uint32_t vmax = 0;
+            const int urow = lane >> 2, piece = lane & 3;
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) stile[(4 * g + i) * LD + 16 * nt + r] = acc[s][nt][i] * sc[nt] + sh[nt];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int row = row0 + 16 * s + urow;
+                const int rowc = row < p.n_out ? row : p.n_out - 1;
+                if constexpr (NT == 1) {                     // [hi 4 | lo 4] of k-group `piece`
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(stile + urow * LD + 4 * piece);
+                    if (p.residual) {
+                        const f16x8 x = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + (((col0 >> 2) + piece) << 4));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += (float)x[q] + (float)x[4 + q];
+                    }
+                    f16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (p.relu) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                        const uint32_t vb = __float_as_uint(v[q]) & 0x7fffffffu;
+                        vmax = (row < p.n_out && vb > vmax) ? vb : vmax;
+                        o[q] = (_Float16)v[q];
+                        o[4 + q] = (_Float16)(v[q] - (float)o[q]);
+                    }
+                    if (row < p.n_out) *reinterpret_cast<f16x8 *>(reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld) + (((col0 >> 2) + piece) << 4)) = o;
+                } else {                                     // 8 channels of a 32-channel block: high terms, low terms 64 bytes on
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stile + urow * LD + 8 * piece);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stile + urow * LD + 8 * piece + 4);
+                    const int unit = (col0 >> 3) + piece;
+                    const int off = ((unit >> 2) << 7) + ((unit & 3) << 4);
+                    f16x8 rh = {}, rl = {};
+                    if (p.residual) {
+                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + off;
+                        rh = *reinterpret_cast<const f16x8 *>(rp);
+                        rl = *reinterpret_cast<const f16x8 *>(rp + 64);
+                    }
+                    f16x8 h, l;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float v = q < 4 ? v0[q] : v1[q - 4];
+                        if (p.residual) v += (float)rh[q] + (float)rl[q];
+                        if (p.relu) v = v > 0.f ? v : 0.f;
+                        const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
+                        vmax = (row < p.n_out && vb > vmax) ? vb : vmax;
+                        h[q] = (_Float16)v;
+                        l[q] = (_Float16)(v - (float)h[q]);
+                    }
+                    if (row < p.n_out) {
+                        char *op = reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld) + off;
+                        *reinterpret_cast<f16x8 *>(op) = h;
+                        *reinterpret_cast<f16x8 *>(op + 64) = l;
+                    }
+                }
+            }
+            if (p.out_absmax) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t t = (uint32_t)__shfl_xor((int)vmax, o);
+                    vmax = t > vmax ? t : vmax;
+                }
+                if (lane == 0) {
+                    uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+                    if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
+                }
+            }
+            return;
         }
     }
     epilogue<MS, NT, true>(p, acc, row0, col0, r, g);
@@ -590,8 +692,6 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(GcParams p) {
 //   B: k-group g of tile col n at (g*BN + n) * 16          (lane-linear both ways)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 
 struct SplitBf16x3 {
@@ -2863,6 +2963,12 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     if (in16) {
         p.wb = packed_h16_ptr(packed_w, kv, c_in, c_out);
         p.dsc = reinterpret_cast<const float *>(p.wb) + packed_h16_image_floats(kv, c_in, c_out);
+        int epi = 1;                                 // the level-1 kernels' LDS epilogue (gather_conv_kernel, H16): pair rows out, in place, one column tile
+        if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_H16_EPI")) epi = atoi(e);
+        p.epi_lds = epi && pl.b * 16 == c_out && !out_row_map && !out_col_group && out_ld % 4 == 0 && (((uintptr_t)out) & 15) == 0 &&
+                    (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0)) &&
+                    ((c_out == 16 && p.out_pairs == 2 && (!residual || p.res_pairs == 2)) ||
+                     (c_out == 32 && p.out_pairs == 1 && (!residual || p.res_pairs == 1)));
     }
     p.n_rb = (n_out + 16 * pl.a - 1) / (16 * pl.a);
     p.n_cb = p.ntot / pl.b;

@@ -480,3 +480,33 @@ def test_rowwave_lds_epilogue_equals_the_shared_epilogue(hip, c, monkeypatch):
             outs[epi] = (ops.pairs_to_rows(outs[epi]), int(rb.max()))
         np.testing.assert_allclose(outs["1"][0].cpu().numpy(), outs["0"][0].cpu().numpy(), atol=4e-6, rtol=0)
         assert abs(outs["1"][1] - outs["0"][1]) <= 2          # the range guard's absmax word (float bits): the same maximum
+
+
+@pytest.mark.parametrize("cout", [16, 32])
+def test_h16_lds_epilogue_equals_the_shared_epilogue(hip, cout, monkeypatch):
+    """Round 4: the level-1 kernels (`gather_conv_h16_kernel`: 16-channel pair rows in, 16- or 32-channel pair rows out) with their
+    epilogue through LDS (CPD_GC_H16_EPI, the default) against the shared fragment-shaped epilogue on the same launch: <= 1 ulp apart,
+    with the pair residual + ReLU of a SparseBasicBlock (16 -> 16) and without (the 16 -> 32 down-sampling layer's SubM stand-in)."""
+    import torch
+    from cpd_amd import ops
+    rng = np.random.default_rng(cout)
+    batch, shape = 2, [9, 128, 128]
+    idx = random_sites(rng, batch, shape, 50001)
+    d_idx = dev(idx)
+    rows = idx.shape[0]
+    nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
+    g = torch.Generator().manual_seed(cout)
+    xp = ops.rows_to_pairs((torch.randn(rows, 16, generator=g) * 2).cuda())
+    rp = ops.rows_to_pairs(torch.randn(rows, cout, generator=g).cuda())
+    packed = ops.pack_weight((torch.randn(27, 16, cout, generator=g) * (2.0 / (27 * 16)) ** 0.5).cuda())
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+    monkeypatch.setenv("CPD_TUNE", "1")
+    for res, relu in ((rp, True), (None, False)):
+        outs = {}
+        for epi in ("0", "1"):
+            monkeypatch.setenv("CPD_GC_H16_EPI", epi)
+            with ops.launch_log() as log:
+                outs[epi] = ops.pairs_to_rows(ops.gather_conv(xp, 16, packed, nbr, 27, rows, cout, scale, shift, res, relu, math="f16x2", in_pairs=True,
+                                                              out_pairs=True, res_pairs=res is not None))
+            assert len(log.counts) == 1 and next(iter(log.counts)).startswith("gather_conv_h16_kernel<"), log.counts
+        np.testing.assert_allclose(outs["1"].cpu().numpy(), outs["0"].cpu().numpy(), atol=4e-6, rtol=0)
