@@ -889,7 +889,88 @@ __device__ __forceinline__ void tile_conv_split_body(const GcParams &p) {
             }
         return;
     }
-    epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g, in_inv);
+    if constexpr (BM == 128 && BN == 128) {
+        // Epilogue through LDS (round 4; as the window kernels'): 32 rows per pass -- two sub-tiles of the waves of one wave row -- go to
+        // a row-major tile, then a thread owns (row, four adjacent columns): 16-byte residual loads and stores, also through the row
+        // map / the column-group scatter of a ConvTranspose run as one GEMM (a group is a multiple of four columns wide there).
+        // p.epi_lds = 0: `out` / `residual` / the group width do not allow 16-byte pieces -- same walk, element accesses.
+        constexpr int LD = BN + 4, C4 = BN / 4, RPI = 256 / C4, UNITS = 32 / RPI;
+        float *const stile = reinterpret_cast<float *>(smem);
+        float sc[NT], sh[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = col0 + wc * (BN / 2) + nt * 16 + r;
+            sc[nt] = p.scale ? p.scale[col] : 1.f;
+            if (p.dsc) sc[nt] *= p.dsc[col];
+            sc[nt] *= in_inv;
+            sh[nt] = p.shift ? p.shift[col] : 0.f;
+        }
+        uint32_t vmax = 0;
+        const int c4 = tid % C4, urow = tid / C4;
+        const int col = col0 + 4 * c4;
+        const int grp = p.col_group ? col / p.col_group : 0, cloc = col - grp * p.col_group;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {       // (unrolled: the accumulator indices must be constants)
+            __syncthreads();                         // every wave is done with the last stage's LDS (or the previous pass's tile)
+            if (wr == (pass >> 1)) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            stile[(16 * s2 + 4 * g + i) * LD + wc * (BN / 2) + 16 * nt + r] = acc[(pass & 1) * 2 + s2][nt][i] * sc[nt] + sh[nt];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < UNITS; ++k) {
+                const int lrow = urow + k * RPI;
+                const int row = row0 + pass * 32 + lrow;
+                if (row >= p.n_out) continue;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 4 * c4);
+                if (p.residual) {
+                    const float *rp = p.residual + (size_t)row * p.res_ld + col;
+                    if (p.epi_lds) v += *reinterpret_cast<const f32x4 *>(rp);
+                    else v += f32x4{rp[0], rp[1], rp[2], rp[3]};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (p.relu) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                    const uint32_t vb = __float_as_uint(v[q]) & 0x7fffffffu;
+                    vmax = vb > vmax ? vb : vmax;
+                }
+                if (p.epi_lds) {
+                    float *op;
+                    if (p.col_group) op = p.out + (size_t)p.out_row_map[(size_t)grp * p.n_out + row] * p.out_ld + cloc;
+                    else op = p.out + (p.out_row_map ? (size_t)p.out_row_map[row] : (size_t)row) * p.out_ld + col;
+                    *reinterpret_cast<f32x4 *>(op) = v;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (p.col_group) {
+                            const int gq = (col + q) / p.col_group;
+                            p.out[(size_t)p.out_row_map[(size_t)gq * p.n_out + row] * p.out_ld + (col + q - gq * p.col_group)] = v[q];
+                        } else {
+                            p.out[(p.out_row_map ? (size_t)p.out_row_map[row] : (size_t)row) * p.out_ld + col + q] = v[q];
+                        }
+                    }
+                }
+            }
+        }
+        if (p.out_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t = (uint32_t)__shfl_xor((int)vmax, o);
+                vmax = t > vmax ? t : vmax;
+            }
+            if (lane == 0) {
+                uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+                if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
+            }
+        }
+    } else {
+        epilogue<MS, NT>(p, acc, row0 + wr * (BM / 2), col0 + wc * (BN / 2), r, g, in_inv);
+    }
 }
 
 template <int BM, int BN, bool DB>
@@ -2843,6 +2924,9 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
                     !out_col_group && p.split == 1 && out_ld % 4 == 0 && (((uintptr_t)out) & 15) == 0 &&
                     (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0));
     }
+    if (pl.use_wg == 2)      // the 128 x 128 split tile kernels' LDS epilogue: 16-byte pieces when the operands allow (element accesses otherwise)
+        p.epi_lds = out_ld % 4 == 0 && (((uintptr_t)out) & 15) == 0 && (!out_col_group || out_col_group % 4 == 0) &&
+                    (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0));
     const dim3 grid(p.items, p.split), block(pl.use_wg == 3 && pl.a > 128 ? pl.a * 2 : 256);
     {   // launch log (cpd_launch_log_*): the instantiation this call runs
         char nm[96];

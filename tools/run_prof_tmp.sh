@@ -1,3 +1,2 @@
-python -m pytest tests/test_gpu_sparse.py tests/test_gpu_pipeline.py -x -q 2>&1 | tail -3
-CPD_HIP_LIB=$PWD/tools/probe/libcpd_head.so python bench.py --no-extras --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('head', d['value'], d['ms_per_step'], d['roofline']['frac']); print({k:round(v['ms_per_frame'],4) for k,v in d['roofline']['all_conv_kernels'].items() if 'h16' in k or 'false' in k})"
-python bench.py --no-extras --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('new', d['value'], d['ms_per_step'], d['roofline']['frac'], d['results_digest'].get('equal_to_single_stream_pass')); print({k:round(v['ms_per_frame'],4) for k,v in d['roofline']['all_conv_kernels'].items() if 'h16' in k or 'false' in k})"
+for f in 48; do for lib in tools/probe/libcpd_head.so cpd_amd/csrc/libcpd_hip.so; do echo "FRAMES=$f $lib"; CPD_HIP_LIB=$PWD/$lib FRAMES=$f python tools/conv_bench.py dense f16x2 20 2>&1 | grep -v amdgpu.ids | grep "tile_conv"; done; done
+python -m pytest tests/test_gpu_dense.py tests/test_gpu_train.py tests/test_gpu_autograd.py -x -q 2>&1 | tail -3
