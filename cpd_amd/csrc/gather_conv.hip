@@ -1355,9 +1355,10 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
 // before the commit ("every wave is done with this stage's weights") goes: one barrier per stage instead of two
 // WV = waves per workgroup: 4, or (round 4, fp16-pair rows) 8 -- 256-row workgroups: the (tap, channel block) weight images every
 // workgroup re-fetches through the vector L1 serve twice the rows (at 128 columns they are HALF of a 128-row workgroup's L1 traffic)
-// EPI (fp16-pair kernels): the instantiation's epilogue goes through LDS (see the end of the body) -- a second kernel rather than a
-// branch: with both epilogues in one kernel the 64-column instantiation spilled an accumulator inside its stage loop
-template <class S, int BN, int MS, bool SC = false, bool PS = false, int WB = 1, int WV = 4, bool EPI = false>
+// EPI != 0: the instantiation's epilogue goes through LDS (see the end of the body; 1: `out` / `residual` are fp16-pair rows, 2: fp32
+// rows) -- separate kernels rather than branches: with both epilogues in one kernel, or with the row format a run-time flag, the
+// 64-column instantiation spilled an accumulator inside its stage loop
+template <class S, int BN, int MS, bool SC = false, bool PS = false, int WB = 1, int WV = 4, int EPI = 0>
 __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char *const sb0, int *const sidx) {
     float in_s = 1.f, in_inv = 1.f;
     if (SC) in_pow2_scale(p.in_absmax, in_s, in_inv);
@@ -1646,13 +1647,14 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             }
         return;
     }
-    if constexpr (!EPI) {
+    if constexpr (EPI == 0) {
         epilogue<MS, NT, true>(p, acc, row0, col0, r, g, in_inv);
     } else {
-        // Epilogue through LDS (round 4; fp16-pair rows in and out): a wave's rows are consecutive rows of `out` and of the residual. Its
-        // accumulators go to a wave-private LDS tile in row-major order; a lane then owns (row, 8 adjacent channels) units: 32 contiguous
-        // bytes of accumulators, one 16-byte piece of the residual row's high terms and one of its low terms, two 16-byte stores -- against
-        // the shared epilogue's 2-byte residual loads and 4-byte stores in fragment coordinates (a lane = one column of four rows).
+        constexpr bool OP = EPI == 1;                // pair rows (out and residual) or fp32 rows
+        // Epilogue through LDS (round 4; rows written in place, pair rows or fp32 rows on either side): a wave's rows are consecutive rows
+        // of `out` and of the residual. Its accumulators go to a wave-private LDS tile in row-major order; a lane then owns (row, 8 adjacent
+        // channels) units: 32 contiguous bytes of accumulators, two 16-byte pieces of the residual row, two 16-byte stores -- against the
+        // shared epilogue's 2- / 4-byte residual loads and 4-byte stores in fragment coordinates (a lane = one column of four rows).
         // The tile aliases the weight buffers and the rulebook columns (nobody needs them any more): EPI_R rows per wave and pass.
         constexpr int EPI_R = (BN == 32 && MS == 2 && WV == 4) ? 32 : 16;
         constexpr int LD = BN + 4, UPR = BN / 8, RPI = 64 / UPR, UNITS = EPI_R / RPI;   // floats per tile row; units per row; rows per instruction; units per lane and pass
@@ -1671,7 +1673,12 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             sh[nt] = p.shift ? p.shift[col] : 0.f;
         }
         uint32_t vmax = 0;
-        const int pair_off = (((col0 >> 3) + cg) >> 2 << 7) + ((((col0 >> 3) + cg) & 3) << 4);     // byte offset of the unit's high terms in a pair row
+        // a unit's two 16-byte pieces in a row of `out` / `residual`: pair rows -- the high terms of its 8 channels, the low terms 64 bytes
+        // on --, fp32 rows -- channels 0-3 and 4-7
+        const int pair_off = (((col0 >> 3) + cg) >> 2 << 7) + ((((col0 >> 3) + cg) & 3) << 4);
+        const int f32_off = (col0 + 8 * cg) * 4;
+        const int res_off = OP ? pair_off : f32_off;
+        constexpr int res_2nd = OP ? 64 : 16;
 #pragma unroll
         for (int pass = 0; pass < 16 * MS / EPI_R; ++pass) {
             __syncthreads();                         // every wave is done with the last stage's LDS (or, wave by wave, the previous pass's tile)
@@ -1683,7 +1690,7 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                     for (int i = 0; i < 4; ++i) stile[(16 * s + 4 * g + i) * LD + 16 * nt + r] = acc[pass * (EPI_R / 16) + s][nt][i] * sc[nt] + sh[nt];
             __syncthreads();
             constexpr int UC = UNITS > 2 ? 2 : UNITS;        // units whose residual pieces are in flight together
-            f16x8 rh[UC], rl[UC];
+            f32x4 ra[UC], rb[UC];
 #pragma unroll
             for (int k = 0; k < UNITS; ++k) {
                 if (p.residual && k % UC == 0) {
@@ -1691,9 +1698,9 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                     for (int kc = 0; kc < UC; ++kc) {
                         const int row = row0 + pass * EPI_R + urow + (k + kc) * RPI;
                         const int rowc = row < p.n_out ? row : p.n_out - 1;
-                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + pair_off;
-                        rh[kc] = *reinterpret_cast<const f16x8 *>(rp);
-                        rl[kc] = *reinterpret_cast<const f16x8 *>(rp + 64);
+                        const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + res_off;
+                        ra[kc] = *reinterpret_cast<const f32x4 *>(rp);
+                        rb[kc] = *reinterpret_cast<const f32x4 *>(rp + res_2nd);
                     }
                 }
                 const int lrow = urow + k * RPI;
@@ -1704,22 +1711,30 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     float v = q < 4 ? v0[q] : v1[q - 4];
-                    if (p.residual) v += (float)rh[k % UC][q] + (float)rl[k % UC][q];   // h + l is exact in fp32
+                    if (p.residual) {
+                        if constexpr (OP) v += (float)__builtin_bit_cast(f16x8, ra[k % UC])[q] + (float)__builtin_bit_cast(f16x8, rb[k % UC])[q];   // h + l is exact in fp32
+                        else v += q < 4 ? ra[k % UC][q] : rb[k % UC][q - 4];
+                    }
                     if (p.relu) v = v > 0.f ? v : 0.f;
                     t[q] = v;
                     const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
                     vmax = (row < p.n_out && vb > vmax) ? vb : vmax;
                 }
                 if (row < p.n_out) {
-                    f16x8 h, l;
+                    char *const orow = reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld);
+                    if constexpr (OP) {
+                        f16x8 h, l;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        h[q] = (_Float16)t[q];
-                        l[q] = (_Float16)(t[q] - (float)h[q]);
+                        for (int q = 0; q < 8; ++q) {
+                            h[q] = (_Float16)t[q];
+                            l[q] = (_Float16)(t[q] - (float)h[q]);
+                        }
+                        *reinterpret_cast<f16x8 *>(orow + pair_off) = h;
+                        *reinterpret_cast<f16x8 *>(orow + pair_off + 64) = l;
+                    } else {
+                        *reinterpret_cast<f32x4 *>(orow + f32_off) = f32x4{t[0], t[1], t[2], t[3]};
+                        *reinterpret_cast<f32x4 *>(orow + f32_off + 16) = f32x4{t[4], t[5], t[6], t[7]};
                     }
-                    char *op = reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld) + pair_off;
-                    *reinterpret_cast<f16x8 *>(op) = h;
-                    *reinterpret_cast<f16x8 *>(op + 64) = l;
                 }
             }
         }
@@ -1827,13 +1842,24 @@ rowwave_conv_f16p_kernel(GcParams p) {            // fp16-pair input rows (GcPar
     __shared__ int sidx[4 * CPD_RW_TAPS * 16 * MS];
     rowwave_conv_split_body<SplitF16x2, BN, MS, false, true, CPD_RW_WB>(p, sb, sidx);
 }
+#define CPD_RW_EPI_KERNEL(NAME, SCALED, PAIRS_IN)                                                                                             \
+    template <int BN, int MS = 2>                                                                                                             \
+    __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : (BN == 64 && MS == 2 ? 5 : 4), 8))) \
+    NAME(GcParams p) {                                                                                                                         \
+        constexpr int SB = CPD_RW_WB * SplitF16x2::NP * BN * 64;                                                                              \
+        __shared__ __attribute__((aligned(16))) char sm[SB + 4 * CPD_RW_TAPS * 16 * MS * 4];                                                  \
+        static_assert(sizeof(sm) >= 4 * ((BN == 32 && MS == 2) ? 32 : 16) * (BN + 4) * 4, "epilogue tile");                                   \
+        rowwave_conv_split_body<SplitF16x2, BN, MS, SCALED, PAIRS_IN, CPD_RW_WB, 4, 2>(p, sm, reinterpret_cast<int *>(sm + SB));               \
+    }
+CPD_RW_EPI_KERNEL(rowwave_conv_f16e_kernel, false, false)      // fp32 rows in: the LDS-epilogue forms of rowwave_conv_f16_kernel / _f16s_kernel
+CPD_RW_EPI_KERNEL(rowwave_conv_f16se_kernel, true, false)
 template <int BN, int MS = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 && MS == 2 ? 3 : (BN == 64 && MS == 2 ? 5 : 4), 8)))
 rowwave_conv_f16pe_kernel(GcParams p) {           // ... pair rows out too, in place: the epilogue through LDS (GcParams::epi_lds)
     constexpr int SB = CPD_RW_WB * SplitF16x2::NP * BN * 64;                    // weight buffers, then the rulebook columns: ONE array, the
     __shared__ __attribute__((aligned(16))) char sm[SB + 4 * CPD_RW_TAPS * 16 * MS * 4];    // epilogue's tile aliases both
     static_assert(sizeof(sm) >= 4 * ((BN == 32 && MS == 2) ? 32 : 16) * (BN + 4) * 4, "epilogue tile");
-    rowwave_conv_split_body<SplitF16x2, BN, MS, false, true, CPD_RW_WB, 4, true>(p, sm, reinterpret_cast<int *>(sm + SB));
+    rowwave_conv_split_body<SplitF16x2, BN, MS, false, true, CPD_RW_WB, 4, 1>(p, sm, reinterpret_cast<int *>(sm + SB));
 }
 #ifndef CPD_RW8_DEFAULT
 #define CPD_RW8_DEFAULT 0            // column-tile widths (sum of 32 / 64 / 128) that take the wide-workgroup variant by default
@@ -2917,10 +2943,12 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         const int sp = rowwave_split(pl, n_out, c_in, c_out, kv);
         if (sp > 1 && part_bytes >= (size_t)sp * n_out * c_out * sizeof(float)) { p.split = sp; p.part = part; }
     }
-    {   // the pair-row row-wave kernels' LDS epilogue (rowwave_conv_split_body): pair rows out, a pair-row residual or none, rows in place
+    {   // the f16x2 row-wave kernels' LDS epilogue (rowwave_conv_split_body): rows in place, no tap split; pair-row kernels write pair rows
+        // (pair residual), fp32-row kernels fp32 rows (fp32 residual) -- the mixed layers keep the shared epilogue
         int epi = 1;                                 // tuning: 0 = the shared fragment-shaped epilogue
         if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_RW_EPI")) epi = atoi(e);
-        p.epi_lds = epi && pl.use_wg == 3 && pl.a <= 128 && pl.math == 2 && p.in_pairs && p.out_pairs == 1 && (!residual || p.res_pairs == 1) && !out_row_map &&
+        p.epi_lds = epi && pl.use_wg == 3 && pl.a <= 128 && pl.math == 2 && !out_row_map &&
+                    (p.in_pairs ? (p.out_pairs == 1 && (!residual || p.res_pairs == 1)) : (p.out_pairs == 0 && p.res_pairs == 0)) &&
                     !out_col_group && p.split == 1 && out_ld % 4 == 0 && (((uintptr_t)out) & 15) == 0 &&
                     (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0));
     }
@@ -2930,7 +2958,8 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     const dim3 grid(p.items, p.split), block(pl.use_wg == 3 && pl.a > 128 ? pl.a * 2 : 256);
     {   // launch log (cpd_launch_log_*): the instantiation this call runs
         char nm[96];
-        const char *sc = (pl.math == 2 && in_absmax) ? "f16s" : (pl.math == 2 ? (p.in_pairs ? (p.epi_lds ? "f16pe" : "f16p") : "f16") : "bf16");
+        const bool e = pl.use_wg == 3 && p.epi_lds;      // (the LDS-epilogue instantiations of the row-wave kernels: f16e / f16se / f16pe)
+        const char *sc = (pl.math == 2 && in_absmax) ? (e ? "f16se" : "f16s") : (pl.math == 2 ? (p.in_pairs ? (e ? "f16pe" : "f16p") : (e ? "f16e" : "f16")) : "bf16");
         if (pl.use_wg == 3 && pl.a > 128) snprintf(nm, sizeof nm, "rowwave_conv_f16pw_kernel<%d,%d>", pl.b, pl.a / 32);
         else if (pl.use_wg == 3) snprintf(nm, sizeof nm, "rowwave_conv_%s_kernel<%d,%d>", sc, pl.b, pl.a / 64);
         else if (pl.use_wg == 2) snprintf(nm, sizeof nm, "tile_conv_%s_kernel<%d,%d>", sc, pl.a, pl.b);
@@ -2940,6 +2969,21 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
         cpd_launch_log_note(nm);
     }
 #define CPD_LAUNCH(K, LDS) hipLaunchKernelGGL((K), grid, block, (LDS), hs, p)
+#define CPD_RW_EPI_LAUNCH(NAME)                                                   \
+    do {                                                                          \
+        if (pl.a == 64) {                                                         \
+            if (pl.b == 32) CPD_LAUNCH((NAME<32, 1>), 0);                         \
+            else if (pl.b == 64) CPD_LAUNCH((NAME<64, 1>), 0);                    \
+            else CPD_LAUNCH((NAME<128, 1>), 0);                                   \
+        } else if (pl.b == 32) CPD_LAUNCH((NAME<32, 2>), 0);                      \
+        else if (pl.b == 64) CPD_LAUNCH((NAME<64, 2>), 0);                        \
+        else CPD_LAUNCH((NAME<128, 2>), 0);                                       \
+        return rowwave_finish(p, hs);                                             \
+    } while (0)
+    if (pl.use_wg == 3 && pl.math == 2 && p.epi_lds && !p.in_pairs) {
+        if (in_absmax) CPD_RW_EPI_LAUNCH(rowwave_conv_f16se_kernel);
+        else CPD_RW_EPI_LAUNCH(rowwave_conv_f16e_kernel);
+    }
     if (pl.use_wg == 3 && pl.math == 2 && in_absmax) {
         if (pl.a == 64) {
             if (pl.b == 32) CPD_LAUNCH((rowwave_conv_f16s_kernel<32, 1>), 0);

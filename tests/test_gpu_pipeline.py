@@ -506,7 +506,7 @@ def test_fp16_pair_rows_between_sparse_layers_do_not_change_the_result(hip):
     pair_launches = sum(v for k, v in logs[0].items() if "f16p" in k)
     assert pair_launches == 15, logs[0]            # 4 + 5 + 5 + conv_out: the layers that read levels 2-4 (conv2.down reads 16 fp32 channels)
     assert not any("f16p" in k for k in logs[1]), logs[1]
-    assert not any(k.startswith("rowwave_conv_f16_kernel") for k in logs[0]), logs[0]
+    assert not any(k.startswith(("rowwave_conv_f16_kernel", "rowwave_conv_f16e_kernel")) for k in logs[0]), logs[0]
     (ra, ia), (rb, ib) = outs
     for name in ("x_conv2", "x_conv3", "x_conv4"):
         fa, ca, _ = ia["levels"][name]

@@ -449,6 +449,36 @@ def test_chunk_ordered_rulebooks_equal_the_plain_builders(hip):
 
 
 @pytest.mark.parametrize("c", [32, 64, 128])
+def test_rowwave_lds_epilogue_on_fp32_rows_equals_the_shared_epilogue(hip, c, monkeypatch):
+    """... and the fp32-row forms (`rowwave_conv_f16e_kernel`, and `f16se` with a range block on the input: the module path, the train
+    step's forward, a guarded re-run): fp32 residual pieces in, fp32 row pieces out."""
+    import torch
+    from cpd_amd import ops
+    rng = np.random.default_rng(c + 1)
+    batch, shape = 2, [9, 128, 128]
+    idx = random_sites(rng, batch, shape, 90001)
+    d_idx = dev(idx)
+    rows = idx.shape[0]
+    nbr = ops.rulebook_subm(d_idx, ops.SiteIndex.build(d_idx, batch, shape))
+    g = torch.Generator().manual_seed(c)
+    x = (torch.randn(rows, c, generator=g) * 2).cuda()
+    res = torch.randn(rows, c, generator=g).cuda()
+    packed = ops.pack_weight((torch.randn(27, c, c, generator=g) * (2.0 / (27 * c)) ** 0.5).cuda())
+    scale, shift = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.1).cuda()
+    monkeypatch.setenv("CPD_TUNE", "1")
+    for guarded in (False, True):
+        am = ops.absmax_rows(x) if guarded else None
+        for r_, relu in ((res, True), (None, False)):
+            outs = {}
+            for epi in ("0", "1"):
+                monkeypatch.setenv("CPD_GC_RW_EPI", epi)
+                with ops.launch_log() as log:
+                    outs[epi] = ops.gather_conv(x, c, packed, nbr, 27, rows, c, scale, shift, r_, relu, math="f16x2", in_absmax=am)
+                assert list(log.counts) == ["rowwave_conv_f16%s%s_kernel<%d,2>" % ("s" if guarded else "", "e" if epi == "1" else "", c)], log.counts
+            np.testing.assert_allclose(outs["1"].cpu().numpy(), outs["0"].cpu().numpy(), atol=4e-6, rtol=0)
+
+
+@pytest.mark.parametrize("c", [32, 64, 128])
 def test_rowwave_lds_epilogue_equals_the_shared_epilogue(hip, c, monkeypatch):
     """Round 4: `rowwave_conv_f16pe_kernel` -- the pair-row row-wave kernel with its epilogue through LDS (transposed tile, 16-byte
     residual pieces in, 16-byte pair pieces out) -- against `rowwave_conv_f16p_kernel` (fragment-shaped epilogue) on the same launch:

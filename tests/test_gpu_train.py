@@ -308,4 +308,5 @@ def test_full_size_config3_step_is_locally_exact_on_the_benchmarked_kernels(hip)
                  "rowwave_conv_f16_kernel<128,1>",
                  # the one-frame 3 x 3 BEV / head layers on 64-column window tiles (round 3's small-batch tile rule)
                  "window_conv_f16_kernel<64,128>", "window_conv_f16s_kernel<64,128>", "window_conv_f16_kernel<16,128>"):
-        assert log.counts.get(name, 0) > 0, (name, sorted(log.counts))
+        # (a row-wave layer large enough to run unsplit takes the LDS-epilogue form of its kernel: f16e / f16se, round 4)
+        assert log.counts.get(name, 0) + log.counts.get(name.replace("_kernel<", "e_kernel<"), 0) > 0, (name, sorted(log.counts))
