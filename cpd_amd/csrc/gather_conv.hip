@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H16 &&
             if (t_cur < 0) break;
         }
     }
-    if constexpr (H16 && NT <= 2 && 16 * (16 * NT + 4) <= 32 * 16 * MS) {
+    if constexpr ((H16 || (!VEC && NT == 1)) && NT <= 2 && 16 * (16 * NT + 4) <= 32 * 16 * MS) {     // (!VEC: the 5 -> 16 input layer)
         if (p.epi_lds) {
             // Epilogue through LDS (round 4; the level-1 layers: 16-channel pair rows in, 16- or 32-channel pair rows out, in place):
             // sub-tile by sub-tile the accumulators go to a wave-private tile (this wave's rulebook columns: not needed any more) in
@@ -3097,6 +3097,12 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
                     (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0)) &&
                     ((c_out == 16 && p.out_pairs == 2 && (!residual || p.res_pairs == 2)) ||
                      (c_out == 32 && p.out_pairs == 1 && (!residual || p.res_pairs == 1)));
+    }
+    if (!in16 && !pl.vec) {                          // the 5 -> 16 input layer writing 16-channel pair rows: the same LDS epilogue
+        int epi = 1;
+        if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_H16_EPI")) epi = atoi(e);
+        p.epi_lds = epi && pl.b == 1 && c_out == 16 && p.out_pairs == 2 && (!residual || p.res_pairs == 2) && !out_row_map && !out_col_group &&
+                    out_ld % 4 == 0 && (((uintptr_t)out) & 15) == 0 && (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0));
     }
     p.n_rb = (n_out + 16 * pl.a - 1) / (16 * pl.a);
     p.n_cb = p.ntot / pl.b;
