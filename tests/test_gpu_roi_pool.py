@@ -97,6 +97,36 @@ def test_voxel_query_from_cell_geometry_matches_oracle(oracle, hip, max_range, r
     np.testing.assert_array_equal(idx_p.cpu().numpy(), want_p)
 
 
+@pytest.mark.parametrize("c,c2", [(16, 24), (32, 32), (64, 48), (32, 64)])
+def test_pool_max_mlp_equals_pool_max_followed_by_the_gemm(hip, c, c2):
+    """cpd_voxel_pool_max_mlp (pooling + the module's output MLP in one kernel, written into a column block of wider rows) against
+    cpd_voxel_pool_max followed by the 1 x 1 GEMM it replaces (voxel_pool_modules.py:96-121), incl. empty balls and a last block of
+    points that is not full."""
+    from cpd_amd import ops, roi_pool
+    from cpd_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(c + c2)
+    n, m, ns = 5000, 4099, 16
+    fin = torch.randn(n, c, generator=g).cuda()
+    xyz = (torch.rand(n, 3, generator=g) * 10).cuda()
+    new_xyz = (torch.rand(m, 3, generator=g) * 10).cuda()
+    idx = torch.randint(0, n, (m, ns), generator=g, dtype=torch.int32).cuda()
+    idx[::7, 0] = -1                                                        # empty balls
+    w_pos, b_pos = torch.randn(3, c, generator=g).cuda(), torch.randn(c, generator=g).cuda()
+    w_out, t_out = (torch.randn(c, c2, generator=g) * 0.2).cuda(), torch.randn(c2, generator=g).cuda()
+    pooled = roi_pool.voxel_pool_max(fin, xyz, new_xyz, idx, w_pos, b_pos)
+    want = torch.relu(pooled @ w_out + t_out)
+    wide = torch.full((m, c2 + 40), -7.0, device="cuda")
+    with ops.launch_log() as log:
+        check(lib().cpd_voxel_pool_max_mlp(m, c, ns, ptr(fin), fin.stride(0), ptr(xyz), ptr(new_xyz), ptr(idx), ptr(w_pos), ptr(b_pos), ptr(w_out),
+                                           ptr(t_out), c2, 1, wide[:, 24:].data_ptr(), wide.stride(0), stream()), "cpd_voxel_pool_max_mlp")
+    assert log.counts == {"voxel_pool_max_mlp_kernel": 1}
+    np.testing.assert_allclose(wide[:, 24:24 + c2].cpu().numpy(), want.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    assert bool((wide[:, :24] == -7.0).all()) and bool((wide[:, 24 + c2:] == -7.0).all())      # nothing outside the block is touched
+    # unsupported shapes are refused, not approximated
+    assert lib().cpd_voxel_pool_max_mlp(m, 48, ns, ptr(fin), 48, ptr(xyz), ptr(new_xyz), ptr(idx), ptr(w_pos), ptr(b_pos), ptr(w_out), ptr(t_out),
+                                        c2, 1, wide.data_ptr(), wide.stride(0), stream()) != 0
+
+
 def test_group_points_matches_oracle(oracle, hip):
     from cpd_amd import roi_pool
     rng = np.random.default_rng(5)
