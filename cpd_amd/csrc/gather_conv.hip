@@ -1348,6 +1348,12 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
 #ifndef CPD_RW_BOTH_MIN
 #define CPD_RW_BOTH_MIN 128      // narrowest column tile that does it (64: 0.1171 -> 0.1162, bench equal: not worth a second variant)
 #endif
+#ifndef CPD_RW_GLW
+#define CPD_RW_GLW 0         // 1 (diagnostic builds): the fp16-pair row-wave kernels' weight stages direct-to-LDS, as the window kernels do.
+#endif                       // Measured and NOT kept (round 4, 48 frames, same box): <32,2> 1012 -> 1054 us, <64,2> 1203 -> 1261, <128,2> 1568 -> 1589
+                             // (67 instead of 72 registers at 32 columns, same occupancy): the LDS-direct load lands a stage later than the
+                             // register copy it replaces can be consumed, and these kernels live on loads in flight
+
 #ifndef CPD_RW_WB
 #define CPD_RW_WB 2          // weight buffers of the f16x2 row-wave kernels (diagnostic builds: 1 = round 2's single buffer, two barriers)
 #endif
@@ -1534,12 +1540,26 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                 }
             }
         };
+        // GLW (fp16-pair kernels, two weight buffers): the stage's weight block goes global -> LDS directly (global_load_lds_dwordx4: the
+        // packed image is copied lane-linearly there), into the buffer the PREVIOUS stage read: no staging registers, no ds_write pass
+        constexpr bool GLW = CPD_RW_GLW && PS && WB == 2 && B_SLOTS % THREADS == 0;
+        auto issue_weights = [&](int t, int kk, int slot) {
+            const char *wt = reinterpret_cast<const char *>(p.wb) + (uint32_t)(t * sk + kk) * b_stage32;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int id = j * THREADS + tid;
+                const int pg = id / BN, n = id - pg * BN;
+                char *lbase = sb0 + slot * (NP * B_IMG) + ((j * THREADS + wave * 64) << 4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wt + (uint32_t)(pg * p.np + col0 + n) * 16u),
+                                                 (__attribute__((address_space(3))) void *)lbase, 16, 0, 0);
+            }
+        };
         typename S::frag a[MS][NP];
         auto stage_commit = [&](uint32_t on, int slot) {      // B -> LDS buffer `slot`, A -> split fragments
             char *const sb = sb0 + (WB > 1 ? slot * (NP * B_IMG) : 0);
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
-                if (B_SLOTS % THREADS == 0 || j * THREADS + tid < B_SLOTS) {
+                if (!GLW && (B_SLOTS % THREADS == 0 || j * THREADS + tid < B_SLOTS)) {
                     // k order of the LDS weight image = the gathered fragments': the packed slot (piece image q, k-group go, column n)
                     // holds channels 8 go .. 8 go + 7; its half hf (channels 4 (2 go + hf) ..) goes to k-group (2 go + hf) & 3, position go >> 1
                     const int id = j * THREADS + tid;
@@ -1610,13 +1630,13 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
         bool ok2 = ok1 && advance(rem, k2);
         int t2 = ok2 ? __builtin_ctz(rem) : 0;
         load_rows(onc, kc, tc);
-        load_weights(tc, kc);
+        if (GLW) issue_weights(tc, kc, 0); else load_weights(tc, kc);
         stage_commit(onc, 0);
         __syncthreads();
         int par = 0;
         while (true) {
             if (ok1) {
-                load_weights(t1, k1);
+                if (GLW) issue_weights(t1, k1, par ^ 1); else load_weights(t1, k1);
                 load_rows(on1, k1, t1);
             }
             stage_mma(onc, par);
