@@ -251,11 +251,18 @@ def get_voxel_centers(voxel_coords_zyx, downsample_times, voxel_size, point_clou
     return (centers + 0.5) * vs + torch.tensor(point_cloud_range[0:3], device=centers.device).float()
 
 
+_DENSE_IDX = {}
+
+
 def get_global_grid_points_of_roi(rois, grid_size):
     """voxel_rcnn_head.py:365-386: (B*N, G^3, 3) global grid points of each RoI (torch on the device)."""
     rois = rois.view(-1, rois.shape[-1])
-    n = rois.shape[0]
-    dense_idx = rois.new_ones((grid_size, grid_size, grid_size)).nonzero().repeat(n, 1, 1).float()
+    # the (G^3, 3) index triples of the reference's `new_ones(G, G, G).nonzero()` (row-major), built once per (G, device): nonzero() reads its
+    # count back to the host on every call; broadcast instead of .repeat(n, 1, 1) -- the same values through the same operations
+    key = (int(grid_size), rois.device)
+    dense_idx = _DENSE_IDX.get(key)
+    if dense_idx is None:
+        dense_idx = _DENSE_IDX[key] = rois.new_ones((grid_size, grid_size, grid_size)).nonzero().float()[None]
     size = rois[:, 3:6]
     local = (dense_idx + 0.5) / grid_size * size.unsqueeze(1) - size.unsqueeze(1) / 2
     ca, sa = torch.cos(rois[:, 6]), torch.sin(rois[:, 6])
@@ -286,7 +293,8 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
         feats, coords, shape = levels[name]
         stride = strides[name]
         xyz = get_voxel_centers(coords[:, 1:4], stride, voxel_size, point_cloud_range).contiguous()
-        cnt = torch.bincount(coords[:, 0].long(), minlength=batch_size).int()
+        # (per-sample row counts: the training branch's grouping needs them; the fused eval path does not -- and bincount reads back)
+        cnt = None if fused else torch.bincount(coords[:, 0].long(), minlength=batch_size).int()
         cur = torch.cat([bidx, gc // stride], dim=-1).int().contiguous().view(-1, 4)
         index = indexes.get(name) if indexes else None
         v2p = None if index is not None else generate_voxel2pinds(coords, batch_size, shape)
