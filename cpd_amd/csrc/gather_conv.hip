@@ -1079,16 +1079,24 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
 
     f32x4 ra[AJ];
     f32x4u rbv[BJ];
+    // Window rows and (GLDS) weight stages are addressed through BUFFER resources with 32-bit offsets (round 4): a lane's offset is a
+    // loop-invariant register plus a per-window / per-stage scalar -- one v_add per load instead of 64-bit multiply-adds, shifts and
+    // clamps (12 v_lshl_add_u64 + the compare / select pairs per stage: a third of the loop's non-MFMA vector instructions, which compete
+    // with the MFMAs for issue). A row outside the tensor is out of range and reads zeros (it only feeds masked taps): the offset of a
+    // negative row wraps past the 4 GB the launcher guarantees the tensor to be smaller than.
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0,
+                                                                             (int)(uint32_t)((size_t)p.n_out * p.in_ld * sizeof(float)), 0x00020000);
+    const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
+    uint32_t voff_a[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) voff_a[j] = (uint32_t)(a_row + 32 * j) * row_bytes + (uint32_t)a_piece * 16u;
     auto load_window = [&](int kk, int dy) {
-        const long long base = (long long)row0 + (long long)dy * p.img_w - 1;
+        const uint32_t s_base = (uint32_t)(row0 + dy * p.img_w - 1) * row_bytes + (uint32_t)kk * 128u;      // (mod 2^32: see above)
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int w = a_row + 32 * j;
-            if (AJ * 32 <= WROWS || w < WROWS) {
-                long long rr = base + w;                          // rows outside the tensor only feed masked taps
-                rr = rr < 0 ? 0 : (rr >= p.n_out ? (long long)p.n_out - 1 : rr);
-                ra[j] = *reinterpret_cast<const f32x4 *>(p.in + (size_t)rr * p.in_ld + kk * 32 + a_piece * 4);
-            }
+            if (AJ * 32 <= WROWS || w < WROWS)
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff_a[j] + s_base, 0, 0));
         }
     };
     auto store_window = [&]() {
@@ -1124,16 +1132,23 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
     // GLDS: the weight stage goes global -> LDS directly (global_load_lds_dwordx4: per-lane source address, destination =
     // wave-uniform base + 16 * lane; the stage image is lane-linear in its slot id), into the buffer the PREVIOUS stage read,
     // under this stage's MFMAs: no staging registers, no ds_write pass, one barrier per stage
-    auto issue_weights = [&](int st, int buf) {
-        const int kk = st / 9, t = st - kk * 9;
-        const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wb), 0, (int)(uint32_t)(9u * (uint32_t)sk * (uint32_t)b_stage), 0x00020000);
+    uint32_t voff_b[GLDS ? BJ : 1];
+    if (GLDS) {
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int id = j * 256 + tid;
             const int pg = id / BN, n = id - pg * BN;
+            voff_b[j] = (uint32_t)(pg * p.np + col0 + n) * 16u;
+        }
+    }
+    auto issue_weights = [&](int st, int buf) {
+        const int kk = st / 9, t = st - kk * 9;
+        const uint32_t s_stage = (uint32_t)(t * sk + kk) * (uint32_t)b_stage;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
             char *lbase = sb + buf * (NP * B_IMG) + ((j * 256 + wave * 64) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wt + ((size_t)pg * p.np + col0 + n) * 16),
-                                             (__attribute__((address_space(3))) void *)lbase, 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void *)lbase, 16, voff_b[GLDS ? j : 0] + s_stage, 0, 0, 0);
         }
     };
 
@@ -3194,6 +3209,7 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
         return CPD_ERR_ARG;
     const int bn = window_bn(frames, h, w, c_in, c_out, flags);
     if (!bn || in_ld % 4 || (((uintptr_t)in) & 15)) return CPD_ERR_UNSUPPORTED;
+    if ((size_t)frames * h * w * in_ld * sizeof(float) >= 0xfff00000ull) return CPD_ERR_UNSUPPORTED;   // (32-bit buffer offsets; the table path takes larger tensors)
     GcParams p;
     memset(&p, 0, sizeof(p));
     const int n_out = frames * h * w;
