@@ -1142,12 +1142,13 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
             voff_b[j] = (uint32_t)(pg * p.np + col0 + n) * 16u;
         }
     }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave << 10);     // this wave's 64 slots of a 256-slot pass of the weight image (scalar, once)
     auto issue_weights = [&](int st, int buf) {
         const int kk = st / 9, t = st - kk * 9;
         const uint32_t s_stage = (uint32_t)(t * sk + kk) * (uint32_t)b_stage;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            char *lbase = sb + buf * (NP * B_IMG) + ((j * 256 + wave * 64) << 4);
+            char *lbase = sb + buf * (NP * B_IMG) + (j << 12) + wave_lds;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void *)lbase, 16, voff_b[GLDS ? j : 0] + s_stage, 0, 0, 0);
         }
     };
