@@ -1113,8 +1113,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
             }
         }
     };
-    auto load_weights = [&](int st) {
-        const int kk = st / 9, t = st - kk * 9;
+    auto load_weights = [&](int t, int kk) {
         const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
@@ -1143,8 +1142,7 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
         }
     }
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave << 10);     // this wave's 64 slots of a 256-slot pass of the weight image (scalar, once)
-    auto issue_weights = [&](int st, int buf) {
-        const int kk = st / 9, t = st - kk * 9;
+    auto issue_weights = [&](int t, int kk, int buf) {
         const uint32_t s_stage = (uint32_t)(t * sk + kk) * (uint32_t)b_stage;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
@@ -1155,19 +1153,24 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
 
     typename S::frag abl_a[(CPD_GC_ABLATE & 256) ? MS : 1][NP], abl_b[(CPD_GC_ABLATE & 256) ? NT : 1][NP];   // diagnostic builds only
     load_window(0, -1);
-    if (GLDS) issue_weights(0, 0); else load_weights(0);
+    if (GLDS) issue_weights(0, 0, 0); else load_weights(0, 0);
     store_window();
     if (!GLDS) store_weights();
     __syncthreads();
     const int n_stage = 9 * sk;
+    // stage = (channel block kk, tap t = 3 dyi + dxi), walked with counters: the flat index cost a handful of divisions by 9 and 3 per stage
+    int t = 0, dxi = 0, kk = 0;
     for (int st = 0; st < n_stage; ++st) {
-        const int t = st % 9, dx = t - (t / 3) * 3 - 1;
+        const int dx = dxi - 1;
         const int nx = st + 1;
-        const bool new_window = nx < n_stage && nx % 3 == 0;     // the next stage starts another dy (or channel block)
+        int tn = t + 1, kkn = kk, dxn = dxi + 1;                 // the stage after this one
+        if (dxn == 3) dxn = 0;
+        if (tn == 9) { tn = 0; ++kkn; }
+        const bool new_window = nx < n_stage && dxn == 0;        // the next stage starts another dy (or channel block)
         // CPD_GC_ABLATE (diagnostic builds only, wrong results): 64 no weight stages, 128 no window loads / splits / stores,
         // 256 fragments read from LDS in the first stage only, 512 no MFMAs
-        if (GLDS && nx < n_stage && !(CPD_GC_ABLATE & 64)) issue_weights(nx, nx & 1);
-        if (new_window && !(CPD_GC_ABLATE & 128)) load_window(nx / 9, (nx % 9) / 3 - 1);   // in flight under this stage's MFMAs
+        if (GLDS && nx < n_stage && !(CPD_GC_ABLATE & 64)) issue_weights(tn, kkn, nx & 1);
+        if (new_window && !(CPD_GC_ABLATE & 128)) load_window(kkn, (tn == 0 ? 0 : (tn == 3 ? 1 : 2)) - 1);   // in flight under this stage's MFMAs
         const char *const sbr = sb + (GLDS ? (st & 1) * (NP * B_IMG) : 0);
         {
             const typename S::frag zero = {};
@@ -1236,12 +1239,13 @@ __device__ __forceinline__ void window_conv_split_body(const GcParams &p) {
         } else {
             __syncthreads();                   // everyone is done reading the images before they are overwritten
             if (nx < n_stage) {
-                load_weights(nx);
+                load_weights(tn, kkn);
                 if (new_window) store_window();
                 store_weights();
             }
             __syncthreads();
         }
+        t = tn; kk = kkn; dxi = dxn;
     }
     if (CPD_GC_ABLATE & 1024) {             // diagnostic builds only: no epilogue (one store keeps the accumulators live)
         float t = 0.f;
