@@ -1346,6 +1346,477 @@ window_conv_f16s_kernel(GcParams p) {             // pre-scaled input (see tile_
     window_conv_split_body<SplitF16x2, BN, (BN >= 64 && BM == 128) || (BM == 256 && BN < 64) ? 4 : 2, BN >= 64, BM, true>(p);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// fp16-PAIR DENSE activations (round 5). The BEV maps between two split-fp16 dense layers are stored the way the sparse
+// levels have been since round 3: a row keeps its 4 * C bytes, every 32-channel block holds its 32 fp16 HIGH terms (64 B) then its 32
+// fp16 LOW terms (64 B) -- the split x = h + l made ONCE by the producing epilogue. The kernels below take the stored bits as MFMA
+// fragments: the window / tile staging is a 16-byte load and ONE ds_write_b128 per piece -- no convert / subtract / convert and half
+// the LDS write instructions of the fp32-row kernels (whose staging shares the SIMD's issue port with the MFMAs).
+// LDS image of the staged rows: ROW-MAJOR, 128 bytes per row = the row's (32-channel block) bytes as they lie in HBM, with the eight
+// 16-byte pieces of row w XOR-swizzled by (w & 7): slot(w, piece) = 8 w + (piece ^ (w & 7)). Eight lanes stage one row (one 128-byte
+// line, 8 distinct slots), two rows of different parity fill all 16 slot residues: conflict-free b128 writes; a fragment read (lane (r, g)
+// reads piece 4 q + g of row base + r) touches 8 consecutive rows of piece P and 8 of piece P ^ 1 per 16-lane group -- again all 16
+// residues, at EVERY row offset (the three dx taps read at offsets 0 / 1 / 2). Same partial products as the fp32-row kernels (the split
+// of a value is the same two halves whoever makes it), summed in the same order: results equal the fp32-row path's on pair-exact inputs.
+template <int BN, int SH, int BM>
+__device__ __forceinline__ void window_conv_pairs_body(const GcParams &p) {
+    using S = SplitF16x2;
+    constexpr int NP = 2;
+    constexpr bool GLDS = BN >= 64;
+    constexpr int WC = (BN >= 64 && BM == 128) ? 2 : 1, WR = 4 / WC;
+    constexpr int WM = BM / WR;                         // rows per wave
+    constexpr int MS = WM / 16, NT = BN / WC / 16;
+    constexpr int WROWS = BM + 2;
+    constexpr int AJ = (WROWS * 8 + 255) / 256;         // 16-byte pieces per thread per window
+    constexpr int A_BYTES = (BM + 8) * 128;             // window image (row-major, swizzled)
+    constexpr int B_SLOTS = NP * 4 * BN;                // 16-byte B pieces of one stage
+    constexpr int BJ = (B_SLOTS + 255) / 256;
+    constexpr int B_IMG = BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const sa = smem;
+    char *const sb = smem + A_BYTES;                    // GLDS: two weight buffers, sb and sb + NP * B_IMG
+    static_assert(!GLDS || B_SLOTS % 256 == 0, "direct-to-LDS weight stages are whole wave instructions");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave - wr * WC;
+    const int r = lane & 15, g = lane >> 4;
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
+    const int row0 = rb * BM, col0 = cb * BN;
+
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t dir_ok = 0;
+    {
+        const int hw = p.img_h * p.img_w;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) {
+            const int pix = (row0 + wr * WM + 16 * s + r) % hw;
+            const int y = pix / p.img_w, x = pix - y * p.img_w;
+            const uint32_t b = (y > 0 ? 1u : 0u) | (y < p.img_h - 1 ? 2u : 0u) | (x > 0 ? 4u : 0u) | (x < p.img_w - 1 ? 8u : 0u);
+            dir_ok |= b << (4 * s);
+        }
+    }
+    uint64_t lane_ok = 0, need_mask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) {
+            const uint32_t b = dir_ok >> (4 * s);
+            const bool ok = (dy < 0 ? (b & 1u) : dy > 0 ? (b & 2u) : 1u) && (dx < 0 ? (b & 4u) : dx > 0 ? (b & 8u) : 1u);
+            lane_ok |= (uint64_t)(ok ? 1 : 0) << (4 * t + s);
+            need_mask |= (uint64_t)(__all(ok) ? 0 : 1) << (4 * t + s);
+        }
+    }
+    need_mask = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(need_mask >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)need_mask);
+
+    const int a_piece = tid & 7;                        // 16-byte piece of the row's 128-byte block: half (h / l) a_piece >> 2, k-group a_piece & 3
+    const int a_row = tid >> 3;                         // window row, + 32 * j
+    const int sk = p.c_in >> 5;
+    const size_t b_stage = (size_t)NP * 4 * p.np * 16;
+
+    f32x4u ra[AJ];
+    f32x4u rbv[GLDS ? 1 : BJ];
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0,
+                                                                             (int)(uint32_t)((size_t)p.n_out * p.in_ld * sizeof(float)), 0x00020000);
+    const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
+    uint32_t voff_a[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) voff_a[j] = (uint32_t)(a_row + 32 * j) * row_bytes + (uint32_t)a_piece * 16u;
+    const int a_dst = (a_row << 7) + ((a_piece ^ (a_row & 7)) << 4);      // (+ 4096 j: 32 rows further on, same swizzle)
+    auto load_window = [&](int kk, int dy) {
+        const uint32_t s_base = (uint32_t)(row0 + dy * p.img_w - 1) * row_bytes + (uint32_t)kk * 128u;      // (mod 2^32: rows outside the tensor read zeros)
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int w = a_row + 32 * j;
+            if (AJ * 32 <= WROWS || w < WROWS)
+                ra[j] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff_a[j] + s_base, 0, 0));
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int w = a_row + 32 * j;
+            if (AJ * 32 <= WROWS || w < WROWS) *reinterpret_cast<f32x4u *>(sa + a_dst + j * 4096) = ra[j];
+        }
+    };
+    auto load_weights = [&](int t, int kk) {
+        const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+#pragma unroll
+        for (int j = 0; j < (GLDS ? 1 : BJ); ++j) {
+            const int id = j * 256 + tid;        // slot in the B stage image: (piece*4 + g)*BN + n
+            const int pg = id / BN, n = id - pg * BN;
+            if (B_SLOTS % 256 == 0 || id < B_SLOTS)
+                rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+        }
+    };
+    auto store_weights = [&]() {
+#pragma unroll
+        for (int j = 0; j < (GLDS ? 1 : BJ); ++j)
+            if (B_SLOTS % 256 == 0 || j * 256 + tid < B_SLOTS) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+    };
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wb), 0, (int)(uint32_t)(9u * (uint32_t)sk * (uint32_t)b_stage), 0x00020000);
+    uint32_t voff_b[GLDS ? BJ : 1];
+    if (GLDS) {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int id = j * 256 + tid;
+            const int pg = id / BN, n = id - pg * BN;
+            voff_b[j] = (uint32_t)(pg * p.np + col0 + n) * 16u;
+        }
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave << 10);
+    auto issue_weights = [&](int t, int kk, int buf) {
+        const uint32_t s_stage = (uint32_t)(t * sk + kk) * (uint32_t)b_stage;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            char *lbase = sb + buf * (NP * B_IMG) + (j << 12) + wave_lds;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void *)lbase, 16, voff_b[GLDS ? j : 0] + s_stage, 0, 0, 0);
+        }
+    };
+
+    load_window(0, -1);
+    if (GLDS) issue_weights(0, 0, 0); else load_weights(0, 0);
+    store_window();
+    if (!GLDS) store_weights();
+    __syncthreads();
+    const int n_stage = 9 * sk;
+    const int w_lane = wr * WM + r + 1;                  // window row of this lane's sub-tile 0 at dx = 0
+    int t = 0, dxi = 0, kk = 0;
+    for (int st = 0; st < n_stage; ++st) {
+        const int nx = st + 1;
+        int tn = t + 1, kkn = kk, dxn = dxi + 1;
+        if (dxn == 3) dxn = 0;
+        if (tn == 9) { tn = 0; ++kkn; }
+        const bool new_window = nx < n_stage && dxn == 0;
+        if (GLDS && nx < n_stage) issue_weights(tn, kkn, nx & 1);
+        if (new_window) load_window(kkn, (tn == 0 ? 0 : (tn == 3 ? 1 : 2)) - 1);   // in flight under this stage's MFMAs
+        const char *const sbr = sb + (GLDS ? (st & 1) * (NP * B_IMG) : 0);
+        {
+            // fragment addresses of this stage (dx = dxi - 1): row w = w_lane + dx + 16 s, piece 4 q + g at slot (4 q + g) ^ (w & 7); 16 s leaves
+            // w & 7 alone and 4 q flips address bit 6: one base per stage, sub-tiles and halves are immediates / one XOR
+            const int w0 = w_lane + dxi - 1;
+            const char *const a_src = sa + (w0 << 7) + ((g ^ (w0 & 7)) << 4);
+            const typename S::frag zero = {};
+#pragma unroll
+            for (int s0 = 0; s0 < MS; s0 += SH) {
+                typename S::frag a[SH][NP];
+#pragma unroll
+                for (int s = 0; s < SH; ++s) {
+                    const char *src = a_src + (s0 + s) * 2048;
+                    a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
+                    a[s][1] = *reinterpret_cast<const typename S::frag *>(reinterpret_cast<const char *>((uintptr_t)src ^ 64));
+                    if ((need_mask >> (4 * t + s0 + s)) & 1) {          // scalar test; rarely taken
+                        asm volatile("" ::: "memory");                  // keeps this a branch (no if-conversion into 8 selects)
+                        const bool ok = (lane_ok >> (4 * t + s0 + s)) & 1;
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) a[s][q] = ok ? a[s][q] : zero;
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = wc * (BN / WC) + 16 * nt + r;
+                    const char *src = sbr + ((g * BN + n) << 4);
+                    typename S::frag b[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+#pragma unroll
+                    for (int s = 0; s < SH; ++s) acc[s0 + s][nt] = S::mma(a[s], b, acc[s0 + s][nt]);
+                }
+                if (SH < MS) asm volatile("" ::: "memory");
+            }
+        }
+        if (GLDS) {
+            if (new_window) {
+                __syncthreads();           // everyone is done reading the window before it is overwritten
+                store_window();
+            }
+            __syncthreads();               // the next stage's weights have landed (vmcnt(0) is part of it), window visible
+        } else {
+            __syncthreads();
+            if (nx < n_stage) {
+                load_weights(tn, kkn);
+                if (new_window) store_window();
+                store_weights();
+            }
+            __syncthreads();
+        }
+        t = tn; kk = kkn; dxi = dxn;
+    }
+    if constexpr (BN >= 64) {
+        // Epilogue through LDS, PAIR rows out: 64 rows per pass to a row-major tile, then a thread owns (row, 8 adjacent columns): the high
+        // terms of its 8 channels are one 16-byte store, the low terms another 64 bytes on
+        constexpr int LD = BN + 4, WN = BN / WC;
+        constexpr int C8 = BN / 8, RPI = 256 / C8, UNITS = 64 / RPI;
+        static_assert(WM == 64, "a pass is one wave row");
+        float *const stile = reinterpret_cast<float *>(smem);
+        float sc[NT], sh[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = col0 + wc * WN + nt * 16 + r;
+            sc[nt] = p.scale ? p.scale[col] : 1.f;
+            if (p.dsc) sc[nt] *= p.dsc[col];
+            sh[nt] = p.shift ? p.shift[col] : 0.f;
+        }
+        uint32_t vmax = 0;
+        const int c8 = tid % C8, urow = tid / C8;
+        const int pair_off = (((col0 >> 3) + c8) >> 2 << 7) + ((((col0 >> 3) + c8) & 3) << 4);
+#pragma unroll 1
+        for (int pass = 0; pass < WR; ++pass) {
+            __syncthreads();
+            if (wr == pass) {
+#pragma unroll
+                for (int s = 0; s < MS; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) stile[(16 * s + 4 * g + i) * LD + wc * WN + 16 * nt + r] = acc[s][nt][i] * sc[nt] + sh[nt];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < UNITS; ++k) {
+                const int lrow = urow + k * RPI;
+                const int row = row0 + pass * 64 + lrow;
+                if (row >= p.n_out) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * c8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * c8 + 4);
+                f16x8 h, l;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = q < 4 ? v0[q] : v1[q - 4];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
+                    vmax = vb > vmax ? vb : vmax;
+                    h[q] = (_Float16)v;
+                    l[q] = (_Float16)(v - (float)h[q]);
+                }
+                char *const orow = reinterpret_cast<char *>(p.out + (size_t)row * p.out_ld);
+                *reinterpret_cast<f16x8 *>(orow + pair_off) = h;
+                *reinterpret_cast<f16x8 *>(orow + pair_off + 64) = l;
+            }
+        }
+        if (p.out_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t2 = (uint32_t)__shfl_xor((int)vmax, o);
+                vmax = t2 > vmax ? t2 : vmax;
+            }
+            if (lane == 0) {
+                uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+                if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
+            }
+        }
+    } else {
+        epilogue<MS, NT>(p, acc, row0 + wr * WM, col0 + wc * (BN / WC), r, g, 1.f);       // the 16-column head tile: fp32 rows out (decode reads them)
+    }
+}
+// pair rows in; pair rows out (64- / 128-column tiles) or fp32 rows out (the 16-column head tile)
+template <int BN, int BM = 128>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 || BM == 256 ? 3 : 4, BN == 128 || BM == 256 ? 3 : 4)))
+window_conv_f16p_kernel(GcParams p) {
+    window_conv_pairs_body<BN, (BN >= 64 && BM == 128) || (BM == 256 && BN < 64) ? 4 : 2, BM>(p);
+}
+
+// The 128 x 128 split tile kernel on fp16-pair rows (strided dense conv through its pixel table, 1 x 1 / ConvTranspose GEMMs): rows
+// gathered through a BUFFER resource with 32-bit offsets (a row without a neighbour, or past the tile's end, is the index clamped to
+// n_in: out of range, reads zeros -- no selects, no 64-bit address arithmetic), staged as they lie (no split), the same
+// swizzled row-major LDS image as the window kernel above; weights as in tile_conv_f16_kernel (registers -> LDS, fetched after the MFMA
+// block); LDS epilogue writing pair rows, also through the row map / the ConvTranspose column-group scatter.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+tile_conv_f16p_kernel(GcParams p) {
+    using S = SplitF16x2;
+    constexpr int NP = 2, BM = 128, BN = 128;
+    constexpr int MS = BM / 32, NT = BN / 32;
+    constexpr int AJ = BM / 32;
+    constexpr int BJ = NP * BN / 64;
+    constexpr int A_BYTES = BM * 128, B_IMG = BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const sa = smem;
+    char *const sb = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = item / p.n_cb, cb = item - rb * p.n_cb;
+    const int row0 = rb * BM, col0 = cb * BN;
+
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int s = 0; s < MS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int a_piece = tid & 7;
+    const int a_row = tid >> 3;    // + 32*j
+    int a_rowc[AJ];
+    bool a_ok[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int row = row0 + a_row + 32 * j;
+        a_ok[j] = row < p.n_out;
+        a_rowc[j] = a_ok[j] ? row : p.n_out - 1;
+    }
+    const int sk = p.c_in >> 5;
+    const int n_stage = p.kv * sk;
+    const size_t b_stage = (size_t)NP * 4 * p.np * 16;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0,
+                                                                             (int)(uint32_t)((size_t)p.n_in_rows * p.in_ld * sizeof(float)), 0x00020000);
+    const uint32_t row_bytes = (uint32_t)p.in_ld * 4u, n_in = (uint32_t)p.n_in_rows;
+    int idx_cur[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) idx_cur[j] = a_ok[j] ? (p.nbr ? p.nbr[a_rowc[j]] : a_rowc[j]) : -1;
+
+    f32x4u ra[AJ];
+    f32x4u rbv[BJ];
+    auto stage_load_b = [&](int st) {
+        const int kk = st / p.kv, t = st - kk * p.kv;
+        const char *wt = reinterpret_cast<const char *>(p.wb) + ((size_t)t * sk + kk) * b_stage;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int id = j * 256 + tid;
+            const int pg = id / BN, n = id - pg * BN;
+            rbv[j] = *reinterpret_cast<const f32x4u *>(wt + ((size_t)pg * p.np + col0 + n) * 16);
+        }
+    };
+    auto stage_load = [&](int st) {
+        const int kk = st / p.kv;
+        const uint32_t c_off = (uint32_t)kk * 128u + (uint32_t)a_piece * 16u;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const uint32_t id = (uint32_t)idx_cur[j];                        // -1 = no neighbour: 0xffffffff -> clamped to n_in -> out of range -> zeros
+            const uint32_t rowi = id < n_in ? id : n_in;
+            ra[j] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, rowi * row_bytes + c_off, 0, 0));
+        }
+    };
+    const int a_dst = (a_row << 7) + ((a_piece ^ (a_row & 7)) << 4);
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4u *>(sa + a_dst + j * 4096) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4u *>(sb + ((j * 256 + tid) << 4)) = rbv[j];
+    };
+    auto idx_load = [&](int st) {
+        if (!p.nbr) return;
+        const int t = st % p.kv;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) idx_cur[j] = a_ok[j] ? p.nbr[(size_t)t * p.n_out + a_rowc[j]] : -1;
+    };
+    stage_load(0);
+    if (1 < n_stage) idx_load(1);
+    stage_load_b(0);
+    stage_store();
+    __syncthreads();
+    const int m_lane = wr * (BM / 2) + r;
+    const char *const a_src = sa + (m_lane << 7) + ((g ^ (m_lane & 7)) << 4);      // + 2048 s; ^ 64 for the low terms
+    for (int st = 0; st < n_stage; ++st) {
+        const int nx = st + 1;
+        if (nx < n_stage) {
+            stage_load(nx);
+            if (nx + 1 < n_stage) idx_load(nx + 1);
+        }
+        {
+            typename S::frag a[MS][NP];
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                const char *src = a_src + s * 2048;
+                a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
+                a[s][1] = *reinterpret_cast<const typename S::frag *>(reinterpret_cast<const char *>((uintptr_t)src ^ 64));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = wc * (BN / 2) + 16 * nt + r;
+                const char *src = sb + ((g * BN + n) << 4);
+                typename S::frag b[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+#pragma unroll
+                for (int s = 0; s < MS; ++s) acc[s][nt] = S::mma(a[s], b, acc[s][nt]);
+            }
+        }
+        __syncthreads();                   // single buffer: everyone is done reading before it is overwritten
+        if (nx < n_stage) {
+            stage_load_b(nx);
+            stage_store();
+        }
+        __syncthreads();
+    }
+    {
+        // Epilogue through LDS, pair rows out: 32 rows per pass; a thread owns (row, 8 adjacent columns) = two 16-byte stores, also through
+        // the row map / the column-group scatter (groups are multiples of 32 columns wide: a unit never straddles a group or a pair block)
+        constexpr int LD = BN + 4, C8 = BN / 8, RPI = 256 / C8, UNITS = 32 / RPI;
+        float *const stile = reinterpret_cast<float *>(smem);
+        float sc[NT], sh[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = col0 + wc * (BN / 2) + nt * 16 + r;
+            sc[nt] = p.scale ? p.scale[col] : 1.f;
+            if (p.dsc) sc[nt] *= p.dsc[col];
+            sh[nt] = p.shift ? p.shift[col] : 0.f;
+        }
+        uint32_t vmax = 0;
+        const int c8 = tid % C8, urow = tid / C8;
+        const int col = col0 + 8 * c8;
+        const int grp = p.col_group ? col / p.col_group : 0, cloc = col - grp * p.col_group;
+        const int pair_off = ((cloc >> 5) << 7) + (((cloc >> 3) & 3) << 4);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {       // (unrolled: the accumulator indices must be constants)
+            __syncthreads();
+            if (wr == (pass >> 1)) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            stile[(16 * s2 + 4 * g + i) * LD + wc * (BN / 2) + 16 * nt + r] = acc[(pass & 1) * 2 + s2][nt][i] * sc[nt] + sh[nt];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < UNITS; ++k) {
+                const int lrow = urow + k * RPI;
+                const int row = row0 + pass * 32 + lrow;
+                if (row >= p.n_out) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * c8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stile + lrow * LD + 8 * c8 + 4);
+                f16x8 h, l;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = q < 4 ? v0[q] : v1[q - 4];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    const uint32_t vb = __float_as_uint(v) & 0x7fffffffu;
+                    vmax = vb > vmax ? vb : vmax;
+                    h[q] = (_Float16)v;
+                    l[q] = (_Float16)(v - (float)h[q]);
+                }
+                size_t orow_i;
+                if (p.col_group) orow_i = (size_t)p.out_row_map[(size_t)grp * p.n_out + row];
+                else orow_i = p.out_row_map ? (size_t)p.out_row_map[row] : (size_t)row;
+                char *const orow = reinterpret_cast<char *>(p.out + orow_i * p.out_ld);
+                *reinterpret_cast<f16x8 *>(orow + pair_off) = h;
+                *reinterpret_cast<f16x8 *>(orow + pair_off + 64) = l;
+            }
+        }
+        if (p.out_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t2 = (uint32_t)__shfl_xor((int)vmax, o);
+                vmax = t2 > vmax ? t2 : vmax;
+            }
+            if (lane == 0) {
+                uint32_t *slot = p.out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+                if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
+            }
+        }
+    }
+}
+
 // Split kernel for SPARSE layers: a workgroup owns 64*MS output rows x BN columns, wave w the
 // rows [16*MS*w, 16*MS*(w+1)) x all BN columns. Only the weights go through LDS (one (tap, 32-channel)
 // block of the split image per stage, shared by the four waves); a wave gathers ITS rows' 128-byte channel
@@ -3214,7 +3685,10 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
         return CPD_ERR_ARG;
     const int bn = window_bn(frames, h, w, c_in, c_out, flags);
     if (!bn || in_ld % 4 || (((uintptr_t)in) & 15)) return CPD_ERR_UNSUPPORTED;
-    if ((size_t)frames * h * w * in_ld * sizeof(float) >= 0xfff00000ull) return CPD_ERR_UNSUPPORTED;   // (32-bit buffer offsets; the table path takes larger tensors)
+    // 32-bit buffer offsets (the table path takes larger tensors): a row before the tensor's first or after its last must land OUTSIDE
+    // num_records and read zeros -- the largest excursion is (w + 1) rows before row 0 / a whole window (<= 258 rows) + w + 1 rows past
+    // the last tile's first row, times the row pitch: the tensor plus that distance must stay below 2^32 (size-aware: ADVICE r4)
+    if ((size_t)frames * h * w * in_ld * sizeof(float) + ((size_t)w + 1 + 288) * in_ld * sizeof(float) >= 0x100000000ull) return CPD_ERR_UNSUPPORTED;
     GcParams p;
     memset(&p, 0, sizeof(p));
     const int n_out = frames * h * w;

@@ -396,13 +396,15 @@ class VoxelRCNNHead(nn.Module):
         self._fc = {k: pack(getattr(self, k)) for k in ("shared_fc_layers", "cls_layers", "reg_layers")}
 
     @staticmethod
-    def _run(layers, x, math=None, in_block=None):
+    def _run(layers, x, math=None, in_block=None, return_block=False):
         """the stack as 1 x 1 GEMM launches. math = "f16x2": the split-fp16 tile kernels, range-guarded the whole way -- every layer
-        takes the absmax block its producer filled (`in_block` for the first; measured when None) and fills the next one."""
+        takes the absmax block its producer filled (`in_block` for the first; measured when None) and fills the next one.
+        return_block: also return the absmax block of the stack's output (None on the fp32 path), so that a caller feeding the output
+        to further stacks does not measure it again."""
         if math != "f16x2":
             for w, cin, cout, s, t, relu in layers:
                 x = ops.gather_conv(x, cin, w, None, 1, x.shape[0], cout, s, t, None, relu)
-            return x
+            return (x, None) if return_block else x
         blocks = ops.absmax_blocks(len(layers), x.device)
         rb = in_block if in_block is not None else ops.absmax_rows(x)
         for i, (w, cin, cout, s, t, relu) in enumerate(layers):
@@ -410,7 +412,7 @@ class VoxelRCNNHead(nn.Module):
             x = ops.gather_conv(x, cin, w, None, 1, x.shape[0], cout, s, t, None, relu, dense=True, math="f16x2" if ok else "f32",
                                 in_absmax=rb if ok else None, out_absmax=blocks[i])
             rb = blocks[i]
-        return x
+        return (x, rb) if return_block else x
 
     @torch.no_grad()
     def forward(self, batch_dict):

@@ -64,8 +64,10 @@ class VoxelRCNNEngine:
         n_roi = max(1, max(counts))                                     # reorder_rois_for_refining: at least one (zero) RoI
         cnt = torch.tensor(counts, dtype=torch.int64, device=self.device)
         valid = torch.arange(n_roi, device=self.device)[None, :] < cnt[:, None]
-        rois = (ob[:, :n_roi] * valid[..., None]).contiguous()          # zero boxes past a frame's count, like the reference's new_zeros block
-        roi_labels = (ol[:, :n_roi] * valid).contiguous()
+        # zero boxes past a frame's count, like the reference's new_zeros block -- by SELECTION: the slots past a frame's count were
+        # never written by cpd_select_boxes (stale allocator bytes, possibly NaN bit patterns, and NaN * 0 is NaN: ADVICE r4)
+        rois = torch.where(valid[..., None], ob[:, :n_roi], ob.new_zeros(())).contiguous()
+        roi_labels = torch.where(valid, ol[:, :n_roi], ol.new_zeros(())).contiguous()
         # ---- second stage
         lv = {name: levels[name] for name in self.sources}
         pooled = roi_pool.roi_grid_pool(rois, lv, self.strides, dict(zip(self.sources, self.head.roi_grid_pool_layers)), self.head.grid_size,
@@ -74,8 +76,7 @@ class VoxelRCNNEngine:
         x = pooled.reshape(pooled.shape[0], -1).contiguous()
         fc = self.head._fc
         m = self.cfg.conv_math if self.cfg.conv_math == "f16x2" else None     # FC stacks on the split-fp16 tile kernels, range-guarded
-        shared = self.head._run(fc["shared_fc_layers"], x, math=m)
-        rb = ops.absmax_rows(shared) if m else None
+        shared, rb = self.head._run(fc["shared_fc_layers"], x, math=m, return_block=True)    # rb: the block the last shared layer's epilogue filled
         rcnn_cls = self.head._run(fc["cls_layers"], shared, math=m, in_block=rb)
         rcnn_reg = self.head._run(fc["reg_layers"], shared, math=m, in_block=rb)
         cls, boxes = self.head.generate_predicted_boxes(batch, rois, rcnn_cls, rcnn_reg)
@@ -95,7 +96,7 @@ class VoxelRCNNEngine:
             fb, fs, fl = fb.cpu(), fs.cpu(), fl.cpu()
         out = [{"pred_boxes": fb[b, :ns[b]], "pred_scores": fs[b, :ns[b]], "pred_labels": fl[b, :ns[b]]} for b in range(batch)]
         if return_intermediates:
-            return out, dict(rois=rois, roi_labels=roi_labels, roi_scores=os_[:, :n_roi] * valid, batch_box_preds=boxes,
+            return out, dict(rois=rois, roi_labels=roi_labels, roi_scores=torch.where(valid, os_[:, :n_roi], os_.new_zeros(())), batch_box_preds=boxes,
                              batch_cls_preds=cls, levels=lv, pooled=pooled)
         return out
 

@@ -137,3 +137,152 @@ def test_post_processing_matches_a_plain_restatement(hip):
         torch.testing.assert_close(got[b]["pred_boxes"], boxes[b][sel])
         torch.testing.assert_close(got[b]["pred_scores"], s[sel])
         assert torch.equal(got[b]["pred_labels"], labels[b][sel])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 5: tight evidence for the BENCHMARKED two-stage path -- full widths, GRID_SIZE 6, the default
+# split-fp16 arithmetic, the K = 27 648 stage-split GEMM -- against float64 and against an oracle composition.
+
+def _full_engine(host_results=False):
+    from cpd_amd.engine import ModelConfig, init_state_dict
+    from cpd_amd.two_stage import VoxelRCNNEngine
+    cfg = ModelConfig()
+    sd = init_state_dict(cfg, 0)
+    mcfg = models.waymo_voxel_rcnn_cfg()
+    torch.manual_seed(0)
+    head = models.__all__[mcfg.ROI_HEAD.NAME](input_channels={"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 128},
+                                              model_cfg=mcfg.ROI_HEAD, point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size,
+                                              num_class=1)
+    with torch.no_grad():
+        for m in head.modules():                           # non-trivial BatchNorm statistics; output layers that spread the scores
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.75, 1.25)
+                m.weight.uniform_(0.75, 1.25); m.bias.normal_(0, 0.1)
+        for stack in (head.cls_layers, head.reg_layers):
+            stack[-1].weight.normal_(0, 0.3); stack[-1].bias.normal_(0, 0.3)
+    sd.update({"roi_head." + k: v.detach().clone() for k, v in head.state_dict().items()})
+    return cfg, mcfg, sd, VoxelRCNNEngine(cfg, mcfg.ROI_HEAD, mcfg.POST_PROCESSING, sd, host_results=host_results)
+
+
+def test_k_heavy_fc_stacks_f16x2_match_float64(hip):
+    """The second stage's FC stacks exactly as `VoxelRCNNEngine` runs them at the bench's size (16 frames x 495 RoIs = 7920 rows):
+    27 648 -> 256 (the 8-way stage split of the split-fp16 tile kernel + split_finish), 256 -> 256, and the cls / reg stacks, under
+    math = "f16x2" with the range guard's blocks chained -- against float64 GEMMs on the same inputs, <= 1e-4 of O(1) outputs,
+    the instantiations asserted through the launch log."""
+    cfg, mcfg, sd, eng = _full_engine()
+    g = torch.Generator().manual_seed(11)
+    n, k = 495 * 16, 27648
+    x = torch.relu(torch.randn(n, k, generator=g)).cuda()                  # pooled features are post-ReLU
+    fc = eng.head._fc
+    with ops.launch_log() as log:
+        shared, rb = eng.head._run(fc["shared_fc_layers"], x, math="f16x2", return_block=True)
+        cls = eng.head._run(fc["cls_layers"], shared, math="f16x2", in_block=rb)
+        reg = eng.head._run(fc["reg_layers"], shared, math="f16x2", in_block=rb)
+    names = log.counts
+    assert any(nm.startswith("tile_conv_f16s_kernel") for nm in names), names          # the range-guarded split-fp16 tile kernel ...
+    assert names.get("split_finish_kernel", 0) >= 1, names                                # ... with its stages dealt to several workgroups
+    assert ops.absmax_value(rb) == float(shared.abs().max())                              # the block the last shared layer filled IS max |shared|
+
+    # the float64 stacks straight from the module's own parameters (BatchNorm1d eval formula, not the folded scale / shift)
+    def ref_stack(seq, v):
+        v = v.double()
+        for m in seq:
+            if isinstance(m, torch.nn.Linear):
+                v = v @ m.weight.double().t()
+                if m.bias is not None:
+                    v = v + m.bias.double()
+            elif isinstance(m, torch.nn.BatchNorm1d):
+                v = (v - m.running_mean.double()) / torch.sqrt(m.running_var.double() + m.eps) * m.weight.double() + m.bias.double()
+            elif isinstance(m, torch.nn.ReLU):
+                v = torch.relu(v)
+        return v
+    with torch.no_grad():
+        want_shared = ref_stack(eng.head.shared_fc_layers, x)
+        want_cls = ref_stack(eng.head.cls_layers, want_shared)
+        want_reg = ref_stack(eng.head.reg_layers, want_shared)
+    for got, want, what in ((shared, want_shared, "shared"), (cls, want_cls, "cls"), (reg, want_reg, "reg")):
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got.double() - want).abs().max())
+        assert err <= 1e-4 * scale, (what, err, scale)
+    assert float(want_shared.abs().max()) > 1.0 and float(want_cls.abs().max()) > 0.5        # O(1) outputs: the bound means something
+
+
+def test_full_size_two_stage_engine_matches_the_oracle_composition(oracle, hip):
+    """`VoxelRCNNEngine` as bench.py's `value_two_stage` runs it -- full widths, GRID_SIZE 6, two radii per level, the default
+    split-fp16 arithmetic -- on one full 160k-point frame (last of a batch of two, so that frames with different RoI counts share
+    the padded block) against an ORACLE composition: ref_pipeline's first stage, then tests/ref_two_stage.py (oracle.voxel_query,
+    numpy grouping + MLPs + FC stacks in float64, oracle.anchor_decode, oracle.nms). RoIs are matched one to one; second-stage
+    predictions agree to 1e-3 for every RoI whose neighbour queries took the same decisions in both pipelines -- the RoIs where a
+    grid point sits within fp32 rounding of a cell boundary or of the query radius (engine and oracle RoIs differ by ~1e-5) are
+    FOUND by running the oracle's queries on the engine's grid points, listed, and bounded; final detections likewise."""
+    import ref_pipeline
+    import ref_two_stage as r2
+    from cpd_amd import roi_pool
+    cfg, mcfg, sd, eng = _full_engine()
+    pts = waymo_cloud(0)
+    ref, rt = ref_pipeline.forward(oracle, cfg, sd, [pts])
+    o_rois = ref[0]["pred_boxes"][None].astype(np.float32)
+    o_labels = ref[0]["pred_labels"][None]
+    n_roi = o_rois.shape[1]
+    assert n_roi > 300                                                    # random weights keep ~495 proposals: the bench's load
+    clouds = [torch.from_numpy(waymo_cloud(5, n_points=60000)).cuda(), torch.from_numpy(pts).cuda()]
+    fi = 1
+    got, it = eng.forward(clouds, return_intermediates=True)
+    assert torch.isfinite(it["rois"]).all() and torch.isfinite(it["batch_box_preds"]).all()          # padded slots are ZERO boxes (ADVICE r4)
+    e_rois = it["rois"][fi].cpu().numpy()
+    n_e = int((np.abs(e_rois).sum(-1) > 0).sum())
+    assert n_e == n_roi, (n_e, n_roi)
+    e_rois = e_rois[:n_roi]
+    j = np.abs(e_rois[:, None, :] - o_rois[0][None, :, :]).max(-1).argmin(1)          # engine RoI e <-> oracle RoI j[e]
+    assert sorted(j.tolist()) == list(range(n_roi))
+    np.testing.assert_allclose(e_rois, o_rois[0][j], atol=1e-3, rtol=1e-4)
+    np.testing.assert_array_equal(it["roi_labels"][fi, :n_roi].cpu().numpy(), o_labels[0][j])
+    # ---- the oracle's second stage on ITS OWN first stage
+    levels = {name: rt["levels"][name] for name in eng.sources}
+    final, ot = r2.second_stage(oracle, cfg, mcfg.ROI_HEAD, mcfg.POST_PROCESSING, sd, o_rois, o_labels, levels, 1)
+    # ---- which RoIs' neighbour queries decide differently on the engine's grid points (same device function the engine calls)
+    e_grid, _ = roi_pool.get_global_grid_points_of_roi(it["rois"][fi:fi + 1, :n_roi].clone(), eng.head.grid_size)
+    e_grid = e_grid.cpu().numpy()                                                      # (n_roi, 216, 3), engine RoI order
+    inv = np.empty(n_roi, np.int64); inv[j] = np.arange(n_roi)                        # oracle RoI o <-> engine RoI inv[o]
+    o_grid, _ = r2.grid_points(o_rois, eng.head.grid_size)
+    assert float(np.abs(e_grid[inv] - o_grid).max()) <= 2e-3                          # the same grid up to the RoIs' rounding
+    strides = {"x_conv3": 4, "x_conv4": 8}
+    _, q_e = r2.roi_grid_pool(oracle, sd, mcfg.ROI_HEAD, o_rois, levels, strides, cfg.voxel_size, cfg.point_cloud_range, 1, grid_xyz=e_grid[inv])
+    g3 = eng.head.grid_size ** 3
+    flip = np.zeros(n_roi, bool)
+    for key, (idx_o, empty_o) in ot["queries"].items():
+        idx_e, empty_e = q_e[key]
+        d = (idx_o != idx_e).any(1) | (empty_o != empty_e)
+        flip |= d.reshape(n_roi, g3).any(1)
+    flips = np.nonzero(flip)[0]
+    print("RoIs whose neighbour queries decide differently on the engine's grid points (oracle order):", flips.tolist())
+    assert len(flips) <= max(3, int(0.04 * n_roi)), len(flips)
+    # ---- second-stage predictions, RoI by RoI
+    e_cls = it["batch_cls_preds"][fi, :n_roi].cpu().numpy()[inv]
+    e_box = it["batch_box_preds"][fi, :n_roi].cpu().numpy()[inv]
+    o_cls, o_box = ot["batch_cls_preds"][0], ot["batch_box_preds"][0]
+    same = ~flip
+    assert same.sum() >= 0.96 * n_roi
+    np.testing.assert_allclose(e_cls[same], o_cls[same], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(e_box[same], o_box[same], atol=1e-3, rtol=1e-4)
+    assert float(np.abs(e_cls - o_cls).max()) < 0.5                                   # ... and a flipped RoI moves a little, not wildly
+    # ---- final detections. post_processing is a greedy NMS in score order: two RoIs whose scores differ by less than the 1e-3 the
+    # predictions are compared at may swap ranks between the pipelines, and one swapped suppression decision cascades through the
+    # frame's ~470 kept boxes -- so the stage is checked where it is DEFINED: the oracle's post_processing (fp32 sigmoid, stable
+    # descending order, oracle.nms at 0.3) on the ENGINE's own second-stage predictions must select exactly the engine's detections.
+    e_cls_f = it["batch_cls_preds"][fi:fi + 1, :n_roi].cpu().numpy()
+    e_box_f = it["batch_box_preds"][fi:fi + 1, :n_roi].cpu().numpy()
+    e_lab_f = it["roi_labels"][fi:fi + 1, :n_roi].cpu().numpy()
+    pp = r2.post_processing(oracle, mcfg.POST_PROCESSING, e_box_f, e_cls_f, e_lab_f, sigmoid_dtype=np.float32)[0]
+    a = got[fi]["pred_boxes"].cpu().numpy()
+    assert len(a) > 10 and len(a) == len(pp["pred_boxes"]), (len(a), len(pp["pred_boxes"]))
+    np.testing.assert_array_equal(a, pp["pred_boxes"])
+    np.testing.assert_allclose(got[fi]["pred_scores"].cpu().numpy(), pp["pred_scores"], atol=1e-6)
+    np.testing.assert_array_equal(got[fi]["pred_labels"].cpu().numpy(), pp["pred_labels"])
+    # end to end (informational + a floor): detections of the oracle's own chain that the engine also reports, at 1e-3
+    b = final[0]["pred_boxes"]
+    d = np.abs(a[:, None, :] - b[None, :, :]).max(-1)
+    common = int((d.min(1) <= 1e-3).sum())
+    print("final detections: engine %d, oracle chain %d, in common at 1e-3: %d (rank swaps among scores closer than 1e-3 cascade through "
+          "the greedy NMS; %d RoIs with flipped neighbour queries)" % (len(a), len(b), common, len(flips)))
+    assert abs(len(a) - len(b)) <= 0.1 * len(b) and common >= 0.6 * len(b)
