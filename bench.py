@@ -105,6 +105,8 @@ def parse():
                     "(ModelConfig.plan_rulebooks: the staged row-wave kernel)")
     ap.add_argument("--pair-rows", type=int, choices=[0, 1, 2], default=2, help="fp16-pair rows between the f16x2 sparse layers "
                     "(ModelConfig.pair_rows): 1 = levels 2-4, 2 = level 1 as well (pair_rows_level1)")
+    ap.add_argument("--dense-pairs", type=int, choices=[0, 1], default=1, help="ModelConfig.pair_rows_dense: fp16-pair BEV / head maps between "
+                    "the split-fp16 dense layers (round 5; 0 = fp32 dense maps, the round-4 form: same detections)")
     ap.add_argument("--conv-math", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
                     help="arithmetic of the layers with >= 32 input channels: split-fp16 x2 (3 products) or split-bf16 x3 (6 products) "
                          "on the 16-bit matrix pipe (both fp32-level error), or fp32 MFMA")
@@ -725,7 +727,7 @@ def main():
     distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"), torch.device("cuda", local))
 
     cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk, plan_rulebooks=bool(args.plan), plan_tile_rows=args.plan_tile, row_order_level0=bool(args.order_level0), pair_rows=bool(args.pair_rows),
-                      pair_rows_level1=args.pair_rows == 2)
+                      pair_rows_level1=args.pair_rows == 2, pair_rows_dense=bool(args.dense_pairs))
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local
     if args.mode == "train":
@@ -830,10 +832,14 @@ def main():
                                           ("the same split-fp16 arithmetic on the K = 16 MFMA (v_mfma_f32_16x16x16_f16, gather_conv_h16_kernel), "
                                            "reading fp16-pair rows" if (cfg.pair_rows and cfg.pair_rows_level1) else "fp32 MFMA"),
                                  "f32": "fp32 MFMA everywhere"}[cfg.conv_math],
+                   "pair_rows_dense": bool(cfg.pair_rows and cfg.pair_rows_dense) and cfg.conv_math == "f16x2",
                    "pair_rows": bool(cfg.pair_rows) and cfg.conv_math == "f16x2", "pair_rows_level1": bool(cfg.pair_rows and cfg.pair_rows_level1) and cfg.conv_math == "f16x2",
                    "activation_storage": ("between the sparse layers of levels %s: fp16-pair rows (each fp32 activation stored as its two fp16 "
-                                          "terms h + l, 4 bytes per channel, split made once by the producing epilogue); exported levels, the "
-                                          "BEV map and every dense activation: fp32" % ("1-4" if cfg.pair_rows_level1 else "2-4"))
+                                          "terms h + l, 4 bytes per channel, split made once by the producing epilogue)%s; exported levels: fp32"
+                                          % ("1-4" if cfg.pair_rows_level1 else "2-4",
+                                             " -- and (batches of >= 8 frames) the stride-8 output, the densified BEV map and every dense map up to the "
+                                             "head's hidden layer as pair maps as well (window_conv_f16p / tile_conv_f16p kernels); head output maps fp32"
+                                             if cfg.pair_rows_dense else "; the BEV map and every dense activation: fp32"))
                    if (cfg.pair_rows and cfg.conv_math == "f16x2") else "fp32 everywhere",
                    "distinct_clouds_per_rank": POOL,
                    "range_guard": ("f16x2 range guard on: every conv epilogue records max |out|, the verdict rides with the step's count "

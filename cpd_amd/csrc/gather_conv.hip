@@ -1618,9 +1618,167 @@ __device__ __forceinline__ void window_conv_pairs_body(const GcParams &p) {
 }
 // pair rows in; pair rows out (64- / 128-column tiles) or fp32 rows out (the 16-column head tile)
 template <int BN, int BM = 128>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 || BM == 256 ? 3 : 4, BN == 128 || BM == 256 ? 3 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN >= 64 ? 3 : 4, BN >= 64 ? 3 : 4)))
 window_conv_f16p_kernel(GcParams p) {
     window_conv_pairs_body<BN, (BN >= 64 && BM == 128) || (BM == 256 && BN < 64) ? 4 : 2, BM>(p);
+}
+
+// The 16-column head tile on pair rows (the fused SeparateHead output convs, 320 -> 11): 12 MFMAs per wave and stage cannot hide a
+// memory round trip, and the per-stage form above pays one per stage for its 2 KB weight block and one per dy for the window (round 4:
+// 1.2 us per stage, 0.13 of the matrix ceiling, 2.7 TB/s of HBM for a kernel that only streams its input). Here a STAGE GROUP = the three
+// dx taps of one (32-channel block, dy): at the group's first instruction the NEXT group's window rows (registers) and its three weight
+// blocks (6 KB, buffer_load ... lds into the other half of a double buffer) are issued, the group's 36 MFMAs per wave run from LDS with
+// no barrier in between, and one barrier pair per group swaps the window -- a round trip is covered by a whole group of every
+// workgroup on the CU (3 per CU: 46 KB of LDS each).
+template <int BM>
+__device__ __forceinline__ void window_conv_pairs16_body(const GcParams &p) {
+    using S = SplitF16x2;
+    constexpr int NP = 2, BN = 16;
+    constexpr int WM = BM / 4;                          // rows per wave (4 x 1 wave grid)
+    constexpr int MS = WM / 16;
+    constexpr int WROWS = BM + 2;
+    constexpr int AJ = (WROWS * 8 + 255) / 256;
+    constexpr int A_BYTES = (BM + 8) * 128;
+    constexpr int B_TAP = NP * 4 * BN * 16;             // bytes of one tap's weight block (2 KB)
+    constexpr int B_GRP = 3 * B_TAP;
+    constexpr int B_IMG = BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const sa = smem;
+    char *const sb = smem + A_BYTES;                    // two group buffers of B_GRP bytes
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int r = lane & 15, g = lane >> 4;
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = item * BM;
+
+    f32x4 acc[MS][1];
+#pragma unroll
+    for (int s = 0; s < MS; ++s) acc[s][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t dir_ok = 0;
+    {
+        const int hw = p.img_h * p.img_w;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) {
+            const int pix = (row0 + wave * WM + 16 * s + r) % hw;
+            const int y = pix / p.img_w, x = pix - y * p.img_w;
+            const uint32_t b = (y > 0 ? 1u : 0u) | (y < p.img_h - 1 ? 2u : 0u) | (x > 0 ? 4u : 0u) | (x < p.img_w - 1 ? 8u : 0u);
+            dir_ok |= b << (4 * s);
+        }
+    }
+    uint64_t lane_ok = 0, need_mask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) {
+            const uint32_t b = dir_ok >> (4 * s);
+            const bool ok = (dy < 0 ? (b & 1u) : dy > 0 ? (b & 2u) : 1u) && (dx < 0 ? (b & 4u) : dx > 0 ? (b & 8u) : 1u);
+            lane_ok |= (uint64_t)(ok ? 1 : 0) << (4 * t + s);
+            need_mask |= (uint64_t)(__all(ok) ? 0 : 1) << (4 * t + s);
+        }
+    }
+    need_mask = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(need_mask >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)need_mask);
+
+    const int a_piece = tid & 7, a_row = tid >> 3;
+    const int sk = p.c_in >> 5;
+    const uint32_t b_stage = (uint32_t)NP * 4u * (uint32_t)p.np * 16u;       // bytes of one (tap, 32-channel block) of the packed image
+    f32x4u ra[AJ];
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0,
+                                                                             (int)(uint32_t)((size_t)p.n_out * p.in_ld * sizeof(float)), 0x00020000);
+    const uint32_t row_bytes = (uint32_t)p.in_ld * 4u;
+    uint32_t voff_a[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) voff_a[j] = (uint32_t)(a_row + 32 * j) * row_bytes + (uint32_t)a_piece * 16u;
+    const int a_dst = (a_row << 7) + ((a_piece ^ (a_row & 7)) << 4);
+    auto load_window = [&](int kk, int dy) {
+        const uint32_t s_base = (uint32_t)(row0 + dy * p.img_w - 1) * row_bytes + (uint32_t)kk * 128u;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int w = a_row + 32 * j;
+            if (AJ * 32 <= WROWS || w < WROWS)
+                ra[j] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff_a[j] + s_base, 0, 0));
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int w = a_row + 32 * j;
+            if (AJ * 32 <= WROWS || w < WROWS) *reinterpret_cast<f32x4u *>(sa + a_dst + j * 4096) = ra[j];
+        }
+    };
+    // a group's weights: three taps x 128 slots = six wave instructions of 64 slots; wave w issues instructions w and w + 4 (< 6).
+    // slot id of a tap's block = (piece * 4 + k-group) * 16 + column  ->  packed image offset (pg * np + n) * 16
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wb), 0, (int)(9u * (uint32_t)sk * b_stage), 0x00020000);
+    const uint32_t voff_w = (uint32_t)((lane >> 4) * p.np + (lane & 15)) * 16u;      // (the second half of a tap's block: + 4 * np * 16 bytes, a scalar)
+    auto issue_weights = [&](int kk, int dyi, int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = wave_s + 4 * k;                  // wave instruction 0 ... 5: tap i >> 1 of the group, half i & 1
+            if (i < 6) {
+                const int tap = 3 * dyi + (i >> 1);
+                const uint32_t s_off = (uint32_t)(tap * sk + kk) * b_stage;
+                char *lbase = sb + buf * B_GRP + (i >> 1) * B_TAP + (i & 1) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void *)lbase, 16, voff_w, s_off + (uint32_t)(i & 1) * 64u * (uint32_t)p.np, 0, 0);
+            }
+        }
+    };
+
+    load_window(0, -1);
+    issue_weights(0, 0, 0);
+    store_window();
+    __syncthreads();
+    const int n_group = 3 * sk;
+    const int w_lane = wave * WM + r + 1;
+    int dyi = 0, kk = 0;
+    for (int gi = 0; gi < n_group; ++gi) {
+        int dyn = dyi + 1, kkn = kk;
+        if (dyn == 3) { dyn = 0; ++kkn; }
+        const bool more = gi + 1 < n_group;
+        if (more) {                                        // the next group's rows and weights: in flight under this group's three taps
+            load_window(kkn, dyn - 1);
+            issue_weights(kkn, dyn, (gi + 1) & 1);
+        }
+        const char *const sbr = sb + (gi & 1) * B_GRP;
+        const typename S::frag zero = {};
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+            const int t = 3 * dyi + dxi;
+            const int w0 = w_lane + dxi - 1;
+            const char *const a_src = sa + (w0 << 7) + ((g ^ (w0 & 7)) << 4);
+            typename S::frag a[MS][NP];
+#pragma unroll
+            for (int s = 0; s < MS; ++s) {
+                const char *src = a_src + s * 2048;
+                a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
+                a[s][1] = *reinterpret_cast<const typename S::frag *>(reinterpret_cast<const char *>((uintptr_t)src ^ 64));
+                if ((need_mask >> (4 * t + s)) & 1) {
+                    asm volatile("" ::: "memory");
+                    const bool ok = (lane_ok >> (4 * t + s)) & 1;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) a[s][q] = ok ? a[s][q] : zero;
+                }
+            }
+            const char *src = sbr + dxi * B_TAP + ((g * BN + r) << 4);
+            typename S::frag b[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const typename S::frag *>(src + q * B_IMG);
+#pragma unroll
+            for (int s = 0; s < MS; ++s) acc[s][0] = S::mma(a[s], b, acc[s][0]);
+        }
+        __syncthreads();               // everyone is done reading the window (and this group's weight buffer)
+        if (more) store_window();
+        __syncthreads();               // window visible; the next group's weights have landed (vmcnt(0) precedes the barrier)
+        dyi = dyn; kk = kkn;
+    }
+    epilogue<MS, 1>(p, acc, row0 + wave * WM, 0, r, g, 1.f);       // fp32 rows out (decode reads them)
+}
+template <int BM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // (46 KB of LDS: three workgroups per CU)
+window_conv_f16p16_kernel(GcParams p) {
+    window_conv_pairs16_body<BM>(p);
 }
 
 // The 128 x 128 split tile kernel on fp16-pair rows (strided dense conv through its pixel table, 1 x 1 / ConvTranspose GEMMs): rows
@@ -3405,6 +3563,29 @@ static int gather_conv_impl(const float *in, int in_ld, int n_in, int c_in, cons
     if (in16 && (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || (c_out != 16 && c_out != 32) || in_ld % 4 || (((uintptr_t)in) & 15) || in_absmax ||
                  (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
         return CPD_ERR_UNSUPPORTED;
+    if ((flags & CPD_GC_IN_PAIRS) && (flags & CPD_GC_DENSE) && !in16) {
+        // DENSE pair rows (round 5: the BEV maps between split-fp16 dense layers): the 128 x 128 pair tile kernel (tile_conv_f16p_kernel) --
+        // strided conv through its pixel table, 1 x 1 GEMMs, ConvTranspose(k = s) through the row map / column-group scatter. Pair rows in
+        // AND out, no residual, no pre-scaling, no stage split; anything else is refused (nothing else reads dense pair rows)
+        if (!(flags & CPD_GC_F16X2) || !(flags & CPD_GC_OUT_PAIRS) || (flags & CPD_GC_RES_PAIRS) || residual || in_absmax || c_in % 32 || c_out % 128 ||
+            in_ld % 4 || out_ld % 4 || (((uintptr_t)in) & 15) || (((uintptr_t)out) & 15) || (out_col_group && out_col_group % 32) ||
+            (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull || split_math(flags, cpd_tuning()) != 2)
+            return CPD_ERR_UNSUPPORTED;
+        GcParams p;
+        memset(&p, 0, sizeof p);
+        p.in_pairs = 1; p.out_pairs = 1; p.split = 1;
+        p.in = in; p.w = packed_w; p.out_absmax = out_absmax; p.nbr = nbr; p.scale = scale; p.shift = shift; p.out = out; p.out_row_map = out_row_map;
+        p.in_ld = in_ld; p.c_in = c_in; p.kc = c_in / 16; p.n_in_rows = n_in;
+        p.kv = kv; p.n_out = n_out; p.c_out = c_out; p.ntot = c_out / 16; p.np = c_out;
+        p.relu = relu; p.out_ld = out_ld; p.col_group = out_col_group; p.n_sub = (n_out + 15) / 16;
+        p.wb = packed_f16_ptr(packed_w, kv, c_in, c_out);
+        p.dsc = packed_dsc_ptr(packed_w, kv, c_in, c_out);
+        p.n_rb = (n_out + 127) / 128; p.n_cb = c_out / 128; p.items = p.n_rb * p.n_cb;
+        cpd_launch_log_note("tile_conv_f16p_kernel<128,128>");
+        hipLaunchKernelGGL(tile_conv_f16p_kernel, dim3(p.items), dim3(256), 128 * 128 + 2 * 128 * 64 > 32 * 132 * 4 ? 128 * 128 + 2 * 128 * 64 : 32 * 132 * 4,
+                           cpd_s(stream), p);
+        return cpd_check_launch();
+    }
     if ((flags & CPD_GC_IN_PAIRS) && !in16 &&
         (!(flags & CPD_GC_F16X2) || (flags & CPD_GC_DENSE) || c_in % 32 || c_out % 32 || in_ld % 4 || in_absmax || kv > CPD_RW_TAPS ||
          (size_t)n_in * in_ld * sizeof(float) >= 0xfffff000ull))
@@ -3708,6 +3889,31 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
         // the 64- / 128-column tiles' LDS epilogue: 16-byte row pieces when `out` (and `residual`) allow them
         p.epi_lds = out_ld % 4 == 0 && (((uintptr_t)out) & 15) == 0 && (!residual || (res_ld % 4 == 0 && (((uintptr_t)residual) & 15) == 0));
         if (bn >= 64 && c_out % bn) return CPD_ERR_UNSUPPORTED;       // (window_bn never picks such a tile)
+    }
+    if (flags & (CPD_GC_IN_PAIRS | CPD_GC_OUT_PAIRS | CPD_GC_RES_PAIRS)) {
+        // fp16-pair rows (round 5): pair rows in; pair rows out on the 64- / 128-column tiles, fp32 rows out on the 16-column head tile
+        // (window_conv_f16p_kernel). The batch sizes that take the 128 x 128 / 256 x 64 / 256 x 16 tiles; no residual, no pre-scaling
+        const bool pin = (flags & CPD_GC_IN_PAIRS) != 0, pout = (flags & CPD_GC_OUT_PAIRS) != 0;
+        if (!pin || (flags & CPD_GC_RES_PAIRS) || residual || in_absmax || math != 2 || (bn >= 64 && !p.epi_lds)) return CPD_ERR_UNSUPPORTED;
+        if (!((bn == 128 && bm == 128) || (bn == 64 && bm == 256) || (bn == 16 && bm == 256))) return CPD_ERR_UNSUPPORTED;
+        if (pout != (bn >= 64)) return CPD_ERR_UNSUPPORTED;
+        p.in_pairs = 1; p.out_pairs = pout ? 1 : 0;
+        char nm[96];
+        snprintf(nm, sizeof nm, "window_conv_f16p_kernel<%d,%d>", bn, bm);
+        cpd_launch_log_note(nm);
+        const size_t win = (size_t)(bm + 8) * 128, tile = (size_t)64 * (bn + 4) * 4;
+        const size_t wts = bn >= 64 ? 2 * 2 * (size_t)bn * 64 : 2 * (size_t)bn * 64;
+        const size_t ldsp = win + wts > tile ? win + wts : tile;
+        if (bn == 128) hipLaunchKernelGGL((window_conv_f16p_kernel<128, 128>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);
+        else if (bn == 64) hipLaunchKernelGGL((window_conv_f16p_kernel<64, 256>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);
+        else {
+            // the 16-column head tile: stage groups of three taps, next group's rows and weights a whole group ahead (window_conv_pairs16_body)
+            int grouped = 1;
+            if (const char *e = cpd_knob(cpd_tuning(), "CPD_GC_P16_GROUPED")) grouped = atoi(e);
+            if (grouped) hipLaunchKernelGGL((window_conv_f16p16_kernel<256>), dim3(p.items), dim3(256), win + 2 * 3 * 2 * 4 * 16 * 16, cpd_s(stream), p);
+            else hipLaunchKernelGGL((window_conv_f16p_kernel<16, 256>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);
+        }
+        return cpd_check_launch();
     }
     {
         char nm[96];

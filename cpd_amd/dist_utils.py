@@ -97,3 +97,44 @@ def reduce_gradients(flat_grad, world=None, group=None):
         return 1.0
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
+
+
+class BucketedReduce:
+    """The train step's gradient exchange in BUCKETS that overlap the backward pass (round 5; DDP's bucketing, tools/train.py:143): the
+    backward produces gradients head -> BEV -> sparse, so the bucket of the dense half (the tail of the flat buffer) can be on the wire
+    while the sparse half is still being back-propagated. `start(lo, hi)` launches the all-reduce of flat[lo:hi] asynchronously -- it
+    is ordered after everything queued so far on the CURRENT stream --, `finish()` reduces whatever was not started (synchronously) and
+    waits for the started ones. The result is the one all-reduce's, bit for bit (an all-reduce is element-wise). Without a process
+    group (or with one rank) everything is a no-op and the factor is 1."""
+
+    def __init__(self, flat_grad, world=None, group=None):
+        self.flat, self.group = flat_grad, group
+        self.active = dist.is_available() and dist.is_initialized()
+        if self.active:
+            world = world or dist.get_world_size(group)
+            self.active = world > 1 or bool(os.environ.get("CPD_FORCE_DIST"))
+        self.world = world if self.active else 1
+        self.started = []                 # (lo, hi, work)
+
+    def start(self, lo, hi):
+        if not self.active or hi <= lo:
+            return
+        for a, b, _ in self.started:
+            assert hi <= a or lo >= b, "gradient buckets must not overlap"
+        work = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.started.append((lo, hi, work))
+
+    def finish(self):
+        """-> the factor that turns the sums into means"""
+        if not self.active:
+            return 1.0
+        n = self.flat.numel()
+        pos = 0
+        for lo, hi, _ in sorted(self.started, key=lambda t: t[0]) + [(n, n, None)]:
+            if lo > pos:
+                dist.all_reduce(self.flat[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
+            pos = max(pos, hi)
+        for _, _, work in self.started:
+            work.wait()
+        self.started = []
+        return 1.0 / self.world

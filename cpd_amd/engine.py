@@ -64,6 +64,11 @@ class ModelConfig:
     # the row take the bits as MFMA fragments -- same products, no split in the stage loop); a range-guard re-run uses fp32 rows
     pair_rows: bool = True
     pair_rows_level1: bool = True          # ... and level 1 (16 channels: K = 16 MFMA form of the wave kernel) as well
+    # ... and the DENSE half (round 5): conv_out writes pair rows, densify copies them, every BEV / head map between two split-fp16 layers
+    # is a pair-row map (window_conv_f16p_kernel / tile_conv_f16p_kernel take the stored bits as MFMA fragments: no split in the
+    # staging); the head's output maps are fp32. Only batches large enough for the kernels' big tiles (>= 8 frames at 188 x 188):
+    # smaller batches keep fp32 dense maps. Exported tensors (bev_cat, encoded) are decoded to fp32.
+    pair_rows_dense: bool = True
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
     # "bricks" (round 4, measured, NOT the default): rows of the strided levels in 8 x 8 (y, x) brick order of their z-plane,
     # pattern-sorted inside every 128-row tile (ops.order_rows_bricks); with plan_rulebooks their sub-manifold rulebooks are PLANNED
@@ -316,12 +321,15 @@ class CenterPointEngine:
         self.head2 = _Layer(w2, None, b2, False, dev)
         self.head_ld = 16 * ((n_out + 15) // 16)
 
-    def _final_depth(self):
+    def _final_shape(self):
         shape = self.cfg.sparse_shape
         for stage in ["conv2", "conv3", "conv4", "conv_out"]:
             k, s, pd = _DOWN[stage]
             shape = ops.conv_out_shape(shape, k, s, pd)
-        return shape[0]
+        return shape
+
+    def _final_depth(self):
+        return self._final_shape()[0]
 
     # ------------------------------------------------------------------ forward pieces
     # Range guard of the f16x2 path. Every conv epilogue raises an absmax block to max |out| (a wave
@@ -385,7 +393,7 @@ class CenterPointEngine:
             x = self._conv(c2, y, nbr, n, residual=x, in_pairs=pairs, out_pairs=pairs, res_pairs=pairs)
         return x
 
-    def backbone3d(self, feats, coords, batch, index=None, pair_rows=False, export_levels=True, canonical0=False):
+    def backbone3d(self, feats, coords, batch, index=None, pair_rows=False, export_levels=True, canonical0=False, dense_pairs=False):
         """VoxelResBackBone8x.forward (spconv_backbone.py:502-558). Returns per-level
         {name: (features, indices, spatial_shape)} and the stride-8 output. `index`: the level-0 site index when the
         voxelizer already built it (cpd_voxelize_batch_index). `pair_rows`: levels 2-4 keep their activations as fp16-pair rows
@@ -456,7 +464,9 @@ class CenterPointEngine:
         k, s, pd = _DOWN["conv_out"]
         out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
         nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
-        x = self._conv(L["conv_out"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in)
+        # (dense_pairs: the stride-8 output stays in pair rows -- densify is a copy of row bytes, so the BEV map it builds is a pair-row map)
+        x = self._conv(L["conv_out"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in, out_pairs=bool(dense_pairs) and pairs_in)
+        self.encoded_pairs = bool(dense_pairs) and pairs_in
         self._rb_stage = "backbone"                            # the densified map inherits this output's range block
         return levels, (x, out_idx, out_shape)
 
@@ -481,10 +491,43 @@ class CenterPointEngine:
             self._bev_cache[key] = t
         return self._bev_cache[key]
 
-    def bev_and_head(self, dense_rows, batch, h, w):
-        """BaseBEVBackbone.forward (base_bev_backbone.py:85-122) + CenterHead convs
-        (center_head.py:323-330) on channels-last rows [batch*h*w, C]."""
+    def dense_pairs_ok(self, batch, h, w):
+        """can this batch run its dense half on fp16-pair maps? Every 3 x 3 / stride 1 layer must take one of the window tiles the pair
+        kernels exist for (128 x 128, 256 x 64, 256 x 16: cpd_conv3x3_rows_tile), the strided / deblock GEMMs need 128-column tiles,
+        and every map must stay below the 4 GB a buffer resource addresses."""
         cfg = self.cfg
+        if not (cfg.pair_rows_dense and cfg.pair_rows and cfg.conv_math == "f16x2"):
+            return False
+        key = ("dense_pairs", batch, h, w)
+        if key in self._bev_cache:
+            return self._bev_cache[key]
+        ok = True
+        cur_h, cur_w = h, w
+        widest = self.bev_levels[0][0][0].c_in
+        for lvl, (convs, de, u, c_up) in enumerate(self.bev_levels):
+            stride = cfg.bev_layer_strides[lvl]
+            if stride == 2:
+                cur_h, cur_w = (cur_h + 2 - 3) // 2 + 1, (cur_w + 2 - 3) // 2 + 1
+                ok = ok and convs[0].c_out % 128 == 0 and convs[0].c_in % 32 == 0
+            for cv in (convs if stride == 1 else convs[1:]):
+                ok = ok and ops.conv3x3_rows_tile(batch, cur_h, cur_w, cv.c_in, cv.c_out) == (128, 128)
+            ok = ok and de.c_out % 128 == 0 and c_up % 32 == 0
+            widest = max(widest, max(cv.c_out for cv in convs))
+        c_cat = sum(cfg.bev_num_upsample_filters)
+        widest = max(widest, c_cat, self.head1.c_out)
+        ok = ok and ops.conv3x3_rows_tile(batch, h, w, c_cat, self.shared.c_out) == (256, 64)
+        ok = ok and ops.conv3x3_rows_tile(batch, h, w, self.head1.c_in, self.head1.c_out) == (256, 64)
+        ok = ok and ops.conv3x3_rows_tile(batch, h, w, self.head2.c_in, self.head2.c_out) == (256, 16)
+        ok = ok and batch * h * w * widest * 4 + (w + 300) * widest * 4 < 0xfff00000
+        self._bev_cache[key] = bool(ok)
+        return bool(ok)
+
+    def bev_and_head(self, dense_rows, batch, h, w, pairs=False):
+        """BaseBEVBackbone.forward (base_bev_backbone.py:85-122) + CenterHead convs
+        (center_head.py:323-330) on channels-last rows [batch*h*w, C]. `pairs`: `dense_rows` and every map up to the head's hidden
+        layer are fp16-pair maps (ModelConfig.pair_rows_dense); the returned concat map is then a pair map, the head rows are fp32."""
+        cfg = self.cfg
+        pk = dict(in_pairs=True, out_pairs=True) if pairs else {}
         T = self._bev_tables(batch, h, w)
         if getattr(self, "_rb_stage", None) != "backbone":     # called on its own (tests, tools): the input's range is unknown
             self._range_reset()
@@ -505,26 +548,26 @@ class CenterPointEngine:
             else:
                 raise NotImplementedError("BEV stride pattern outside the shipped configs")
             n_lvl = batch * ho * wo
-            x = self._conv(convs[0], x, nbr0, n_lvl, dense=True)
+            x = self._conv(convs[0], x, nbr0, n_lvl, dense=True, **pk)
             nbr_same = T["s1"][0] if (ho, wo) == (h, w) else T["s1_half"][0]
             for cv in convs[1:]:
-                x = self._conv(cv, x, nbr_same, n_lvl, dense=True)
+                x = self._conv(cv, x, nbr_same, n_lvl, dense=True, **pk)
             cur_h, cur_w = ho, wo
             dst = cat[:, col:col + c_up]
             x_rb = self._rb                                    # the next level goes on from x, not from the deblock's output
             if u == 1:
-                self._conv(de, x, None, n_lvl, out=dst, dense=True, out_rb=cat_rb)
+                self._conv(de, x, None, n_lvl, out=dst, dense=True, out_rb=cat_rb, **pk)
             elif u == 2 and (ho * 2, wo * 2) == (h, w):
-                self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up, dense=True, out_rb=cat_rb)
+                self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up, dense=True, out_rb=cat_rb, **pk)
             else:
                 raise NotImplementedError("upsample stride outside the shipped configs")
             self._rb = x_rb
             col += c_up
         self._rb = cat_rb
-        s = self._conv(self.shared, cat, T["s1"][0], n_full, dense=True)
-        h1 = self._conv(self.head1, s, T["s1"][0], n_full, dense=True)
+        s = self._conv(self.shared, cat, T["s1"][0], n_full, dense=True, **pk)
+        h1 = self._conv(self.head1, s, T["s1"][0], n_full, dense=True, **pk)
         out = torch.empty((n_full, self.head_ld), dtype=torch.float32, device=self.device)
-        self._conv(self.head2, h1, T["s1"][0], n_full, out=out)
+        self._conv(self.head2, h1, T["s1"][0], n_full, out=out, dense=pairs, in_pairs=pairs)
         return cat, out
 
     def decode_and_nms(self, head_rows, batch, h, w, raw=False):
@@ -630,13 +673,16 @@ class CenterPointEngine:
         self._guard_left = getattr(self, "_guard_left", 0)
         self._rb_scaled = self._guard_left > 0
         self._range_high = False
+        fd, fh, fw = self._final_shape()
         while True:
+            dp = (not self._rb_scaled) and self.dense_pairs_ok(batch, fh, fw)
             levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0, canonical0=canonical0,
                                                               export_levels=proposals if proposals is not None else return_intermediates,
-                                                              pair_rows=self.cfg.pair_rows and not self._rb_scaled)
+                                                              pair_rows=self.cfg.pair_rows and not self._rb_scaled, dense_pairs=dp)
             d, h, w = out_shape
+            dp = dp and self.encoded_pairs
             dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
-            cat, head = self.bev_and_head(dense, batch, h, w)
+            cat, head = self.bev_and_head(dense, batch, h, w, pairs=dp)
             results = self.decode_and_nms(head, batch, h, w, raw=proposals is not None)
             if results is not None:
                 break
@@ -655,9 +701,11 @@ class CenterPointEngine:
         if proposals is not None:
             return results + (levels,)
         if return_intermediates:
+            if dp:                                         # exported tensors are fp32 (h + l is exact)
+                x, dense, cat = ops.pairs_to_rows(x), ops.pairs_to_rows(dense), ops.pairs_to_rows(cat)
             return results, dict(voxel_features=feats, voxel_coords=coords, levels=levels,
                                  encoded=(x, out_idx, out_shape), spatial_features_nhwc=dense, bev_cat=cat,
-                                 head_rows=head)
+                                 head_rows=head, dense_pairs=dp)
         return results
 
     __call__ = forward

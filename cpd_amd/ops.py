@@ -243,6 +243,14 @@ def rulebook_subm(indices, index, ksize=(3, 3, 3), canonical=None):
     return nbr
 
 
+def conv3x3_rows_tile(frames, h, w, c_in, c_out, math="f16x2"):
+    """(bm, bn) of the rulebook-free window kernel for a 3 x 3 / stride 1 / pad 1 layer over frames x h x w pixel rows, or None when the
+    layer takes the table path (cpd_conv3x3_rows_tile)"""
+    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib().cpd_conv3x3_rows_tile(int(frames), int(h), int(w), int(c_in), int(c_out), CONV_MATH[math], ctypes.byref(bm), ctypes.byref(bn))
+    return (bm.value, bn.value) if rc == 0 else None
+
+
 def conv_out_shape(in_shape, ksize, stride, pad):
     o = (ctypes.c_int32 * 3)()
     check(lib().cpd_conv_out_shape(iarr(in_shape), iarr(ksize), iarr(stride), iarr(pad), o), "cpd_conv_out_shape")
@@ -315,7 +323,9 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
     (one extra pass over `inp`) instead of trusting it to stay below 65504.
     `in_pairs` / `out_pairs` / `res_pairs`: the rows of `inp` / `out` / `residual` are fp16-PAIR rows (CPD_GC_*_PAIRS of
     include/cpd_hip.h: per 32-channel block the fp16 high terms, then the fp16 low terms -- rows_to_pairs / pairs_to_rows here):
-    storage between the engine's f16x2 sparse layers, sparse (non-`dense`) f16x2 calls only."""
+    storage between the engine's f16x2 sparse layers; with `dense` (round 5) the BEV maps between split-fp16 dense layers: the window
+    kernel's 128 x 128 / 256 x 64 / 256 x 16 tiles and the 128 x 128 tile kernel (window_conv_f16p_kernel / tile_conv_f16p_kernel) --
+    a shape they do not take raises (CPD_ERR_UNSUPPORTED): nothing else reads dense pair rows."""
     _need_cuda(inp, "inp")
     assert inp.dim() == 2 and inp.stride(1) == 1
     if guard and in_absmax is None and (math == "f16x2") and c_in % 32 == 0:
@@ -329,7 +339,8 @@ def gather_conv(inp, c_in, packed_w, nbr, kv, n_out, c_out, scale=None, shift=No
         res_ld = residual.stride(0)
     flags = _gc_flags(dense, bf16x3, math) | (16 if in_pairs else 0) | (32 if out_pairs else 0) | (64 if res_pairs else 0)
     image = getattr(nbr, "image", None)             # 3x3 / stride 1 / pad 1 pixel table: the rulebook-free window kernel
-    if image is not None and not (flags & 0x70) and out_row_map is None and kv == 9 and n_out == image[0] * image[1] * image[2] and inp.shape[0] == n_out:
+    # (pair rows: dense maps only -- cpd_conv3x3_rows takes CPD_GC_IN_PAIRS / OUT_PAIRS on the tiles of large batches)
+    if image is not None and (dense or not (flags & 0x70)) and out_row_map is None and kv == 9 and n_out == image[0] * image[1] * image[2] and inp.shape[0] == n_out:
         rc = lib().cpd_conv3x3_rows_ranged(
             ctypes.c_void_p(inp.data_ptr()), inp.stride(0), image[0], image[1], image[2], c_in, ptr(packed_w), c_out,
             ptr(scale), ptr(shift), ctypes.c_void_p(residual.data_ptr()) if residual is not None else None, res_ld,

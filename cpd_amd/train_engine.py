@@ -288,7 +288,13 @@ class CenterPointTrainer:
         self._voxelizers = []
         self._bev_cache = {}
         self._build(state_dict)
+        dense_first = self.store._pending[self._n_sparse_slots][0]
         self.store.finalize(self.device)
+        # gradient buckets (dist_utils.BucketedReduce): [dense_offset, end) = BEV backbone + head, complete when the BEV half of the
+        # backward pass is; [0, dense_offset) = sparse backbone. CPD_TRAIN_BUCKETS=0: one all-reduce after the whole backward (round 4)
+        self.dense_offset = self.store.slots[dense_first][0]
+        self.bucketed_reduce = os.environ.get("CPD_TRAIN_BUCKETS", "1") != "0"
+        self._reduce = None
         for c in self.layers:
             c.to(self.device)
         # every packed image (forward + adjoint) of every layer is rebuilt after each optimiser step: three launches for all of
@@ -356,6 +362,7 @@ class CenterPointTrainer:
         S["conv_out"] = mk(p + "conv_out.0", self._sparse_w(sd, p + "conv_out.0"), None, p + "conv_out.1", self.SPARSE_BN,
                            mode="strided")
         self.sparse = S
+        self._n_sparse_slots = len(st._pending)          # the flat store lays its slots out in creation order: [sparse | BEV | head]
 
         p = "backbone_2d."
         depth, C = self._final_depth(), cfg.out_features
@@ -551,6 +558,7 @@ class CenterPointTrainer:
             for cv in reversed(convs[1:]):
                 d, _ = cv.backward(d, nbr_same, n_lvl)
             carry, _ = convs[0].backward(d, adj0, n_in_lvl)
+        self._start_dense_bucket()                              # the BEV + head gradients go on the wire under the sparse half's backward
         batch, h, w, dd, C = tp["dense_shape"]
         dx = carry.view(batch * h * w * dd, C).index_select(0, tp["dense_rows"])      # HeightCompression backward
         for stage, nbr, nbr_dn_t, n_in in reversed(tp["stages"]):
@@ -563,6 +571,26 @@ class CenterPointTrainer:
         S["conv_input"].backward(dx, None, 0, need_dx=False)
         self.store.join_side()                  # every weight gradient is in the flat buffer from here on
         self.tape = None
+
+    def _start_dense_bucket(self):
+        """N > 1: start the all-reduce of the dense half's gradient bucket. Its gradients come from both streams (BatchNorm / bias
+        terms on the main one, weight gradients on the side one), so the collective is launched from the side stream after that
+        stream has been made to wait for the main stream's work so far: the main stream -- the critical input-gradient chain -- never
+        waits."""
+        self._reduce = None
+        if not (self.bucketed_reduce and (self.pg is not None or self.world > 1)):
+            return
+        red = dist_utils.BucketedReduce(self.store.grad, self.world, self.pg)
+        if red.active:
+            side = self.store.side
+            if side is not None:
+                ev = self.store.mark()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    red.start(self.dense_offset, self.store.grad.numel())
+            else:
+                red.start(self.dense_offset, self.store.grad.numel())
+        self._reduce = red
 
     def loss(self, rows, gt_boxes):
         """CenterHead.assign_targets + get_loss (center_head.py:159-250). Returns (loss, d_rows, parts)."""
@@ -594,7 +622,11 @@ class CenterPointTrainer:
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        scale = dist_utils.reduce_gradients(st.grad, self.world, self.pg)   # the one collective (no-op without a process group)
+        if self._reduce is not None:                                          # the dense bucket is on the wire since the middle of the backward pass
+            scale = self._reduce.finish()                                    # (sparse bucket now; then wait for both)
+            self._reduce = None
+        else:
+            scale = dist_utils.reduce_gradients(st.grad, self.world, self.pg)   # one collective (no-op without a process group)
         if ev is not None:
             e1.record()
             ev.append((e0, e1))

@@ -26,6 +26,14 @@ def _worker(rank, world, port, q):
     grad = torch.full((1000,), float(rank + 1))          # rank r holds gradient r+1 everywhere
     scale = du.reduce_gradients(grad, world)
     assert scale == 0.5 and torch.all(grad == 3.0)       # sum over ranks, mean = sum * scale
+    # the bucketed, overlapped form (train_engine: the dense half's bucket starts while the sparse half back-propagates) == one all-reduce
+    g1 = torch.arange(1000, dtype=torch.float32) * (rank + 1) + rank
+    g2 = g1.clone()
+    du.reduce_gradients(g1, world)
+    br = du.BucketedReduce(g2, world)
+    br.start(600, 1000)
+    br.start(100, 200)
+    assert br.finish() == 0.5 and torch.equal(g1, g2)
     du.barrier()
     q.put((rank, seeds, mx, thr))
     du.shutdown()

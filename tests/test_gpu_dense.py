@@ -410,3 +410,97 @@ def test_stage_split_of_small_dense_launches(hip, monkeypatch, cin, cout, hw, k,
     again, _, _ = run(1)
     assert torch.equal(got, again)
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 5: fp16-PAIR dense maps (ModelConfig.pair_rows_dense; window_conv_f16p_kernel / tile_conv_f16p_kernel). The kernels take the
+# stored (h, l) bits as MFMA fragments; against the ORACLE on the bench's layer shapes at the batch size that selects the pair tiles,
+# and against the fp32-row kernels on pair-exact inputs (same partial products, same order: <= 5e-6).
+
+def _pairs_case(rng, batch, cin, h, w):
+    x = np.maximum(rng.normal(size=(batch, cin, h, w)), 0).astype(np.float32)              # a post-ReLU map
+    rows = nhwc_rows(x)
+    pairs = ops.rows_to_pairs(rows)
+    exact = ops.pairs_to_rows(pairs)                                                        # what the pair map holds (h + l: 22 significand bits)
+    return exact.cpu().numpy().reshape(batch, h, w, cin).transpose(0, 3, 1, 2), exact, pairs
+
+
+PAIR_SHAPES = [
+    (128, 128, 3, 1, 8, 188, 188, "window_conv_f16p_kernel<128,128>"),     # BEV block 0
+    (256, 128, 3, 1, 8, 188, 188, "window_conv_f16p_kernel<128,128>"),     # BEV block 0, first conv (reads the densified pair map)
+    (256, 256, 3, 1, 8, 94, 94, "window_conv_f16p_kernel<128,128>"),       # BEV block 1
+    (128, 256, 3, 2, 8, 188, 188, "tile_conv_f16p_kernel<128,128>"),       # BEV block 1, strided conv
+    (512, 64, 3, 1, 8, 188, 188, "window_conv_f16p_kernel<64,256>"),       # CenterHead shared conv (reads the pair concat map)
+    (64, 320, 3, 1, 8, 188, 188, "window_conv_f16p_kernel<64,256>"),       # fused first head convs
+    (320, 11, 3, 1, 8, 188, 188, "window_conv_f16p_kernel<16,256>"),       # fused output convs: pair rows in, fp32 rows out
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,batch,h,w,kernel", PAIR_SHAPES)
+def test_pair_dense_kernels_match_oracle_and_the_fp32_row_kernels(oracle, hip, cin, cout, k, stride, batch, h, w, kernel):
+    rng = np.random.default_rng(cin * 3 + cout + stride)
+    x_nchw, exact, pairs = _pairs_case(rng, batch, cin, h, w)
+    wt = (rng.normal(size=(cout, cin, k, k)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32); shift = rng.normal(size=cout).astype(np.float32)
+    nbr, ho, wo = ops.rulebook_conv2d(batch, h, w, k, k, stride, 1, "cuda")
+    packed = ops.pack_weight(torch.from_numpy(wt).permute(2, 3, 1, 0).reshape(k * k, cin, cout).contiguous().cuda())
+    sc, sh = torch.from_numpy(scale).cuda(), torch.from_numpy(shift).cuda()
+    n_out = batch * ho * wo
+    pout = cout % 64 == 0
+    blk = ops.absmax_blocks(1, "cuda")[0]
+    with ops.launch_log() as log:
+        got = ops.gather_conv(pairs, cin, packed, nbr, k * k, n_out, cout, sc, sh, None, True, dense=True, math="f16x2",
+                              in_pairs=True, out_pairs=pout, out_absmax=blk)
+    assert log.counts == {kernel: 1}, log.counts
+    got_rows = ops.pairs_to_rows(got) if pout else got
+    assert ops.absmax_value(blk) >= float(got_rows.abs().max())              # the block holds the fp32 maximum (the stored h + l rounds it to 22 bits)
+    # (a) the fp32-row kernel on the same (pair-exact) input: the same products in the same order, output stored to 22 bits
+    base = ops.gather_conv(exact, cin, packed, nbr, k * k, n_out, cout, sc, sh, None, True, dense=True, math="f16x2")
+    want_rows = ops.pairs_to_rows(ops.rows_to_pairs(base)) if pout else base
+    # (not bitwise: pair-exact inputs whose low term sits exactly on fp16's rounding tie re-split to another (h, l) with the same sum
+    # in the fp32-row kernel, so single products move by 2^-22 relative and sums by a few fp32 ulps of their largest partial sum;
+    # measured 1.9e-6 at |out| <= 8 on 36 M outputs -- fifty times inside the 1e-4 contract)
+    assert float((got_rows - want_rows).abs().max()) <= 5e-6
+    # (b) the oracle
+    want = np.maximum(oracle.conv2d(x_nchw, wt, None, stride, 1) * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    np.testing.assert_allclose(rows_nchw(got_rows, batch, ho, wo), want, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("cin,cout,u,batch,h,w", [(128, 256, 1, 8, 188, 188), (256, 256, 2, 8, 94, 94)])
+def test_pair_deconv_kernels_match_oracle(oracle, hip, cin, cout, u, batch, h, w):
+    """The two deblocks on pair maps, writing their column block of a 512-wide pair concat buffer (row stride 512, column offset 256),
+    the ConvTranspose(k = s = 2) through the row map / column-group scatter."""
+    rng = np.random.default_rng(cin + cout + u + 5)
+    x_nchw, exact, pairs = _pairs_case(rng, batch, cin, h, w)
+    wd = (rng.normal(size=(cin, cout, u, u)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    want = np.maximum(oracle.deconv2d(x_nchw, wd, u), 0)
+    packed = ops.pack_weight(torch.from_numpy(wd).permute(0, 2, 3, 1).reshape(1, cin, u * u * cout).contiguous().cuda())
+    n = batch * h * w
+    H, W = h * u, w * u
+    cat = torch.full((batch * H * W, 512), float("nan"), device="cuda")
+    dst = cat[:, 256:256 + cout]
+    with ops.launch_log() as log:
+        if u == 1:
+            ops.gather_conv(pairs, cin, packed, None, 1, n, cout, None, None, None, True, out=dst, dense=True, math="f16x2", in_pairs=True, out_pairs=True)
+        else:
+            bi = torch.arange(batch, device="cuda").view(-1, 1, 1); yy = torch.arange(h, device="cuda").view(1, -1, 1)
+            xx = torch.arange(w, device="cuda").view(1, 1, -1)
+            maps = torch.stack([((bi * H + 2 * yy + a) * W + 2 * xx + c).reshape(-1) for a in range(2) for c in range(2)])
+            ops.gather_conv(pairs, cin, packed, None, 1, n, 4 * cout, None, None, None, True, out=dst, out_row_map=maps.to(torch.int32).contiguous(),
+                            out_col_group=cout, dense=True, math="f16x2", in_pairs=True, out_pairs=True)
+    assert log.counts == {"tile_conv_f16p_kernel<128,128>": 1}, log.counts
+    assert bool(torch.isnan(cat[:, :256]).all())                               # nothing outside the block is touched
+    got = ops.pairs_to_rows(dst.contiguous())
+    np.testing.assert_allclose(rows_nchw(got, batch, H, W), want, atol=1e-4, rtol=0)
+
+
+def test_dense_pair_shapes_the_kernels_do_not_take_are_refused(hip):
+    """nothing else reads dense pair rows: an unsupported shape raises instead of computing on the wrong format"""
+    from cpd_amd._lib import CpdHipError
+    x = torch.zeros((4 * 50 * 50, 128), device="cuda")
+    nbr, _, _ = ops.rulebook_conv2d(4, 50, 50, 3, 3, 1, 1, "cuda")
+    packed = ops.pack_weight(torch.zeros((9, 128, 128), device="cuda"))
+    with pytest.raises(CpdHipError):
+        ops.gather_conv(x, 128, packed, nbr, 9, x.shape[0], 128, dense=True, math="f16x2", in_pairs=True, out_pairs=True)   # too few rows for the window tiles
+    with pytest.raises(CpdHipError):
+        ops.gather_conv(x, 128, packed, nbr, 9, x.shape[0], 128, dense=True, math="f32", in_pairs=True, out_pairs=True)
