@@ -1501,17 +1501,19 @@ __device__ __forceinline__ void window_conv_pairs_body(const GcParams &p) {
         {
             // fragment addresses of this stage (dx = dxi - 1): row w = w_lane + dx + 16 s, piece 4 q + g at slot (4 q + g) ^ (w & 7); 16 s leaves
             // w & 7 alone and 4 q flips address bit 6: one base per stage, sub-tiles and halves are immediates / one XOR
+            // (offsets into the __shared__ array, not pointers: an XOR on a pointer goes through a 64-bit integer and comes back as a FLAT
+            // pointer -- flat_load_dwordx4 instead of ds_read_b128, found in the ISA)
             const int w0 = w_lane + dxi - 1;
-            const char *const a_src = sa + (w0 << 7) + ((g ^ (w0 & 7)) << 4);
+            const uint32_t a_off = (uint32_t)((w0 << 7) + ((g ^ (w0 & 7)) << 4));       // (the window image starts at smem + 0)
+            const uint32_t a_off_l = a_off ^ 64u;
             const typename S::frag zero = {};
 #pragma unroll
             for (int s0 = 0; s0 < MS; s0 += SH) {
                 typename S::frag a[SH][NP];
 #pragma unroll
                 for (int s = 0; s < SH; ++s) {
-                    const char *src = a_src + (s0 + s) * 2048;
-                    a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
-                    a[s][1] = *reinterpret_cast<const typename S::frag *>(reinterpret_cast<const char *>((uintptr_t)src ^ 64));
+                    a[s][0] = *reinterpret_cast<const typename S::frag *>(smem + a_off + (s0 + s) * 2048);
+                    a[s][1] = *reinterpret_cast<const typename S::frag *>(smem + a_off_l + (s0 + s) * 2048);
                     if ((need_mask >> (4 * t + s0 + s)) & 1) {          // scalar test; rarely taken
                         asm volatile("" ::: "memory");                  // keeps this a branch (no if-conversion into 8 selects)
                         const bool ok = (lane_ok >> (4 * t + s0 + s)) & 1;
@@ -1747,13 +1749,13 @@ __device__ __forceinline__ void window_conv_pairs16_body(const GcParams &p) {
         for (int dxi = 0; dxi < 3; ++dxi) {
             const int t = 3 * dyi + dxi;
             const int w0 = w_lane + dxi - 1;
-            const char *const a_src = sa + (w0 << 7) + ((g ^ (w0 & 7)) << 4);
+            const uint32_t a_off = (uint32_t)((w0 << 7) + ((g ^ (w0 & 7)) << 4));
+            const uint32_t a_off_l = a_off ^ 64u;
             typename S::frag a[MS][NP];
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
-                const char *src = a_src + s * 2048;
-                a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
-                a[s][1] = *reinterpret_cast<const typename S::frag *>(reinterpret_cast<const char *>((uintptr_t)src ^ 64));
+                a[s][0] = *reinterpret_cast<const typename S::frag *>(smem + a_off + s * 2048);
+                a[s][1] = *reinterpret_cast<const typename S::frag *>(smem + a_off_l + s * 2048);
                 if ((need_mask >> (4 * t + s)) & 1) {
                     asm volatile("" ::: "memory");
                     const bool ok = (lane_ok >> (4 * t + s)) & 1;
@@ -1872,7 +1874,8 @@ tile_conv_f16p_kernel(GcParams p) {
     stage_store();
     __syncthreads();
     const int m_lane = wr * (BM / 2) + r;
-    const char *const a_src = sa + (m_lane << 7) + ((g ^ (m_lane & 7)) << 4);      // + 2048 s; ^ 64 for the low terms
+    const uint32_t a_off = (uint32_t)((m_lane << 7) + ((g ^ (m_lane & 7)) << 4));   // + 2048 s; ^ 64 for the low terms (offsets, not pointers: see the window kernel)
+    const uint32_t a_off_l = a_off ^ 64u;
     for (int st = 0; st < n_stage; ++st) {
         const int nx = st + 1;
         if (nx < n_stage) {
@@ -1883,9 +1886,8 @@ tile_conv_f16p_kernel(GcParams p) {
             typename S::frag a[MS][NP];
 #pragma unroll
             for (int s = 0; s < MS; ++s) {
-                const char *src = a_src + s * 2048;
-                a[s][0] = *reinterpret_cast<const typename S::frag *>(src);
-                a[s][1] = *reinterpret_cast<const typename S::frag *>(reinterpret_cast<const char *>((uintptr_t)src ^ 64));
+                a[s][0] = *reinterpret_cast<const typename S::frag *>(smem + a_off + s * 2048);
+                a[s][1] = *reinterpret_cast<const typename S::frag *>(smem + a_off_l + s * 2048);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {

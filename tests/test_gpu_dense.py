@@ -495,12 +495,17 @@ def test_pair_deconv_kernels_match_oracle(oracle, hip, cin, cout, u, batch, h, w
 
 
 def test_dense_pair_shapes_the_kernels_do_not_take_are_refused(hip):
-    """nothing else reads dense pair rows: an unsupported shape raises instead of computing on the wrong format"""
+    """nothing else reads dense pair rows: a shape neither pair kernel takes raises instead of computing on the wrong format; a small
+    128-column layer (too few rows for the window tiles) goes to the pair tile kernel through its pixel table"""
     from cpd_amd._lib import CpdHipError
     x = torch.zeros((4 * 50 * 50, 128), device="cuda")
     nbr, _, _ = ops.rulebook_conv2d(4, 50, 50, 3, 3, 1, 1, "cuda")
     packed = ops.pack_weight(torch.zeros((9, 128, 128), device="cuda"))
+    with ops.launch_log() as log:
+        ops.gather_conv(x, 128, packed, nbr, 9, x.shape[0], 128, dense=True, math="f16x2", in_pairs=True, out_pairs=True)
+    assert log.counts == {"tile_conv_f16p_kernel<128,128>": 1}, log.counts
+    packed64 = ops.pack_weight(torch.zeros((9, 128, 64), device="cuda"))
     with pytest.raises(CpdHipError):
-        ops.gather_conv(x, 128, packed, nbr, 9, x.shape[0], 128, dense=True, math="f16x2", in_pairs=True, out_pairs=True)   # too few rows for the window tiles
+        ops.gather_conv(x, 128, packed64, nbr, 9, x.shape[0], 64, dense=True, math="f16x2", in_pairs=True, out_pairs=True)   # 64 columns, too few rows for the 256-row window tile
     with pytest.raises(CpdHipError):
         ops.gather_conv(x, 128, packed, nbr, 9, x.shape[0], 128, dense=True, math="f32", in_pairs=True, out_pairs=True)
