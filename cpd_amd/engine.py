@@ -292,6 +292,12 @@ class CenterPointEngine:
             w_kio = wd.permute(0, 2, 3, 1).reshape(1, cin, u * u * cout)
             de = _Layer(w_kio, s.repeat(u * u), t.repeat(u * u), True, dev)
             self.bev_levels.append((convs, de, u, cout))
+        self._build_head()
+
+    def _build_head(self):
+        """CenterHead's convolutions (center_head.py:73-94); a subclass with another dense head (cpd_amd/anchor_engine.py) overrides this,
+        `_head_rows` and `decode_and_nms`."""
+        cfg, sd, dev = self.cfg, self.sd, self.device
         p = "dense_head."
         s, t = _fold_bn(sd, p + "shared_conv.1", self.HEAD_BN_EPS, sd.get(p + "shared_conv.0.bias"))
         w = sd[p + "shared_conv.0.weight"]
@@ -514,13 +520,16 @@ class CenterPointEngine:
             ok = ok and de.c_out % 128 == 0 and c_up % 32 == 0
             widest = max(widest, max(cv.c_out for cv in convs))
         c_cat = sum(cfg.bev_num_upsample_filters)
-        widest = max(widest, c_cat, self.head1.c_out)
-        ok = ok and ops.conv3x3_rows_tile(batch, h, w, c_cat, self.shared.c_out) == (256, 64)
-        ok = ok and ops.conv3x3_rows_tile(batch, h, w, self.head1.c_in, self.head1.c_out) == (256, 64)
-        ok = ok and ops.conv3x3_rows_tile(batch, h, w, self.head2.c_in, self.head2.c_out) == (256, 16)
+        ok = ok and self._head_pairs_ok(batch, h, w, c_cat)
+        widest = max(widest, c_cat, getattr(getattr(self, "head1", None), "c_out", 0))
         ok = ok and batch * h * w * widest * 4 + (w + 300) * widest * 4 < 0xfff00000
         self._bev_cache[key] = bool(ok)
         return bool(ok)
+
+    def _head_pairs_ok(self, batch, h, w, c_cat):
+        return (ops.conv3x3_rows_tile(batch, h, w, c_cat, self.shared.c_out) == (256, 64) and
+                ops.conv3x3_rows_tile(batch, h, w, self.head1.c_in, self.head1.c_out) == (256, 64) and
+                ops.conv3x3_rows_tile(batch, h, w, self.head2.c_in, self.head2.c_out) == (256, 16))
 
     def bev_and_head(self, dense_rows, batch, h, w, pairs=False):
         """BaseBEVBackbone.forward (base_bev_backbone.py:85-122) + CenterHead convs
@@ -564,11 +573,17 @@ class CenterPointEngine:
             self._rb = x_rb
             col += c_up
         self._rb = cat_rb
+        return cat, self._head_rows(cat, batch, h, w, T, pairs)
+
+    def _head_rows(self, cat, batch, h, w, T, pairs):
+        """the dense head's convolutions on the concat map's rows -> what decode_and_nms takes (CenterHead: the head rows)"""
+        pk = dict(in_pairs=True, out_pairs=True) if pairs else {}
+        n_full = batch * h * w
         s = self._conv(self.shared, cat, T["s1"][0], n_full, dense=True, **pk)
         h1 = self._conv(self.head1, s, T["s1"][0], n_full, dense=True, **pk)
         out = torch.empty((n_full, self.head_ld), dtype=torch.float32, device=self.device)
         self._conv(self.head2, h1, T["s1"][0], n_full, out=out, dense=pairs, in_pairs=pairs)
-        return cat, out
+        return out
 
     def decode_and_nms(self, head_rows, batch, h, w, raw=False):
         """generate_predicted_boxes (center_head.py:252-303) + class_agnostic_nms

@@ -872,6 +872,13 @@ class CenterPoint(nn.Module):
     def to_engine_config(self):
         from .engine import ModelConfig
         c = self.model_cfg
+        if c.DENSE_HEAD.NAME != "CenterHead":            # anchor dense head: the backbone fields only (the head has its own config)
+            return ModelConfig(point_cloud_range=self.point_cloud_range, voxel_size=self.voxel_size,
+                               num_point_features=self.num_point_features, num_filters=list(c.BACKBONE_3D.NUM_FILTERS),
+                               out_features=c.BACKBONE_3D.OUT_FEATURES, bev_layer_nums=list(c.BACKBONE_2D.LAYER_NUMS),
+                               bev_layer_strides=list(c.BACKBONE_2D.LAYER_STRIDES), bev_num_filters=list(c.BACKBONE_2D.NUM_FILTERS),
+                               bev_upsample_strides=list(c.BACKBONE_2D.UPSAMPLE_STRIDES),
+                               bev_num_upsample_filters=list(c.BACKBONE_2D.NUM_UPSAMPLE_FILTERS), num_class=self.num_class)
         pp = c.DENSE_HEAD.POST_PROCESSING
         return ModelConfig(point_cloud_range=self.point_cloud_range, voxel_size=self.voxel_size,
                            num_point_features=self.num_point_features, num_filters=list(c.BACKBONE_3D.NUM_FILTERS),
@@ -924,6 +931,22 @@ def waymo_voxel_rcnn_cfg():
     cfg.POST_PROCESSING = AttrDict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], SCORE_THRESH=0.01, OUTPUT_RAW_SCORE=False, EVAL_METRIC="waymo",
                                    NMS_CONFIG=dict(MULTI_CLASSES_NMS=False, NMS_TYPE="nms_gpu", NMS_THRESH=0.3, NMS_PRE_MAXSIZE=4096,
                                                    NMS_POST_MAXSIZE=50075))
+    return cfg
+
+
+def waymo_voxel_rcnn_dbscan_cfg():
+    """MODEL section of voxel_rcnn_dbscan_single_train.yaml:12-174 (voxel_rcnn_oyster_single_train.yaml is the same model): `VoxelRCNN` =
+    AnchorHeadSingleV2 proposals -> VoxelRCNNHead (class-agnostic) -> class-agnostic NMS 0.3 at score 0.1."""
+    from .anchor_engine import dbscan_dense_head_cfg
+    cfg = waymo_voxel_rcnn_cfg()
+    cfg.DENSE_HEAD = AttrDict(dbscan_dense_head_cfg())
+    cfg.BACKBONE_3D.MM = False
+    rh = cfg.ROI_HEAD
+    rh.NAME = "VoxelRCNNHead"
+    rh.NMS_CONFIG["TRAIN"]["NMS_POST_MAXSIZE"] = 500
+    rh.NMS_CONFIG["TEST"]["NMS_POST_MAXSIZE"] = 200
+    rh.TARGET_CONFIG.update(ROI_PER_IMAGE=150, CLS_FG_THRESH=0.75, CLS_BG_THRESH=0.25, CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8, REG_FG_THRESH=0.55)
+    cfg.POST_PROCESSING.SCORE_THRESH = 0.1
     return cfg
 
 
@@ -998,7 +1021,13 @@ class VoxelRCNN(CenterPoint):
         return pred_dicts, recall, batch_dict
 
     def to_engine(self, device="cuda", **kw):
-        """The fused two-stage inference engine (cpd_amd/two_stage.py) on this model's weights."""
+        """The fused two-stage inference engine (cpd_amd/two_stage.py) on this model's weights; with an anchor dense head
+        (voxel_rcnn_dbscan / oyster configs) its first stage is cpd_amd.anchor_engine.AnchorPointEngine."""
         from .two_stage import VoxelRCNNEngine
         sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
-        return VoxelRCNNEngine(self.to_engine_config(), self.model_cfg.ROI_HEAD, self.model_cfg.POST_PROCESSING, sd, device=device, **kw)
+        rpn = None
+        if self.model_cfg.DENSE_HEAD.NAME != "CenterHead":
+            from .anchor_engine import AnchorPointEngine
+            rpn = AnchorPointEngine(self.to_engine_config(), sd, self.model_cfg.DENSE_HEAD, self.model_cfg.ROI_HEAD.NMS_CONFIG["TEST"],
+                                    class_names=self.class_names, device=device)
+        return VoxelRCNNEngine(self.to_engine_config(), self.model_cfg.ROI_HEAD, self.model_cfg.POST_PROCESSING, sd, device=device, rpn=rpn, **kw)

@@ -420,6 +420,14 @@ class VoxelRCNNHead(nn.Module):
             raise NotImplementedError("VoxelRCNNHead: eval forward only")
         if self._fc is None:
             self._pack_fc()
+        if "rois" not in batch_dict:
+            # RoIHeadTemplate.proposal_layer on the dense head's predictions (voxel_rcnn_head.py:883-885, roi_head_template.py:53-114):
+            # the anchor-head configs (voxel_rcnn_dbscan / oyster) reach the RoI head this way; CenterHead already left `rois` behind
+            nms = self.model_cfg["NMS_CONFIG"]["TEST"]
+            rois7, roi_scores, roi_labels, _ = proposal_layer(batch_dict["batch_box_preds"], batch_dict["batch_cls_preds"], float(nms["NMS_THRESH"]),
+                                                              int(nms["NMS_PRE_MAXSIZE"]), int(nms["NMS_POST_MAXSIZE"]))
+            batch_dict.update(rois=rois7, roi_scores=roi_scores, roi_labels=roi_labels,
+                              has_class_labels=batch_dict["batch_cls_preds"].shape[-1] > 1)
         rois, b = batch_dict["rois"], batch_dict["batch_size"]
         levels = {}
         for name in self.sources:

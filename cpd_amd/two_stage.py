@@ -28,11 +28,14 @@ from .engine import CenterPointEngine, ModelConfig
 class VoxelRCNNEngine:
     """points [N, C] per frame -> {'pred_boxes', 'pred_scores', 'pred_labels'} per frame (second-stage refined, final NMS 0.3)."""
 
-    def __init__(self, cfg: ModelConfig, roi_cfg, post_cfg, state_dict: Dict[str, torch.Tensor], device="cuda", host_results=False):
+    def __init__(self, cfg: ModelConfig, roi_cfg, post_cfg, state_dict: Dict[str, torch.Tensor], device="cuda", host_results=False, rpn=None):
+        """`rpn`: the first stage -- any engine whose forward(points_list, proposals=levels) returns (RoI block, scores, 1-based labels,
+        per-frame counts, levels) and that keeps `level_indexes`; default the CenterPoint engine on the same state dict
+        (voxel_rcnn_cproto_center.yaml); cpd_amd.anchor_engine.AnchorPointEngine for the dbscan / oyster configs."""
         self.cfg, self.roi_cfg, self.post_cfg = cfg, roi_cfg, post_cfg
         self.device = torch.device(device)
         self.host_results = bool(host_results)
-        self.rpn = CenterPointEngine(cfg, state_dict, device=device)
+        self.rpn = rpn if rpn is not None else CenterPointEngine(cfg, state_dict, device=device)
         nf = cfg.num_filters
         channels = {"x_conv1": nf[0], "x_conv2": nf[1], "x_conv3": nf[2], "x_conv4": nf[3]}
         agnostic = bool(roi_cfg.get("CLASS_AGNOSTIC", False))

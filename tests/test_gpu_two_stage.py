@@ -290,3 +290,87 @@ def test_full_size_two_stage_engine_matches_the_oracle_composition(oracle, hip):
     print("final detections: engine %d, oracle chain %d, in common at 1e-3: %d (rank swaps among scores closer than 1e-3 cascade through "
           "the greedy NMS; %d RoIs with flipped neighbour queries)" % (len(a), len(b), common, len(flips)))
     assert abs(len(a) - n_pad - len(b)) <= 0.1 * len(b) and common >= 0.6 * len(b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The OTHER shipped two-stage family (voxel_rcnn_dbscan / oyster_single_train.yaml: AnchorHeadSingleV2 proposals -> VoxelRCNNHead):
+# cpd_amd.anchor_engine.AnchorPointEngine as the fused engine's first stage.
+
+def _anchor_model(seed=7):
+    cfg = models.waymo_voxel_rcnn_dbscan_cfg()
+    cfg.BACKBONE_2D.NUM_FILTERS, cfg.BACKBONE_2D.NUM_UPSAMPLE_FILTERS, cfg.BACKBONE_2D.LAYER_NUMS = [64, 128], [128, 128], [2, 2]
+    torch.manual_seed(seed)
+    net = models.VoxelRCNN(cfg, point_cloud_range=[-20.0, -20.0, -2.0, 20.0, 20.0, 4.0]).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.75, 1.25)
+                m.weight.uniform_(0.75, 1.25); m.bias.normal_(0, 0.1)
+        for br in net.dense_head.BRANCHES:                                       # the reference's N(0, 0.001) branch convs leave every anchor at its bias:
+            getattr(net.dense_head, br)[0].weight.normal_(0, (2.0 / (9 * 64)) ** 0.5)   # spread the features ...
+        net.dense_head.conv_cls[3].weight.normal_(0, 0.5)                       # ... and the anchor scores
+        net.dense_head.conv_reg[3].weight.normal_(0, 0.02); net.dense_head.conv_dim[3].weight.normal_(0, 0.02)
+        net.roi_head.cls_layers[-1].weight.normal_(0, 0.3); net.roi_head.cls_layers[-1].bias.normal_(0, 0.3)
+        net.roi_head.reg_layers[-1].weight.normal_(0, 0.01); net.roi_head.reg_layers[-1].bias.zero_()
+    return net
+
+
+def test_anchor_two_stage_engine_matches_the_module_composition(hip):
+    from cpd_amd import spconv as sp
+    sp.install(conv_math="f32")
+    net = _anchor_model()
+    net.dense_head.conv_math = "f32"
+    clouds = _clouds()
+    bd = _batch_dict(net, clouds)
+    bd["points"] = torch.cat([torch.nn.functional.pad(c, (1, 0), value=float(b)) for b, c in enumerate(clouds)])
+    with torch.no_grad():
+        for m in net.module_list[:-1]:
+            bd = m(bd)
+        dense = dict(cls=bd["batch_cls_preds"].clone(), box=bd["batch_box_preds"].clone())
+        bd = net.roi_head(bd)
+        want, _ = net.post_processing(bd)
+    assert bd["rois"].shape[1] == 200
+    ecfg = net.to_engine_config()
+    ecfg.conv_math = "f32"
+    from cpd_amd.anchor_engine import AnchorPointEngine
+    from cpd_amd.two_stage import VoxelRCNNEngine
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    rpn = AnchorPointEngine(ecfg, sd, net.model_cfg.DENSE_HEAD, net.model_cfg.ROI_HEAD.NMS_CONFIG["TEST"])
+    eng = VoxelRCNNEngine(ecfg, net.model_cfg.ROI_HEAD, net.model_cfg.POST_PROCESSING, sd, rpn=rpn)
+    got, it = eng.forward(clouds, return_intermediates=True)
+    assert sum(len(g["pred_boxes"]) for g in got) > 10, "nothing survived: the comparison would be vacuous"
+    # first stage: the anchor head's decoded predictions, anchor for anchor (same occupancy mask, same anchor order)
+    np.testing.assert_allclose(rpn.last_dense["batch_cls_preds"].cpu().numpy(), dense["cls"].cpu().numpy(), atol=2e-4)
+    np.testing.assert_allclose(rpn.last_dense["batch_box_preds"].cpu().numpy(), dense["box"].cpu().numpy(), atol=2e-4, rtol=1e-4)
+    # proposals: 200 per frame out of ~15000 anchors ranked by a score; anchors whose scores differ by less than the two pipelines'
+    # rounding may swap ranks, so the RoI sets are matched by geometry
+    assert it["rois"].shape == bd["rois"].shape
+    for b in range(3):
+        x, y = it["rois"][b].cpu().numpy(), bd["rois"][b].cpu().numpy()
+        d = np.abs(x[:, None, :] - y[None, :, :]).max(-1)
+        assert (d.min(1) <= 1e-3).mean() >= 0.95, float((d.min(1) <= 1e-3).mean())
+    # second stage in isolation: the MODULE head on the engine's own RoIs and levels predicts what the engine predicts
+    bd2 = dict(batch_size=3, rois=it["rois"], roi_labels=it["roi_labels"], roi_scores=it["roi_scores"], has_class_labels=True,
+               multi_scale_3d_features=it["levels"], multi_scale_3d_strides={"x_conv3": 4, "x_conv4": 8})
+    with torch.no_grad():
+        bd2 = net.roi_head(bd2)
+    np.testing.assert_allclose(it["batch_box_preds"].cpu().numpy(), bd2["batch_box_preds"].cpu().numpy(), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(it["batch_cls_preds"].cpu().numpy(), bd2["batch_cls_preds"].cpu().numpy(), atol=2e-4, rtol=1e-4)
+    # post_processing in isolation: exact
+    bd3 = dict(batch_size=3, batch_box_preds=it["batch_box_preds"], batch_cls_preds=it["batch_cls_preds"], cls_preds_normalized=False,
+               has_class_labels=True, roi_labels=it["roi_labels"])
+    iso, _ = net.post_processing(bd3)
+    for b in range(3):
+        assert torch.equal(got[b]["pred_boxes"], iso[b]["pred_boxes"]) and torch.equal(got[b]["pred_labels"], iso[b]["pred_labels"])
+    # end to end: most detections in common
+    for g, w in zip(got, want):
+        x, y = g["pred_boxes"].cpu().numpy(), w["pred_boxes"].cpu().numpy()
+        assert abs(len(x) - len(y)) <= max(3, 0.1 * len(y))
+        if len(x) and len(y):
+            d = np.abs(x[:, None, :] - y[None, :, :]).max(-1).min(1)
+            assert (d <= 2e-3).mean() >= 0.8, float((d <= 2e-3).mean())
+    # ... and through the model's own to_engine() in the default arithmetic
+    eng2 = net.to_engine()
+    assert type(eng2.rpn).__name__ == "AnchorPointEngine"
+    got2 = eng2.forward(clouds)
+    assert all(torch.isfinite(g["pred_boxes"]).all() for g in got2) and sum(len(g["pred_boxes"]) for g in got2) > 10
