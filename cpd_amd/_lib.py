@@ -109,6 +109,7 @@ SIGNATURES = {
     "cpd_group_points_grad": (_I, [_I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_voxel_pool_max": (_I, [_I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "cpd_voxel_pool_max_mlp": (_I, [_I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),
+    "cpd_voxel_pool_max_mlp_ranged": (_I, [_I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP, _VP]),
     "cpd_bn_stats_finalize": (_I, [_VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_bn_finalize": (_I, [_VP, _VP, _I, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_pack_weight_adjoint": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),

@@ -88,14 +88,14 @@ class AnchorPointEngine(CenterPointEngine):
         return rois, scores, labels, [int(v) for v in ns[:batch]]
 
     @torch.no_grad()
-    def forward(self, points_list, return_intermediates=False, proposals=None):
+    def forward(self, points_list, return_intermediates=False, proposals=None, pair_levels=False):
         if isinstance(points_list, torch.Tensor):
             points_list = [points_list]
         if proposals is None:
             raise NotImplementedError("AnchorPointEngine is a first stage: call forward(points, proposals=[...])")
         self._cur_points = points_list
         try:
-            return super().forward(points_list, return_intermediates=False, proposals=proposals)
+            return super().forward(points_list, return_intermediates=False, proposals=proposals, pair_levels=pair_levels)
         finally:
             self._cur_points = None
 

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(256) voxel_pool_max_mlp_kernel(int m, int nsam
                                                                  const int32_t *__restrict__ idx, const float *__restrict__ wpos,
                                                                  const float *__restrict__ bpos, const float *__restrict__ wout,
                                                                  const float *__restrict__ tout, int c2, int relu,
-                                                                 float *__restrict__ out, int out_ld) {
+                                                                 float *__restrict__ out, int out_ld, uint32_t *__restrict__ out_absmax) {
     // thread = (point slot, channel); a block walks CPD_POOL_ITERS x (256 / C) consecutive points. The pooled channels of the block's
     // points go through LDS (a broadcast read per four channels); the thread's column(s) of w_out stay in registers over the walk.
     constexpr int PPB = 256 / C, ITERS = 8;                          // NCOL columns of w_out per thread: c2 <= NCOL * C (the launcher's choice)
@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(256) voxel_pool_max_mlp_kernel(int m, int nsam
         for (int k = 0; k < C; ++k) wcol[q][k] = co < c2 ? wout[k * c2 + co] : 0.f;
     }
     const float w0 = wpos[ch], w1 = wpos[C + ch], w2 = wpos[2 * C + ch], b0 = bpos[ch];
+    uint32_t vmax = 0;
     for (int it = 0; it < ITERS; ++it) {
         const int pt = (blockIdx.x * ITERS + it) * PPB + slot;
         if (blockIdx.x * ITERS * PPB + it * PPB >= m) break;         // (block-uniform)
@@ -402,9 +403,13 @@ __global__ void __launch_bounds__(256) voxel_pool_max_mlp_kernel(int m, int nsam
                 best = b0 > 0.f ? b0 : 0.f;
             } else {
                 const float nx = new_xyz[3 * (size_t)pt], ny = new_xyz[3 * (size_t)pt + 1], nz = new_xyz[3 * (size_t)pt + 2];
+                const int32_t j0 = id[0];
 #pragma unroll 8
                 for (int s = 0; s < nsample; ++s) {                 // (unrolled: the samples' loads in flight together)
                     const int32_t j = id[s];
+                    // the query pre-fills every slot with the first hit (voxel_query_gpu.cu:62-66) and real hits are distinct voxels: a later
+                    // slot equal to slot 0 is that pre-fill -- its value is already in `best` (round 5: a third of the gathers at 16 samples)
+                    if (s > 0 && j == j0) continue;
                     const float dx = xyz[3 * (size_t)j] - nx, dy = xyz[3 * (size_t)j + 1] - ny, dz = xyz[3 * (size_t)j + 2] - nz;
                     const float pos = ((dx * w0 + dy * w1) + dz * w2) + b0;
                     const float v = fin[(size_t)j * fin_ld + ch] + pos;
@@ -429,7 +434,22 @@ __global__ void __launch_bounds__(256) voxel_pool_max_mlp_kernel(int m, int nsam
             }
             acc += tcol[q];
             if (relu) acc = acc > 0.f ? acc : 0.f;
-            if (live && co < c2) out[(size_t)pt * out_ld + co] = acc;
+            if (live && co < c2) {
+                out[(size_t)pt * out_ld + co] = acc;
+                const uint32_t vb = __float_as_uint(acc) & 0x7fffffffu;
+                vmax = vb > vmax ? vb : vmax;
+            }
+        }
+    }
+    if (out_absmax) {                                                // the range block of the rows written (cpd_gather_conv's `in_absmax` downstream)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)vmax, o);
+            vmax = t > vmax ? t : vmax;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t *slot = out_absmax + (blockIdx.x & (CPD_ABSMAX_SLOTS - 1)) * CPD_ABSMAX_STRIDE;
+            if (vmax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, vmax);
         }
     }
 }
@@ -951,10 +971,10 @@ extern "C" int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, i
     return cpd_check_launch();
 }
 
-extern "C" int cpd_voxel_pool_max_mlp(int m, int c, int nsample, const float *features_in, int features_ld, const float *xyz,
-                                      const float *new_xyz, const int32_t *idx, const float *w_pos, const float *b_pos,
-                                      const float *w_out, const float *t_out, int c_out, int relu, float *out, int out_ld,
-                                      cpd_stream_t st) {
+static int voxel_pool_max_mlp_impl(int m, int c, int nsample, const float *features_in, int features_ld, const float *xyz,
+                                   const float *new_xyz, const int32_t *idx, const float *w_pos, const float *b_pos,
+                                   const float *w_out, const float *t_out, int c_out, int relu, float *out, int out_ld,
+                                   uint32_t *out_absmax, cpd_stream_t st) {
     if (m < 0 || c <= 0 || nsample <= 0 || c_out <= 0 || features_ld < c || out_ld < c_out || !w_pos || !b_pos || !w_out || !t_out ||
         (m > 0 && (!features_in || !xyz || !new_xyz || !idx || !out)))
         return CPD_ERR_ARG;
@@ -963,11 +983,25 @@ extern "C" int cpd_voxel_pool_max_mlp(int m, int c, int nsample, const float *fe
     const dim3 grid((unsigned)cpd_div_up((long long)m, 8 * (256 / c)));     // ITERS x points per pass
     cpd_launch_log_note("voxel_pool_max_mlp_kernel");
 #define CPD_POOL_MLP(C, N) voxel_pool_max_mlp_kernel<C, N><<<grid, 256, 0, cpd_s(st)>>>(m, nsample, features_in, features_ld, xyz, new_xyz, idx, w_pos, \
-                                                                                         b_pos, w_out, t_out, c_out, relu, out, out_ld)
+                                                                                         b_pos, w_out, t_out, c_out, relu, out, out_ld, out_absmax)
     if (c_out <= c) { if (c == 16) CPD_POOL_MLP(16, 1); else if (c == 32) CPD_POOL_MLP(32, 1); else CPD_POOL_MLP(64, 1); }
     else { if (c == 16) CPD_POOL_MLP(16, 2); else if (c == 32) CPD_POOL_MLP(32, 2); else CPD_POOL_MLP(64, 2); }
 #undef CPD_POOL_MLP
     return cpd_check_launch();
+}
+extern "C" int cpd_voxel_pool_max_mlp(int m, int c, int nsample, const float *features_in, int features_ld, const float *xyz,
+                                      const float *new_xyz, const int32_t *idx, const float *w_pos, const float *b_pos,
+                                      const float *w_out, const float *t_out, int c_out, int relu, float *out, int out_ld,
+                                      cpd_stream_t st) {
+    return voxel_pool_max_mlp_impl(m, c, nsample, features_in, features_ld, xyz, new_xyz, idx, w_pos, b_pos, w_out, t_out, c_out, relu, out, out_ld,
+                                   nullptr, st);
+}
+extern "C" int cpd_voxel_pool_max_mlp_ranged(int m, int c, int nsample, const float *features_in, int features_ld, const float *xyz,
+                                             const float *new_xyz, const int32_t *idx, const float *w_pos, const float *b_pos,
+                                             const float *w_out, const float *t_out, int c_out, int relu, float *out, int out_ld,
+                                             uint32_t *out_absmax, cpd_stream_t st) {
+    return voxel_pool_max_mlp_impl(m, c, nsample, features_in, features_ld, xyz, new_xyz, idx, w_pos, b_pos, w_out, t_out, c_out, relu, out, out_ld,
+                                   out_absmax, st);
 }
 
 extern "C" int cpd_voxel_query_index_grid(int m, int batch, int r1, int r2, int r3, int nsample, float radius, int z_range,

@@ -429,7 +429,16 @@ class CenterPointEngine:
         pairs16 = pairs and self.cfg.pair_rows_level1
         x = self._conv(L["conv_input"], feats, nbr, coords.shape[0], out_pairs=pairs16)
         x = self._blocks(L["conv1"], x, nbr, pairs=pairs16)
-        levels = {"x_conv1": (ops.pairs_to_rows(x) if pairs16 and want("x_conv1") else x, coords, shape)}
+        raw = getattr(self, "_export_pair_levels", False)     # exported levels stay fp16-pair rows, tagged `_cpd_pairs` (the RoI pooling's first GEMM reads them as they are)
+
+        def export(t, is_pairs, name):
+            if not (is_pairs and want(name)):
+                return t
+            if raw and t.shape[1] % 32 == 0:
+                t._cpd_pairs = True
+                return t
+            return ops.pairs_to_rows(t)
+        levels = {"x_conv1": (export(x, pairs16, "x_conv1"), coords, shape)}
         self.level_indexes["x_conv1"] = index
         coords_c = coords_c0               # the list the next level's output set is marked from: canonical order wherever one exists
         pairs_in = pairs16                 # (what conv2.down reads)
@@ -465,7 +474,7 @@ class CenterPointEngine:
             x = self._blocks(L[stage], x, nbr, pairs=pairs_out)
             pairs_in = pairs_out
             coords, coords_c, index, shape = out_idx, out_c, out_index, out_shape
-            levels["x_conv%d" % i] = (ops.pairs_to_rows(x) if pairs_in and want("x_conv%d" % i) else x, coords, shape)
+            levels["x_conv%d" % i] = (export(x, pairs_in, "x_conv%d" % i), coords, shape)
             self.level_indexes["x_conv%d" % i] = index
         k, s, pd = _DOWN["conv_out"]
         out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
@@ -625,8 +634,10 @@ class CenterPointEngine:
 
     # ------------------------------------------------------------------ whole frame(s)
     @torch.no_grad()
-    def forward(self, points_list, return_intermediates=False, proposals=None):
+    def forward(self, points_list, return_intermediates=False, proposals=None, pair_levels=False):
         """points_list: list of [N_i, C] device tensors (one per frame of the batch).
+        pair_levels (with proposals): the exported levels of >= 32 channels are left as fp16-pair rows (tensor attribute `_cpd_pairs`)
+        when the step ran on pair rows -- what roi_pool's first GEMM takes directly; default fp32 rows.
         proposals = a collection of level names: the first stage of a two-stage detector -- returns
         (boxes [B, cap, 7], scores, labels i64 (1-based), per-frame counts (host list), levels) with the named levels' features
         exported as fp32 rows and their site indexes in self.level_indexes; nothing but the counts leaves the device."""
@@ -689,6 +700,7 @@ class CenterPointEngine:
         self._rb_scaled = self._guard_left > 0
         self._range_high = False
         fd, fh, fw = self._final_shape()
+        self._export_pair_levels = bool(pair_levels) and proposals is not None
         while True:
             dp = (not self._rb_scaled) and self.dense_pairs_ok(batch, fh, fw)
             levels, (x, out_idx, out_shape) = self.backbone3d(feats, coords, batch, index=index0, canonical0=canonical0,

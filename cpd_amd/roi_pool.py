@@ -202,7 +202,7 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         return torch.cat(outs, dim=1)
 
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices=None,
-                index=None, grid=None, out=None):
+                index=None, grid=None, out=None, out_block=None):
         """`index` / `grid` / `out` (beyond the reference's arguments): the level's ops.SiteIndex instead of the dense volume, its
         cell_geometry(...) when xyz = get_voxel_centers of that level (eval: the query then computes the centres), and (eval) the
         [M, sum C2] block to write -- may be a column slice of wider rows."""
@@ -210,9 +210,13 @@ class NeighborVoxelSAModuleMSG(nn.Module):
             self._packed = None
             return self._forward_train(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index)
         with torch.no_grad():
-            return self._forward_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid, out)
+            return self._forward_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid, out,
+                                      out_block)
 
-    def _forward_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid=None, out=None):
+    def _forward_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, new_coords, features, voxel2point_indices, index, grid=None, out=None,
+                      out_block=None):
+        """`out_block` (eval): an absmax block (ops.absmax_blocks) the pooling kernels raise to max |out| of what they write -- the range
+        block of the pooled rows for a split-fp16 consumer (cpd_voxel_pool_max_mlp_ranged)"""
         if self._packed is None:
             self._pack()
         new_coords = new_coords[:, [0, 3, 2, 1]].contiguous()                 # (b,x,y,z) -> (b,z,y,x), l.84
@@ -223,7 +227,11 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         assert out.shape == (m, width) and out.stride(1) == 1
         col = 0
         for k, pk in enumerate(self._packed):
-            fin = ops.gather_conv(features, pk["c0"], pk["w_in"], None, 1, n, pk["c1"], pk["s_in"], pk["t_in"], None, False)
+            if getattr(features, "_cpd_pairs", False):     # fp16-pair rows straight from the engine's sparse level: the split-fp16 row-wave GEMM
+                fin = ops.gather_conv(features, pk["c0"], pk["w_in"], None, 1, n, pk["c1"], pk["s_in"], pk["t_in"], None, False, math="f16x2",
+                                      in_pairs=True)
+            else:
+                fin = ops.gather_conv(features, pk["c0"], pk["w_in"], None, 1, n, pk["c1"], pk["s_in"], pk["t_in"], None, False)
             idx = torch.zeros((m, self.nsamples[k]), dtype=torch.int32, device=xyz.device)
             zr, yr, xr = self.query_ranges[k]
             if index is not None:
@@ -234,12 +242,14 @@ class NeighborVoxelSAModuleMSG(nn.Module):
                                             ptr(new_coords), ptr(voxel2point_indices), ptr(idx), stream()), "cpd_voxel_query")
             if pk["c1"] in (16, 32, 64) and pk["c2"] <= 2 * pk["c1"]:        # pooling + output MLP in one kernel, written straight into the scales' shared rows
                 o = out[:, col:col + pk["c2"]]
-                check(lib().cpd_voxel_pool_max_mlp(m, pk["c1"], self.nsamples[k], _p(fin), fin.stride(0), ptr(xyz), ptr(new_xyz), ptr(idx),
-                                                   ptr(pk["w_pos"]), ptr(pk["b_pos"]), ptr(pk["w_out_folded"]), ptr(pk["t_out"]), pk["c2"], 1,
-                                                   _p(o), out.stride(0), stream()), "cpd_voxel_pool_max_mlp")
+                check(lib().cpd_voxel_pool_max_mlp_ranged(m, pk["c1"], self.nsamples[k], _p(fin), fin.stride(0), ptr(xyz), ptr(new_xyz), ptr(idx),
+                                                          ptr(pk["w_pos"]), ptr(pk["b_pos"]), ptr(pk["w_out_folded"]), ptr(pk["t_out"]), pk["c2"], 1,
+                                                          _p(o), out.stride(0), ptr(out_block), stream()), "cpd_voxel_pool_max_mlp")
             else:
                 pooled = voxel_pool_max(fin, xyz, new_xyz, idx, pk["w_pos"], pk["b_pos"])
                 out[:, col:col + pk["c2"]] = ops.gather_conv(pooled, pk["c1"], pk["w_out"], None, 1, m, pk["c2"], pk["s_out"], pk["t_out"], None, True)
+                if out_block is not None:
+                    ops.absmax_rows(out[:, col:col + pk["c2"]], block=out_block)
             col += pk["c2"]
         return out
 
@@ -265,13 +275,16 @@ def get_global_grid_points_of_roi(rois, grid_size):
         dense_idx = _DENSE_IDX[key] = rois.new_ones((grid_size, grid_size, grid_size)).nonzero().float()[None]
     size = rois[:, 3:6]
     local = (dense_idx + 0.5) / grid_size * size.unsqueeze(1) - size.unsqueeze(1) / 2
-    ca, sa = torch.cos(rois[:, 6]), torch.sin(rois[:, 6])
-    zeros, ones = torch.zeros_like(ca), torch.ones_like(ca)
-    rot = torch.stack((ca, sa, zeros, -sa, ca, zeros, zeros, zeros, ones), dim=1).view(-1, 3, 3)   # rotate_points_along_z
-    return torch.matmul(local, rot) + rois[:, None, 0:3], local
+    # rotate_points_along_z (common_utils.py:35-57): local @ [[c, s, 0], [-s, c, 0], [0, 0, 1]] written out -- two products and one sum
+    # per coordinate, elementwise on the device. (torch.matmul here was a batched rocBLAS GEMM of 3 x 3 matrices: the one vendor-library
+    # call left on the inference path, round 5)
+    ca, sa = torch.cos(rois[:, 6])[:, None], torch.sin(rois[:, 6])[:, None]
+    lx, ly = local[..., 0], local[..., 1]
+    rotated = torch.stack((lx * ca - ly * sa, lx * sa + ly * ca, local[..., 2]), dim=-1)
+    return rotated + rois[:, None, 0:3], local
 
 
-def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, point_cloud_range, batch_size, indexes=None):
+def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, point_cloud_range, batch_size, indexes=None, out_block=None):
     """VoxelRCNNHead.roi_grid_pool (voxel_rcnn_head.py:186-273). `levels[name]` = (features, indices, shape) as
     returned by CenterPointEngine.backbone3d; `pool_layers[name]` a NeighborVoxelSAModuleMSG; `indexes[name]`
     an optional ops.SiteIndex of that level (otherwise the dense voxel2pinds volume is built).
@@ -299,9 +312,9 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
         index = indexes.get(name) if indexes else None
         v2p = None if index is not None else generate_voxel2pinds(coords, batch_size, shape)
         out = layer(xyz=xyz, xyz_batch_cnt=cnt, new_xyz=grid_xyz.contiguous().view(-1, 3), new_xyz_batch_cnt=new_cnt,
-                    new_coords=cur, features=feats.contiguous(), voxel2point_indices=v2p, index=index,
+                    new_coords=cur, features=feats if feats.is_contiguous() else feats.contiguous(), voxel2point_indices=v2p, index=index,
                     grid=cell_geometry(voxel_size, stride, point_cloud_range) if index is not None else None,
-                    **(dict(out=whole[:, col:col + widths[len(pooled)]]) if fused else {}))
+                    **(dict(out=whole[:, col:col + widths[len(pooled)]], out_block=out_block) if fused else {}))
         if fused:
             col += widths[len(pooled)]
         pooled.append(out if fused else out.view(-1, grid_size ** 3, out.shape[-1]))

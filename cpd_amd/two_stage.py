@@ -63,7 +63,9 @@ class VoxelRCNNEngine:
             points_list = [points_list]
         batch = len(points_list)
         # ---- first stage: proposals (padded device block + host counts) and the pooled levels
-        ob, os_, ol, counts, levels = self.rpn.forward(points_list, proposals=self.sources)
+        # (the pooled levels stay fp16-pair rows when the first stage ran on them: the pooling's first 1 x 1 GEMM takes the stored bits;
+        # intermediates for a caller are fp32)
+        ob, os_, ol, counts, levels = self.rpn.forward(points_list, proposals=self.sources, pair_levels=not return_intermediates)
         n_roi = max(1, max(counts))                                     # reorder_rois_for_refining: at least one (zero) RoI
         cnt = torch.tensor(counts, dtype=torch.int64, device=self.device)
         valid = torch.arange(n_roi, device=self.device)[None, :] < cnt[:, None]
@@ -73,13 +75,14 @@ class VoxelRCNNEngine:
         roi_labels = torch.where(valid, ol[:, :n_roi], ol.new_zeros(())).contiguous()
         # ---- second stage
         lv = {name: levels[name] for name in self.sources}
+        m = self.cfg.conv_math if self.cfg.conv_math == "f16x2" else None     # FC stacks on the split-fp16 tile kernels, range-guarded
+        xb = ops.absmax_blocks(1, self.device)[0] if m else None              # the pooled rows' range block, raised by the pooling kernels themselves
         pooled = roi_pool.roi_grid_pool(rois, lv, self.strides, dict(zip(self.sources, self.head.roi_grid_pool_layers)), self.head.grid_size,
                                         self.cfg.voxel_size, self.cfg.point_cloud_range, batch,
-                                        indexes={name: self.rpn.level_indexes[name] for name in self.sources})
+                                        indexes={name: self.rpn.level_indexes[name] for name in self.sources}, out_block=xb)
         x = pooled.reshape(pooled.shape[0], -1).contiguous()
         fc = self.head._fc
-        m = self.cfg.conv_math if self.cfg.conv_math == "f16x2" else None     # FC stacks on the split-fp16 tile kernels, range-guarded
-        shared, rb = self.head._run(fc["shared_fc_layers"], x, math=m, return_block=True)    # rb: the block the last shared layer's epilogue filled
+        shared, rb = self.head._run(fc["shared_fc_layers"], x, math=m, in_block=xb, return_block=True)    # rb: the block the last shared layer's epilogue filled
         rcnn_cls = self.head._run(fc["cls_layers"], shared, math=m, in_block=rb)
         rcnn_reg = self.head._run(fc["reg_layers"], shared, math=m, in_block=rb)
         cls, boxes = self.head.generate_predicted_boxes(batch, rois, rcnn_cls, rcnn_reg)

@@ -594,6 +594,13 @@ int cpd_voxel_pool_max_mlp(int m, int c, int nsample, const float *features_in, 
                            const float *xyz, const float *new_xyz, const int32_t *idx, const float *w_pos,
                            const float *b_pos, const float *w_out, const float *t_out, int c_out, int relu,
                            float *out, int out_ld, cpd_stream_t stream);
+/* ... and raising `out_absmax` (an absmax block, see cpd_gather_conv_ranged; may be NULL) to the bits of max |out| of the rows this call
+ * writes: the RoI head's 27648-wide pooled rows (voxel_rcnn_head.py:186-273 -> shared_fc_layers, l.694-705) reach the split-fp16 FC
+ * GEMMs with their range block already filled -- no separate pass over 880 MB of pooled features. */
+int cpd_voxel_pool_max_mlp_ranged(int m, int c, int nsample, const float *features_in, int features_ld,
+                                  const float *xyz, const float *new_xyz, const int32_t *idx, const float *w_pos,
+                                  const float *b_pos, const float *w_out, const float *t_out, int c_out, int relu,
+                                  float *out, int out_ld, uint32_t *out_absmax, cpd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dataloader pre-filter on the device.
