@@ -433,11 +433,12 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
         fb = min(B, 16)
         last, kept = [None], {}
 
-        def two_step(i):
-            last[0] = two.forward([clouds[(i * fb + j) % POOL] for j in range(fb)], return_intermediates=True)
-            kept[i] = last[0][0]
+        def two_step(i):                              # the production call: no intermediates (the pooled levels travel as fp16-pair rows)
+            last[0] = two.forward([clouds[(i * fb + j) % POOL] for j in range(fb)])
+            kept[i] = last[0]
         sec = time_steps(two_step, 4, 2)
-        res, it = last[0]
+        res = last[0]
+        _, it = two.forward([clouds[j % POOL] for j in range(fb)], return_intermediates=True)       # (RoI count of the report; untimed)
         # results digest of the two-stage step (VERDICT r4 #2c), taken after the clock stopped: every timed step's final detections,
         # and the first timed step run once more -- the same frames must give bit-identical second-stage detections
         from cpd_amd.digest import step_digest
@@ -481,9 +482,10 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
         last = [None]
 
         def anchor_step(i):
-            last[0] = two.forward([clouds[(i * fb + j) % POOL] for j in range(fb)], return_intermediates=True)
+            last[0] = two.forward([clouds[(i * fb + j) % POOL] for j in range(fb)])
         sec = time_steps(anchor_step, 4, 2)
-        res, it = last[0]
+        res = last[0]
+        _, it = two.forward([clouds[j % POOL] for j in range(fb)], return_intermediates=True)
         out["value_two_stage_anchor"] = {"value": fb / sec, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 4, "frames_per_step": fb,
                                          "rois_per_frame": it["rois"].shape[1], "anchors_per_frame": int(rpn.last_dense["batch_cls_preds"].shape[1]),
                                          "final_boxes_per_frame": sum(len(r["pred_boxes"]) for r in res) / fb,

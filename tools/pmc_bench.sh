@@ -33,7 +33,7 @@ print("cpu_baseline", d.get("cpu_baseline"))
 PY
 # variants quoted in DESIGN.md §5 (one bench line each; no CPU baseline, no roofline pass)
 if [ "${2:-}" = "variants" ]; then
-  for v in "bf16x3:--conv-math bf16x3" "f32:--conv-math f32" "streams1:--streams 1" "streams3:--streams 3" "device_results:--device-results" "1frame:--frames 1 --steps 100 --streams 1" "4frames:--frames 4 --steps 100 --streams 1" "4frames_2streams:--frames 4 --steps 100" "16frames:--frames 16 --steps 48" "canonical_rows:--row-order canonical" "modules:--api modules"; do
+  for v in "bf16x3:--conv-math bf16x3" "f32:--conv-math f32" "streams1:--streams 1" "streams3:--streams 3" "device_results:--device-results" "1frame:--frames 1 --steps 100 --streams 1" "4frames:--frames 4 --steps 100 --streams 1" "4frames_2streams:--frames 4 --steps 100" "16frames:--frames 16 --steps 48" "canonical_rows:--row-order canonical" "fp32_dense_maps:--dense-pairs 0" "modules:--api modules"; do
     python bench.py --no-cpu-baseline --no-roofline --no-extras ${v#*:} > gpurun_out/${tag}_bench_${v%%:*}.json 2>> gpurun_out/${tag}_bench.err
     python -c "import json,sys; d=json.load(open('gpurun_out/${tag}_bench_${v%%:*}.json')); print('${v%%:*}', round(d['value'],1), 'frames/s', round(d['ms_per_step'],2), 'ms/step')"
   done
