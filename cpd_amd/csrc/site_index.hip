@@ -765,7 +765,7 @@ extern "C" int cpd_densify_nhwc(const float *feat, const int32_t *indices, int n
     hipStream_t s = cpd_s(stream);
     Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
     size_t total = (size_t)batch * shape_zyx[0] * shape_zyx[1] * shape_zyx[2] * c;
-    CPD_HIP_TRY(hipMemsetAsync(out, 0, total * sizeof(float), s));
+    if (cpd_zero_fill(out, total * sizeof(float), s)) return CPD_ERR_LAUNCH;      // (a grid-stride loop of 16-byte stores: the memory system's write rate)
     long long threads = (long long)n * (c / 4);
     if (threads > 0) densify_nhwc_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(feat, indices, n, c / 4, g, out);
     return cpd_check_launch();
@@ -777,7 +777,7 @@ extern "C" int cpd_densify_nhwc_cd(const float *feat, const int32_t *indices, in
     hipStream_t s = cpd_s(stream);
     Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
     size_t total = (size_t)batch * shape_zyx[0] * shape_zyx[1] * shape_zyx[2] * c;
-    CPD_HIP_TRY(hipMemsetAsync(out, 0, total * sizeof(float), s));
+    if (cpd_zero_fill(out, total * sizeof(float), s)) return CPD_ERR_LAUNCH;      // (a grid-stride loop of 16-byte stores: the memory system's write rate)
     long long threads = (long long)n * c;
     if (threads > 0) densify_nhwc_cd_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(feat, indices, n, c, g, out);
     return cpd_check_launch();
@@ -789,7 +789,7 @@ extern "C" int cpd_densify_nchw(const float *feat, const int32_t *indices, int n
     hipStream_t s = cpd_s(stream);
     Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
     size_t total = (size_t)batch * shape_zyx[0] * shape_zyx[1] * shape_zyx[2] * c;
-    CPD_HIP_TRY(hipMemsetAsync(out, 0, total * sizeof(float), s));
+    if (cpd_zero_fill(out, total * sizeof(float), s)) return CPD_ERR_LAUNCH;      // (a grid-stride loop of 16-byte stores: the memory system's write rate)
     long long threads = (long long)n * c;
     if (threads > 0) densify_nchw_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(feat, indices, n, c, g, out);
     return cpd_check_launch();
