@@ -71,6 +71,8 @@ SIGNATURES = {
     "cpd_densify_nchw": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_densify_nhwc": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_densify_nhwc_cd": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
+    "cpd_densify_nhwc_rows": (_I, [_VP, _VP, _I, _I, _I, _I3, _VP, _VP]),
+    "cpd_densify_nhwc_clear": (_I, [_VP, _I, _I, _I, _I3, _VP, _VP]),
     "cpd_rulebook_conv2d": (_I, [_I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
     "cpd_center_decode_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cpd_center_decode": (_I, [_VP, _VP, _VP, _VP, _VP, _I, ctypes.c_longlong, _I, _I, _I, _I, _I, _I, _F, _FP, _FP, _FP, _F,

@@ -348,6 +348,16 @@ __global__ void __launch_bounds__(256) densify_nhwc_kernel(const float *__restri
     reinterpret_cast<float4 *>(out)[(pix * g.d + q.y) * c4 + k] = v;
 }
 
+// the same rows set back to zero: the second half of a densify into a PERSISTENT pre-zeroed map (cpd_densify_nhwc_rows / _clear)
+__global__ void __launch_bounds__(256) densify_clear_kernel(const int32_t *__restrict__ idx, int n, int c4, Grid g, float *__restrict__ out) {
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int i = (int)(tid / c4), k = (int)(tid % c4);
+    if (i >= n) return;
+    int4 q = reinterpret_cast<const int4 *>(idx)[i];
+    size_t pix = ((size_t)q.x * g.h + q.z) * g.w + q.w;
+    reinterpret_cast<float4 *>(out)[(pix * g.d + q.y) * c4 + k] = float4{0.f, 0.f, 0.f, 0.f};
+}
+
 // channels-last pixels with the REFERENCE's channel order c*D + z (what view(N, C*D, H, W) of spconv's dense() gives): lanes run over
 // the channels of a site, so a wave writes D-strided floats of one pixel
 __global__ void __launch_bounds__(256) densify_nhwc_cd_kernel(const float *__restrict__ feat, const int32_t *__restrict__ idx,
@@ -768,6 +778,27 @@ extern "C" int cpd_densify_nhwc(const float *feat, const int32_t *indices, int n
     if (cpd_zero_fill(out, total * sizeof(float), s)) return CPD_ERR_LAUNCH;      // (a grid-stride loop of 16-byte stores: the memory system's write rate)
     long long threads = (long long)n * (c / 4);
     if (threads > 0) densify_nhwc_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(feat, indices, n, c / 4, g, out);
+    return cpd_check_launch();
+}
+
+// cpd_densify_nhwc without the clear: `out` is a caller-owned map that IS all zero (a persistent buffer); the occupied rows are
+// scattered into it, and cpd_densify_nhwc_clear(indices ...) -- queued after the map's last reader -- puts the zeros back by writing the
+// same rows: 2 x (sites x C) floats moved instead of the whole (B, H, W, D * C) map (12 % occupied at the stride-8 level of a Waymo frame).
+extern "C" int cpd_densify_nhwc_rows(const float *feat, const int32_t *indices, int n, int c, int batch,
+                                     const int32_t shape_zyx[3], float *out, cpd_stream_t stream) {
+    if (!valid_shape(batch, shape_zyx) || n < 0 || c <= 0 || (c & 3) || !out || (n > 0 && (!feat || !indices)))
+        return CPD_ERR_ARG;
+    Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
+    long long threads = (long long)n * (c / 4);
+    if (threads > 0) densify_nhwc_kernel<<<cpd_div_up(threads, 256), 256, 0, cpd_s(stream)>>>(feat, indices, n, c / 4, g, out);
+    return cpd_check_launch();
+}
+extern "C" int cpd_densify_nhwc_clear(const int32_t *indices, int n, int c, int batch, const int32_t shape_zyx[3], float *out,
+                                      cpd_stream_t stream) {
+    if (!valid_shape(batch, shape_zyx) || n < 0 || c <= 0 || (c & 3) || !out || (n > 0 && !indices)) return CPD_ERR_ARG;
+    Grid g{batch, shape_zyx[0], shape_zyx[1], shape_zyx[2]};
+    long long threads = (long long)n * (c / 4);
+    if (threads > 0) densify_clear_kernel<<<cpd_div_up(threads, 256), 256, 0, cpd_s(stream)>>>(indices, n, c / 4, g, out);
     return cpd_check_launch();
 }
 

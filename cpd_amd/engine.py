@@ -69,6 +69,7 @@ class ModelConfig:
     # staging); the head's output maps are fp32. Only batches large enough for the kernels' big tiles (>= 8 frames at 188 x 188):
     # smaller batches keep fp32 dense maps. Exported tensors (bev_cat, encoded) are decoded to fp32.
     pair_rows_dense: bool = True
+    persistent_dense_map: bool = True      # densify into a persistent pre-zeroed map, re-zero the occupied rows after its reader (ops.DenseMap)
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
     # "bricks" (round 4, measured, NOT the default): rows of the strided levels in 8 x 8 (y, x) brick order of their z-plane,
     # pattern-sorted inside every 128-row tile (ops.order_rows_bricks); with plan_rulebooks their sub-manifold rulebooks are PLANNED
@@ -567,6 +568,9 @@ class CenterPointEngine:
                 raise NotImplementedError("BEV stride pattern outside the shipped configs")
             n_lvl = batch * ho * wo
             x = self._conv(convs[0], x, nbr0, n_lvl, dense=True, **pk)
+            if lvl == 0 and getattr(self, "_dense_map", None) is not None:
+                self._dense_map.clear()                        # the densified map's only reader is queued: its rows go back to zero
+                self._dense_map = None
             nbr_same = T["s1"][0] if (ho, wo) == (h, w) else T["s1_half"][0]
             for cv in convs[1:]:
                 x = self._conv(cv, x, nbr_same, n_lvl, dense=True, **pk)
@@ -708,7 +712,19 @@ class CenterPointEngine:
                                                               pair_rows=self.cfg.pair_rows and not self._rb_scaled, dense_pairs=dp)
             d, h, w = out_shape
             dp = dp and self.encoded_pairs
-            dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
+            # the BEV map: a persistent pre-zeroed buffer per batch shape -- the occupied rows (12 % at this level) are scattered in and,
+            # once its one reader (the first BEV conv) is queued, zeroed again: no 36 MB-per-frame clear (round 5). Callers that keep the
+            # map (return_intermediates) get a fresh tensor
+            dmap = None
+            if self.cfg.persistent_dense_map and not return_intermediates:
+                key = ("dense_map", batch, d, h, w, x.shape[1])
+                dmap = self._bev_cache.get(key)
+                if dmap is None:
+                    dmap = self._bev_cache[key] = ops.DenseMap(batch, out_shape, x.shape[1], self.device)
+                dense = dmap.scatter(x, out_idx).view(batch * h * w, d * x.shape[1])
+            else:
+                dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
+            self._dense_map = dmap
             cat, head = self.bev_and_head(dense, batch, h, w, pairs=dp)
             results = self.decode_and_nms(head, batch, h, w, raw=proposals is not None)
             if results is not None:

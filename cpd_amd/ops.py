@@ -493,6 +493,34 @@ def densify_nhwc(feat, indices, batch, shape_zyx, out=None):
     return out
 
 
+class DenseMap:
+    """A persistent, pre-zeroed (B, H, W, D * C) map for densify_nhwc: `scatter` writes the occupied rows into it, `clear` -- queued after
+    the map's last reader -- zeroes the same rows again (cpd_densify_nhwc_rows / _clear). A map left dirty (an exception between the
+    two) is cleared in full on its next use."""
+
+    def __init__(self, batch, shape_zyx, c, device):
+        self.batch, self.shape, self.c = int(batch), [int(v) for v in shape_zyx], int(c)
+        self.buf = torch.zeros((self.batch, self.shape[1], self.shape[2], self.shape[0] * self.c), dtype=torch.float32, device=device)
+        self.dirty = None                # the index list scattered and not yet cleared
+
+    def scatter(self, feat, indices):
+        if self.dirty is not None:
+            self.buf.zero_()
+        feat, indices = feat.contiguous(), indices.contiguous()
+        assert feat.shape[1] == self.c
+        self.dirty = indices
+        check(lib().cpd_densify_nhwc_rows(ptr(feat), ptr(indices), feat.shape[0], self.c, self.batch, iarr(self.shape), ptr(self.buf), stream()),
+              "cpd_densify_nhwc_rows")
+        return self.buf
+
+    def clear(self):
+        if self.dirty is None:
+            return
+        check(lib().cpd_densify_nhwc_clear(ptr(self.dirty), self.dirty.shape[0], self.c, self.batch, iarr(self.shape), ptr(self.buf), stream()),
+              "cpd_densify_nhwc_clear")
+        self.dirty = None
+
+
 def densify_nhwc_cd(feat, indices, batch, shape_zyx):
     """(B, H, W, C*D) with channel = c*D + z: the reference's (B, C*D, H, W) map in channels_last memory."""
     feat = feat.contiguous()

@@ -292,6 +292,13 @@ int cpd_densify_nchw(const float *feat, const int32_t *indices, int n, int c, in
                      const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
 int cpd_densify_nhwc(const float *feat, const int32_t *indices, int n, int c, int batch,
                      const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
+/* cpd_densify_nhwc into a PERSISTENT map that is all zero on entry (no clear inside), and the call that restores that state afterwards by
+ * zeroing the same rows -- queue it after the map's last reader. SparseConvTensor.dense() semantics as above (height_compression.py:136-138);
+ * moves 2 x sites x c floats instead of the whole map. */
+int cpd_densify_nhwc_rows(const float *feat, const int32_t *indices, int n, int c, int batch,
+                          const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
+int cpd_densify_nhwc_clear(const int32_t *indices, int n, int c, int batch, const int32_t shape_zyx[3], float *out,
+                           cpd_stream_t stream);
 int cpd_densify_nhwc_cd(const float *feat, const int32_t *indices, int n, int c, int batch,
                         const int32_t shape_zyx[3], float *out, cpd_stream_t stream);
 /* Dense-pixel rulebooks for the BEV convs: nbr[kh*kw][ho*wo*batch] for a (kh x kw, stride, pad)
