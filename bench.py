@@ -319,6 +319,55 @@ def pmc_stamp():
         return None
 
 
+class ClockSampler:
+    """rocm-smi (shader clock, socket power) sampled on a background thread while the block runs: the state the chip was in next to
+    `roofline.frac` (the dominant kernel is limited by the socket power cap). Used around the single-stream roofline
+    pass, never around the timed region."""
+
+    def __enter__(self):
+        import threading
+        self.samples, self._stop = [], False
+
+        def run():
+            import subprocess
+            while not self._stop:
+                try:
+                    o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                    d = json.loads(o)
+                    c = d[sorted(d)[0]]
+                    rec = {}
+                    for k, v in c.items():
+                        m = re.search(r"([0-9.]+)", str(v))
+                        if not m:
+                            continue
+                        if "sclk" in k.lower() and "level" not in k.lower():         # ("sclk clock speed:": "(1910Mhz)"; the level key is an index)
+                            rec["sclk_MHz"] = float(m.group(1))
+                        elif "power" in k.lower() and "W" in k:
+                            rec["power_W"] = float(m.group(1))
+                    if rec:
+                        if not self.samples:
+                            rec["raw"] = {k: str(v) for k, v in c.items() if "sclk" in k.lower() or "power" in k.lower()}
+                        self.samples.append(rec)
+                except Exception:
+                    pass
+                time.sleep(0.2)
+        self._t = threading.Thread(target=run, daemon=True)
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._t.join(timeout=6)
+
+    def summary(self):
+        def med(key):
+            v = sorted(x[key] for x in self.samples if key in x)
+            return v[len(v) // 2] if v else None
+        return {"samples": len(self.samples), "sclk_MHz_median": med("sclk_MHz"), "socket_power_W_median": med("power_W"),
+                "first_sample_raw": self.samples[0].get("raw") if self.samples else None,
+                "note": "rocm-smi sampled every ~0.2 s during the single-stream roofline pass (nominal peak clock 2400 MHz, socket cap 1400 W)"}
+
+
 def time_steps(step, steps, warmup):
     """warmup + timed steps of step(i) on the current stream -> seconds per step"""
     for i in range(warmup):
@@ -897,7 +946,7 @@ def main():
         # Second pass, same configuration (same streams / batch), with every cpd_gather_conv launch
         # bracketed by HIP events on its own launch stream.
         n_prof = min(args.steps, 6)
-        with ConvProfiler() as prof:
+        with ConvProfiler() as prof, ClockSampler() as clk:
             run_steps(min(POOL // max(1, B) + 1, 4), 1)   # settle the allocator with the profiler's own temporaries in play
             torch.cuda.synchronize()
             prof.records.clear()
@@ -919,6 +968,7 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "peak_basis": peak_basis, "achieved_over_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "clock_state": clk.summary(),
             "power_cap_note": "peak is the nominal 2.4 GHz figure; measured on this part (tools/mfma_power_probe.hip, tools/power_probe.py): a "
                               "loop of nothing but f16 MFMAs on register operands sustains 0.65 (random data) to 0.74 (half zeros) of it under "
                               "the 1400 W socket cap, and this kernel runs at 1.9-2.1 GHz for the same reason (DESIGN.md 4.1)",
