@@ -107,6 +107,7 @@ SIGNATURES = {
     "cpd_voxel_query": (_I, [_I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_voxel_query_index": (_I, [_I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "cpd_voxel_query_index_grid": (_I, [_I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "cpd_roi_grid_points": (_I, [_VP, _I, _I, _I, _I, _FP, _FP, _I, _I3, ctypes.POINTER(ctypes.c_void_p), _I, _VP, _VP]),
     "cpd_group_points": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_group_points_grad": (_I, [_I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_voxel_pool_max": (_I, [_I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),

@@ -1004,6 +1004,85 @@ extern "C" int cpd_voxel_pool_max_mlp_ranged(int m, int c, int nsample, const fl
                                    out_absmax, st);
 }
 
+// ---- RoI grid points (round 5) ----------------------------------------------------------------------------------------------------
+// VoxelRCNNHead.get_global_grid_points_of_roi + the cell coordinates roi_grid_pool derives from them (voxel_rcnn_head.py:186-273, 365-386;
+// common_utils.rotate_points_along_z, common_utils.py:35-57) in ONE launch, thread = grid point: the reference's (and this library's
+// earlier) torch sequence was ~25 elementwise launches over 1.7 M points per 16-frame step. fp32 operation for operation (this file is
+// compiled with -ffp-contract=off):
+//   local = (i + 0.5) / G * size - size / 2;  x = lx cos - ly sin, y = lx sin + ly cos, z = lz;  + centre
+//   cell  = (point - range_lo) // voxel_size           (torch floor_divide on floats: c10::div_floor_floating)
+//   level = cell // stride -> int32                    (the same floor division, then .int())
+__device__ __forceinline__ float div_floor_f(float a, float b) {      // c10::div_floor_floating<float>
+    if (b == 0.f) return __fdiv_rn(a, b);
+    const float mod = fmodf(a, b);
+    float div = __fdiv_rn(a - mod, b);
+    if (mod != 0.f && ((b < 0.f) != (mod < 0.f))) div -= 1.f;
+    float fl;
+    if (div != 0.f) {
+        fl = floorf(div);
+        if (div - fl > 0.5f) fl += 1.f;
+    } else {
+        fl = copysignf(0.f, __fdiv_rn(a, b));
+    }
+    return fl;
+}
+struct GridLevels {
+    int n;
+    int stride[4];
+    int32_t *coords[4];           // [m][4] = (b, x, y, z) as roi_grid_pool's `cur_coords`, or (b, z, y, x) when bzyx
+};
+__global__ void __launch_bounds__(256) roi_grid_points_kernel(const float *__restrict__ rois, int roi_ld, int n_rois, int rois_per_frame, int g,
+                                                              float vx, float vy, float vz, float lx0, float ly0, float lz0, GridLevels lv,
+                                                              int bzyx, float *__restrict__ grid_xyz) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g3 = g * g * g;
+    if (tid >= (long long)n_rois * g3) return;
+    const int roi = (int)(tid / g3), k = (int)(tid - (long long)roi * g3);
+    const int ix = k / (g * g), iy = (k / g) % g, iz = k % g;              // new_ones(G, G, G).nonzero(): row-major triples
+    const float *r = rois + (size_t)roi * roi_ld;
+    const float gf = (float)g;
+    const float sx = r[3], sy = r[4], sz = r[5];
+    const float lx = __fdiv_rn((float)ix + 0.5f, gf) * sx - __fdiv_rn(sx, 2.f);
+    const float ly = __fdiv_rn((float)iy + 0.5f, gf) * sy - __fdiv_rn(sy, 2.f);
+    const float lz = __fdiv_rn((float)iz + 0.5f, gf) * sz - __fdiv_rn(sz, 2.f);
+    const float ca = cosf(r[6]), sa = sinf(r[6]);
+    const float px = (lx * ca - ly * sa) + r[0];
+    const float py = (lx * sa + ly * ca) + r[1];
+    const float pz = lz + r[2];
+    float *o = grid_xyz + (size_t)tid * 3;
+    o[0] = px; o[1] = py; o[2] = pz;
+    const float cx = div_floor_f(px - lx0, vx), cy = div_floor_f(py - ly0, vy), cz = div_floor_f(pz - lz0, vz);
+    const int b = roi / rois_per_frame;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        if (l >= lv.n) break;
+        const float st = (float)lv.stride[l];
+        const int x = (int)div_floor_f(cx, st), y = (int)div_floor_f(cy, st), z = (int)div_floor_f(cz, st);
+        int4 *dst = reinterpret_cast<int4 *>(lv.coords[l]) + tid;
+        *dst = bzyx ? make_int4(b, z, y, x) : make_int4(b, x, y, z);
+    }
+}
+extern "C" int cpd_roi_grid_points(const float *rois, int roi_ld, int n_rois, int rois_per_frame, int grid_size, const float voxel_size[3],
+                                   const float range_lo[3], int n_levels, const int32_t *strides, int32_t *const *level_coords, int bzyx,
+                                   float *grid_xyz, cpd_stream_t st) {
+    if (n_rois < 0 || roi_ld < 7 || rois_per_frame <= 0 || grid_size <= 0 || grid_size > 32 || !voxel_size || !range_lo || n_levels < 0 ||
+        n_levels > 4 || (n_levels > 0 && (!strides || !level_coords)) || (n_rois > 0 && (!rois || !grid_xyz)))
+        return CPD_ERR_ARG;
+    if (n_rois == 0) return CPD_OK;
+    GridLevels lv;
+    lv.n = n_levels;
+    for (int l = 0; l < 4; ++l) {
+        lv.stride[l] = l < n_levels ? strides[l] : 1;
+        lv.coords[l] = l < n_levels ? level_coords[l] : nullptr;
+        if (l < n_levels && (strides[l] <= 0 || !level_coords[l] || (((uintptr_t)level_coords[l]) & 15))) return CPD_ERR_ARG;
+    }
+    const long long m = (long long)n_rois * grid_size * grid_size * grid_size;
+    cpd_launch_log_note("roi_grid_points_kernel");
+    roi_grid_points_kernel<<<cpd_div_up(m, 256), 256, 0, cpd_s(st)>>>(rois, roi_ld, n_rois, rois_per_frame, grid_size, voxel_size[0], voxel_size[1],
+                                                                       voxel_size[2], range_lo[0], range_lo[1], range_lo[2], lv, bzyx, grid_xyz);
+    return cpd_check_launch();
+}
+
 extern "C" int cpd_voxel_query_index_grid(int m, int batch, int r1, int r2, int r3, int nsample, float radius, int z_range,
                                           int y_range, int x_range, const float *new_xyz, const int32_t *new_coords,
                                           const void *index, int n_sites, const float cell_xyz[3], const float origin_xyz[3],

@@ -284,23 +284,41 @@ def get_global_grid_points_of_roi(rois, grid_size):
     return rotated + rois[:, None, 0:3], local
 
 
+def roi_grid_points(rois, grid_size, voxel_size, point_cloud_range, strides=(), bzyx=False):
+    """(grid_xyz [B*N*G^3, 3], {stride: int32 [B*N*G^3, 4] cell coordinates}) of rois [B, N, 7]: get_global_grid_points_of_roi and
+    roi_grid_pool's `cur_coords` arithmetic (voxel_rcnn_head.py:186-273, 365-386) in one launch (cpd_roi_grid_points). Coordinates
+    come as (b, x, y, z) like the reference's, or (b, z, y, x) with bzyx (what the neighbour queries take)."""
+    assert rois.dim() == 3 and rois.shape[-1] >= 7
+    b, n = rois.shape[0], rois.shape[1]
+    flat = rois.reshape(b * n, rois.shape[-1]).contiguous().float()
+    m = b * n * grid_size ** 3
+    grid_xyz = torch.empty((m, 3), dtype=torch.float32, device=rois.device)
+    strides = [int(v) for v in strides]
+    coords = [torch.empty((m, 4), dtype=torch.int32, device=rois.device) for _ in strides]
+    ptrs = (ctypes.c_void_p * max(1, len(strides)))(*[c.data_ptr() for c in coords])
+    from ._lib import farr
+    check(lib().cpd_roi_grid_points(_p(flat), flat.stride(0), b * n, n, int(grid_size), farr([float(v) for v in voxel_size]),
+                                    farr([float(v) for v in point_cloud_range[0:3]]), len(strides), iarr(strides) if strides else None, ptrs,
+                                    int(bool(bzyx)), _p(grid_xyz), stream()), "cpd_roi_grid_points")
+    return grid_xyz, dict(zip(strides, coords))
+
+
 def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, point_cloud_range, batch_size, indexes=None, out_block=None):
     """VoxelRCNNHead.roi_grid_pool (voxel_rcnn_head.py:186-273). `levels[name]` = (features, indices, shape) as
     returned by CenterPointEngine.backbone3d; `pool_layers[name]` a NeighborVoxelSAModuleMSG; `indexes[name]`
     an optional ops.SiteIndex of that level (otherwise the dense voxel2pinds volume is built).
     Returns (B*N, G^3, sum C)."""
-    grid_xyz, _ = get_global_grid_points_of_roi(rois.clone(), grid_size)
-    grid_xyz = grid_xyz.view(batch_size, -1, 3)
-    gc = torch.cat([(grid_xyz[:, :, 0:1] - point_cloud_range[0]) // voxel_size[0],
-                    (grid_xyz[:, :, 1:2] - point_cloud_range[1]) // voxel_size[1],
-                    (grid_xyz[:, :, 2:3] - point_cloud_range[2]) // voxel_size[2]], dim=-1)
-    bidx = torch.arange(batch_size, device=rois.device, dtype=gc.dtype).view(-1, 1, 1).expand(-1, gc.shape[1], 1)
-    new_cnt = torch.full((batch_size,), gc.shape[1], dtype=torch.int32, device=rois.device)
+    # the grid points and their (b, x, y, z) cells at every pooled level: one launch (round 5; the torch sequence of the reference --
+    # get_global_grid_points_of_roi, three floor divisions, cat, int -- was ~25 launches over B*N*G^3 points)
+    grid_flat, cells = roi_grid_points(rois.reshape(batch_size, -1, rois.shape[-1]), grid_size, voxel_size, point_cloud_range,
+                                       strides=sorted({int(strides[name]) for name in pool_layers}))
+    per_frame = grid_flat.shape[0] // batch_size
+    new_cnt = torch.full((batch_size,), per_frame, dtype=torch.int32, device=rois.device)
     pooled = []
     # eval: the levels' blocks are written side by side into one [M, sum C] tensor by the pooling kernels themselves (no torch.cat)
     fused = not torch.is_grad_enabled() and all(not layer.training for layer in pool_layers.values())
     widths = [sum(int(seq[0].out_channels) for seq in layer.mlps_out) for layer in pool_layers.values()] if fused else []
-    whole = torch.empty((gc.shape[0] * gc.shape[1], sum(widths)), dtype=torch.float32, device=rois.device) if fused else None
+    whole = torch.empty((grid_flat.shape[0], sum(widths)), dtype=torch.float32, device=rois.device) if fused else None
     col = 0
     for name, layer in pool_layers.items():
         feats, coords, shape = levels[name]
@@ -308,10 +326,10 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
         xyz = get_voxel_centers(coords[:, 1:4], stride, voxel_size, point_cloud_range).contiguous()
         # (per-sample row counts: the training branch's grouping needs them; the fused eval path does not -- and bincount reads back)
         cnt = None if fused else torch.bincount(coords[:, 0].long(), minlength=batch_size).int()
-        cur = torch.cat([bidx, gc // stride], dim=-1).int().contiguous().view(-1, 4)
+        cur = cells[int(stride)]
         index = indexes.get(name) if indexes else None
         v2p = None if index is not None else generate_voxel2pinds(coords, batch_size, shape)
-        out = layer(xyz=xyz, xyz_batch_cnt=cnt, new_xyz=grid_xyz.contiguous().view(-1, 3), new_xyz_batch_cnt=new_cnt,
+        out = layer(xyz=xyz, xyz_batch_cnt=cnt, new_xyz=grid_flat, new_xyz_batch_cnt=new_cnt,
                     new_coords=cur, features=feats if feats.is_contiguous() else feats.contiguous(), voxel2point_indices=v2p, index=index,
                     grid=cell_geometry(voxel_size, stride, point_cloud_range) if index is not None else None,
                     **(dict(out=whole[:, col:col + widths[len(pooled)]], out_block=out_block) if fused else {}))

@@ -564,6 +564,15 @@ int cpd_voxel_query_index(int m, int batch, int r1, int r2, int r3, int nsample,
                           int z_range, int y_range, int x_range, const float *new_xyz, const float *xyz,
                           const int32_t *new_coords, const void *index, int use_perm, int n_sites,
                           int32_t *idx, cpd_stream_t stream);
+/* RoI grid points and their cell coordinates in one launch: VoxelRCNNHead.get_global_grid_points_of_roi + the `cur_coords` arithmetic of
+ * roi_grid_pool (cpd/models/roi_heads/voxel_rcnn_head.py:186-273, 365-386; rotate_points_along_z, cpd/utils/common_utils.py:35-57).
+ * rois [n_rois, roi_ld >= 7] (x, y, z, dx, dy, dz, heading), frame of RoI i = i / rois_per_frame. grid_xyz [n_rois * G^3, 3] = the global
+ * grid points (fp32, the reference's operation order); for each of n_levels (<= 4) strides, level_coords[l] [n_rois * G^3, 4] int32 =
+ * (b, x, y, z) with x = ((px - range_lo.x) // voxel_size.x) // stride (torch floor division on floats, then int), or (b, z, y, x) when
+ * bzyx != 0 (the order the neighbour queries take). level_coords pointers must be 16-byte aligned. */
+int cpd_roi_grid_points(const float *rois, int roi_ld, int n_rois, int rois_per_frame, int grid_size, const float voxel_size[3],
+                        const float range_lo[3], int n_levels, const int32_t *strides, int32_t *const *level_coords, int bzyx,
+                        float *grid_xyz, cpd_stream_t stream);
 /* The same query for a VOXEL level, where the reference passes xyz = get_voxel_centers(indices) (common_utils.py:66-82;
  * voxel_rcnn_head.py:236-241): a site's coordinates are (cell + 0.5) * cell_xyz + origin_xyz per axis in fp32, so the kernel evaluates
  * the distance test from the cell coordinates (same operations, same order: identical decisions) and reads nothing per candidate

@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from cpd_amd import ops
+
 pytestmark = pytest.mark.gpu
 
 
@@ -242,3 +244,36 @@ def test_voxel_rcnn_head_eval_forward_matches_reference_module(golden, hip):
     out = head(bd)
     np.testing.assert_allclose(out["batch_cls_preds"].cpu().numpy(), g["batch_cls_preds"], atol=1e-4, rtol=0)
     np.testing.assert_allclose(out["batch_box_preds"].cpu().numpy(), g["batch_box_preds"], atol=2e-4, rtol=1e-5)
+
+
+def test_roi_grid_points_kernel_matches_the_torch_sequence(hip):
+    """cpd_roi_grid_points (one launch) against the reference's torch sequence it replaces -- get_global_grid_points_of_roi, the three
+    float floor divisions, cat, int (voxel_rcnn_head.py:186-273, 365-386): grid points to fp32 rounding (the device cos / sin of torch's
+    build and of this library's may differ in the last bit), cells equal except where a point sits within that rounding of a cell face."""
+    from cpd_amd import roi_pool
+    g = torch.Generator().manual_seed(4)
+    B, N, G = 3, 257, 6
+    rois = torch.cat([torch.rand(B, N, 2, generator=g) * 150.4 - 75.2, torch.rand(B, N, 1, generator=g) * 6 - 2, torch.rand(B, N, 3, generator=g) * 6 + 0.3,
+                      torch.rand(B, N, 1, generator=g) * 7 - 3.5], dim=-1).cuda()
+    rois[1, 100:] = 0                                                          # padded (zero) RoIs
+    vs, pcr = [0.1, 0.1, 0.15], [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    with ops.launch_log() as log:
+        grid, cells = roi_pool.roi_grid_points(rois, G, vs, pcr, strides=[4, 8])
+    assert log.counts == {"roi_grid_points_kernel": 1}
+    want, _ = roi_pool.get_global_grid_points_of_roi(rois.clone(), G)
+    want = want.view(B, -1, 3)
+    np.testing.assert_allclose(grid.view(B, -1, 3).cpu().numpy(), want.cpu().numpy(), atol=2e-5, rtol=0)
+    gc = torch.cat([(want[:, :, 0:1] - pcr[0]) // vs[0], (want[:, :, 1:2] - pcr[1]) // vs[1], (want[:, :, 2:3] - pcr[2]) // vs[2]], dim=-1)
+    bidx = torch.arange(B, device="cuda", dtype=gc.dtype).view(-1, 1, 1).expand(-1, gc.shape[1], 1)
+    for stride in (4, 8):
+        cur = torch.cat([bidx, gc // stride], dim=-1).int().view(-1, 4)
+        same = (cells[stride] == cur).all(dim=1)
+        assert float(same.float().mean()) >= 0.9995, float(same.float().mean())
+        assert int((cells[stride] - cur).abs().max()) <= 1                    # a differing cell is the neighbour across the face
+    # on ITS OWN grid points the kernel's cells are exactly torch's floor divisions (the arithmetic, separated from the cos / sin bits)
+    gc2 = torch.stack([(grid[:, 0] - pcr[0]) // vs[0], (grid[:, 1] - pcr[1]) // vs[1], (grid[:, 2] - pcr[2]) // vs[2]], dim=-1)
+    b2 = torch.arange(B, device="cuda").repeat_interleave(N * G ** 3).view(-1, 1).to(gc2.dtype)
+    for stride in (4, 8):
+        assert torch.equal(cells[stride], torch.cat([b2, gc2 // stride], dim=-1).int())
+    _, zyx = roi_pool.roi_grid_points(rois, G, vs, pcr, strides=[4], bzyx=True)
+    assert torch.equal(zyx[4], cells[4][:, [0, 3, 2, 1]])

@@ -242,8 +242,8 @@ def test_full_size_two_stage_engine_matches_the_oracle_composition(oracle, hip):
     levels = {name: rt["levels"][name] for name in eng.sources}
     final, ot = r2.second_stage(oracle, cfg, mcfg.ROI_HEAD, mcfg.POST_PROCESSING, sd, o_rois, o_labels, levels, 1)
     # ---- which RoIs' neighbour queries decide differently on the engine's grid points (same device function the engine calls)
-    e_grid, _ = roi_pool.get_global_grid_points_of_roi(it["rois"][fi:fi + 1, :n_roi].clone(), eng.head.grid_size)
-    e_grid = e_grid.cpu().numpy()                                                      # (n_roi, 216, 3), engine RoI order
+    e_grid, _ = roi_pool.roi_grid_points(it["rois"][fi:fi + 1, :n_roi].contiguous(), eng.head.grid_size, cfg.voxel_size, cfg.point_cloud_range)
+    e_grid = e_grid.view(n_roi, -1, 3).cpu().numpy()                                   # (n_roi, 216, 3), engine RoI order
     inv = np.empty(n_roi, np.int64); inv[j] = np.arange(n_roi)                        # oracle RoI o <-> engine RoI inv[o]
     o_grid, _ = r2.grid_points(o_rois, eng.head.grid_size)
     assert float(np.abs(e_grid[inv] - o_grid).max()) <= 2e-3                          # the same grid up to the RoIs' rounding
