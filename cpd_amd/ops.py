@@ -590,6 +590,20 @@ def nms_batch(boxes, counts, thresh, normal=False):
     return keep, num
 
 
+def rank_scores(cls, boxes, labels, score_thresh, pre_max, normalized=False):
+    """post_processing's score pipeline for a batch in one launch (cpd_rank_scores): cls [B, R, C] logits (scores when `normalized`),
+    boxes [B, R, 7], labels [B, R] i64 -> (boxes, scores, labels i32) ranked by max-class sigmoid score descending (ties: lower index),
+    rows below the threshold last with score -1, and n_ok [B] i32 = min(rows above the threshold, pre_max)."""
+    b, r, c = cls.shape
+    cls, boxes, labels = cls.contiguous().float(), boxes.contiguous().float(), labels.contiguous().long()
+    ob, osc = torch.empty_like(boxes), torch.empty((b, r), dtype=torch.float32, device=cls.device)
+    ol = torch.empty((b, r), dtype=torch.int32, device=cls.device)
+    n_ok = torch.empty((b,), dtype=torch.int32, device=cls.device)
+    check(lib().cpd_rank_scores(ptr(cls), c, ptr(boxes), ctypes.c_void_p(labels.data_ptr()), b, r, float(score_thresh), int(pre_max),
+                                int(bool(normalized)), ptr(ob), ptr(osc), ptr(ol), ptr(n_ok), stream()), "cpd_rank_scores")
+    return ob, osc, ol, n_ok
+
+
 def select_boxes(boxes, scores, labels, keep, num_keep, post_max, label_offset=0):
     """out[b][k] = in[b][keep[b][k]], k < min(num_keep[b], post_max). Returns padded
     (boxes [batch,post_max,7], scores, labels i64, counts [batch] i32)."""

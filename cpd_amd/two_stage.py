@@ -88,15 +88,11 @@ class VoxelRCNNEngine:
         cls, boxes = self.head.generate_predicted_boxes(batch, rois, rcnn_cls, rcnn_reg)
         # ---- post_processing, all frames at once
         pp, nms = self.post_cfg, self.post_cfg["NMS_CONFIG"]
-        scores = torch.sigmoid(cls).max(dim=-1)[0]                       # (B, R); class-agnostic head: one column
-        ok = scores >= pp["SCORE_THRESH"]
-        ranked, order = torch.sort(torch.where(ok, scores, torch.full_like(scores, -1.0)), dim=1, descending=True, stable=True)   # ties: lower index first
-        n_ok = ok.sum(dim=1).clamp(max=int(nms["NMS_PRE_MAXSIZE"])).to(torch.int32)
-        sboxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 7)).contiguous()
-        slabels = torch.gather(roi_labels, 1, order).to(torch.int32).contiguous()
+        # sigmoid, max over classes, threshold, stable descending rank, gathers: one launch (cpd_rank_scores)
+        sboxes, ranked, slabels, n_ok = ops.rank_scores(cls, boxes, roi_labels, pp["SCORE_THRESH"], int(nms["NMS_PRE_MAXSIZE"]))
         keep, num_keep = ops.nms_batch(sboxes, n_ok, float(nms["NMS_THRESH"]))
         post = min(int(nms["NMS_POST_MAXSIZE"]), n_roi)
-        fb, fs, fl, fn = ops.select_boxes(sboxes, ranked.contiguous(), slabels, keep, num_keep, post, label_offset=0)
+        fb, fs, fl, fn = ops.select_boxes(sboxes, ranked, slabels, keep, num_keep, post, label_offset=0)
         ns = fn.tolist()                                                 # the stage's one read-back
         if self.host_results:
             fb, fs, fl = fb.cpu(), fs.cpu(), fl.cpu()

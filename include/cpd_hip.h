@@ -354,6 +354,15 @@ int cpd_nms_normal(const float *boxes, int n, float thresh, int64_t *keep, int32
 int cpd_nms_batch(const float *boxes, const int32_t *counts, int batch, int capacity, float thresh,
                   int normal, int64_t *keep, int32_t *num_keep, void *workspace,
                   size_t workspace_bytes, cpd_stream_t stream);
+/* The score half of Detector3DTemplate.post_processing (cpd/models/detectors/detector3d_template.py:222-343, MULTI_CLASSES_NMS False) and of
+ * class_agnostic_nms (cpd/models/model_utils/model_nms_utils.py:113-124) for a whole batch in one launch: per frame, score = max over the
+ * n_cls columns of sigmoid(cls) (of cls itself when normalized != 0), rows with score >= score_thresh ranked by score descending (ties: lower
+ * index first -- a stable sort), the others after them with score -1; out_boxes / out_scores / out_labels (int32) = the r rows in that order,
+ * n_ok[b] = min(#rows above the threshold, pre_max): what cpd_nms_batch + cpd_select_boxes take next. cls [batch, r, n_cls], boxes
+ * [batch, r, 7], labels_i64 [batch, r]. r <= 8192, else CPD_ERR_UNSUPPORTED. */
+int cpd_rank_scores(const float *cls, int n_cls, const float *boxes, const void *labels_i64, int batch, int r, float score_thresh,
+                    int pre_max, int normalized, float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *n_ok,
+                    cpd_stream_t stream);
 /* class_agnostic_nms tail (model_nms_utils.py:126-127,134) + the `+1` of center_head.py:301, batched:
  * out[b][k] = in[b][keep[b][k]] for k < out_n[b] = min(num_keep[b], post_max).
  * out_boxes [batch,post_max,7], out_scores [batch,post_max], out_labels [batch,post_max] i64.  */

@@ -380,3 +380,32 @@ def test_anchor_two_stage_engine_matches_the_module_composition(hip):
     assert type(eng2.rpn).__name__ == "AnchorPointEngine"
     got2 = eng2.forward(clouds)
     assert all(torch.isfinite(g["pred_boxes"]).all() for g in got2) and sum(len(g["pred_boxes"]) for g in got2) > 10
+
+
+def test_rank_scores_kernel_matches_the_torch_sequence(hip):
+    """cpd_rank_scores against the torch sequence of post_processing it replaces (sigmoid, max over classes, threshold, stable descending
+    sort, gathers), incl. ties (lower index first), rows below the threshold, NaN logits and the pre-NMS cap."""
+    g = torch.Generator().manual_seed(9)
+    B, R, C = 3, 497, 3
+    cls = (torch.randn(B, R, C, generator=g) * 2).cuda()
+    cls[0, 10] = cls[0, 3]                                   # an exact tie
+    cls[1, 7, :] = float("nan")
+    cls[2, :50] = -9.0                                       # below the threshold after the sigmoid
+    boxes = torch.randn(B, R, 7, generator=g).cuda()
+    labels = torch.randint(1, 4, (B, R), generator=g).cuda()
+    thr, pre = 0.3, 400
+    ob, osc, ol, n_ok = ops.rank_scores(cls, boxes, labels, thr, pre)
+    scores = torch.sigmoid(cls).max(dim=-1)[0]
+    ok = scores >= thr
+    ranked, order = torch.sort(torch.where(ok, scores, torch.full_like(scores, -1.0)), dim=1, descending=True, stable=True)
+    assert n_ok.tolist() == ok.sum(dim=1).clamp(max=pre).tolist()
+    np.testing.assert_allclose(osc.cpu().numpy(), ranked.cpu().numpy(), atol=1e-6, rtol=0)
+    for b in range(B):
+        k = int(ok[b].sum())
+        # (rows the two sigmoids round to scores one ulp apart may swap with a neighbour: compare the ranked prefix as a set first)
+        assert set(map(tuple, ob[b, :k].cpu().numpy().round(5).tolist())) == set(map(tuple, boxes[b][order[b, :k]].cpu().numpy().round(5).tolist()))
+        same = (ob[b, :k] == boxes[b][order[b, :k]]).all(dim=1)
+        assert float(same.float().mean()) >= 0.99
+        assert torch.equal(ol[b, :k][same].long(), labels[b][order[b, :k]][same])
+    i3, i10 = [int((ob[0] == boxes[0, i]).all(dim=1).nonzero()[0]) for i in (3, 10)]
+    assert i10 == i3 + 1                                     # the tie: lower index first
