@@ -272,7 +272,7 @@ struct FrameOffsets {
 // of FrameOffsets, not by 2^31 cells.
 __global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__restrict__ pts, int n, int c, VoxGeom geo,
                                                              long long cells, FrameOffsets fo, int32_t *__restrict__ pkey,
-                                                             uint64_t *bitmap) {
+                                                             uint64_t *bitmap, uint32_t *__restrict__ touched) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = pts + (size_t)i * c;
@@ -289,7 +289,10 @@ __global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__rest
     if (ok) key = (long long)fo.frame_of_lane(i, threadIdx.x & 63) * cells + local;
     // consecutive returns of a beam often share a voxel: the lane after an equal key leaves the bit to its neighbour
     const long long prev = __shfl_up(key, 1);
-    if (ok && ((threadIdx.x & 63) == 0 || prev != key)) atomicOr((unsigned long long *)&bitmap[key >> 6], 1ull << (key & 63));
+    if (ok && ((threadIdx.x & 63) == 0 || prev != key)) {
+        atomicOr((unsigned long long *)&bitmap[key >> 6], 1ull << (key & 63));
+        touched[(key >> 6) / SCAN_TILE] = 1u;                        // (the touched-block scan's mark: any non-zero word, plain store)
+    }
     pkey[i] = local;
 }
 
@@ -364,7 +367,7 @@ __global__ void __launch_bounds__(256) vox_assign_batch_kernel(int n, FrameOffse
 // bitmap = ascending (frame, z, y, x). No first-appearance scan over the points, no rank -> row map: the site index is canonical.
 // Frame f owns the ranks between the prefix at its first cell and at the next frame's.
 __global__ void vox_frames_canonical_kernel(int nf, long long cells, const uint64_t *__restrict__ bitmap, const uint32_t *__restrict__ base,
-                                            const int32_t *__restrict__ total, int32_t *n_voxels) {
+                                            const uint32_t *__restrict__ block_sums, const int32_t *__restrict__ total, int32_t *n_voxels) {
     // lane f: the ranks at the first cells of frames f and f + 1 (0 at frame 0, the total at frame nf) -- all frames' lookups in flight
     // together instead of one dependent pair of loads after the other on a single thread (23 -> ~3 us at 48 frames)
     const int f = threadIdx.x;                        // (nf <= CPD_VOX_MAX_FRAMES = 64 = the block)
@@ -372,6 +375,9 @@ __global__ void vox_frames_canonical_kernel(int nf, long long cells, const uint6
         if (fr <= 0) return 0;
         if (fr >= nf) return *total;
         const long long key = (long long)fr * cells;
+        // (the prefix entries of a scan block without a bit are not written by the touched-block scan: the rank anywhere inside such a
+        // block is the count at its start)
+        if (scan_block_empty(block_sums, key >> 6)) return (int32_t)scan_block_start(block_sums, key >> 6);
         return (int32_t)(base[key >> 6] + __popcll(bitmap[key >> 6] & ((1ull << (key & 63)) - 1ull)));
     };
     if (f < nf) n_voxels[f] = rank_at(f + 1) - rank_at(f);
@@ -699,6 +705,9 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
     }
     if (cpd_zero_fill(w.bitmap, (size_t)w.words * 8, s)) return CPD_ERR_LAUNCH;
     if (cpd_zero_fill(w.counts, (size_t)cap * 4, s)) return CPD_ERR_LAUNCH;
+    // the bitmap's scan visits only the 32 KB blocks that hold a bit (device_scan_touched): its spine starts out zero and the key
+    // kernel marks the blocks it sets bits in
+    CPD_HIP_TRY(hipMemsetAsync(w.bsum_bm, 0, (size_t)scan_num_blocks(w.words) * 4, s));
     const int nb = cpd_div_up(n, 256);
     bool cascade = false;                    // tuning only (CPD_TUNE=1 CPD_VOX_CASCADE=1): round 2's atomicMin cascade, for A/B timing
     if (const char *e = cpd_knob(cpd_tuning(), "CPD_VOX_CASCADE")) cascade = atoi(e) != 0;
@@ -707,13 +716,13 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
         // counts and falls back to the exact path if a frame exceeds it. Point lists by counting sort (above): ppos in w.first's
         // words, the compact list in w.slots' (cap * max_points >= n of them), the segment offsets in the workspace's vid words.
         int32_t *const ppos = w.first, *const order = w.slots, *const offsets = vid_ws;
-        vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap);
-        rc = device_scan(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
+        vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap, w.bsum_bm);
+        rc = device_scan_touched(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
         if (rc) return rc;
         vox_count_kernel<<<nb, 256, 0, s>>>(n, cells, fo, w.pkey, w.bitmap, w.base, w.prank, ppos, w.counts);
         rc = device_scan(n, CountFn{w.counts}, StoreOffsetFn{offsets}, w.bsum_pt, nullptr, -1, s);   // (ranks < occupied cells <= n <= cap)
         if (rc) return rc;
-        vox_frames_canonical_kernel<<<1, 64, 0, s>>>(n_frames, cells, w.bitmap, w.base, w.nocc, n_voxels);
+        vox_frames_canonical_kernel<<<1, 64, 0, s>>>(n_frames, cells, w.bitmap, w.base, w.bsum_bm, w.nocc, n_voxels);
         vox_scatter_kernel<<<nb, 256, 0, s>>>(n, w.prank, ppos, offsets, order);
         const long long threads_c = (long long)cap * c;
         vox_build_kernel<<<cpd_div_up(threads_c, 256), 256, 0, s>>>(points, c, max_points, cap, fo, n_voxels + n_frames, w.pkey, w.counts, offsets,
@@ -723,14 +732,14 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
     if (cpd_fill_bytes(w.first, 0x7f, (size_t)n * 4, s)) return CPD_ERR_LAUNCH;
     if (cpd_fill_bytes(w.slots, 0x7f, (size_t)cap * max_points * 4, s)) return CPD_ERR_LAUNCH;
     CPD_HIP_TRY(hipMemsetAsync(frame_base, 0, (CPD_VOX_MAX_FRAMES + 1) * 4, s));
-    vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap);
-    rc = device_scan(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
+    vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap, w.bsum_bm);
+    rc = device_scan_touched(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
     if (rc) return rc;
     vox_first_batch_kernel<<<nb, 256, 0, s>>>(n, cells, fo, w.pkey, w.bitmap, w.base, w.prank, w.first);
     if (canonical) {
         // rows = ranks: the max_voxels cap (defined on first-appearance order) is NOT applied -- the caller checks the per-frame
         // counts and falls back to the exact path if a frame exceeds it
-        vox_frames_canonical_kernel<<<1, 64, 0, s>>>(n_frames, cells, w.bitmap, w.base, w.nocc, n_voxels);
+        vox_frames_canonical_kernel<<<1, 64, 0, s>>>(n_frames, cells, w.bitmap, w.base, w.bsum_bm, w.nocc, n_voxels);
         vox_assign_canonical_kernel<<<nb, 256, 0, s>>>(n, fo, w.pkey, w.prank, w.first, coords, geo.g[1], geo.g[2]);
         vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, nullptr, w.first, w.slots, w.counts);
     } else {
