@@ -241,7 +241,14 @@ int cpd_gather_conv(const float *in, int in_ld, int n_in, int c_in, const float 
  *                     -- or c_in == 16 (c_out 16 or 32; the wave kernel's K = 16 MFMA form): 16-channel pair rows hold, per group of
  *                     four channels, the four high terms (8 B) then the four low terms (8 B)
  *   CPD_GC_OUT_PAIRS  `out` rows are written as pairs (the sparse kernels' epilogues; c_out % 32 == 0 or c_out == 16, no out_col_group)
- *   CPD_GC_RES_PAIRS  `residual` rows are pairs (c_out % 32 == 0 or c_out == 16) */
+ *   CPD_GC_RES_PAIRS  `residual` rows are pairs (c_out % 32 == 0 or c_out == 16)
+ * Round 5 -- DENSE pair maps (the Conv2d / ConvTranspose2d layers of BaseBEVBackbone and CenterHead, base_bev_backbone.py:31-59,
+ * center_head.py:11-45,73-94, between two split-fp16 layers): CPD_GC_DENSE | CPD_GC_F16X2 | CPD_GC_IN_PAIRS | CPD_GC_OUT_PAIRS on
+ * cpd_gather_conv* runs the 128 x 128 pair tile kernel (strided conv through its pixel table, 1 x 1 GEMM, ConvTranspose(k = s) through
+ * out_row_map / out_col_group with groups of a multiple of 32 columns): c_in % 32 == 0, c_out % 128 == 0, pairs in AND out, no residual,
+ * no in_absmax, < 4 GB of input; on cpd_conv3x3_rows* (below) the window kernel's 128 x 128 and 256 x 64 tiles (pairs in and out) and
+ * its 256 x 16 tile (pairs in, fp32 rows out: c_out <= 16) -- the tiles cpd_conv3x3_rows_tile reports for the problem. Any other
+ * shape: CPD_ERR_UNSUPPORTED (nothing else reads dense pair rows; keep that map fp32). */
 #define CPD_GC_IN_PAIRS 16
 #define CPD_GC_OUT_PAIRS 32
 #define CPD_GC_RES_PAIRS 64
