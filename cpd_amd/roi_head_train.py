@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .autograd_ops import HipConv1d, HipLinear
+from .autograd_ops import HipBatchNorm1d, HipConv1d, HipLinear
 from . import roi_pool as rp
 
 TWO_PI = 2 * np.pi
@@ -255,7 +255,7 @@ def assign_targets(target_layer, batch_dict, ind=""):
 def _fc_stack(pre, widths, dp, final=None, dropout_between=True):
     layers = []
     for k, w in enumerate(widths):
-        layers += [HipLinear(pre, w, bias=False), nn.BatchNorm1d(w), nn.ReLU()]
+        layers += [HipLinear(pre, w, bias=False), HipBatchNorm1d(w), nn.ReLU()]
         pre = w
         if dropout_between and k != len(widths) - 1 and dp > 0:
             layers.append(nn.Dropout(dp))

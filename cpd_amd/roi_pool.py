@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .autograd_ops import HipConv1d, HipLinear
+from .autograd_ops import HipBatchNorm1d, HipBatchNorm2d, HipConv1d, HipLinear, HipPointwiseConv2d
 from ._lib import check, iarr, lib, ptr, stream
 
 
@@ -161,9 +161,10 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         self.query_ranges, self.radii, self.nsamples = query_ranges, radii, nsamples
         self.mlps_in, self.mlps_pos, self.mlps_out = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         for spec in mlps:
-            self.mlps_in.append(nn.Sequential(HipConv1d(spec[0], spec[1], kernel_size=1, bias=False), nn.BatchNorm1d(spec[1])))
-            self.mlps_pos.append(nn.Sequential(nn.Conv2d(3, spec[1], kernel_size=1, bias=False), nn.BatchNorm2d(spec[1])))
-            self.mlps_out.append(nn.Sequential(HipConv1d(spec[1], spec[2], kernel_size=1, bias=False), nn.BatchNorm1d(spec[2]),
+            # (round 5: BatchNorm and the 3 -> C position conv on the C-ABI kernels too -- training runs no torch conv / BatchNorm kernel)
+            self.mlps_in.append(nn.Sequential(HipConv1d(spec[0], spec[1], kernel_size=1, bias=False), HipBatchNorm1d(spec[1])))
+            self.mlps_pos.append(nn.Sequential(HipPointwiseConv2d(3, spec[1], kernel_size=1, bias=False), HipBatchNorm2d(spec[1])))
+            self.mlps_out.append(nn.Sequential(HipConv1d(spec[1], spec[2], kernel_size=1, bias=False), HipBatchNorm1d(spec[2]),
                                                nn.ReLU()))
         for m in self.modules():                                   # init_weights, voxel_pool_modules.py:60-68
             if isinstance(m, (nn.Conv2d, nn.Conv1d)):
@@ -395,7 +396,7 @@ class VoxelRCNNHead(nn.Module):
         def stack(pre, widths, final=None):
             layers = []
             for k, wdt in enumerate(widths):
-                layers += [HipLinear(pre, wdt, bias=False), nn.BatchNorm1d(wdt), nn.ReLU()]
+                layers += [HipLinear(pre, wdt, bias=False), HipBatchNorm1d(wdt), nn.ReLU()]
                 pre = wdt
                 if k != len(widths) - 1 and dp > 0:
                     layers.append(nn.Dropout(dp))

@@ -210,3 +210,38 @@ def test_reference_style_training_loop_matches_float64_reference(oracle, hip):
         worst.append((err / max(2e-3, 3 * err32), err, err32, k))
     worst.sort(reverse=True)
     assert len(used) >= 30 and worst[0][0] <= 1.0, (sorted(used)[:4], worst[:8])
+
+
+def test_hip_batchnorm_and_pointwise_conv_match_torch(hip):
+    """HipBatchNorm1d / 2d and HipPointwiseConv2d (cpd_amd/autograd_ops.py) against the torch modules they subclass, training mode:
+    outputs, running statistics, and the gradients into input, weight and bias (float64 torch as the reference)."""
+    import torch
+    from cpd_amd.autograd_ops import HipBatchNorm1d, HipBatchNorm2d, HipPointwiseConv2d
+    torch.manual_seed(3)
+    for shape, cls, ref_cls in (((4099, 48), HipBatchNorm1d, torch.nn.BatchNorm1d), ((1, 32, 5001), HipBatchNorm1d, torch.nn.BatchNorm1d),
+                                ((2, 24, 37, 16), HipBatchNorm2d, torch.nn.BatchNorm2d)):
+        c = shape[1]
+        x = (torch.randn(*shape) * 2 + 0.5).cuda().requires_grad_(True)
+        m, r = cls(c, eps=1e-3, momentum=0.01).cuda().train(), ref_cls(c, eps=1e-3, momentum=0.01).double().cuda().train()
+        with torch.no_grad():
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(); r.weight.copy_(m.weight.double()); r.bias.copy_(m.bias.double())
+        xr = x.detach().double().requires_grad_(True)
+        y, yr = m(x), r(xr)
+        gy = torch.randn_like(y)
+        y.backward(gy); yr.backward(gy.double())
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), atol=2e-5)
+        np.testing.assert_allclose(m.running_mean.cpu().numpy(), r.running_mean.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(m.running_var.cpu().numpy(), r.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert int(m.num_batches_tracked) == 1
+        for a, b, what in ((x.grad, xr.grad, "dx"), (m.weight.grad, r.weight.grad, "dgamma"), (m.bias.grad, r.bias.grad, "dbeta")):
+            scale = float(b.abs().max())
+            assert float((a.double() - b).abs().max()) <= 2e-5 * max(scale, 1.0), (shape, what)
+    conv, ref = HipPointwiseConv2d(3, 32, kernel_size=1, bias=False).cuda(), torch.nn.Conv2d(3, 32, kernel_size=1, bias=False).double().cuda()
+    with torch.no_grad():
+        ref.weight.copy_(conv.weight.double())
+    x = torch.randn(1, 3, 700, 16).cuda()
+    y, yr = conv(x), ref(x.double())
+    gy = torch.randn_like(y)
+    y.backward(gy); yr.backward(gy.double())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)

@@ -62,6 +62,15 @@ def test_proto_head_training_step_matches_reference(golden, hip):
     n_fc = sum(isinstance(m, HipLinear) for m in head.modules())
     n_c1 = sum(isinstance(m, HipConv1d) for m in head.modules())
     assert n_fc >= 12 and n_c1 == 16 and sum(fwd_log.counts.values()) >= n_fc + n_c1, (n_fc, n_c1, fwd_log.counts)
+    # round 5: no torch BatchNorm / Conv2d module is left in the head -- BatchNorm1d / 2d and the 3 -> C position convs are the C-ABI's too
+    from cpd_amd.autograd_ops import HipBatchNorm1d, HipBatchNorm2d, HipPointwiseConv2d
+    for m in head.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            assert isinstance(m, (HipBatchNorm1d, HipBatchNorm2d)), type(m)
+        if isinstance(m, torch.nn.Conv2d):
+            assert isinstance(m, HipPointwiseConv2d), type(m)
+    assert sum(isinstance(m, HipPointwiseConv2d) for m in head.modules()) == 8
+    assert all(int(m.num_batches_tracked) == 1 for m in head.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
     t0, t1 = head.forward_ret_dict["targets_dict0"], head.forward_ret_dict["targets_dict1"]
     # sampling and targets
     np.testing.assert_allclose(t0["rois"].cpu().numpy(), g["t_rois"], rtol=0, atol=1e-6)
