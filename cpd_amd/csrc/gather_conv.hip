@@ -1620,7 +1620,7 @@ __device__ __forceinline__ void window_conv_pairs_body(const GcParams &p) {
 }
 // pair rows in; pair rows out (64- / 128-column tiles) or fp32 rows out (the 16-column head tile)
 template <int BN, int BM = 128>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN >= 64 ? 3 : 4, BN >= 64 ? 3 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BN == 128 || BM == 256) && BN >= 64 ? 3 : 4, (BN == 128 || BM == 256) && BN >= 64 ? 3 : 4)))
 window_conv_f16p_kernel(GcParams p) {
     window_conv_pairs_body<BN, (BN >= 64 && BM == 128) || (BM == 256 && BN < 64) ? 4 : 2, BM>(p);
 }
@@ -1778,7 +1778,7 @@ __device__ __forceinline__ void window_conv_pairs16_body(const GcParams &p) {
     epilogue<MS, 1>(p, acc, row0 + wave * WM, 0, r, g, 1.f);       // fp32 rows out (decode reads them)
 }
 template <int BM>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // (46 KB of LDS: three workgroups per CU)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ? 3 : 4, BM == 256 ? 3 : 4)))      // (256 rows: 46 KB of LDS, three workgroups per CU)
 window_conv_f16p16_kernel(GcParams p) {
     window_conv_pairs16_body<BM>(p);
 }
@@ -3897,7 +3897,7 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
         // (window_conv_f16p_kernel). The batch sizes that take the 128 x 128 / 256 x 64 / 256 x 16 tiles; no residual, no pre-scaling
         const bool pin = (flags & CPD_GC_IN_PAIRS) != 0, pout = (flags & CPD_GC_OUT_PAIRS) != 0;
         if (!pin || (flags & CPD_GC_RES_PAIRS) || residual || in_absmax || math != 2 || (bn >= 64 && !p.epi_lds)) return CPD_ERR_UNSUPPORTED;
-        if (!((bn == 128 && bm == 128) || (bn == 64 && bm == 256) || (bn == 16 && bm == 256))) return CPD_ERR_UNSUPPORTED;
+        if (!((bn == 128 && bm == 128) || (bn == 64 && (bm == 256 || bm == 128)) || (bn == 16 && (bm == 256 || bm == 128)))) return CPD_ERR_UNSUPPORTED;
         if (pout != (bn >= 64)) return CPD_ERR_UNSUPPORTED;
         p.in_pairs = 1; p.out_pairs = pout ? 1 : 0;
         char nm[96];
@@ -3907,7 +3907,9 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
         const size_t wts = bn >= 64 ? 2 * 2 * (size_t)bn * 64 : 2 * (size_t)bn * 64;
         const size_t ldsp = win + wts > tile ? win + wts : tile;
         if (bn == 128) hipLaunchKernelGGL((window_conv_f16p_kernel<128, 128>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);
-        else if (bn == 64) hipLaunchKernelGGL((window_conv_f16p_kernel<64, 256>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);
+        else if (bn == 64 && bm == 256) hipLaunchKernelGGL((window_conv_f16p_kernel<64, 256>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);
+        else if (bn == 64) hipLaunchKernelGGL((window_conv_f16p_kernel<64, 128>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);      // (4 ... 7-frame batches)
+        else if (bm == 128) hipLaunchKernelGGL((window_conv_f16p16_kernel<128>), dim3(p.items), dim3(256), win + 2 * 3 * 2 * 4 * 16 * 16, cpd_s(stream), p);
         else {
             // the 16-column head tile: stage groups of three taps, next group's rows and weights a whole group ahead (window_conv_pairs16_body)
             int grouped = 1;

@@ -66,8 +66,8 @@ class ModelConfig:
     pair_rows_level1: bool = True          # ... and level 1 (16 channels: K = 16 MFMA form of the wave kernel) as well
     # ... and the DENSE half (round 5): conv_out writes pair rows, densify copies them, every BEV / head map between two split-fp16 layers
     # is a pair-row map (window_conv_f16p_kernel / tile_conv_f16p_kernel take the stored bits as MFMA fragments: no split in the
-    # staging); the head's output maps are fp32. Only batches large enough for the kernels' big tiles (>= 8 frames at 188 x 188):
-    # smaller batches keep fp32 dense maps. Exported tensors (bev_cat, encoded) are decoded to fp32.
+    # staging); the head's output maps are fp32. Only batches whose layers all take a window tile the pair kernels exist for (>= 2
+    # frames at 188 x 188; engine.dense_pairs_ok): smaller batches keep fp32 dense maps. Exported tensors (bev_cat, encoded) are fp32.
     pair_rows_dense: bool = True
     persistent_dense_map: bool = True      # densify into a persistent pre-zeroed map, re-zero the occupied rows after its reader (ops.DenseMap)
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
@@ -526,7 +526,7 @@ class CenterPointEngine:
                 cur_h, cur_w = (cur_h + 2 - 3) // 2 + 1, (cur_w + 2 - 3) // 2 + 1
                 ok = ok and convs[0].c_out % 128 == 0 and convs[0].c_in % 32 == 0
             for cv in (convs if stride == 1 else convs[1:]):
-                ok = ok and ops.conv3x3_rows_tile(batch, cur_h, cur_w, cv.c_in, cv.c_out) == (128, 128)
+                ok = ok and ops.conv3x3_rows_tile(batch, cur_h, cur_w, cv.c_in, cv.c_out) in ((128, 128), (128, 64))
             ok = ok and de.c_out % 128 == 0 and c_up % 32 == 0
             widest = max(widest, max(cv.c_out for cv in convs))
         c_cat = sum(cfg.bev_num_upsample_filters)
@@ -537,9 +537,9 @@ class CenterPointEngine:
         return bool(ok)
 
     def _head_pairs_ok(self, batch, h, w, c_cat):
-        return (ops.conv3x3_rows_tile(batch, h, w, c_cat, self.shared.c_out) == (256, 64) and
-                ops.conv3x3_rows_tile(batch, h, w, self.head1.c_in, self.head1.c_out) == (256, 64) and
-                ops.conv3x3_rows_tile(batch, h, w, self.head2.c_in, self.head2.c_out) == (256, 16))
+        return (ops.conv3x3_rows_tile(batch, h, w, c_cat, self.shared.c_out) in ((256, 64), (128, 64)) and
+                ops.conv3x3_rows_tile(batch, h, w, self.head1.c_in, self.head1.c_out) in ((256, 64), (128, 64)) and
+                ops.conv3x3_rows_tile(batch, h, w, self.head2.c_in, self.head2.c_out) in ((256, 16), (128, 16)))
 
     def bev_and_head(self, dense_rows, batch, h, w, pairs=False):
         """BaseBEVBackbone.forward (base_bev_backbone.py:85-122) + CenterHead convs

@@ -503,8 +503,11 @@ def test_fp16_pair_rows_between_sparse_layers_do_not_change_the_result(hip):
             outs.append(eng.forward(clouds, return_intermediates=True))
         logs.append(log.counts)
         assert eng.range_reruns == 0
-    pair_launches = sum(v for k, v in logs[0].items() if "f16p" in k)
+    pair_launches = sum(v for k, v in logs[0].items() if k.startswith("rowwave_conv_f16p"))
     assert pair_launches == 15, logs[0]            # 4 + 5 + 5 + conv_out: the layers that read levels 2-4 (conv2.down reads 16 fp32 channels)
+    # round 5: at three frames the dense half runs on pair maps too (window / tile pair kernels; the head's output tile writes fp32)
+    dense_pair = sum(v for k, v in logs[0].items() if k.startswith(("window_conv_f16p", "tile_conv_f16p")))
+    assert dense_pair == 17 and outs[0][1]["dense_pairs"], logs[0]       # 6 + 6 block convs, 2 deblocks, shared conv, the two head launches
     assert not any("f16p" in k for k in logs[1]), logs[1]
     assert not any(k.startswith(("rowwave_conv_f16_kernel", "rowwave_conv_f16e_kernel")) for k in logs[0]), logs[0]
     (ra, ia), (rb, ib) = outs
