@@ -1999,6 +1999,9 @@ tile_conv_f16p_kernel(GcParams p) {
 #ifndef CPD_RW_BOTH_MIN
 #define CPD_RW_BOTH_MIN 128      // narrowest column tile that does it (64: 0.1171 -> 0.1162, bench equal: not worth a second variant)
 #endif
+#ifndef CPD_RW_NT
+#define CPD_RW_NT 0          // bit 0: output stores of the LDS epilogue non-temporal, bit 1: residual loads, bit 2: rulebook columns (round 5 experiment:
+#endif                       // the streams that are read / written once should not evict the gathered rows -- 13.5 reads each -- from the XCD's 4 MB L2)
 #ifndef CPD_RW_GLW
 #define CPD_RW_GLW 0         // 1 (diagnostic builds): the fp16-pair row-wave kernels' weight stages direct-to-LDS, as the window kernels do.
 #endif                       // Measured and NOT kept (round 4, 48 frames, same box): <32,2> 1012 -> 1054 us, <64,2> 1203 -> 1261, <128,2> 1568 -> 1589
@@ -2121,7 +2124,8 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
             for (int u = 0; u < U; ++u) {
                 const int e = u * 64 + lane, t = e / (16 * MS), row = wrow0 + (e & (16 * MS - 1));
                 v[u] = -1;
-                if (e < n_el && ((my_any >> t) & 1u) && row < p.n_out) v[u] = p.nbr ? p.nbr[(size_t)t * p.n_out + row] : row;
+                if (e < n_el && ((my_any >> t) & 1u) && row < p.n_out)
+                    v[u] = p.nbr ? ((CPD_RW_NT & 4) ? __builtin_nontemporal_load(p.nbr + (size_t)t * p.n_out + row) : p.nbr[(size_t)t * p.n_out + row]) : row;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -2370,8 +2374,13 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                         const int row = row0 + pass * EPI_R + urow + (k + kc) * RPI;
                         const int rowc = row < p.n_out ? row : p.n_out - 1;
                         const char *rp = reinterpret_cast<const char *>(p.residual + (size_t)rowc * p.res_ld) + res_off;
-                        ra[kc] = *reinterpret_cast<const f32x4 *>(rp);
-                        rb[kc] = *reinterpret_cast<const f32x4 *>(rp + res_2nd);
+                        if (CPD_RW_NT & 2) {
+                            ra[kc] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rp));
+                            rb[kc] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rp + res_2nd));
+                        } else {
+                            ra[kc] = *reinterpret_cast<const f32x4 *>(rp);
+                            rb[kc] = *reinterpret_cast<const f32x4 *>(rp + res_2nd);
+                        }
                     }
                 }
                 const int lrow = urow + k * RPI;
@@ -2400,8 +2409,13 @@ __device__ __forceinline__ void rowwave_conv_split_body(const GcParams &p, char 
                             h[q] = (_Float16)t[q];
                             l[q] = (_Float16)(t[q] - (float)h[q]);
                         }
-                        *reinterpret_cast<f16x8 *>(orow + pair_off) = h;
-                        *reinterpret_cast<f16x8 *>(orow + pair_off + 64) = l;
+                        if (CPD_RW_NT & 1) {
+                            __builtin_nontemporal_store(h, reinterpret_cast<f16x8 *>(orow + pair_off));
+                            __builtin_nontemporal_store(l, reinterpret_cast<f16x8 *>(orow + pair_off + 64));
+                        } else {
+                            *reinterpret_cast<f16x8 *>(orow + pair_off) = h;
+                            *reinterpret_cast<f16x8 *>(orow + pair_off + 64) = l;
+                        }
                     } else {
                         *reinterpret_cast<f32x4 *>(orow + f32_off) = f32x4{t[0], t[1], t[2], t[3]};
                         *reinterpret_cast<f32x4 *>(orow + f32_off + 16) = f32x4{t[4], t[5], t[6], t[7]};

@@ -53,6 +53,16 @@ __global__ void __launch_bounds__(256) probe(const float *__restrict__ table, co
                 const int r0 = grp[lane >> 3], r1 = grp[8 + (lane >> 3)];
                 a = *reinterpret_cast<const f32x4 *>(table + (size_t)r0 * 32 + q * 4);
                 b = *reinterpret_cast<const f32x4 *>(table + (size_t)r1 * 32 + q * 4);
+            } else if (SHAPE == 5) {                            // line-shaped gather DIRECT TO LDS (global_load_lds_dwordx4): no VGPR write-back
+                extern __shared__ __attribute__((aligned(16))) char lds[];
+                const int q = lane & 7;
+                const int r0 = grp[lane >> 3], r1 = grp[8 + (lane >> 3)];
+                char *base = lds + (threadIdx.x >> 6) * 2048;                       // 2 KB per wave: two 1 KB instructions
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(table + (size_t)r0 * 32 + q * 4),
+                                                 (__attribute__((address_space(3))) void *)base, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(table + (size_t)r1 * 32 + q * 4),
+                                                 (__attribute__((address_space(3))) void *)(base + 1024), 16, 0, 0);
+                a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a;
             } else {                                            // planar frag: table [8 pieces][n_rows][4 floats]
                 const int r = grp[lane & 15], g = lane >> 4;
                 a = *reinterpret_cast<const f32x4 *>(table + ((size_t)(2 * g) * n_rows + r) * 4);
@@ -60,6 +70,11 @@ __global__ void __launch_bounds__(256) probe(const float *__restrict__ table, co
             }
             acc += a * b;
         }
+    }
+    if (SHAPE == 5) {
+        extern __shared__ __attribute__((aligned(16))) char lds[];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc[0] += *reinterpret_cast<const float *>(lds + (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 2048);
     }
     if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[threadIdx.x] = acc[0];
 }
@@ -76,9 +91,9 @@ int main(int argc, char **argv) {
     const int cus = prop.multiProcessorCount;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char *names[] = {"frag (16 rows x 4 pieces per instr)", "quad (64 B contiguous per quad)", "line (128 B per 8 lanes)", "quad + lane transpose to frag",
-                           "planar frag"};
+                           "planar frag", "line, direct to LDS (global_load_lds)"};
     // row patterns: random rows | runs of R consecutive rows at random places (what x-runs of a sparse level look like)
-    for (int run : {1, 2, 4, 8, 16}) {
+    for (int run : {1, 4}) {
         std::vector<int32_t> h((size_t)n_groups * 16);
         srand(7);
         for (size_t g = 0; g < (size_t)n_groups; ++g)
@@ -88,8 +103,8 @@ int main(int argc, char **argv) {
                 for (int k = 0; k < run; ++k) h[g * 16 + s + k] = base + k;
             }
         hipMemcpy(rows, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-        for (int wgs_per_cu : {2, 6}) {
-            for (int shape = 0; shape < 5; ++shape) {
+        for (int wgs_per_cu : {2, 6, 8}) {
+            for (int shape = 0; shape < 6; ++shape) {
                 const dim3 grid(cus * wgs_per_cu), block(256);
                 float best = 1e30f;
                 for (int rep = 0; rep < 4; ++rep) {
@@ -99,7 +114,8 @@ int main(int argc, char **argv) {
                         case 1: hipLaunchKernelGGL(probe<1>, grid, block, 0, 0, table, rows, n_groups, n_rows, iters, sink); break;
                         case 2: hipLaunchKernelGGL(probe<2>, grid, block, 0, 0, table, rows, n_groups, n_rows, iters, sink); break;
                         case 3: hipLaunchKernelGGL(probe<3>, grid, block, 0, 0, table, rows, n_groups, n_rows, iters, sink); break;
-                        default: hipLaunchKernelGGL(probe<4>, grid, block, 0, 0, table, rows, n_groups, n_rows, iters, sink); break;
+                        case 4: hipLaunchKernelGGL(probe<4>, grid, block, 0, 0, table, rows, n_groups, n_rows, iters, sink); break;
+                        default: hipLaunchKernelGGL(probe<5>, grid, block, 8192, 0, table, rows, n_groups, n_rows, iters, sink); break;
                     }
                     hipEventRecord(e1, 0); hipEventSynchronize(e1);
                     float ms; hipEventElapsedTime(&ms, e0, e1);
