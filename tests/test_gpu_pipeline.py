@@ -688,3 +688,29 @@ def test_voxel_backbone8x_eval_side_by_side_stages_match_oracle(oracle, hip):
         tr = bb(dict(batch))
     assert tr["multi_scale_3d_features1"]["x_conv1"].features.shape[0] == stages[1][0].shape[0]
     assert list(tr["encoded_spconv_tensor1"].spatial_shape) == [2, 20, 20]
+
+
+def test_persistent_dense_map_leaves_no_rows_behind(hip):
+    """ModelConfig.persistent_dense_map (ops.DenseMap): the BEV map is scattered into a pre-zeroed persistent buffer and its rows are
+    zeroed again after the first BEV conv. Different batches through ONE engine, then the first batch again: bit-identical to its first
+    run and to an engine that clears a fresh map every step; a map left dirty (an exception between scatter and clear) is cleared in full."""
+    from cpd_amd import ops
+    cfg_a, cfg_b = ModelConfig(), ModelConfig(persistent_dense_map=False)
+    sd = init_state_dict(cfg_a, seed=0)
+    ea, eb = CenterPointEngine(cfg_a, sd), CenterPointEngine(cfg_b, sd)
+    batches = [[torch.from_numpy(waymo_cloud(10 * r + k, n_points=50000 + 7000 * k)).cuda() for k in range(2)] for r in range(3)]
+    first = ea.forward(batches[0])
+    assert any(isinstance(v, ops.DenseMap) for v in ea._bev_cache.values())
+    ea.forward(batches[1]); ea.forward(batches[2])
+    again = ea.forward(batches[0])
+    fresh = eb.forward(batches[0])
+    assert not any(isinstance(v, ops.DenseMap) for v in eb._bev_cache.values())
+    for x, y, z in zip(first, again, fresh):
+        for k in ("pred_boxes", "pred_scores", "pred_labels"):
+            assert torch.equal(x[k], y[k]) and torch.equal(x[k], z[k]), k
+    dmap = next(v for v in ea._bev_cache.values() if isinstance(v, ops.DenseMap))
+    assert float(dmap.buf.abs().max()) == 0.0 and dmap.dirty is None          # between steps the map is all zero
+    dmap.buf.fill_(3.0); dmap.dirty = torch.zeros((1, 4), dtype=torch.int32, device="cuda")      # as if a step had died half-way
+    after = ea.forward(batches[0])
+    for x, y in zip(first, after):
+        assert torch.equal(x["pred_boxes"], y["pred_boxes"])
