@@ -37,6 +37,6 @@ if keys:
     for st in ("voxelize+mean_vfe", "rulebook_subm", "rulebook_conv", "densify", "sparse_conv_c<=16"):
         row = []
         for cfg in (a, b):
-            v = [d["hbm_stages"][st]["us_per_frame"] for d in res[cfg] if "hbm_stages" in d]
+            v = [d["hbm_stages"][st]["us_per_frame"] for d in res[cfg] if st in d.get("hbm_stages", {})]
             row.append(sum(v) / len(v) if v else 0.0)
         print("%-44s %12.2f %12.2f  us/frame" % (st, row[0], row[1]))
