@@ -107,6 +107,8 @@ def parse():
                     "(ModelConfig.pair_rows): 1 = levels 2-4, 2 = level 1 as well (pair_rows_level1)")
     ap.add_argument("--dense-pairs", type=int, choices=[0, 1], default=1, help="ModelConfig.pair_rows_dense: fp16-pair BEV / head maps between "
                     "the split-fp16 dense layers (round 5; 0 = fp32 dense maps, the round-4 form: same detections)")
+    ap.add_argument("--index-stream", type=int, choices=[0, 1], default=1, help="ModelConfig.index_side_stream: the strided stages' index chain "
+                    "(output sets, row order, rulebooks) on a second HIP stream, one stage ahead of the convolutions")
     ap.add_argument("--dense-map", type=int, choices=[0, 1], default=1, help="ModelConfig.persistent_dense_map (0: densify into a fresh, fully "
                     "cleared map every step -- the round-4 form)")
     ap.add_argument("--conv-math", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
@@ -820,7 +822,8 @@ def main():
     distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"), torch.device("cuda", local))
 
     cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk, plan_rulebooks=bool(args.plan), plan_tile_rows=args.plan_tile, row_order_level0=bool(args.order_level0), pair_rows=bool(args.pair_rows),
-                      pair_rows_level1=args.pair_rows == 2, pair_rows_dense=bool(args.dense_pairs), persistent_dense_map=bool(args.dense_map))
+                      pair_rows_level1=args.pair_rows == 2, pair_rows_dense=bool(args.dense_pairs), persistent_dense_map=bool(args.dense_map),
+                      index_side_stream=bool(args.index_stream))
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local
     if args.mode == "train":

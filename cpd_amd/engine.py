@@ -88,6 +88,10 @@ class ModelConfig:
     plan_rulebooks: bool = False           # "bricks" only: plan the sub-manifold rulebooks -> the staged row-wave kernel
     row_order_chunk: int = 4096
     row_order_min_rows: int = 65536        # below this a level does not fill the chip either way
+    # the strided stages' index chain (output set, row order, rulebooks) on a second HIP stream, one stage ahead of the convolutions
+    # (engine.backbone3d); batches above `index_side_stream_max_frames` fill the chip with every launch and keep one stream
+    index_side_stream: bool = True
+    index_side_stream_max_frames: int = 1 << 30
 
     @property
     def grid_zyx(self):
@@ -338,6 +342,11 @@ class CenterPointEngine:
     def _final_depth(self):
         return self._final_shape()[0]
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     # ------------------------------------------------------------------ forward pieces
     # Range guard of the f16x2 path. Every conv epilogue raises an absmax block to max |out| (a wave
     # reduction + a rarely issued atomic: free). OPTIMISTIC pass: the layers run their unscaled kernels and only RECORD; the largest
@@ -423,6 +432,19 @@ class CenterPointEngine:
             feats = feats.index_select(0, n2o.long())
             if self.cfg.chunked_rulebooks:
                 canon0 = (coords_c0, o2n, self.cfg.row_order_chunk)
+        # The INDEX CHAIN of the strided stages (output set -> row order -> rulebooks: 6-8 small launches and one count read-back per
+        # stage) depends on site lists only, never on features. With `index_side_stream` it runs on a second HIP stream, one stage ahead
+        # of the convolutions: stage k + 1's tables are built while stage k's convs run, and the count read-backs wait for the side
+        # stream only (the host keeps queueing convs). What it buys is concurrency where a launch does not fill the chip (one frame:
+        # 0.6 of 3.0 ms of kernel time is index work). Same kernels, same results.
+        side = self._side_stream() if (self.cfg.index_side_stream and feats.is_cuda and batch <= self.cfg.index_side_stream_max_frames) else None
+        if side is not None:
+            main = torch.cuda.current_stream(self.device)
+            # side-stream tensors read on `main` (tables, lists, indexes) live until the NEXT step's chain starts, and that start waits
+            # for everything queued on `main`: the caching allocator may hand a freed block to the side stream only after its readers ran
+            side.wait_stream(main)
+            self._index_keep = []
+
         nbr = ops.rulebook_subm(coords, index, canonical=canon0)               # 'subm1' and 'res1' are the same L0 table
         self._range_reset()                                  # (the 5-channel input layer runs on the fp32 pipe: no block for `feats`)
         # level 1 (16 channels): with pair rows its layers run the K = 16 split-fp16 MFMA on 16-channel pair rows (three products of
@@ -443,20 +465,23 @@ class CenterPointEngine:
         self.level_indexes["x_conv1"] = index
         coords_c = coords_c0               # the list the next level's output set is marked from: canonical order wherever one exists
         pairs_in = pairs16                 # (what conv2.down reads)
-        for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
+
+        def tables(stage, coords_c, index, shape):
+            """everything of a strided stage that depends on the site lists only: its output set, row order, both rulebooks"""
             k, s, pd = _DOWN[stage]
             out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
+            if stage == "conv_out":
+                return dict(out_idx=out_idx, out_c=out_idx, out_index=out_index, out_shape=out_shape,
+                            nbr_dn=ops.rulebook_conv(out_idx, index, k, s, pd), nbr=None, pairs_out=False)
             out_c = out_idx
             # "bricks" per level: only where the staged kernel is used (plan_channels: the widths it wins at); other levels keep "taps"
             c_lvl = L[stage + ".down"].c_out
             use_plan = self.cfg.plan_rulebooks and pairs and c_lvl in self.cfg.plan_channels
             bricks = self.cfg.row_order == "bricks" and out_idx.shape[0] >= self.cfg.row_order_min_rows and (use_plan or not self.cfg.plan_rulebooks)
+            canon = None                      # (canonical list, order, chunk) of a chunk-ordered level: its tables are built chunk-wise
             if bricks:
                 out_idx, _, old_to_new = ops.order_rows_bricks(out_c, out_index, brick=self.cfg.row_order_brick, tile_rows=self.cfg.plan_tile_rows)
                 out_index.set_order(old_to_new)
-            canon = None                      # (canonical list, order, chunk) of a chunk-ordered level: its tables are built chunk-wise
-            if bricks:
-                pass
             elif self.cfg.row_order in ("taps", "bricks") and out_idx.shape[0] >= self.cfg.row_order_min_rows:
                 # rows of the level sorted, chunk by chunk, by their neighbour pattern (ops.order_rows_by_taps): the level's
                 # site list in the new order + the rank -> row map installed in its index re-order everything that follows
@@ -467,21 +492,35 @@ class CenterPointEngine:
                     canon = (out_c, old_to_new, self.cfg.row_order_chunk)
             nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd, canonical=canon)
             # (pair rows are read through the row-wave kernel's 4 GB buffer resource: a level that large stays fp32)
-            pairs_out = pairs and out_idx.shape[0] * L[stage + ".down"].c_out * 4 < 0xfffff000
-            x = self._conv(L[stage + ".down"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in, out_pairs=pairs_out)
+            pairs_out = pairs and out_idx.shape[0] * c_lvl * 4 < 0xfffff000
             nbr = ops.rulebook_subm(out_idx, out_index, canonical=canon)
             if bricks and pairs_out and use_plan:
                 ops.rulebook_plan(nbr, self.cfg.plan_tile_rows)  # the level's four SubM convs: the staged row-wave kernel
-            x = self._blocks(L[stage], x, nbr, pairs=pairs_out)
+            return dict(out_idx=out_idx, out_c=out_c, out_index=out_index, out_shape=out_shape, nbr_dn=nbr_dn, nbr=nbr, pairs_out=pairs_out, canon=canon)
+
+        def stage_tables(stage, coords_c, index, shape):
+            if side is None:
+                return tables(stage, coords_c, index, shape)
+            with torch.cuda.stream(side):
+                T = tables(stage, coords_c, index, shape)
+                ev = side.record_event()
+            self._index_keep.append(T)
+            main.wait_event(ev)
+            return T
+
+        for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
+            T = stage_tables(stage, coords_c, index, shape)
+            out_idx, out_c, out_index, out_shape, pairs_out = T["out_idx"], T["out_c"], T["out_index"], T["out_shape"], T["pairs_out"]
+            x = self._conv(L[stage + ".down"], x, T["nbr_dn"], out_idx.shape[0], in_pairs=pairs_in, out_pairs=pairs_out)
+            x = self._blocks(L[stage], x, T["nbr"], pairs=pairs_out)
             pairs_in = pairs_out
             coords, coords_c, index, shape = out_idx, out_c, out_index, out_shape
             levels["x_conv%d" % i] = (export(x, pairs_in, "x_conv%d" % i), coords, shape)
             self.level_indexes["x_conv%d" % i] = index
-        k, s, pd = _DOWN["conv_out"]
-        out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
-        nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
+        T = stage_tables("conv_out", coords_c, index, shape)
+        out_idx, out_index, out_shape = T["out_idx"], T["out_index"], T["out_shape"]
         # (dense_pairs: the stride-8 output stays in pair rows -- densify is a copy of row bytes, so the BEV map it builds is a pair-row map)
-        x = self._conv(L["conv_out"], x, nbr_dn, out_idx.shape[0], in_pairs=pairs_in, out_pairs=bool(dense_pairs) and pairs_in)
+        x = self._conv(L["conv_out"], x, T["nbr_dn"], out_idx.shape[0], in_pairs=pairs_in, out_pairs=bool(dense_pairs) and pairs_in)
         self.encoded_pairs = bool(dense_pairs) and pairs_in
         self._rb_stage = "backbone"                            # the densified map inherits this output's range block
         return levels, (x, out_idx, out_shape)

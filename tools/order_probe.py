@@ -70,8 +70,27 @@ for lvl, (k, s, p, c) in enumerate([([3, 3, 3], [2, 2, 2], [1, 1, 1], 32), ([3, 
             orders["mask-sorted in chunks of %d" % R] = (rank // R) * (1 << 27) + mask
         pop = ((nbr >= 0).long()).sum(0)
         orders["popcount-sorted in chunks of 1024"] = (rank // 1024) * 32 + pop
+    if os.environ.get("ORDER_SET", "") == "band":
+        # round 5: (b, y-band, z, y, x) "band-major" order -- a chunk of 4096 rows is then a band of y-lines through ALL z-planes, so a
+        # row's z-neighbours sit in its own chunk instead of 1.3 chunks away -- then the usual pattern sort inside 4096-row chunks
+        orders = {"canonical (b,z,y,x)": None}
+        mask = ((nbr >= 0).long() << torch.arange(27, device=nbr.device).view(-1, 1)).sum(0)
+        rank = torch.arange(n_out, device=nbr.device)
+        orders["canonical + mask chunks 4096"] = (rank // 4096) * (1 << 27) + mask
+        for band in (8, 16, 32, 64):
+            bkey = (((b_ * ((H + band - 1) // band) + y_ // band) * D + z_) * band + y_ % band) * W + x_
+            brank = torch.empty_like(rank); brank[torch.argsort(bkey, stable=True)] = rank
+            orders["band %d" % band] = bkey
+            for R in (4096, 16384):
+                orders["band %d + mask chunks %d" % (band, R)] = (brank // R) * (1 << 27) + mask
+        orders["LOCAL (synthetic: tap t -> row + t - 13)"] = "local"
     for name, key in orders.items():
-        if key is None:
+        if isinstance(key, str):
+            off = (torch.arange(27, device=nbr.device).view(-1, 1) - 13)
+            nb0 = torch.where(nbr >= 0, (torch.arange(n_out, device=nbr.device).view(1, -1) + off).clamp(0, n_out - 1).to(torch.int32), nbr).contiguous()
+            nb, perm = reorder(o_idx, nb0, (torch.arange(n_out, device=nbr.device) // 4096) * (1 << 27) + ((nbr >= 0).long() << torch.arange(27, device=nbr.device).view(-1, 1)).sum(0))
+            xin = x
+        elif key is None:
             nb, xin = nbr, x
         else:
             nb, perm = reorder(o_idx, nbr, key)
