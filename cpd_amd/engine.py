@@ -8,6 +8,7 @@ SparseBasicBlock residual are folded into the conv epilogues, activations stay c
 HBM, rulebooks are built once per indice_key, and nothing leaves the device until the final boxes.
 Weights come in under the reference's own state_dict names (so a CPD checkpoint loads unchanged).
 """
+import contextlib
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List
@@ -91,6 +92,7 @@ class ModelConfig:
     # the strided stages' index chain (output set, row order, rulebooks) on a second HIP stream, one stage ahead of the convolutions
     # (engine.backbone3d); batches above `index_side_stream_max_frames` fill the chip with every launch and keep one stream
     index_side_stream: bool = True
+    deblock_side_stream: bool = True       # ... and the BEV deblocks that have a level of convolutions between them and the shared conv
     index_side_stream_max_frames: int = 1 << 30
 
     @property
@@ -433,38 +435,18 @@ class CenterPointEngine:
             if self.cfg.chunked_rulebooks:
                 canon0 = (coords_c0, o2n, self.cfg.row_order_chunk)
         # The INDEX CHAIN of the strided stages (output set -> row order -> rulebooks: 6-8 small launches and one count read-back per
-        # stage) depends on site lists only, never on features. With `index_side_stream` it runs on a second HIP stream, one stage ahead
-        # of the convolutions: stage k + 1's tables are built while stage k's convs run, and the count read-backs wait for the side
-        # stream only (the host keeps queueing convs). What it buys is concurrency where a launch does not fill the chip (one frame:
-        # 0.6 of 3.0 ms of kernel time is index work). Same kernels, same results.
+        # stage) depends on site lists only, never on features. With `index_side_stream` it runs on a second HIP stream, a stage ahead
+        # of the convolutions: stage 2's chain is queued before the level-1 convs, stage k + 1's right after stage k's convs; the
+        # count read-backs then wait for that stream only (the host keeps queueing convs), and the index kernels overlap convolutions
+        # that do not fill the chip (one frame: 0.6 of 3.0 ms of kernel time is index work). Same kernels, same results.
         side = self._side_stream() if (self.cfg.index_side_stream and feats.is_cuda and batch <= self.cfg.index_side_stream_max_frames) else None
+        main = torch.cuda.current_stream(self.device) if side is not None else None
         if side is not None:
-            main = torch.cuda.current_stream(self.device)
             # side-stream tensors read on `main` (tables, lists, indexes) live until the NEXT step's chain starts, and that start waits
             # for everything queued on `main`: the caching allocator may hand a freed block to the side stream only after its readers ran
             side.wait_stream(main)
-            self._index_keep = []
-
-        nbr = ops.rulebook_subm(coords, index, canonical=canon0)               # 'subm1' and 'res1' are the same L0 table
-        self._range_reset()                                  # (the 5-channel input layer runs on the fp32 pipe: no block for `feats`)
-        # level 1 (16 channels): with pair rows its layers run the K = 16 split-fp16 MFMA on 16-channel pair rows (three products of
-        # 16 matrix cycles instead of four fp32 MFMAs of 32); the 5-channel input layer stays on the fp32 pipe and writes the first pairs
+        self._index_keep = []
         pairs16 = pairs and self.cfg.pair_rows_level1
-        x = self._conv(L["conv_input"], feats, nbr, coords.shape[0], out_pairs=pairs16)
-        x = self._blocks(L["conv1"], x, nbr, pairs=pairs16)
-        raw = getattr(self, "_export_pair_levels", False)     # exported levels stay fp16-pair rows, tagged `_cpd_pairs` (the RoI pooling's first GEMM reads them as they are)
-
-        def export(t, is_pairs, name):
-            if not (is_pairs and want(name)):
-                return t
-            if raw and t.shape[1] % 32 == 0:
-                t._cpd_pairs = True
-                return t
-            return ops.pairs_to_rows(t)
-        levels = {"x_conv1": (export(x, pairs16, "x_conv1"), coords, shape)}
-        self.level_indexes["x_conv1"] = index
-        coords_c = coords_c0               # the list the next level's output set is marked from: canonical order wherever one exists
-        pairs_in = pairs16                 # (what conv2.down reads)
 
         def tables(stage, coords_c, index, shape):
             """everything of a strided stage that depends on the site lists only: its output set, row order, both rulebooks"""
@@ -498,27 +480,55 @@ class CenterPointEngine:
                 ops.rulebook_plan(nbr, self.cfg.plan_tile_rows)  # the level's four SubM convs: the staged row-wave kernel
             return dict(out_idx=out_idx, out_c=out_c, out_index=out_index, out_shape=out_shape, nbr_dn=nbr_dn, nbr=nbr, pairs_out=pairs_out, canon=canon)
 
-        def stage_tables(stage, coords_c, index, shape):
+        def stage_tables(stage, prev):
+            """queue a stage's index chain (on the side stream when there is one); prev = the tables of the stage before it"""
             if side is None:
-                return tables(stage, coords_c, index, shape)
-            with torch.cuda.stream(side):
-                T = tables(stage, coords_c, index, shape)
-                ev = side.record_event()
+                T = tables(stage, prev["out_c"], prev["out_index"], prev["out_shape"])
+                T["ev"] = None
+            else:
+                with torch.cuda.stream(side):
+                    T = tables(stage, prev["out_c"], prev["out_index"], prev["out_shape"])
+                    T["ev"] = side.record_event()
             self._index_keep.append(T)
-            main.wait_event(ev)
             return T
 
-        for i, stage in enumerate(["conv2", "conv3", "conv4"], start=2):
-            T = stage_tables(stage, coords_c, index, shape)
-            out_idx, out_c, out_index, out_shape, pairs_out = T["out_idx"], T["out_c"], T["out_index"], T["out_shape"], T["pairs_out"]
+        nbr = ops.rulebook_subm(coords, index, canonical=canon0)               # 'subm1' and 'res1' are the same L0 table
+        stages = ["conv2", "conv3", "conv4", "conv_out"]
+        T_next = stage_tables(stages[0], dict(out_c=coords_c0, out_index=index, out_shape=shape))
+        self._range_reset()                                  # (the 5-channel input layer runs on the fp32 pipe: no block for `feats`)
+        # level 1 (16 channels): with pair rows its layers run the K = 16 split-fp16 MFMA on 16-channel pair rows (three products of
+        # 16 matrix cycles instead of four fp32 MFMAs of 32); the 5-channel input layer stays on the fp32 pipe and writes the first pairs
+        x = self._conv(L["conv_input"], feats, nbr, coords.shape[0], out_pairs=pairs16)
+        x = self._blocks(L["conv1"], x, nbr, pairs=pairs16)
+        raw = getattr(self, "_export_pair_levels", False)     # exported levels stay fp16-pair rows, tagged `_cpd_pairs` (the RoI pooling's first GEMM reads them as they are)
+
+        def export(t, is_pairs, name):
+            if not (is_pairs and want(name)):
+                return t
+            if raw and t.shape[1] % 32 == 0:
+                t._cpd_pairs = True
+                return t
+            return ops.pairs_to_rows(t)
+        levels = {"x_conv1": (export(x, pairs16, "x_conv1"), coords, shape)}
+        self.level_indexes["x_conv1"] = index
+        pairs_in = pairs16                 # (what conv2.down reads)
+        T = T_next
+        for i, stage in enumerate(stages, start=2):
+            if T["ev"] is not None:
+                main.wait_event(T["ev"])
+            out_idx, out_shape = T["out_idx"], T["out_shape"]
+            if stage == "conv_out":
+                break
+            pairs_out = T["pairs_out"]
             x = self._conv(L[stage + ".down"], x, T["nbr_dn"], out_idx.shape[0], in_pairs=pairs_in, out_pairs=pairs_out)
             x = self._blocks(L[stage], x, T["nbr"], pairs=pairs_out)
             pairs_in = pairs_out
-            coords, coords_c, index, shape = out_idx, out_c, out_index, out_shape
-            levels["x_conv%d" % i] = (export(x, pairs_in, "x_conv%d" % i), coords, shape)
-            self.level_indexes["x_conv%d" % i] = index
-        T = stage_tables("conv_out", coords_c, index, shape)
-        out_idx, out_index, out_shape = T["out_idx"], T["out_index"], T["out_shape"]
+            levels["x_conv%d" % i] = (export(x, pairs_in, "x_conv%d" % i), out_idx, out_shape)
+            self.level_indexes["x_conv%d" % i] = T["out_index"]
+            # the next stage's chain is queued AFTER this stage's convs: its count read-back blocks the host, and the main stream
+            # should have its work queued by then (issued before them -- tried -- the main stream idles while the host waits:
+            # one frame 2.93 vs 2.78 ms)
+            T = stage_tables(stages[i - 1], T)
         # (dense_pairs: the stride-8 output stays in pair rows -- densify is a copy of row bytes, so the BEV map it builds is a pair-row map)
         x = self._conv(L["conv_out"], x, T["nbr_dn"], out_idx.shape[0], in_pairs=pairs_in, out_pairs=bool(dense_pairs) and pairs_in)
         self.encoded_pairs = bool(dense_pairs) and pairs_in
@@ -597,6 +607,9 @@ class CenterPointEngine:
         x = dense_rows
         col = 0
         cur_h, cur_w = h, w
+        side = self._side_stream() if (cfg.index_side_stream and cfg.deblock_side_stream and dense_rows.is_cuda) else None
+        main = torch.cuda.current_stream(self.device) if side is not None else None
+        held, joins = [], []
         for lvl, (convs, de, u, c_up) in enumerate(self.bev_levels):
             stride = cfg.bev_layer_strides[lvl]
             if stride == 1:
@@ -616,14 +629,27 @@ class CenterPointEngine:
             cur_h, cur_w = ho, wo
             dst = cat[:, col:col + c_up]
             x_rb = self._rb                                    # the next level goes on from x, not from the deblock's output
-            if u == 1:
-                self._conv(de, x, None, n_lvl, out=dst, dense=True, out_rb=cat_rb, **pk)
-            elif u == 2 and (ho * 2, wo * 2) == (h, w):
-                self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up, dense=True, out_rb=cat_rb, **pk)
-            else:
-                raise NotImplementedError("upsample stride outside the shipped configs")
+            # a deblock that is not the last one has a whole level of convolutions between it and its reader (the shared conv): with the
+            # side stream it runs beside them -- an HBM-bound GEMM (2.6 GB per 48 frames) under matrix-bound window convs
+            aside = side is not None and lvl + 1 < len(self.bev_levels)
+            if aside:
+                ev = main.record_event()
+                held.append(x)                                 # (main-stream tensor read on the side stream: alive until the join below)
+            with (torch.cuda.stream(side) if aside else contextlib.nullcontext()):
+                if aside:
+                    side.wait_event(ev)
+                if u == 1:
+                    self._conv(de, x, None, n_lvl, out=dst, dense=True, out_rb=cat_rb, **pk)
+                elif u == 2 and (ho * 2, wo * 2) == (h, w):
+                    self._conv(de, x, None, n_lvl, out=dst, out_row_map=T["up2"], out_col_group=c_up, dense=True, out_rb=cat_rb, **pk)
+                else:
+                    raise NotImplementedError("upsample stride outside the shipped configs")
+                if aside:
+                    joins.append(side.record_event())
             self._rb = x_rb
             col += c_up
+        for ev in joins:
+            main.wait_event(ev)
         self._rb = cat_rb
         return cat, self._head_rows(cat, batch, h, w, T, pairs)
 

@@ -285,6 +285,12 @@ class CenterPointTrainer:
             self._pack_images |= 1
         if self.device.type == "cuda" and os.environ.get("CPD_TRAIN_SIDE_STREAM", "1") != "0":
             self.store.side = torch.cuda.Stream(device=self.device)
+        # the strided stages' index chain on its own stream, one stage ahead of the forward convolutions (forward(); CPD_TRAIN_INDEX_STREAM=0:
+        # every table first, on the main stream)
+        self.index_side_stream = self.device.type == "cuda" and os.environ.get("CPD_TRAIN_INDEX_STREAM", "1") != "0"
+        self.async_repack = os.environ.get("CPD_TRAIN_ASYNC_REPACK", "0") != "0"            # optimizer_step: repack on the side stream (measured: 9.60 -> 9.93 ms/step -- off)
+        self._repack_ev = None
+        self.early_targets = os.environ.get("CPD_TRAIN_EARLY_TARGETS", "1") != "0"      # forward_backward: targets_early()
         self._voxelizers = []
         self._bev_cache = {}
         self._build(state_dict)
@@ -434,9 +440,12 @@ class CenterPointTrainer:
         while len(self._voxelizers) < len(points_list):
             self._voxelizers.append(ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features,
                                                   cfg.max_points_per_voxel, cfg.max_voxels, device=self.device))
-        outs = [self._voxelizers[b](pts, batch_idx=b, coord_cols=4, want_voxels=False, want_mean=True, sync=False)
+        return [self._voxelizers[b](pts, batch_idx=b, coord_cols=4, want_voxels=False, want_mean=True, sync=False)
                 for b, pts in enumerate(points_list)]
-        ms = torch.cat([o[4] for o in outs]).tolist()
+
+    @staticmethod
+    def _voxelize_finish(outs):
+        ms = torch.cat([o[4] for o in outs]).tolist()          # the read-back of the voxel counts
         feats = torch.cat([o[3][:m] for o, m in zip(outs, ms)])
         coords = torch.cat([o[1][:m] for o, m in zip(outs, ms)])
         return feats, coords
@@ -461,26 +470,63 @@ class CenterPointTrainer:
         cfg, S = self.cfg, self.sparse
         self.store.update_stats = bool(update_stats)
         batch = len(points_list)
-        feats, coords = self._voxelize(points_list)
+        feats, coords = self._voxelize_finish(self._voxelize(points_list))
         shape = cfg.sparse_shape
-        # every rulebook first (they depend on coordinates only): the output-set sizes are the step's host read-backs,
-        # and taking them before any convolution is queued keeps the conv chain free of launch bubbles
+        # The rulebooks depend on coordinates only, and their output-set sizes are the step's host read-backs. Round 5: the index chain of
+        # the strided stages (output set, both rulebooks, the transposed one for the backward pass) runs on its own HIP stream, one
+        # stage ahead of the convolutions -- the read-backs wait for that stream only, so the conv chain is still queued without
+        # bubbles, and the 25 small index launches of a step overlap layers that do not fill the chip at one frame per GPU.
+        # (`index_side_stream=False`: all tables first on the main stream, the round-2 form.) Tables are kept until the next step's
+        # chain starts, and that start waits for everything queued on the main stream (caching-allocator safety across streams).
         index = ops.SiteIndex.build(coords, batch, shape)
-        nbr0 = ops.rulebook_subm(coords, index)
         n0 = coords.shape[0]
-        tables = []
-        for stage in ["conv2", "conv3", "conv4", "conv_out"]:
+        side = None
+        if self.index_side_stream and coords.is_cuda:
+            if getattr(self, "_index_side", None) is None:
+                self._index_side = torch.cuda.Stream(device=self.device)
+            side = self._index_side
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+        self._index_keep = keep = []
+
+        def stage_tables(stage, coords, index, shape):
             k, s, pd = _DOWN[stage]
             out_idx, out_index, out_shape = ops.conv_outset(coords, batch, shape, k, s, pd)
             nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
             nbr_dn_t = train_ops.rulebook_conv_transpose(coords, batch, shape, k, s, pd, out_index)
             nbr_sub = None if stage == "conv_out" else ops.rulebook_subm(out_idx, out_index)
-            tables.append((stage, nbr_dn, nbr_dn_t, nbr_sub, out_idx.shape[0]))
-            coords, index, shape = out_idx, out_index, out_shape
+            rows = None
+            if stage == "conv_out":                          # HeightCompression's row map (used by the backward pass): coordinates only, too
+                (d, h, w), ci = out_shape, out_idx.long()
+                rows = ((ci[:, 0] * h + ci[:, 2]) * w + ci[:, 3]) * d + ci[:, 1]
+            return (stage, nbr_dn, nbr_dn_t, nbr_sub, out_idx.shape[0], out_idx, out_index, out_shape, rows)
+
+        stages = ["conv2", "conv3", "conv4", "conv_out"]
+
+        def queue_tables(stage, coords, index, shape):
+            if side is None:
+                return stage_tables(stage, coords, index, shape), None
+            with torch.cuda.stream(side):
+                t = stage_tables(stage, coords, index, shape)
+                return t, side.record_event()
+
+        nbr0 = ops.rulebook_subm(coords, index)
+        keep.append((coords, index, nbr0))
+        # stage 2's tables go out before the level-1 layers are queued, stage k + 1's after stage k's layers
+        nxt = queue_tables(stages[0], coords, index, shape)
         tape = {"nbr0": nbr0, "stages": []}
+        if getattr(self, "_repack_ev", None) is not None:      # the previous optimiser step's weight images (optimizer_step)
+            torch.cuda.current_stream(self.device).wait_event(self._repack_ev)
+            self._repack_ev = None
         x = S["conv_input"].forward(feats, nbr0, n0)
         x = self._blocks_fwd(S["conv1"], x, nbr0)
-        for stage, nbr_dn, nbr_dn_t, nbr_sub, n_stage in tables:
+        for si, stage in enumerate(stages):
+            t, ev = nxt
+            keep.append(t)
+            coords, index, shape = t[5], t[6], t[7]
+            if ev is not None:
+                main.wait_event(ev)
+            _, nbr_dn, nbr_dn_t, nbr_sub, n_stage = t[:5]
             n_in = x.shape[0]
             if stage == "conv_out":
                 x = S["conv_out"].forward(x, nbr_dn, n_stage)
@@ -488,11 +534,13 @@ class CenterPointTrainer:
                 x = S[stage + ".down"].forward(x, nbr_dn, n_stage)
                 x = self._blocks_fwd(S[stage], x, nbr_sub)
             tape["stages"].append((stage, nbr_sub, nbr_dn_t, n_in))
+            if si + 1 < len(stages):                       # (after this stage's layers are queued: the read-back inside blocks the host)
+                nxt = queue_tables(stages[si + 1], coords, index, shape)
+        dense_rows = t[8]
         d, h, w = shape
         C = x.shape[1]
         dense = ops.densify_nhwc(x, coords, batch, shape).view(batch * h * w, d * C)
-        ci = coords.long()
-        tape["dense_rows"] = ((ci[:, 0] * h + ci[:, 2]) * w + ci[:, 3]) * d + ci[:, 1]
+        tape["dense_rows"] = dense_rows
         tape["dense_shape"] = (batch, h, w, d, C)
 
         T = self._bev_tables(batch, h, w)
@@ -592,14 +640,49 @@ class CenterPointTrainer:
                 red.start(self.dense_offset, self.store.grad.numel())
         self._reduce = red
 
-    def loss(self, rows, gt_boxes):
-        """CenterHead.assign_targets + get_loss (center_head.py:159-250). Returns (loss, d_rows, parts)."""
+    def _targets(self, gt_boxes, hw):
+        cfg = self.cfg
+        return center_loss.assign_targets(gt_boxes, hw, cfg.point_cloud_range, cfg.voxel_size, cfg.num_class, cfg.feature_map_stride,
+                                          num_max_objs=self.num_max_objs)
+
+    def targets_early(self, gt_boxes, after=None):
+        """CenterHead.assign_targets at the START of the step, on the (then idle) weight-gradient stream: the targets depend on the
+        ground-truth boxes only, their ~50 small torch launches and two host read-backs would otherwise sit between the forward and
+        the backward pass on the main stream -- the read-backs there make the host wait for the whole forward, and the backward's
+        launches are then issued in real time instead of a step ahead. Returns what `loss(..., targets=)` takes (None without a
+        side stream). `after`: an event of the main stream the targets are ordered after (default: everything queued on it so far)."""
+        side = self.store.side
+        if side is None or not gt_boxes.is_cuda:
+            return None
+        shape = self.cfg.sparse_shape
+        for stage in ["conv2", "conv3", "conv4", "conv_out"]:
+            k, s, pd = _DOWN[stage]
+            shape = ops.conv_out_shape(shape, k, s, pd)
+        hw = (shape[1], shape[2])
+        main = torch.cuda.current_stream(self.device)
+        gt_boxes.record_stream(side)
+        with torch.cuda.stream(side):
+            if after is not None:                        # (gt_boxes may have been produced on the main stream)
+                side.wait_event(after)
+            else:
+                side.wait_stream(main)
+            tg = self._targets(gt_boxes, hw)
+            ev = side.record_event()
+        for t in tg:
+            t.record_stream(main)
+        return (tg, ev, hw)
+
+    def loss(self, rows, gt_boxes, targets=None):
+        """CenterHead.assign_targets + get_loss (center_head.py:159-250). Returns (loss, d_rows, parts). `targets`: what
+        targets_early(gt_boxes) returned for the same boxes."""
         cfg = self.cfg
         h, w = self.tape["hw"]
         batch = self.tape["batch"]
-        heat, tgt, inds, masks = center_loss.assign_targets(
-            gt_boxes, (h, w), cfg.point_cloud_range, cfg.voxel_size, cfg.num_class, cfg.feature_map_stride,
-            num_max_objs=self.num_max_objs)
+        if targets is not None and targets[2] == (h, w):
+            (heat, tgt, inds, masks), ev, _ = targets
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        else:
+            heat, tgt, inds, masks = self._targets(gt_boxes, (h, w))
         if self.fused_loss:                     # one HIP launch group: loss parts + d(loss)/d(rows), no autograd graph
             losses, d_rows = train_ops.center_loss(rows, batch, h * w, cfg.num_class, self.head_slices["hm"][0], heat, tgt, inds,
                                                    masks, self.code_weights)
@@ -611,8 +694,15 @@ class CenterPointTrainer:
         return loss.detach(), leaf.grad, parts
 
     def forward_backward(self, points_list, gt_boxes):
+        # Target assignment (~50 small torch launches, two host read-backs) runs on the side stream, ordered after the START of the step
+        # only, and is issued once the forward pass is queued: its read-backs then wait for the side stream alone while the main
+        # stream works through the forward, and the host -- a step's worth of launches ahead by then -- queues loss and backward without
+        # ever waiting for the forward to finish. (Issued first, the host is away from the main stream for ~1 ms at the start of every
+        # step: measured, no gain.)
+        ev0 = self.store.mark()
         rows = self.forward(points_list)
-        loss, d_rows, parts = self.loss(rows, gt_boxes)
+        tg = self.targets_early(gt_boxes, after=ev0) if self.early_targets else None
+        loss, d_rows, parts = self.loss(rows, gt_boxes, targets=tg)
         self.backward(d_rows)
         return loss, parts
 
@@ -640,7 +730,17 @@ class CenterPointTrainer:
         self.steps_done += 1
         train_ops.adam_step(st.flat, st.grad, st.m, st.v, lr, b1, self.betas[1], 1e-8, self.weight_decay,
                             self.steps_done, grad_scale=scale, grad_scale_dev=clip)
-        self._repack_all()
+        # the packed weight images are rebuilt on the side stream: the next step's voxelizer / index chain / target assignment do not
+        # read them, its first convolution waits for the event (forward())
+        side = st.side
+        if side is not None and self.async_repack:
+            ev = st.mark()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                self._repack_all()
+                self._repack_ev = side.record_event()
+        else:
+            self._repack_all()
 
     def _repack_all(self):
         if self._pack is None:
