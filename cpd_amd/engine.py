@@ -92,7 +92,11 @@ class ModelConfig:
     # the strided stages' index chain (output set, row order, rulebooks) on a second HIP stream, one stage ahead of the convolutions
     # (engine.backbone3d); batches above `index_side_stream_max_frames` fill the chip with every launch and keep one stream
     index_side_stream: bool = True
-    deblock_side_stream: bool = True       # ... and the BEV deblocks that have a level of convolutions between them and the shared conv
+    # ... and the BEV deblocks that have a level of convolutions between them and the shared conv, for batches of up to
+    # `deblock_side_stream_max_frames` frames (same box: one frame 2.84 -> 2.79 ms, 4 frames +0.6 %; at 48 frames the HBM-bound GEMM
+    # slows the window convs it runs beside by more than it hides: 1240 -> 1227 frames/s)
+    deblock_side_stream: bool = True
+    deblock_side_stream_max_frames: int = 8
     index_side_stream_max_frames: int = 1 << 30
 
     @property
@@ -607,7 +611,8 @@ class CenterPointEngine:
         x = dense_rows
         col = 0
         cur_h, cur_w = h, w
-        side = self._side_stream() if (cfg.index_side_stream and cfg.deblock_side_stream and dense_rows.is_cuda) else None
+        side = self._side_stream() if (cfg.index_side_stream and cfg.deblock_side_stream and dense_rows.is_cuda
+                                       and batch <= cfg.deblock_side_stream_max_frames) else None
         main = torch.cuda.current_stream(self.device) if side is not None else None
         held, joins = [], []
         for lvl, (convs, de, u, c_up) in enumerate(self.bev_levels):
