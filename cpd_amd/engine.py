@@ -15,7 +15,7 @@ from typing import Dict, List
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 @dataclass
@@ -349,9 +349,7 @@ class CenterPointEngine:
         return self._final_shape()[0]
 
     def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
+        return _lib.side_stream(self.device, "index")      # (per current stream: an engine may be driven from several streams over its life)
 
     # ------------------------------------------------------------------ forward pieces
     # Range guard of the f16x2 path. Every conv epilogue raises an absmax block to max |out| (a wave

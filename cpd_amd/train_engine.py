@@ -22,7 +22,7 @@ from typing import Dict, List
 
 import torch
 
-from . import center_loss, dist_utils, ops, train_ops
+from . import _lib, center_loss, dist_utils, ops, train_ops
 from .engine import _DOWN, ModelConfig
 
 
@@ -268,6 +268,7 @@ class CenterPointTrainer:
         self.num_max_objs = num_max_objs
         self.code_weights = code_weights
         self.fused_loss = True
+        self.fused_targets = os.environ.get("CPD_TRAIN_FUSED_TARGETS", "1") != "0"    # cpd_center_targets instead of center_loss.assign_targets
         self.steps_done = 0
         self.store = _Flat()
         self.store.math = cfg.conv_math
@@ -284,7 +285,7 @@ class CenterPointTrainer:
         elif cfg.conv_math != "f32":
             self._pack_images |= 1
         if self.device.type == "cuda" and os.environ.get("CPD_TRAIN_SIDE_STREAM", "1") != "0":
-            self.store.side = torch.cuda.Stream(device=self.device)
+            self.store.side = _lib.side_stream(self.device, "wgrad")
         # the strided stages' index chain on its own stream, one stage ahead of the forward convolutions (forward(); CPD_TRAIN_INDEX_STREAM=0:
         # every table first, on the main stream)
         self.index_side_stream = self.device.type == "cuda" and os.environ.get("CPD_TRAIN_INDEX_STREAM", "1") != "0"
@@ -482,9 +483,7 @@ class CenterPointTrainer:
         n0 = coords.shape[0]
         side = None
         if self.index_side_stream and coords.is_cuda:
-            if getattr(self, "_index_side", None) is None:
-                self._index_side = torch.cuda.Stream(device=self.device)
-            side = self._index_side
+            side = _lib.side_stream(self.device, "index")
             main = torch.cuda.current_stream(self.device)
             side.wait_stream(main)
         self._index_keep = keep = []
@@ -642,8 +641,8 @@ class CenterPointTrainer:
 
     def _targets(self, gt_boxes, hw):
         cfg = self.cfg
-        return center_loss.assign_targets(gt_boxes, hw, cfg.point_cloud_range, cfg.voxel_size, cfg.num_class, cfg.feature_map_stride,
-                                          num_max_objs=self.num_max_objs)
+        fn = train_ops.center_targets if (self.fused_targets and gt_boxes.is_cuda) else center_loss.assign_targets
+        return fn(gt_boxes, hw, cfg.point_cloud_range, cfg.voxel_size, cfg.num_class, cfg.feature_map_stride, num_max_objs=self.num_max_objs)
 
     def targets_early(self, gt_boxes, after=None):
         """CenterHead.assign_targets at the START of the step, on the (then idle) weight-gradient stream: the targets depend on the
@@ -694,14 +693,15 @@ class CenterPointTrainer:
         return loss.detach(), leaf.grad, parts
 
     def forward_backward(self, points_list, gt_boxes):
-        # Target assignment (~50 small torch launches, two host read-backs) runs on the side stream, ordered after the START of the step
+        # Target assignment is three launches of cpd_center_targets inside loss() (`fused_targets`, round 5). The torch restatement
+        # (fused_targets = False: ~50 small torch launches, two host read-backs) runs on the side stream, ordered after the START of the step
         # only, and is issued once the forward pass is queued: its read-backs then wait for the side stream alone while the main
         # stream works through the forward, and the host -- a step's worth of launches ahead by then -- queues loss and backward without
         # ever waiting for the forward to finish. (Issued first, the host is away from the main stream for ~1 ms at the start of every
         # step: measured, no gain.)
         ev0 = self.store.mark()
         rows = self.forward(points_list)
-        tg = self.targets_early(gt_boxes, after=ev0) if self.early_targets else None
+        tg = self.targets_early(gt_boxes, after=ev0) if (self.early_targets and not self.fused_targets) else None
         loss, d_rows, parts = self.loss(rows, gt_boxes, targets=tg)
         self.backward(d_rows)
         return loss, parts

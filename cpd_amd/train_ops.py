@@ -190,6 +190,25 @@ def rulebook_conv2d_transpose(batch, h, w, kh, kw, stride, pad, device):
     return nbr_t
 
 
+def center_targets(gt_boxes, feature_map_size, point_cloud_range, voxel_size, num_classes, feature_map_stride=8, num_max_objs=500,
+                   gaussian_overlap=0.1, min_radius=2):
+    """CenterHead.assign_targets on the device (cpd_center_targets; same arguments and returns as center_loss.assign_targets: heat
+    [B, nc, H, W], target_boxes [B, K, 8], inds [B, K] i64, masks [B, K] i64) -- three launches, no host read-back."""
+    gt = gt_boxes.contiguous().float()
+    B, M, _ = gt.shape
+    H, W = int(feature_map_size[0]), int(feature_map_size[1])
+    K, dev = int(num_max_objs), gt.device
+    heat = torch.empty((B, num_classes, H, W), dtype=torch.float32, device=dev)
+    target = torch.empty((B, K, 8), dtype=torch.float32, device=dev)
+    inds = torch.empty((B, K), dtype=torch.int64, device=dev)
+    masks = torch.empty((B, K), dtype=torch.int64, device=dev)
+    ws = _ws(lib().cpd_center_targets_workspace_bytes(B, K), dev)
+    check(lib().cpd_center_targets(_p(gt) if M > 0 else None, B, M, int(num_classes), H, W, K, farr(point_cloud_range[:2]), farr(voxel_size[:2]),
+                                   int(feature_map_stride), float(gaussian_overlap), int(min_radius), _p(heat), _p(target), _p(inds), _p(masks),
+                                   ptr(ws), ws.numel(), stream()), "cpd_center_targets")
+    return heat, target, inds, masks
+
+
 def center_loss(rows, batch, hw, num_classes, hm_col, heat, target, inds, masks, code_weights, loc_weight=2.0, cls_weight=1.0):
     """Fused CenterHead loss + gradient (cpd_center_loss) on contiguous head rows [batch*hw, ld].
     Returns (losses[3] = total, hm, loc on the device, d_rows [batch*hw, ld])."""

@@ -532,6 +532,19 @@ int cpd_center_loss(const float *rows, int ld, int batch, int hw, int num_classe
                     const int64_t *masks, int k, const float code_weights[8], float loc_weight,
                     float cls_weight, float *d_rows, float *losses, void *ws, size_t ws_bytes,
                     cpd_stream_t stream);
+/* CenterHead.assign_targets / assign_target_of_single_head (center_head.py:103-219) with centernet_utils.gaussian_radius /
+ * draw_gaussian_to_heatmap (centernet_utils.py:9-69) for every sample of a batch, on the device, nothing read back (the reference
+ * walks the boxes on the CPU, l.204). gt_boxes [batch][m][8] = x, y, z, dx, dy, dz, heading, class (1..num_classes; < 1 = padding):
+ * the boxes with class >= 1 are taken in their order (l.180-196), the first k of them (NUM_MAX_OBJS, l.113) give
+ * heat [batch][num_classes][h][w] (gaussians of radius max(min_radius, int(gaussian_radius(dx, dy / pixel, gaussian_overlap))),
+ * max-merged), target [batch][k][8] = (x - int x, y - int y, z, log dx, log dy, log dz, cos, sin), inds [batch][k] = y * w + x of the
+ * centre pixel, masks [batch][k] = 1 -- boxes with dx <= 0 or dy <= 0 and unused slots give zeros. fp32 in the reference's operation
+ * order; the gaussian in double, rounded to float (numpy). Outputs must be 16-byte aligned; m <= 12000. Deterministic. Three launches. */
+size_t cpd_center_targets_workspace_bytes(int batch, int k);
+int cpd_center_targets(const float *gt_boxes, int batch, int m, int num_classes, int h, int w, int k,
+                       const float pc_range_xy[2], const float voxel_xy[2], int feature_map_stride,
+                       double gaussian_overlap, int min_radius, float *heat, float *target, int64_t *inds,
+                       int64_t *masks, void *ws, size_t ws_bytes, cpd_stream_t stream);
 /* AnchorHeadTemplate.get_loss (anchor_head_template.py:179-334) fused with its gradient: sigmoid focal
  * classification loss (alpha 0.25, gamma 2), smooth-L1 (beta 1/9, code_weights) on the residual-coded boxes
  * with the sin-difference heading encoding, cross entropy on the direction bins (dir_preds NULL: no direction

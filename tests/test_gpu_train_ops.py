@@ -492,3 +492,58 @@ def test_scaled_gradient_convs_do_not_hide_nan_or_overflow(hip, monkeypatch):
     dzp = torch.cat([dz, dz.new_zeros(1, c)]).double()
     want = sum(dzp[idx[t]] @ wgt[8 - t].double().T for t in range(9))
     assert (dx.double() - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+
+
+def _targets_args():
+    return ((188, 188), [-75.2, -75.2, -2, 75.2, 75.2, 4], [0.1, 0.1, 0.15], 3)
+
+
+def test_center_targets_kernel_matches_the_reference_golden(hip, golden):
+    """cpd_center_targets against what the reference's own CenterHead.assign_target_of_single_head produced (tests/golden/center_loss.npz,
+    tools of make_golden.py): heat map to float rounding of the CPU's exp / division, masks and indices exactly, targets to 1e-5."""
+    g = golden("center_loss")
+    gt = torch.from_numpy(g["gt_boxes"])[None].cuda()
+    heat, tgt, inds, masks = T.center_targets(gt, *_targets_args(), feature_map_stride=8, num_max_objs=500, gaussian_overlap=0.1, min_radius=2)
+    np.testing.assert_allclose(heat[0].cpu().numpy(), g["heatmap"], atol=1e-6)
+    np.testing.assert_array_equal(masks[0].cpu().numpy(), g["mask"])
+    np.testing.assert_array_equal(inds[0].cpu().numpy(), g["inds"])
+    np.testing.assert_allclose(tgt[0].cpu().numpy(), g["ret_boxes"], atol=1e-5)
+
+
+@pytest.mark.parametrize("batch,m,k", [(1, 40, 500), (3, 120, 50), (2, 0, 16), (2, 7, 500), (1, 700, 500)])
+def test_center_targets_kernel_matches_the_torch_restatement(hip, batch, m, k):
+    """... and against cpd_amd.center_loss.assign_targets (itself pinned on the golden above) on random boxes: padding rows interleaved
+    with boxes, more boxes than slots (the head's boxes are compacted BEFORE the truncation), degenerate boxes (dx <= 0), boxes on the
+    map's border and outside it (patches clipped), several boxes on one pixel and class (max-merge), no box at all, class ids above
+    num_classes (clamped like the restatement), an odd map size (the clear kernel's byte tail). Masks / indices / radii exactly. The
+    kernel divides like the reference on the CPU; torch on the GPU multiplies by the reciprocal of a scalar divisor, which moves a
+    pixel coordinate by up to two ulps (1.5e-5 at 100 pixels: the fractional-offset targets agree to that), so the heat maps are
+    compared to 1e-6 and in their sets of peaks."""
+    from cpd_amd import center_loss
+    rng = np.random.default_rng(1000 * batch + m + k)
+    gt = np.zeros((batch, m, 8), np.float32)
+    if m:
+        gt[..., 0:2] = rng.uniform(-80, 80, (batch, m, 2))
+        gt[..., 2] = rng.uniform(-1, 3, (batch, m))
+        gt[..., 3:6] = rng.uniform(0.3, 12.0, (batch, m, 3))
+        gt[..., 6] = rng.uniform(-4, 4, (batch, m))
+        gt[..., 7] = rng.integers(1, 4, (batch, m))
+        gt[:, ::5] = 0                                    # padding rows in between
+        if m > 6:
+            gt[:, 1, 3] = 0.0                             # degenerate box: valid = False, zeros everywhere
+            gt[:, 2, 7] = 7                               # a class id above num_classes
+            gt[:, 3, :2] = gt[:, 4, :2]                   # two boxes on one pixel
+            gt[:, 3, 7] = gt[:, 4, 7]
+            gt[:, 6, :2] = [75.15, -75.19]                # a corner pixel: the patch is clipped on two sides
+    dev_gt = torch.from_numpy(gt).cuda()
+    for hw in ((188, 188), (47, 51)):
+        args = (hw,) + _targets_args()[1:]
+        kw = dict(feature_map_stride=8 if hw[0] == 188 else 32, num_max_objs=k, gaussian_overlap=0.1, min_radius=2)
+        want = center_loss.assign_targets(dev_gt, *args, **kw)
+        got = T.center_targets(dev_gt, *args, **kw)
+        assert torch.equal(got[3], want[3]) and torch.equal(got[2], want[2])
+        torch.testing.assert_close(got[1], want[1], rtol=0, atol=4e-5)      # (x - int x at x ~ 100: two ulps of the coordinate = 1.5e-5)
+        torch.testing.assert_close(got[0], want[0], rtol=0, atol=1e-6)
+        assert torch.equal(got[0] == 1.0, want[0] == 1.0)
+        again = T.center_targets(dev_gt, *args, **kw)
+        assert all(torch.equal(a, b) for a, b in zip(got, again))     # deterministic (max-merge is order-independent)
