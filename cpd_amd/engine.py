@@ -424,6 +424,29 @@ class CenterPointEngine:
         self.level_indexes = {}                               # name -> SiteIndex of the level (in the level's row order)
         L = self.sparse
         shape = self.cfg.sparse_shape
+        # The INDEX CHAIN of the strided stages (output set -> row order -> rulebooks: 6-8 small launches and one count read-back per
+        # stage) depends on site lists only, never on features. With `index_side_stream` it runs on a second HIP stream, ahead of the
+        # convolutions, and PIPELINED: a stage's output set is marked and counted (conv_outset_begin) as soon as the list it is marked
+        # from exists -- stage 2's right here, before the level-0 index, rulebook and the level-1 convs are queued; stage k + 1's as
+        # soon as stage k's list is emitted -- so that by the time the host asks for a count (conv_outset_end) the side stream has it,
+        # and the host is never away from the main stream for long. The index kernels overlap convolutions that do not fill the chip
+        # (one frame: 0.6 of 3.0 ms of kernel time is index work). Same kernels, same results.
+        side = self._side_stream() if (self.cfg.index_side_stream and feats.is_cuda and batch <= self.cfg.index_side_stream_max_frames) else None
+        main = torch.cuda.current_stream(self.device) if side is not None else None
+        stages = ["conv2", "conv3", "conv4", "conv_out"]
+        self._index_keep = []
+
+        def begin(stage, coords_c, shape):
+            k, s, pd = _DOWN[stage]
+            return ops.conv_outset_begin(coords_c, batch, shape, k, s, pd)
+
+        if side is not None:
+            # side-stream tensors read on `main` (tables, lists, indexes) live until the NEXT step's chain starts, and that start waits
+            # for everything queued on `main` before this point: the caching allocator may hand a freed block to the side stream only
+            # after its readers ran
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                pending = begin(stages[0], coords, shape)
         if index is None:
             index = ops.SiteIndex.build(coords, batch, shape)
         coords_c0, canon0 = coords, None
@@ -436,28 +459,21 @@ class CenterPointEngine:
             feats = feats.index_select(0, n2o.long())
             if self.cfg.chunked_rulebooks:
                 canon0 = (coords_c0, o2n, self.cfg.row_order_chunk)
-        # The INDEX CHAIN of the strided stages (output set -> row order -> rulebooks: 6-8 small launches and one count read-back per
-        # stage) depends on site lists only, never on features. With `index_side_stream` it runs on a second HIP stream, a stage ahead
-        # of the convolutions: stage 2's chain is queued before the level-1 convs, stage k + 1's right after stage k's convs; the
-        # count read-backs then wait for that stream only (the host keeps queueing convs), and the index kernels overlap convolutions
-        # that do not fill the chip (one frame: 0.6 of 3.0 ms of kernel time is index work). Same kernels, same results.
-        side = self._side_stream() if (self.cfg.index_side_stream and feats.is_cuda and batch <= self.cfg.index_side_stream_max_frames) else None
-        main = torch.cuda.current_stream(self.device) if side is not None else None
-        if side is not None:
-            # side-stream tensors read on `main` (tables, lists, indexes) live until the NEXT step's chain starts, and that start waits
-            # for everything queued on `main`: the caching allocator may hand a freed block to the side stream only after its readers ran
-            side.wait_stream(main)
-        self._index_keep = []
         pairs16 = pairs and self.cfg.pair_rows_level1
 
-        def tables(stage, coords_c, index, shape):
-            """everything of a strided stage that depends on the site lists only: its output set, row order, both rulebooks"""
+        def tables(stage, index, pending, after=None):
+            """everything of a strided stage that depends on the site lists only: its output set (`pending`: its conv_outset_begin),
+            row order, both rulebooks -- and the next stage's conv_outset_begin; index = the site index of the stage's input level,
+            `after`: an event of the main stream that index is complete at"""
             k, s, pd = _DOWN[stage]
-            out_idx, out_index, out_shape = ops.conv_outset(coords_c, batch, shape, k, s, pd)
+            out_idx, out_index, out_shape = ops.conv_outset_end(pending)
+            if after is not None:
+                torch.cuda.current_stream(self.device).wait_event(after)
             if stage == "conv_out":
                 return dict(out_idx=out_idx, out_c=out_idx, out_index=out_index, out_shape=out_shape,
-                            nbr_dn=ops.rulebook_conv(out_idx, index, k, s, pd), nbr=None, pairs_out=False)
+                            nbr_dn=ops.rulebook_conv(out_idx, index, k, s, pd), nbr=None, pairs_out=False, pending=None)
             out_c = out_idx
+            pending = begin(stages[stages.index(stage) + 1], out_c, out_shape)     # (the canonical list: what the next output set is marked from)
             # "bricks" per level: only where the staged kernel is used (plan_channels: the widths it wins at); other levels keep "taps"
             c_lvl = L[stage + ".down"].c_out
             use_plan = self.cfg.plan_rulebooks and pairs and c_lvl in self.cfg.plan_channels
@@ -480,23 +496,23 @@ class CenterPointEngine:
             nbr = ops.rulebook_subm(out_idx, out_index, canonical=canon)
             if bricks and pairs_out and use_plan:
                 ops.rulebook_plan(nbr, self.cfg.plan_tile_rows)  # the level's four SubM convs: the staged row-wave kernel
-            return dict(out_idx=out_idx, out_c=out_c, out_index=out_index, out_shape=out_shape, nbr_dn=nbr_dn, nbr=nbr, pairs_out=pairs_out, canon=canon)
+            return dict(out_idx=out_idx, out_c=out_c, out_index=out_index, out_shape=out_shape, nbr_dn=nbr_dn, nbr=nbr, pairs_out=pairs_out, canon=canon,
+                        pending=pending)
 
-        def stage_tables(stage, prev):
-            """queue a stage's index chain (on the side stream when there is one); prev = the tables of the stage before it"""
+        def stage_tables(stage, index, pending, after=None):
+            """queue a stage's index chain (on the side stream when there is one)"""
             if side is None:
-                T = tables(stage, prev["out_c"], prev["out_index"], prev["out_shape"])
+                T = tables(stage, index, pending)
                 T["ev"] = None
             else:
                 with torch.cuda.stream(side):
-                    T = tables(stage, prev["out_c"], prev["out_index"], prev["out_shape"])
+                    T = tables(stage, index, pending, after)
                     T["ev"] = side.record_event()
             self._index_keep.append(T)
             return T
 
+        ev_index = main.record_event() if side is not None else None          # the level-0 index (and its order) are complete here
         nbr = ops.rulebook_subm(coords, index, canonical=canon0)               # 'subm1' and 'res1' are the same L0 table
-        stages = ["conv2", "conv3", "conv4", "conv_out"]
-        T_next = stage_tables(stages[0], dict(out_c=coords_c0, out_index=index, out_shape=shape))
         self._range_reset()                                  # (the 5-channel input layer runs on the fp32 pipe: no block for `feats`)
         # level 1 (16 channels): with pair rows its layers run the K = 16 split-fp16 MFMA on 16-channel pair rows (three products of
         # 16 matrix cycles instead of four fp32 MFMAs of 32); the 5-channel input layer stays on the fp32 pipe and writes the first pairs
@@ -514,7 +530,11 @@ class CenterPointEngine:
         levels = {"x_conv1": (export(x, pairs16, "x_conv1"), coords, shape)}
         self.level_indexes["x_conv1"] = index
         pairs_in = pairs16                 # (what conv2.down reads)
-        T = T_next
+        if side is None:
+            pending = begin(stages[0], coords_c0, shape)
+        # (a stage's chain is queued AFTER the previous stage's convs: its count read-back can still block the host for a moment, and
+        # the main stream should have its work by then)
+        T = stage_tables(stages[0], index, pending, after=ev_index)
         for i, stage in enumerate(stages, start=2):
             if T["ev"] is not None:
                 main.wait_event(T["ev"])
@@ -527,10 +547,7 @@ class CenterPointEngine:
             pairs_in = pairs_out
             levels["x_conv%d" % i] = (export(x, pairs_in, "x_conv%d" % i), out_idx, out_shape)
             self.level_indexes["x_conv%d" % i] = T["out_index"]
-            # the next stage's chain is queued AFTER this stage's convs: its count read-back blocks the host, and the main stream
-            # should have its work queued by then (issued before them -- tried -- the main stream idles while the host waits:
-            # one frame 2.93 vs 2.78 ms)
-            T = stage_tables(stages[i - 1], T)
+            T = stage_tables(stages[i - 1], T["out_index"], T["pending"])
         # (dense_pairs: the stride-8 output stays in pair rows -- densify is a copy of row bytes, so the BEV map it builds is a pair-row map)
         x = self._conv(L["conv_out"], x, T["nbr_dn"], out_idx.shape[0], in_pairs=pairs_in, out_pairs=bool(dense_pairs) and pairs_in)
         self.encoded_pairs = bool(dense_pairs) and pairs_in
@@ -683,9 +700,20 @@ class CenterPointEngine:
         # topk(NMS_PRE_MAXSIZE) + sort inside nms_gpu are identities (K = 500 <= 4096)
         assert cfg.max_obj_per_sample <= cfg.nms_pre_maxsize
         keep, num_keep = ops.nms_batch(boxes, counts, cfg.nms_thresh)
-        ob, os_, ol, on = ops.select_boxes(boxes, scores, labels, keep, num_keep, cfg.nms_post_maxsize, label_offset=1)
         flag = self._range_exceeded_flag()        # the range guard's verdict travels with the counts: no extra synchronisation
-        ns = (torch.cat([on, flag]) if flag is not None else on).tolist()      # the one host read-back of the stage
+        # counts, the verdict and the padded boxes / scores / labels are ONE device block: with host results one blocking copy brings a
+        # step's whole output over (they were four: the counts, then three tensors at ~25 us of synchronisation each)
+        ob, os_, ol, on, blk = ops.select_boxes(boxes, scores, labels, keep, num_keep, cfg.nms_post_maxsize, label_offset=1,
+                                                packed=True, extra_ints=1)
+        lay = blk._cpd_layout
+        hdr = blk[:4 * lay["n_hdr"]].view(torch.int32)
+        if flag is not None:
+            hdr[batch:batch + 1].copy_(flag)
+        whole = self.host_results and not raw
+        # (blocking copies. Asynchronous copies into pinned memory queued on the compute stream were measured 5-8 ms per step SLOWER on
+        # MI355X / ROCm 7.2 -- tools/d2h_probe.py -- whatever the wait that followed them: event, stream or a later blocking read.)
+        host = blk.cpu() if whole else None       # the one host read-back of the stage
+        ns = (ops.unpack_boxes(host, lay)[0] if whole else hdr).tolist()
         high = bool(ns[batch]) if flag is not None else False
         if getattr(self, "_rb_scaled", False):
             self._range_exceeded, self._range_high = False, high     # guarded already: exact whatever the range; `high` keeps it guarded
@@ -696,11 +724,8 @@ class CenterPointEngine:
             return None                           # forward() runs the step again, guarded
         if raw:                                   # the padded device block + per-frame counts (the two-stage engine's proposals)
             return ob, os_, ol, ns
-        if self.host_results:
-            # blocking copies: the first waits for the frame's last kernel, the rest are ~20 us each. (Asynchronous copies
-            # into pinned memory queued on the compute stream were measured 5-8 ms per step SLOWER on MI355X / ROCm 7.2 --
-            # tools/d2h_probe.py -- whatever the wait that followed them: event, stream or a later blocking read.)
-            ob, os_, ol = ob.cpu(), os_.cpu(), ol.cpu()
+        if whole:
+            _, ob, os_, ol = ops.unpack_boxes(host, lay)
         return [{"pred_boxes": ob[b, :ns[b]], "pred_scores": os_[b, :ns[b]], "pred_labels": ol[b, :ns[b]]}
                 for b in range(batch)]
 

@@ -257,9 +257,9 @@ def conv_out_shape(in_shape, ksize, stride, pad):
     return [o[0], o[1], o[2]]
 
 
-def conv_outset(in_indices, batch, in_shape, ksize, stride, pad):
-    """Active output sites of a SparseConv3d in canonical (b,z,y,x) order.
-    Returns (out_indices [n_out,4] i32, out_index SiteIndex, out_shape)."""
+def conv_outset_begin(in_indices, batch, in_shape, ksize, stride, pad):
+    """First half of conv_outset: the launches that mark and count a SparseConv3d's active output sites (cpd_conv_outset). Returns a
+    handle for conv_outset_end -- which reads the count back; queueing other work between the two hides the read-back's wait."""
     in_indices = in_indices.contiguous()
     out_shape = conv_out_shape(in_shape, ksize, stride, pad)
     out_index = SiteIndex(batch, out_shape, 0, in_indices.device)
@@ -267,11 +267,23 @@ def conv_outset(in_indices, batch, in_shape, ksize, stride, pad):
     check(lib().cpd_conv_outset(ptr(in_indices), in_indices.shape[0], batch, iarr(in_shape), iarr(ksize),
                                 iarr(stride), iarr(pad), ptr(out_index.buf), out_index.buf.numel(), ptr(n_out_dev),
                                 stream()), "cpd_conv_outset")
+    return (in_indices, batch, out_shape, out_index, n_out_dev)
+
+
+def conv_outset_end(handle):
+    """Second half: (out_indices [n_out,4] i32 in canonical (b,z,y,x) order, out_index SiteIndex, out_shape)."""
+    in_indices, batch, out_shape, out_index, n_out_dev = handle
     n_out = int(n_out_dev.item())  # the one host sync of a strided layer: sizes the output tensors
     out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=in_indices.device)
     check(lib().cpd_index_emit(ptr(out_index.buf), batch, iarr(out_shape), ptr(out_indices), n_out, stream()),
           "cpd_index_emit")
     return out_indices, out_index, out_shape
+
+
+def conv_outset(in_indices, batch, in_shape, ksize, stride, pad):
+    """Active output sites of a SparseConv3d in canonical (b,z,y,x) order.
+    Returns (out_indices [n_out,4] i32, out_index SiteIndex, out_shape)."""
+    return conv_outset_end(conv_outset_begin(in_indices, batch, in_shape, ksize, stride, pad))
 
 
 def rulebook_conv(out_indices, in_index, ksize, stride, pad, canonical=None):
@@ -604,18 +616,54 @@ def rank_scores(cls, boxes, labels, score_thresh, pre_max, normalized=False):
     return ob, osc, ol, n_ok
 
 
-def select_boxes(boxes, scores, labels, keep, num_keep, post_max, label_offset=0):
+def select_boxes(boxes, scores, labels, keep, num_keep, post_max, label_offset=0, packed=False, extra_ints=0):
     """out[b][k] = in[b][keep[b][k]], k < min(num_keep[b], post_max). Returns padded
-    (boxes [batch,post_max,7], scores, labels i64, counts [batch] i32)."""
+    (boxes [batch,post_max,7], scores, labels i64, counts [batch] i32).
+    packed=True: the four outputs are views of ONE allocation, returned as a fifth value (a flat uint8 tensor: counts -- `batch` int32
+    followed by `extra_ints` more words the caller may fill --, then boxes, scores, labels): one device-to-host copy moves a step's
+    results, `unpack_boxes` cuts the host copy up again."""
     batch, cap = boxes.shape[0], boxes.shape[1]
     dev = boxes.device
-    ob = torch.empty((batch, post_max, 7), dtype=torch.float32, device=dev)
-    os_ = torch.empty((batch, post_max), dtype=torch.float32, device=dev)
-    ol = torch.empty((batch, post_max), dtype=torch.int64, device=dev)
-    on = torch.zeros((batch,), dtype=torch.int32, device=dev)
+    if packed:
+        lay = _box_block_layout(batch, int(post_max), int(extra_ints))
+        blk = torch.empty((lay["bytes"],), dtype=torch.uint8, device=dev)
+        hdr, ob, os_, ol = _box_block_views(blk, lay)
+        hdr.zero_()
+        on = hdr[:batch]
+    else:
+        ob = torch.empty((batch, post_max, 7), dtype=torch.float32, device=dev)
+        os_ = torch.empty((batch, post_max), dtype=torch.float32, device=dev)
+        ol = torch.empty((batch, post_max), dtype=torch.int64, device=dev)
+        on = torch.zeros((batch,), dtype=torch.int32, device=dev)
     check(lib().cpd_select_boxes(ptr(boxes), ptr(scores), ptr(labels), ptr(keep), ptr(num_keep), batch, cap, int(post_max),
                                  int(label_offset), ptr(ob), ptr(os_), ptr(ol), ptr(on), stream()), "cpd_select_boxes")
+    if packed:
+        blk._cpd_layout = lay
+        return ob, os_, ol, on, blk
     return ob, os_, ol, on
+
+
+def _box_block_layout(batch, post_max, extra_ints):
+    a = lambda n: (n + 15) // 16 * 16
+    n_hdr = batch + extra_ints
+    o_box = a(4 * n_hdr)
+    o_sc = a(o_box + 4 * batch * post_max * 7)
+    o_lab = a(o_sc + 4 * batch * post_max)
+    return dict(batch=batch, post_max=post_max, n_hdr=n_hdr, o_box=o_box, o_sc=o_sc, o_lab=o_lab, bytes=a(o_lab + 8 * batch * post_max))
+
+
+def _box_block_views(blk, lay):
+    b, pm = lay["batch"], lay["post_max"]
+    hdr = blk[:4 * lay["n_hdr"]].view(torch.int32)
+    ob = blk[lay["o_box"]:lay["o_box"] + 4 * b * pm * 7].view(torch.float32).view(b, pm, 7)
+    os_ = blk[lay["o_sc"]:lay["o_sc"] + 4 * b * pm].view(torch.float32).view(b, pm)
+    ol = blk[lay["o_lab"]:lay["o_lab"] + 8 * b * pm].view(torch.int64).view(b, pm)
+    return hdr, ob, os_, ol
+
+
+def unpack_boxes(host_blk, lay):
+    """(header int32 words, boxes, scores, labels) of a host copy of select_boxes(packed=True)'s block"""
+    return _box_block_views(host_blk, lay)
 
 
 # ---------------------------------------------------------------------------------------- B3
