@@ -87,3 +87,22 @@ def test_two_engines_two_streams_48_frames_equal_single_stream_and_oracle(oracle
     np.testing.assert_allclose(a, b[j], atol=1e-3, rtol=1e-4)
     np.testing.assert_array_equal(g["pred_labels"].numpy(), want["pred_labels"][j])
     assert frame_digest(g) == da[1][fi]
+
+
+@pytest.mark.parametrize("frames", [1, 3])
+def test_side_stream_index_chain_changes_no_detection(hip, frames):
+    """The strided stages' index chain on its own HIP stream, pipelined a stage ahead (ModelConfig.index_side_stream; for small batches
+    the first BEV deblock too): same kernels, same arguments, so every detection of every step must equal, bit for bit, the run with
+    everything on one stream. Four steps on alternating clouds through ONE engine: the tables a step leaves on the side stream's
+    allocator pool are recycled by the next step while the main stream may still be reading them unless the engine orders that."""
+    sd = init_state_dict(ModelConfig(), seed=0)
+    host = _clouds(2 * frames)
+    dev = [torch.from_numpy(c).cuda() for c in host]
+    batches = [dev[:frames], dev[frames:], dev[:frames], dev[frames:]]
+    outs = []
+    for on in (False, True):
+        eng = CenterPointEngine(ModelConfig(index_side_stream=on, deblock_side_stream=on), sd, host_results=True)
+        outs.append([step_digest(eng.forward(b)) for b in batches])
+    assert sum(outs[0][0][0]) > 0
+    assert outs[0] == outs[1]
+    assert outs[0][0] == outs[0][2] and outs[0][1] == outs[0][3]          # and a step does not depend on the one before it

@@ -310,3 +310,30 @@ def test_full_size_config3_step_is_locally_exact_on_the_benchmarked_kernels(hip)
                  "window_conv_f16_kernel<64,128>", "window_conv_f16s_kernel<64,128>", "window_conv_f16_kernel<16,128>"):
         # (a row-wave layer large enough to run unsplit takes the LDS-epilogue form of its kernel: f16e / f16se, round 4)
         assert log.counts.get(name, 0) + log.counts.get(name.replace("_kernel<", "e_kernel<"), 0) > 0, (name, sorted(log.counts))
+
+
+def test_step_is_bitwise_the_same_with_and_without_the_side_streams(hip):
+    """Round 5 moved the index chain of the strided stages to its own HIP stream (a stage ahead of the forward layers) and the target
+    assignment off the main stream. Neither changes a kernel or an argument: three optimiser steps with the streams on give, bit for
+    bit, the parameters and the losses of three steps with everything on the main stream (index_side_stream = False) -- a missing
+    event (a conv reading a rulebook still being built) or a block the allocator recycled across streams would show up here; the torch
+    target path on its side stream (fused_targets = False) against the same path in line likewise."""
+    from cpd_amd.train_engine import CenterPointTrainer
+    cfg = small_cfg()
+    scenes = [scene(seed=s) for s in (1, 2, 3)]
+
+    def run(index_stream, fused, early):
+        tr = CenterPointTrainer(cfg, init_state_dict(cfg, seed=5), lr=1e-3, num_max_objs=50)
+        tr.index_side_stream, tr.fused_targets, tr.early_targets = index_stream, fused, early
+        losses = []
+        for pts, gt in scenes:
+            loss, _ = tr.step([torch.from_numpy(p).cuda() for p in pts], torch.from_numpy(gt).cuda())
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return losses, tr.store.flat.clone()
+
+    for fused in (True, False):
+        l0, p0 = run(False, fused, False)
+        l1, p1 = run(True, fused, True)
+        assert l0 == l1, (fused, l0, l1)
+        assert torch.equal(p0, p1), "parameters differ after three steps (fused targets: %s)" % fused
