@@ -477,20 +477,34 @@ class CenterPointTrainer:
         # the strided stages (output set, both rulebooks, the transposed one for the backward pass) runs on its own HIP stream, one
         # stage ahead of the convolutions -- the read-backs wait for that stream only, so the conv chain is still queued without
         # bubbles, and the 25 small index launches of a step overlap layers that do not fill the chip at one frame per GPU.
-        # (`index_side_stream=False`: all tables first on the main stream, the round-2 form.) Tables are kept until the next step's
+        # (`index_side_stream=False`: the same order of calls on the main stream.) Tables are kept until the next step's
         # chain starts, and that start waits for everything queued on the main stream (caching-allocator safety across streams).
-        index = ops.SiteIndex.build(coords, batch, shape)
+        stages = ["conv2", "conv3", "conv4", "conv_out"]
         n0 = coords.shape[0]
         side = None
+        self._index_keep = keep = []
+
+        def begin(stage, coords, shape):
+            k, s, pd = _DOWN[stage]
+            return ops.conv_outset_begin(coords, batch, shape, k, s, pd)
+
         if self.index_side_stream and coords.is_cuda:
             side = _lib.side_stream(self.device, "index")
             main = torch.cuda.current_stream(self.device)
-            side.wait_stream(main)
-        self._index_keep = keep = []
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                pending = begin(stages[0], coords, shape)            # stage 2's output set is marked and counted beside the level-0 index build
+        index = ops.SiteIndex.build(coords, batch, shape)
+        ev_index = main.record_event() if side is not None else None
 
-        def stage_tables(stage, coords, index, shape):
+        def stage_tables(stage, coords, index, shape, pending, after=None):
+            """a stage's output set (`pending`: its conv_outset_begin), the next stage's conv_outset_begin, its rulebooks; coords / index /
+            shape = the stage's input level; `after`: an event of the main stream that `index` is complete at"""
             k, s, pd = _DOWN[stage]
-            out_idx, out_index, out_shape = ops.conv_outset(coords, batch, shape, k, s, pd)
+            out_idx, out_index, out_shape = ops.conv_outset_end(pending)
+            if after is not None:
+                torch.cuda.current_stream(self.device).wait_event(after)
+            nxt = begin(stages[stages.index(stage) + 1], out_idx, out_shape) if stage != "conv_out" else None
             nbr_dn = ops.rulebook_conv(out_idx, index, k, s, pd)
             nbr_dn_t = train_ops.rulebook_conv_transpose(coords, batch, shape, k, s, pd, out_index)
             nbr_sub = None if stage == "conv_out" else ops.rulebook_subm(out_idx, out_index)
@@ -498,31 +512,31 @@ class CenterPointTrainer:
             if stage == "conv_out":                          # HeightCompression's row map (used by the backward pass): coordinates only, too
                 (d, h, w), ci = out_shape, out_idx.long()
                 rows = ((ci[:, 0] * h + ci[:, 2]) * w + ci[:, 3]) * d + ci[:, 1]
-            return (stage, nbr_dn, nbr_dn_t, nbr_sub, out_idx.shape[0], out_idx, out_index, out_shape, rows)
+            return (stage, nbr_dn, nbr_dn_t, nbr_sub, out_idx.shape[0], out_idx, out_index, out_shape, rows, nxt)
 
-        stages = ["conv2", "conv3", "conv4", "conv_out"]
-
-        def queue_tables(stage, coords, index, shape):
+        def queue_tables(stage, coords, index, shape, pending, after=None):
             if side is None:
-                return stage_tables(stage, coords, index, shape), None
+                return stage_tables(stage, coords, index, shape, pending), None
             with torch.cuda.stream(side):
-                t = stage_tables(stage, coords, index, shape)
+                t = stage_tables(stage, coords, index, shape, pending, after)
                 return t, side.record_event()
 
         nbr0 = ops.rulebook_subm(coords, index)
         keep.append((coords, index, nbr0))
-        # stage 2's tables go out before the level-1 layers are queued, stage k + 1's after stage k's layers
-        nxt = queue_tables(stages[0], coords, index, shape)
         tape = {"nbr0": nbr0, "stages": []}
         if getattr(self, "_repack_ev", None) is not None:      # the previous optimiser step's weight images (optimizer_step)
             torch.cuda.current_stream(self.device).wait_event(self._repack_ev)
             self._repack_ev = None
         x = S["conv_input"].forward(feats, nbr0, n0)
         x = self._blocks_fwd(S["conv1"], x, nbr0)
+        if side is None:
+            pending = begin(stages[0], coords, shape)
+        # a stage's chain is queued after the previous stage's layers (the count read-back inside can still block the host for a moment;
+        # the main stream has its work by then), its output set having been marked a stage earlier
+        nxt = queue_tables(stages[0], coords, index, shape, pending, after=ev_index)
         for si, stage in enumerate(stages):
             t, ev = nxt
             keep.append(t)
-            coords, index, shape = t[5], t[6], t[7]
             if ev is not None:
                 main.wait_event(ev)
             _, nbr_dn, nbr_dn_t, nbr_sub, n_stage = t[:5]
@@ -533,8 +547,9 @@ class CenterPointTrainer:
                 x = S[stage + ".down"].forward(x, nbr_dn, n_stage)
                 x = self._blocks_fwd(S[stage], x, nbr_sub)
             tape["stages"].append((stage, nbr_sub, nbr_dn_t, n_in))
-            if si + 1 < len(stages):                       # (after this stage's layers are queued: the read-back inside blocks the host)
-                nxt = queue_tables(stages[si + 1], coords, index, shape)
+            coords, index, shape = t[5], t[6], t[7]
+            if si + 1 < len(stages):
+                nxt = queue_tables(stages[si + 1], coords, index, shape, t[9])
         dense_rows = t[8]
         d, h, w = shape
         C = x.shape[1]
