@@ -132,8 +132,14 @@ class HipLinear(torch.nn.Linear):
     """nn.Linear (same parameters, same state_dict names) whose forward on device tensors is ONE cpd_gather_conv launch -- a 1 x 1
     "convolution" over the rows -- and whose gradients are the C-ABI's (input gradient = the same kernel on the adjoint weights, weight
     gradient = cpd_conv_wgrad, bias gradient = cpd_col_sum): the FC stacks of the second stage (voxel_rcnn_head.py:129-166 shared_fc /
-    cls / reg layers) then train without rocBLAS (VERDICT r3 missing #4). Host tensors take torch's own path (host-side unit tests)."""
+    cls / reg layers) then train without rocBLAS (VERDICT r3 missing #4). Host tensors take torch's own path (host-side unit tests).
+    fp32 in, fp32 out: inputs of another dtype are cast and autocast is not consulted. The packed weight image is rebuilt when the
+    parameter's version counter or storage changes; a host that updates weights through raw pointers (the C-ABI optimiser) calls
+    `invalidate_packed()` afterwards."""
     conv_math = "f32"
+
+    def invalidate_packed(self):
+        self._pk_ver = None
 
     def _packed(self):
         ver = (self.weight._version, self.weight.data_ptr())
@@ -154,8 +160,12 @@ class HipLinear(torch.nn.Linear):
 
 class HipConv1d(torch.nn.Conv1d):
     """nn.Conv1d(kernel_size=1) on (B, C, N) tensors as the same 1 x 1 launch over the N rows (the per-voxel and output MLPs of the RoI
-    grid pooling, voxel_pool_modules.py:36-58); parameters and state_dict names are Conv1d's."""
+    grid pooling, voxel_pool_modules.py:36-58); parameters and state_dict names are Conv1d's. fp32 contract and `invalidate_packed()` as
+    HipLinear."""
     conv_math = "f32"
+
+    def invalidate_packed(self):
+        self._pk_ver = None
 
     def _packed(self):
         ver = (self.weight._version, self.weight.data_ptr())
@@ -165,12 +175,15 @@ class HipConv1d(torch.nn.Conv1d):
         return self._pk
 
     def forward(self, x):
-        if not x.is_cuda or self.kernel_size != (1,) or x.shape[0] != 1:
+        if not x.is_cuda or self.kernel_size != (1,) or self.stride != (1,) or self.padding != (0,) or self.groups != 1:
             return super().forward(x)
-        rows = x[0].t()                                                    # (N, C)
+        # (B, C, N) -> B * N rows: every batch size takes the same kernel and arithmetic (batch != 1 used to fall back to
+        # torch). fp32 in, fp32 out: inputs of another dtype are cast, autocast is not consulted (the contract of every C-ABI module here)
+        b, c, n = x.shape
+        rows = x.permute(0, 2, 1).reshape(b * n, c)
         spec = ConvSpec(None, 1, rows.shape[0], dense=True, math=self.conv_math, mode="same", packed=self._packed())
         y = gather_conv(rows, self.weight[:, :, 0].t().unsqueeze(0), self.bias, spec)
-        return y.t().unsqueeze(0)
+        return y.view(b, n, self.out_channels).permute(0, 2, 1)
 
 
 
