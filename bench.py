@@ -115,6 +115,7 @@ def parse():
                     "the split-fp16 dense layers (round 5; 0 = fp32 dense maps, the round-4 form: same detections)")
     ap.add_argument("--index-stream", type=int, choices=[0, 1], default=1, help="ModelConfig.index_side_stream: the strided stages' index chain "
                     "(output sets, row order, rulebooks) on a second HIP stream, one stage ahead of the convolutions")
+    ap.add_argument("--vox-batch-min", type=int, default=2, help="ModelConfig.batched_voxelizer_min_frames")
     ap.add_argument("--deblock-stream", type=int, choices=[0, 1], default=1, help="ModelConfig.deblock_side_stream: the first BEV deblock beside the "
                     "next level's convolutions, on the side stream")
     ap.add_argument("--dense-map", type=int, choices=[0, 1], default=1, help="ModelConfig.persistent_dense_map (0: densify into a fresh, fully "
@@ -847,7 +848,8 @@ def main():
 
     cfg = ModelConfig(conv_math=args.conv_math, row_order=args.row_order, row_order_chunk=args.row_order_chunk, plan_rulebooks=bool(args.plan), plan_tile_rows=args.plan_tile, row_order_level0=bool(args.order_level0), pair_rows=bool(args.pair_rows),
                       pair_rows_level1=args.pair_rows == 2, pair_rows_dense=bool(args.dense_pairs), persistent_dense_map=bool(args.dense_map),
-                      index_side_stream=bool(args.index_stream), deblock_side_stream=bool(args.deblock_stream))
+                      index_side_stream=bool(args.index_stream), deblock_side_stream=bool(args.deblock_stream),
+                      batched_voxelizer_min_frames=args.vox_batch_min)
     sd = init_state_dict(cfg, seed=0)                 # same random-init weights on every rank
     dev = "cuda:%d" % local
     if args.mode == "train":

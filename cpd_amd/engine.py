@@ -72,6 +72,7 @@ class ModelConfig:
     pair_rows_dense: bool = True
     persistent_dense_map: bool = True      # densify into a persistent pre-zeroed map, re-zero the occupied rows after its reader (ops.DenseMap)
     voxelizer_group: int = 64             # frames per batched-voxelizer call (its FrameOffsets kernel argument holds 64)
+    batched_voxelizer_min_frames: int = 2  # smaller batches: one voxelizer call per frame + a separate level-0 index build
     # "bricks" (round 4, measured, NOT the default): rows of the strided levels in 8 x 8 (y, x) brick order of their z-plane,
     # pattern-sorted inside every 128-row tile (ops.order_rows_bricks); with plan_rulebooks their sub-manifold rulebooks are PLANNED
     # (ops.rulebook_plan) and the SparseBasicBlock convs of levels 2-4 run the staged row-wave kernel, which fetches a tile's distinct
@@ -744,7 +745,7 @@ class CenterPointEngine:
         index0 = None
         canonical0 = False
         z_extra = self.cfg.sparse_shape[0] - self.cfg.grid_zyx[0]
-        if batch > 1 and self.voxelizer.batch_supported(batch, z_extra):
+        if batch >= self.cfg.batched_voxelizer_min_frames and self.voxelizer.batch_supported(batch, z_extra):
             # one set of voxelizer launches for the whole batch; rows come out frame after frame; the voxelizer's occupancy
             # bitmap / prefix / rank -> row map ARE the level-0 site index of the backbone
             n_pts = sum(int(p.shape[0]) for p in points_list)
