@@ -45,3 +45,9 @@ for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
     print("queue %s stream %s: %d kernels, kernel time %.2f ms, gaps %.2f ms (of which gaps < 20 us: %.2f ms)" % (q[0], q[1], len(rs), kt, tot_gap / 1e6, small / 1e6))
     for n, g in gaps.most_common(12):
         print("    %-60s gap before it: total %.3f ms over %d (avg %.1f us)" % (n, g / 1e6, gapn[n], g / 1e3 / gapn[n]))
+    kt_by = collections.Counter(); kn_by = collections.Counter()
+    for r in rs:
+        kt_by[short(r["Kernel_Name"])] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); kn_by[short(r["Kernel_Name"])] += 1
+    print("    -- kernel time on this queue")
+    for n, t in kt_by.most_common(22):
+        print("    %-60s %8.3f ms over %5d launches (avg %.1f us)" % (n, t / 1e6, kn_by[n], t / 1e3 / kn_by[n]))
