@@ -26,6 +26,7 @@ class AnchorPointEngine(CenterPointEngine):
     def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], head_cfg, nms_cfg, class_names=("Vehicle", "Pedestrian", "Cyclist"),
                  device="cuda", host_results=False):
         self.head_cfg, self.nms_cfg, self.class_names = head_cfg, nms_cfg, list(class_names)
+        self.proposal_first_rows = None       # candidates per frame the proposal NMS looks at first (None: max(512, 4 * NMS_POST_MAXSIZE))
         super().__init__(cfg, state_dict, device=device, host_results=host_results)
         if nms_cfg.get("MULTI_CLASSES_NMS", False) or nms_cfg["NMS_TYPE"] != "nms_gpu":
             raise NotImplementedError("proposal NMS variant not selected by the shipped CPD configs")
@@ -74,10 +75,20 @@ class AnchorPointEngine(CenterPointEngine):
                                                           hd.num_dir_bins)
         self.last_dense = dict(batch_cls_preds=cls, batch_box_preds=boxes, anchor_mask=mask)      # (references, for tests and tools)
         nms = self.nms_cfg
-        rois, scores, labels, kept = roi_pool.proposal_layer(boxes, cls, float(nms["NMS_THRESH"]), int(nms["NMS_PRE_MAXSIZE"]),
-                                                             int(nms["NMS_POST_MAXSIZE"]))
+        post = int(nms["NMS_POST_MAXSIZE"])
+        # proposal NMS over each frame's first `rows` candidates (exact while the NMS_POST_MAXSIZE-th survivor is among them: it almost
+        # always is -- a 0.8 threshold suppresses little -- and the `incomplete` word that says otherwise rides with the counts)
+        rows = min(int(nms["NMS_PRE_MAXSIZE"]), max(512, 64 * ((4 * post + 63) // 64))) if self.proposal_first_rows is None else int(self.proposal_first_rows)
+        rois, scores, labels, kept, inc = roi_pool.proposal_layer(boxes, cls, float(nms["NMS_THRESH"]), int(nms["NMS_PRE_MAXSIZE"]), post,
+                                                                  first_rows=rows)
         flag = self._range_exceeded_flag()
-        ns = (torch.cat([kept.to(torch.int32), flag]) if flag is not None else kept).tolist()       # the stage's one read-back
+        tail = [inc.max().view(1)] + ([flag] if flag is not None else [])
+        ns = torch.cat([kept.to(torch.int32)] + tail).tolist()                                       # the stage's one read-back
+        if ns[batch]:                                    # some frame needs boxes beyond its first `rows`: the full NMS, once more
+            self.proposal_full_reruns = getattr(self, "proposal_full_reruns", 0) + 1
+            rois, scores, labels, kept = roi_pool.proposal_layer(boxes, cls, float(nms["NMS_THRESH"]), int(nms["NMS_PRE_MAXSIZE"]), post)
+            ns[:batch] = kept.tolist()
+        del ns[batch]
         high = bool(ns[batch]) if flag is not None else False
         if getattr(self, "_rb_scaled", False):
             self._range_exceeded, self._range_high = False, high

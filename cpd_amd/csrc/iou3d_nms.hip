@@ -64,9 +64,11 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const float *__restrict__
 // (row, column block): lane = column box, the ballot is the mask word -- N * N/64 / 2 independent
 // waves instead of the reference's 64 serial IoUs per thread. Batched over samples (blockIdx.z);
 // per-sample box counts may live on the device (no host round trip between decode and NMS).
+// (round 5) `box_cap` = boxes per sample in `boxes_all`, `cap` = rows / columns of the sample's MASK: the first-survivors entry point
+// (cpd_nms_batch_first) builds the mask of a sample's first `cap` < box_cap boxes only.
 template <bool NORMAL>
 __global__ void __launch_bounds__(256) nms_mask_kernel(const float *__restrict__ boxes_all, const int32_t *__restrict__ counts,
-                                                       int n_host, int cap, float thr,
+                                                       int n_host, int cap, int box_cap, float thr,
                                                        unsigned long long *__restrict__ mask_all) {
     const int smp = blockIdx.z;
     const int n = counts ? min(counts[smp], cap) : n_host;
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(256) nms_mask_kernel(const float *__restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.y * 4 + wave;
     if (row >= n || cb * 64 >= n || cb < (row >> 6)) return;
-    const float *boxes = boxes_all + (size_t)smp * cap * 7;
+    const float *boxes = boxes_all + (size_t)smp * box_cap * 7;
     const int ncb_cap = (cap + 63) >> 6;
     unsigned long long *mask = mask_all + (size_t)smp * cap * ncb_cap;
     const int col = cb * 64 + lane;
@@ -104,10 +106,15 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
 // pass is register-only (shuffles); then lane i (= kept row i of the block) reads its later words
 // and a butterfly OR folds them into the removed set. With LDS=true the sample's whole mask is
 // first copied into LDS with coalesced, pipelined loads (fits up to 1024 boxes).
+// (round 5) `keep_cap` = entries per sample in `keep_all` (the boxes' capacity), `cap` = the mask's; `max_keep`: the scan stops after
+// the 64-box block in which the max_keep-th survivor was found (the survivors up to there are exactly the full scan's first ones);
+// `incomplete` (may be NULL): set to 1 when the sample has more boxes than the mask covers and fewer than max_keep survived among those
+// it covers -- the caller then needs the full scan.
 template <bool LDS>
 __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *__restrict__ mask_all,
-                                                      const int32_t *__restrict__ counts, int n_host, int cap,
-                                                      long long *__restrict__ keep_all, int *__restrict__ num_keep) {
+                                                      const int32_t *__restrict__ counts, int n_host, int cap, int keep_cap, int max_keep,
+                                                      long long *__restrict__ keep_all, int *__restrict__ num_keep,
+                                                      int *__restrict__ incomplete) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_mask[];
     const int smp = blockIdx.x;
     const int n = counts ? min(counts[smp], cap) : n_host;
@@ -115,7 +122,7 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *
     const int ncb_cap = (cap + 63) >> 6;
     const int ncb = (n + 63) >> 6;
     const unsigned long long *gmask = mask_all + (size_t)smp * cap * ncb_cap;
-    long long *keep = keep_all + (size_t)smp * cap;
+    long long *keep = keep_all + (size_t)smp * keep_cap;
     if (LDS) {
         const int total = n * ncb_cap;
         for (int e = lane; e < total; e += 64) s_mask[e] = gmask[e];
@@ -146,6 +153,7 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *
         const bool mine = (keptmask >> lane) & 1ull;
         if (mine) keep[kept + __popcll(keptmask & ((1ull << lane) - 1ull))] = myrow;
         kept += __popcll(keptmask);
+        if (kept >= max_keep) break;
         // later words: lane i holds row (nb*64+i); fold word w of all kept rows with a butterfly OR
         for (int w = nb + 1; w < ncb; ++w) {
             const unsigned long long v = mine ? mask[(size_t)myrow * ncb_cap + w] : 0ull;
@@ -155,28 +163,35 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *
                 if (k == (w >> 6) && lane == (w & 63)) remv[k] |= all;
         }
     }
-    if (lane == 0) num_keep[smp] = kept;
+    if (lane == 0) {
+        num_keep[smp] = kept;
+        if (incomplete) incomplete[smp] = (kept < max_keep && counts && counts[smp] > cap) ? 1 : 0;
+    }
 }
 
+// `lim` = boxes per sample the mask covers (cap: all of them), `max_keep` = survivors wanted (INT_MAX: all), see nms_scan_kernel
 static int nms_impl(bool normal, const float *boxes, const int32_t *counts, int batch, int cap, float thr, int64_t *keep,
-                    int32_t *num_keep, void *ws, size_t ws_bytes, hipStream_t s) {
+                    int32_t *num_keep, void *ws, size_t ws_bytes, hipStream_t s, int lim = -1, int max_keep = 0x7fffffff,
+                    int32_t *incomplete = nullptr) {
     if (cap < 0 || batch <= 0 || !keep || !num_keep || (cap > 0 && (!boxes || !ws))) return CPD_ERR_ARG;
     if (cap > 64 * 64 * 8) return CPD_ERR_UNSUPPORTED;
     if (cap == 0) {
         CPD_HIP_TRY(hipMemsetAsync(num_keep, 0, 4 * (size_t)batch, s));
+        if (incomplete) CPD_HIP_TRY(hipMemsetAsync(incomplete, 0, 4 * (size_t)batch, s));
         return CPD_OK;
     }
-    if (ws_bytes < (size_t)batch * cpd_nms_workspace_bytes(cap)) return CPD_ERR_WORKSPACE;
-    const int ncb = (cap + 63) / 64;
+    const int mcap = (lim > 0 && lim < cap) ? lim : cap;            // rows / columns of a sample's mask
+    if (ws_bytes < (size_t)batch * cpd_nms_workspace_bytes(mcap)) return CPD_ERR_WORKSPACE;
+    const int ncb = (mcap + 63) / 64;
     unsigned long long *mask = (unsigned long long *)ws;
-    dim3 grid(ncb, (cap + 3) / 4, batch);
-    if (normal) nms_mask_kernel<true><<<grid, 256, 0, s>>>(boxes, counts, cap, cap, thr, mask);
-    else nms_mask_kernel<false><<<grid, 256, 0, s>>>(boxes, counts, cap, cap, thr, mask);
-    const size_t lds = (size_t)cap * ncb * 8;
+    dim3 grid(ncb, (mcap + 3) / 4, batch);
+    if (normal) nms_mask_kernel<true><<<grid, 256, 0, s>>>(boxes, counts, mcap, mcap, cap, thr, mask);
+    else nms_mask_kernel<false><<<grid, 256, 0, s>>>(boxes, counts, mcap, mcap, cap, thr, mask);
+    const size_t lds = (size_t)mcap * ncb * 8;
     if (lds <= 64 * 1024)
-        nms_scan_kernel<true><<<batch, 64, lds, s>>>(mask, counts, cap, cap, (long long *)keep, num_keep);
+        nms_scan_kernel<true><<<batch, 64, lds, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete);
     else
-        nms_scan_kernel<false><<<batch, 64, 0, s>>>(mask, counts, cap, cap, (long long *)keep, num_keep);
+        nms_scan_kernel<false><<<batch, 64, 0, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete);
     return cpd_check_launch();
 }
 
@@ -286,6 +301,13 @@ extern "C" int cpd_nms_batch(const float *boxes, const int32_t *counts, int batc
     if (!counts) return CPD_ERR_ARG;
     return nms_impl(normal != 0, boxes, counts, batch, capacity, thresh, keep, num_keep, workspace, workspace_bytes,
                     cpd_s(stream));
+}
+extern "C" int cpd_nms_batch_first(const float *boxes, const int32_t *counts, int batch, int capacity, float thresh, int normal,
+                                   int max_keep, int row_limit, int64_t *keep, int32_t *num_keep, int32_t *incomplete, void *workspace,
+                                   size_t workspace_bytes, cpd_stream_t stream) {
+    if (!counts || !incomplete || max_keep <= 0 || row_limit <= 0) return CPD_ERR_ARG;
+    return nms_impl(normal != 0, boxes, counts, batch, capacity, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream), row_limit,
+                    max_keep, incomplete);
 }
 extern "C" int cpd_select_boxes(const float *boxes, const float *scores, const int32_t *labels, const int64_t *keep,
                                 const int32_t *num_keep, int batch, int capacity, int post_max, int label_offset,

@@ -602,6 +602,21 @@ def nms_batch(boxes, counts, thresh, normal=False):
     return keep, num
 
 
+def nms_batch_first(boxes, counts, thresh, max_keep, row_limit, normal=False):
+    """nms_batch for callers that keep the first `max_keep` survivors only (cpd_nms_batch_first): the mask covers a sample's first
+    `row_limit` boxes, the scan stops once max_keep survived. Returns (keep, num_keep, incomplete [batch] i32): keep[b][:min(num_keep[b],
+    max_keep)] equal nms_batch's first entries; incomplete[b] = 1 -> the sample needs the full nms_batch."""
+    boxes = boxes.contiguous()
+    batch, cap = boxes.shape[0], boxes.shape[1]
+    keep = torch.empty((batch, cap), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros((batch,), dtype=torch.int32, device=boxes.device)
+    inc = torch.zeros((batch,), dtype=torch.int32, device=boxes.device)
+    ws = torch.empty(batch * lib().cpd_nms_workspace_bytes(min(int(row_limit), cap)), dtype=torch.uint8, device=boxes.device)
+    check(lib().cpd_nms_batch_first(ptr(boxes), ptr(counts), batch, cap, float(thresh), 1 if normal else 0, int(max_keep), int(row_limit),
+                                    ptr(keep), ptr(num), ptr(inc), ptr(ws), ws.numel(), stream()), "cpd_nms_batch_first")
+    return keep, num, inc
+
+
 def rank_scores(cls, boxes, labels, score_thresh, pre_max, normalized=False):
     """post_processing's score pipeline for a batch in one launch (cpd_rank_scores): cls [B, R, C] logits (scores when `normalized`),
     boxes [B, R, 7], labels [B, R] i64 -> (boxes, scores, labels i32) ranked by max-class sigmoid score descending (ties: lower index),

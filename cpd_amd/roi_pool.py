@@ -342,21 +342,29 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
     return torch.cat(pooled, dim=-1)
 
 
-def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize, nms_post_maxsize):
+def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize, nms_post_maxsize, first_rows=None):
     """RoIHeadTemplate.proposal_layer (cpd/models/roi_heads/roi_head_template.py:53-114) for dense
     (B, N, 7+C) / (B, N, num_class) predictions with class-agnostic rotated NMS
     (model_nms_utils.class_agnostic_nms, l.115-134): per sample max class score -> top NMS_PRE_MAXSIZE ->
     rotated NMS -> first NMS_POST_MAXSIZE. All samples go through ONE batched mask / scan / select launch set
     (cpd_nms_batch, cpd_select_boxes); nothing is read back. Returns (rois [B, post, 7+C], roi_scores [B, post],
     roi_labels [B, post] i64 = argmax class + 1); slots past a sample's kept count are zero like the reference's
-    new_zeros buffers (their label is 1: the reference's `roi_labels + 1` applies to every slot)."""
+    new_zeros buffers (their label is 1: the reference's `roi_labels + 1` applies to every slot).
+    `first_rows` = R (engines; round 5): only the first NMS_POST_MAXSIZE survivors are kept, and greedy suppression decides a box from the
+    boxes before it -- the NMS runs over each sample's first R candidates (ops.nms_batch_first: R^2 / 2 IoUs instead of 4096^2 / 2, the
+    scan stops at the NMS_POST_MAXSIZE-th survivor) and a fifth value comes back, `incomplete` [B] i32: 1 where a sample found fewer than
+    NMS_POST_MAXSIZE survivors among its first R -- the caller reads it with the counts and calls again without `first_rows`."""
     b, n, cdim = batch_box_preds.shape
     scores, labels = torch.max(batch_cls_preds, dim=-1)                       # l.94
     k = min(int(nms_pre_maxsize), n)
     top_scores, order = torch.topk(scores, k=k, dim=1)                        # class_agnostic_nms l.124 (sorted descending)
     boxes = torch.gather(batch_box_preds, 1, order.unsqueeze(-1).expand(-1, -1, cdim)).contiguous()
     counts = torch.full((b,), k, dtype=torch.int32, device=boxes.device)
-    keep, num_keep = ops.nms_batch(boxes[:, :, :7].contiguous(), counts, nms_thresh)
+    incomplete = None
+    if first_rows is not None and int(first_rows) < k:
+        keep, num_keep, incomplete = ops.nms_batch_first(boxes[:, :, :7].contiguous(), counts, nms_thresh, int(nms_post_maxsize), int(first_rows))
+    else:
+        keep, num_keep = ops.nms_batch(boxes[:, :, :7].contiguous(), counts, nms_thresh)
     top_labels = torch.gather(labels, 1, order).int().contiguous()
     rois7, roi_scores, roi_labels, kept = ops.select_boxes(boxes[:, :, :7].contiguous(), top_scores.contiguous(), top_labels, keep,
                                                            num_keep, int(nms_post_maxsize), label_offset=1)
@@ -367,6 +375,8 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize
     roi_labels = torch.where(valid, roi_labels, torch.ones_like(roi_labels))
     if cdim > 7:
         raise NotImplementedError("7+C box codes (velocity ...) are not used by the CPD configs")
+    if first_rows is not None:
+        return rois7, roi_scores, roi_labels, kept, (incomplete if incomplete is not None else torch.zeros_like(kept))
     return rois7, roi_scores, roi_labels, kept
 
 

@@ -361,6 +361,17 @@ int cpd_nms_normal(const float *boxes, int n, float thresh, int64_t *keep, int32
 int cpd_nms_batch(const float *boxes, const int32_t *counts, int batch, int capacity, float thresh,
                   int normal, int64_t *keep, int32_t *num_keep, void *workspace,
                   size_t workspace_bytes, cpd_stream_t stream);
+/* cpd_nms_batch for callers that keep only the FIRST max_keep survivors of a sample -- class_agnostic_nms keeps
+ * selected[:NMS_POST_MAXSIZE] (model_nms_utils.py:115-134), RoIHeadTemplate.proposal_layer 4096 candidates -> the first few hundred
+ * (roi_head_template.py:53-114): greedy suppression decides box i from boxes before i only, so the first max_keep survivors are known
+ * as soon as the scan has found them. The mask is built for the first `row_limit` boxes of each sample only ((row_limit)^2 / 2 IoUs
+ * instead of capacity^2 / 2) and the scan stops after the 64-box block that holds the max_keep-th survivor: keep[b][0 .. min(num_keep[b],
+ * max_keep)) are EXACTLY cpd_nms_batch's first entries. incomplete[b] = 1 when sample b has more than row_limit boxes and fewer than
+ * max_keep of its first row_limit survived -- the answer then needs boxes the mask does not cover, and the caller runs cpd_nms_batch
+ * (the flag is a device word: read it with the counts). workspace = batch * cpd_nms_workspace_bytes(min(row_limit, capacity)). */
+int cpd_nms_batch_first(const float *boxes, const int32_t *counts, int batch, int capacity, float thresh,
+                        int normal, int max_keep, int row_limit, int64_t *keep, int32_t *num_keep,
+                        int32_t *incomplete, void *workspace, size_t workspace_bytes, cpd_stream_t stream);
 /* The score half of Detector3DTemplate.post_processing (cpd/models/detectors/detector3d_template.py:222-343, MULTI_CLASSES_NMS False) and of
  * class_agnostic_nms (cpd/models/model_utils/model_nms_utils.py:113-124) for a whole batch in one launch: per frame, score = max over the
  * n_cls columns of sigmoid(cls) (of cls itself when normalized != 0), rows with score >= score_thresh ranked by score descending (ties: lower

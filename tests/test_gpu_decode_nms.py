@@ -119,3 +119,60 @@ def test_empty_inputs(hip):
     e = torch.zeros((0, 7), device="cuda")
     assert ops.nms(e, 0.5).shape[0] == 0
     assert ops.boxes_iou_bev(e, torch.zeros((3, 7), device="cuda")).shape == (0, 3)
+
+
+def test_nms_first_survivors_equal_the_full_scan(oracle, hip, golden):
+    """cpd_nms_batch_first: the first `max_keep` survivors from a mask over each sample's first `row_limit` boxes, scan stopped at the
+    max_keep-th survivor (class_agnostic_nms keeps selected[:NMS_POST_MAXSIZE], model_nms_utils.py:115-134). (a) the reference's own
+    4096-box fixture: the first 200 / 500 selected boxes; (b) batches of random sets of different sizes and crowding against
+    cpd_nms_batch, for several (max_keep, row_limit), rotated and axis-aligned; (c) `incomplete`: a crowded sample (30 distinct boxes,
+    each repeated 40 times: 30 survivors among 1200) is flagged when the mask does not cover all of it and fewer than max_keep
+    survived -- and not when the mask covers it, or when max_keep were found."""
+    g = golden("nms_n4096")
+    boxes, scores, thr = dev(g["boxes"]), dev(g["scores"]), float(g["thr"])
+    s_top, idx = torch.topk(scores, k=4096)
+    sorted_boxes = boxes[idx][:, 0:7].contiguous()[None]
+    cnt = torch.tensor([4096], dtype=torch.int32, device="cuda")
+    want = g["selected"]
+    for max_keep, rows in ((200, 512), (500, 1024), (100, 4096), (64, 64)):
+        keep, num, inc = ops.nms_batch_first(sorted_boxes, cnt, thr, max_keep, rows)
+        k = min(int(num[0]), max_keep)
+        if int(inc[0]):
+            assert k < max_keep                                       # flagged only when the prefix came up short
+            continue
+        assert k == min(max_keep, len(want))
+        np.testing.assert_array_equal(idx[keep[0, :k]].cpu().numpy(), want[:k])
+
+    rng = np.random.default_rng(5)
+    sizes = [1, 63, 64, 65, 700, 2048]
+    cap = max(sizes)
+    bb = np.zeros((len(sizes), cap, 7), np.float32)
+    for i, n in enumerate(sizes):
+        b, s = random_boxes(100 + i, n, span=max(6.0, n ** 0.5 * (0.6 if i % 2 else 1.5)))      # every other sample crowded
+        bb[i, :n] = b[np.argsort(-s, kind="stable")]
+    dbb = dev(bb)
+    counts = torch.tensor(sizes, dtype=torch.int32, device="cuda")
+    for normal in (False, True):
+        full_keep, full_num = ops.nms_batch(dbb, counts, 0.3, normal=normal)
+        for max_keep, rows in ((10, 64), (50, 256), (200, 512), (300, 2048), (5, 4096)):
+            keep, num, inc = ops.nms_batch_first(dbb, counts, 0.3, max_keep, rows, normal=normal)
+            for i, n in enumerate(sizes):
+                fk = full_keep[i, :int(full_num[i])].cpu().numpy()
+                k = min(int(num[i]), max_keep)
+                np.testing.assert_array_equal(keep[i, :k].cpu().numpy(), fk[:k])            # always a prefix of the full answer
+                if int(inc[i]):
+                    assert n > rows and k < max_keep
+                else:
+                    assert k == min(max_keep, len(fk)), (normal, max_keep, rows, n, k, len(fk))
+
+    base, _ = random_boxes(9, 30, span=60.0)
+    crowd = np.repeat(base, 40, axis=0)[None].astype(np.float32)                            # 1200 boxes, 30 survivors
+    cc = torch.tensor([1200], dtype=torch.int32, device="cuda")
+    n_full = int(ops.nms_batch(dev(crowd), cc, 0.5)[1][0])
+    assert n_full <= 30
+    _, num, inc = ops.nms_batch_first(dev(crowd), cc, 0.5, 100, 512)
+    assert int(inc[0]) == 1 and int(num[0]) < 100
+    _, num, inc = ops.nms_batch_first(dev(crowd), cc, 0.5, 100, 1200)
+    assert int(inc[0]) == 0 and int(num[0]) == n_full
+    _, num, inc = ops.nms_batch_first(dev(crowd), cc, 0.5, 10, 512)
+    assert int(inc[0]) == 0 and int(num[0]) >= 10

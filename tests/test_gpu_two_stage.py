@@ -375,6 +375,16 @@ def test_anchor_two_stage_engine_matches_the_module_composition(hip):
         if len(x) and len(y):
             d = np.abs(x[:, None, :] - y[None, :, :]).max(-1).min(1)
             assert (d <= 2e-3).mean() >= 0.8, float((d <= 2e-3).mean())
+    # the proposal NMS looks at each frame's first max(512, 4 x NMS_POST_MAXSIZE) candidates (cpd_nms_batch_first); 64 candidates cannot hold
+    # 200 survivors, so the `incomplete` word sends the step through the full NMS -- and all of the anchors is the full NMS itself: the
+    # same RoIs bit for bit, three ways
+    base = (it["rois"].clone(), it["roi_scores"].clone(), it["roi_labels"].clone())
+    for rows, reruns in ((64, 1), (1 << 20, 0)):
+        rpn.proposal_first_rows, rpn.proposal_full_reruns = rows, 0
+        _, it_r = eng.forward(clouds, return_intermediates=True)
+        assert rpn.proposal_full_reruns == reruns, (rows, rpn.proposal_full_reruns)
+        assert torch.equal(it_r["rois"], base[0]) and torch.equal(it_r["roi_scores"], base[1]) and torch.equal(it_r["roi_labels"], base[2])
+    rpn.proposal_first_rows = None
     # ... and through the model's own to_engine() in the default arithmetic
     eng2 = net.to_engine()
     assert type(eng2.rpn).__name__ == "AnchorPointEngine"
