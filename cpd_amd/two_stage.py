@@ -92,10 +92,12 @@ class VoxelRCNNEngine:
         sboxes, ranked, slabels, n_ok = ops.rank_scores(cls, boxes, roi_labels, pp["SCORE_THRESH"], int(nms["NMS_PRE_MAXSIZE"]))
         keep, num_keep = ops.nms_batch(sboxes, n_ok, float(nms["NMS_THRESH"]))
         post = min(int(nms["NMS_POST_MAXSIZE"]), n_roi)
-        fb, fs, fl, fn = ops.select_boxes(sboxes, ranked, slabels, keep, num_keep, post, label_offset=0)
-        ns = fn.tolist()                                                 # the stage's one read-back
-        if self.host_results:
-            fb, fs, fl = fb.cpu(), fs.cpu(), fl.cpu()
+        fb, fs, fl, fn, blk = ops.select_boxes(sboxes, ranked, slabels, keep, num_keep, post, label_offset=0, packed=True)
+        if self.host_results:                                            # counts + boxes + scores + labels: one block, one copy
+            hdr, fb, fs, fl = ops.unpack_boxes(blk.cpu(), blk._cpd_layout)
+            ns = hdr.tolist()
+        else:
+            ns = fn.tolist()                                             # the stage's one read-back
         out = [{"pred_boxes": fb[b, :ns[b]], "pred_scores": fs[b, :ns[b]], "pred_labels": fl[b, :ns[b]]} for b in range(batch)]
         if return_intermediates:
             return out, dict(rois=rois, roi_labels=roi_labels, roi_scores=torch.where(valid, os_[:, :n_roi], os_.new_zeros(())), batch_box_preds=boxes,
