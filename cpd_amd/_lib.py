@@ -86,6 +86,7 @@ SIGNATURES = {
     "cpd_nms_normal": (_I, [_VP, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_nms_batch": (_I, [_VP, _VP, _I, _I, _F, _I, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_nms_batch_first": (_I, [_VP, _VP, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_nms_batch_where": (_I, [_VP, _VP, _VP, _I, _I, _F, _I, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_rank_scores": (_I, [_VP, _I, _VP, _VP, _I, _I, _F, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "cpd_select_boxes": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "cpd_boxes_iou_bev_cpu": (_I, [_VP, _I, _VP, _I, _VP]),

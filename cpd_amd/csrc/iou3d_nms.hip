@@ -69,8 +69,9 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const float *__restrict__
 template <bool NORMAL>
 __global__ void __launch_bounds__(256) nms_mask_kernel(const float *__restrict__ boxes_all, const int32_t *__restrict__ counts,
                                                        int n_host, int cap, int box_cap, float thr,
-                                                       unsigned long long *__restrict__ mask_all) {
+                                                       unsigned long long *__restrict__ mask_all, const int32_t *__restrict__ only_if) {
     const int smp = blockIdx.z;
+    if (only_if && !only_if[smp]) return;          // (cpd_nms_batch_where: samples whose flag is 0 keep what they have)
     const int n = counts ? min(counts[smp], cap) : n_host;
     const int cb = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,9 +115,10 @@ template <bool LDS>
 __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *__restrict__ mask_all,
                                                       const int32_t *__restrict__ counts, int n_host, int cap, int keep_cap, int max_keep,
                                                       long long *__restrict__ keep_all, int *__restrict__ num_keep,
-                                                      int *__restrict__ incomplete) {
+                                                      int *__restrict__ incomplete, const int32_t *__restrict__ only_if) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_mask[];
     const int smp = blockIdx.x;
+    if (only_if && !only_if[smp]) return;
     const int n = counts ? min(counts[smp], cap) : n_host;
     const int lane = threadIdx.x;
     const int ncb_cap = (cap + 63) >> 6;
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *
 // `lim` = boxes per sample the mask covers (cap: all of them), `max_keep` = survivors wanted (INT_MAX: all), see nms_scan_kernel
 static int nms_impl(bool normal, const float *boxes, const int32_t *counts, int batch, int cap, float thr, int64_t *keep,
                     int32_t *num_keep, void *ws, size_t ws_bytes, hipStream_t s, int lim = -1, int max_keep = 0x7fffffff,
-                    int32_t *incomplete = nullptr) {
+                    int32_t *incomplete = nullptr, const int32_t *only_if = nullptr) {
     if (cap < 0 || batch <= 0 || !keep || !num_keep || (cap > 0 && (!boxes || !ws))) return CPD_ERR_ARG;
     if (cap > 64 * 64 * 8) return CPD_ERR_UNSUPPORTED;
     if (cap == 0) {
@@ -185,13 +187,13 @@ static int nms_impl(bool normal, const float *boxes, const int32_t *counts, int 
     const int ncb = (mcap + 63) / 64;
     unsigned long long *mask = (unsigned long long *)ws;
     dim3 grid(ncb, (mcap + 3) / 4, batch);
-    if (normal) nms_mask_kernel<true><<<grid, 256, 0, s>>>(boxes, counts, mcap, mcap, cap, thr, mask);
-    else nms_mask_kernel<false><<<grid, 256, 0, s>>>(boxes, counts, mcap, mcap, cap, thr, mask);
+    if (normal) nms_mask_kernel<true><<<grid, 256, 0, s>>>(boxes, counts, mcap, mcap, cap, thr, mask, only_if);
+    else nms_mask_kernel<false><<<grid, 256, 0, s>>>(boxes, counts, mcap, mcap, cap, thr, mask, only_if);
     const size_t lds = (size_t)mcap * ncb * 8;
     if (lds <= 64 * 1024)
-        nms_scan_kernel<true><<<batch, 64, lds, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete);
+        nms_scan_kernel<true><<<batch, 64, lds, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete, only_if);
     else
-        nms_scan_kernel<false><<<batch, 64, 0, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete);
+        nms_scan_kernel<false><<<batch, 64, 0, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete, only_if);
     return cpd_check_launch();
 }
 
@@ -308,6 +310,12 @@ extern "C" int cpd_nms_batch_first(const float *boxes, const int32_t *counts, in
     if (!counts || !incomplete || max_keep <= 0 || row_limit <= 0) return CPD_ERR_ARG;
     return nms_impl(normal != 0, boxes, counts, batch, capacity, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream), row_limit,
                     max_keep, incomplete);
+}
+extern "C" int cpd_nms_batch_where(const float *boxes, const int32_t *counts, const int32_t *where, int batch, int capacity, float thresh,
+                                   int normal, int64_t *keep, int32_t *num_keep, void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
+    if (!counts || !where || capacity <= 0) return CPD_ERR_ARG;
+    return nms_impl(normal != 0, boxes, counts, batch, capacity, thresh, keep, num_keep, workspace, workspace_bytes, cpd_s(stream), -1,
+                    0x7fffffff, nullptr, where);
 }
 extern "C" int cpd_select_boxes(const float *boxes, const float *scores, const int32_t *labels, const int64_t *keep,
                                 const int32_t *num_keep, int batch, int capacity, int post_max, int label_offset,

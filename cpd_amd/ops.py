@@ -617,6 +617,17 @@ def nms_batch_first(boxes, counts, thresh, max_keep, row_limit, normal=False):
     return keep, num, inc
 
 
+def nms_batch_where(boxes, counts, where, thresh, keep, num_keep, normal=False):
+    """nms_batch for the samples whose `where` word (device i32 [batch]) is non-zero, written into the given keep / num_keep; the other
+    samples keep theirs (cpd_nms_batch_where): the device-side fallback of nms_batch_first, no read-back in between."""
+    boxes = boxes.contiguous()
+    batch, cap = boxes.shape[0], boxes.shape[1]
+    ws = torch.empty(batch * lib().cpd_nms_workspace_bytes(cap), dtype=torch.uint8, device=boxes.device)
+    check(lib().cpd_nms_batch_where(ptr(boxes), ptr(counts), ptr(where), batch, cap, float(thresh), 1 if normal else 0, ptr(keep), ptr(num_keep),
+                                    ptr(ws), ws.numel(), stream()), "cpd_nms_batch_where")
+    return keep, num_keep
+
+
 def rank_scores(cls, boxes, labels, score_thresh, pre_max, normalized=False):
     """post_processing's score pipeline for a batch in one launch (cpd_rank_scores): cls [B, R, C] logits (scores when `normalized`),
     boxes [B, R, 7], labels [B, R] i64 -> (boxes, scores, labels i32) ranked by max-class sigmoid score descending (ties: lower index),

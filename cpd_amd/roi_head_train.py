@@ -332,7 +332,7 @@ class VoxelRCNNProtoHead(nn.Module):
         if batch_dict.get("rois", None) is not None:
             return batch_dict
         rois, scores, labels, _ = rp.proposal_layer(batch_dict["batch_box_preds"], batch_dict["batch_cls_preds"], nms_config["NMS_THRESH"],
-                                                    nms_config["NMS_PRE_MAXSIZE"], nms_config["NMS_POST_MAXSIZE"])
+                                                    nms_config["NMS_PRE_MAXSIZE"], nms_config["NMS_POST_MAXSIZE"], first_rows="auto", device_fallback=True)
         batch_dict.update(rois=rois, roi_scores=scores, roi_labels=labels, has_class_labels=batch_dict["batch_cls_preds"].shape[-1] > 1)
         return batch_dict
 

@@ -342,7 +342,7 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
     return torch.cat(pooled, dim=-1)
 
 
-def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize, nms_post_maxsize, first_rows=None):
+def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize, nms_post_maxsize, first_rows=None, device_fallback=False):
     """RoIHeadTemplate.proposal_layer (cpd/models/roi_heads/roi_head_template.py:53-114) for dense
     (B, N, 7+C) / (B, N, num_class) predictions with class-agnostic rotated NMS
     (model_nms_utils.class_agnostic_nms, l.115-134): per sample max class score -> top NMS_PRE_MAXSIZE ->
@@ -353,7 +353,12 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize
     `first_rows` = R (engines; round 5): only the first NMS_POST_MAXSIZE survivors are kept, and greedy suppression decides a box from the
     boxes before it -- the NMS runs over each sample's first R candidates (ops.nms_batch_first: R^2 / 2 IoUs instead of 4096^2 / 2, the
     scan stops at the NMS_POST_MAXSIZE-th survivor) and a fifth value comes back, `incomplete` [B] i32: 1 where a sample found fewer than
-    NMS_POST_MAXSIZE survivors among its first R -- the caller reads it with the counts and calls again without `first_rows`."""
+    NMS_POST_MAXSIZE survivors among its first R -- the caller reads it with the counts and calls again without `first_rows`.
+    `device_fallback=True` (callers without a read-back: the module path): the full NMS of exactly those samples is queued right behind
+    (ops.nms_batch_where, predicated on the device word) and four values come back as without `first_rows` -- the same answer as the
+    full call, at the cost of a launch of empty workgroups when no sample needs it. `first_rows="auto"` = max(512, 4 x NMS_POST_MAXSIZE)."""
+    if first_rows == "auto":
+        first_rows = max(512, 64 * ((4 * int(nms_post_maxsize) + 63) // 64))
     b, n, cdim = batch_box_preds.shape
     scores, labels = torch.max(batch_cls_preds, dim=-1)                       # l.94
     k = min(int(nms_pre_maxsize), n)
@@ -362,7 +367,10 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize
     counts = torch.full((b,), k, dtype=torch.int32, device=boxes.device)
     incomplete = None
     if first_rows is not None and int(first_rows) < k:
-        keep, num_keep, incomplete = ops.nms_batch_first(boxes[:, :, :7].contiguous(), counts, nms_thresh, int(nms_post_maxsize), int(first_rows))
+        b7 = boxes[:, :, :7].contiguous()
+        keep, num_keep, incomplete = ops.nms_batch_first(b7, counts, nms_thresh, int(nms_post_maxsize), int(first_rows))
+        if device_fallback:
+            ops.nms_batch_where(b7, counts, incomplete, nms_thresh, keep, num_keep)
     else:
         keep, num_keep = ops.nms_batch(boxes[:, :, :7].contiguous(), counts, nms_thresh)
     top_labels = torch.gather(labels, 1, order).int().contiguous()
@@ -375,7 +383,7 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize
     roi_labels = torch.where(valid, roi_labels, torch.ones_like(roi_labels))
     if cdim > 7:
         raise NotImplementedError("7+C box codes (velocity ...) are not used by the CPD configs")
-    if first_rows is not None:
+    if first_rows is not None and not device_fallback:
         return rois7, roi_scores, roi_labels, kept, (incomplete if incomplete is not None else torch.zeros_like(kept))
     return rois7, roi_scores, roi_labels, kept
 
@@ -467,7 +475,8 @@ class VoxelRCNNHead(nn.Module):
             # the anchor-head configs (voxel_rcnn_dbscan / oyster) reach the RoI head this way; CenterHead already left `rois` behind
             nms = self.model_cfg["NMS_CONFIG"]["TEST"]
             rois7, roi_scores, roi_labels, _ = proposal_layer(batch_dict["batch_box_preds"], batch_dict["batch_cls_preds"], float(nms["NMS_THRESH"]),
-                                                              int(nms["NMS_PRE_MAXSIZE"]), int(nms["NMS_POST_MAXSIZE"]))
+                                                              int(nms["NMS_PRE_MAXSIZE"]), int(nms["NMS_POST_MAXSIZE"]),
+                                                              first_rows="auto", device_fallback=True)
             batch_dict.update(rois=rois7, roi_scores=roi_scores, roi_labels=roi_labels,
                               has_class_labels=batch_dict["batch_cls_preds"].shape[-1] > 1)
         rois, b = batch_dict["rois"], batch_dict["batch_size"]

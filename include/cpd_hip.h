@@ -372,6 +372,12 @@ int cpd_nms_batch(const float *boxes, const int32_t *counts, int batch, int capa
 int cpd_nms_batch_first(const float *boxes, const int32_t *counts, int batch, int capacity, float thresh,
                         int normal, int max_keep, int row_limit, int64_t *keep, int32_t *num_keep,
                         int32_t *incomplete, void *workspace, size_t workspace_bytes, cpd_stream_t stream);
+/* ... and the full call for exactly the samples that asked for it, without a host read-back in between: cpd_nms_batch over the
+ * samples b with where[b] != 0 (a device array, e.g. cpd_nms_batch_first's `incomplete`); the others keep their keep / num_keep.
+ * The launch costs its empty workgroups when no sample asks (measured: DESIGN 5h).                                              */
+int cpd_nms_batch_where(const float *boxes, const int32_t *counts, const int32_t *where, int batch,
+                        int capacity, float thresh, int normal, int64_t *keep, int32_t *num_keep,
+                        void *workspace, size_t workspace_bytes, cpd_stream_t stream);
 /* The score half of Detector3DTemplate.post_processing (cpd/models/detectors/detector3d_template.py:222-343, MULTI_CLASSES_NMS False) and of
  * class_agnostic_nms (cpd/models/model_utils/model_nms_utils.py:113-124) for a whole batch in one launch: per frame, score = max over the
  * n_cls columns of sigmoid(cls) (of cls itself when normalized != 0), rows with score >= score_thresh ranked by score descending (ties: lower

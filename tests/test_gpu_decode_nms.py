@@ -176,3 +176,30 @@ def test_nms_first_survivors_equal_the_full_scan(oracle, hip, golden):
     assert int(inc[0]) == 0 and int(num[0]) == n_full
     _, num, inc = ops.nms_batch_first(dev(crowd), cc, 0.5, 10, 512)
     assert int(inc[0]) == 0 and int(num[0]) >= 10
+
+
+def test_nms_device_fallback_completes_the_flagged_samples(hip):
+    """cpd_nms_batch_where: the full scan for exactly the samples cpd_nms_batch_first flagged, queued behind it without a read-back -- the
+    pair returns cpd_nms_batch's first max_keep survivors for every sample; unflagged samples keep their early-exit answer."""
+    rng = np.random.default_rng(11)
+    cap, max_keep, rows = 1500, 100, 256
+    bb = np.zeros((3, cap, 7), np.float32)
+    b0, s0 = random_boxes(1, cap, span=60.0)                     # sparse: 100 survivors within the first 256
+    bb[0] = b0[np.argsort(-s0, kind="stable")]
+    base, _ = random_boxes(2, 30, span=60.0)
+    bb[1, :1200] = np.repeat(base, 40, axis=0)                    # 30 survivors among 1200: flagged
+    b2, s2 = random_boxes(3, 200, span=40.0)
+    bb[2, :200] = b2[np.argsort(-s2, kind="stable")]              # fewer boxes than the mask covers: complete by construction
+    counts = torch.tensor([cap, 1200, 200], dtype=torch.int32, device="cuda")
+    dbb = dev(bb)
+    full_keep, full_num = ops.nms_batch(dbb, counts, 0.5)
+    keep, num, inc = ops.nms_batch_first(dbb, counts, 0.5, max_keep, rows)
+    assert inc.tolist() == [0, 1, 0]
+    early0 = (keep[0].clone(), int(num[0]))
+    ops.nms_batch_where(dbb, counts, inc, 0.5, keep, num)
+    assert torch.equal(keep[0], early0[0]) and int(num[0]) == early0[1]           # untouched
+    for i in range(3):
+        k = min(int(full_num[i]), max_keep)
+        assert min(int(num[i]), max_keep) == k
+        np.testing.assert_array_equal(keep[i, :k].cpu().numpy(), full_keep[i, :k].cpu().numpy())
+    assert int(num[1]) == int(full_num[1])                                        # the flagged sample got the full answer
