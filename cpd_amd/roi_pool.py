@@ -377,8 +377,10 @@ def proposal_layer(batch_box_preds, batch_cls_preds, nms_thresh, nms_pre_maxsize
     rois7, roi_scores, roi_labels, kept = ops.select_boxes(boxes[:, :, :7].contiguous(), top_scores.contiguous(), top_labels, keep,
                                                            num_keep, int(nms_post_maxsize), label_offset=1)
     valid = torch.arange(int(nms_post_maxsize), device=boxes.device)[None, :] < kept[:, None]
-    rois7 = rois7 * valid[..., None]
-    roi_scores = roi_scores * valid
+    # zero slots past a sample's count by SELECTION: cpd_select_boxes never wrote them (stale allocator bytes, possibly NaN bit patterns,
+    # and NaN * 0 is NaN -- the hazard ADVICE r4 found in two_stage.py)
+    rois7 = torch.where(valid[..., None], rois7, rois7.new_zeros(()))
+    roi_scores = torch.where(valid, roi_scores, roi_scores.new_zeros(()))
     # the reference adds 1 to EVERY slot of its zero-initialised buffer (roi_head_template.py:111): padded slots carry label 1
     roi_labels = torch.where(valid, roi_labels, torch.ones_like(roi_labels))
     if cdim > 7:
