@@ -397,7 +397,7 @@ def module_api_runner(cfg, sd, dev, clouds, conv_math):
     contract, state_dict names) runs in eval mode under no_grad, results are copied to the host like the engine's."""
     from cpd_amd import models
     from cpd_amd import spconv as sp
-    sp.install(conv_math=conv_math)
+    sp.install(conv_math=conv_math, row_order="taps" if cfg.row_order == "taps" else "canonical")      # (the engine's row order, opt-in for modules)
     net = models.CenterPoint(point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size).to(dev).eval()
     net.load_state_dict(sd)
     vox = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features, cfg.max_points_per_voxel, cfg.max_voxels,
@@ -569,7 +569,7 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
     run = module_api_runner(cfg, sd, dev, clouds, cfg.conv_math)
     sec = time_steps(lambda i: run([clouds[(i * B + j) % POOL] for j in range(B)]), 6, 2)
     out["module_api"] = {"value": B / sec, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 6, "ratio_to_engine": B / sec / value,
-                         "note": "device voxelizer -> batch_dict -> cpd_amd.models.CenterPoint (eval, no_grad; canonical row order, "
+                         "note": "device voxelizer -> batch_dict -> cpd_amd.models.CenterPoint (eval, no_grad; the row order of --row-order (tap-pattern by default: spconv.install(row_order=...)), "
                                  "first-appearance voxel order as at the B1 boundary), results copied to the host"}
     return out
 

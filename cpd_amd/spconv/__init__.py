@@ -13,15 +13,19 @@ from .pytorch import (SparseConv3d, SparseConvTensor, SparseInverseConv3d, Spars
 __version__ = "2.1.22+cpd_amd"
 
 
-def install(conv_math=None):
+def install(conv_math=None, row_order=None):
     """conv_math: package default for modules built without their own (`"f32"` | `"f16x2"` | `"bf16x3"`,
     cpd_amd.spconv.pytorch.conv.set_default_conv_math; also CPD_CONV_MATH).
+    row_order: `"canonical"` (default) | `"taps"` -- the row order of the levels strided SparseConv3d layers produce
+    (cpd_amd.spconv.pytorch.conv.set_default_row_order; also CPD_ROW_ORDER).
     Make `import spconv`, `import spconv.pytorch`, `from spconv.pytorch.utils import PointToVoxel`,
     `from spconv.utils import Point2VoxelCPU3d` and `import cumm.tensorview as tv` resolve to this
     package (only if the real spconv is absent)."""
     me = sys.modules[__name__]
     if conv_math is not None:
         pytorch.conv.set_default_conv_math(conv_math)
+    if row_order is not None:
+        pytorch.conv.set_default_row_order(row_order)
     for name, mod in {"spconv": me, "spconv.pytorch": pytorch, "spconv.pytorch.conv": pytorch.conv,
                       "spconv.pytorch.utils": pytorch.utils, "spconv.utils": utils}.items():
         sys.modules.setdefault(name, mod)

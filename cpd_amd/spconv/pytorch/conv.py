@@ -33,6 +33,26 @@ def default_conv_math():
     return _DEFAULT_CONV_MATH[0]
 
 
+# Row order of the levels a strided 3 x 3 x 3 SparseConv3d produces: "canonical" = ascending (b, z, y, x) (the default: what a caller
+# who reads `indices` sees is the documented order), "taps" = every chunk of 4096 canonical rows sorted by sub-manifold neighbour
+# pattern (ops.order_rows_by_taps; the engine's order, DESIGN 4.1 "row order of the strided levels"): the SubM layers that follow skip
+# (16-row group, tap) pairs nearly exactly. Any order is a valid sparse tensor -- spconv's own is a hash order --; features, indices,
+# rulebooks, the level's site index (and through it HeightCompression, the RoI pooling's queries and the transposed rulebooks of the
+# backward pass) all follow. `cpd_amd.spconv.install(row_order="taps")`, set_default_row_order() or CPD_ROW_ORDER.
+_DEFAULT_ROW_ORDER = [os.environ.get("CPD_ROW_ORDER", "canonical")]
+ROW_ORDER_MIN_ROWS = 65536            # below this a level does not fill the chip either way (ModelConfig.row_order_min_rows)
+ROW_ORDER_CHUNK = 4096
+
+
+def set_default_row_order(order):
+    assert order in ("canonical", "taps"), order
+    _DEFAULT_ROW_ORDER[0] = order
+
+
+def default_row_order():
+    return _DEFAULT_ROW_ORDER[0]
+
+
 def fold_batchnorm(bn, conv_bias=None):
     """Eval-mode BatchNorm (+ the preceding conv's bias) as the conv epilogue's per-channel (scale, shift), cached on the
     BatchNorm module until one of its tensors (or the bias) changes."""
@@ -128,16 +148,26 @@ class SparseConvolution(SparseModule):
         cached = x.find_indice_pair(self.indice_key)
         if self.subm:
             if cached is None:
-                nbr = ops.rulebook_subm(x.indices.contiguous(), x.site_index(), self.kernel_size)
-                cached = dict(nbr=nbr, out_indices=x.indices, out_shape=x.spatial_shape, out_index=x.site_index())
+                # (a chunk-ordered level -- row order "taps" -- carries its canonical list: the table is then built chunk-wise)
+                nbr = ops.rulebook_subm(x.indices.contiguous(), x.site_index(), self.kernel_size, canonical=getattr(x, "_row_canon", None))
+                cached = dict(nbr=nbr, out_indices=x.indices, out_shape=x.spatial_shape, out_index=x.site_index(),
+                              canon=getattr(x, "_row_canon", None))
                 if self.indice_key is not None:
                     x.indice_dict[self.indice_key] = cached
         else:
             if cached is None:
-                out_idx, out_index, out_shape = ops.conv_outset(x.indices.contiguous(), x.batch_size, x.spatial_shape,
-                                                                self.kernel_size, self.stride, self.padding)
-                nbr = ops.rulebook_conv(out_idx, x.site_index(), self.kernel_size, self.stride, self.padding)
-                cached = dict(nbr=nbr, out_indices=out_idx, out_shape=out_shape, out_index=out_index)
+                src = getattr(x, "_row_canon", None)          # the output set is marked from the canonical list where the level has one
+                out_idx, out_index, out_shape = ops.conv_outset((src[0] if src is not None else x.indices).contiguous(), x.batch_size,
+                                                                x.spatial_shape, self.kernel_size, self.stride, self.padding)
+                canon = None
+                if (_DEFAULT_ROW_ORDER[0] == "taps" and list(self.kernel_size) == [3, 3, 3] and list(self.stride) == [2, 2, 2]
+                        and out_idx.shape[0] >= ROW_ORDER_MIN_ROWS):
+                    out_c = out_idx
+                    out_idx, _, old_to_new = ops.order_rows_by_taps(out_c, out_index, chunk_rows=ROW_ORDER_CHUNK)
+                    out_index.set_order(old_to_new)
+                    canon = (out_c, old_to_new, ROW_ORDER_CHUNK)
+                nbr = ops.rulebook_conv(out_idx, x.site_index(), self.kernel_size, self.stride, self.padding, canonical=canon)
+                cached = dict(nbr=nbr, out_indices=out_idx, out_shape=out_shape, out_index=out_index, canon=canon)
                 if self.indice_key is not None:
                     x.indice_dict[self.indice_key] = cached
         nbr, out_indices = cached["nbr"], cached["out_indices"]
@@ -167,6 +197,7 @@ class SparseConvolution(SparseModule):
         out = SparseConvTensor(out_feats, out_indices, cached["out_shape"], x.batch_size, x.grid, x.benchmark)
         out.indice_dict = x.indice_dict
         out._site_index = cached["out_index"]
+        out._row_canon = cached.get("canon")
         return out
 
 

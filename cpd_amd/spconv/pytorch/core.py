@@ -17,6 +17,7 @@ class SparseConvTensor:
         self.grid = grid
         self.benchmark = benchmark
         self._site_index = None   # SiteIndex of (indices, spatial_shape), built lazily
+        self._row_canon = None    # (canonical site list, old_to_new, chunk) of a level kept in tap-pattern row order (conv.py)
 
     @property
     def spatial_size(self):
@@ -35,6 +36,7 @@ class SparseConvTensor:
         t = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.grid, self.benchmark)
         t.indice_dict = self.indice_dict
         t._site_index = self._site_index
+        t._row_canon = self._row_canon
         return t
 
     def dense(self, channels_first=True):

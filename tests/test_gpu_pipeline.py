@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from cpd_amd import ops
 from cpd_amd.engine import CenterPointEngine, ModelConfig, init_state_dict
 from cpd_amd.synthetic import waymo_cloud
 
@@ -714,3 +715,49 @@ def test_persistent_dense_map_leaves_no_rows_behind(hip):
     after = ea.forward(batches[0])
     for x, y in zip(first, after):
         assert torch.equal(x["pred_boxes"], y["pred_boxes"])
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x2"])
+def test_module_path_in_tap_pattern_row_order_changes_no_result(hip, math):
+    """cpd_amd.spconv.install(row_order="taps"): the levels strided SparseConv3d layers produce are kept in the engine's tap-pattern
+    row order (chunks of 4096 canonical rows sorted by neighbour pattern). A row's sum does not depend on where the row sits, so: every
+    sparse level is the SAME set of (index, feature row) pairs, bit for bit; the BEV map and the detections are identical; and the
+    levels really are re-ordered (their index lists differ from the canonical run's). Full-size cloud, two frames: levels 2 and 3 are
+    above the 65536-row threshold the order applies from."""
+    from cpd_amd import models
+    from cpd_amd import spconv as sp
+    from cpd_amd.spconv.pytorch import conv as spc
+    cfg = ModelConfig()
+    sd = init_state_dict(cfg, seed=4)
+    vox = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features, cfg.max_points_per_voxel, cfg.max_voxels)
+    clouds = [torch.from_numpy(waymo_cloud(s)).cuda() for s in (0, 1)]
+    old_math, old_order = spc.default_conv_math(), spc.default_row_order()
+    outs = {}
+    try:
+        for order in ("canonical", "taps"):
+            sp.install(conv_math=math, row_order=order)
+            net = models.CenterPoint(point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size).cuda().eval()
+            net.load_state_dict(sd)
+            with torch.no_grad():
+                _, coords, _, feats, nvox = vox.batch(clouds)
+                n = int(nvox[2])
+                bd = {"voxel_features": feats[:n].clone(), "voxel_coords": coords[:n].clone(), "batch_size": 2}
+                preds, _ = net(bd)
+            outs[order] = (preds, {k: (t.features.clone(), t.indices.clone()) for k, t in bd["multi_scale_3d_features"].items()},
+                           bd["spatial_features"].clone())
+    finally:
+        spc.set_default_conv_math(old_math); spc.set_default_row_order(old_order)
+    (pa, la, sa), (pb, lb, sb) = outs["canonical"], outs["taps"]
+    assert sum(len(p["pred_boxes"]) for p in pa) > 10
+    for p, q in zip(pa, pb):
+        assert all(torch.equal(p[k], q[k]) for k in ("pred_boxes", "pred_scores", "pred_labels"))
+    assert torch.equal(sa, sb)
+    reordered = 0
+    for name in la:
+        (fa, ia), (fb, ib) = la[name], lb[name]
+        assert ia.shape == ib.shape
+        key = lambda i: ((i[:, 0].long() * 64 + i[:, 1]) * 2048 + i[:, 2]) * 2048 + i[:, 3]
+        oa, ob = torch.argsort(key(ia)), torch.argsort(key(ib))
+        assert torch.equal(ia[oa], ib[ob]) and torch.equal(fa[oa], fb[ob]), name
+        reordered += int(not torch.equal(ia, ib))
+    assert reordered >= 2, "no level was re-ordered: the comparison would be vacuous"
