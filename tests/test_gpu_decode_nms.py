@@ -203,3 +203,25 @@ def test_nms_device_fallback_completes_the_flagged_samples(hip):
         assert min(int(num[i]), max_keep) == k
         np.testing.assert_array_equal(keep[i, :k].cpu().numpy(), full_keep[i, :k].cpu().numpy())
     assert int(num[1]) == int(full_num[1])                                        # the flagged sample got the full answer
+
+
+def test_select_boxes_packed_block_round_trips(hip):
+    """ops.select_boxes(packed=True): counts (+ extra header words), boxes, scores and labels as views of ONE allocation -- the same values
+    as the four separate tensors, and a host copy of the block cut up by ops.unpack_boxes gives them back (one D2H copy per step)."""
+    g = torch.Generator().manual_seed(3)
+    B, cap, post = 3, 300, 128
+    boxes = torch.randn(B, cap, 7, generator=g).cuda()
+    scores = torch.rand(B, cap, generator=g).cuda()
+    labels = torch.randint(0, 3, (B, cap), generator=g).int().cuda()
+    keep = torch.stack([torch.randperm(cap, generator=g) for _ in range(B)]).cuda()
+    num_keep = torch.tensor([5, 200, 0], dtype=torch.int32, device="cuda")
+    ob, os_, ol, on = ops.select_boxes(boxes, scores, labels, keep, num_keep, post, label_offset=1)
+    pb, ps, pl, pn, blk = ops.select_boxes(boxes, scores, labels, keep, num_keep, post, label_offset=1, packed=True, extra_ints=2)
+    assert pn.tolist() == on.tolist() == [5, 128, 0]
+    lay = blk._cpd_layout
+    hdr, hb, hs, hl = ops.unpack_boxes(blk.cpu(), lay)
+    assert hdr.tolist() == [5, 128, 0, 0, 0]                      # the extra words start at zero
+    for b, n in enumerate(on.tolist()):
+        for dev_t, packed_t, host_t in ((ob, pb, hb), (os_, ps, hs), (ol, pl, hl)):
+            assert torch.equal(dev_t[b, :n], packed_t[b, :n]) and torch.equal(dev_t[b, :n].cpu(), host_t[b, :n])
+    assert hl.dtype == torch.int64 and hb.shape == (B, post, 7)

@@ -75,7 +75,7 @@ first half of the round, before the side streams of §5j, on ITS profile box):
 | same run, `--dense-pairs 0` (fp32 dense maps: the round-4 dense half) | %.1f (pairs: +%.1f %%; other boxes +2.0 %%, +2.2 %%, +2.6 %%, +3.1 %%) | |
 | `--streams 1` / `--streams 3` | %.1f (%.1f under rocprofv3) / %.1f | |
 | `value_host_input` | %.1f (%.3f of `value`) | |
-| `--api modules` / `module_api` | **%.1f / %.1f** [901.5 / 907.1: results now leave with one copy per key] | |
+| `--api modules` / `module_api` | **%.1f / %.1f** [901.5 / 907.1: one result copy per key, levels in tap-pattern order (§5e)] | |
 | `--conv-math bf16x3` / `f32` | %.1f / %.1f | |
 | `--row-order canonical` | %.1f | |
 | `--frames 16` | %.1f | |
