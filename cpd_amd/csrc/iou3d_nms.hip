@@ -111,8 +111,10 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
 // the 64-box block in which the max_keep-th survivor was found (the survivors up to there are exactly the full scan's first ones);
 // `incomplete` (may be NULL): set to 1 when the sample has more boxes than the mask covers and fewer than max_keep survived among those
 // it covers -- the caller then needs the full scan.
+// (round 5) launched with 256 threads when LDS: all four waves copy the mask (16-byte pieces), wave 0 scans -- one wave fetching 32 KB in
+// 8-byte pieces was most of the kernel's 55 us at 500 boxes.
 template <bool LDS>
-__global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *__restrict__ mask_all,
+__global__ void __launch_bounds__(LDS ? 256 : 64) nms_scan_kernel(const unsigned long long *__restrict__ mask_all,
                                                       const int32_t *__restrict__ counts, int n_host, int cap, int keep_cap, int max_keep,
                                                       long long *__restrict__ keep_all, int *__restrict__ num_keep,
                                                       int *__restrict__ incomplete, const int32_t *__restrict__ only_if) {
@@ -126,9 +128,18 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long *
     const unsigned long long *gmask = mask_all + (size_t)smp * cap * ncb_cap;
     long long *keep = keep_all + (size_t)smp * keep_cap;
     if (LDS) {
-        const int total = n * ncb_cap;
-        for (int e = lane; e < total; e += 64) s_mask[e] = gmask[e];
+        const int total = n * ncb_cap;                    // words; the sample's mask starts 16-byte aligned (cap * ncb_cap words per sample, a
+        const int pairs = total >> 1;                     // 256-byte aligned workspace) and so does s_mask
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(gmask);
+        uint4 *s4 = reinterpret_cast<uint4 *>(s_mask);
+        if ((((size_t)cap * ncb_cap) & 1) == 0) {
+            for (int e = threadIdx.x; e < pairs; e += blockDim.x) s4[e] = g4[e];
+            if ((total & 1) && threadIdx.x == 0) s_mask[total - 1] = gmask[total - 1];
+        } else {
+            for (int e = threadIdx.x; e < total; e += blockDim.x) s_mask[e] = gmask[e];
+        }
         __syncthreads();
+        if (threadIdx.x >= 64) return;                    // (no barrier below this point)
     }
     const unsigned long long *mask = LDS ? s_mask : gmask;
     constexpr int MAXW = 8;  // up to 64*64*8 = 32768 boxes
@@ -191,7 +202,7 @@ static int nms_impl(bool normal, const float *boxes, const int32_t *counts, int 
     else nms_mask_kernel<false><<<grid, 256, 0, s>>>(boxes, counts, mcap, mcap, cap, thr, mask, only_if);
     const size_t lds = (size_t)mcap * ncb * 8;
     if (lds <= 64 * 1024)
-        nms_scan_kernel<true><<<batch, 64, lds, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete, only_if);
+        nms_scan_kernel<true><<<batch, 256, lds, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete, only_if);
     else
         nms_scan_kernel<false><<<batch, 64, 0, s>>>(mask, counts, mcap, mcap, cap, max_keep, (long long *)keep, num_keep, incomplete, only_if);
     return cpd_check_launch();
