@@ -44,6 +44,7 @@ rows.append("| `r05_bench_bf16x3.json`, `…f32.json`, `…canonical_rows.json`,
 rows.append("| `r05_bench_16frames.json`, `…4frames.json`, `…4frames_2streams.json`, `…1frame.json` | `--frames 16`; `--frames 4 --streams 1`; `--frames 4`; `--frames 1 --streams 1` | %.1f; **%.1f** (%.2f ms; 737.5 before the side streams); **%.1f** (1009.0); **%.1f (%.2f ms; 3.02)** — DESIGN §5j |" % (g("16frames"), g("4frames"), m("4frames"), g("4frames_2streams"), g("1frame"), m("1frame")))
 rows.append("| `r05_train_bench.json`, `r05_train_kernel_stats.csv`, `r05_train_bench_under_rocprof.json` | `python bench.py --mode train --steps 40 --warmup 10` (sets `GPU_MAX_HW_QUEUES=8`) | **%.2f ms/step = %.1f train frames/s** (9.62 / 104.0 in the first half of the round: index chain on its own stream, `cpd_center_targets`, eight hardware queues — DESIGN §5a); 300-step same-box pairs: 9.74 / 9.90 → 8.78–9.33 |" % (t["ms_per_step"], t["value"]))
 rows.append("| `r05_band_order_probe.txt` | `FRAMES=48 ORDER_SET=band python tools/order_probe.py f16x2` | the row-wave kernels on canonical, band-major ((b, y-band, z, y, x), bands of 8 … 64 lines) and pattern-sorted orders of the three levels — and on a SYNTHETIC rulebook of perfect locality (`LOCAL`): 932.7 → 910.7, 1140.5 → 1110.2, 1534.6 → 1494.7 µs. L2 misses are worth 2.5 % of these kernels: DESIGN §8.1 |")
+rows.append("| `r05_local_pmc.txt` | `tools/local_pmc.sh` (six `--pmc` passes of `tools/local_probe_one.py` per level and variant) | the counters behind the row above: real vs perfect-locality rulebook, 32 ch: L2 hit 0.826 → 0.867, fabric fetch 1793 → 1233 MB, TD busy 0.94 / 0.93, L1 accesses and L1 → L2 reads identical, **1015.5 vs 1026.8 µs**; 128 ch: 0.828 → 0.880, 2454 → 1573 MB, 1791.3 vs 1783.1 µs |")
 rows.append("| `r05_1frame_timeline.txt` | `rocprofv3 --kernel-trace … bench.py --frames 1 --streams 1`, then `tools/trace_gaps.py … --between select_boxes_kernel 30 60` + one step kernel by kernel (queue, start µs, duration µs) | the one-frame step under the tracer (3.29 ms; 2.7–2.8 untraced): main queue 2.42 ms of kernels per step, the index queue 0.57 ms running beside the convolutions of the stage before; what is left on the main queue: 17 × `split_finish`, the decode / NMS tail, the shared conv on the table path |")
 table = "| file | command | what to read |\n|---|---|---|\n" + "\n".join(rows) + "\n"
 
