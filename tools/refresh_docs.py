@@ -43,6 +43,7 @@ rows.append("| `r05_bench_streams1.json`, `…streams3.json` | `--streams 1 | 3`
 rows.append("| `r05_bench_bf16x3.json`, `…f32.json`, `…canonical_rows.json`, `…device_results.json`, `…modules.json` | one flag each | %.1f / %.1f / %.1f / %.1f / %.1f |" % tuple(g(n) for n in ("bf16x3", "f32", "canonical_rows", "device_results", "modules")))
 rows.append("| `r05_bench_16frames.json`, `…4frames.json`, `…4frames_2streams.json`, `…1frame.json` | `--frames 16`; `--frames 4 --streams 1`; `--frames 4`; `--frames 1 --streams 1` | %.1f; **%.1f** (%.2f ms; 737.5 before the side streams); **%.1f** (1009.0); **%.1f (%.2f ms; 3.02)** — DESIGN §5j |" % (g("16frames"), g("4frames"), m("4frames"), g("4frames_2streams"), g("1frame"), m("1frame")))
 rows.append("| `r05_train_bench.json`, `r05_train_kernel_stats.csv`, `r05_train_bench_under_rocprof.json` | `python bench.py --mode train --steps 40 --warmup 10` (sets `GPU_MAX_HW_QUEUES=8`) | **%.2f ms/step = %.1f train frames/s** (9.62 / 104.0 in the first half of the round: index chain on its own stream, `cpd_center_targets`, eight hardware queues — DESIGN §5a); 300-step same-box pairs: 9.74 / 9.90 → 8.78–9.33 |" % (t["ms_per_step"], t["value"]))
+rows.append('| `r05_rowwave_pmc.json` | `tools/pmc_rowwave.sh r05` (13 `--pmc` passes of the default bench, one counter block each) | the row-wave kernels at the end of the round (unchanged since round 4: the reference set for the §8.1 discussion) — `<32,2>` / `<64,2>` / `<128,2>`: 917 / 1005 / 1185 µs, MFMA busy 0.23 / 0.37 / 0.46, waves per CU 25.7 / 17.7 / 10.3, TD busy **0.96 / 0.89 / 0.72**, TA busy 0.80 / 0.64 / 0.44, L1 hit 0.54 / 0.53 / 0.53 (L1 latency 62 / 46 / 36 cycles per access), L2 hit 0.79 / 0.80 / 0.78 (L2 read latency 305 / 259 / 233 cycles), wave cycles waiting 0.47 / 0.44 / 0.30, issue-stalled 0.34 / 0.33 / 0.44, 2.91 / 2.77 / 2.85 GB per launch |')
 rows.append("| `r05_band_order_probe.txt` | `FRAMES=48 ORDER_SET=band python tools/order_probe.py f16x2` | the row-wave kernels on canonical, band-major ((b, y-band, z, y, x), bands of 8 … 64 lines) and pattern-sorted orders of the three levels — and on a SYNTHETIC rulebook of perfect locality (`LOCAL`): 932.7 → 910.7, 1140.5 → 1110.2, 1534.6 → 1494.7 µs. L2 misses are worth 2.5 % of these kernels: DESIGN §8.1 |")
 rows.append("| `r05_local_pmc.txt` | `tools/local_pmc.sh` (six `--pmc` passes of `tools/local_probe_one.py` per level and variant) | the counters behind the row above: real vs perfect-locality rulebook, 32 ch: L2 hit 0.826 → 0.867, fabric fetch 1793 → 1233 MB, TD busy 0.94 / 0.93, L1 accesses and L1 → L2 reads identical, **1015.5 vs 1026.8 µs**; 128 ch: 0.828 → 0.880, 2454 → 1573 MB, 1791.3 vs 1783.1 µs |")
 rows.append("| `r05_1frame_timeline.txt` | `rocprofv3 --kernel-trace … bench.py --frames 1 --streams 1`, then `tools/trace_gaps.py … --between select_boxes_kernel 30 60` + one step kernel by kernel (queue, start µs, duration µs) | the one-frame step under the tracer (3.29 ms; 2.7–2.8 untraced): main queue 2.42 ms of kernels per step, the index queue 0.57 ms running beside the convolutions of the stage before; what is left on the main queue: 17 × `split_finish`, the decode / NMS tail, the shared conv on the table path |")
