@@ -528,36 +528,30 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
     # the other shipped two-stage family (voxel_rcnn_dbscan / oyster_single_train.yaml): AnchorHeadSingleV2 proposals (6 anchors per BEV
     # cell, occupancy-masked, NMS 0.8 -> 200 RoIs per frame) -> VoxelRCNNHead -> NMS 0.3 (cpd_amd/anchor_engine.py + two_stage.py)
     try:
-        from cpd_amd import anchor_head, models
-        from cpd_amd.anchor_engine import AnchorPointEngine, dbscan_dense_head_cfg
+        from cpd_amd.anchor_engine import AnchorPointEngine, synthetic_two_stage_state
         from cpd_amd.two_stage import VoxelRCNNEngine
-        import numpy as _np
-        mcfg = models.waymo_voxel_rcnn_dbscan_cfg()
-        torch.manual_seed(1)
-        grid = _np.array(ops.voxel_grid_size(cfg.voxel_size, cfg.point_cloud_range)[::-1])
-        dh = anchor_head.AnchorHeadSingleV2(dbscan_dense_head_cfg(), input_channels=sum(cfg.bev_num_upsample_filters), num_class=cfg.num_class,
-                                            class_names=["Vehicle", "Pedestrian", "Cyclist"], grid_size=grid, point_cloud_range=cfg.point_cloud_range)
-        with torch.no_grad():
-            for br in dh.BRANCHES:
-                getattr(dh, br)[0].weight.normal_(0, (2.0 / (9 * 64)) ** 0.5)
-            dh.conv_cls[3].weight.normal_(0, 0.5)
-        a_sd = {k: v for k, v in sd.items() if not k.startswith("dense_head.")}
-        a_sd.update({"dense_head." + k: v.detach().clone() for k, v in dh.state_dict().items()})
-        a_sd.update({"roi_head." + k: v.detach().clone() for k, v in
-                     models.__all__["VoxelRCNNHead"](input_channels={"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 128},
-                                                      model_cfg=mcfg.ROI_HEAD, point_cloud_range=cfg.point_cloud_range,
-                                                      voxel_size=cfg.voxel_size, num_class=1).state_dict().items()})
+        mcfg, a_sd = synthetic_two_stage_state(cfg, sd, seed=1)
         rpn = AnchorPointEngine(cfg, a_sd, mcfg.DENSE_HEAD, mcfg.ROI_HEAD.NMS_CONFIG["TEST"], device=dev)
         two = VoxelRCNNEngine(cfg, mcfg.ROI_HEAD, mcfg.POST_PROCESSING, a_sd, device=dev, host_results=not args.device_results, rpn=rpn)
         fb = min(B, 16)
-        last = [None]
+        last, kept = [None], {}
 
         def anchor_step(i):
             last[0] = two.forward([clouds[(i * fb + j) % POOL] for j in range(fb)])
+            kept[i] = last[0]
         sec = time_steps(anchor_step, 4, 2)
         res = last[0]
         _, it = two.forward([clouds[j % POOL] for j in range(fb)], return_intermediates=True)
+        # results digest, after the clock stopped: every timed step's final detections and the first timed step once more --
+        # bit-identical or the figure is not printed as repeatable; the full-size parity test of this very model (same state dict builder)
+        # is tests/test_gpu_two_stage.py::test_full_size_anchor_two_stage_engine_matches_the_oracle_composition
+        from cpd_amd.digest import step_digest
+        dig = {i: step_digest(r) for i, r in sorted(kept.items()) if i >= 2}
+        again = step_digest(two.forward([clouds[(2 * fb + j) % POOL] for j in range(fb)]))
         out["value_two_stage_anchor"] = {"value": fb / sec, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 4, "frames_per_step": fb,
+                                         "results_digest": {"timed_steps": [dig[i][2] for i in sorted(dig)], "boxes_per_frame_step0": dig[2][0],
+                                                            "step0_rerun": again[2], "repeatable": again[2] == dig[2][2]},
+                                         "proposal_full_reruns": int(getattr(rpn, "proposal_full_reruns", 0)),
                                          "rois_per_frame": it["rois"].shape[1], "anchors_per_frame": int(rpn.last_dense["batch_cls_preds"].shape[1]),
                                          "final_boxes_per_frame": sum(len(r["pred_boxes"]) for r in res) / fb,
                                          "note": "VoxelRCNN of the dbscan / oyster configs: AnchorHeadSingleV2 first stage (fp32 dense maps, occupancy-masked "

@@ -23,6 +23,8 @@ from .engine import CenterPointEngine, ModelConfig
 
 
 class AnchorPointEngine(CenterPointEngine):
+    pad_label = 1                          # roi_head_template.py:111: `roi_labels + 1` on every slot of the zero buffer, padded ones included
+
     def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], head_cfg, nms_cfg, class_names=("Vehicle", "Pedestrian", "Cyclist"),
                  device="cuda", host_results=False):
         self.head_cfg, self.nms_cfg, self.class_names = head_cfg, nms_cfg, list(class_names)
@@ -111,6 +113,30 @@ class AnchorPointEngine(CenterPointEngine):
             self._cur_points = None
 
     __call__ = forward
+
+
+def synthetic_two_stage_state(cfg: ModelConfig, sd, seed=1):
+    """Random-init parameters of the dbscan / oyster model on top of a first-stage state dict `sd` (engine.init_state_dict): the
+    AnchorHeadSingleV2 dense head -- its branch convs and class scores SPREAD (the reference's N(0, 0.001) init leaves every anchor at its
+    bias: nothing to rank) -- and a class-agnostic VoxelRCNNHead. What bench.py's `value_two_stage_anchor` and the full-size parity test
+    (tests/test_gpu_two_stage.py) both run. -> (model cfg, state dict)"""
+    from . import models
+    mcfg = models.waymo_voxel_rcnn_dbscan_cfg()
+    torch.manual_seed(seed)
+    grid = np.array(ops.voxel_grid_size(cfg.voxel_size, cfg.point_cloud_range)[::-1])
+    dh = anchor_head.AnchorHeadSingleV2(dbscan_dense_head_cfg(), input_channels=sum(cfg.bev_num_upsample_filters), num_class=cfg.num_class,
+                                        class_names=["Vehicle", "Pedestrian", "Cyclist"], grid_size=grid, point_cloud_range=cfg.point_cloud_range)
+    with torch.no_grad():
+        for br in dh.BRANCHES:
+            getattr(dh, br)[0].weight.normal_(0, (2.0 / (9 * 64)) ** 0.5)
+        dh.conv_cls[3].weight.normal_(0, 0.5)
+    out = {k: v for k, v in sd.items() if not k.startswith("dense_head.")}
+    out.update({"dense_head." + k: v.detach().clone() for k, v in dh.state_dict().items()})
+    out.update({"roi_head." + k: v.detach().clone() for k, v in
+                models.__all__["VoxelRCNNHead"](input_channels={"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 128},
+                                                 model_cfg=mcfg.ROI_HEAD, point_cloud_range=cfg.point_cloud_range,
+                                                 voxel_size=cfg.voxel_size, num_class=1).state_dict().items()})
+    return mcfg, out
 
 
 def dbscan_dense_head_cfg():

@@ -519,14 +519,13 @@ class CenterPointEngine:
         # 16 matrix cycles instead of four fp32 MFMAs of 32); the 5-channel input layer stays on the fp32 pipe and writes the first pairs
         x = self._conv(L["conv_input"], feats, nbr, coords.shape[0], out_pairs=pairs16)
         x = self._blocks(L["conv1"], x, nbr, pairs=pairs16)
-        raw = getattr(self, "_export_pair_levels", False)     # exported levels stay fp16-pair rows, tagged `_cpd_pairs` (the RoI pooling's first GEMM reads them as they are)
+        raw = getattr(self, "_export_pair_levels", False)     # exported levels stay fp16-pair rows, wrapped in ops.PairRows (the RoI pooling's first GEMM reads them as they are)
 
         def export(t, is_pairs, name):
             if not (is_pairs and want(name)):
                 return t
             if raw and t.shape[1] % 32 == 0:
-                t._cpd_pairs = True
-                return t
+                return ops.PairRows(t)
             return ops.pairs_to_rows(t)
         levels = {"x_conv1": (export(x, pairs16, "x_conv1"), coords, shape)}
         self.level_indexes["x_conv1"] = index
@@ -734,7 +733,7 @@ class CenterPointEngine:
     @torch.no_grad()
     def forward(self, points_list, return_intermediates=False, proposals=None, pair_levels=False):
         """points_list: list of [N_i, C] device tensors (one per frame of the batch).
-        pair_levels (with proposals): the exported levels of >= 32 channels are left as fp16-pair rows (tensor attribute `_cpd_pairs`)
+        pair_levels (with proposals): the exported levels of >= 32 channels are left as fp16-pair rows (ops.PairRows instead of a tensor)
         when the step ran on pair rows -- what roi_pool's first GEMM takes directly; default fp32 rows.
         proposals = a collection of level names: the first stage of a two-stage detector -- returns
         (boxes [B, cap, 7], scores, labels i64 (1-based), per-frame counts (host list), levels) with the named levels' features

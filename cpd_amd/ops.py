@@ -407,6 +407,31 @@ def pairs_to_rows(x, c=None):
     return (halves[:, :, 0] + halves[:, :, 1]).reshape(n, c)
 
 
+class PairRows:
+    """fp16-pair rows handed from an engine to a consumer that reads the stored bits (the RoI pooling's first GEMM): `rows` is a
+    contiguous [N, C] float32-typed tensor whose BYTES are, per 32-channel block, [32 high halves | 32 low halves] -- not fp32 values.
+    The layout travels as this type, not as an attribute on the tensor (.contiguous() / slicing / .to() return a new
+    tensor and silently dropped the attribute; the bytes would then have been read as fp32)."""
+    __slots__ = ("rows",)
+
+    def __init__(self, rows):
+        assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.is_contiguous() and rows.shape[1] % 32 == 0, \
+            "PairRows: contiguous [N, C] fp16-pair rows, C a multiple of 32"
+        self.rows = rows
+
+    @property
+    def shape(self):
+        return self.rows.shape
+
+    @property
+    def device(self):
+        return self.rows.device
+
+    def float_rows(self):
+        """the fp32 values (h + l, exact)"""
+        return pairs_to_rows(self.rows)
+
+
 class launch_log:
     """with ops.launch_log() as log: ...; log.counts -> {kernel instantiation: launches} of the conv / weight-gradient calls made
     inside (cpd_launch_log_*; diagnostics for tests and tools)."""

@@ -228,8 +228,8 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         assert out.shape == (m, width) and out.stride(1) == 1
         col = 0
         for k, pk in enumerate(self._packed):
-            if getattr(features, "_cpd_pairs", False):     # fp16-pair rows straight from the engine's sparse level: the split-fp16 row-wave GEMM
-                fin = ops.gather_conv(features, pk["c0"], pk["w_in"], None, 1, n, pk["c1"], pk["s_in"], pk["t_in"], None, False, math="f16x2",
+            if isinstance(features, ops.PairRows):         # fp16-pair rows straight from the engine's sparse level: the split-fp16 row-wave GEMM
+                fin = ops.gather_conv(features.rows, pk["c0"], pk["w_in"], None, 1, n, pk["c1"], pk["s_in"], pk["t_in"], None, False, math="f16x2",
                                       in_pairs=True)
             else:
                 fin = ops.gather_conv(features, pk["c0"], pk["w_in"], None, 1, n, pk["c1"], pk["s_in"], pk["t_in"], None, False)
@@ -323,6 +323,11 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
     col = 0
     for name, layer in pool_layers.items():
         feats, coords, shape = levels[name]
+        if isinstance(feats, ops.PairRows):
+            if not fused:                                # the training branch differentiates through fp32 rows
+                feats = feats.float_rows()
+        elif not feats.is_contiguous():
+            feats = feats.contiguous()
         stride = strides[name]
         xyz = get_voxel_centers(coords[:, 1:4], stride, voxel_size, point_cloud_range).contiguous()
         # (per-sample row counts: the training branch's grouping needs them; the fused eval path does not -- and bincount reads back)
@@ -331,7 +336,7 @@ def roi_grid_pool(rois, levels, strides, pool_layers, grid_size, voxel_size, poi
         index = indexes.get(name) if indexes else None
         v2p = None if index is not None else generate_voxel2pinds(coords, batch_size, shape)
         out = layer(xyz=xyz, xyz_batch_cnt=cnt, new_xyz=grid_flat, new_xyz_batch_cnt=new_cnt,
-                    new_coords=cur, features=feats if feats.is_contiguous() else feats.contiguous(), voxel2point_indices=v2p, index=index,
+                    new_coords=cur, features=feats, voxel2point_indices=v2p, index=index,
                     grid=cell_geometry(voxel_size, stride, point_cloud_range) if index is not None else None,
                     **(dict(out=whole[:, col:col + widths[len(pooled)]], out_block=out_block) if fused else {}))
         if fused:

@@ -30,7 +30,8 @@ class VoxelRCNNEngine:
 
     def __init__(self, cfg: ModelConfig, roi_cfg, post_cfg, state_dict: Dict[str, torch.Tensor], device="cuda", host_results=False, rpn=None):
         """`rpn`: the first stage -- any engine whose forward(points_list, proposals=levels) returns (RoI block, scores, 1-based labels,
-        per-frame counts, levels) and that keeps `level_indexes`; default the CenterPoint engine on the same state dict
+        per-frame counts, levels) -- with `pair_levels=True` the levels may come back as cpd_amd.ops.PairRows-tagged fp16-pair rows -- and that
+        keeps `level_indexes` and `pad_label` (the label of a padded RoI slot: 0 for CenterHead, 1 for proposal_layer); default the CenterPoint engine on the same state dict
         (voxel_rcnn_cproto_center.yaml); cpd_amd.anchor_engine.AnchorPointEngine for the dbscan / oyster configs."""
         self.cfg, self.roi_cfg, self.post_cfg = cfg, roi_cfg, post_cfg
         self.device = torch.device(device)
@@ -72,7 +73,9 @@ class VoxelRCNNEngine:
         # zero boxes past a frame's count, like the reference's new_zeros block -- by SELECTION: the slots past a frame's count were
         # never written by cpd_select_boxes (stale allocator bytes, possibly NaN bit patterns, and NaN * 0 is NaN: ADVICE r4)
         rois = torch.where(valid[..., None], ob[:, :n_roi], ob.new_zeros(())).contiguous()
-        roi_labels = torch.where(valid, ol[:, :n_roi], ol.new_zeros(())).contiguous()
+        # the label of a padded slot is the first stage's: 0 behind CenterHead's reorder_rois_for_refining (center_head.py:340-350, a
+        # new_zeros block), 1 behind RoIHeadTemplate.proposal_layer (roi_head_template.py:111 adds 1 to EVERY slot of its zero buffer)
+        roi_labels = torch.where(valid, ol[:, :n_roi], ol.new_full((), int(getattr(self.rpn, "pad_label", 0)))).contiguous()
         # ---- second stage
         lv = {name: levels[name] for name in self.sources}
         m = self.cfg.conv_math if self.cfg.conv_math == "f16x2" else None     # FC stacks on the split-fp16 tile kernels, range-guarded

@@ -392,6 +392,142 @@ def test_anchor_two_stage_engine_matches_the_module_composition(hip):
     assert all(torch.isfinite(g["pred_boxes"]).all() for g in got2) and sum(len(g["pred_boxes"]) for g in got2) > 10
 
 
+def _full_anchor_engine():
+    """the model of bench.py's `value_two_stage_anchor`, from the same builder (cpd_amd.anchor_engine.synthetic_two_stage_state)"""
+    from cpd_amd.anchor_engine import AnchorPointEngine, synthetic_two_stage_state
+    from cpd_amd.engine import ModelConfig, init_state_dict
+    from cpd_amd.two_stage import VoxelRCNNEngine
+    cfg = ModelConfig()
+    mcfg, sd = synthetic_two_stage_state(cfg, init_state_dict(cfg, 0), seed=1)
+    rpn = AnchorPointEngine(cfg, sd, mcfg.DENSE_HEAD, mcfg.ROI_HEAD.NMS_CONFIG["TEST"])
+    return cfg, mcfg, sd, rpn, VoxelRCNNEngine(cfg, mcfg.ROI_HEAD, mcfg.POST_PROCESSING, sd, rpn=rpn)
+
+
+def test_full_size_anchor_two_stage_engine_matches_the_oracle_composition(oracle, hip):
+    """`AnchorPointEngine` -> `VoxelRCNNEngine` exactly as bench.py's `value_two_stage_anchor` runs them (full widths,
+    174 600 anchors on the full BEV map, the default split-fp16 arithmetic, GRID_SIZE 6) on one full 160k-point frame -- the last of a batch
+    of two, so that the occupancy mask is a batch's and the RoI block is padded -- against an ORACLE composition:
+    tests/ref_pipeline.py (voxelizer ... BaseBEVBackbone), tests/ref_anchor.py (AnchorHeadSingleV2 unfused, oracle.anchor_decode,
+    proposal_layer on oracle.nms; anchor_head_single.py:31-192, roi_head_template.py:53-114) and tests/ref_two_stage.second_stage.
+    Dense predictions anchor for anchor; proposals matched one to one by geometry at 1e-3 (rank swaps among scores closer than the
+    arithmetics' rounding are LISTED); second-stage predictions RoI by RoI for every RoI whose neighbour queries decide the same on both
+    pipelines' grid points; final detections where the stage is defined. Then the proposal NMS's fallbacks at full size."""
+    import ref_anchor as ra
+    import ref_two_stage as r2
+    from cpd_amd import anchor_head, roi_pool
+    cfg, mcfg, sd, rpn, eng = _full_anchor_engine()
+    assert cfg.conv_math == "f16x2"
+    pts = waymo_cloud(0)
+    other = waymo_cloud(5, n_points=60000)
+    clouds = [torch.from_numpy(other).cuda(), torch.from_numpy(pts).cuda()]
+    fi = 1
+    got, it = eng.forward(clouds, return_intermediates=True)
+    assert getattr(rpn, "proposal_full_reruns", 0) == 0                  # the first 800 candidates held the 200 survivors: the fast path ran
+    # ---- the oracle's first stage (anchors: the generator on the CPU, pinned on the reference class's golden in test_anchor_head.py)
+    grid = oracle.grid_size(cfg.voxel_size, cfg.point_cloud_range)[::-1]
+    agc = mcfg.DENSE_HEAD["ANCHOR_GENERATOR_CONFIG"]
+    fms = [[grid[0] // c["feature_map_stride"], grid[1] // c["feature_map_stride"]] for c in agc]
+    anchors_root = [a.numpy() for a in anchor_head.AnchorGenerator(cfg.point_cloud_range, agc).generate_anchors(fms, device="cpu")[0]]
+    nms_cfg = mcfg.ROI_HEAD.NMS_CONFIG["TEST"]
+    fs = ra.first_stage(oracle, cfg, mcfg.DENSE_HEAD, nms_cfg, sd, pts, anchors_root, mask_points_xy=np.concatenate([other[:, :2], pts[:, :2]]))
+    # ---- dense head: same occupancy mask, same anchors, predictions anchor for anchor
+    np.testing.assert_array_equal(rpn.last_dense["anchor_mask"].cpu().numpy(), fs["mask"])
+    e_cls = rpn.last_dense["batch_cls_preds"][fi].cpu().numpy()
+    e_box = rpn.last_dense["batch_box_preds"][fi].cpu().numpy()
+    assert e_cls.shape == fs["batch_cls_preds"][0].shape and e_cls.shape[0] > 150000
+    scale = max(1.0, float(np.abs(fs["batch_cls_preds"]).max()))         # the spread class scores reach +-13: 1e-4 of the outputs' scale
+    np.testing.assert_allclose(e_cls, fs["batch_cls_preds"][0], atol=1e-4 * scale, rtol=0)
+    np.testing.assert_allclose(e_box, fs["batch_box_preds"][0], atol=1e-3, rtol=1e-4)          # (decoded: exp() of the size residuals, metres)
+    # ---- proposals: 200 of 174 600 anchors, ranked by a score both pipelines know to ~1e-5
+    n_roi = int(fs["kept"][0])
+    assert n_roi == int(nms_cfg["NMS_POST_MAXSIZE"]) == 200
+    e_rois = it["rois"][fi].cpu().numpy()
+    assert e_rois.shape[0] == n_roi and int((np.abs(e_rois).sum(-1) > 0).sum()) == n_roi
+    o_rois = fs["rois"]
+    d = np.abs(e_rois[:, None, :] - o_rois[0][None, :, :]).max(-1)
+    j = d.argmin(1)                                                       # engine RoI e <-> oracle RoI j[e]
+    hit = d[np.arange(n_roi), j] <= 1e-3
+    lost = np.nonzero(~hit)[0]
+    print("engine RoIs without an oracle partner at 1e-3 (rank swaps at the NMS_PRE_MAXSIZE cut or among near-equal scores):", lost.tolist())
+    assert hit.mean() >= 0.97 and len(set(j[hit].tolist())) == int(hit.sum())        # one to one
+    np.testing.assert_allclose(e_rois[hit], o_rois[0][j[hit]], atol=1e-3, rtol=1e-4)
+    np.testing.assert_array_equal(it["roi_labels"][fi].cpu().numpy()[hit], fs["roi_labels"][0][j[hit]])
+    np.testing.assert_allclose(it["roi_scores"][fi].cpu().numpy()[hit], fs["roi_scores"][0][j[hit]], atol=1e-4 * scale)
+    assert np.abs(j[hit] - np.nonzero(hit)[0]).max() <= 3 + len(lost)     # ... and only neighbours in the ranking swap
+    # ---- the oracle's second stage on ITS OWN first stage
+    levels = {name: fs["levels"][name] for name in eng.sources}
+    final, ot = r2.second_stage(oracle, cfg, mcfg.ROI_HEAD, mcfg.POST_PROCESSING, sd, o_rois, fs["roi_labels"], levels, 1)
+    # RoIs whose neighbour queries decide differently on the engine's grid points (same recipe as the CenterPoint engine's test above)
+    e_grid, _ = roi_pool.roi_grid_points(it["rois"][fi:fi + 1].contiguous(), eng.head.grid_size, cfg.voxel_size, cfg.point_cloud_range)
+    e_grid = e_grid.view(n_roi, -1, 3).cpu().numpy()
+    o_grid, _ = r2.grid_points(o_rois, eng.head.grid_size)
+    eo = np.nonzero(hit)[0]                                               # engine RoIs with a partner, and their oracle RoIs
+    oo = j[hit]
+    assert float(np.abs(e_grid[eo] - o_grid[oo]).max()) <= 2e-3
+    grid_for_oracle = o_grid.copy()
+    grid_for_oracle[oo] = e_grid[eo]
+    strides = {"x_conv3": 4, "x_conv4": 8}
+    _, q_e = r2.roi_grid_pool(oracle, sd, mcfg.ROI_HEAD, o_rois, levels, strides, cfg.voxel_size, cfg.point_cloud_range, 1, grid_xyz=grid_for_oracle)
+    g3 = eng.head.grid_size ** 3
+    flip = np.zeros(n_roi, bool)
+    for key, (idx_o, empty_o) in ot["queries"].items():
+        idx_e, empty_e = q_e[key]
+        dd = (idx_o != idx_e).any(1) | (empty_o != empty_e)
+        flip |= dd.reshape(n_roi, g3).any(1)
+    print("RoIs whose neighbour queries decide differently on the engine's grid points (oracle order):", np.nonzero(flip)[0].tolist())
+    assert flip.sum() <= max(3, int(0.05 * n_roi)), int(flip.sum())
+    same = ~flip[oo]
+    e_cls2 = it["batch_cls_preds"][fi].cpu().numpy()[eo][same]
+    e_box2 = it["batch_box_preds"][fi].cpu().numpy()[eo][same]
+    assert same.sum() >= 0.92 * n_roi
+    np.testing.assert_allclose(e_cls2, ot["batch_cls_preds"][0][oo][same], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(e_box2, ot["batch_box_preds"][0][oo][same], atol=1e-3, rtol=1e-4)
+    # ---- final detections where the stage is DEFINED: the oracle's post_processing on the ENGINE's own second-stage predictions (the
+    # whole padded block; padded slots carry label 1 like the reference's proposal_layer, roi_head_template.py:111)
+    e_cls_f = it["batch_cls_preds"][fi:fi + 1].cpu().numpy()
+    e_box_f = it["batch_box_preds"][fi:fi + 1].cpu().numpy()
+    e_lab_f = it["roi_labels"][fi:fi + 1].cpu().numpy()
+    pp = r2.post_processing(oracle, mcfg.POST_PROCESSING, e_box_f, e_cls_f, e_lab_f, sigmoid_dtype=np.float32)[0]
+    a = got[fi]["pred_boxes"].cpu().numpy()
+    assert len(a) > 10 and len(a) == len(pp["pred_boxes"]), (len(a), len(pp["pred_boxes"]))
+    np.testing.assert_array_equal(a, pp["pred_boxes"])
+    np.testing.assert_allclose(got[fi]["pred_scores"].cpu().numpy(), pp["pred_scores"], atol=1e-6)
+    np.testing.assert_array_equal(got[fi]["pred_labels"].cpu().numpy(), pp["pred_labels"])
+    # the shorter frame of the batch found its 200 proposals too; had it found fewer, its padded slots would be zero boxes of label 1
+    assert it["roi_labels"].min() >= 1
+    # end to end (informational + a floor)
+    b = final[0]["pred_boxes"]
+    dd = np.abs(a[:, None, :] - b[None, :, :]).max(-1)
+    common = int((dd.min(1) <= 1e-3).sum())
+    print("final detections: engine %d, oracle chain %d, in common at 1e-3: %d" % (len(a), len(b), common))
+    assert abs(len(a) - len(b)) <= 0.1 * len(b) and common >= 0.6 * len(b)
+    # the production call (pair-row levels into the pooling's first GEMM): the same detections up to fp32 rounding
+    ap = eng.forward(clouds)[fi]["pred_boxes"].cpu().numpy()
+    dp = np.abs(ap[:, None, :] - a[None, :, :]).max(-1)
+    assert abs(len(ap) - len(a)) <= 3 and (dp.min(1) <= 1e-3).mean() >= 0.97
+    # ---- the proposal NMS's two fallbacks on this full frame. (i) 64 first rows cannot hold 200 survivors: the `incomplete` word sends
+    # the step through the full 4096-candidate NMS (cpd_nms_batch) -- the same RoIs bit for bit; all rows: the full NMS itself
+    base = (it["rois"].clone(), it["roi_scores"].clone(), it["roi_labels"].clone())
+    for rows, reruns in ((64, 1), (1 << 20, 0)):
+        rpn.proposal_first_rows, rpn.proposal_full_reruns = rows, 0
+        _, it_r = eng.forward(clouds, return_intermediates=True)
+        assert rpn.proposal_full_reruns == reruns, (rows, rpn.proposal_full_reruns)
+        assert torch.equal(it_r["rois"], base[0]) and torch.equal(it_r["roi_scores"], base[1]) and torch.equal(it_r["roi_labels"], base[2])
+    rpn.proposal_first_rows = None
+    # (ii) the device fallback of the module path (cpd_nms_batch_first + cpd_nms_batch_where, no read-back) on the engine's dense
+    # predictions: frames that need more than their first 64 / 256 rows are finished on the device -- the full call's answer, exactly
+    cls_d, box_d = rpn.last_dense["batch_cls_preds"], rpn.last_dense["batch_box_preds"]
+    args = (box_d, cls_d, float(nms_cfg["NMS_THRESH"]), int(nms_cfg["NMS_PRE_MAXSIZE"]), int(nms_cfg["NMS_POST_MAXSIZE"]))
+    full = roi_pool.proposal_layer(*args)
+    assert torch.equal(full[0], base[0]) and torch.equal(full[2], base[2])
+    for rows in (64, 256, "auto"):
+        dev = roi_pool.proposal_layer(*args, first_rows=rows, device_fallback=True)
+        for x, y in zip(dev, full):
+            assert torch.equal(x, y), rows
+    inc = roi_pool.proposal_layer(*args, first_rows=64)[4]
+    assert int(inc.min()) == 1                                            # (every frame DID need the fallback at 64 rows)
+
+
 def test_rank_scores_kernel_matches_the_torch_sequence(hip):
     """cpd_rank_scores against the torch sequence of post_processing it replaces (sigmoid, max over classes, threshold, stable descending
     sort, gathers), incl. ties (lower index first), rows below the threshold, NaN logits and the pre-NMS cap."""
