@@ -18,7 +18,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : the dominant conv kernel (today window_conv_f16_kernel<128>: split-fp16 on the fp16 MFMA pipe, priced against
                  2500 / 3 TFLOP/s) measured live with HIP events on the launch stream in a second pass right after the timed
                  region; `traffic` from the round's committed rocprofv3 --pmc passes of this same command
-  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host cores: median of three
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host cores: median of five
                  full frames on all hardware threads, and one frame on ONE thread (rank 0, N = 1 only)
 and, at N = 1 unless --no-extras, measured in the same process right after the timed region (each its own engine, same clouds):
   value_fp32_mfma      frames/s of the same step with conv_math = "f32" (fp32-input MFMA everywhere: the reference's arithmetic)
@@ -328,6 +328,45 @@ def pmc_stamp():
                 "same_kernel_sources": (d.get("kernel_source_hash") == here) if d.get("kernel_source_hash") else None}
     except Exception:
         return None
+
+
+def mfma_power_probe(dev, seconds=1.2):
+    """What the matrix pipe of THIS part sustains under its socket power cap (VERDICT r5 #3a): cpd_mfma_burn (csrc/diag.hip) -- waves of
+    nothing but v_mfma_f32_16x16x32_f16 on register operands -- launched back to back for `seconds` per operand pattern on the current
+    stream, HIP events around every group of launches, rocm-smi sampled alongside. Patterns: A post-ReLU-like (half zeros) x B random --
+    what the dominant kernel multiplies (activations x weights) --, and random x random. -> dict for roofline["power_probe"]."""
+    from cpd_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda: (torch.randn(512 * 8, generator=g) * 1.5).half().to(dev)
+    a_relu, b_rand, a_rand = torch.relu(rnd()), rnd(), rnd()
+    blocks, iters = 256 * 8, 1500
+    sink = torch.empty(blocks * 256, dtype=torch.float32, device=dev)
+    flops = float(lib().cpd_mfma_burn_flops(blocks, iters))
+    out = {}
+    for name, a, b in (("relu_like_x_random", a_relu, b_rand), ("random_x_random", a_rand, b_rand)):
+        launch = lambda: check(lib().cpd_mfma_burn(ptr(a), ptr(b), ptr(sink), blocks, iters, stream()), "cpd_mfma_burn")
+        launch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.3:                       # let the clock settle under the load before the timed part
+            launch()
+            torch.cuda.synchronize()
+        ms_total, n = 0.0, 0
+        with ClockSampler() as clk:
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    launch()
+                e1.record()
+                e1.synchronize()
+                ms_total += e0.elapsed_time(e1)
+                n += 5
+        cs = clk.summary()
+        out[name] = {"f16_mfma_tflops": flops * n / (ms_total * 1e-3) / 1e12, "launches": n, "sclk_MHz_median": cs["sclk_MHz_median"],
+                     "socket_power_W_median": cs["socket_power_W_median"]}
+    return out
 
 
 class ClockSampler:
@@ -681,7 +720,28 @@ def cpu_model():
         return "unknown"
 
 
-def cpu_baseline(cfg, sd, clouds_np, full_frames=3, one_thread=True):
+def physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo: the CORES of the box (SMT siblings counted once); None if unreadable"""
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":", 1)[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(cfg, sd, clouds_np, full_frames=5, one_thread=True):
     """The oracle's un-fused restatement of the reference graph on the host CPU: `full_frames` full 160k-point frames on all
     hardware threads (value = 1 / median), then ONE frame on one thread (OpenMP team size set through libgomp; the voxelizer,
     rulebook builds and NMS scan are serial either way, as in the reference)."""
@@ -690,9 +750,11 @@ def cpu_baseline(cfg, sd, clouds_np, full_frames=3, one_thread=True):
     import ref_pipeline
     from oracle import Oracle
     o = Oracle()
-    cores = os.cpu_count() or 1
+    threads = os.cpu_count() or 1
     if os.environ.get("OMP_NUM_THREADS", "").isdigit():      # `OMP_NUM_THREADS=k python bench.py` bounds the team
-        cores = min(cores, max(1, int(os.environ["OMP_NUM_THREADS"])))
+        threads = min(threads, max(1, int(os.environ["OMP_NUM_THREADS"])))
+    phys = physical_cores()
+    cores = min(threads, phys) if phys else threads          # `cores` = physical cores the team can occupy; `threads` = the OpenMP team
     # one untimed voxelizer call so that, as in the reference's generator object, the dense lookup
     # volume already exists (it is allocated once per worker, data_processor.py:133-144)
     o.voxelize(clouds_np[0][:1000], cfg.voxel_size, cfg.point_cloud_range, cfg.max_points_per_voxel, cfg.max_voxels)
@@ -702,17 +764,17 @@ def cpu_baseline(cfg, sd, clouds_np, full_frames=3, one_thread=True):
         ref_pipeline.forward(o, cfg, sd, [clouds_np[i % len(clouds_np)]])
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    out = {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
-           "sample": "%d full 160k-point frames through the whole path (oracle/cpd_oracle.c, OpenMP on %d threads): %s s, median %.1f s"
-                     % (len(times), cores, "/".join("%.1f" % t for t in times), med)}
-    if one_thread and cores > 1:
+    out = {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "threads": threads, "cpu": cpu_model(), "kind": "port",
+           "sample": "%d full 160k-point frames through the whole path (oracle/cpd_oracle.c, OpenMP team of %d threads on %d physical cores): "
+                     "%s s, median %.1f s" % (len(times), threads, cores, "/".join("%.1f" % t for t in times), med)}
+    if one_thread and threads > 1:
         try:
             gomp = ctypes.CDLL("libgomp.so.1")
             gomp.omp_set_num_threads(1)
             t0 = time.perf_counter()
             ref_pipeline.forward(o, cfg, sd, [clouds_np[0]])
             dt1 = time.perf_counter() - t0
-            gomp.omp_set_num_threads(cores)
+            gomp.omp_set_num_threads(threads)
             out["one_thread"] = {"value": 1.0 / dt1, "unit": "frames/s", "cores": 1, "sample": "1 full frame, %.1f s" % dt1}
         except OSError:
             out["one_thread"] = None
@@ -1001,6 +1063,10 @@ def main():
         conv_flops = sum(v[0] for v in agg.values()) / (n_prof * B)        # algorithmic conv flop per frame
         conv_bytes = prof.bytes_total / (n_prof * B)                       # algorithmic conv HBM bytes per frame
         peak, peak_basis = kernel_peak(key)
+        try:
+            probe = mfma_power_probe(dev) if rank == 0 else None
+        except Exception as e:                            # (a diagnostic must not take the line down)
+            probe = {"error": repr(e)[:200]}
         out["roofline"] = {
             "bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "peak_basis": peak_basis, "achieved_over_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
@@ -1008,6 +1074,14 @@ def main():
             "power_cap_note": "peak is the nominal 2.4 GHz figure; measured on this part (tools/mfma_power_probe.hip, tools/power_probe.py): a "
                               "loop of nothing but f16 MFMAs on register operands sustains 0.65 (random data) to 0.74 (half zeros) of it under "
                               "the 1400 W socket cap, and this kernel runs at 1.9-2.1 GHz for the same reason (DESIGN.md 4.1)",
+            # the ceiling the cap leaves (VERDICT r5 #3a): the same MFMA instruction alone, timed in this process on this box -- `frac`
+            # prices the kernel against the nominal 2.4 GHz peak, frac_of_power_capped against what the matrix pipe sustains under 1400 W
+            "power_probe": probe,
+            "power_capped_peak": (probe["relu_like_x_random"]["f16_mfma_tflops"] * peak / PEAK_BF16_MFMA_TFLOPS
+                                  if probe and "relu_like_x_random" in probe and peak != PEAK_FP32_MFMA_TFLOPS else None),
+            "power_capped_peak_basis": "cpd_mfma_burn (csrc/diag.hip): v_mfma_f32_16x16x32_f16 on register operands, nothing else in the loop, "
+                                       "A = post-ReLU-like fp16 values (half zeros), B = random fp16 values, ~1.2 s sustained on this box right "
+                                       "after the roofline pass; / the kernel's partial products per multiply-add",
             "traffic": pmc_traffic(key),
             "traffic_source": pmc_stamp(),
             "traffic_unit": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 --pmc passes of this "
@@ -1025,6 +1099,8 @@ def main():
                                  for k, v in sorted(agg.items())},
         }
 
+    if out.get("roofline") and out["roofline"].get("power_capped_peak"):
+        out["roofline"]["frac_of_power_capped"] = out["roofline"]["achieved"] / out["roofline"]["power_capped_peak"]
     if not args.no_roofline and args.api == "engine":
         with HbmStageProfiler() as hp:
             run_steps(2, 1)

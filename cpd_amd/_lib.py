@@ -107,6 +107,8 @@ SIGNATURES = {
     "cpd_transform_points": (_I, [_VP, _I, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _I, _VP, _VP]),
     "cpd_atss_workspace_bytes": (_SZ, [_I, _I]),
     "cpd_atss_assign": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "cpd_mfma_burn_flops": (_D, [_I, _I]),
+    "cpd_mfma_burn": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "cpd_voxel2pinds": (_I, [_VP, _I, _I, _I3, _VP, _VP]),
     "cpd_voxel_query": (_I, [_I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cpd_voxel_query_index": (_I, [_I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),

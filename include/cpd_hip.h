@@ -738,6 +738,14 @@ int cpd_atss_assign(const float *anchors, int n_anchors, const float *gt_boxes, 
                     int match_height, float *labels, float *reg_targets, float *reg_weights, void *workspace,
                     size_t workspace_bytes, cpd_stream_t stream);
 
+/* Diagnostic (csrc/diag.hip; replaces nothing in the reference): the matrix pipe's sustained rate on THIS part under its socket power
+ * cap -- `blocks` workgroups of four waves, each wave `iters` x 16 v_mfma_f32_16x16x32_f16 on register operands (a 64 x 64 x 32 tile
+ * step), nothing else in the loop. a_operands / b_operands: 512 x 16 bytes of fp16 values each (what the operand DATA is matters: the
+ * clock the cap allows depends on it); sink: blocks * 256 floats. cpd_mfma_burn_flops: the flops of one such launch (HOST only).
+ * bench.py times it beside the dominant kernel: roofline.power_capped_peak. */
+double cpd_mfma_burn_flops(int blocks, int iters);
+int cpd_mfma_burn(const void *a_operands, const void *b_operands, float *sink, int blocks, int iters, cpd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
