@@ -971,6 +971,65 @@ def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
     return selected, src[selected]
 
 
+def multi_classes_nms(cls_scores, box_preds, nms_config, score_thresh=None):
+    """model_nms_utils.multi_classes_nms (cpd/models/model_utils/model_nms_utils.py:137-170) on the B3 operators: per class column k --
+    score threshold, the NMS_PRE_MAXSIZE best, rotated NMS, the first NMS_POST_MAXSIZE -- concatenated class by class.
+    -> (pred_scores, pred_labels (the column index k, 0-based as in the reference), pred_boxes). Ties rank the lower index first (a
+    stable sort, like class_agnostic_nms here); with score_thresh None every row competes (the reference reads an unset variable there)."""
+    pred_scores, pred_labels, pred_boxes = [], [], []
+    for k in range(cls_scores.shape[1]):
+        if score_thresh is not None:
+            mask = cls_scores[:, k] >= score_thresh
+            box_scores, cur = cls_scores[mask, k], box_preds[mask]
+        else:
+            box_scores, cur = cls_scores[:, k], box_preds
+        selected = box_scores.new_zeros((0,), dtype=torch.long)
+        if box_scores.shape[0] > 0:
+            ranked, order = torch.sort(box_scores, descending=True, stable=True)
+            n = min(nms_config["NMS_PRE_MAXSIZE"], box_scores.shape[0])
+            top, order = ranked[:n], order[:n]
+            keep, _ = getattr(iou3d_nms_utils, nms_config["NMS_TYPE"])(cur[order][:, 0:7], top, nms_config["NMS_THRESH"])
+            selected = order[keep[:nms_config["NMS_POST_MAXSIZE"]]]
+        pred_scores.append(box_scores[selected])
+        pred_labels.append(torch.full((len(selected),), k, dtype=torch.long, device=box_scores.device))
+        pred_boxes.append(cur[selected])
+    return torch.cat(pred_scores, dim=0), torch.cat(pred_labels, dim=0), torch.cat(pred_boxes, dim=0)
+
+
+def post_process_frame(pp, num_class, box_preds, cls_preds, normalized, label_preds=None, label_mapping=None):
+    """One frame of Detector3DTemplate.post_processing (cpd/models/detectors/detector3d_template.py:246-331): every branch of it --
+    MULTI_CLASSES_NMS (single tensor or the multi-head list with `label_mapping`), WBF (score mask only: the fusion itself happens in the
+    evaluation scripts), class-agnostic NMS with OUTPUT_RAW_SCORE. `label_preds`: the RoI / dense-head labels when has_class_labels.
+    -> (boxes, scores, labels)"""
+    multi = isinstance(cls_preds, (list, tuple))
+    src = cls_preds
+    if not normalized:
+        cls_preds = [torch.sigmoid(x) for x in cls_preds] if multi else torch.sigmoid(cls_preds)
+    nms = pp.NMS_CONFIG
+    if nms["MULTI_CLASSES_NMS"]:
+        if not multi:
+            cls_preds = [cls_preds]
+            # (the reference builds arange(1, num_class) here -- one entry short of its own assert on the next line; classes 1..num_class)
+            label_mapping = [torch.arange(1, cls_preds[0].shape[1] + 1, device=cls_preds[0].device)]
+        start, scores, labels, boxes = 0, [], [], []
+        for cur, mapping in zip(cls_preds, label_mapping):
+            assert cur.shape[1] == len(mapping)
+            s_, l_, b_ = multi_classes_nms(cur, box_preds[start:start + cur.shape[0]], nms, pp.SCORE_THRESH)
+            scores.append(s_); labels.append(mapping[l_]); boxes.append(b_)
+            start += cur.shape[0]
+        return torch.cat(boxes, dim=0), torch.cat(scores, dim=0), torch.cat(labels, dim=0)
+    assert not multi, "a multi-head class list needs MULTI_CLASSES_NMS (detector3d_template.py:268-290)"
+    cls, labels = torch.max(cls_preds, dim=-1)
+    labels = label_preds if label_preds is not None else labels + 1
+    if pp.get("WBF", False):
+        mask = cls > pp.SCORE_THRESH
+        return box_preds[mask], cls[mask], labels[mask]
+    sel, scores = class_agnostic_nms(cls, box_preds, nms, pp.SCORE_THRESH)
+    if pp.OUTPUT_RAW_SCORE:
+        scores = torch.max(src, dim=-1)[0][sel]
+    return box_preds[sel], scores, labels[sel]
+
+
 class VoxelRCNN(CenterPoint):
     """The two-stage detector (cpd/models/detectors/voxel_rcnn.py:3-43 over Detector3DTemplate's module_topology with `roi_head`,
     detector3d_template.py:22-25,170-190): CenterPoint's modules with the dense head predicting boxes in every mode (its NMS output is
@@ -991,23 +1050,22 @@ class VoxelRCNN(CenterPoint):
 
     def post_processing(self, batch_dict):
         pp = self.model_cfg.POST_PROCESSING
-        if pp.NMS_CONFIG["MULTI_CLASSES_NMS"] or pp.get("WBF", False):
-            raise NotImplementedError("MULTI_CLASSES_NMS / WBF post-processing is not selected by the shipped CPD configs")
         pred_dicts = []
         for b in range(batch_dict["batch_size"]):
             boxes = batch_dict["batch_box_preds"][b]
-            src = batch_dict["batch_cls_preds"][b]
-            assert src.shape[1] in (1, self.num_class)
-            cls = src if batch_dict["cls_preds_normalized"] else torch.sigmoid(src)
-            cls, labels = torch.max(cls, dim=-1)
+            src = batch_dict["batch_cls_preds"]
+            src = [x[b] for x in src] if isinstance(src, (list, tuple)) else src[b]
+            if not isinstance(src, list):
+                assert src.shape[1] in (1, self.num_class)
+            labels = None
             if batch_dict.get("has_class_labels", False):
                 labels = batch_dict["roi_labels" if "roi_labels" in batch_dict else "batch_pred_labels"][b]
-            else:
-                labels = labels + 1
-            sel, scores = class_agnostic_nms(cls, boxes, pp.NMS_CONFIG, pp.SCORE_THRESH)
-            if pp.OUTPUT_RAW_SCORE:
-                scores = torch.max(src, dim=-1)[0][sel]
-            pred_dicts.append({"pred_boxes": boxes[sel], "pred_scores": scores, "pred_labels": labels[sel]})
+            fb, fs, fl = post_process_frame(pp, self.num_class, boxes, src, batch_dict["cls_preds_normalized"], labels,
+                                            batch_dict.get("multihead_label_mapping"))
+            rec = {"pred_boxes": fb, "pred_scores": fs, "pred_labels": fl}
+            if pp.get("WBF", False):
+                rec["WBF"] = True
+            pred_dicts.append(rec)
         return pred_dicts, {}
 
     def forward(self, batch_dict):

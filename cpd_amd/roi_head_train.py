@@ -147,15 +147,28 @@ class ProposalTargetLayer(nn.Module):
             return draw(easy, num)
         raise NotImplementedError
 
-    def subsample_rois(self, max_overlaps):
-        """l.293-362 (scalar thresholds)."""
+    def subsample_rois(self, max_overlaps, gts=None):
+        """l.293-362: scalar thresholds, or (`gts` = every RoI's assigned ground-truth row, CLS_SCORE_TYPE roi_iou_x / roi_ioud_x) the
+        per-class threshold LISTS, class c + 1 of the assigned box selecting entry c (l.300-309, 318-325)."""
         per_image = self.g("ROI_PER_IMAGE")
         fg_per_image = int(np.round(self.g("FG_RATIO") * per_image))
-        fg_thresh = min(self.g("REG_FG_THRESH"), self.g("CLS_FG_THRESH"))
         lo = self.g("CLS_BG_THRESH_LO")
-        fg = (max_overlaps >= fg_thresh).nonzero().view(-1)
         easy = (max_overlaps < lo).nonzero().view(-1)
-        hard = ((max_overlaps < self.g("REG_FG_THRESH")) & (max_overlaps >= lo)).nonzero().view(-1)
+        if gts is None:
+            fg_thresh = min(self.g("REG_FG_THRESH"), self.g("CLS_FG_THRESH"))
+            fg = (max_overlaps >= fg_thresh).nonzero().view(-1)
+            hard = ((max_overlaps < self.g("REG_FG_THRESH")) & (max_overlaps >= lo)).nonzero().view(-1)
+        else:
+            reg_t, cls_t = list(self.g("REG_FG_THRESH")), list(self.g("CLS_FG_THRESH"))
+            fg_m = torch.zeros_like(max_overlaps, dtype=torch.bool)
+            hard_m = torch.zeros_like(max_overlaps, dtype=torch.bool)
+            for c in range(len(cls_t)):
+                own = gts[..., -1] == (c + 1)
+                fg_m |= (max_overlaps >= min(reg_t[c], cls_t[c])) & own
+            for c in range(len(reg_t)):
+                own = gts[..., -1] == (c + 1)
+                hard_m |= (max_overlaps < reg_t[c]) & (max_overlaps >= lo) & own
+            fg, hard = fg_m.nonzero().view(-1), hard_m.nonzero().view(-1)
         n_fg, n_bg = fg.numel(), hard.numel() + easy.numel()
         if n_fg > 0 and n_bg > 0:
             k = min(fg_per_image, n_fg)
@@ -193,9 +206,8 @@ class ProposalTargetLayer(nn.Module):
                 overlaps, assign = self.get_max_iou_with_same_class(rois[i], labels[i], cur_gt[:, 0:7], cur_gt[:, -1].long())
             else:
                 overlaps, assign = torch.max(ops.boxes_iou3d(rois[i][:, 0:7].contiguous(), cur_gt[:, 0:7].contiguous()), dim=1)
-            if self.g("CLS_SCORE_TYPE") in ("roi_iou_x", "roi_ioud_x"):
-                raise NotImplementedError("per-class threshold lists (CLS_SCORE_TYPE %s) are not used by the shipped configs" % self.g("CLS_SCORE_TYPE"))
-            sel = self.subsample_rois(overlaps)
+            by_class = self.g("CLS_SCORE_TYPE") in ("roi_iou_x", "roi_ioud_x")            # l.258-261
+            sel = self.subsample_rois(overlaps, gts=cur_gt[assign] if by_class else None)
             out_rois[i], out_labels[i], out_iou[i], out_scores[i] = rois[i][sel], labels[i][sel], overlaps[sel], scores[i][sel]
             out_gt[i] = cur_gt[assign[sel]]
             for key in extra_keys:
@@ -204,9 +216,48 @@ class ProposalTargetLayer(nn.Module):
 
     @torch.no_grad()
     def forward(self, batch_dict, ind=""):
-        """l.32-196 for CLS_SCORE_TYPE in {cls, roi_iou, roi_ioud}."""
+        """l.32-196: CLS_SCORE_TYPE cls / roi_iou / roi_ioud (scalar thresholds) and roi_iou_x / roi_ioud_x (per-class threshold lists
+        picked by the class of the RoI's assigned ground truth, l.57-80, 128-184; ENABLE_HARD_SAMPLING draws np.random.randint once per
+        class, after the sampling's own draws, and -- as the reference does -- switches whole BATCH rows on: `mask_prob[ints]` indexes
+        dimension 0 of the (B, ROI_PER_IMAGE) mask)."""
         rois, gt_of_rois, ious, scores, labels, extra = self.sample_rois_for_rcnn(batch_dict, ind)
         kind = self.g("CLS_SCORE_TYPE")
+
+        def direction_weight():
+            a, g_ = _limit(rois[..., 6]), _limit(gt_of_rois[..., 6])
+            d = torch.abs(a - g_)
+            w = 1 - torch.min(d, TWO_PI - d) / np.pi
+            lo, hi = self.g("DIRECTION_MIN"), self.g("DIRECTION_MAX")
+            return (torch.clamp(w, lo, hi) - lo) / (hi - lo)
+
+        if kind in ("roi_iou_x", "roi_ioud_x"):
+            gt_cls = gt_of_rois[..., -1]
+            reg_valid = torch.zeros_like(ious, dtype=torch.long)
+            reg_t = list(self.g("REG_FG_THRESH"))
+            for c in range(len(reg_t)):
+                own = gt_cls == (c + 1)
+                this = ((ious > reg_t[c]) & own).long()
+                if self.g("ENABLE_HARD_SAMPLING", False):
+                    hard = (ious < reg_t[c]) & (ious > self.g("HARD_SAMPLING_THRESH")[c]) & own
+                    every = int(1 / self.g("HARD_SAMPLING_RATIO")[c])
+                    on = torch.zeros_like(hard)
+                    on[list(range(np.random.randint(0, every), on.shape[0], every))] = True
+                    this = this + (hard & on).long()
+                reg_valid += this
+            fg_l, bg_l = list(self.g("CLS_FG_THRESH")), list(self.g("CLS_BG_THRESH"))
+            cls_labels = torch.zeros_like(ious)
+            dw = direction_weight() if kind == "roi_ioud_x" else None
+            for c in range(len(bg_l)):
+                fg, bg = ious > fg_l[c], ious < bg_l[c]
+                mid = (~fg) & (~bg)
+                lab = fg.float()
+                lab[mid] = (ious[mid] - bg_l[c]) / (fg_l[c] - bg_l[c])
+                if dw is not None:
+                    lab = lab * dw
+                own = gt_cls == (c + 1)
+                cls_labels[own] = lab[own]
+            return {"rois": rois, "gt_of_rois": gt_of_rois, "gt_iou_of_rois": ious, "roi_scores": scores, "roi_labels": labels,
+                    "reg_valid_mask": reg_valid, "rcnn_cls_labels": cls_labels, "additional_data": extra}
         reg_valid = (ious > self.g("REG_FG_THRESH")).long()
         fg_t, bg_t = self.g("CLS_FG_THRESH"), self.g("CLS_BG_THRESH")
         if kind == "cls":
@@ -218,11 +269,7 @@ class ProposalTargetLayer(nn.Module):
             cls_labels = fg.float()
             cls_labels[mid] = (ious[mid] - bg_t) / (fg_t - bg_t)
             if kind == "roi_ioud":
-                a, g_ = _limit(rois[..., 6]), _limit(gt_of_rois[..., 6])
-                d = torch.abs(a - g_)
-                w = 1 - torch.min(d, TWO_PI - d) / np.pi
-                lo, hi = self.g("DIRECTION_MIN"), self.g("DIRECTION_MAX")
-                cls_labels = cls_labels * ((torch.clamp(w, lo, hi) - lo) / (hi - lo))
+                cls_labels = cls_labels * direction_weight()
         else:
             raise NotImplementedError(kind)
         return {"rois": rois, "gt_of_rois": gt_of_rois, "gt_iou_of_rois": ious, "roi_scores": scores, "roi_labels": labels,

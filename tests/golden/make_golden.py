@@ -409,6 +409,63 @@ def proto_head(m):
                                                                            t0["reg_valid_mask"].numel(), sum(k.startswith("g.") for k in out)))
 
 
+def target_layer_x(m):
+    """ProposalTargetLayer.forward (proposal_target_layer.py:32-196, 198-362) with the PER-CLASS threshold lists of CLS_SCORE_TYPE
+    `roi_iou_x` and `roi_ioud_x` (l.57-80, 128-184, 258-259, 297-322), with and without ENABLE_HARD_SAMPLING, from the reference's own
+    class on CPU (_load_roi_stack: its boxes_iou3d_gpu is the oracle's) under recorded seeds. Own RNG: moves no other fixture."""
+    R = _load_roi_stack(m)
+    g = np.random.default_rng(2580)
+    B, n_gt, n_roi = 2, 9, 300
+    sizes = np.array([[4.6, 2.0, 1.7], [0.9, 0.8, 1.7], [1.8, 0.8, 1.7]])
+    gt = np.zeros((B, n_gt + 2, 8), np.float32)
+    for b in range(B):
+        for i in range(n_gt - b):
+            c = 1 + (i % 3)
+            gt[b, i] = [g.uniform(-17, 17), g.uniform(-17, 17), g.uniform(-0.3, 0.6), *(sizes[c - 1] * g.uniform(0.9, 1.1, 3)), g.uniform(-3.1, 3.1), c]
+    rois = np.zeros((B, n_roi, 7), np.float32)
+    labels = np.zeros((B, n_roi), np.int64)
+    for b in range(B):
+        ng = n_gt - b
+        for j in range(n_roi):
+            if j < 240:
+                src = gt[b, j % ng, :7].copy()
+                lvl = [0.02, 0.08, 0.2, 0.4][(j // ng) % 4]
+                src[:3] += g.normal(0, lvl, 3) * [1.0, 1.0, 0.3]
+                src[3:6] *= g.uniform(1 - lvl, 1 + lvl, 3)
+                src[6] += g.normal(0, 2 * lvl)
+                rois[b, j] = src
+                labels[b, j] = int(gt[b, j % ng, 7])
+            else:
+                rois[b, j] = [g.uniform(-18, 18), g.uniform(-18, 18), g.uniform(-0.3, 0.6), *g.uniform(0.7, 4.5, 3), g.uniform(-3.1, 3.1)]
+                labels[b, j] = g.integers(1, 4)
+    scores = g.uniform(0, 1, (B, n_roi)).astype(np.float32)
+    out = dict(gt=gt, rois=rois, roi_labels=labels, roi_scores=scores)
+    case = 0
+    for kind in ("roi_iou_x", "roi_ioud_x"):
+        for hard in (False, True):
+            cfg = AttrDict(ROI_PER_IMAGE=64, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True, CLS_SCORE_TYPE=kind,
+                           CLS_FG_THRESH=[0.75, 0.6, 0.65], CLS_BG_THRESH=[0.25, 0.15, 0.2], CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8,
+                           REG_FG_THRESH=[0.55, 0.4, 0.45], DIRECTION_MIN=0.1, DIRECTION_MAX=0.9, ENABLE_HARD_SAMPLING=hard,
+                           HARD_SAMPLING_THRESH=[0.3, 0.2, 0.25], HARD_SAMPLING_RATIO=[0.5, 0.25, 0.34])
+            layer = R["ptl"].ProposalTargetLayer(roi_sampler_cfg=cfg)
+            seed = 300 + case
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            t = layer.forward({"batch_size": B, "rois": torch.from_numpy(rois), "roi_scores": torch.from_numpy(scores),
+                               "roi_labels": torch.from_numpy(labels), "gt_boxes": torch.from_numpy(gt)})
+            pre = "c%d_" % case
+            out[pre + "kind"] = np.int64(0 if kind == "roi_iou_x" else 1)
+            out[pre + "hard"], out[pre + "seed"] = np.int64(hard), np.int64(seed)
+            for k in ("rois", "gt_of_rois", "gt_iou_of_rois", "roi_scores", "roi_labels", "reg_valid_mask", "rcnn_cls_labels"):
+                out[pre + k] = t[k].numpy()
+            print("target_layer_x case %d (%s, hard %d): %d reg-valid of %d, cls labels in [%.3f, %.3f]" %
+                  (case, kind, hard, int(t["reg_valid_mask"].sum()), t["reg_valid_mask"].numel(), float(t["rcnn_cls_labels"].min()),
+                   float(t["rcnn_cls_labels"].max())))
+            case += 1
+    out["n_cases"] = np.int64(case)
+    np.savez_compressed(os.path.join(HERE, "target_layer_x.npz"), **out)
+
+
 PROTO_NAMES = ["Vehicle", "Pedestrian", "Cyclist", "Dis_Small", "Sign"]
 
 
@@ -654,6 +711,8 @@ def main():
         return proto_crop(m)
     if len(sys.argv) > 1 and sys.argv[1] == "proto_head":
         return proto_head(m)
+    if len(sys.argv) > 1 and sys.argv[1] == "target_layer_x":
+        return target_layer_x(m)
     if len(sys.argv) > 1 and sys.argv[1] == "points_in_boxes":
         return points_in_boxes_fixture(m)
     if len(sys.argv) > 1 and sys.argv[1] == "merge_sweeps":

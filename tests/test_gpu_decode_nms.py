@@ -225,3 +225,58 @@ def test_select_boxes_packed_block_round_trips(hip):
         for dev_t, packed_t, host_t in ((ob, pb, hb), (os_, ps, hs), (ol, pl, hl)):
             assert torch.equal(dev_t[b, :n], packed_t[b, :n]) and torch.equal(dev_t[b, :n].cpu(), host_t[b, :n])
     assert hl.dtype == torch.int64 and hb.shape == (B, post, 7)
+
+
+def test_multi_classes_nms_and_the_post_processing_branches_vs_oracle(oracle, hip):
+    """model_nms_utils.multi_classes_nms (model_nms_utils.py:137-170) and Detector3DTemplate.post_processing's MULTI_CLASSES_NMS / WBF /
+    OUTPUT_RAW_SCORE branches (detector3d_template.py:246-331) through cpd_amd.models, against a plain restatement on oracle.nms: per
+    class column -- threshold, descending order, rotated NMS, first NMS_POST_MAXSIZE -- concatenated."""
+    from cpd_amd import models
+    n, nc, thr = 600, 3, 0.3
+    bs = _clean_boxes(oracle, n, thr)
+    rng = np.random.default_rng(5)
+    logits = rng.normal(0, 2, (n, nc)).astype(np.float32)
+    prob = (1.0 / (1.0 + np.exp(-logits.astype(np.float64)))).astype(np.float32)
+    nms_cfg = dict(MULTI_CLASSES_NMS=True, NMS_TYPE="nms_gpu", NMS_THRESH=thr, NMS_PRE_MAXSIZE=256, NMS_POST_MAXSIZE=40)
+    score_thresh = 0.2
+
+    def want_multi(p):
+        out_s, out_l, out_b = [], [], []
+        for k in range(nc):
+            ok = np.nonzero(p[:, k] >= score_thresh)[0]
+            order = ok[np.argsort(-p[ok, k], kind="stable")][:nms_cfg["NMS_PRE_MAXSIZE"]]
+            keep = oracle.nms(np.ascontiguousarray(bs[order]), thr)
+            sel = order[keep][:nms_cfg["NMS_POST_MAXSIZE"]]
+            out_s.append(p[sel, k]); out_l.append(np.full(len(sel), k)); out_b.append(bs[sel])
+        return np.concatenate(out_s), np.concatenate(out_l), np.concatenate(out_b)
+
+    s_, l_, b_ = models.multi_classes_nms(dev(prob), dev(bs), nms_cfg, score_thresh)
+    ws, wl, wb = want_multi(prob)
+    assert len(ws) > 30
+    np.testing.assert_array_equal(l_.cpu().numpy(), wl)
+    np.testing.assert_array_equal(b_.cpu().numpy(), wb)
+    np.testing.assert_array_equal(s_.cpu().numpy(), ws)
+    # the detector's post_processing on logits: sigmoid on the device (<= 1 ulp from numpy's: compare the selection through the boxes)
+    pp = models.AttrDict(SCORE_THRESH=score_thresh, OUTPUT_RAW_SCORE=False, NMS_CONFIG=nms_cfg)
+    fb, fs, fl = models.post_process_frame(pp, nc, dev(bs), dev(logits), False)
+    np.testing.assert_array_equal(fb.cpu().numpy(), wb)
+    np.testing.assert_array_equal(fl.cpu().numpy(), wl + 1)                  # classes 1 .. num_class
+    np.testing.assert_allclose(fs.cpu().numpy(), ws, atol=1e-6)
+    # multi-head list form with its label mapping (two heads over disjoint box ranges)
+    heads = [dev(logits[:350, :2]), dev(logits[350:, 2:])]
+    mapping = [torch.tensor([1, 2]).cuda(), torch.tensor([3]).cuda()]
+    hb, hs, hl = models.post_process_frame(pp, nc, dev(bs), heads, False, None, mapping)
+    assert set(hl.cpu().tolist()) <= {1, 2, 3} and len(hb) > 10
+    first = (hl != 3).cpu().numpy()
+    d = np.abs(hb.cpu().numpy()[:, None] - bs[None]).max(-1).argmin(1)       # which input box each output is
+    assert (d[first] < 350).all() and (d[~first] >= 350).all()
+    # WBF: the score mask only; class-agnostic with OUTPUT_RAW_SCORE: raw logits of the selected rows
+    pw = models.AttrDict(SCORE_THRESH=0.6, OUTPUT_RAW_SCORE=False, WBF=True, NMS_CONFIG=dict(nms_cfg, MULTI_CLASSES_NMS=False))
+    wb_, ws_, wl_ = models.post_process_frame(pw, nc, dev(bs), dev(prob), True)
+    m = prob.max(-1) > 0.6
+    np.testing.assert_array_equal(wb_.cpu().numpy(), bs[m])
+    np.testing.assert_array_equal(wl_.cpu().numpy(), prob.argmax(-1)[m] + 1)
+    pr = models.AttrDict(SCORE_THRESH=score_thresh, OUTPUT_RAW_SCORE=True, NMS_CONFIG=dict(nms_cfg, MULTI_CLASSES_NMS=False))
+    rb, rs, rl = models.post_process_frame(pr, nc, dev(bs), dev(logits), False)
+    sel = np.abs(rb.cpu().numpy()[:, None] - bs[None]).max(-1).argmin(1)
+    np.testing.assert_array_equal(rs.cpu().numpy(), logits.max(-1)[sel])

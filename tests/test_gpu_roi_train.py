@@ -121,3 +121,32 @@ def test_grouping_backward_is_the_scatter_add_of_the_forward(hip):
     want = torch.zeros(n0 + n1, c, dtype=torch.float64, device="cuda").index_add_(0, rows.reshape(-1), w.permute(0, 2, 1).reshape(-1, c).double())
     assert torch.equal(out, feats.detach()[rows].permute(0, 2, 1))
     assert float((feats.grad.double() - want).abs().max()) < 1e-5
+
+
+def test_per_class_threshold_target_layer_matches_reference(golden, hip):
+    """ProposalTargetLayer with CLS_SCORE_TYPE roi_iou_x / roi_ioud_x (per-class threshold lists; proposal_target_layer.py:57-80, 128-184,
+    258-259, 297-322), with and without ENABLE_HARD_SAMPLING, against tests/golden/target_layer_x.npz -- the reference's own class on CPU
+    under recorded seeds (make_golden.py::target_layer_x). The sampler draws the same random numbers in the same order: sampled RoIs,
+    labels and the regression mask are exact; IoUs and the soft class labels to fp32 rounding of the device IoU."""
+    import torch
+    from cpd_amd.roi_head_train import ProposalTargetLayer
+    g = golden("target_layer_x")
+    bd = {"batch_size": 2, "rois": torch.from_numpy(g["rois"]).cuda(), "roi_scores": torch.from_numpy(g["roi_scores"]).cuda(),
+          "roi_labels": torch.from_numpy(g["roi_labels"]).cuda(), "gt_boxes": torch.from_numpy(g["gt"]).cuda()}
+    for case in range(int(g["n_cases"])):
+        pre = "c%d_" % case
+        cfg = dict(ROI_PER_IMAGE=64, FG_RATIO=0.5, SAMPLE_ROI_BY_EACH_CLASS=True, CLS_SCORE_TYPE=("roi_iou_x", "roi_ioud_x")[int(g[pre + "kind"])],
+                   CLS_FG_THRESH=[0.75, 0.6, 0.65], CLS_BG_THRESH=[0.25, 0.15, 0.2], CLS_BG_THRESH_LO=0.1, HARD_BG_RATIO=0.8,
+                   REG_FG_THRESH=[0.55, 0.4, 0.45], DIRECTION_MIN=0.1, DIRECTION_MAX=0.9, ENABLE_HARD_SAMPLING=bool(g[pre + "hard"]),
+                   HARD_SAMPLING_THRESH=[0.3, 0.2, 0.25], HARD_SAMPLING_RATIO=[0.5, 0.25, 0.34])
+        np.random.seed(int(g[pre + "seed"]))
+        torch.manual_seed(int(g[pre + "seed"]))
+        t = ProposalTargetLayer(cfg)(dict(bd))
+        np.testing.assert_array_equal(t["rois"].cpu().numpy(), g[pre + "rois"], err_msg=pre)
+        np.testing.assert_array_equal(t["gt_of_rois"].cpu().numpy(), g[pre + "gt_of_rois"], err_msg=pre)
+        np.testing.assert_array_equal(t["roi_labels"].cpu().numpy(), g[pre + "roi_labels"], err_msg=pre)
+        np.testing.assert_array_equal(t["roi_scores"].cpu().numpy(), g[pre + "roi_scores"], err_msg=pre)
+        np.testing.assert_array_equal(t["reg_valid_mask"].cpu().numpy(), g[pre + "reg_valid_mask"], err_msg=pre)
+        np.testing.assert_allclose(t["gt_iou_of_rois"].cpu().numpy(), g[pre + "gt_iou_of_rois"], rtol=0, atol=1e-5, err_msg=pre)
+        np.testing.assert_allclose(t["rcnn_cls_labels"].cpu().numpy(), g[pre + "rcnn_cls_labels"], rtol=0, atol=5e-5, err_msg=pre)
+        assert int(t["reg_valid_mask"].sum()) > 20 and 0.0 < float(t["rcnn_cls_labels"].mean()) < 1.0
