@@ -27,17 +27,19 @@ def gaussian_radius(height, width, min_overlap=0.5):
 
 def assign_targets(gt_boxes, feature_map_size, point_cloud_range, voxel_size, num_classes, feature_map_stride=8,
                    num_max_objs=500, gaussian_overlap=0.1, min_radius=2):
-    """gt_boxes [B, M, 8] (x,y,z,dx,dy,dz,heading,class 1..num_classes; zero rows = padding);
-    feature_map_size (H, W). Returns heatmaps [B,nc,H,W], target_boxes [B,K,8], inds [B,K] i64,
-    masks [B,K] i64 (K = num_max_objs) -- assign_target_of_single_head for every sample."""
-    B, M, _ = gt_boxes.shape
+    """gt_boxes [B, M, 8 + E] (x,y,z,dx,dy,dz,heading, E extra columns such as velocity, class 1..num_classes LAST; zero rows =
+    padding); feature_map_size (H, W). Returns heatmaps [B,nc,H,W], target_boxes [B,K,8 + E] (the extras behind the 8 regression
+    targets, center_head.py:115,154-155), inds [B,K] i64, masks [B,K] i64 (K = num_max_objs) -- assign_target_of_single_head for
+    every sample."""
+    B, M, C = gt_boxes.shape
+    assert C >= 8, "gt_boxes rows are (x, y, z, dx, dy, dz, heading, [extras ...], class)"
     H, W = int(feature_map_size[0]), int(feature_map_size[1])
     dev = gt_boxes.device
     K = num_max_objs
     # the reference first keeps this head's boxes (class >= 1: padding rows are 'bg', center_head.py:180-196), THEN walks the
     # first NUM_MAX_OBJS of that filtered list (l.113): compact the kept rows to the front, stably, before truncating
     if M > 0:
-        drop = (gt_boxes[..., 7] < 1).to(torch.int8)
+        drop = (gt_boxes[..., -1] < 1).to(torch.int8)
         order = torch.sort(drop, dim=1, stable=True)[1]
         gt_boxes = torch.gather(gt_boxes, 1, order.unsqueeze(-1).expand(-1, -1, gt_boxes.shape[2]))
     g = gt_boxes[:, :K].float()
@@ -48,7 +50,7 @@ def assign_targets(gt_boxes, feature_map_size, point_cloud_range, voxel_size, nu
     cxi, cyi = cx.int(), cy.int()
     dx = g[..., 3] / voxel_size[0] / feature_map_stride
     dy = g[..., 4] / voxel_size[1] / feature_map_stride
-    valid = (dx > 0) & (dy > 0) & (g[..., 7] >= 1)
+    valid = (dx > 0) & (dy > 0) & (g[..., -1] >= 1)
     radius = torch.clamp_min(gaussian_radius(dx.clamp_min(1e-6), dy.clamp_min(1e-6), min_overlap=gaussian_overlap).int(), min_radius)
     radius = torch.where(valid, radius, torch.zeros_like(radius))
 
@@ -64,18 +66,20 @@ def assign_targets(gt_boxes, feature_map_size, point_cloud_range, voxel_size, nu
         py = cyi[..., None, None] + oy[None, None]
         inside = (ox.abs()[None, None] <= r) & (oy.abs()[None, None] <= r) & (px >= 0) & (px < W) & (py >= 0) & (py < H) \
             & valid[..., None, None]
-        cls = (g[..., 7].long() - 1).clamp(0, num_classes - 1)[..., None, None]
+        cls = (g[..., -1].long() - 1).clamp(0, num_classes - 1)[..., None, None]
         b_idx = torch.arange(B, device=dev)[:, None, None, None]
         lin = ((b_idx * num_classes + cls) * H + py.clamp(0, H - 1).long()) * W + px.clamp(0, W - 1).long()
         vals = torch.where(inside, gauss, torch.zeros_like(gauss))
         heat.view(-1).scatter_reduce_(0, lin.reshape(-1), vals.reshape(-1), reduce="amax", include_self=True)
 
-    target = torch.zeros((B, K, 8), dtype=torch.float32, device=dev)
+    target = torch.zeros((B, K, C), dtype=torch.float32, device=dev)
     inds = torch.zeros((B, K), dtype=torch.int64, device=dev)
     masks = torch.zeros((B, K), dtype=torch.int64, device=dev)
     if Mk > 0:
         t = torch.stack([cx - cxi.float(), cy - cyi.float(), z, g[..., 3].clamp_min(1e-12).log(), g[..., 4].clamp_min(1e-12).log(),
                          g[..., 5].clamp_min(1e-12).log(), torch.cos(g[..., 6]), torch.sin(g[..., 6])], dim=-1)
+        if C > 8:
+            t = torch.cat([t, g[..., 7:-1]], dim=-1)
         v = valid[..., None].float()
         target[:, :Mk] = t * v
         inds[:, :Mk] = (cyi.long() * W + cxi.long()) * valid.long()

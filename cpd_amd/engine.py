@@ -810,11 +810,11 @@ class CenterPointEngine:
             # map (return_intermediates) get a fresh tensor
             dmap = None
             if self.cfg.persistent_dense_map and not return_intermediates:
-                key = ("dense_map", batch, d, h, w, x.shape[1])
+                key = ("dense_map", d, h, w, x.shape[1])
                 dmap = self._bev_cache.get(key)
-                if dmap is None:
+                if dmap is None or dmap.batch < batch:      # one map, sized for the largest batch seen; smaller batches use its leading frames
                     dmap = self._bev_cache[key] = ops.DenseMap(batch, out_shape, x.shape[1], self.device)
-                dense = dmap.scatter(x, out_idx).view(batch * h * w, d * x.shape[1])
+                dense = dmap.scatter(x, out_idx, batch).view(batch * h * w, d * x.shape[1])
             else:
                 dense = ops.densify_nhwc(x, out_idx, batch, out_shape).view(batch * h * w, d * x.shape[1])
             self._dense_map = dmap

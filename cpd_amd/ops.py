@@ -533,27 +533,33 @@ def densify_nhwc(feat, indices, batch, shape_zyx, out=None):
 class DenseMap:
     """A persistent, pre-zeroed (B, H, W, D * C) map for densify_nhwc: `scatter` writes the occupied rows into it, `clear` -- queued after
     the map's last reader -- zeroes the same rows again (cpd_densify_nhwc_rows / _clear). A map left dirty (an exception between the
-    two) is cleared in full on its next use."""
+    two) is cleared in full on its next use. ONE map serves every batch size up to its capacity: the leading `batch` frames of the
+    (B, H, W, D * C) layout are a valid map of that batch, and scatter / clear touch occupied rows only (a map per batch
+    size pinned the sum of the sizes seen -- 36 MB per frame)."""
 
     def __init__(self, batch, shape_zyx, c, device):
-        self.batch, self.shape, self.c = int(batch), [int(v) for v in shape_zyx], int(c)
+        self.batch, self.shape, self.c = int(batch), [int(v) for v in shape_zyx], int(c)       # batch = the capacity in frames
         self.buf = torch.zeros((self.batch, self.shape[1], self.shape[2], self.shape[0] * self.c), dtype=torch.float32, device=device)
-        self.dirty = None                # the index list scattered and not yet cleared
+        self.dirty = None                # (index list, frames) scattered and not yet cleared
 
-    def scatter(self, feat, indices):
+    def scatter(self, feat, indices, batch=None):
+        """-> the (batch, H, W, D * C) map (a view of the leading frames); batch <= capacity, default the capacity"""
+        batch = self.batch if batch is None else int(batch)
+        assert 1 <= batch <= self.batch
         if self.dirty is not None:
             self.buf.zero_()
         feat, indices = feat.contiguous(), indices.contiguous()
         assert feat.shape[1] == self.c
-        self.dirty = indices
-        check(lib().cpd_densify_nhwc_rows(ptr(feat), ptr(indices), feat.shape[0], self.c, self.batch, iarr(self.shape), ptr(self.buf), stream()),
+        self.dirty = (indices, batch)
+        check(lib().cpd_densify_nhwc_rows(ptr(feat), ptr(indices), feat.shape[0], self.c, batch, iarr(self.shape), ptr(self.buf), stream()),
               "cpd_densify_nhwc_rows")
-        return self.buf
+        return self.buf[:batch]
 
     def clear(self):
         if self.dirty is None:
             return
-        check(lib().cpd_densify_nhwc_clear(ptr(self.dirty), self.dirty.shape[0], self.c, self.batch, iarr(self.shape), ptr(self.buf), stream()),
+        indices, batch = self.dirty
+        check(lib().cpd_densify_nhwc_clear(ptr(indices), indices.shape[0], self.c, batch, iarr(self.shape), ptr(self.buf), stream()),
               "cpd_densify_nhwc_clear")
         self.dirty = None
 
@@ -642,12 +648,21 @@ def nms_batch_first(boxes, counts, thresh, max_keep, row_limit, normal=False):
     return keep, num, inc
 
 
+_NMS_WHERE_WS = {}
+
+
 def nms_batch_where(boxes, counts, where, thresh, keep, num_keep, normal=False):
     """nms_batch for the samples whose `where` word (device i32 [batch]) is non-zero, written into the given keep / num_keep; the other
     samples keep theirs (cpd_nms_batch_where): the device-side fallback of nms_batch_first, no read-back in between."""
     boxes = boxes.contiguous()
     batch, cap = boxes.shape[0], boxes.shape[1]
-    ws = torch.empty(batch * lib().cpd_nms_workspace_bytes(cap), dtype=torch.uint8, device=boxes.device)
+    # the full-capacity mask workspace (2 MB per sample at 4096 boxes, 10 MB at TRAIN's 9000) is only TOUCHED by flagged samples:
+    # one grow-only buffer per (device, stream) instead of an allocation per call (ADVICE r5; kernels of one stream run in order)
+    need = batch * lib().cpd_nms_workspace_bytes(cap)
+    key = (str(boxes.device), stream().value)
+    ws = _NMS_WHERE_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _NMS_WHERE_WS[key] = torch.empty(need, dtype=torch.uint8, device=boxes.device)
     check(lib().cpd_nms_batch_where(ptr(boxes), ptr(counts), ptr(where), batch, cap, float(thresh), 1 if normal else 0, ptr(keep), ptr(num_keep),
                                     ptr(ws), ws.numel(), stream()), "cpd_nms_batch_where")
     return keep, num_keep

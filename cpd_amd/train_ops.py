@@ -194,6 +194,12 @@ def center_targets(gt_boxes, feature_map_size, point_cloud_range, voxel_size, nu
                    gaussian_overlap=0.1, min_radius=2):
     """CenterHead.assign_targets on the device (cpd_center_targets; same arguments and returns as center_loss.assign_targets: heat
     [B, nc, H, W], target_boxes [B, K, 8], inds [B, K] i64, masks [B, K] i64) -- three launches, no host read-back."""
+    if gt_boxes.shape[-1] != 8:
+        # cpd_center_targets reads rows of exactly 8 floats (class in column 7). Ground truth with extra columns (velocity ...: the
+        # reference keeps them, center_head.py:149-155) or fewer goes through the torch restatement, which honours shape[-1] (ADVICE r5)
+        from . import center_loss as _cl
+        return _cl.assign_targets(gt_boxes, feature_map_size, point_cloud_range, voxel_size, num_classes, feature_map_stride, num_max_objs,
+                                  gaussian_overlap, min_radius)
     gt = gt_boxes.contiguous().float()
     B, M, _ = gt.shape
     H, W = int(feature_map_size[0]), int(feature_map_size[1])

@@ -711,10 +711,19 @@ def test_persistent_dense_map_leaves_no_rows_behind(hip):
             assert torch.equal(x[k], y[k]) and torch.equal(x[k], z[k]), k
     dmap = next(v for v in ea._bev_cache.values() if isinstance(v, ops.DenseMap))
     assert float(dmap.buf.abs().max()) == 0.0 and dmap.dirty is None          # between steps the map is all zero
-    dmap.buf.fill_(3.0); dmap.dirty = torch.zeros((1, 4), dtype=torch.int32, device="cuda")      # as if a step had died half-way
+    dmap.buf.fill_(3.0); dmap.dirty = (torch.zeros((1, 4), dtype=torch.int32, device="cuda"), 1)      # as if a step had died half-way
     after = ea.forward(batches[0])
     for x, y in zip(first, after):
         assert torch.equal(x["pred_boxes"], y["pred_boxes"])
+    # ONE map for every batch size: a smaller batch runs in the leading frames of the same buffer, a larger one replaces it
+    for frames in ([batches[1][0]], batches[0] + [batches[2][1]], [batches[2][0]]):
+        got, want = ea.forward(frames), eb.forward(frames)
+        for x, y in zip(got, want):
+            for k in ("pred_boxes", "pred_scores", "pred_labels"):
+                assert torch.equal(x[k], y[k]), (len(frames), k)
+        maps = [v for v in ea._bev_cache.values() if isinstance(v, ops.DenseMap)]
+        assert len(maps) == 1 and maps[0].batch >= len(frames) and float(maps[0].buf.abs().max()) == 0.0
+    assert maps[0].batch == 3
 
 
 @pytest.mark.parametrize("math", ["f32", "f16x2"])
