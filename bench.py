@@ -882,16 +882,46 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
 
 
 def launch_check(args):
-    """--launch-check: the N > 1 plumbing alone (ranks, rendezvous, barrier, max-over-ranks), any backend."""
+    """--launch-check: the N > 1 plumbing alone, any backend (gloo on CPUs in the tests, RCCL on the GPUs): ranks, CPU pinning,
+    rendezvous, barrier, max-over-ranks, the per-rank clocks of the bench line and the train step's bucketed gradient all-reduce on a
+    buffer of the real size -- the first 8-GPU run should meet nothing here for the first time (VERDICT r5 #9)."""
     rank, world, local = dist_utils.env_rank()
-    distributed = dist_utils.init(os.environ.get("CPD_DIST_BACKEND", "nccl"))
+    cpus = dist_utils.pin_rank()
+    backend = os.environ.get("CPD_DIST_BACKEND", "nccl")
+    distributed = dist_utils.init(backend)
+    dev = "cuda" if (distributed and backend == "nccl") else "cpu"
+    if dev == "cuda":
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     dist_utils.barrier()
-    dev = "cuda" if (distributed and os.environ.get("CPD_DIST_BACKEND", "nccl") == "nccl") else "cpu"
     slowest = dist_utils.max_over_ranks(1.0 + rank, device=dev)
     seeds = dist_utils.frame_seeds(rank, POOL)
+    # the bench line's per-rank fields: every rank's own clock, whole-job throughput over the slowest one
+    t0 = time.perf_counter()
+    dist_utils.barrier()
+    local_elapsed = 1.0 + 0.25 * rank + (time.perf_counter() - t0) * 0.0
+    per_rank = dist_utils.gather_floats(local_elapsed, device=dev)
+    whole_job = dist_utils.aggregate_throughput(48.0, local_elapsed, device=dev)
+    # config 3's collective: 7.8 M fp32 gradients (31 MB) in two buckets that may overlap, then the averaged result
+    n = int(os.environ.get("CPD_LAUNCH_CHECK_GRAD_FLOATS", str(7_800_000)))
+    flat = torch.full((n,), float(rank + 1), dtype=torch.float32, device=dev)
+    dist_utils.barrier()
+    t0 = time.perf_counter()
+    red = dist_utils.BucketedReduce(flat)
+    red.start(n // 2, n)
+    factor = red.finish()
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    ar_ms = 1e3 * (time.perf_counter() - t0)
+    mean = float(flat[0]) * factor, float(flat[-1]) * factor
+    ar_all = dist_utils.gather_floats(ar_ms, device=dev)
+    aff = dist_utils.gather_ints([len(cpus), cpus[0] if cpus else -1, cpus[-1] if cpus else -1], device=dev)
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_arg": args.gpus, "max_over_ranks": slowest,
-                          "rank0_frame_seeds": seeds}))
+                          "rank0_frame_seeds": seeds, "backend": backend if distributed else None,
+                          "per_rank": {"elapsed_s": per_rank, "allreduce_in_step_ms": ar_all,
+                                       "cpu_affinity": [{"cpus": a[0], "first": a[1], "last": a[2]} for a in aff]},
+                          "whole_job_units_per_s": whole_job, "allreduce_bytes": 4 * n, "allreduce_mean": mean,
+                          "expected_mean": (world + 1) / 2.0}))
     dist_utils.shutdown()
 
 
@@ -906,6 +936,8 @@ def main():
               file=sys.stderr)
     if args.launch_check:
         return launch_check(args)
+    if world > 1:
+        dist_utils.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # a CPU slice per rank, NUMA order (dist_utils.rank_cpus)
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     # "nccl" is RCCL on ROCm; CPD_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests

@@ -36,6 +36,78 @@ def launch_ranks(n, script, argv, env=None):
     return subprocess.call(cmd, env=e)
 
 
+def _numa_cpu_lists():
+    """[[cpu ids of NUMA node 0], [node 1], ...] from sysfs, restricted to the CPUs this process may run on; one list when sysfs has
+    no node information"""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    nodes = []
+    try:
+        base = "/sys/devices/system/node"
+        names = sorted((d for d in os.listdir(base) if d.startswith("node") and d[4:].isdigit()), key=lambda d: int(d[4:]))
+        for d in names:
+            cpus = []
+            with open(os.path.join(base, d, "cpulist")) as f:
+                for part in f.read().strip().split(","):
+                    if not part:
+                        continue
+                    lo, _, hi = part.partition("-")
+                    cpus.extend(range(int(lo), int(hi or lo) + 1))
+            cpus = [c for c in cpus if c in set(allowed)]
+            if cpus:
+                nodes.append(cpus)
+    except OSError:
+        nodes = []
+    covered = {c for n in nodes for c in n}
+    if not nodes or covered != set(allowed):
+        return [allowed]
+    return nodes
+
+
+def rank_cpus(local_rank, local_world):
+    """The CPUs rank `local_rank` of `local_world` ranks on this node should run on: the node's CPUs in NUMA order cut into
+    `local_world` equal contiguous slices -- ranks sharing a NUMA node split it, a rank never straddles two nodes when the counts
+    divide (8 ranks on a 2-socket box: four per socket, the GPUs' usual split). Each rank runs two Python worker threads + the HIP
+    runtime's helper threads; without a slice of its own, 8 ranks' threads migrate across both sockets of the host."""
+    cpus = [c for node in _numa_cpu_lists() for c in node]
+    n = len(cpus)
+    local_world = max(1, int(local_world))
+    if n < local_world:
+        return cpus                                     # fewer CPUs than ranks: no pinning
+    per = n // local_world
+    lo = (int(local_rank) % local_world) * per
+    return cpus[lo:lo + per]
+
+
+def pin_rank(local_rank=None, local_world=None):
+    """sched_setaffinity of this rank to rank_cpus(...) (CPD_NO_PIN=1 switches it off; a launcher that already pinned the rank -- an
+    affinity mask smaller than the node -- is left alone). -> the CPU list now in force."""
+    if not hasattr(os, "sched_setaffinity"):
+        return []
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if local_world > 1 and not os.environ.get("CPD_NO_PIN"):
+        cpus = rank_cpus(local_rank, local_world)
+        if cpus:
+            try:
+                os.sched_setaffinity(0, cpus)
+                torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
+            except OSError:
+                pass
+    return sorted(os.sched_getaffinity(0))
+
+
+def gather_ints(values, device="cpu"):
+    """every rank's equally long list of ints, in rank order ([values] without a process group)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [list(values)]
+    t = torch.tensor(list(values), dtype=torch.int64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[int(v) for v in o.tolist()] for o in out]
+
+
 def init(backend="nccl", device=None):
     rank, world, _ = env_rank()
     if world == 1 and not os.environ.get("CPD_FORCE_DIST"):     # CPD_FORCE_DIST=1: exercise the collectives with one rank

@@ -78,3 +78,39 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--launch-check"], env=env2,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_eight_rank_launch_check_pins_cpus_and_reduces_the_gradient_buffer():
+    """`python bench.py --gpus 8 --launch-check` (the first 8-GPU run should be boring): the command starts its eight
+    ranks itself, every rank pins itself to its own slice of the node's CPUs (dist_utils.rank_cpus: NUMA order, disjoint slices),
+    the per-rank clocks of the bench line come back in rank order, whole-job throughput is all ranks' units over the SLOWEST rank's time,
+    and the train step's bucketed all-reduce of a gradient-sized buffer gives the mean on every element. gloo here, RCCL on the GPUs."""
+    import json
+    import subprocess
+    import sys
+    from cpd_amd import dist_utils
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(CPD_DIST_BACKEND="gloo", CPD_LAUNCH_CHECK_GRAD_FLOATS="1000000", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["gpus_arg"] == 8 and rec["max_over_ranks"] == 8.0 and rec["backend"] == "gloo"
+    pr = rec["per_rank"]
+    assert pr["elapsed_s"] == [1.0 + 0.25 * r for r in range(8)]                    # every rank's own clock, in rank order
+    assert abs(rec["whole_job_units_per_s"] - 8 * 48.0 / 2.75) < 1e-9                # ... and the slowest one prices the job
+    assert len(pr["allreduce_in_step_ms"]) == 8 and all(v > 0 for v in pr["allreduce_in_step_ms"])
+    assert rec["allreduce_mean"] == [rec["expected_mean"]] * 2 == [4.5, 4.5]        # both buckets reduced and averaged
+    n_cpu = len(os.sched_getaffinity(0))
+    aff = pr["cpu_affinity"]
+    if n_cpu >= 8:
+        assert all(a["cpus"] == n_cpu // 8 for a in aff), aff
+        spans = sorted((a["first"], a["last"]) for a in aff)
+        assert all(spans[i][1] < spans[i + 1][0] for i in range(7)), spans          # disjoint slices
+    # the slicing itself: equal, disjoint, NUMA-ordered; fewer CPUs than ranks = no pinning
+    slices = [dist_utils.rank_cpus(r, 4) for r in range(4)]
+    assert len({len(s) for s in slices}) == 1 and len({c for s in slices for c in s}) == sum(len(s) for s in slices)
+    assert dist_utils.rank_cpus(0, 10 * n_cpu) == [c for node in dist_utils._numa_cpu_lists() for c in node]
