@@ -45,6 +45,9 @@ __global__ void __launch_bounds__(256) probe(const float *__restrict__ table, co
 
 int main(int argc, char **argv) {
     const int n_rows = argc > 1 ? atoi(argv[1]) : 1 << 14;            // 16 K rows x 128 B = 2 MB: fits one XCD's L2
+    // argv[2] = W > 0: every row id is drawn from the FIXED window [0, W) -- W = 64 / 128 rows = 8 / 16 KB: what every CU's 32 KB vector L1
+    // retains (is an L1 hit any cheaper than an L2 hit for this shape?); 0: the moving 4096-row neighbourhoods of the default
+    const int fixed_window = argc > 2 ? atoi(argv[2]) : 0;
     const int n_groups = 1 << 18;
     const int iters = 4;
     float *table, *sink;
@@ -54,13 +57,15 @@ int main(int argc, char **argv) {
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("table %d rows (%.1f MB), fixed window %d rows\n", n_rows, n_rows * 128 / 1048576.0, fixed_window);
     for (int keep : {16, 8, 4, 2, 1, 0}) {
+        if (fixed_window > 0 && keep != 16 && keep != 1) continue;
         std::vector<int32_t> h((size_t)n_groups * 16);
         srand(7);
         for (size_t g = 0; g < (size_t)n_groups; ++g) {
             const int first = rand() % 16;                             // which rows of the group are real: `keep` consecutive ones from a random start
             for (int s = 0; s < 16; ++s) {
-                const int base = (int)((g * 37) % (size_t)(n_rows - 4096 - 16)) + rand() % 4096;
+                const int base = fixed_window > 0 ? rand() % fixed_window : (int)((g * 37) % (size_t)(n_rows - 4096 - 16)) + rand() % 4096;
                 h[g * 16 + s] = ((s - first + 16) % 16) < keep ? base : -1;
             }
         }
