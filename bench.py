@@ -436,7 +436,9 @@ def module_api_runner(cfg, sd, dev, clouds, conv_math):
     contract, state_dict names) runs in eval mode under no_grad, results are copied to the host like the engine's."""
     from cpd_amd import models
     from cpd_amd import spconv as sp
-    sp.install(conv_math=conv_math, row_order="taps" if cfg.row_order == "taps" else "canonical")      # (the engine's row order, opt-in for modules)
+    # (the engine's row order and -- round 6 -- its fast forms, both opt-in for modules: pair rows between fused sparse layers, the
+    # optimistic range guard, the level-0 index the voxelizer built)
+    sp.install(conv_math=conv_math, row_order="taps" if cfg.row_order == "taps" else "canonical", fast_eval=conv_math == "f16x2")
     net = models.CenterPoint(point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size).to(dev).eval()
     net.load_state_dict(sd)
     vox = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features, cfg.max_points_per_voxel, cfg.max_voxels,
@@ -444,9 +446,9 @@ def module_api_runner(cfg, sd, dev, clouds, conv_math):
 
     def run(frames):
         with torch.no_grad():
-            _, coords, _, feats, nvox = vox.batch(frames)
+            _, coords, _, feats, nvox, index0 = vox.batch(frames, index_z_extra=1)
             n = int(nvox[len(frames)])
-            bd = {"voxel_features": feats[:n], "voxel_coords": coords[:n], "batch_size": len(frames)}
+            bd = {"voxel_features": feats[:n], "voxel_coords": coords[:n], "batch_size": len(frames), "voxel_index": index0}
             preds, _ = net(bd)
             # results to the host: one concatenation + one copy per key (a blocking copy per frame and key -- 144 of them at 48
             # frames -- was 3 of the step's 55 ms spent in synchronisation), cut up again on the host

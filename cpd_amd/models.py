@@ -23,6 +23,7 @@ import torch.nn as nn
 from . import autograd_ops, iou3d_nms_utils, ops, train_ops
 from . import spconv as _spconv_pkg
 from .spconv import pytorch as spconv
+from .spconv.pytorch import conv as _spc
 from .spconv.pytorch.conv import default_conv_math, fold_batchnorm as _fold_batchnorm, fusable_eval as _fusable_eval
 
 
@@ -100,7 +101,9 @@ class SparseBasicBlock(spconv.SparseModule):
             s1, t1 = _fold_batchnorm(self.bn1, self.conv1.bias)
             s2, t2 = _fold_batchnorm(self.bn2, self.conv2.bias)
             out = self.conv1(x, scale=s1, shift=t1, relu=True)
-            return self.conv2(out, scale=s2, shift=t2, residual=x.features.contiguous().float(), relu=True)
+            # (fast eval: the identity travels as the fp16-pair rows the block was handed; conv.py decodes them if conv2 cannot take them)
+            res = x._pairs if (_spc.optimistic() and x._pairs is not None) else x.features.contiguous().float()
+            return self.conv2(out, scale=s2, shift=t2, residual=res, relu=True)
         identity = x
         out = self.conv1(x)
         out = replace_feature(out, self.relu(self.bn1(out.features)))
@@ -110,6 +113,24 @@ class SparseBasicBlock(spconv.SparseModule):
             identity = self.downsample(x)
         out = replace_feature(out, self.relu(out.features + identity.features))
         return out
+
+
+def _mark_pairs_out(backbone, keep_fp32=()):
+    """Fast eval (spconv.install(fast_eval=True), f16x2): every sparse conv of the backbone whose consumer is another fused sparse layer
+    may leave fp16-pair rows (`pairs_out`, read by SparseConvolution.forward inside an optimistic range pass only); the layers in
+    `keep_fp32` -- conv_out: HeightCompression reads fp32 rows -- never do."""
+    for m in backbone.modules():
+        if isinstance(m, spconv.SparseConvolution):
+            m.pairs_out = not any(m is k for k in keep_fp32)
+
+
+def _adopt_voxel_index(x_in, batch_dict):
+    """batch_dict["voxel_index"] (optional, beyond the reference's keys): the ops.SiteIndex of `voxel_coords` over the backbone's
+    sparse_shape when the voxelizer built it with the voxel list (ops.Voxelizer.batch(index_z_extra=1)) -- the level-0 index of the
+    sparse tensor as it stands, instead of a second bitmap / scan / permutation pass here. Checked against the tensor it is for."""
+    idx = batch_dict.get("voxel_index")
+    if idx is not None and isinstance(idx, ops.SiteIndex) and idx.batch == x_in.batch_size and list(idx.shape) == list(x_in.spatial_shape):
+        x_in._site_index = idx
 
 
 class VoxelResBackBone8x(nn.Module):
@@ -160,10 +181,12 @@ class VoxelResBackBone8x(nn.Module):
         self.num_point_features = self.out_features
         if model_cfg.get("RETURN_NUM_FEATURES_AS_DICT", False):
             self.num_point_features = {"x_conv1": nf[0], "x_conv2": nf[1], "x_conv3": nf[2], "x_conv4": nf[3]}
+        _mark_pairs_out(self, keep_fp32=[self.conv_out[0]])
 
     def forward(self, batch_dict):
         x_in = spconv.SparseConvTensor(features=batch_dict["voxel_features"], indices=batch_dict["voxel_coords"].int(),
                                        spatial_shape=self.sparse_shape, batch_size=batch_dict["batch_size"])
+        _adopt_voxel_index(x_in, batch_dict)
         x = self.conv_input(x_in)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)
@@ -316,6 +339,8 @@ def _range_in_out(x, c_in, math, out_rb=None):
     block this launch fills: the caller's `out_rb` or a fresh one); (None, None) for the other arithmetics."""
     if math != "f16x2":
         return None, None
+    if _spc.optimistic():                       # fast eval: unscaled kernels, max |out| recorded in the pass's pool (spconv/pytorch/conv.py)
+        return None, _spc.record_block()
     rb_in = None
     if c_in % 32 == 0:
         rb_in = ops.tagged_range(x)
@@ -619,7 +644,7 @@ class SeparateHead(nn.Module):
                                  in_absmax=rb_in, out_absmax=rb_h1)
             rows = torch.empty((n, img["ld"]), dtype=torch.float32, device=x.device)
             ops.gather_conv(h1, img["c1"], img["w2"], nbr, 9, n, img["n_out"], None, img["b2"], None, False, out=rows, dense=True, math=math,
-                            in_absmax=rb_h1)
+                            in_absmax=None if _spc.optimistic() else rb_h1)
             maps = HeadMaps((name, _nchw(rows[:, c0:c0 + co], b, h, w)) for name, (c0, co) in img["slices"].items())
             maps.rows, maps.slices, maps.ld = rows, img["slices"], img["ld"]
             return maps
@@ -862,12 +887,44 @@ class CenterPoint(nn.Module):
     def forward(self, batch_dict):
         """centerpoint.py:9-22: training returns ({'loss': loss}, tb_dict, disp_dict) -- `loss.backward()` then reaches every
         parameter through the differentiable C-ABI convs (cpd_amd/autograd_ops.py); eval returns (pred_dicts, recall_dicts)."""
-        for m in self.module_list:
-            batch_dict = m(batch_dict)
+        batch_dict = self._run_modules(batch_dict)
         if self.training:
             loss_rpn, tb_dict = self.dense_head.get_loss()
             return {"loss": loss_rpn}, dict(loss_rpn=loss_rpn.item(), **tb_dict), {}
         return batch_dict["final_box_dicts"], {}
+
+    FAST_EVAL_STICKY_STEPS = 16
+
+    def _run_modules(self, batch_dict):
+        """module_list over the batch_dict. Fast eval (spconv.install(fast_eval=True), every module in eval(), no autograd, f16x2): the
+        modules run inside an optimistic range pass -- unscaled split-fp16 kernels, fp16-pair rows between the fused sparse layers,
+        max |activation| recorded --, the verdict is read once behind the last module, and a step with an activation >= 2^15 is run
+        AGAIN on the guarded kernels (exact at any magnitude); the model then stays guarded for FAST_EVAL_STICKY_STEPS steps, like
+        the engine (engine.RANGE_STICKY_STEPS)."""
+        fast = (not self.training and _spc.fast_eval() and default_conv_math() == "f16x2" and _fusable_eval(self)
+                and getattr(self, "_guard_left", 0) <= 0)
+        if fast:
+            feats = batch_dict.get("voxel_features")
+            fast = feats is not None and feats.is_cuda
+        if fast:
+            src = dict(batch_dict)
+            with _spc.range_pass(feats.device) as rp:
+                for m in self.module_list:
+                    batch_dict = m(batch_dict)
+                flag = rp.exceeded()
+            if not int(flag.item()):
+                return batch_dict
+            import warnings
+            warnings.warn("cpd_amd: an activation reached 2^15 -- step re-run with the range-guarded f16x2 kernels; the model stays "
+                          "guarded for the next %d steps" % self.FAST_EVAL_STICKY_STEPS)
+            self.range_reruns = getattr(self, "range_reruns", 0) + 1
+            self._guard_left = self.FAST_EVAL_STICKY_STEPS + 1
+            batch_dict = src
+        if getattr(self, "_guard_left", 0) > 0:
+            self._guard_left -= 1
+        for m in self.module_list:
+            batch_dict = m(batch_dict)
+        return batch_dict
 
     def to_engine_config(self):
         from .engine import ModelConfig

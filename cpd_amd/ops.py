@@ -415,8 +415,8 @@ class PairRows:
     __slots__ = ("rows",)
 
     def __init__(self, rows):
-        assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.is_contiguous() and rows.shape[1] % 32 == 0, \
-            "PairRows: contiguous [N, C] fp16-pair rows, C a multiple of 32"
+        assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.is_contiguous() and (rows.shape[1] % 32 == 0 or rows.shape[1] == 16), \
+            "PairRows: contiguous [N, C] fp16-pair rows, C a multiple of 32 (or the 16-channel level's [hi 4 | lo 4] k-group form)"
         self.rows = rows
 
     @property

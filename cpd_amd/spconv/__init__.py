@@ -13,11 +13,13 @@ from .pytorch import (SparseConv3d, SparseConvTensor, SparseInverseConv3d, Spars
 __version__ = "2.1.22+cpd_amd"
 
 
-def install(conv_math=None, row_order=None):
+def install(conv_math=None, row_order=None, fast_eval=None):
     """conv_math: package default for modules built without their own (`"f32"` | `"f16x2"` | `"bf16x3"`,
     cpd_amd.spconv.pytorch.conv.set_default_conv_math; also CPD_CONV_MATH).
     row_order: `"canonical"` (default) | `"taps"` -- the row order of the levels strided SparseConv3d layers produce
     (cpd_amd.spconv.pytorch.conv.set_default_row_order; also CPD_ROW_ORDER).
+    fast_eval: True | False -- the engine's fast forms on the fused eval path of the f16x2 modules: fp16-pair rows between fused sparse
+    layers and the optimistic range guard (cpd_amd.spconv.pytorch.conv.set_fast_eval; also CPD_FAST_EVAL). Same detections.
     Make `import spconv`, `import spconv.pytorch`, `from spconv.pytorch.utils import PointToVoxel`,
     `from spconv.utils import Point2VoxelCPU3d` and `import cumm.tensorview as tv` resolve to this
     package (only if the real spconv is absent)."""
@@ -26,6 +28,8 @@ def install(conv_math=None, row_order=None):
         pytorch.conv.set_default_conv_math(conv_math)
     if row_order is not None:
         pytorch.conv.set_default_row_order(row_order)
+    if fast_eval is not None:
+        pytorch.conv.set_fast_eval(fast_eval)
     for name, mod in {"spconv": me, "spconv.pytorch": pytorch, "spconv.pytorch.conv": pytorch.conv,
                       "spconv.pytorch.utils": pytorch.utils, "spconv.utils": utils}.items():
         sys.modules.setdefault(name, mod)

@@ -53,6 +53,64 @@ def default_row_order():
     return _DEFAULT_ROW_ORDER[0]
 
 
+# The engine's fast forms on the fused eval path of the MODULES (round 6), f16x2 only, opt-in through
+# `cpd_amd.spconv.install(fast_eval=True)` / set_fast_eval() / CPD_FAST_EVAL=1:
+#   * fp16-pair rows between the fused sparse layers (the producing epilogue writes x = h + l once; up to 27 gathers of the row take the
+#     bits as MFMA fragments) -- a SparseConvTensor then carries ops.PairRows and decodes `.features` only for a caller who reads it;
+#   * the OPTIMISTIC range guard: layers run their unscaled kernels and only RECORD max |out| into a pool of blocks; the detector
+#     (models.CenterPoint.forward) reads the pool's maximum with its results and runs the step again on the guarded kernels (fp32 rows,
+#     today's path) if an activation reached 2^15 -- exactly the engine's scheme (engine._range_reset).
+# Outside a `range_pass` (a module called on its own, a custom detector) every layer stays guarded, as before.
+_FAST_EVAL = [os.environ.get("CPD_FAST_EVAL", "0") not in ("0", "", "false")]
+_RANGE = {"pool": None, "next": 0, "active": False}
+
+
+def set_fast_eval(on):
+    _FAST_EVAL[0] = bool(on)
+
+
+def fast_eval():
+    return _FAST_EVAL[0]
+
+
+class range_pass:
+    """with range_pass(device, n_blocks) as rp: ... the fused layers inside run unguarded and record; rp.exceeded() -> device int32 [1]
+    (1: some recorded activation >= 2^15, NaN or inf: run the step again outside the pass)."""
+
+    def __init__(self, device, n_blocks=96):
+        self.device, self.n = device, int(n_blocks)
+
+    def __enter__(self):
+        pool = _RANGE["pool"]
+        if pool is None or pool.device != torch.device(self.device) or pool.shape[0] < self.n:
+            pool = _RANGE["pool"] = ops.absmax_blocks(self.n, self.device)
+        else:
+            pool.zero_()
+        _RANGE["next"], _RANGE["active"] = 0, True
+        return self
+
+    def __exit__(self, *exc):
+        _RANGE["active"] = False
+
+    @staticmethod
+    def exceeded():
+        return (_RANGE["pool"].max() >= 0x47000000).to(torch.int32).view(1)       # bits of 32768.0f; NaN / inf bits are larger
+
+
+def optimistic():
+    """inside a range_pass: the fused f16x2 layers record instead of guarding"""
+    return _RANGE["active"]
+
+
+def record_block():
+    """the next block of the active pass's pool (a layer's `out_absmax`)"""
+    if _RANGE["next"] >= _RANGE["pool"].shape[0]:
+        raise RuntimeError("range_pass: more fused conv launches than the %d absmax blocks of the pass" % _RANGE["pool"].shape[0])
+    b = _RANGE["pool"][_RANGE["next"]]
+    _RANGE["next"] += 1
+    return b
+
+
 def fold_batchnorm(bn, conv_bias=None):
     """Eval-mode BatchNorm (+ the preceding conv's bias) as the conv epilogue's per-channel (scale, shift), cached on the
     BatchNorm module until one of its tensors (or the bias) changes."""
@@ -141,7 +199,11 @@ class SparseConvolution(SparseModule):
         if self.inverse:
             raise NotImplementedError("SparseInverseConv3d is declared by the reference (spconv_backbone.py:24) "
                                       "but never instantiated by any shipped config")
-        feats = x.features.contiguous().float()
+        fused = scale is not None or shift is not None or residual is not None or relu
+        # fp16-pair rows in (round 6): only between fused split-fp16 layers of an optimistic pass (the guarded re-run reads fp32 rows)
+        fast = fused and optimistic() and self.conv_math == "f16x2" and not torch.is_grad_enabled()
+        in_pairs = fast and x._pairs is not None and (self.in_channels % 32 == 0 or self.in_channels == 16)
+        feats = x._pairs.rows if in_pairs else x.features.contiguous().float()
         if not feats.is_cuda:
             raise ops._lib.CpdHipError("cpd_amd.spconv runs on the GPU only (no CPU fallback)")
         kv = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
@@ -180,17 +242,34 @@ class SparseConvolution(SparseModule):
 
         spec = autograd_ops.ConvSpec(nbr, kv, out_indices.shape[0], dense=False, math=self.conv_math,
                                      mode="same" if self.subm else "strided", adjoint=adjoint, packed=self._packed_weight())
-        if scale is not None or shift is not None or residual is not None or relu:
+        if fused:
             assert not torch.is_grad_enabled(), "the fused epilogue is an inference path"
             shift = ops.epilogue_shift(scale, shift, self.bias)
-            # f16x2: the range block travels with the feature tensor (ops.tag_range); a tensor without one -- or modified in place
-            # since it was tagged -- is measured first
-            guard = self.conv_math == "f16x2"
-            rb_in = ops.range_block(x.features, self.in_channels) if guard and self.in_channels % 32 == 0 else None
-            rb_out = ops.absmax_blocks(1, feats.device)[0] if guard else None
-            out_feats = ops.gather_conv(feats, self.in_channels, spec.packed, nbr, kv, spec.n_out, self.out_channels, scale, shift,
-                                        residual, relu, dense=False, math=self.conv_math, in_absmax=rb_in, out_absmax=rb_out)
-            ops.tag_range(out_feats, rb_out)
+            if fast:
+                # optimistic pass: unscaled kernels, max |out| recorded; pair rows out where the consumer is another fused sparse layer
+                # (`pairs_out`, set by the containers: SparseBasicBlock, the backbone) and the kernels have the form -- the engine's
+                # combinations: fp32 5-channel rows -> 16-channel pairs, pairs -> pairs, a pair residual with pair rows out
+                out_pairs = bool(getattr(self, "pairs_out", False)) and (self.out_channels % 32 == 0 or self.out_channels == 16) \
+                    and (in_pairs or self.in_channels < 16)
+                res_pairs = isinstance(residual, ops.PairRows)
+                if res_pairs and not out_pairs:
+                    residual, res_pairs = residual.float_rows(), False
+                out_feats = ops.gather_conv(feats, self.in_channels, spec.packed, nbr, kv, spec.n_out, self.out_channels, scale, shift,
+                                            residual.rows if res_pairs else residual, relu, dense=False, math=self.conv_math,
+                                            out_absmax=record_block(), in_pairs=in_pairs, out_pairs=out_pairs, res_pairs=res_pairs)
+                if out_pairs:
+                    out_feats = ops.PairRows(out_feats)
+            else:
+                if isinstance(residual, ops.PairRows):
+                    residual = residual.float_rows()
+                # f16x2: the range block travels with the feature tensor (ops.tag_range); a tensor without one -- or modified in place
+                # since it was tagged -- is measured first
+                guard = self.conv_math == "f16x2"
+                rb_in = ops.range_block(x.features, self.in_channels) if guard and self.in_channels % 32 == 0 else None
+                rb_out = ops.absmax_blocks(1, feats.device)[0] if guard else None
+                out_feats = ops.gather_conv(feats, self.in_channels, spec.packed, nbr, kv, spec.n_out, self.out_channels, scale, shift,
+                                            residual, relu, dense=False, math=self.conv_math, in_absmax=rb_in, out_absmax=rb_out)
+                ops.tag_range(out_feats, rb_out)
         else:
             w_kio = self.weight.reshape(self.out_channels, kv, self.in_channels).permute(1, 2, 0)
             out_feats = autograd_ops.gather_conv(feats, w_kio, self.bias, spec)

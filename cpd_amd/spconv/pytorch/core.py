@@ -9,7 +9,10 @@ class SparseConvTensor:
     (neighbour table) and site index built by the HIP kernels."""
 
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None, benchmark=False):
-        self.features = features
+        # `features` may arrive as ops.PairRows (fp16-pair rows left by a fused split-fp16 layer): the next fused layer takes the stored
+        # bits as they are; anyone who READS `.features` gets fp32 rows, decoded once and kept (h + l is exact in fp32)
+        self._pairs = features if isinstance(features, ops.PairRows) else None
+        self._features = None if self._pairs is not None else features
         self.indices = indices.int() if indices.dtype != torch.int32 else indices
         self.spatial_shape = [int(s) for s in spatial_shape]
         self.batch_size = int(batch_size)
@@ -18,6 +21,17 @@ class SparseConvTensor:
         self.benchmark = benchmark
         self._site_index = None   # SiteIndex of (indices, spatial_shape), built lazily
         self._row_canon = None    # (canonical site list, old_to_new, chunk) of a level kept in tap-pattern row order (conv.py)
+
+    @property
+    def features(self):
+        if self._features is None and self._pairs is not None:
+            self._features = self._pairs.float_rows()
+        return self._features
+
+    @features.setter
+    def features(self, value):
+        self._pairs = value if isinstance(value, ops.PairRows) else None
+        self._features = None if self._pairs is not None else value
 
     @property
     def spatial_size(self):

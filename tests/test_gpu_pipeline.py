@@ -770,3 +770,79 @@ def test_module_path_in_tap_pattern_row_order_changes_no_result(hip, math):
         assert torch.equal(ia[oa], ib[ob]) and torch.equal(fa[oa], fb[ob]), name
         reordered += int(not torch.equal(ia, ib))
     assert reordered >= 2, "no level was re-ordered: the comparison would be vacuous"
+
+
+def test_fast_eval_module_path_matches_the_guarded_modules_and_reruns_out_of_range_steps(hip):
+    """cpd_amd.spconv.install(fast_eval=True) (round 6): the fused eval modules run the engine's fast forms -- fp16-pair
+    rows between fused sparse layers (kernel names asserted), the unscaled split-fp16 kernels inside an optimistic range pass, the
+    level-0 index handed over by the voxelizer (batch_dict["voxel_index"]). Against the same model on the guarded fp32-row path: every
+    sparse level the same rows to fp32 rounding (read through `.features`: pair rows decode on demand), the BEV map and the head maps
+    to 1e-4, the same detections. Then a batch whose activations leave fp16's range: the step is re-run guarded, the results are the
+    guarded path's bit for bit, and the model stays guarded for the sticky steps."""
+    import warnings
+    from cpd_amd import models
+    from cpd_amd import spconv as sp
+    from cpd_amd.spconv.pytorch import conv as spc
+    cfg = ModelConfig()
+    sd = init_state_dict(cfg, seed=4)
+    vox = ops.Voxelizer(cfg.voxel_size, cfg.point_cloud_range, cfg.num_point_features, cfg.max_points_per_voxel, cfg.max_voxels)
+    clouds = [torch.from_numpy(waymo_cloud(s)).cuda() for s in (0, 1)]
+    old_math, old_order, old_fast = spc.default_conv_math(), spc.default_row_order(), spc.fast_eval()
+    outs = {}
+    try:
+        for fast in (False, True):
+            sp.install(conv_math="f16x2", row_order="taps", fast_eval=fast)
+            net = models.CenterPoint(point_cloud_range=cfg.point_cloud_range, voxel_size=cfg.voxel_size).cuda().eval()
+            net.load_state_dict(sd)
+            with torch.no_grad():
+                _, coords, _, feats, nvox, index0 = vox.batch(clouds, index_z_extra=1)
+                n = int(nvox[2])
+                bd = {"voxel_features": feats[:n].clone(), "voxel_coords": coords[:n].clone(), "batch_size": 2}
+                if fast:
+                    bd["voxel_index"] = index0
+                with ops.launch_log() as log:
+                    preds, _ = net(bd)
+            lv = bd["multi_scale_3d_features"]
+            if fast:
+                assert all(t._pairs is not None for t in lv.values()), "no level travelled as pair rows"
+                assert bd["encoded_spconv_tensor"]._pairs is None                 # conv_out hands HeightCompression fp32 rows
+                names = log.counts
+                assert any(k.startswith("rowwave_conv_f16pe_kernel") for k in names), names      # pair rows in AND out, LDS epilogue
+                assert any(k.startswith("gather_conv_h16_kernel") for k in names), names         # the 16-channel level on pair rows
+                assert not any("f16s" in k for k in names), names                                 # nothing ran guarded
+                assert net.backbone_3d.conv_input[0].indice_key == "subm1" and bd["voxel_index"] is index0
+            outs[fast] = (preds, {k: (t.features.clone(), t.indices.clone()) for k, t in lv.items()}, bd["spatial_features"].clone(),
+                          bd["st_features_2d"].clone())
+        (pa, la, sa, ca), (pb, lb, sb_, cb) = outs[False], outs[True]
+        assert sum(len(p["pred_boxes"]) for p in pa) > 10
+        for name in la:
+            assert torch.equal(la[name][1], lb[name][1]), name                     # same rows in the same order
+            scale = max(1.0, float(la[name][0].abs().max()))
+            assert float((la[name][0] - lb[name][0]).abs().max()) <= 1e-4 * scale, name
+        assert float((sa - sb_).abs().max()) <= 1e-4 * max(1.0, float(sa.abs().max()))
+        assert float((ca - cb).abs().max()) <= 1e-4 * max(1.0, float(ca.abs().max()))
+        for p, q in zip(pa, pb):
+            assert abs(len(p["pred_boxes"]) - len(q["pred_boxes"])) <= 2
+            x, y = p["pred_boxes"].cpu().numpy(), q["pred_boxes"].cpu().numpy()
+            d = np.abs(x[:, None, :] - y[None, :, :]).max(-1).min(1)
+            assert (d <= 1e-3).mean() >= 0.98
+        # ---- out of range: features x 2^14 push the first layers' activations beyond fp16 -> optimistic pass flags it, guarded re-run
+        with torch.no_grad():
+            big = {"voxel_features": feats[:n].clone() * 16384.0, "voxel_coords": coords[:n].clone(), "batch_size": 2}
+            sp.install(fast_eval=False)
+            want, _ = net(dict(big))
+            sp.install(fast_eval=True)
+            net.range_reruns = 0
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter("always")
+                got, _ = net(dict(big))
+            assert net.range_reruns == 1 and any("re-run" in str(w.message) for w in wlist)
+            for p, q in zip(want, got):
+                assert torch.isfinite(q["pred_boxes"]).all() and all(torch.equal(p[k], q[k]) for k in ("pred_boxes", "pred_scores", "pred_labels"))
+            left = net._guard_left
+            assert left == net.FAST_EVAL_STICKY_STEPS
+            again, _ = net(dict(big))                                              # guarded straight away: no second re-run
+            assert net.range_reruns == 1 and net._guard_left == left - 1
+            assert all(torch.equal(p["pred_boxes"], q["pred_boxes"]) for p, q in zip(want, again))
+    finally:
+        spc.set_default_conv_math(old_math); spc.set_default_row_order(old_order); spc.set_fast_eval(old_fast)
