@@ -605,7 +605,35 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
     sec = time_steps(lambda i: run([clouds[(i * B + j) % POOL] for j in range(B)]), 6, 2)
     out["module_api"] = {"value": B / sec, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 6, "ratio_to_engine": B / sec / value,
                          "note": "device voxelizer -> batch_dict -> cpd_amd.models.CenterPoint (eval, no_grad; the row order of --row-order (tap-pattern by default: spconv.install(row_order=...)), "
-                                 "first-appearance voxel order as at the B1 boundary), results copied to the host"}
+                                 "fast eval (round 6: pair rows between fused sparse layers, optimistic range pass, the voxelizer's level-0 index; spconv.install(fast_eval=True)), "
+                                 "first-appearance voxel order as at the B1 boundary), results copied to the host; ONE stream -- ratio_to_engine is "
+                                 "against the headline's %d stream(s); two_batches_in_flight: two model instances on two HIP streams, as the headline runs" % max(1, args.streams)}
+    if max(1, args.streams) >= 2:
+        try:
+            import threading
+            runs = [run, module_api_runner(cfg, sd, dev, clouds, cfg.conv_math)]
+            strs = list(streams[:2]) + [torch.cuda.Stream(device=dev) for _ in range(2 - len(streams[:2]))]
+
+            def go(n):
+                def worker(w):
+                    torch.cuda.set_device(torch.device(dev))
+                    with torch.cuda.stream(strs[w]):
+                        for i in range(w, n, 2):
+                            runs[w]([clouds[(i * B + j) % POOL] for j in range(B)])
+                        strs[w].synchronize()
+                ts = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+                [t.start() for t in ts]
+                [t.join() for t in ts]
+            go(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            go(8)
+            torch.cuda.synchronize()
+            sec2 = (time.perf_counter() - t0) / 8
+            out["module_api"]["two_batches_in_flight"] = {"value": B / sec2, "ms_per_step_amortised": 1e3 * sec2, "steps": 8,
+                                                          "ratio_to_engine": B / sec2 / value}
+        except Exception as e:
+            out["module_api"]["two_batches_in_flight"] = {"error": repr(e)[:300]}
     return out
 
 

@@ -62,7 +62,14 @@ def default_row_order():
 #     today's path) if an activation reached 2^15 -- exactly the engine's scheme (engine._range_reset).
 # Outside a `range_pass` (a module called on its own, a custom detector) every layer stays guarded, as before.
 _FAST_EVAL = [os.environ.get("CPD_FAST_EVAL", "0") not in ("0", "", "false")]
-_RANGE = {"pool": None, "next": 0, "active": False}
+import threading as _threading
+
+
+class _RangeState(_threading.local):          # per thread: two batches in flight on two HIP streams (two worker threads) each own a pass
+    pool, next, active = None, 0, False
+
+
+_RANGE = _RangeState()
 
 
 def set_fast_eval(on):
@@ -81,33 +88,33 @@ class range_pass:
         self.device, self.n = device, int(n_blocks)
 
     def __enter__(self):
-        pool = _RANGE["pool"]
+        pool = _RANGE.pool
         if pool is None or pool.device != torch.device(self.device) or pool.shape[0] < self.n:
-            pool = _RANGE["pool"] = ops.absmax_blocks(self.n, self.device)
+            pool = _RANGE.pool = ops.absmax_blocks(self.n, self.device)
         else:
             pool.zero_()
-        _RANGE["next"], _RANGE["active"] = 0, True
+        _RANGE.next, _RANGE.active = 0, True
         return self
 
     def __exit__(self, *exc):
-        _RANGE["active"] = False
+        _RANGE.active = False
 
     @staticmethod
     def exceeded():
-        return (_RANGE["pool"].max() >= 0x47000000).to(torch.int32).view(1)       # bits of 32768.0f; NaN / inf bits are larger
+        return (_RANGE.pool.max() >= 0x47000000).to(torch.int32).view(1)       # bits of 32768.0f; NaN / inf bits are larger
 
 
 def optimistic():
     """inside a range_pass: the fused f16x2 layers record instead of guarding"""
-    return _RANGE["active"]
+    return _RANGE.active
 
 
 def record_block():
     """the next block of the active pass's pool (a layer's `out_absmax`)"""
-    if _RANGE["next"] >= _RANGE["pool"].shape[0]:
-        raise RuntimeError("range_pass: more fused conv launches than the %d absmax blocks of the pass" % _RANGE["pool"].shape[0])
-    b = _RANGE["pool"][_RANGE["next"]]
-    _RANGE["next"] += 1
+    if _RANGE.next >= _RANGE.pool.shape[0]:
+        raise RuntimeError("range_pass: more fused conv launches than the %d absmax blocks of the pass" % _RANGE.pool.shape[0])
+    b = _RANGE.pool[_RANGE.next]
+    _RANGE.next += 1
     return b
 
 

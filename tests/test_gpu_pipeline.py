@@ -825,7 +825,7 @@ def test_fast_eval_module_path_matches_the_guarded_modules_and_reruns_out_of_ran
             assert abs(len(p["pred_boxes"]) - len(q["pred_boxes"])) <= 2
             x, y = p["pred_boxes"].cpu().numpy(), q["pred_boxes"].cpu().numpy()
             d = np.abs(x[:, None, :] - y[None, :, :]).max(-1).min(1)
-            assert (d <= 1e-3).mean() >= 0.98
+            assert (d <= 5e-3).mean() >= 0.98 and np.median(d) <= 5e-4        # (decoded: exp() of the sizes, atan2 of the heading maps)
         # ---- out of range: features x 2^14 push the first layers' activations beyond fp16 -> optimistic pass flags it, guarded re-run
         with torch.no_grad():
             big = {"voxel_features": feats[:n].clone() * 16384.0, "voxel_coords": coords[:n].clone(), "batch_size": 2}
