@@ -824,8 +824,10 @@ def test_fast_eval_module_path_matches_the_guarded_modules_and_reruns_out_of_ran
         for p, q in zip(pa, pb):
             assert abs(len(p["pred_boxes"]) - len(q["pred_boxes"])) <= 2
             x, y = p["pred_boxes"].cpu().numpy(), q["pred_boxes"].cpu().numpy()
-            d = np.abs(x[:, None, :] - y[None, :, :]).max(-1).min(1)
-            assert (d <= 5e-3).mean() >= 0.98 and np.median(d) <= 5e-4        # (decoded: exp() of the sizes, atan2 of the heading maps)
+            # (centres and sizes; the heading is atan2 of two head maps that random-init weights leave near zero: 1e-4 on the maps is
+            # 1e-2 rad there, so it is compared on the maps above, not here)
+            d = np.abs(x[:, None, :6] - y[None, :, :6]).max(-1).min(1)
+            assert (d <= 2e-3).mean() >= 0.98 and np.median(d) <= 5e-4
         # ---- out of range: features x 2^14 push the first layers' activations beyond fp16 -> optimistic pass flags it, guarded re-run
         with torch.no_grad():
             big = {"voxel_features": feats[:n].clone() * 16384.0, "voxel_coords": coords[:n].clone(), "batch_size": 2}
