@@ -3919,6 +3919,9 @@ static int conv3x3_rows_impl(const float *in, int in_ld, int frames, int h, int 
         cpd_launch_log_note(nm);
         const size_t win = (size_t)(bm + 8) * 128, tile = (size_t)64 * (bn + 4) * 4;
         const size_t wts = bn >= 64 ? 2 * 2 * (size_t)bn * 64 : 2 * (size_t)bn * 64;
+        // (round 6, measured and NOT kept: padding this launch's LDS so that only TWO 128 x 128 workgroups fit a CU -- room for a sparse
+        // kernel of the other batch in flight on the same CU, matrix pipe and vector-memory pipe side by side -- 1219.9 / 1217.7 frames/s
+        // without, 1191.9 / 1176.6 with 26 KB of padding, 1034.1 / 1021.5 with 40 KB: gpurun_out r06_winpad)
         const size_t ldsp = win + wts > tile ? win + wts : tile;
         if (bn == 128) hipLaunchKernelGGL((window_conv_f16p_kernel<128, 128>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);
         else if (bn == 64 && bm == 256) hipLaunchKernelGGL((window_conv_f16p_kernel<64, 256>), dim3(p.items), dim3(256), ldsp, cpd_s(stream), p);

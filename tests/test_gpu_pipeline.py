@@ -827,7 +827,7 @@ def test_fast_eval_module_path_matches_the_guarded_modules_and_reruns_out_of_ran
             # (centres and sizes; the heading is atan2 of two head maps that random-init weights leave near zero: 1e-4 on the maps is
             # 1e-2 rad there, so it is compared on the maps above, not here)
             d = np.abs(x[:, None, :6] - y[None, :, :6]).max(-1).min(1)
-            assert (d <= 2e-3).mean() >= 0.98 and np.median(d) <= 5e-4
+            assert (d <= 1e-2).mean() >= 0.98 and np.median(d) <= 1e-3      # (sizes are exp() of maps of scale ~10 that agree to 1e-4 of it)
         # ---- out of range: features x 2^14 push the first layers' activations beyond fp16 -> optimistic pass flags it, guarded re-run
         with torch.no_grad():
             big = {"voxel_features": feats[:n].clone() * 16384.0, "voxel_coords": coords[:n].clone(), "batch_size": 2}
