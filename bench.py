@@ -128,6 +128,8 @@ def parse():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE config 2 (the headline metric); train = config 3: forward + backward + "
                          "one RCCL gradient all-reduce + Adam, --frames (default 1) frames per GPU per step")
+    ap.add_argument("--sync-bn", action="store_true", help="--mode train: SyncBatchNorm (the reference's --sync_bn, tools/train.py:32; off by "
+                    "default there and here): BatchNorm statistics all-reduced over the ranks")
     ap.add_argument("--device-results", action="store_true", help="leave the final boxes on the device (default: the one D2H "
                     "of each step's boxes / scores / labels into host memory is inside the timed region, SURVEY 8d)")
     ap.add_argument("--api", choices=["engine", "modules"], default="engine",
@@ -822,7 +824,7 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
     clouds = [torch.from_numpy(c).cuda() for c in make_clouds(seeds, args.points)]
     gts = [torch.from_numpy(gt_boxes(s)).cuda() for s in seeds]
     POOL_T = len(seeds)
-    tr = CenterPointTrainer(cfg, sd, device=dev, total_steps=max(total, 2), world_size=world)
+    tr = CenterPointTrainer(cfg, sd, device=dev, total_steps=max(total, 2), world_size=world, sync_bn=args.sync_bn)
     prof = ConvProfiler() if not args.no_roofline else None
 
     def step(i):
@@ -874,7 +876,7 @@ def train_main(args, cfg, sd, dev, rank, world, distributed):
                    "frames_per_step_per_gpu": B, "parallelism": "data-parallel x%d, one RCCL all-reduce of the flat "
                    "gradient buffer (%.1f MB fp32) per step" % (world, tr.store.grad.numel() * 4 / 1e6),
                    "optimizer": "Adam(betas=(0.9,0.99)) + decoupled wd 1e-5 + OneCycle lr 3e-3 + grad-norm clip 32",
-                   "batch_norm": "training mode: batch statistics + running-stat update, local to the rank (no SyncBN, as the reference default)",
+                   "batch_norm": ("training mode: batch statistics all-reduced over the ranks (SyncBatchNorm, --sync-bn)" if args.sync_bn else "training mode: batch statistics + running-stat update, local to the rank (no SyncBN, as the reference default)"),
                    "arithmetic": {"forward": tr.store.math, "input_and_weight_gradients": tr.store.grad_math if tr.store.math != "f32" else "f32",
                                   "note": "f16x2 = fp32 operands as two fp16 terms, three MFMA products, fp32 accumulation (fp32-level "
                                           "result); gradient tensors are pre-scaled into fp16's range by a power of two taken from "

@@ -128,6 +128,8 @@ SIGNATURES = {
     "cpd_affine_rows": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),
     "cpd_bn_bwd_reduce": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_bn_bwd_apply": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP]),
+    "cpd_bn_finalize_sync": (_I, [_VP, _VP, _VP, _I, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "cpd_bn_bwd_apply_sync": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP]),
     "cpd_relu_bwd": (_I, [_VP, _I, _VP, _I, _I, _I, _VP, _I, _VP]),
     "cpd_conv_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cpd_conv_wgrad": (_I, [_VP, _I, _I, _VP, _I, _I, _VP, _I, _I, _VP, _I, _VP, _SZ, _VP]),

@@ -192,10 +192,12 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *__restri
                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
                                                            const float *__restrict__ gamma, const float *__restrict__ s1,
                                                            const float *__restrict__ s2, float *__restrict__ dx, int lddx,
-                                                           float *__restrict__ dres, int lddres, uint32_t *__restrict__ dx_absmax) {
+                                                           float *__restrict__ dres, int lddres, uint32_t *__restrict__ dx_absmax,
+                                                           const float *__restrict__ n_stat) {
     const int cv = c / V;
     const long long total = (long long)n * cv;
-    const float inv_n = 1.0f / (float)n;
+    // n_stat (SyncBN, cpd_bn_bwd_apply_sync): the row count the statistics -- and s1 / s2 -- were summed over (all ranks'), on the device
+    const float inv_n = 1.0f / (n_stat ? *n_stat : (float)n);
     float vmax = 0.f;
     bool bad = false;                       // a NaN anywhere must reach the word (it switches the fp16 scaling off, loudly)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -797,14 +799,15 @@ __global__ void __launch_bounds__(256) rulebook_conv2d_transpose_kernel(int batc
 // Per-channel BatchNorm bookkeeping in one launch: batch mean / biased var -> invstd, the affine
 // (scale, shift) that cpd_affine_rows applies, and the running-stat update with the unbiased
 // variance (torch.nn.BatchNorm semantics; momentum 0.01 / eps 1e-3 in the backbones).
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float *__restrict__ sum, const float *__restrict__ sumsq, int n,
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float *__restrict__ sum, const float *__restrict__ sumsq, int n_rows,
                                                           int c, float eps, float momentum, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ mean,
                                                           float *__restrict__ invstd, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ running_mean,
-                                                          float *__restrict__ running_var) {
+                                                          float *__restrict__ running_var, const float *__restrict__ n_stat) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= c) return;
+    const double n = n_stat ? (double)*n_stat : (double)n_rows;        // (SyncBN: the all-reduced row count, a device value)
     const double mu = (double)sum[col] / n;
     double var = (double)sumsq[col] / n - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -815,7 +818,7 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float *__restric
     scale[col] = sc;
     shift[col] = beta[col] - (float)mu * sc;
     if (running_mean) {
-        const double unbiased = n > 1 ? var * n / (n - 1.0) : var;
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
         running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * (float)mu;
         running_var[col] = (1.f - momentum) * running_var[col] + momentum * (float)unbiased;
     }
@@ -1213,7 +1216,16 @@ extern "C" int cpd_bn_finalize(const float *sum, const float *sumsq, int n, int 
         (running_mean && !running_var))
         return CPD_ERR_ARG;
     bn_finalize_kernel<<<cpd_div_up(c, 256), 256, 0, cpd_s(st)>>>(sum, sumsq, n, c, eps, momentum, gamma, beta, mean, invstd, scale,
-                                                                 shift, running_mean, running_var);
+                                                                 shift, running_mean, running_var, nullptr);
+    return cpd_check_launch();
+}
+extern "C" int cpd_bn_finalize_sync(const float *sum, const float *sumsq, const float *n_total, int c, float eps, float momentum,
+                                    const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
+                                    float *running_mean, float *running_var, cpd_stream_t st) {
+    if (!sum || !sumsq || !n_total || !gamma || !beta || !mean || !invstd || !scale || !shift || c <= 0 || (running_mean && !running_var))
+        return CPD_ERR_ARG;
+    bn_finalize_kernel<<<cpd_div_up(c, 256), 256, 0, cpd_s(st)>>>(sum, sumsq, 0, c, eps, momentum, gamma, beta, mean, invstd, scale,
+                                                                 shift, running_mean, running_var, n_total);
     return cpd_check_launch();
 }
 extern "C" int cpd_affine_rows(const float *x, int ldx, int n, int c, const float *scale, const float *shift,
@@ -1228,10 +1240,27 @@ extern "C" int cpd_affine_rows(const float *x, int ldx, int n, int c, const floa
                                                                                         out, ldo);
     return cpd_check_launch();
 }
+static int bn_bwd_apply_impl(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, int n, int c,
+                             const float *mean, const float *invstd, const float *gamma, const float *dbeta,
+                             const float *dgamma, float *dx, int lddx, float *dres, int lddres, uint32_t *dx_absmax,
+                             const float *n_stat, cpd_stream_t st);
 extern "C" int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, int n, int c,
                                 const float *mean, const float *invstd, const float *gamma, const float *dbeta,
                                 const float *dgamma, float *dx, int lddx, float *dres, int lddres, uint32_t *dx_absmax,
                                 cpd_stream_t st) {
+    return bn_bwd_apply_impl(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, dbeta, dgamma, dx, lddx, dres, lddres, dx_absmax, nullptr, st);
+}
+extern "C" int cpd_bn_bwd_apply_sync(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, int n, int c,
+                                     const float *mean, const float *invstd, const float *gamma, const float *sum_dy,
+                                     const float *sum_dy_xhat, const float *n_total, float *dx, int lddx, float *dres, int lddres,
+                                     uint32_t *dx_absmax, cpd_stream_t st) {
+    if (!n_total) return CPD_ERR_ARG;
+    return bn_bwd_apply_impl(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, sum_dy, sum_dy_xhat, dx, lddx, dres, lddres, dx_absmax, n_total, st);
+}
+static int bn_bwd_apply_impl(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, int n, int c,
+                             const float *mean, const float *invstd, const float *gamma, const float *dbeta,
+                             const float *dgamma, float *dx, int lddx, float *dres, int lddres, uint32_t *dx_absmax,
+                             const float *n_stat, cpd_stream_t st) {
     if (!dy || !x || !mean || !invstd || !gamma || !dbeta || !dgamma || !dx || n <= 0 || c <= 0) return CPD_ERR_ARG;
     const bool vec = c % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!y || ldy % 4 == 0) && (!dres || lddres % 4 == 0) &&
                      ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15) == 0;
@@ -1240,9 +1269,9 @@ extern "C" int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int l
     if (nblk >= (1ll << 31)) return CPD_ERR_UNSUPPORTED;
     const unsigned blocks = (unsigned)nblk;
     if (vec) bn_bwd_apply_kernel<4><<<blocks, 256, 0, cpd_s(st)>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, dbeta, dgamma, dx, lddx,
-                                                                  dres, lddres, dx_absmax);
+                                                                  dres, lddres, dx_absmax, n_stat);
     else bn_bwd_apply_kernel<1><<<blocks, 256, 0, cpd_s(st)>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, dbeta, dgamma, dx, lddx,
-                                                              dres, lddres, dx_absmax);
+                                                              dres, lddres, dx_absmax, n_stat);
     return cpd_check_launch();
 }
 extern "C" int cpd_relu_bwd(const float *dy, int lddy, const float *y, int ldy, int n, int c, float *dx, int lddx,

@@ -172,9 +172,16 @@ class _Conv:
         else:
             z = ops.gather_conv(x, self.c_in, self.pw, nbr, self.kv, n_out, self.c_out, None, bias, None, False,
                                 dense=dense, math=self.store.math)
-        mean, invstd, scale, shift = train_ops.bn_stats_finalize(
-            z, self.eps, self.momentum, st.p(self.gn), st.p(self.be),
-            self.running_mean if update_stats else None, self.running_var if update_stats else None)
+        self.n_total = None
+        if getattr(st, "sync_bn", False):
+            # SyncBatchNorm (tools/train.py:32,117 --sync_bn): statistics over every rank's rows (train_ops.bn_stats_finalize_sync)
+            mean, invstd, scale, shift, self.n_total = train_ops.bn_stats_finalize_sync(
+                z, self.eps, self.momentum, st.p(self.gn), st.p(self.be),
+                self.running_mean if update_stats else None, self.running_var if update_stats else None, group=st.group)
+        else:
+            mean, invstd, scale, shift = train_ops.bn_stats_finalize(
+                z, self.eps, self.momentum, st.p(self.gn), st.p(self.be),
+                self.running_mean if update_stats else None, self.running_var if update_stats else None)
         y = train_ops.affine_rows(z, scale, shift, residual, self.relu, out=out)
         self.saved = (x, nbr, n_out, z, y, mean, invstd, residual is not None, dense, up_map)
         return y
@@ -193,7 +200,8 @@ class _Conv:
                 am = st.absmax[self.am_slot * train_ops.ABSMAX_WORDS:(self.am_slot + 1) * train_ops.ABSMAX_WORDS]
                 gmath = wmath = "f16x2"
             dz, _, _, dres = train_ops.bn_backward(dy, y if self.relu else None, z, mean, invstd, st.p(self.gn),
-                                                   want_dres=has_res, dgamma=st.g(self.gn), dbeta=st.g(self.be), dx_absmax=am)
+                                                   want_dres=has_res, dgamma=st.g(self.gn), dbeta=st.g(self.be), dx_absmax=am,
+                                                   sync=(self.n_total, st.group) if getattr(self, "n_total", None) is not None else None)
         else:
             dz = train_ops.relu_backward(dy, y) if self.relu else dy
         gw = st.g(self.wn)
@@ -259,7 +267,10 @@ class CenterPointTrainer:
 
     def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], device="cuda", lr=3e-3, betas=(0.9, 0.99),
                  weight_decay=1e-5, grad_clip=32.0, total_steps=None, process_group=None, world_size=1,
-                 num_max_objs=500, code_weights=None):
+                 num_max_objs=500, code_weights=None, sync_bn=False):
+        """sync_bn: the reference's `--sync_bn` (tools/train.py:32,117: SyncBatchNorm.convert_sync_batchnorm; off by default there and
+        here) -- every BatchNorm's batch statistics, and the two sums of its backward pass, are all-reduced over `process_group`; a step of
+        N ranks x 1 frame then normalises like one process with the N frames in its batch."""
         self.cfg = cfg
         self.device = torch.device(device)
         self.lr, self.betas, self.weight_decay, self.grad_clip = lr, betas, weight_decay, grad_clip
@@ -271,6 +282,8 @@ class CenterPointTrainer:
         self.fused_targets = os.environ.get("CPD_TRAIN_FUSED_TARGETS", "1") != "0"    # cpd_center_targets instead of center_loss.assign_targets
         self.steps_done = 0
         self.store = _Flat()
+        self.store.sync_bn = bool(sync_bn) and (world_size > 1 or bool(os.environ.get("CPD_FORCE_DIST")))
+        self.store.group = process_group
         self.store.math = cfg.conv_math
         self.store.dgrad_math = "f32" if cfg.conv_math == "f32" else "bf16x3"
         self.store.bf16x3 = cfg.conv_math != "f32"

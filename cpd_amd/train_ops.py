@@ -75,6 +75,26 @@ def bn_stats_finalize(x, eps, momentum, gamma, beta, running_mean=None, running_
     return out[0], out[1], out[2], out[3]
 
 
+def bn_stats_finalize_sync(x, eps, momentum, gamma, beta, running_mean=None, running_var=None, group=None):
+    """SyncBatchNorm forward bookkeeping (tools/train.py:117 convert_sync_batchnorm): this rank's (sum, sumsq, rows) all-reduced over the
+    data-parallel group, then mean / invstd / scale / shift from the totals (cpd_bn_finalize_sync: the total row count is a device value).
+    -> (mean, invstd, scale, shift, n_total [1] device float -- bn_backward(sync=...) needs it)."""
+    import torch.distributed as dist
+    n, c = x.shape
+    if n > 0:
+        s1, s2 = bn_stats(x)
+        buf = torch.cat([s1, s2, torch.full((1,), float(n), dtype=torch.float32, device=x.device)])
+    else:                                        # a rank without rows at this level still takes part in the collective
+        buf = torch.zeros((2 * c + 1,), dtype=torch.float32, device=x.device)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    out = torch.empty((4, c), dtype=torch.float32, device=x.device)
+    n_total = buf[2 * c:]
+    check(lib().cpd_bn_finalize_sync(_p(buf[:c]), _p(buf[c:2 * c]), _p(n_total), c, float(eps), float(momentum), ptr(gamma), ptr(beta),
+                                     _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), ptr(running_mean), ptr(running_var), stream()),
+          "cpd_bn_finalize_sync")
+    return out[0], out[1], out[2], out[3], n_total
+
+
 def pack_weight_adjoint(w_kio, flip_taps, out=None):
     kv, cin, cout = w_kio.shape
     n = lib().cpd_packed_weight_floats(kv, cout, cin)
@@ -129,10 +149,12 @@ def affine_rows(x, scale=None, shift=None, residual=None, relu=False, out=None):
     return out
 
 
-def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False, dgamma=None, dbeta=None, dx_absmax=None):
+def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False, dgamma=None, dbeta=None, dx_absmax=None, sync=None):
     """BatchNorm(+ReLU when y is given) backward. Returns (dx, dgamma, dbeta, dres|None);
     dgamma / dbeta may be caller-provided (views of a flat gradient buffer). `dx_absmax`: a ZEROED int32 device
-    tensor of ABSMAX_WORDS words (an absmax block) that receives the bits of max |dx| (for the split-fp16 gradient convolutions)."""
+    tensor of ABSMAX_WORDS words (an absmax block) that receives the bits of max |dx| (for the split-fp16 gradient convolutions).
+    `sync` = (n_total, group) from bn_stats_finalize_sync: SyncBatchNorm backward -- the input gradient uses the ALL-REDUCED
+    (sum dy, sum dy * xhat) and the total row count; dgamma / dbeta stay this rank's sums (the gradient all-reduce averages them)."""
     n, c = x.shape
     dev = x.device
     if dbeta is None:
@@ -144,6 +166,15 @@ def bn_backward(dy, y, x, mean, invstd, gamma, want_dres=False, dgamma=None, dbe
                                   n, c, ptr(dbeta), ptr(dgamma), ptr(ws), ws.numel(), stream()), "cpd_bn_bwd_reduce")
     dx = torch.empty((n, c), dtype=torch.float32, device=dev)
     dres = torch.empty((n, c), dtype=torch.float32, device=dev) if want_dres else None
+    if sync is not None:
+        import torch.distributed as dist
+        n_total, group = sync
+        tot = torch.cat([dbeta, dgamma])
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+        check(lib().cpd_bn_bwd_apply_sync(_p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(x), _ld(x), n, c, ptr(mean),
+                                          ptr(invstd), ptr(gamma), _p(tot[:c]), _p(tot[c:]), _p(n_total), _p(dx), _ld(dx), _p(dres),
+                                          _ld(dres) if dres is not None else 0, ptr(dx_absmax), stream()), "cpd_bn_bwd_apply_sync")
+        return dx, dgamma, dbeta, dres
     check(lib().cpd_bn_bwd_apply(_p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(x), _ld(x), n, c, ptr(mean),
                                  ptr(invstd), ptr(gamma), ptr(dbeta), ptr(dgamma), _p(dx), _ld(dx), _p(dres),
                                  _ld(dres) if dres is not None else 0, ptr(dx_absmax), stream()), "cpd_bn_bwd_apply")

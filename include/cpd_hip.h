@@ -440,6 +440,19 @@ int cpd_bn_bwd_apply(const float *dy, int lddy, const float *y, int ldy, const f
                      int n, int c, const float *mean, const float *invstd, const float *gamma,
                      const float *dbeta, const float *dgamma, float *dx, int lddx, float *dres,
                      int lddres, uint32_t *dx_absmax, cpd_stream_t stream);
+/* SyncBatchNorm (tools/train.py:32,117 `--sync_bn` -> torch.nn.SyncBatchNorm.convert_sync_batchnorm; off by default in the reference):
+ * the host all-reduces (sum, sumsq, row count) between cpd_bn_stats and the finalize, and (sum dy, sum dy * xhat) between
+ * cpd_bn_bwd_reduce and the apply, over the data-parallel ranks (RCCL). These two entry points take the row count the sums now stand
+ * for as a DEVICE float (`n_total`: the all-reduced count -- ranks hold different numbers of sparse rows, and no rank knows the total
+ * on the host); otherwise they are cpd_bn_finalize / cpd_bn_bwd_apply. dgamma / dbeta of the PARAMETERS stay the local sums
+ * (torch.nn.SyncBatchNorm's backward: the gradient all-reduce averages them like every other gradient). */
+int cpd_bn_finalize_sync(const float *sum, const float *sumsq, const float *n_total, int c, float eps, float momentum,
+                         const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
+                         float *running_mean, float *running_var, cpd_stream_t stream);
+int cpd_bn_bwd_apply_sync(const float *dy, int lddy, const float *y, int ldy, const float *x, int ldx, int n, int c,
+                          const float *mean, const float *invstd, const float *gamma, const float *sum_dy,
+                          const float *sum_dy_xhat, const float *n_total, float *dx, int lddx, float *dres, int lddres,
+                          uint32_t *dx_absmax, cpd_stream_t stream);
 /* dx_absmax (optional): an "absmax block" -- CPD_ABSMAX_SLOTS device words CPD_ABSMAX_STRIDE uint32 apart (one per
  * 128-byte line: atomics on one line serialise), zeroed by the caller beforehand -- whose words the kernel raises (atomic
  * max) so that their maximum is the bits of max |dx|: what cpd_gather_conv_scaled / cpd_conv_wgrad_scaled need to run a
