@@ -839,12 +839,15 @@ def test_fast_eval_module_path_matches_the_guarded_modules_and_reruns_out_of_ran
                 warnings.simplefilter("always")
                 got, _ = net(dict(big))
             assert net.range_reruns == 1 and any("re-run" in str(w.message) for w in wlist)
+            # (a ReLU network is positively homogeneous: activations beyond 2^15 mean size logits in the thousands, whose exp() is inf in
+            # fp32 on ANY path -- bit-identical to the guarded path is the statement, inf for inf)
+            same = lambda a, b: a.shape == b.shape and bool(torch.isclose(a.float(), b.float(), rtol=0, atol=0, equal_nan=True).all())
             for p, q in zip(want, got):
-                assert torch.isfinite(q["pred_boxes"]).all() and all(torch.equal(p[k], q[k]) for k in ("pred_boxes", "pred_scores", "pred_labels"))
+                assert len(q["pred_boxes"]) > 0 and all(same(p[k], q[k]) for k in ("pred_boxes", "pred_scores", "pred_labels"))
             left = net._guard_left
             assert left == net.FAST_EVAL_STICKY_STEPS
             again, _ = net(dict(big))                                              # guarded straight away: no second re-run
             assert net.range_reruns == 1 and net._guard_left == left - 1
-            assert all(torch.equal(p["pred_boxes"], q["pred_boxes"]) for p, q in zip(want, again))
+            assert all(same(p["pred_boxes"], q["pred_boxes"]) for p, q in zip(want, again))
     finally:
         spc.set_default_conv_math(old_math); spc.set_default_row_order(old_order); spc.set_fast_eval(old_fast)

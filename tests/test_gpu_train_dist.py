@@ -105,15 +105,16 @@ def _sync_bn_worker(rank, world, port, q):
     mean, invstd, scale, shift, n_total = train_ops.bn_stats_finalize_sync(xr, 1e-3, 0.01, gamma.cuda(), beta.cuda(), rm, rv)
     y = train_ops.affine_rows(xr, scale, shift, None, True)
     dx, dgamma, dbeta, _ = train_ops.bn_backward(dyr, y, xr, mean, invstd, gamma.cuda(), sync=(n_total, None))
-    layer = dict(mean=mean.cpu(), invstd=invstd.cpu(), n_total=float(n_total.item()), y=y.cpu(), dx=dx.cpu(), dgamma=dgamma.cpu(), dbeta=dbeta.cpu(),
-                 rm=rm.cpu(), rv=rv.cpu())
+    # (numpy through the queue: a torch tensor travels as a shared-memory handle that dies with this process)
+    layer = dict(mean=mean.cpu().numpy(), invstd=invstd.cpu().numpy(), n_total=float(n_total.item()), y=y.cpu().numpy(), dx=dx.cpu().numpy(),
+                 dgamma=dgamma.cpu().numpy(), dbeta=dbeta.cpu().numpy(), rm=rm.cpu().numpy(), rv=rv.cpu().numpy())
     # (ii) a whole train step with sync_bn: N ranks x 1 frame normalise like one process with the N frames in its batch
     cfg = _cfg()
     tr = CenterPointTrainer(cfg, init_state_dict(cfg, seed=4), lr=1e-3, world_size=world, num_max_objs=20, grad_clip=0.0, sync_bn=True)
     pts, gt = _frame(rank)
     tr.step([pts], gt)
     sd = tr.state_dict()
-    q.put((rank, layer, {k: v.cpu() for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")},
+    q.put((rank, layer, {k: v.cpu().numpy() for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")},
            tr.store.flat.double().sum().item()))
     dist.barrier()
     dist.destroy_process_group()
@@ -145,6 +146,8 @@ def test_sync_batchnorm_matches_one_process_over_all_rows(hip):
         p.join(120)
         assert p.exitcode == 0
     (_, l0, rs0, sum0), (_, l1, rs1, sum1) = out
+    l0, l1 = ({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in l.items()} for l in (l0, l1))
+    rs0, rs1 = ({k: torch.from_numpy(v) for k, v in r.items()} for r in (rs0, rs1))
     x, dy, gamma, beta = _sync_bn_data()
     xc, dyc = x.cuda(), dy.cuda()
     rm, rv = torch.zeros(48, device="cuda"), torch.ones(48, device="cuda")
