@@ -39,6 +39,7 @@ SIGNATURES = {
     "cpd_voxelize_batch": (_I, [_VP, _I3, _I, _I, _FP, _FP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_voxelize_batch_index": (_I, [_VP, _I3, _I, _I, _FP, _FP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP, _SZ, _I, _VP]),
     "cpd_voxelize_batch_canonical": (_I, [_VP, _I3, _I, _I, _FP, _FP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP, _SZ, _I, _VP]),
+    "cpd_voxelize_batch_frames": (_I, [_VP, _I3, _I, _I, _FP, _FP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP, _SZ, _I, _I, _VP]),
     "cpd_voxelize": (_I, [_VP, _I, _I, _FP, _FP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "cpd_index_bytes": (_SZ, [_I, _I3, _I]),
     "cpd_index_build": (_I, [_VP, _I, _I, _I3, _VP, _SZ, _VP]),

@@ -267,15 +267,46 @@ struct FrameOffsets {
     }
 };
 
+// Where the rows of the batch's (virtually concatenated) point list live: one base pointer per frame. A caller with ONE contiguous
+// buffer gives base + off[f] * c (cpd_voxelize_batch*); a caller whose frames sit in separate allocations -- the usual case: clouds
+// arrive one by one -- gives them as they are (cpd_voxelize_batch_frames) and no concatenation pass (153 MB at 48 frames) is needed.
+struct FramePts {
+    const float *p[CPD_VOX_MAX_FRAMES];
+    __device__ __forceinline__ const float *row(const FrameOffsets &fo, int f, int i, int c) const { return p[f] + (size_t)(i - fo.off[f]) * c; }
+};
+
+// (the batched gather: slot entries are indices into the batch's virtual concatenation; a voxel's points all sit in its frame)
+__global__ void __launch_bounds__(256) vox_gather_frames_kernel(FramePts pts, FrameOffsets fo, int c, int P, int cap,
+                                                                const int32_t *__restrict__ n_vox, const int32_t *__restrict__ slots,
+                                                                const int32_t *__restrict__ counts, float *voxels, int32_t *num_points,
+                                                                float *mean) {
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = (int)(tid / c), ch = (int)(tid % c);
+    if (v >= cap || v >= *n_vox) return;
+    int cnt = counts[v];
+    if (cnt > P) cnt = P;
+    const int frame = cnt > 0 ? fo.frame_of(slots[(size_t)v * P]) : 0;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) {  // sum order p = 0..P-1, zeros included (mean_vfe.py:41)
+        float val = 0.f;
+        if (p < cnt) val = pts.row(fo, frame, slots[(size_t)v * P + p], c)[ch];
+        if (voxels) voxels[((size_t)v * P + p) * c + ch] = val;
+        s += val;
+    }
+    if (mean) mean[(size_t)v * c + ch] = __fdiv_rn(s, (float)(cnt < 1 ? 1 : cnt));
+    if (ch == 0) num_points[v] = cnt;
+}
+
 // Batched form: pkey holds the point's cell INSIDE its frame (< cells, 31 bits); the bitmap position frame * cells + cell is
 // formed in 64 bits where it is needed (the frame of a point follows from its index), so a batch is bounded by the 64 frames
 // of FrameOffsets, not by 2^31 cells.
-__global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__restrict__ pts, int n, int c, VoxGeom geo,
+__global__ void __launch_bounds__(256) vox_keys_batch_kernel(FramePts pts, int n, int c, VoxGeom geo,
                                                              long long cells, FrameOffsets fo, int32_t *__restrict__ pkey,
                                                              uint64_t *bitmap, uint32_t *__restrict__ touched) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float *p = pts + (size_t)i * c;
+    const int frame = fo.frame_of_lane(i, threadIdx.x & 63);
+    const float *p = pts.row(fo, frame, i, c);
     int32_t cz[3];
     bool ok = true;
 #pragma unroll
@@ -286,7 +317,7 @@ __global__ void __launch_bounds__(256) vox_keys_batch_kernel(const float *__rest
     }
     long long key = -1;
     const int32_t local = ok ? (cz[0] * geo.g[1] + cz[1]) * geo.g[2] + cz[2] : -1;
-    if (ok) key = (long long)fo.frame_of_lane(i, threadIdx.x & 63) * cells + local;
+    if (ok) key = (long long)frame * cells + local;
     // consecutive returns of a beam often share a voxel: the lane after an equal key leaves the bit to its neighbour
     const long long prev = __shfl_up(key, 1);
     if (ok && ((threadIdx.x & 63) == 0 || prev != key)) {
@@ -491,7 +522,7 @@ __global__ void __launch_bounds__(256) vox_scatter_kernel(int n, const int32_t *
 }
 
 // thread (voxel v, channel ch): the voxel's kept points = the max_points smallest indices of its segment, ascending
-__global__ void __launch_bounds__(256) vox_build_kernel(const float *__restrict__ pts, int c, int P, int cap, FrameOffsets fo,
+__global__ void __launch_bounds__(256) vox_build_kernel(FramePts pts, int c, int P, int cap, FrameOffsets fo,
                                                         const int32_t *__restrict__ n_vox, const int32_t *__restrict__ pkey,
                                                         const int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
                                                         const int32_t *__restrict__ order, float *voxels, int32_t *coords,
@@ -520,13 +551,14 @@ __global__ void __launch_bounds__(256) vox_build_kernel(const float *__restrict_
                 last = best;
             }
         }
+        const int frame = kept > 0 ? fo.frame_of(sel[0]) : 0;      // (a voxel's points all belong to its frame)
         float val[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) val[p] = p < kept ? pts[(size_t)sel[p] * c + ch] : 0.f;
+        for (int p = 0; p < 8; ++p) val[p] = p < kept ? pts.row(fo, frame, sel[p], c)[ch] : 0.f;
         if (ch == 0 && kept > 0) {
             const int32_t key = pkey[sel[0]];                      // the cell inside the frame
             int32_t *o = coords + (size_t)v * 4;
-            o[0] = fo.frame_of(sel[0]); o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
+            o[0] = frame; o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
         }
         float s = 0.f;
 #pragma unroll
@@ -541,6 +573,7 @@ __global__ void __launch_bounds__(256) vox_build_kernel(const float *__restrict_
         return;
     }
     int32_t last = -1;
+    int frame = 0;
     float s = 0.f;
     for (int p = 0; p < P; ++p) {      // sum order p = 0..P-1, zeros included (mean_vfe.py:41)
         float val = 0.f;
@@ -551,11 +584,12 @@ __global__ void __launch_bounds__(256) vox_build_kernel(const float *__restrict_
                 best = (x > last && x < best) ? x : best;
             }
             last = best;
-            val = pts[(size_t)best * c + ch];
+            if (p == 0) frame = fo.frame_of(best);
+            val = pts.row(fo, frame, best, c)[ch];
             if (p == 0 && ch == 0) {
                 const int32_t key = pkey[best];                    // the cell inside the frame
                 int32_t *o = coords + (size_t)v * 4;
-                o[0] = fo.frame_of(best); o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
+                o[0] = frame; o[1] = key / (gx * gy); o[2] = (key / gx) % gy; o[3] = key % gx;
             }
         }
         if (voxels) voxels[((size_t)v * P + p) * c + ch] = val;
@@ -650,7 +684,7 @@ extern "C" size_t cpd_voxelize_batch_workspace_bytes(int n_total, int n_frames, 
 // `index` != NULL: the occupancy bitmap, its popcount prefix and the rank -> row map are built INSIDE that site index (of
 // the grid with z_extra more z-levels -- the backbone's sparse_shape = grid + [1,0,0], spconv_backbone.py:412), which is
 // then the level-0 index of the sparse tensor as it stands: no second bitmap, mark, scan and permutation pass.
-static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets, int n_frames, int c,
+static int voxelize_batch_impl(const float *points, const float *const *frame_points, const int32_t *frame_offsets, int n_frames, int c,
                                const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
                                float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
                                int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index, size_t index_bytes,
@@ -672,7 +706,13 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
     }
     if (frame_offsets[0] != 0) return CPD_ERR_ARG;
     const int n = frame_offsets[n_frames];
-    if (n > 0 && !points) return CPD_ERR_ARG;
+    if (n > 0 && !points && !frame_points) return CPD_ERR_ARG;
+    FramePts fp;
+    for (int f = 0; f < CPD_VOX_MAX_FRAMES; ++f) fp.p[f] = nullptr;
+    for (int f = 0; f < n_frames; ++f) {
+        fp.p[f] = frame_points ? frame_points[f] : points + (size_t)frame_offsets[f] * c;
+        if (!fp.p[f] && frame_offsets[f + 1] > frame_offsets[f]) return CPD_ERR_ARG;
+    }
     int cap;
     rc = batch_caps(n, n_frames, max_voxels, cells, &cap);
     if (rc) return rc;
@@ -716,7 +756,7 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
         // counts and falls back to the exact path if a frame exceeds it. Point lists by counting sort (above): ppos in w.first's
         // words, the compact list in w.slots' (cap * max_points >= n of them), the segment offsets in the workspace's vid words.
         int32_t *const ppos = w.first, *const order = w.slots, *const offsets = vid_ws;
-        vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap, w.bsum_bm);
+        vox_keys_batch_kernel<<<nb, 256, 0, s>>>(fp, n, c, geo, cells, fo, w.pkey, w.bitmap, w.bsum_bm);
         rc = device_scan_touched(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
         if (rc) return rc;
         vox_count_kernel<<<nb, 256, 0, s>>>(n, cells, fo, w.pkey, w.bitmap, w.base, w.prank, ppos, w.counts);
@@ -725,14 +765,14 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
         vox_frames_canonical_kernel<<<1, 64, 0, s>>>(n_frames, cells, w.bitmap, w.base, w.bsum_bm, w.nocc, n_voxels);
         vox_scatter_kernel<<<nb, 256, 0, s>>>(n, w.prank, ppos, offsets, order);
         const long long threads_c = (long long)cap * c;
-        vox_build_kernel<<<cpd_div_up(threads_c, 256), 256, 0, s>>>(points, c, max_points, cap, fo, n_voxels + n_frames, w.pkey, w.counts, offsets,
+        vox_build_kernel<<<cpd_div_up(threads_c, 256), 256, 0, s>>>(fp, c, max_points, cap, fo, n_voxels + n_frames, w.pkey, w.counts, offsets,
                                                                      order, voxels, coords, num_points, mean_features, geo.g[1], geo.g[2]);
         return cpd_check_launch();
     }
     if (cpd_fill_bytes(w.first, 0x7f, (size_t)n * 4, s)) return CPD_ERR_LAUNCH;
     if (cpd_fill_bytes(w.slots, 0x7f, (size_t)cap * max_points * 4, s)) return CPD_ERR_LAUNCH;
     CPD_HIP_TRY(hipMemsetAsync(frame_base, 0, (CPD_VOX_MAX_FRAMES + 1) * 4, s));
-    vox_keys_batch_kernel<<<nb, 256, 0, s>>>(points, n, c, geo, cells, fo, w.pkey, w.bitmap, w.bsum_bm);
+    vox_keys_batch_kernel<<<nb, 256, 0, s>>>(fp, n, c, geo, cells, fo, w.pkey, w.bitmap, w.bsum_bm);
     rc = device_scan_touched(w.words, PopcFn{w.bitmap}, StoreBaseFn{w.base}, w.bsum_bm, w.nocc, -1, s);
     if (rc) return rc;
     vox_first_batch_kernel<<<nb, 256, 0, s>>>(n, cells, fo, w.pkey, w.bitmap, w.base, w.prank, w.first);
@@ -751,8 +791,8 @@ static int voxelize_batch_impl(const float *points, const int32_t *frame_offsets
         vox_insert_batch_kernel<<<nb, 256, 0, s>>>(n, max_points, w.prank, w.vid, w.first, w.slots, w.counts);
     }
     const long long threads = (long long)cap * c;
-    vox_gather_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(points, c, max_points, cap, n_voxels + n_frames, w.slots, w.counts,
-                                                               voxels, num_points, mean_features);
+    vox_gather_frames_kernel<<<cpd_div_up(threads, 256), 256, 0, s>>>(fp, fo, c, max_points, cap, n_voxels + n_frames, w.slots, w.counts,
+                                                                      voxels, num_points, mean_features);
     return cpd_check_launch();
 }
 
@@ -760,7 +800,7 @@ extern "C" int cpd_voxelize_batch(const float *points, const int32_t *frame_offs
                                   const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
                                   float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
                                   int32_t *n_voxels, void *workspace, size_t workspace_bytes, cpd_stream_t stream) {
-    return voxelize_batch_impl(points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
+    return voxelize_batch_impl(points, nullptr, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
                                num_points, mean_features, n_voxels, workspace, workspace_bytes, nullptr, 0, 0, 0, stream);
 }
 
@@ -770,7 +810,7 @@ extern "C" int cpd_voxelize_batch_index(const float *points, const int32_t *fram
                                         int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index,
                                         size_t index_bytes, int z_extra, cpd_stream_t stream) {
     if (!index) return CPD_ERR_ARG;
-    return voxelize_batch_impl(points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
+    return voxelize_batch_impl(points, nullptr, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
                                num_points, mean_features, n_voxels, workspace, workspace_bytes, index, index_bytes, z_extra, 0, stream);
 }
 
@@ -780,6 +820,20 @@ extern "C" int cpd_voxelize_batch_canonical(const float *points, const int32_t *
                                             int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index,
                                             size_t index_bytes, int z_extra, cpd_stream_t stream) {
     if (!index) return CPD_ERR_ARG;
-    return voxelize_batch_impl(points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
+    return voxelize_batch_impl(points, nullptr, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
                                num_points, mean_features, n_voxels, workspace, workspace_bytes, index, index_bytes, z_extra, 1, stream);
+}
+
+// The frames' point lists as they lie -- one device pointer per frame (a HOST array of n_frames pointers; frame f holds
+// frame_offsets[f + 1] - frame_offsets[f] rows of c floats) -- instead of one concatenated buffer: everything else is
+// cpd_voxelize_batch (index = NULL), cpd_voxelize_batch_index (canonical = 0) or cpd_voxelize_batch_canonical (canonical = 1).
+extern "C" int cpd_voxelize_batch_frames(const float *const *frame_points, const int32_t *frame_offsets, int n_frames, int c,
+                                         const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
+                                         float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
+                                         int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index,
+                                         size_t index_bytes, int z_extra, int canonical, cpd_stream_t stream) {
+    if (!frame_points || (canonical && !index)) return CPD_ERR_ARG;
+    return voxelize_batch_impl(nullptr, frame_points, frame_offsets, n_frames, c, vsize_xyz, range_xyz, max_points, max_voxels, voxels, coords,
+                               num_points, mean_features, n_voxels, workspace, workspace_bytes, index, index ? index_bytes : 0,
+                               index ? z_extra : 0, canonical, stream);
 }

@@ -91,15 +91,17 @@ class Voxelizer:
         index, max_voxels cap not applied (cpd_voxelize_batch_canonical; the caller checks n_voxels against the cap)."""
         for p in points_list:
             _need_cuda(p, "points")
-        pts = torch.cat([p.contiguous() for p in points_list]) if len(points_list) > 1 else points_list[0].contiguous()
-        nf = len(points_list)
+        # the frames as they lie (cpd_voxelize_batch_frames: one device pointer per frame) -- no concatenated copy of the batch's points
+        frames = [p.contiguous() for p in points_list]
+        nf = len(frames)
         offs = [0]
-        for p in points_list:
+        for p in frames:
+            assert p.dim() == 2 and p.shape[1] == self.c and p.dtype == torch.float32
             offs.append(offs[-1] + p.shape[0])
-        n, c = pts.shape
-        assert c == self.c and pts.dtype == torch.float32
+        n, c = offs[-1], self.c
         cap = max(1, min(self.max_voxels * nf, n))
-        dev = pts.device
+        dev = frames[0].device
+        fptrs = (ctypes.c_void_p * nf)(*[ctypes.c_void_p(p.data_ptr()) for p in frames])
         voxels = torch.empty((cap, self.P, c), dtype=torch.float32, device=dev) if want_voxels else None
         coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         num = torch.empty((cap,), dtype=torch.int32, device=dev)
@@ -113,16 +115,15 @@ class Voxelizer:
         if index_z_extra is not None:
             g = self.grid_zyx
             index = SiteIndex(nf, [g[0] + int(index_z_extra), g[1], g[2]], max(n, 1), dev)
-            fn = lib().cpd_voxelize_batch_canonical if canonical else lib().cpd_voxelize_batch_index
-            check(fn(ptr(pts), iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
-                     ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
-                     self._wsb.numel(), ptr(index.buf), index.buf.numel(), int(index_z_extra), stream()),
-                  "cpd_voxelize_batch_canonical" if canonical else "cpd_voxelize_batch_index")
+            check(lib().cpd_voxelize_batch_frames(fptrs, iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
+                                                  ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
+                                                  self._wsb.numel(), ptr(index.buf), index.buf.numel(), int(index_z_extra),
+                                                  1 if canonical else 0, stream()), "cpd_voxelize_batch_frames")
             return voxels, coords, num, mean, nvox, index
         assert not canonical, "canonical rows come with the in-place index (index_z_extra)"
-        check(lib().cpd_voxelize_batch(ptr(pts), iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
-                                       ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
-                                       self._wsb.numel(), stream()), "cpd_voxelize_batch")
+        check(lib().cpd_voxelize_batch_frames(fptrs, iarr(offs), nf, c, farr(self.vs), farr(self.rg), self.P, self.max_voxels,
+                                              ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(self._wsb),
+                                              self._wsb.numel(), None, 0, 0, 0, stream()), "cpd_voxelize_batch_frames")
         return voxels, coords, num, mean, nvox
 
 

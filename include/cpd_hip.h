@@ -103,6 +103,15 @@ int cpd_voxelize_batch_canonical(const float *points, const int32_t *frame_offse
                                  int max_voxels, float *voxels, int32_t *coords, int32_t *num_points,
                                  float *mean_features, int32_t *n_voxels, void *workspace, size_t workspace_bytes,
                                  void *index, size_t index_bytes, int z_extra, cpd_stream_t stream);
+/* cpd_voxelize_batch / _index / _canonical for frames that sit in SEPARATE device allocations (clouds arrive one by one from the
+ * dataloader, data_processor.py:43-59 is called per frame): frame_points = HOST array of n_frames device pointers, frame f holding
+ * frame_offsets[f + 1] - frame_offsets[f] rows of c floats. No concatenated copy of the batch's points is needed (153 MB at 48 frames).
+ * index = NULL: cpd_voxelize_batch; index != NULL: cpd_voxelize_batch_index (canonical = 0) or cpd_voxelize_batch_canonical (1). */
+int cpd_voxelize_batch_frames(const float *const *frame_points, const int32_t *frame_offsets, int n_frames, int c,
+                              const float vsize_xyz[3], const float range_xyz[6], int max_points, int max_voxels,
+                              float *voxels, int32_t *coords, int32_t *num_points, float *mean_features,
+                              int32_t *n_voxels, void *workspace, size_t workspace_bytes, void *index,
+                              size_t index_bytes, int z_extra, int canonical, cpd_stream_t stream);
 
 /* ===== B2. Sparse convolution ==============================================================
  * Replaces [SPCONV] SparseConvTensor / SubMConv3d / SparseConv3d / .dense() as called from

@@ -101,6 +101,47 @@ def test_batched_voxelizer_equals_per_frame(hip, max_voxels):
     assert counts[len(frames)] == row
 
 
+def test_concatenated_buffer_entry_points_equal_the_per_frame_pointer_form(hip):
+    """cpd_voxelize_batch / _index / _canonical (ONE concatenated point buffer + offsets) against cpd_voxelize_batch_frames (one device
+    pointer per frame: what ops.Voxelizer.batch calls since round 6 -- no torch.cat of the batch's points): identical outputs, an empty
+    frame in the middle included, and the site indexes they leave behind identical byte for byte."""
+    import ctypes
+    import torch
+    from cpd_amd import ops
+    from cpd_amd._lib import check, farr, iarr, lib, ptr, stream
+    from cpd_amd.synthetic import WAYMO, waymo_cloud
+    vs, rg = WAYMO["voxel_size"], WAYMO["point_cloud_range"]
+    frames = [torch.from_numpy(waymo_cloud(0, n_points=30000)).cuda(), torch.from_numpy(waymo_cloud(1, n_points=10)[:0]).cuda(),
+              torch.from_numpy(waymo_cloud(2, n_points=41000)).cuda()]
+    vox = ops.Voxelizer(vs, rg, 5, 5, 1000000)
+    cat = torch.cat(frames)
+    offs = [0, 30000, 30000, 71000]
+    n, nf, c = cat.shape[0], 3, 5
+    for mode in ("plain", "index", "canonical"):
+        if mode == "plain":
+            got = vox.batch(frames, want_voxels=True)
+        else:
+            got = vox.batch(frames, want_voxels=True, index_z_extra=1, canonical=mode == "canonical")
+        cap = got[1].shape[0]
+        voxels = torch.empty((cap, 5, c), device="cuda"); coords = torch.empty((cap, 4), dtype=torch.int32, device="cuda")
+        num = torch.empty((cap,), dtype=torch.int32, device="cuda"); mean = torch.empty((cap, c), device="cuda")
+        nvox = torch.zeros((nf + 1,), dtype=torch.int32, device="cuda")
+        ws = torch.empty(lib().cpd_voxelize_batch_workspace_bytes(n, nf, 5, 1000000, farr(vs), farr(rg)), dtype=torch.uint8, device="cuda")
+        common = (ptr(cat), iarr(offs), nf, c, farr(vs), farr(rg), 5, 1000000, ptr(voxels), ptr(coords), ptr(num), ptr(mean), ptr(nvox), ptr(ws), ws.numel())
+        if mode == "plain":
+            check(lib().cpd_voxelize_batch(*common, stream()), "cpd_voxelize_batch")
+        else:
+            g = vox.grid_zyx
+            index = ops.SiteIndex(nf, [g[0] + 1, g[1], g[2]], n, cat.device)
+            fn = lib().cpd_voxelize_batch_canonical if mode == "canonical" else lib().cpd_voxelize_batch_index
+            check(fn(*common, ptr(index.buf), index.buf.numel(), 1, stream()), mode)
+            assert torch.equal(index.buf, got[5].buf), mode
+        k = int(nvox[nf])
+        assert k == int(got[4][nf]) and k > 1000 and torch.equal(nvox, got[4])
+        assert torch.equal(coords[:k], got[1][:k]) and torch.equal(num[:k], got[2][:k]), mode
+        assert torch.equal(voxels[:k], got[0][:k]) and torch.equal(mean[:k], got[3][:k]), mode
+
+
 def test_batched_voxelizer_builds_the_level0_site_index(oracle, hip):
     """cpd_voxelize_batch_index: same voxels as cpd_voxelize_batch, and the site index it leaves behind (over the grid with one
     more z-level, the backbone's sparse_shape) answers every neighbour lookup like an index built from the coordinates
