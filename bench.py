@@ -484,7 +484,26 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
                 return [host[(i * frames + j) % POOL].cuda(non_blocking=True) for j in range(frames)]
             return [clouds[(i * frames + j) % POOL] for j in range(frames)]
 
-        if n_streams == 1:
+        # host input, double-buffered: a worker's NEXT batch is copied on its own copy stream while the current one
+        # computes; the compute stream waits on the copies' event only. (The voxelizer takes the frames where they land:
+        # cpd_voxelize_batch_frames, no concatenation.)
+        copy_streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if host is not None else []
+
+        def prefetch(i, w):
+            with torch.cuda.stream(copy_streams[w]):
+                ts = [host[(i * frames + j) % POOL].cuda(non_blocking=True) for j in range(frames)]
+                ev = copy_streams[w].record_event()
+            return ts, ev
+
+        def take(pending):
+            ts, ev = pending
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for t in ts:
+                t.record_stream(cur)
+            return ts
+
+        if n_streams == 1 and host is None:
             sec = time_steps(lambda i: engs[0].forward(batch_of(i)), steps, warmup)
             return frames / sec, sec
         strs = list(streams[:n_streams]) + [torch.cuda.Stream(device=dev) for _ in range(n_streams - len(streams))]
@@ -493,8 +512,15 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
             def worker(w):
                 torch.cuda.set_device(torch.device(dev))
                 with torch.cuda.stream(strs[w]):
-                    for i in range(w, n, n_streams):
-                        engs[w].forward(batch_of(i))
+                    if host is not None:
+                        nxt = prefetch(w, w) if w < n else None
+                        for i in range(w, n, n_streams):
+                            cur = take(nxt)
+                            nxt = prefetch(i + n_streams, w) if i + n_streams < n else None
+                            engs[w].forward(cur)
+                    else:
+                        for i in range(w, n, n_streams):
+                            engs[w].forward(batch_of(i))
                     strs[w].synchronize()
             ts = [threading.Thread(target=worker, args=(w,)) for w in range(n_streams)]
             [t.start() for t in ts]
@@ -514,7 +540,7 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
     v, sec = engine_rate(cfg, B, 8, 2, n_streams=max(1, args.streams), host=host)
     out["value_host_input"] = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 8, "ratio_to_value": v / value,
                                "h2d_MB_per_step": sum(int(c.numel()) * 4 for c in host[:B]) / 1e6 if B <= POOL else None,
-                               "note": "PCIe-inclusive: clouds in pinned host memory, H2D inside the step (%d stream(s))" % max(1, args.streams)}
+                               "note": "PCIe-inclusive: clouds in pinned host memory, H2D inside the timed region (%d stream(s)), double-buffered: a worker's next batch is copied on its own copy stream while the current one computes" % max(1, args.streams)}
     del host
     if cfg.conv_math != "f32":
         c32 = ModelConfig(conv_math="f32", row_order=cfg.row_order, row_order_chunk=cfg.row_order_chunk)
