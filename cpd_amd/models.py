@@ -1126,9 +1126,8 @@ class VoxelRCNN(CenterPoint):
         return pred_dicts, {}
 
     def forward(self, batch_dict):
-        for m in self.module_list:
-            batch_dict = m(batch_dict)
-        if self.training:
+        batch_dict = self._run_modules(batch_dict)          # (fast eval: the first stage inside the optimistic range pass, CenterPoint._run_modules;
+        if self.training:                                   # the RoI head reads the pooled levels' `.features` -- fp32 rows, decoded on demand)
             loss_rpn, tb_dict = self.dense_head.get_loss()
             loss_rcnn, tb_dict = self.roi_head.get_loss(tb_dict)
             return {"loss": loss_rpn + loss_rcnn}, tb_dict, {}

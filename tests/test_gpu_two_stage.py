@@ -107,6 +107,36 @@ def test_two_stage_engine_matches_the_module_composition(hip):
         loose(g, w, 2e-3)
 
 
+def test_two_stage_module_in_fast_eval_matches_the_guarded_modules(hip):
+    """models.VoxelRCNN through spconv.install(conv_math="f16x2", fast_eval=True) (round 6: the first stage inside the optimistic range
+    pass, pair rows between its fused sparse layers; the RoI head reads the pooled levels' `.features`, decoded on demand) against the same
+    model on the guarded f16x2 modules: RoIs, second-stage predictions and detections agree to fp32 rounding."""
+    from cpd_amd import spconv as sp
+    from cpd_amd.spconv.pytorch import conv as spc
+    old = (spc.default_conv_math(), spc.fast_eval())
+    try:
+        sp.install(conv_math="f16x2", fast_eval=False)
+        net = _model()
+        clouds = _clouds()
+        with torch.no_grad():
+            want, _, bd = net(_batch_dict(net, clouds))
+        sp.install(fast_eval=True)
+        with torch.no_grad():
+            got, _, bf = net(_batch_dict(net, clouds))
+        assert all(t._pairs is not None for t in bf["multi_scale_3d_features"].values())       # the levels did travel as pair rows
+        assert sum(len(g["pred_boxes"]) for g in got) > 10
+        assert bf["rois"].shape == bd["rois"].shape
+        d = (bf["rois"] - bd["rois"]).abs().max(-1)[0]
+        assert float((d <= 1e-3).float().mean()) >= 0.9                   # (near-tied proposals may swap ranks between the arithmetics)
+        for g, w in zip(got, want):
+            assert abs(len(g["pred_boxes"]) - len(w["pred_boxes"])) <= 2
+            x, y = g["pred_boxes"].cpu().numpy(), w["pred_boxes"].cpu().numpy()
+            dd = np.abs(x[:, None, :] - y[None, :, :]).max(-1).min(1)
+            assert (dd <= 2e-3).mean() >= 0.75, float((dd <= 2e-3).mean())
+    finally:
+        spc.set_default_conv_math(old[0]); spc.set_fast_eval(old[1])
+
+
 def test_post_processing_matches_a_plain_restatement(hip):
     """detector3d_template.py:222-343 with MULTI_CLASSES_NMS False, has_class_labels True: sigmoid, score threshold, top-k order,
     rotated NMS at 0.3, labels from roi_labels -- restated with torch + the B3 IoU operator, greedy loop on the host."""
