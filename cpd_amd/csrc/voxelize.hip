@@ -260,6 +260,14 @@ struct FrameOffsets {
     }
     // the same for lane `lane` of a wave whose lanes hold consecutive points: the wave's first and last point are looked up on the
     // scalar unit; only a wave that straddles a frame boundary searches per lane
+    // ... and for a point index that is NOT consecutive across the lanes but usually in one frame wave-wide (a voxel's first point, the
+    // voxels of a wave being neighbours in row order): the first valid lane's frame, found on the scalar unit, is tried first
+    __device__ __forceinline__ int frame_of_near(int i) const {
+        const unsigned long long m = __ballot(i >= 0);
+        int hint = 0;
+        if (m) hint = frame_of(__builtin_amdgcn_readlane(i, __builtin_ctzll(m)));
+        return (i >= off[hint] && i < off[hint + 1]) ? hint : (i >= 0 ? frame_of(i) : 0);
+    }
     __device__ __forceinline__ int frame_of_lane(int i, int lane) const {
         const int i0 = __builtin_amdgcn_readfirstlane(i - lane);
         const int f0 = frame_of(i0), f1 = frame_of(i0 + 63);
@@ -285,7 +293,7 @@ __global__ void __launch_bounds__(256) vox_gather_frames_kernel(FramePts pts, Fr
     if (v >= cap || v >= *n_vox) return;
     int cnt = counts[v];
     if (cnt > P) cnt = P;
-    const int frame = cnt > 0 ? fo.frame_of(slots[(size_t)v * P]) : 0;
+    const int frame = fo.frame_of_near(cnt > 0 ? slots[(size_t)v * P] : -1);
     float s = 0.f;
     for (int p = 0; p < P; ++p) {  // sum order p = 0..P-1, zeros included (mean_vfe.py:41)
         float val = 0.f;
@@ -551,7 +559,7 @@ __global__ void __launch_bounds__(256) vox_build_kernel(FramePts pts, int c, int
                 last = best;
             }
         }
-        const int frame = kept > 0 ? fo.frame_of(sel[0]) : 0;      // (a voxel's points all belong to its frame)
+        const int frame = fo.frame_of_near(kept > 0 ? sel[0] : -1);      // (a voxel's points all belong to its frame)
         float val[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) val[p] = p < kept ? pts.row(fo, frame, sel[p], c)[ch] : 0.f;
