@@ -147,3 +147,70 @@ def test_voxel_backbone8x_is_registered_with_the_reference_parameter_names():
     cfg.MM = True
     mm = models.VoxelBackBone8x(cfg, input_channels=5, grid_size=[400, 400, 40])
     assert "conv4_2.2.0.weight" in mm.state_dict() and "conv_input_2.0.weight" in mm.state_dict()
+
+
+def test_pair_rows_travel_as_a_type_and_decode_on_demand():
+    """ops.PairRows (round 6): the fp16-pair layout travels as a TYPE, not as an attribute a .contiguous() would drop; a
+    SparseConvTensor that carries pair rows decodes `.features` once, exactly (x = h + l for values with <= 22 significant bits), and a
+    plain assignment to `.features` retires the pairs."""
+    from cpd_amd import ops
+    from cpd_amd.spconv.pytorch.core import SparseConvTensor
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(50, 64, generator=g)
+    x = x.half().float() + (torch.randn(50, 64, generator=g) * 1e-4).half().float()      # exactly representable as h + l
+    pairs = ops.rows_to_pairs(x)
+    p = ops.PairRows(pairs)
+    assert tuple(p.shape) == (50, 64) and torch.equal(p.float_rows(), x)
+    x16 = x[:, :16].contiguous()
+    assert torch.equal(ops.PairRows(ops.rows_to_pairs(x16)).float_rows(), x16)            # the 16-channel [hi 4 | lo 4] form
+    for bad in (pairs[:, :48], pairs.t(), pairs.double()):                                # not whole blocks / not contiguous / not fp32-typed
+        try:
+            ops.PairRows(bad)
+            raise RuntimeError("accepted")
+        except AssertionError:
+            pass
+    idx = torch.zeros((50, 4), dtype=torch.int32)
+    t = SparseConvTensor(p, idx, [4, 8, 8], 1)
+    assert t._pairs is p and t._features is None
+    f = t.features
+    assert torch.equal(f, x) and t.features is f                                          # decoded once, kept
+    t2 = t.replace_feature(p)
+    assert t2._pairs is p and t2.indice_dict is t.indice_dict
+    t.features = x * 2
+    assert t._pairs is None and torch.equal(t.features, x * 2)
+
+
+def test_range_pass_bookkeeping_and_fast_eval_switches():
+    """spconv.pytorch.conv.range_pass: blocks are handed out of a zeroed pool inside the pass only, the verdict is the pool's maximum against
+    2^15, the state is per thread, and install(fast_eval=...) / set_fast_eval toggle the opt-in."""
+    import threading
+    import cpd_amd.spconv as shim
+    from cpd_amd.spconv.pytorch import conv as spc
+    old = spc.fast_eval()
+    try:
+        shim.install(fast_eval=True)
+        assert spc.fast_eval()
+        spc.set_fast_eval(False)
+        assert not spc.fast_eval() and not spc.optimistic()
+        with spc.range_pass("cpu", n_blocks=4) as rp:
+            assert spc.optimistic()
+            a, b = spc.record_block(), spc.record_block()
+            assert a.data_ptr() != b.data_ptr() and int(a.abs().max()) == 0
+            seen = []
+            th = threading.Thread(target=lambda: seen.append(spc.optimistic()))           # another thread is not inside this pass
+            th.start(); th.join()
+            assert seen == [False]
+            assert int(rp.exceeded()) == 0
+            b[0] = 0x47000000                                                             # bits of 32768.0f
+            assert int(rp.exceeded()) == 1
+            spc.record_block(); spc.record_block()
+            try:
+                spc.record_block()
+                raise RuntimeError("a fifth block of four")
+            except RuntimeError as e:
+                assert "range_pass" in str(e)
+        assert not spc.optimistic()
+        with spc.range_pass("cpu", n_blocks=4) as rp:                                     # the pool is re-zeroed
+            assert int(rp.exceeded()) == 0
+    finally:
+        spc.set_fast_eval(old)
