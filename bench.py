@@ -534,14 +534,6 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
         sec = (time.perf_counter() - t0) / steps
         return frames / sec, sec
 
-    # the boundary handing over HOST buffers: same step, same two streams, the clouds start in pinned host memory and their H2D
-    # copies (3.2 MB per frame) are inside the timed region. Never the headline value (inputs resident in HBM is the contract).
-    host = [c.cpu().pin_memory() for c in clouds]
-    v, sec = engine_rate(cfg, B, 8, 2, n_streams=max(1, args.streams), host=host)
-    out["value_host_input"] = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 8, "ratio_to_value": v / value,
-                               "h2d_MB_per_step": sum(int(c.numel()) * 4 for c in host[:B]) / 1e6 if B <= POOL else None,
-                               "note": "PCIe-inclusive: clouds in pinned host memory, H2D inside the timed region (%d stream(s)), double-buffered: a worker's next batch is copied on its own copy stream while the current one computes" % max(1, args.streams)}
-    del host
     if cfg.conv_math != "f32":
         c32 = ModelConfig(conv_math="f32", row_order=cfg.row_order, row_order_chunk=cfg.row_order_chunk)
         v, sec = engine_rate(c32, B, 5, 2)
@@ -662,6 +654,17 @@ def extras(args, cfg, sd, dev, clouds, value, streams=()):
                                                           "ratio_to_engine": B / sec2 / value}
         except Exception as e:
             out["module_api"]["two_batches_in_flight"] = {"error": repr(e)[:300]}
+    # (LAST of the extras: its copy streams are new HIP streams, and HIP deals streams to its few hardware queues in creation order -- created
+    # earlier they moved the side streams of the extras after them onto the queues of their main streams: one frame 2.7 -> 3.1 ms, four
+    # frames 837 -> 763 frames/s inside this process, unchanged as their own processes)
+    # the boundary handing over HOST buffers: same step, same two streams, the clouds start in pinned host memory and their H2D
+    # copies (3.2 MB per frame) are inside the timed region. Never the headline value (inputs resident in HBM is the contract).
+    host = [c.cpu().pin_memory() for c in clouds]
+    v, sec = engine_rate(cfg, B, 8, 2, n_streams=max(1, args.streams), host=host)
+    out["value_host_input"] = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * sec, "steps": 8, "ratio_to_value": v / value,
+                               "h2d_MB_per_step": sum(int(c.numel()) * 4 for c in host[:B]) / 1e6 if B <= POOL else None,
+                               "note": "PCIe-inclusive: clouds in pinned host memory, H2D inside the timed region (%d stream(s)), double-buffered: a worker's next batch is copied on its own copy stream while the current one computes" % max(1, args.streams)}
+    del host
     return out
 
 
